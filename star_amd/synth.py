@@ -1,0 +1,269 @@
+"""Synthetic genomes, annotations and reads for the parity tests and for bench.py.
+
+There is no genome / GTF / FASTQ in the image and no network, so every data set used
+by this project is generated here from fixed seeds.  Everything is
+vectorised with numpy so that bench-size inputs (100+ Mb genome, millions of pairs)
+are produced in seconds.
+
+Layout of a generated data set directory:
+    genome.fa          FASTA, 60 bases per line
+    annot.gtf          exon records of the annotated transcripts (input of --sjdbGTFfile)
+    reads_1.fq [reads_2.fq]
+"""
+import os
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[a] = b
+
+
+def _write_fasta(path, names, seqs, width=60):
+    with open(path, "wb") as f:
+        for name, s in zip(names, seqs):
+            f.write(b">" + name.encode() + b"\n")
+            n = len(s)
+            full = (n // width) * width
+            if full:
+                body = np.empty((n // width, width + 1), dtype=np.uint8)
+                body[:, :width] = s[:full].reshape(-1, width)
+                body[:, width] = 10
+                body.tofile(f)
+            if n > full:
+                s[full:].tofile(f)
+                f.write(b"\n")
+
+
+def make_genome(rng, chr_lengths, repeat_families=(), n_runs=0):
+    """Random ACGT chromosomes with optional repeat families and N runs.
+
+    repeat_families: iterable of (unit_len, copies, divergence): a random unit is pasted
+    `copies` times at random places (either strand), each copy with per-base substitutions.
+    """
+    seqs = [_ACGT[rng.integers(0, 4, size=n)] for n in chr_lengths]
+    for unit_len, copies, div in repeat_families:
+        unit = _ACGT[rng.integers(0, 4, size=unit_len)]
+        for _ in range(copies):
+            c = int(rng.integers(0, len(seqs)))
+            if len(seqs[c]) <= unit_len + 2:
+                continue
+            p = int(rng.integers(0, len(seqs[c]) - unit_len))
+            cp = unit.copy()
+            m = rng.random(unit_len) < div
+            cp[m] = _ACGT[rng.integers(0, 4, size=int(m.sum()))]
+            if rng.random() < 0.5:
+                cp = _COMP[cp[::-1]]
+            seqs[c][p:p + unit_len] = cp
+    for _ in range(n_runs):
+        c = int(rng.integers(0, len(seqs)))
+        ln = int(rng.integers(1, 30))
+        if len(seqs[c]) <= ln + 2:
+            continue
+        p = int(rng.integers(0, len(seqs[c]) - ln))
+        seqs[c][p:p + ln] = ord("N")
+    return seqs
+
+
+def make_transcripts(rng, seqs, n_tr, exon_len=(40, 300), intron_len=(30, 4000), n_exons=(1, 6),
+                     noncanon_frac=0.05):
+    """Multi-exon transcripts; introns get GT..AG (+) or CT..AC (-) written INTO the genome
+    (unless non-canonical) so that junction motifs are meaningful.
+    Returns list of dicts {chr, strand, exons: [(start,end) 0-based inclusive]}.
+    Transcripts never overlap each other so that motif edits do not collide.
+    """
+    trs = []
+    cursor = [1000] * len(seqs)
+    order = rng.integers(0, len(seqs), size=n_tr)
+    for c in order:
+        c = int(c)
+        ne = int(rng.integers(n_exons[0], n_exons[1] + 1))
+        el = rng.integers(exon_len[0], exon_len[1] + 1, size=ne)
+        il = rng.integers(intron_len[0], intron_len[1] + 1, size=max(ne - 1, 0))
+        span = int(el.sum() + il.sum())
+        gap = int(rng.integers(50, 3000))
+        start = cursor[c] + gap
+        if start + span + 1000 >= len(seqs[c]):
+            continue
+        cursor[c] = start + span
+        strand = "+" if rng.random() < 0.5 else "-"
+        exons = []
+        p = start
+        for i in range(ne):
+            exons.append((p, p + int(el[i]) - 1))
+            p += int(el[i])
+            if i < ne - 1:
+                # intron [p, p+il-1]
+                q = p + int(il[i]) - 1
+                if rng.random() >= noncanon_frac:
+                    if strand == "+":
+                        seqs[c][p:p + 2] = np.frombuffer(b"GT", dtype=np.uint8)
+                        seqs[c][q - 1:q + 1] = np.frombuffer(b"AG", dtype=np.uint8)
+                    else:
+                        seqs[c][p:p + 2] = np.frombuffer(b"CT", dtype=np.uint8)
+                        seqs[c][q - 1:q + 1] = np.frombuffer(b"AC", dtype=np.uint8)
+                p = q + 1
+        trs.append({"chr": c, "strand": strand, "exons": exons})
+    return trs
+
+
+def write_gtf(path, names, trs, annotated_mask):
+    with open(path, "w") as f:
+        for i, (t, keep) in enumerate(zip(trs, annotated_mask)):
+            if not keep:
+                continue
+            for (s, e) in t["exons"]:
+                f.write("%s\tsynth\texon\t%d\t%d\t.\t%s\t.\tgene_id \"g%d\"; transcript_id \"t%d\";\n"
+                        % (names[t["chr"]], s + 1, e + 1, t["strand"], i, i))
+
+
+def _fastq_block(prefix, ids, seq, qual_char=b"I"):
+    """Fixed-width FASTQ records as one 2-D uint8 array (fast to write)."""
+    n, L = seq.shape
+    name = np.char.add(prefix, np.char.zfill(ids.astype("U12"), 9)).astype("S")
+    nw = name.dtype.itemsize
+    rec = np.empty((n, 1 + nw + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@")
+    rec[:, 1:1 + nw] = np.frombuffer(name.tobytes(), dtype=np.uint8).reshape(n, nw)
+    o = 1 + nw
+    rec[:, o] = 10
+    rec[:, o + 1:o + 1 + L] = seq
+    o += 1 + L
+    rec[:, o] = 10
+    rec[:, o + 1] = ord("+")
+    rec[:, o + 2] = 10
+    rec[:, o + 3:o + 3 + L] = qual_char[0]
+    rec[:, o + 3 + L] = 10
+    return rec
+
+
+def make_reads(rng, seqs, trs, n_reads, read_len, paired, frac_spliced=0.7, sub_rate=0.01,
+               n_rate=0.001, frag=(200, 500), indel_rate=0.0):
+    """Sample reads (or pairs).  Spliced reads come from the concatenated transcript
+    sequences ("transcriptome"), genomic reads from the chromosomes.  Returns
+    (mate1[n,L], mate2[n,L] or None) as uint8 ASCII matrices.  Mate 2 is the reverse
+    complement of the fragment's other end (standard FR library)."""
+    L = read_len
+    # transcriptome: concatenation of exon sequences of each transcript, separated by a
+    # marker so that fragments never cross transcripts.
+    pieces, tstart, tlen = [], [], []
+    pos = 0
+    for t in trs:
+        s = np.concatenate([seqs[t["chr"]][a:b + 1] for a, b in t["exons"]])
+        if t["strand"] == "-" and rng.random() < 0.5:
+            pass  # strand of sampling is randomised below anyway
+        pieces.append(s)
+        tstart.append(pos)
+        tlen.append(len(s))
+        pos += len(s)
+    fmin = L if not paired else max(frag[0], L)
+    usable = [i for i, n in enumerate(tlen) if n >= fmin]
+    n_spl = int(n_reads * frac_spliced) if usable else 0
+    n_gen = n_reads - n_spl
+    m1 = np.empty((n_reads, L), dtype=np.uint8)
+    m2 = np.empty((n_reads, L), dtype=np.uint8) if paired else None
+
+    def sample(src, starts, flens, out_lo):
+        n = len(starts)
+        idx = np.arange(L)
+        a = src[starts[:, None] + idx]
+        if paired:
+            b = src[(starts + flens - L)[:, None] + idx]
+            b = _COMP[b[:, ::-1]]
+        flip = rng.random(n) < 0.5
+        if paired:
+            # flipping the fragment strand swaps the mates
+            a2 = np.where(flip[:, None], b, a)
+            b2 = np.where(flip[:, None], a, b)
+            m1[out_lo:out_lo + n] = a2
+            m2[out_lo:out_lo + n] = b2
+        else:
+            ar = _COMP[a[:, ::-1]]
+            m1[out_lo:out_lo + n] = np.where(flip[:, None], ar, a)
+
+    if n_spl:
+        tr_seq = np.concatenate(pieces)
+        tl = np.asarray(tlen)
+        ts = np.asarray(tstart)
+        us = np.asarray(usable)
+        w = tl[us].astype(np.float64)
+        pick = us[rng.choice(len(us), size=n_spl, p=w / w.sum())]
+        if paired:
+            fl = rng.integers(frag[0], frag[1] + 1, size=n_spl)
+            fl = np.minimum(np.maximum(fl, L), tl[pick])
+        else:
+            fl = np.full(n_spl, L)
+        off = (rng.random(n_spl) * (tl[pick] - fl + 1)).astype(np.int64)
+        sample(tr_seq, ts[pick] + off, fl, 0)
+    if n_gen:
+        glen = np.asarray([len(s) for s in seqs])
+        gstart = np.concatenate([[0], np.cumsum(glen)[:-1]])
+        gseq = np.concatenate(seqs)
+        if paired:
+            fl = rng.integers(max(frag[0], L), frag[1] + 1, size=n_gen)
+        else:
+            fl = np.full(n_gen, L)
+        ok = np.flatnonzero(glen > frag[1] + 2 if paired else glen > L + 2)
+        c = ok[rng.choice(len(ok), size=n_gen, p=glen[ok] / glen[ok].sum())]
+        off = (rng.random(n_gen) * (glen[c] - fl)).astype(np.int64)
+        sample(gseq, gstart[c] + off, fl, n_spl)
+
+    for m in ([m1, m2] if paired else [m1]):
+        if sub_rate > 0:
+            mask = rng.random(m.shape) < sub_rate
+            # substitute with a DIFFERENT base where possible
+            cur = m[mask]
+            code = np.searchsorted(_ACGT, cur) % 4  # ACGT sorted ascending in ASCII
+            newc = (code + rng.integers(1, 4, size=cur.shape[0])) % 4
+            m[mask] = _ACGT[newc]
+        if n_rate > 0:
+            mask = rng.random(m.shape) < n_rate
+            m[mask] = ord("N")
+        if indel_rate > 0:
+            # single-base deletion or insertion inside the read (kept at length L)
+            rows = np.flatnonzero(rng.random(m.shape[0]) < indel_rate)
+            for r in rows:
+                p = int(rng.integers(10, L - 10))
+                k = int(rng.integers(1, 4))
+                if rng.random() < 0.5:   # deletion of k read bases (=insertion in genome)
+                    m[r, p:L - k] = m[r, p + k:L].copy()
+                    m[r, L - k:] = _ACGT[rng.integers(0, 4, size=k)]
+                else:                    # insertion of k random bases
+                    m[r, p + k:] = m[r, p:L - k].copy()
+                    m[r, p:p + k] = _ACGT[rng.integers(0, 4, size=k)]
+    # shuffle so spliced / genomic reads interleave
+    perm = rng.permutation(n_reads)
+    m1 = m1[perm]
+    if paired:
+        m2 = m2[perm]
+    return m1, m2
+
+
+def write_fastq(prefix, m1, m2=None):
+    n = m1.shape[0]
+    ids = np.arange(n)
+    paths = [prefix + "_1.fq"]
+    _fastq_block("r", ids, m1).tofile(paths[0])
+    if m2 is not None:
+        paths.append(prefix + "_2.fq")
+        _fastq_block("r", ids, m2).tofile(paths[1])
+    return paths
+
+
+def make_dataset(outdir, seed=1, chr_lengths=(300000, 200000, 150000), n_tr=120, n_reads=4000,
+                 read_len=101, paired=True, annotated_frac=0.6, repeat_families=((300, 40, 0.05), (60, 30, 0.0)),
+                 n_runs=20, **read_kw):
+    """One self-contained data set; returns a dict of paths and sizes."""
+    os.makedirs(outdir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    names = ["chr%d" % (i + 1) for i in range(len(chr_lengths))]
+    seqs = make_genome(rng, chr_lengths, repeat_families, n_runs)
+    trs = make_transcripts(rng, seqs, n_tr)
+    fa = os.path.join(outdir, "genome.fa")
+    _write_fasta(fa, names, seqs)
+    gtf = os.path.join(outdir, "annot.gtf")
+    write_gtf(gtf, names, trs, rng.random(len(trs)) < annotated_frac)
+    m1, m2 = make_reads(rng, seqs, trs, n_reads, read_len, paired, **read_kw)
+    fq = write_fastq(os.path.join(outdir, "reads"), m1, m2)
+    return {"fasta": fa, "gtf": gtf, "fastq": fq, "n_reads": n_reads, "read_len": read_len,
+            "paired": paired, "genome_bases": int(sum(chr_lengths)), "n_transcripts": len(trs)}
