@@ -1,0 +1,46 @@
+# Build everything that lives in-tree (the .so files travel to the GPU box with gpurun):
+#   star_amd/lib/libstaramd_host.so   host side (index loader, FASTQ batcher, post-map, SAM/SJ writers)  g++
+#   star_amd/lib/libstaramd.so        HIP engine behind include/star_amd.h                                hipcc gfx950
+#   star_amd/bin/star_amd             CLI: drop-in for `STAR --runMode alignReads`
+#   oracle/_build/liboracle.so        CPU restatement (test infrastructure)
+#   oracle/_ref/STAR                  the reference itself, when /root/reference is present
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -pthread
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
+
+HOST_SRC := $(wildcard star_amd/csrc/host/*.cpp)
+HOST_LIB_SRC := $(filter-out star_amd/csrc/host/main.cpp,$(HOST_SRC))
+HIP_SRC  := $(wildcard star_amd/csrc/engine/*.hip)
+HIP_HDR  := $(wildcard star_amd/csrc/engine/*.h) include/star_amd.h
+
+all: host engine cli oracle
+
+host: star_amd/lib/libstaramd_host.so
+engine: star_amd/lib/libstaramd.so
+cli: star_amd/bin/star_amd
+oracle: oracle/_build/liboracle.so
+
+star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
+	@mkdir -p star_amd/lib
+	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@
+
+star_amd/lib/libstaramd.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p star_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared $(HIP_SRC) -o $@
+
+star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so
+	@mkdir -p star_amd/bin
+	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp -o $@ -Lstar_amd/lib -lstaramd_host -lstaramd -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle/_build/liboracle.so: oracle/star_oracle.cpp include/star_amd.h
+	@mkdir -p oracle/_build
+	$(CXX) $(CXXFLAGS) -shared oracle/star_oracle.cpp -o $@
+
+ref:
+	$(MAKE) -f oracle/Makefile.ref -j8 all
+
+clean:
+	rm -rf star_amd/lib star_amd/bin oracle/_build
+
+.PHONY: all host engine cli oracle ref clean

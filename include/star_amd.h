@@ -1,0 +1,208 @@
+/* star_amd.h -- C ABI of the MI355X seed-search-and-stitch engine.
+ *
+ * The reference (alexdobin/STAR 2.7.11b) has no plugin / FFI interface; the seam this library
+ * replaces is the per-read member function
+ *       int ReadAlign::mapOneRead()            source/ReadAlign.h:187, source/ReadAlign_mapOneRead.cpp:6-118
+ * called from the read loop of ReadAlignChunk::mapChunk (source/ReadAlignChunk_mapChunk.cpp:30-32),
+ * batched to one input chunk.  Inputs and outputs are exactly what that function reads and
+ * leaves behind in the ReadAlign object:
+ *   in : Read1[0] (numeric combined read), Lread, readLength[2], outFilterMismatchNmaxTotal,
+ *        the read-only Genome (G, SA, SAi, chr tables, sjdb tables) and the Parameters subset
+ *        that reaches the hot path;
+ *   out: nW, trAll[iW][0..nWinTr[iW]-1] (best-first per window), trBest, maxScoreMate[], mapMarker.
+ *
+ * Plain C: pointers + sizes, caller-owned buffers, int return codes, no exceptions.
+ * One context per GPU; calls on one context are serialised by the caller.
+ */
+#ifndef STAR_AMD_H
+#define STAR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STARAMD_MAX_N_EXONS 20        /* MAX_N_EXONS, source/IncludeDefine.h:131 */
+#define STARAMD_READ_LEN_MAX 650      /* DEF_readSeqLengthMax, source/IncludeDefine.h:140 */
+#define STARAMD_SPACER_BASE 11        /* MARK_FRAG_SPACER_BASE, source/IncludeDefine.h:174 */
+
+/* error codes (negative) */
+#define STARAMD_OK 0
+#define STARAMD_ERR_ARG (-1)
+#define STARAMD_ERR_DEVICE (-2)            /* HIP runtime failure; see staramd_last_error() */
+#define STARAMD_ERR_RESULT_OVERFLOW (-3)   /* caller's result arrays too small */
+#define STARAMD_ERR_SCRATCH_OVERFLOW (-4)  /* a per-read device work-space cap was exceeded */
+#define STARAMD_ERR_FATAL_READ (-5)        /* a reference exitWithError condition was hit (see status bits) */
+
+/* ---- read-only index: what Genome::genomeLoad leaves in `class Genome`
+ *      (source/Genome.h:26-56, source/Genome_genomeLoad.cpp:139-169,315-336,471-521).
+ *      All pointers are HOST pointers; staramd_create copies them to HBM once. ---- */
+typedef struct staramd_genome {
+    const uint8_t *G;            /* nGenome bytes, codes 0..3 ACGT, 4 N, 5 padding (1 byte/base on disk)   */
+    uint64_t nGenome;
+    const uint8_t *SA;           /* packed suffix array, (GstrandBit+1) bits/entry (PackedArray.h:24-32)    */
+    uint64_t nSA, nSAbyte;
+    const uint8_t *SAi;          /* packed SAindex, (GstrandBit+3) bits/entry                               */
+    uint64_t nSAi, nSAibyte;
+    uint32_t GstrandBit;
+    uint32_t gSAindexNbases;     /* L-mer table depth (14 for human)                                        */
+    uint64_t genomeSAindexStart[17]; /* offsets of the L=1..Nbases tables, [Nbases]=nSAi                    */
+    uint32_t gSAsparseD;
+    uint32_t gChrBinNbits;
+    const uint64_t *chrStart;    /* nChrReal+1 entries                                                      */
+    const uint64_t *chrLength;   /* nChrReal                                                                */
+    uint32_t nChrReal;
+    const uint32_t *chrBin;      /* chrBinN entries: chromosome of every 2^gChrBinNbits block (Genome.cpp:209) */
+    uint64_t chrBinN;
+    /* splice-junction database (Genome_genomeLoad.cpp:471-521) */
+    uint64_t sjGstart;           /* start of the inserted junction "chromosome"                             */
+    uint32_t sjdbOverhang, sjdbLength;
+    uint32_t sjdbN;
+    const uint64_t *sjDstart, *sjAstart, *sjdbStart, *sjdbEnd;
+    const uint8_t *sjdbMotif, *sjdbShiftLeft, *sjdbShiftRight, *sjdbStrand;
+} staramd_genome;
+
+/* ---- Parameters that reach the hot path (defaults: source/parametersDefault) ---- */
+typedef struct staramd_params {
+    uint32_t readNmates;                    /* 1 or 2 */
+    /* seed search */
+    uint32_t seedSearchStartLmax;           /* 50  */
+    double   seedSearchStartLmaxOverLread;  /* 1.0 */
+    uint32_t seedSearchLmax;                /* 0   */
+    uint32_t seedMultimapNmax;              /* 10000 */
+    uint32_t seedPerReadNmax;               /* 1000 */
+    uint32_t seedPerWindowNmax;             /* 50 */
+    uint32_t seedSplitMin;                  /* 12 */
+    uint32_t seedMapMin;                    /* 5 */
+    uint32_t maxNsplit;                     /* 10, hard-coded Parameters.cpp:473 */
+    /* windows (as re-derived by Genome_genomeLoad.cpp:382-410) */
+    uint32_t winAnchorMultimapNmax;         /* 50 */
+    uint32_t winBinNbits;                   /* 16 */
+    uint32_t winAnchorDistNbins;            /* 9 */
+    uint32_t winFlankNbins;                 /* 4 */
+    uint32_t winBinChrNbits;                /* gChrBinNbits - winBinNbits */
+    uint64_t winBinN;
+    uint32_t alignWindowsPerReadNmax;       /* 10000 */
+    uint32_t alignTranscriptsPerWindowNmax; /* 100 */
+    uint32_t alignTranscriptsPerReadNmax;   /* 10000 */
+    /* stitching */
+    uint64_t alignIntronMin;                /* 21 */
+    uint64_t alignIntronMax;                /* 0 */
+    uint64_t alignMatesGapMax;              /* 0 */
+    uint32_t alignSJoverhangMin;            /* 5 */
+    uint32_t alignSJDBoverhangMin;          /* 3 */
+    int32_t  alignSJstitchMismatchNmax[4];  /* 0 -1 0 0 */
+    uint32_t alignSplicedMateMapLmin;       /* 0 */
+    double   alignSplicedMateMapLminOverLmate; /* 0.66 */
+    uint8_t  alignEndsTypeExt[2][2];        /* Parameters.cpp:966-983: all 0 for Local */
+    int32_t  alignEndsProtrudeNbasesMax;    /* 0 */
+    uint8_t  alignEndsProtrudeConcordantPair; /* consumed by the SAM writer only */
+    uint8_t  alignSoftClipAtReferenceEnds;  /* 1 = Yes */
+    uint8_t  alignInsertionFlushRight;      /* 0 */
+    uint8_t  outFilterIntronStrandsRemoveInconsistent; /* 1 */
+    uint8_t  outFilterIntronMotifs;         /* 0 None, 1 RemoveNoncanonical, 2 RemoveNoncanonicalUnannotated */
+    uint8_t  outSAMstrandFieldIntronMotif;  /* 0 */
+    uint8_t  chimSegmentMinPositive;        /* P.pCh.segmentMin>0: record every transcript */
+    uint8_t  outFilterBySJoutStage;         /* 0 (2 => sjNovel whitelist, not supported on device yet) */
+    int32_t  scoreGap, scoreGapNoncan, scoreGapGCAG, scoreGapATAC;   /* 0 -8 -4 -8 */
+    int32_t  scoreDelOpen, scoreDelBase, scoreInsOpen, scoreInsBase; /* -2 -2 -2 -2 */
+    int32_t  scoreStitchSJshift;            /* 1 */
+    int32_t  sjdbScore;                     /* 2 */
+    double   scoreGenomicLengthLog2scale;   /* -0.25 */
+    int32_t  outFilterMultimapScoreRange;   /* 1 */
+    double   outFilterMismatchNoverLmax;    /* 0.3 */
+    uint32_t outFilterMatchNmin;            /* 0: Lread<outFilterMatchNmin => MARKER_READ_TOO_SHORT */
+} staramd_params;
+
+/* ---- one batch of reads: what ReadAlign::oneRead prepares before calling mapOneRead
+ *      (source/ReadAlign_oneRead.cpp:35-78) ---- */
+typedef struct staramd_batch {
+    uint32_t nReads;
+    const uint8_t  *bases;        /* concatenated Read1[0] of every read: mate1 | 11 | revcomp(mate2); codes 0..4, 11 */
+    const uint64_t *readOffset;   /* nReads+1 offsets into bases; Lread[i] = readOffset[i+1]-readOffset[i]  */
+    const uint16_t *mate1Length;  /* readLength[0]; readLength[1] = Lread - readLength[0] - 1 when paired     */
+    const uint16_t *mmMaxTotal;   /* outFilterMismatchNmaxTotal per read (ReadAlign_oneRead.cpp:78)            */
+} staramd_batch;
+
+/* status bits per read */
+#define STARAMD_ST_MAPPED_WINDOWS        0x0001u  /* nW>0 */
+#define STARAMD_ST_READ_TOO_SHORT        0x0002u  /* MARKER_READ_TOO_SHORT                    mapOneRead.cpp:100 */
+#define STARAMD_ST_NO_GOOD_PIECES        0x0004u  /* MARKER_NO_GOOD_PIECES                    :104 */
+#define STARAMD_ST_ALL_PIECES_MULTI      0x0008u  /* MARKER_ALL_PIECES_EXCEED_seedMultimapNmax :108 */
+#define STARAMD_ST_NO_GOOD_WINDOW        0x0010u  /* MARKER_NO_GOOD_WINDOW           stitchPieces.cpp:344 */
+#define STARAMD_ST_TOO_MANY_ANCHORS      0x0020u  /* MARKER_TOO_MANY_ANCHORS_PER_WINDOW assignAlignToWindow.cpp:76 */
+#define STARAMD_ST_FATAL_SEEDS_PER_READ  0x0100u  /* reference exits: storeAligns.cpp:46-51 */
+#define STARAMD_ST_TR_PER_READ_LIMIT     0x0200u  /* reference logs a WARNING and stops: stitchPieces.cpp:290-294 */
+#define STARAMD_ST_WINDOWS_LIMIT         0x0400u  /* alignWindowsPerReadNmax reached (silent in the reference)    */
+#define STARAMD_ST_SCRATCH_OVERFLOW      0x8000u  /* device work-space cap exceeded: results for this read invalid */
+
+typedef struct staramd_read_result {
+    uint32_t status;
+    uint32_t nW;              /* windows that recorded >=1 transcript (ReadAlign::nW after stitchPieces) */
+    uint32_t nTr;             /* total transcripts over those windows                                    */
+    uint32_t trOffset;        /* first transcript of this read in staramd_results.tr                     */
+    int32_t  trBest;          /* index (relative to trOffset) of trBest, -1 if none                      */
+    int32_t  maxScoreMate[2];
+    uint32_t unmappedLength;  /* trBest->rLength of the unmapped classifications (mapOneRead.cpp:100-111) */
+} staramd_read_result;
+
+/* compact Transcript (source/Transcript.h:10-81): every field the post-map code reads */
+typedef struct staramd_transcript {
+    uint32_t iW;              /* ordinal of the window among windows with transcripts */
+    uint32_t exonOffset;      /* first exon in staramd_results.ex */
+    uint16_t nExons;
+    uint16_t rStart, rLength, roStart;
+    uint8_t  Str, roStr;
+    int8_t   iFrag;           /* -1 both mates */
+    uint8_t  sjMotifStrand;
+    uint32_t Chr;
+    uint64_t gStart, gLength;
+    int32_t  maxScore;
+    uint32_t nMatch, nMM, mappedLength;
+    uint32_t nGap, lGap, nDel, lDel, nIns, lIns;
+    uint16_t nUnique, nAnchor;
+    uint16_t intronMotifs[3];
+    uint16_t pad0;
+} staramd_transcript;
+
+typedef struct staramd_exon {
+    uint64_t G;               /* EX_G */
+    uint16_t R, L;            /* EX_R, EX_L */
+    int32_t  sjA;             /* EX_sjA (-1 none) */
+    uint8_t  iFrag;           /* EX_iFrag */
+    int8_t   canonSJ;         /* junction AFTER this exon (canonSJ[iex]); undefined for the last exon */
+    uint8_t  sjAnnot, sjStr;
+    uint16_t shiftSJ[2];
+    uint32_t pad0;
+} staramd_exon;
+
+typedef struct staramd_results {
+    staramd_read_result *reads;   /* nReads entries                       */
+    staramd_transcript  *tr;      uint64_t trCapacity;  uint64_t trCount;  /* count filled by the callee */
+    staramd_exon        *ex;      uint64_t exCapacity;  uint64_t exCount;
+    /* timing of the device work of this call, measured with HIP events on the engine's stream */
+    float msSeed, msWindows, msStitch, msTotalDevice;
+} staramd_results;
+
+typedef struct staramd_ctx staramd_ctx;
+
+/* Upload the index to HBM (once per GPU). maxBatchReads/maxBatchBases size the device work space. */
+int  staramd_create(staramd_ctx **out, int device, const staramd_genome *g, const staramd_params *p,
+                    uint32_t maxBatchReads, uint64_t maxBatchBases);
+/* Replace the index after sjdbInsertJunctions (two-pass); same semantics as create's upload. */
+int  staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p);
+/* Map one batch: replaces the per-read loop around ReadAlign::mapOneRead. */
+int  staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results *r);
+/* Same, but the batch is taken from the copy already resident in HBM from the previous call with
+ * identical geometry (bench: inputs resident before the timed region). */
+int  staramd_map_resident(staramd_ctx *ctx, staramd_results *r);
+void staramd_destroy(staramd_ctx *ctx);
+const char *staramd_last_error(void);
+/* algorithmic counters of the last batch: nSAi, nSAprobe, nGcmp, nSAenum, nGstitch, ... */
+int  staramd_get_counters(staramd_ctx *ctx, uint64_t *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

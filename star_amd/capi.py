@@ -1,0 +1,236 @@
+"""ctypes mirror of include/star_amd.h and of the host library's `sah_*` interface.
+
+Python is only plumbing here (tests, bench.py, smoke): the product is the C-ABI library
+star_amd/lib/libstaramd.so (hand-written HIP for gfx950) plus the C++ host library
+star_amd/lib/libstaramd_host.so.  Loading fails loudly if a library is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+ENGINE_PATH = os.path.join(LIB_DIR, "libstaramd.so")
+HOST_PATH = os.path.join(LIB_DIR, "libstaramd_host.so")
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class Genome(C.Structure):
+    _fields_ = [
+        ("G", u8p), ("nGenome", C.c_uint64),
+        ("SA", u8p), ("nSA", C.c_uint64), ("nSAbyte", C.c_uint64),
+        ("SAi", u8p), ("nSAi", C.c_uint64), ("nSAibyte", C.c_uint64),
+        ("GstrandBit", C.c_uint32), ("gSAindexNbases", C.c_uint32),
+        ("genomeSAindexStart", C.c_uint64 * 17),
+        ("gSAsparseD", C.c_uint32), ("gChrBinNbits", C.c_uint32),
+        ("chrStart", u64p), ("chrLength", u64p), ("nChrReal", C.c_uint32),
+        ("chrBin", u32p), ("chrBinN", C.c_uint64),
+        ("sjGstart", C.c_uint64), ("sjdbOverhang", C.c_uint32), ("sjdbLength", C.c_uint32), ("sjdbN", C.c_uint32),
+        ("sjDstart", u64p), ("sjAstart", u64p), ("sjdbStart", u64p), ("sjdbEnd", u64p),
+        ("sjdbMotif", u8p), ("sjdbShiftLeft", u8p), ("sjdbShiftRight", u8p), ("sjdbStrand", u8p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("readNmates", C.c_uint32),
+        ("seedSearchStartLmax", C.c_uint32), ("seedSearchStartLmaxOverLread", C.c_double),
+        ("seedSearchLmax", C.c_uint32), ("seedMultimapNmax", C.c_uint32), ("seedPerReadNmax", C.c_uint32),
+        ("seedPerWindowNmax", C.c_uint32), ("seedSplitMin", C.c_uint32), ("seedMapMin", C.c_uint32), ("maxNsplit", C.c_uint32),
+        ("winAnchorMultimapNmax", C.c_uint32), ("winBinNbits", C.c_uint32), ("winAnchorDistNbins", C.c_uint32),
+        ("winFlankNbins", C.c_uint32), ("winBinChrNbits", C.c_uint32), ("winBinN", C.c_uint64),
+        ("alignWindowsPerReadNmax", C.c_uint32), ("alignTranscriptsPerWindowNmax", C.c_uint32), ("alignTranscriptsPerReadNmax", C.c_uint32),
+        ("alignIntronMin", C.c_uint64), ("alignIntronMax", C.c_uint64), ("alignMatesGapMax", C.c_uint64),
+        ("alignSJoverhangMin", C.c_uint32), ("alignSJDBoverhangMin", C.c_uint32),
+        ("alignSJstitchMismatchNmax", C.c_int32 * 4),
+        ("alignSplicedMateMapLmin", C.c_uint32), ("alignSplicedMateMapLminOverLmate", C.c_double),
+        ("alignEndsTypeExt", (C.c_uint8 * 2) * 2),
+        ("alignEndsProtrudeNbasesMax", C.c_int32),
+        ("alignEndsProtrudeConcordantPair", C.c_uint8), ("alignSoftClipAtReferenceEnds", C.c_uint8),
+        ("alignInsertionFlushRight", C.c_uint8), ("outFilterIntronStrandsRemoveInconsistent", C.c_uint8),
+        ("outFilterIntronMotifs", C.c_uint8), ("outSAMstrandFieldIntronMotif", C.c_uint8),
+        ("chimSegmentMinPositive", C.c_uint8), ("outFilterBySJoutStage", C.c_uint8),
+        ("scoreGap", C.c_int32), ("scoreGapNoncan", C.c_int32), ("scoreGapGCAG", C.c_int32), ("scoreGapATAC", C.c_int32),
+        ("scoreDelOpen", C.c_int32), ("scoreDelBase", C.c_int32), ("scoreInsOpen", C.c_int32), ("scoreInsBase", C.c_int32),
+        ("scoreStitchSJshift", C.c_int32), ("sjdbScore", C.c_int32),
+        ("scoreGenomicLengthLog2scale", C.c_double),
+        ("outFilterMultimapScoreRange", C.c_int32),
+        ("outFilterMismatchNoverLmax", C.c_double),
+        ("outFilterMatchNmin", C.c_uint32),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [("nReads", C.c_uint32), ("bases", u8p), ("readOffset", u64p), ("mate1Length", u16p), ("mmMaxTotal", u16p)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("nW", C.c_uint32), ("nTr", C.c_uint32), ("trOffset", C.c_uint32),
+                ("trBest", C.c_int32), ("maxScoreMate", C.c_int32 * 2), ("unmappedLength", C.c_uint32)]
+
+
+class Transcript(C.Structure):
+    _fields_ = [("iW", C.c_uint32), ("exonOffset", C.c_uint32), ("nExons", C.c_uint16),
+                ("rStart", C.c_uint16), ("rLength", C.c_uint16), ("roStart", C.c_uint16),
+                ("Str", C.c_uint8), ("roStr", C.c_uint8), ("iFrag", C.c_int8), ("sjMotifStrand", C.c_uint8),
+                ("Chr", C.c_uint32), ("gStart", C.c_uint64), ("gLength", C.c_uint64), ("maxScore", C.c_int32),
+                ("nMatch", C.c_uint32), ("nMM", C.c_uint32), ("mappedLength", C.c_uint32),
+                ("nGap", C.c_uint32), ("lGap", C.c_uint32), ("nDel", C.c_uint32), ("lDel", C.c_uint32), ("nIns", C.c_uint32), ("lIns", C.c_uint32),
+                ("nUnique", C.c_uint16), ("nAnchor", C.c_uint16), ("intronMotifs", C.c_uint16 * 3), ("pad0", C.c_uint16)]
+
+
+class Exon(C.Structure):
+    _fields_ = [("G", C.c_uint64), ("R", C.c_uint16), ("L", C.c_uint16), ("sjA", C.c_int32), ("iFrag", C.c_uint8),
+                ("canonSJ", C.c_int8), ("sjAnnot", C.c_uint8), ("sjStr", C.c_uint8), ("shiftSJ", C.c_uint16 * 2), ("pad0", C.c_uint32)]
+
+
+class Results(C.Structure):
+    _fields_ = [("reads", C.POINTER(ReadResult)),
+                ("tr", C.POINTER(Transcript)), ("trCapacity", C.c_uint64), ("trCount", C.c_uint64),
+                ("ex", C.POINTER(Exon)), ("exCapacity", C.c_uint64), ("exCount", C.c_uint64),
+                ("msSeed", C.c_float), ("msWindows", C.c_float), ("msStitch", C.c_float), ("msTotalDevice", C.c_float)]
+
+
+class ResultBuffers:
+    """Caller-owned result arrays for one batch."""
+
+    def __init__(self, n_reads, tr_cap=None, ex_cap=None):
+        tr_cap = tr_cap or max(1024, n_reads * 24)
+        ex_cap = ex_cap or tr_cap * 4
+        self.reads = (ReadResult * n_reads)()
+        self.tr = (Transcript * tr_cap)()
+        self.ex = (Exon * ex_cap)()
+        self.res = Results()
+        self.res.reads = C.cast(self.reads, C.POINTER(ReadResult))
+        self.res.tr = C.cast(self.tr, C.POINTER(Transcript)); self.res.trCapacity = tr_cap
+        self.res.ex = C.cast(self.ex, C.POINTER(Exon)); self.res.exCapacity = ex_cap
+
+    def as_bytes(self, n_reads):
+        """(reads, transcripts, exons) raw bytes of the filled part -- for bit-exact comparisons."""
+        r = self.res
+        return (bytes(memoryview(self.reads))[:n_reads * C.sizeof(ReadResult)],
+                bytes(memoryview(self.tr))[:r.trCount * C.sizeof(Transcript)],
+                bytes(memoryview(self.ex))[:r.exCount * C.sizeof(Exon)])
+
+
+def _need(path):
+    if not os.path.isfile(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or `make`) first; "
+                           "there is no Python/CPU fallback for the hot path" % path)
+    return path
+
+
+_host = None
+_engine = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        L = C.CDLL(_need(HOST_PATH))
+        L.sah_create.restype = C.c_void_p
+        L.sah_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+        L.sah_genome.restype = C.POINTER(Genome); L.sah_genome.argtypes = [C.c_void_p]
+        L.sah_params.restype = C.POINTER(Params); L.sah_params.argtypes = [C.c_void_p]
+        L.sah_batch_reads.restype = C.c_uint64; L.sah_batch_reads.argtypes = [C.c_void_p]
+        L.sah_genome_load_seconds.restype = C.c_double; L.sah_genome_load_seconds.argtypes = [C.c_void_p]
+        L.sah_next_batch.restype = C.c_int; L.sah_next_batch.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Batch)]
+        L.sah_emit.restype = C.c_int; L.sah_emit.argtypes = [C.c_void_p, C.POINTER(Results)]
+        L.sah_finish.restype = C.c_int; L.sah_finish.argtypes = [C.c_void_p]
+        L.sah_error.restype = C.c_char_p; L.sah_error.argtypes = [C.c_void_p]
+        L.sah_destroy.restype = None; L.sah_destroy.argtypes = [C.c_void_p]
+        _host = L
+    return _host
+
+
+def engine_lib():
+    """The HIP engine.  Raises if the extension has not been built: no fallback."""
+    global _engine
+    if _engine is None:
+        L = C.CDLL(_need(ENGINE_PATH))
+        L.staramd_create.restype = C.c_int
+        L.staramd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Genome), C.POINTER(Params), C.c_uint32, C.c_uint64]
+        L.staramd_update_index.restype = C.c_int
+        L.staramd_update_index.argtypes = [C.c_void_p, C.POINTER(Genome), C.POINTER(Params)]
+        L.staramd_map_batch.restype = C.c_int
+        L.staramd_map_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
+        L.staramd_map_resident.restype = C.c_int
+        L.staramd_map_resident.argtypes = [C.c_void_p, C.POINTER(Results)]
+        L.staramd_destroy.restype = None; L.staramd_destroy.argtypes = [C.c_void_p]
+        L.staramd_last_error.restype = C.c_char_p
+        L.staramd_get_counters.restype = C.c_int
+        L.staramd_get_counters.argtypes = [C.c_void_p, u64p, C.c_int]
+        _engine = L
+    return _engine
+
+
+class HostRun:
+    """One alignReads run on the host side: STAR-style argv in, SAM/SJ/Log files out."""
+
+    def __init__(self, argv):
+        L = host_lib()
+        args = [b"star_amd"] + [a.encode() if isinstance(a, str) else a for a in argv]
+        arr = (C.c_char_p * len(args))(*args)
+        err = C.create_string_buffer(4096)
+        self.h = L.sah_create(len(args), arr, err, 4096)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+        self.L = L
+        self.genome = L.sah_genome(self.h)
+        self.params = L.sah_params(self.h)
+
+    def next_batch(self, max_reads):
+        b = Batch()
+        n = self.L.sah_next_batch(self.h, max_reads, C.byref(b))
+        if n < 0:
+            raise RuntimeError(self.L.sah_error(self.h).decode())
+        return b if n > 0 else None
+
+    def emit(self, results):
+        if self.L.sah_emit(self.h, C.byref(results)) != 0:
+            raise RuntimeError(self.L.sah_error(self.h).decode())
+
+    def finish(self):
+        if self.L.sah_finish(self.h) != 0:
+            raise RuntimeError(self.L.sah_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.sah_destroy(self.h)
+            self.h = None
+
+
+class Engine:
+    """The MI355X engine context (one per GPU)."""
+
+    def __init__(self, genome_p, params_p, device=0, max_reads=65536, max_bases=None):
+        L = engine_lib()
+        self.L = L
+        self.ctx = C.c_void_p()
+        max_bases = max_bases or max_reads * 660
+        rc = L.staramd_create(C.byref(self.ctx), device, genome_p, params_p, max_reads, max_bases)
+        if rc != 0:
+            raise RuntimeError("staramd_create failed (%d): %s" % (rc, L.staramd_last_error().decode()))
+
+    def map_batch(self, batch, bufs):
+        rc = self.L.staramd_map_batch(self.ctx, C.byref(batch), C.byref(bufs.res))
+        if rc != 0:
+            raise RuntimeError("staramd_map_batch failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
+
+    def map_resident(self, bufs):
+        rc = self.L.staramd_map_resident(self.ctx, C.byref(bufs.res))
+        if rc != 0:
+            raise RuntimeError("staramd_map_resident failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
+
+    def counters(self, n=16):
+        out = (C.c_uint64 * n)()
+        k = self.L.staramd_get_counters(self.ctx, out, n)
+        return list(out)[:k]
+
+    def close(self):
+        if self.ctx:
+            self.L.staramd_destroy(self.ctx)
+            self.ctx = C.c_void_p()

@@ -1,0 +1,133 @@
+// host.h -- host side of the MI355X STAR hot path: index loader, parameter set, FASTQ batcher,
+// post-map selection and SAM / SJ.out.tab / Log.final.out writers.
+//
+// These are the "boundary glue" rows of SURVEY.md section 2 (4*,5*,6*,7*,8): cheap integer host code
+// that must reproduce the reference byte for byte; none of it is accelerated.  Each function
+// cites the reference file:line whose behaviour it reproduces.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include "../../../include/star_amd.h"
+
+namespace staramd {
+
+// ---- genomeDir on disk -> host arrays (Genome::genomeLoad, source/Genome_genomeLoad.cpp:18-467) ----
+struct GenomeIndex {
+    std::string dir;
+    std::vector<uint8_t> G, SA, SAi;
+    std::vector<uint64_t> chrStart, chrLength, sjDstart, sjAstart, sjdbStart, sjdbEnd;
+    std::vector<uint32_t> chrBin;
+    std::vector<uint8_t> sjdbMotif, sjdbShiftLeft, sjdbShiftRight, sjdbStrand;
+    std::vector<std::string> chrName;
+    staramd_genome view;      // pointers into the vectors above
+    double loadSeconds = 0;
+    // returns empty string on success, else the error text
+    std::string load(const std::string &genomeDir);
+};
+
+// ---- Parameters: defaults of source/parametersDefault + command-line subset ----
+struct RunParams {
+    staramd_params dev;                 // what reaches the device hot path
+    // run
+    std::string genomeDir, outFileNamePrefix = "./";
+    std::vector<std::string> readFilesIn;
+    int runThreadN = 1;
+    int64_t readMapNumber = -1;
+    std::string commandLine;
+    // host-side filters / output (defaults: parametersDefault:455-530, 241, 266-290)
+    uint32_t outFilterMultimapNmax = 10;
+    uint32_t outFilterMismatchNmax = 10;
+    double outFilterMismatchNoverReadLmax = 1.0;
+    int32_t outFilterScoreMin = 0;
+    double outFilterScoreMinOverLread = 0.66;
+    uint32_t outFilterMatchNmin = 0;
+    double outFilterMatchNminOverLread = 0.66;
+    int32_t outSJfilterOverhangMin[4] = {30, 12, 12, 12};
+    int32_t outSJfilterCountUniqueMin[4] = {3, 1, 1, 1};
+    int32_t outSJfilterCountTotalMin[4] = {3, 1, 1, 1};
+    int32_t outSJfilterDistToOtherSJmin[4] = {10, 0, 5, 10};
+    std::vector<uint64_t> outSJfilterIntronMaxVsReadN = {50000, 100000, 200000};
+    bool outSJfilterReadsUnique = false;   // outSJfilterReads All | Unique
+    int outSAMmapqUnique = 255;
+    int outSAMattrIHstart = 1;
+    uint32_t outSAMflagOR = 0, outSAMflagAND = 65535;
+    bool outSAMunmappedWithin = false;
+    bool outSAMprimaryAllBest = false;
+    bool outSAMmodeNoQS = false;
+    std::vector<std::string> outSAMattrOrder = {"NH", "HI", "AS", "nM"};   // Standard
+    std::string readNameSeparator = "/";
+    uint64_t gpuBatchReads = 65536;      // reads per device batch (ours; --gpuBatchReads)
+    int gpuDevice = 0;
+
+    RunParams();
+    // STAR-style "--name v1 v2 ..." ; returns error text or ""
+    std::string parse(int argc, char **argv);
+    // derive window parameters from the genome (Genome_genomeLoad.cpp:382-410)
+    void finalize(const GenomeIndex &gi);
+};
+
+// ---- one batch of reads in the layout of staramd_batch + the text needed for SAM ----
+struct ReadBatch {
+    uint32_t n = 0;
+    std::vector<uint8_t> bases;           // combined numeric reads
+    std::vector<uint64_t> readOffset;     // n+1
+    std::vector<uint16_t> mate1Length, mmMaxTotal;
+    std::vector<std::string> name;        // without '@', trimmed at readNameSeparator
+    std::vector<std::string> seq[2], qual[2];
+    std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
+    uint64_t firstReadIndex = 0;
+    staramd_batch view() const;
+    void clear();
+};
+
+class FastqReader {
+public:
+    ~FastqReader();
+    std::string open(const std::vector<std::string> &paths);
+    // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
+    // + the PE concatenation of ReadAlign::oneRead (ReadAlign_oneRead.cpp:35-78)
+    bool nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err);
+    uint64_t readsSoFar = 0;
+private:
+    FILE *f[2] = {nullptr, nullptr};
+    int nMates = 0;
+    std::vector<char> lineBuf;
+    bool getLine(int im, std::string &out);
+};
+
+// ---- Stats (source/Stats.{h,cpp}) ----
+struct Stats {
+    uint64_t readN = 0, readBases = 0, mappedMismatchesN = 0, mappedInsN = 0, mappedDelN = 0, mappedInsL = 0, mappedDelL = 0,
+             mappedBases = 0, mappedReadsU = 0, mappedReadsM = 0, unmappedOther = 0, unmappedShort = 0, unmappedMismatch = 0,
+             unmappedMulti = 0, unmappedAll = 0, chimericAll = 0, splicesNsjdb = 0, splicesN[7] = {0, 0, 0, 0, 0, 0, 0};
+    double mappedPortion = 0;
+    time_t timeStart = 0, timeStartMap = 0, timeFinish = 0;
+    void add(const Stats &s);
+    void reportFinal(const std::string &path);   // Stats::reportFinal, Stats.cpp:99-145
+};
+
+// ---- junction table (source/OutSJ.{h,cpp}, ReadAlign_outputTranscriptSJ.cpp, outputSJ.cpp) ----
+struct Junction { uint64_t start; uint32_t gap; int8_t strand, motif, annot; uint32_t countUnique, countMultiple; uint16_t overhangLeft, overhangRight; };
+struct OutSJ {
+    std::vector<Junction> data;
+    void collapse();                                 // OutSJ::collapseSJ, OutSJ.cpp:42-72
+    void mergeFrom(const OutSJ &o) { data.insert(data.end(), o.data.begin(), o.data.end()); }
+    // outputSJ filter + write (outputSJ.cpp:56-138); returns error text or ""
+    std::string filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path);
+};
+
+// ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
+class PostMap {
+public:
+    PostMap(const RunParams &P, const GenomeIndex &gi) : P(P), gi(gi) {}
+    // consumes the device (or oracle) results of one batch; appends SAM text to `sam`
+    std::string process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st);
+    std::string samHeader() const;                   // samHeaders.cpp:27-106
+private:
+    const RunParams &P;
+    const GenomeIndex &gi;
+};
+
+} // namespace staramd

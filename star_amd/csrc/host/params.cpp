@@ -1,0 +1,184 @@
+// params.cpp -- the alignReads flags that reach the hot path or its outputs.
+// Defaults are those of source/parametersDefault; derived values follow Parameters.cpp
+// (alignEndsType :966-983) and Genome_genomeLoad.cpp:382-410 (window geometry).
+// Every other STAR flag is rejected loudly rather than silently ignored.
+#include "host.h"
+#include <cstring>
+#include <cmath>
+#include <cstdlib>
+#include <algorithm>
+#include <map>
+#include <functional>
+
+namespace staramd {
+
+RunParams::RunParams() {
+    memset(&dev, 0, sizeof(dev));
+    dev.readNmates = 1;
+    dev.seedSearchStartLmax = 50; dev.seedSearchStartLmaxOverLread = 1.0; dev.seedSearchLmax = 0;
+    dev.seedMultimapNmax = 10000; dev.seedPerReadNmax = 1000; dev.seedPerWindowNmax = 50;
+    dev.seedSplitMin = 12; dev.seedMapMin = 5; dev.maxNsplit = 10;
+    dev.winAnchorMultimapNmax = 50; dev.winBinNbits = 16; dev.winAnchorDistNbins = 9; dev.winFlankNbins = 4;
+    dev.alignWindowsPerReadNmax = 10000; dev.alignTranscriptsPerWindowNmax = 100; dev.alignTranscriptsPerReadNmax = 10000;
+    dev.alignIntronMin = 21; dev.alignIntronMax = 0; dev.alignMatesGapMax = 0;
+    dev.alignSJoverhangMin = 5; dev.alignSJDBoverhangMin = 3;
+    dev.alignSJstitchMismatchNmax[0] = 0; dev.alignSJstitchMismatchNmax[1] = -1; dev.alignSJstitchMismatchNmax[2] = 0; dev.alignSJstitchMismatchNmax[3] = 0;
+    dev.alignSplicedMateMapLmin = 0; dev.alignSplicedMateMapLminOverLmate = 0.66;
+    dev.alignEndsProtrudeNbasesMax = 0; dev.alignEndsProtrudeConcordantPair = 1;
+    dev.alignSoftClipAtReferenceEnds = 1; dev.alignInsertionFlushRight = 0;
+    dev.outFilterIntronStrandsRemoveInconsistent = 1; dev.outFilterIntronMotifs = 0; dev.outSAMstrandFieldIntronMotif = 0;
+    dev.chimSegmentMinPositive = 0; dev.outFilterBySJoutStage = 0;
+    dev.scoreGap = 0; dev.scoreGapNoncan = -8; dev.scoreGapGCAG = -4; dev.scoreGapATAC = -8;
+    dev.scoreDelOpen = -2; dev.scoreDelBase = -2; dev.scoreInsOpen = -2; dev.scoreInsBase = -2;
+    dev.scoreStitchSJshift = 1; dev.sjdbScore = 2; dev.scoreGenomicLengthLog2scale = -0.25;
+    dev.outFilterMultimapScoreRange = 1; dev.outFilterMismatchNoverLmax = 0.3; dev.outFilterMatchNmin = 0;
+}
+
+std::string RunParams::parse(int argc, char **argv) {
+    std::map<std::string, std::vector<std::string> > kv;
+    std::string cur;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        commandLine += (i > 1 ? " " : "") + a;
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') { cur = a.substr(2); kv[cur]; }
+        else if (cur.empty()) return "EXITING: fatal input ERROR: unrecognized parameter name \"" + a + "\" in input \"Command-Line-Initial\"";
+        else kv[cur].push_back(a);
+    }
+    commandLine = std::string(argc > 0 ? argv[0] : "star_amd") + " " + commandLine;
+    std::string err;
+    auto one = [&](const std::string &k, const std::vector<std::string> &v) -> const std::string & {
+        static std::string empty;
+        if (v.size() != 1) { err = "EXITING: fatal input ERROR: --" + k + " expects exactly one value"; return empty; }
+        return v[0];
+    };
+    auto U = [&](const std::string &k, const std::vector<std::string> &v) { return (uint64_t)strtoull(one(k, v).c_str(), nullptr, 10); };
+    auto I = [&](const std::string &k, const std::vector<std::string> &v) { return (int64_t)strtoll(one(k, v).c_str(), nullptr, 10); };
+    auto D = [&](const std::string &k, const std::vector<std::string> &v) { return strtod(one(k, v).c_str(), nullptr); };
+    auto I4 = [&](const std::string &k, const std::vector<std::string> &v, int32_t *out) {
+        if (v.size() != 4) { err = "EXITING: fatal input ERROR: --" + k + " expects 4 values"; return; }
+        for (int j = 0; j < 4; j++) out[j] = (int32_t)strtol(v[j].c_str(), nullptr, 10);
+    };
+    std::string alignEndsType = "Local";
+    for (auto &e : kv) {
+        const std::string &k = e.first; const std::vector<std::string> &v = e.second;
+        if (k == "runMode") { if (one(k, v) != "alignReads") err = "EXITING: only --runMode alignReads is implemented by the MI355X engine (index generation: use reference STAR)"; }
+        else if (k == "genomeDir") genomeDir = one(k, v);
+        else if (k == "readFilesIn") readFilesIn = v;
+        else if (k == "outFileNamePrefix") outFileNamePrefix = one(k, v);
+        else if (k == "runThreadN") runThreadN = (int)I(k, v);
+        else if (k == "readMapNumber") readMapNumber = I(k, v);
+        else if (k == "gpuBatchReads") gpuBatchReads = U(k, v);
+        else if (k == "gpuDevice") gpuDevice = (int)I(k, v);
+        else if (k == "genomeLoad") { if (one(k, v) != "NoSharedMemory") err = "EXITING: --genomeLoad: the index lives in HBM; only NoSharedMemory is accepted"; }
+        else if (k == "outSAMtype") { if (v.empty() || v[0] != "SAM") err = "EXITING: only --outSAMtype SAM is implemented (BAM: SURVEY.md 8f next #3)"; }
+        else if (k == "outStd") { if (one(k, v) != "Log") err = "EXITING: only --outStd Log is implemented"; }
+        else if (k == "outSAMmode") { const std::string &s = one(k, v); if (s == "NoQS") outSAMmodeNoQS = true; else if (s != "Full") err = "EXITING: unsupported --outSAMmode " + s; }
+        else if (k == "outSAMunmapped") { if (v.size() >= 1 && v[0] == "Within") { outSAMunmappedWithin = true; if (v.size() > 1) err = "EXITING: --outSAMunmapped Within KeepPairs is not implemented"; } else if (!(v.size() == 1 && v[0] == "None")) err = "EXITING: unsupported --outSAMunmapped"; }
+        else if (k == "outSAMattributes") {
+            if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
+            else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
+        }
+        else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
+        else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
+        else if (k == "outSAMmapqUnique") outSAMmapqUnique = (int)I(k, v);
+        else if (k == "outSAMattrIHstart") outSAMattrIHstart = (int)I(k, v);
+        else if (k == "outSAMflagOR") outSAMflagOR = (uint32_t)U(k, v);
+        else if (k == "outSAMflagAND") outSAMflagAND = (uint32_t)U(k, v);
+        else if (k == "readNameSeparator") readNameSeparator = one(k, v);
+        else if (k == "outFilterType") { if (one(k, v) != "Normal") err = "EXITING: --outFilterType BySJout is not implemented"; }
+        else if (k == "outFilterMultimapScoreRange") dev.outFilterMultimapScoreRange = (int32_t)I(k, v);
+        else if (k == "outFilterMultimapNmax") outFilterMultimapNmax = (uint32_t)U(k, v);
+        else if (k == "outFilterMismatchNmax") outFilterMismatchNmax = (uint32_t)U(k, v);
+        else if (k == "outFilterMismatchNoverLmax") dev.outFilterMismatchNoverLmax = D(k, v);
+        else if (k == "outFilterMismatchNoverReadLmax") outFilterMismatchNoverReadLmax = D(k, v);
+        else if (k == "outFilterScoreMin") outFilterScoreMin = (int32_t)I(k, v);
+        else if (k == "outFilterScoreMinOverLread") outFilterScoreMinOverLread = D(k, v);
+        else if (k == "outFilterMatchNmin") { outFilterMatchNmin = (uint32_t)U(k, v); dev.outFilterMatchNmin = outFilterMatchNmin; }
+        else if (k == "outFilterMatchNminOverLread") outFilterMatchNminOverLread = D(k, v);
+        else if (k == "outFilterIntronMotifs") { const std::string &s = one(k, v); if (s == "None") dev.outFilterIntronMotifs = 0; else if (s == "RemoveNoncanonical") dev.outFilterIntronMotifs = 1; else if (s == "RemoveNoncanonicalUnannotated") dev.outFilterIntronMotifs = 2; else err = "EXITING because of FATAL INPUT error: unrecognized value of --outFilterIntronMotifs=" + s; }
+        else if (k == "outFilterIntronStrands") { const std::string &s = one(k, v); if (s == "RemoveInconsistentStrands") dev.outFilterIntronStrandsRemoveInconsistent = 1; else if (s == "None") dev.outFilterIntronStrandsRemoveInconsistent = 0; else err = "EXITING: unsupported --outFilterIntronStrands " + s; }
+        else if (k == "outSJtype") { if (one(k, v) != "Standard") err = "EXITING: only --outSJtype Standard is implemented"; }
+        else if (k == "outSJfilterReads") { const std::string &s = one(k, v); if (s == "Unique") outSJfilterReadsUnique = true; else if (s != "All") err = "EXITING: unsupported --outSJfilterReads " + s; }
+        else if (k == "outSJfilterOverhangMin") I4(k, v, outSJfilterOverhangMin);
+        else if (k == "outSJfilterCountUniqueMin") I4(k, v, outSJfilterCountUniqueMin);
+        else if (k == "outSJfilterCountTotalMin") I4(k, v, outSJfilterCountTotalMin);
+        else if (k == "outSJfilterDistToOtherSJmin") I4(k, v, outSJfilterDistToOtherSJmin);
+        else if (k == "outSJfilterIntronMaxVsReadN") { outSJfilterIntronMaxVsReadN.clear(); for (auto &t : v) outSJfilterIntronMaxVsReadN.push_back(strtoull(t.c_str(), nullptr, 10)); }
+        else if (k == "scoreGap") dev.scoreGap = (int32_t)I(k, v);
+        else if (k == "scoreGapNoncan") dev.scoreGapNoncan = (int32_t)I(k, v);
+        else if (k == "scoreGapGCAG") dev.scoreGapGCAG = (int32_t)I(k, v);
+        else if (k == "scoreGapATAC") dev.scoreGapATAC = (int32_t)I(k, v);
+        else if (k == "scoreGenomicLengthLog2scale") dev.scoreGenomicLengthLog2scale = D(k, v);
+        else if (k == "scoreDelOpen") dev.scoreDelOpen = (int32_t)I(k, v);
+        else if (k == "scoreDelBase") dev.scoreDelBase = (int32_t)I(k, v);
+        else if (k == "scoreInsOpen") dev.scoreInsOpen = (int32_t)I(k, v);
+        else if (k == "scoreInsBase") dev.scoreInsBase = (int32_t)I(k, v);
+        else if (k == "scoreStitchSJshift") dev.scoreStitchSJshift = (int32_t)I(k, v);
+        else if (k == "sjdbScore") dev.sjdbScore = (int32_t)I(k, v);
+        else if (k == "seedSearchStartLmax") dev.seedSearchStartLmax = (uint32_t)U(k, v);
+        else if (k == "seedSearchStartLmaxOverLread") dev.seedSearchStartLmaxOverLread = D(k, v);
+        else if (k == "seedSearchLmax") dev.seedSearchLmax = (uint32_t)U(k, v);
+        else if (k == "seedMultimapNmax") dev.seedMultimapNmax = (uint32_t)U(k, v);
+        else if (k == "seedPerReadNmax") dev.seedPerReadNmax = (uint32_t)U(k, v);
+        else if (k == "seedPerWindowNmax") dev.seedPerWindowNmax = (uint32_t)U(k, v);
+        else if (k == "seedSplitMin") dev.seedSplitMin = (uint32_t)U(k, v);
+        else if (k == "seedMapMin") dev.seedMapMin = (uint32_t)U(k, v);
+        else if (k == "alignIntronMin") dev.alignIntronMin = U(k, v);
+        else if (k == "alignIntronMax") dev.alignIntronMax = U(k, v);
+        else if (k == "alignMatesGapMax") dev.alignMatesGapMax = U(k, v);
+        else if (k == "alignSJoverhangMin") dev.alignSJoverhangMin = (uint32_t)U(k, v);
+        else if (k == "alignSJDBoverhangMin") dev.alignSJDBoverhangMin = (uint32_t)U(k, v);
+        else if (k == "alignSJstitchMismatchNmax") I4(k, v, dev.alignSJstitchMismatchNmax);
+        else if (k == "alignSplicedMateMapLmin") dev.alignSplicedMateMapLmin = (uint32_t)U(k, v);
+        else if (k == "alignSplicedMateMapLminOverLmate") dev.alignSplicedMateMapLminOverLmate = D(k, v);
+        else if (k == "alignWindowsPerReadNmax") dev.alignWindowsPerReadNmax = (uint32_t)U(k, v);
+        else if (k == "alignTranscriptsPerWindowNmax") dev.alignTranscriptsPerWindowNmax = (uint32_t)U(k, v);
+        else if (k == "alignTranscriptsPerReadNmax") dev.alignTranscriptsPerReadNmax = (uint32_t)U(k, v);
+        else if (k == "alignEndsType") alignEndsType = one(k, v);
+        else if (k == "alignEndsProtrude") { if (v.size() != 2) err = "EXITING: --alignEndsProtrude expects 2 values"; else { dev.alignEndsProtrudeNbasesMax = (int32_t)strtol(v[0].c_str(), nullptr, 10); dev.alignEndsProtrudeConcordantPair = v[1] == "ConcordantPair"; } }
+        else if (k == "alignSoftClipAtReferenceEnds") { const std::string &s = one(k, v); dev.alignSoftClipAtReferenceEnds = (s == "Yes"); if (s != "Yes" && s != "No") err = "EXITING: unsupported --alignSoftClipAtReferenceEnds " + s; }
+        else if (k == "alignInsertionFlush") { const std::string &s = one(k, v); dev.alignInsertionFlushRight = (s == "Right"); if (s != "None" && s != "Right") err = "EXITING: unsupported --alignInsertionFlush " + s; }
+        else if (k == "winAnchorMultimapNmax") dev.winAnchorMultimapNmax = (uint32_t)U(k, v);
+        else if (k == "winBinNbits") dev.winBinNbits = (uint32_t)U(k, v);
+        else if (k == "winAnchorDistNbins") dev.winAnchorDistNbins = (uint32_t)U(k, v);
+        else if (k == "winFlankNbins") dev.winFlankNbins = (uint32_t)U(k, v);
+        else err = "EXITING: fatal input ERROR: parameter \"" + k + "\" is outside the scope of the MI355X alignReads engine (SURVEY.md section 2) -- refusing to ignore it";
+        if (!err.empty()) return err;
+    }
+    // Parameters.cpp:966-983
+    memset(dev.alignEndsTypeExt, 0, sizeof(dev.alignEndsTypeExt));
+    if (alignEndsType == "EndToEnd") { dev.alignEndsTypeExt[0][0] = dev.alignEndsTypeExt[0][1] = dev.alignEndsTypeExt[1][0] = dev.alignEndsTypeExt[1][1] = 1; }
+    else if (alignEndsType == "Extend5pOfRead1") dev.alignEndsTypeExt[0][0] = 1;
+    else if (alignEndsType == "Extend5pOfReads12") { dev.alignEndsTypeExt[0][0] = 1; dev.alignEndsTypeExt[1][0] = 1; }
+    else if (alignEndsType == "Extend3pOfRead1") dev.alignEndsTypeExt[0][1] = 1;
+    else if (alignEndsType != "Local") return "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --alignEndsType: " + alignEndsType;
+    {   // Parameters_samAttributes.cpp:172-178,213-216: XS <=> --outSAMstrandField intronMotif
+        bool hasXS = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "XS") != outSAMattrOrder.end();
+        if (hasXS) dev.outSAMstrandFieldIntronMotif = 1;
+        else if (dev.outSAMstrandFieldIntronMotif) outSAMattrOrder.push_back("XS");
+    }
+    if (genomeDir.empty()) return "EXITING: --genomeDir is required";
+    if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";
+    dev.readNmates = (uint32_t)readFilesIn.size();
+    return "";
+}
+
+void RunParams::finalize(const GenomeIndex &gi) {
+    // Genome_genomeLoad.cpp:382-410
+    uint64_t nGenome = gi.view.nGenome;
+    if (!(dev.alignIntronMax == 0 && dev.alignMatesGapMax == 0)) {
+        uint64_t a = std::max<uint64_t>(std::max<uint64_t>(4ull, dev.alignIntronMax), dev.alignMatesGapMax == 0 ? 1000ull : dev.alignMatesGapMax) / 4;
+        dev.winBinNbits = (uint32_t)std::floor(std::log2((double)a) + 0.5);
+        dev.winBinNbits = std::max<uint32_t>(dev.winBinNbits, (uint32_t)std::floor(std::log2((double)(nGenome / 40000 + 1)) + 0.5));
+    }
+    if (dev.winBinNbits > gi.view.gChrBinNbits) dev.winBinNbits = gi.view.gChrBinNbits;
+    if (!(dev.alignIntronMax == 0 && dev.alignMatesGapMax == 0)) {
+        dev.winFlankNbins = (uint32_t)(std::max(dev.alignIntronMax, dev.alignMatesGapMax) / (1ull << dev.winBinNbits) + 1);
+        dev.winAnchorDistNbins = 2 * dev.winFlankNbins;
+    }
+    dev.winBinChrNbits = gi.view.gChrBinNbits - dev.winBinNbits;
+    dev.winBinN = nGenome / (1ull << dev.winBinNbits) + 1;
+}
+
+} // namespace staramd

@@ -1,0 +1,253 @@
+// postmap.cpp -- everything the reference does with the result of mapOneRead:
+//   multMapSelect          source/ReadAlign_multMapSelect.cpp:8-95
+//   mappedFilter           source/ReadAlign_mappedFilter.cpp:3-21
+//   outputAlignments       source/ReadAlign_outputAlignments.cpp:5-72  (recordSJ :76-87, writeSAM :132-256)
+//   outputTranscriptSAM    source/ReadAlign_outputTranscriptSAM.cpp:5-359
+//   outputTranscriptSJ     source/ReadAlign_outputTranscriptSJ.cpp:4-56
+//   Stats::transcriptStats source/Stats.cpp:35-56
+// Host-side integer code; defines the parity surface (Aligned.out.sam, SJ.out.tab, Log.final.out).
+#include "host.h"
+#include <cstring>
+#include <algorithm>
+
+namespace staramd {
+
+namespace {
+inline void appendUint(std::string &s, uint64_t v) {
+    char buf[24]; int n = 0;
+    do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(buf[--n]);
+}
+inline void appendInt(std::string &s, int64_t v) { if (v < 0) { s.push_back('-'); appendUint(s, (uint64_t)(-v)); } else appendUint(s, (uint64_t)v); }
+
+// revComplementNucleotides, SequenceFuns.cpp:16-58
+inline char rcNt(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
+        case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K'; case 'S': return 'S'; case 'W': return 'W';
+        case 'B': return 'V'; case 'D': return 'H'; case 'V': return 'B'; case 'H': return 'D';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; case 'n': return 'n';
+        case 'r': return 'y'; case 'y': return 'r'; case 'k': return 'm'; case 'm': return 'k'; case 's': return 's'; case 'w': return 'w';
+        case 'b': return 'v'; case 'd': return 'h'; case 'v': return 'b'; case 'h': return 'd';
+        default: return c;
+    }
+}
+
+struct TrView {                 // one candidate alignment = header + exon slice of the result arrays
+    const staramd_transcript *t; const staramd_exon *ex;
+    bool primary;
+};
+
+struct ReadCtx {
+    const ReadBatch *b; uint32_t i;
+    uint64_t Lread, readLength[2];
+    int nMates;
+};
+} // namespace
+
+std::string PostMap::samHeader() const {
+    std::string h = "@HD\tVN:1.4\n";
+    for (uint32_t i = 0; i < gi.view.nChrReal; i++) { h += "@SQ\tSN:" + gi.chrName[i] + "\tLN:"; appendUint(h, gi.chrLength[i]); h += "\n"; }
+    h += "@PG\tID:STAR\tPN:STAR\tVN:2.7.11b\tCL:" + P.commandLine + "\n";
+    h += "@CO\tuser command line: " + P.commandLine + "\n";
+    return h;
+}
+
+// ---- ReadAlign::outputTranscriptSAM, mapped branch (:57-356) ----
+static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut) {
+    const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
+    const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
+    bool flagPaired = rc.nMates == 2;
+    uint32_t nEx = t.nExons;
+    uint32_t iExMate, nMates = 1;
+    for (iExMate = 0; iExMate + 1 < nEx; iExMate++) if (ex[iExMate].canonSJ == -3) { nMates = 2; break; }
+    uint32_t samFlagCommon = 0;
+    uint64_t Lread = rc.Lread;
+    if (flagPaired) {
+        samFlagCommon = 0x0001;
+        if (iExMate == nEx - 1) samFlagCommon += 0x0008;      // mateChr == (uint)-1 > nChrReal (:75)
+        else if (P.dev.alignEndsProtrudeConcordantPair ||
+                 ((ex[0].G <= ex[iExMate + 1].G + ex[0].R) && (ex[iExMate].G + ex[iExMate].L <= ex[nEx - 1].G + Lread - ex[nEx - 1].R)))
+            samFlagCommon += 0x0002;
+    }
+    if (b.filter[ir] == 'Y') samFlagCommon += 0x200;
+    uint32_t Str = t.Str;
+    uint32_t leftMate = flagPaired ? Str : 0;
+    uint64_t chrS = gi.chrStart[t.Chr];
+    for (uint32_t imate = 0; imate < nMates; imate++) {
+        uint32_t samFLAG = samFlagCommon;
+        uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
+        uint32_t Mate = ex[iEx1].iFrag;
+        if (Mate == 0) { samFLAG |= Str * 0x10; if (nMates == 2) samFLAG |= (1 - Str) * 0x20; }
+        else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
+        if (flagPaired) samFLAG |= (Mate == 0 ? 0x0040 : 0x0080);
+        if (!tv.primary) samFLAG |= 0x100;
+        std::string cigar, SJmotif, SJintron;
+        uint64_t trimL = 0;    // no clipping implemented (defaults clip nothing: parametersDefault:201-224)
+        uint64_t trimL1 = trimL + ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
+        if (trimL1 > 0) { appendUint(cigar, trimL1); cigar.push_back('S'); }
+        for (uint32_t ii = iEx1; ii <= iEx2; ii++) {
+            if (ii > iEx1) {
+                uint64_t gapG = ex[ii].G - (ex[ii - 1].G + ex[ii - 1].L);
+                uint64_t gapR = (uint64_t)ex[ii].R - ex[ii - 1].R - ex[ii - 1].L;
+                if (gapR > 0) { appendUint(cigar, gapR); cigar.push_back('I'); }
+                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) {
+                    appendUint(cigar, gapG); cigar.push_back('N');
+                    SJmotif.push_back(','); appendInt(SJmotif, ex[ii - 1].canonSJ + (ex[ii - 1].sjAnnot == 0 ? 0 : 20));   // SJ_SAM_AnnotatedMotifShift
+                    SJintron.push_back(','); appendUint(SJintron, ex[ii - 1].G + ex[ii - 1].L + 1 - chrS);
+                    SJintron.push_back(','); appendUint(SJintron, ex[ii].G - chrS);
+                } else if (gapG > 0) { appendUint(cigar, gapG); cigar.push_back('D'); }
+            }
+            appendUint(cigar, ex[ii].L); cigar.push_back('M');
+        }
+        if (SJmotif.empty()) { SJmotif = ",-1"; SJintron = ",-1"; }
+        uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLength[leftMate] : rc.readLength[leftMate] + 1 + rc.readLength[Mate])
+                          - ex[iEx2].R - ex[iEx2].L - trimL;
+        if (trimR1 > 0) { appendUint(cigar, trimR1); cigar.push_back('S'); }
+        int MAPQ = P.outSAMmapqUnique;
+        if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
+        out += b.name[ir]; out.push_back('\t');
+        appendUint(out, (samFLAG & P.outSAMflagAND) | P.outSAMflagOR); out.push_back('\t');
+        out += gi.chrName[t.Chr]; out.push_back('\t');
+        appendUint(out, ex[iEx1].G + 1 - chrS); out.push_back('\t');
+        appendInt(out, MAPQ); out.push_back('\t');
+        out += cigar;
+        if (nMates > 1) {
+            out += "\t=\t"; appendUint(out, ex[imate == 0 ? iExMate + 1 : 0].G + 1 - chrS); out.push_back('\t');
+            if (imate != 0) out.push_back('-');
+            appendUint(out, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);
+        } else out += "\t*\t0\t0";
+        out.push_back('\t');
+        const std::string &sq = b.seq[Mate][ir]; const std::string &ql = b.qual[Mate][ir];
+        if (Mate == Str) { out += sq; out.push_back('\t'); if (!P.outSAMmodeNoQS) out += ql; else out.push_back('*'); }
+        else {
+            size_t n = sq.size();
+            for (size_t k = 0; k < n; k++) out.push_back(rcNt(sq[n - 1 - k]));
+            out.push_back('\t');
+            if (!P.outSAMmodeNoQS) { for (size_t k = 0; k < n; k++) out.push_back(ql[n - 1 - k]); } else out.push_back('*');
+        }
+        for (const std::string &a : P.outSAMattrOrder) {
+            if (a == "NH") { out += "\tNH:i:"; appendUint(out, nTrOut); }
+            else if (a == "HI") { out += "\tHI:i:"; appendInt(out, (int64_t)iTrOut + P.outSAMattrIHstart); }
+            else if (a == "AS") { out += "\tAS:i:"; appendInt(out, t.maxScore); }
+            else if (a == "nM") { out += "\tnM:i:"; appendUint(out, t.nMM); }
+            else if (a == "jM") { out += "\tjM:B:c"; out += SJmotif; }
+            else if (a == "jI") { out += "\tjI:B:i"; out += SJintron; }
+            else if (a == "XS") { if (t.sjMotifStrand == 1) out += "\tXS:A:+"; else if (t.sjMotifStrand == 2) out += "\tXS:A:-"; }
+        }
+        out.push_back('\n');
+    }
+}
+
+// ---- ReadAlign::outputTranscriptSAM, unmapped branch (:11-54) ----
+static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const staramd_transcript *trBest, const staramd_exon *exBest,
+                        int unmapType, const bool mateMap[2]) {
+    const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
+    for (int imate = 0; imate < rc.nMates; imate++) {
+        if (mateMap[imate]) continue;
+        uint32_t samFLAG = 0x4;
+        if (rc.nMates == 2) {
+            samFLAG |= 0x1 + (imate == 0 ? 0x40 : 0x80);
+            if (mateMap[1 - imate]) { if (trBest->Str != (uint32_t)(1 - imate)) samFLAG |= 0x20; }
+            else samFLAG |= 0x8;
+        }
+        if (b.filter[ir] == 'Y') samFLAG |= 0x200;
+        out += b.name[ir]; out.push_back('\t'); appendUint(out, samFLAG); out += "\t*\t0\t0\t*";
+        if (rc.nMates == 2 && mateMap[1 - imate]) { out.push_back('\t'); out += gi.chrName[trBest->Chr]; out.push_back('\t'); appendUint(out, exBest[0].G + 1 - gi.chrStart[trBest->Chr]); }
+        else out += "\t*\t0";
+        out += "\t0\t"; out += b.seq[imate][ir]; out.push_back('\t'); out += b.qual[imate][ir];
+        out += "\tNH:i:0\tHI:i:0\tAS:i:"; appendInt(out, trBest ? trBest->maxScore : 0);
+        out += "\tnM:i:"; appendUint(out, trBest ? trBest->nMM : 0); out += "\tuT:A:"; appendInt(out, unmapType);
+        out.push_back('\n');
+    }
+}
+
+std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st) {
+    std::vector<TrView> trMult;
+    for (uint32_t ir = 0; ir < b.n; ir++) {
+        const staramd_read_result &rr = r.reads[ir];
+        if (rr.status & STARAMD_ST_FATAL_SEEDS_PER_READ)
+            return "EXITING because of FATAL error: too many pieces pere read\nSOLUTION: increase input parameter --seedPerReadNmax";
+        if (rr.status & STARAMD_ST_SCRATCH_OVERFLOW)
+            return "EXITING because of FATAL error: a device work-space cap was exceeded for read " + b.name[ir];
+        ReadCtx rc; rc.b = &b; rc.i = ir; rc.nMates = (int)P.dev.readNmates;
+        rc.Lread = b.readOffset[ir + 1] - b.readOffset[ir];
+        rc.readLength[0] = b.mate1Length[ir]; rc.readLength[1] = rc.nMates == 2 ? rc.Lread - rc.readLength[0] - 1 : 0;
+        st.readN++; st.readBases += rc.readLength[0] + rc.readLength[1];
+        const staramd_transcript *T = r.tr + rr.trOffset;
+        uint64_t nW = rr.nW;
+        const staramd_transcript *trBest = (nW > 0 && rr.trBest >= 0) ? T + rr.trBest : nullptr;
+        // ---- multMapSelect
+        trMult.clear();
+        uint64_t nTr = 0;
+        if (nW > 0) {
+            int maxScore = trBest->maxScore;     // == max over windows' heads (asserted in the reference :20-24)
+            for (uint32_t k = 0; k < rr.nTr; k++)
+                if (T[k].maxScore + P.dev.outFilterMultimapScoreRange >= maxScore) { TrView v; v.t = T + k; v.ex = r.ex + T[k].exonOffset; v.primary = false; trMult.push_back(v); }
+            nTr = trMult.size();
+            if (!(nTr > P.outFilterMultimapNmax || nTr == 0)) {
+                if (nTr == 1) trMult[0].primary = true;
+                else if (P.outSAMprimaryAllBest) { for (auto &v : trMult) if (v.t->maxScore == maxScore) v.primary = true; }
+                else { for (auto &v : trMult) if (v.t == trBest) v.primary = true; }
+            }
+        }
+        // ---- mappedFilter
+        int unmapType = -1;
+        if (nW == 0) { st.unmappedOther++; unmapType = 0; }
+        else if ((trBest->maxScore < P.outFilterScoreMin) || (trBest->maxScore < (int)(P.outFilterScoreMinOverLread * (double)(rc.Lread - 1)))
+                 || (trBest->nMatch < P.outFilterMatchNmin) || (trBest->nMatch < (uint64_t)(P.outFilterMatchNminOverLread * (double)(rc.Lread - 1)))) { st.unmappedShort++; unmapType = 1; }
+        else if ((trBest->nMM > b.mmMaxTotal[ir]) || (double(trBest->nMM) / double(trBest->rLength) > P.dev.outFilterMismatchNoverLmax)) { st.unmappedMismatch++; unmapType = 2; }
+        else if (nTr > P.outFilterMultimapNmax) { st.unmappedMulti++; unmapType = 3; }
+        // ---- outputAlignments
+        bool mateMapped[2] = {false, false};
+        if (unmapType < 0) {
+            if (nTr > 1) { st.mappedReadsM++; unmapType = -2; }
+            else if (nTr == 1) {
+                st.mappedReadsU++;
+                const staramd_transcript &t = *trMult[0].t; const staramd_exon *ex = trMult[0].ex;
+                st.mappedMismatchesN += t.nMM; st.mappedInsN += t.nIns; st.mappedDelN += t.nDel; st.mappedInsL += t.lIns; st.mappedDelL += t.lDel;
+                uint64_t mappedL = 0;
+                for (uint32_t k = 0; k < t.nExons; k++) mappedL += ex[k].L;
+                for (uint32_t k = 0; k + 1 < t.nExons; k++) { if (ex[k].canonSJ >= 0) st.splicesN[ex[k].canonSJ]++; if (ex[k].sjAnnot == 1) st.splicesNsjdb++; }
+                st.mappedBases += mappedL; st.mappedPortion += double(mappedL) / double(rc.Lread);
+            }
+            // recordSJ (:76-87) -> outputTranscriptSJ
+            if (!P.outSJfilterReadsUnique || nTr == 1) {
+                size_t sjReadStartN = sj.data.size();
+                for (uint64_t it = 0; it < nTr; it++) {
+                    const staramd_transcript &t = *trMult[it].t; const staramd_exon *ex = trMult[it].ex;
+                    for (uint32_t iex = 0; iex + 1 < t.nExons; iex++) {
+                        if (ex[iex].canonSJ < 0) continue;
+                        Junction j; j.start = ex[iex].G + ex[iex].L; j.gap = (uint32_t)(ex[iex + 1].G - j.start);
+                        j.overhangLeft = (uint16_t)std::min<uint32_t>(ex[iex].L, ex[iex + 1].L); j.overhangRight = j.overhangLeft;
+                        bool dup = false;
+                        for (size_t ii = sjReadStartN; ii < sj.data.size(); ii++) {
+                            if (sj.data[ii].start == j.start && sj.data[ii].gap == j.gap) {
+                                dup = true;
+                                if (sj.data[ii].overhangLeft < j.overhangLeft) { sj.data[ii].overhangLeft = j.overhangLeft; sj.data[ii].overhangRight = j.overhangLeft; }
+                                break;
+                            }
+                        }
+                        if (dup) continue;
+                        j.motif = ex[iex].canonSJ; j.strand = (int8_t)(ex[iex].canonSJ == 0 ? 0 : (ex[iex].canonSJ + 1) % 2 + 1); j.annot = (int8_t)ex[iex].sjAnnot;
+                        if (nTr == 1) { j.countUnique = 1; j.countMultiple = 0; } else { j.countMultiple = 1; j.countUnique = 0; }
+                        sj.data.push_back(j);
+                    }
+                }
+            }
+            // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
+            for (uint64_t it = 0; it < nTr; it++) samMapped(sam, P, gi, rc, trMult[it], nTr, it);
+            const staramd_exon *exB = r.ex + trBest->exonOffset;
+            mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
+            if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
+            if (unmapType == 4 && P.outSAMunmappedWithin) samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
+        } else if (P.outSAMunmappedWithin) {
+            staramd_transcript t0; memset(&t0, 0, sizeof(t0));
+            samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
+        }
+        if (unmapType >= 0) st.unmappedAll++;
+    }
+    return "";
+}
+
+} // namespace staramd

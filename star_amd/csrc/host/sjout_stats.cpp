@@ -1,0 +1,137 @@
+// sjout_stats.cpp -- junction collapse / filter / SJ.out.tab and Log.final.out.
+//   OutSJ::collapseSJ, Junction::collapseOneSJ, Junction::outputStream   source/OutSJ.cpp:42-123
+//   outputSJ (filters, two-sided distance filter, file)                  source/outputSJ.cpp:20-138
+//   Stats::reportFinal                                                   source/Stats.cpp:99-145
+#include "host.h"
+#include <algorithm>
+#include <fstream>
+#include <iomanip>
+#include <ctime>
+
+namespace staramd {
+
+void OutSJ::collapse() {
+    if (data.empty()) return;
+    std::stable_sort(data.begin(), data.end(), [](const Junction &a, const Junction &b) { return a.start != b.start ? a.start < b.start : a.gap < b.gap; });
+    size_t k = 0;
+    for (size_t i = 1; i < data.size(); i++) {
+        if (data[i].start == data[k].start && data[i].gap == data[k].gap) {
+            data[k].countUnique += data[i].countUnique; data[k].countMultiple += data[i].countMultiple;
+            if (data[k].overhangLeft < data[i].overhangLeft) data[k].overhangLeft = data[i].overhangLeft;
+            if (data[k].overhangRight < data[i].overhangRight) data[k].overhangRight = data[i].overhangRight;
+        } else { ++k; if (k != i) data[k] = data[i]; }
+    }
+    data.resize(k + 1);
+}
+
+std::string OutSJ::filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path) {
+    collapse();
+    // per-junction filter (outputSJ.cpp:59-65)
+    std::vector<Junction> all;
+    for (const Junction &j : data) {
+        int m = (j.motif + 1) / 2;
+        uint32_t tot = j.countMultiple + j.countUnique;
+        bool ok = j.annot > 0 ||
+                  ((j.countUnique >= (uint32_t)P.outSJfilterCountUniqueMin[m] || tot >= (uint32_t)P.outSJfilterCountTotalMin[m])
+                   && j.overhangLeft >= (uint32_t)P.outSJfilterOverhangMin[m] && j.overhangRight >= (uint32_t)P.outSJfilterOverhangMin[m]
+                   && (tot > P.outSJfilterIntronMaxVsReadN.size() || j.gap <= (uint32_t)P.outSJfilterIntronMaxVsReadN[tot - 1]));
+        if (ok) all.push_back(j);
+    }
+    // distance to other junctions' donors / acceptors (:85-120)
+    size_t N = all.size();
+    std::vector<char> keep(N, 0);
+    struct Acc { uint64_t a; uint64_t idx; uint64_t motif; };
+    std::vector<Acc> sjA(N);
+    for (size_t ii = 0; ii < N; ii++) {
+        uint64_t x1 = 0, x2 = (uint64_t)-1;
+        if (ii > 0) x1 = all[ii - 1].start;
+        if (ii + 1 < N) x2 = all[ii + 1].start;
+        uint64_t minDist = std::min(all[ii].start - x1, x2 - all[ii].start);
+        keep[ii] = minDist >= (uint64_t)P.outSJfilterDistToOtherSJmin[(all[ii].motif + 1) / 2];
+        sjA[ii].a = all[ii].start + (uint64_t)all[ii].gap; sjA[ii].idx = ii;
+        sjA[ii].motif = all[ii].annot == 0 ? (uint64_t)all[ii].motif : 8;   // SJ_MOTIF_SIZE+1
+    }
+    // the reference qsorts triples by the acceptor only (compareUint): ties keep an unspecified order, which cannot
+    // change the outcome because equal acceptors give minDist 0 for both members of the tie
+    std::stable_sort(sjA.begin(), sjA.end(), [](const Acc &x, const Acc &y) { return x.a < y.a; });
+    for (size_t ii = 0; ii < N; ii++) {
+        if (sjA[ii].motif == 8) keep[sjA[ii].idx] = 1;
+        else {
+            uint64_t x1 = 0, x2 = (uint64_t)-1;
+            if (ii > 0) x1 = sjA[ii - 1].a;
+            if (ii + 1 < N) x2 = sjA[ii + 1].a;
+            uint64_t minDist = std::min(sjA[ii].a - x1, x2 - sjA[ii].a);
+            keep[sjA[ii].idx] = keep[sjA[ii].idx] && (minDist >= (uint64_t)P.outSJfilterDistToOtherSJmin[(sjA[ii].motif + 1) / 2]);
+        }
+    }
+    std::ofstream out(path.c_str());
+    if (!out.good()) return "EXITING because of fatal ERROR: could not create output file " + path;
+    for (size_t ii = 0; ii < N; ii++) {
+        if (!keep[ii]) continue;
+        const Junction &j = all[ii];
+        uint32_t c = gi.chrBin[j.start >> gi.view.gChrBinNbits];
+        out << gi.chrName.at(c) << "\t" << j.start + 1 - gi.chrStart[c] << "\t" << j.start + j.gap - gi.chrStart[c]
+            << "\t" << int(j.strand) << "\t" << int(j.motif) << "\t" << int(j.annot) << "\t" << j.countUnique << "\t" << j.countMultiple
+            << "\t" << j.overhangLeft << "\n";
+    }
+    return "";
+}
+
+void Stats::add(const Stats &s) {
+    readN += s.readN; readBases += s.readBases; mappedMismatchesN += s.mappedMismatchesN; mappedInsN += s.mappedInsN; mappedDelN += s.mappedDelN;
+    mappedInsL += s.mappedInsL; mappedDelL += s.mappedDelL; mappedBases += s.mappedBases; mappedPortion += s.mappedPortion;
+    mappedReadsU += s.mappedReadsU; mappedReadsM += s.mappedReadsM; unmappedOther += s.unmappedOther; unmappedShort += s.unmappedShort;
+    unmappedMismatch += s.unmappedMismatch; unmappedMulti += s.unmappedMulti; unmappedAll += s.unmappedAll; chimericAll += s.chimericAll;
+    splicesNsjdb += s.splicesNsjdb;
+    for (int i = 0; i < 7; i++) splicesN[i] += s.splicesN[i];
+}
+
+static std::string timeMonthDayTime(time_t t) {      // TimeFunctions.cpp
+    char buf[64]; strftime(buf, sizeof(buf), "%b %d %H:%M:%S", localtime(&t)); return buf;
+}
+
+void Stats::reportFinal(const std::string &path) {
+    std::ofstream so(path.c_str());
+    int w1 = 50;
+    time(&timeFinish);
+    so << std::setiosflags(std::ios::fixed) << std::setprecision(2)
+       << std::setw(w1) << "Started job on |\t" << timeMonthDayTime(timeStart) << "\n"
+       << std::setw(w1) << "Started mapping on |\t" << timeMonthDayTime(timeStartMap) << "\n"
+       << std::setw(w1) << "Finished on |\t" << timeMonthDayTime(timeFinish) << "\n"
+       << std::setw(w1) << "Mapping speed, Million of reads per hour |\t" << double(readN) / 1e6 / difftime(timeFinish, timeStartMap) * 3600 << "\n"
+       << "\n"
+       << std::setw(w1) << "Number of input reads |\t" << readN << "\n"
+       << std::setw(w1) << "Average input read length |\t" << (readN > 0 ? readBases / readN : 0) << "\n"
+       << std::setw(w1) << "UNIQUE READS:\n"
+       << std::setw(w1) << "Uniquely mapped reads number |\t" << mappedReadsU << "\n"
+       << std::setw(w1) << "Uniquely mapped reads % |\t" << (readN > 0 ? double(mappedReadsU) / double(readN) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "Average mapped length |\t" << (mappedReadsU > 0 ? double(mappedBases) / double(mappedReadsU) : 0) << "\n";
+    so << std::setw(w1) << "Number of splices: Total |\t" << splicesN[0] + splicesN[1] + splicesN[2] + splicesN[3] + splicesN[4] + splicesN[5] + splicesN[6] << "\n"
+       << std::setw(w1) << "Number of splices: Annotated (sjdb) |\t" << splicesNsjdb << "\n"
+       << std::setw(w1) << "Number of splices: GT/AG |\t" << splicesN[1] + splicesN[2] << "\n"
+       << std::setw(w1) << "Number of splices: GC/AG |\t" << splicesN[3] + splicesN[4] << "\n"
+       << std::setw(w1) << "Number of splices: AT/AC |\t" << splicesN[5] + splicesN[6] << "\n"
+       << std::setw(w1) << "Number of splices: Non-canonical |\t" << splicesN[0] << "\n";
+    so << std::setw(w1) << "Mismatch rate per base, % |\t" << double(mappedMismatchesN) / double(mappedBases) * 100 << '%' << "\n"
+       << std::setw(w1) << "Deletion rate per base |\t" << (mappedBases > 0 ? double(mappedDelL) / double(mappedBases) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "Deletion average length |\t" << (mappedDelN > 0 ? double(mappedDelL) / double(mappedDelN) : 0) << "\n"
+       << std::setw(w1) << "Insertion rate per base |\t" << (mappedBases > 0 ? double(mappedInsL) / double(mappedBases) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "Insertion average length |\t" << (mappedInsN > 0 ? double(mappedInsL) / double(mappedInsN) : 0) << "\n"
+       << std::setw(w1) << "MULTI-MAPPING READS:\n"
+       << std::setw(w1) << "Number of reads mapped to multiple loci |\t" << mappedReadsM << "\n"
+       << std::setw(w1) << "% of reads mapped to multiple loci |\t" << (readN > 0 ? double(mappedReadsM) / double(readN) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "Number of reads mapped to too many loci |\t" << unmappedMulti << "\n"
+       << std::setw(w1) << "% of reads mapped to too many loci |\t" << (readN > 0 ? double(unmappedMulti) / double(readN) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "UNMAPPED READS:\n"
+       << std::setw(w1) << "Number of reads unmapped: too many mismatches |\t" << unmappedMismatch << "\n"
+       << std::setw(w1) << "% of reads unmapped: too many mismatches |\t" << (readN > 0 ? double(unmappedMismatch) / double(readN) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "Number of reads unmapped: too short |\t" << unmappedShort << "\n"
+       << std::setw(w1) << "% of reads unmapped: too short |\t" << (readN > 0 ? double(unmappedShort) / double(readN) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "Number of reads unmapped: other |\t" << unmappedOther << "\n"
+       << std::setw(w1) << "% of reads unmapped: other |\t" << (readN > 0 ? double(unmappedOther) / double(readN) * 100 : 0) << '%' << "\n"
+       << std::setw(w1) << "CHIMERIC READS:\n"
+       << std::setw(w1) << "Number of chimeric reads |\t" << chimericAll << "\n"
+       << std::setw(w1) << "% of chimeric reads |\t" << (readN > 0 ? double(chimericAll) / double(readN) * 100 : 0) << '%' << "\n" << std::flush;
+}
+
+} // namespace staramd

@@ -1,0 +1,17 @@
+"""Pin the CPU restatement (oracle/) against the reference itself (oracle/_ref/STAR):
+whole-run outputs must be byte-identical on synthetic data sets that exercise the adversarial
+branches listed in SURVEY.md section 4.  Needs the reference binary (built from /root/reference by
+oracle/Makefile.ref; it travels to the GPU box inside oracle/_ref/)."""
+import pytest
+
+from util import DATASETS, compare_outputs, prepare, run_with_engine, oracle_lib, refstar
+
+pytestmark = pytest.mark.skipif(not refstar.have_ref(), reason="oracle/_ref/STAR not built (no /root/reference here)")
+
+
+@pytest.mark.parametrize("name", sorted(DATASETS))
+def test_oracle_matches_reference(name, tmp_path, built):
+    info = prepare(name, str(tmp_path))
+    new = run_with_engine(info, str(tmp_path / name / "orc_"), lambda g, p: oracle_lib.Oracle(g, p))
+    problems = compare_outputs(info["ref_prefix"], new)
+    assert not problems, problems
