@@ -236,6 +236,7 @@ struct Oracle {
                 if ((iSA1 & SAiMarkAbsentMaskC) == 0) break;
                 --Lind; ind1 >>= 2;
             }
+            if (Lind == 0) { NrepAll[iDist] = 0; indAll[2 * iDist] = indAll[2 * iDist + 1] = 0; maxLall[iDist] = 0; continue; }   // base absent from the genome (reference: out-of-bounds read)
             bool iSA2good = true;
             if (g.genomeSAindexStart[Lind - 1] + ind1 + 1 < g.genomeSAindexStart[Lind]) {
                 iSA2 = SAiAt(g.genomeSAindexStart[Lind - 1] + ind1 + 1);
@@ -256,7 +257,7 @@ struct Oracle {
             NrepAll[iDist] = Nrep; indAll[2 * iDist] = indStartEnd[0]; indAll[2 * iDist + 1] = indStartEnd[1]; maxLall[iDist] = maxL;
         }
         for (u64 iDist = 0; iDist < nD; iDist++)
-            if (maxLall[iDist] + iDist == maxLbest)
+            if (maxLall[iDist] + iDist == maxLbest && NrepAll[iDist] > 0)
                 storeAligns(iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, NrepAll[iDist], maxLall[iDist], &indAll[2 * iDist], iFrag);
         return Nrep;
     }

@@ -1,0 +1,231 @@
+// k_seed.hip -- kernel 1: maximal-mappable-prefix seed search.
+//
+// Replaces, per read, the seed phase of ReadAlign::mapOneRead (source/ReadAlign_mapOneRead.cpp:17-93):
+// qualitySplit (SequenceFuns.cpp:411-444), maxMappableLength2strands
+// (ReadAlign_maxMappableLength2strands.cpp:5-115), maxMappableLength / findMultRange /
+// compareSeqToGenome (SuffixArrayFuns.cpp:10-207) and storeAligns (ReadAlign_storeAligns.cpp:10-160).
+//
+// Mapping: one lane = one read, 64 independent reads per wavefront, persistent lanes pulling
+// read ids from a device-wide ticket counter.  The kernel is a chain of dependent random gathers
+// (SAindex entry -> packed SA word -> genome bytes), so throughput is set by the number of
+// independent chains in flight; every lane carries one.  The seed schedule inside a read is kept
+// strictly in the reference's order because storeAligns' de-duplication is order dependent
+// (first (rStart,Length) in schedule order wins).
+#include "dev.h"
+
+struct SeedCnt { u64 nSAi, nSAprobe, nGcmp; };
+
+// SuffixArrayFuns.cpp:10-104 -- the four read/genome direction variants folded into one loop
+__device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, u32 N, u32 L, u64 iSA, bool dirR, bool &compRes, SeedCnt &cn) {
+    cn.nSAprobe++;
+    u64 SAstr = packedGet(X.SA, iSA, X.saBits, X.saMask);
+    bool dirG = (SAstr >> X.strandBit) == 0;
+    SAstr &= X.strandMask;
+    bool useComp = dirR != dirG;
+    const u8 *g = dirG ? X.G + SAstr + L : X.G + (X.nGenome - 1 - SAstr) - L;
+    const u8 *s = dirR ? R + S + L : R + S - L;
+    int sgnG = dirG ? 1 : -1, sgnR = dirR ? 1 : -1;
+    u32 n = N - L;
+    for (u32 ii = 0; ii < n; ii++) {
+        u8 sc = s[sgnR * (int)ii]; if (useComp) sc = compBase(sc);
+        u8 gc = g[sgnG * (int)ii];
+        if (sc != gc) {
+            cn.nGcmp += ii + 1;
+            compRes = dirG ? (sc > gc) : !(sc > gc || gc > 3);
+            return ii + L;
+        }
+    }
+    cn.nGcmp += n;
+    return N;
+}
+
+__device__ __forceinline__ u64 medianUint2(u64 a, u64 b) { return a / 2 + b / 2 + (a % 2 + b % 2) / 2; }
+
+// SuffixArrayFuns.cpp:106-131
+__device__ static u64 findMultRange(const DevIndex &X, const u8 *R, u64 i3, u32 L3, u64 i1, u32 L1, u64 i1a, u32 L1a, u64 i1b, u32 L1b, bool dirR, u32 S, SeedCnt &cn) {
+    bool compRes;
+    if (L1 < L3) { L1b = L1; i1b = i1; i1a = i3; }
+    else if (L1a < L1) { L1b = L1a; i1b = i1a; i1a = i1; }
+    while ((i1b + 1 < i1a) | (i1b > i1a + 1)) {
+        u64 i1c = medianUint2(i1a, i1b);
+        u32 L1c = compareSeqToGenome(X, R, S, L3, L1b, i1c, dirR, compRes, cn);
+        if (L1c == L3) i1a = i1c; else { i1b = i1c; L1b = L1c; }
+    }
+    return i1a;
+}
+
+// SuffixArrayFuns.cpp:133-207
+__device__ static u64 maxMappableLength(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
+    bool compRes;
+    u32 L1, L2, L3, L1a, L1b, L2a, L2b; u64 i3, i1a, i1b, i2a, i2b;
+    L1 = compareSeqToGenome(X, R, S, N, L, i1, dirR, compRes, cn);
+    L2 = compareSeqToGenome(X, R, S, N, L, i2, dirR, compRes, cn);
+    L = min(L1, L2);
+    L1a = L1; L1b = L1; i1a = i1; i1b = i1; L2a = L2; L2b = L2; i2a = i2; i2b = i2;
+    i3 = i1; L3 = L1;
+    while (i1 + 1 < i2) {
+        i3 = medianUint2(i1, i2);
+        L3 = compareSeqToGenome(X, R, S, N, L, i3, dirR, compRes, cn);
+        if (L3 == N) break;
+        if (compRes) { if (L3 > L1) { L1b = L1a; L1a = L1; i1b = i1a; i1a = i1; } i1 = i3; L1 = L3; }
+        else { if (L3 > L2) { L2b = L2a; L2a = L2; i2b = i2a; i2a = i2; } i2 = i3; L2 = L3; }
+        L = min(L1, L2);
+    }
+    if (L3 < N) { if (L1 > L2) { i3 = i1; L3 = L1; } else { i3 = i2; L3 = L2; } }
+    i1 = findMultRange(X, R, i3, L3, i1, L1, i1a, L1a, i1b, L1b, dirR, S, cn);
+    i2 = findMultRange(X, R, i3, L3, i2, L2, i2a, L2a, i2b, L2b, dirR, S, cn);
+    L = L3; ind0 = i1; ind1 = i2;
+    return i2 - i1 + 1;
+}
+
+struct SeedState {
+    DSeed *PC; u32 nP; u32 cap;
+    u64 nA; u32 multNmin, multNminL;
+    bool fatal;
+};
+
+// ReadAlign_storeAligns.cpp:10-160 (OPTIM_STOREaligns_SIMPLE branch)
+__device__ static void storeAligns(const DevIndex &X, SeedState &st, u32 iDir, u32 Shift, u64 Nrep, u32 L, u64 ind0, u32 iFrag) {
+    if (Nrep > X.P.seedMultimapNmax) { if (Nrep < st.multNmin || st.multNmin == 0) { st.multNmin = (u32)min(Nrep, (u64)0xFFFFFFFFu); st.multNminL = L; } return; }
+    st.nA += Nrep;
+    u32 rStart = iDir == 0 ? Shift : Shift + 1 - L;
+    int iP;
+    for (iP = (int)st.nP - 1; iP >= 0; iP--) {
+        if (st.PC[iP].rStart <= rStart) {
+            if (st.PC[iP].rStart == rStart && st.PC[iP].L < L) continue;
+            if (st.PC[iP].rStart == rStart && st.PC[iP].L == L) return;
+            break;
+        }
+    }
+    iP++;
+    if (st.nP + 1 > X.P.seedPerReadNmax || st.nP + 1 > st.cap) { st.fatal = true; return; }    // reference: exitWithError :46-51
+    for (int ii = (int)st.nP - 1; ii >= iP; ii--) st.PC[ii + 1] = st.PC[ii];
+    st.nP++;
+    DSeed s; s.saStart = ind0; s.nrep = (u32)Nrep; s.rStart = (u16)rStart; s.L = (u16)L; s.dir = (u8)iDir; s.iFrag = (u8)iFrag;
+    for (int k = 0; k < 6; k++) s.pad[k] = 0;
+    st.PC[iP] = s;
+    if (Nrep != 1) { if (Nrep < st.multNmin || st.multNmin == 0) { st.multNmin = (u32)Nrep; st.multNminL = L; } }
+}
+
+// ReadAlign_maxMappableLength2strands.cpp:5-115
+__device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R, SeedState &st, u32 pieceStartIn, u32 pieceLengthIn, u32 iDir, u32 &maxLbest, u32 iFrag, SeedCnt &cn) {
+    const u32 DMAX = 8;           // gSAsparseD values above 8 are rejected at context creation
+    u64 NrepAll[DMAX], ind0All[DMAX]; u32 maxLall[DMAX];
+    maxLbest = 0;
+    bool dirR = iDir == 0;
+    u32 nD = min(pieceLengthIn, X.sparseD);
+    for (u32 iDist = 0; iDist < nD; iDist++) {
+        u32 pieceStart; u32 pieceLength = pieceLengthIn - iDist;
+        u32 Lmax = min(X.saiNbases, pieceLength);
+        u64 ind1 = 0;
+        if (dirR) { pieceStart = pieceStartIn + iDist; for (u32 ii = 0; ii < Lmax; ii++) { ind1 <<= 2; ind1 += (u64)R[pieceStart + ii]; } }
+        else { pieceStart = pieceStartIn - iDist; for (u32 ii = 0; ii < Lmax; ii++) { ind1 <<= 2; ind1 += 3 - (u64)R[pieceStart - ii]; } }
+        u32 Lind = Lmax; u64 iSA1 = 0, iSA2;
+        while (Lind > 0) {
+            iSA1 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1, X.saiBits, X.saiMask); cn.nSAi++;
+            if ((iSA1 & X.saiAbsentBit) == 0) break;
+            --Lind; ind1 >>= 2;
+        }
+        if (Lind == 0) { NrepAll[iDist] = 0; ind0All[iDist] = 0; maxLall[iDist] = 0; continue; }   // base absent from the genome (reference: out-of-bounds)
+        bool iSA2good = true;
+        if (X.saiStart[Lind - 1] + ind1 + 1 < X.saiStart[Lind]) {
+            iSA2 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1 + 1, X.saiBits, X.saiMask); cn.nSAi++;
+            if ((iSA2 & X.saiAbsentBit) == 0) iSA2 = (iSA2 & ~X.saiNbit) - 1;
+            else { iSA2 = X.nSA - 1; iSA2good = false; }
+        } else { iSA2 = X.nSA - 1; iSA2good = false; }
+        bool iSA1noN = (iSA1 & X.saiNbit) == 0;
+        u64 Nrep, i0, i1; u32 maxL;
+        if (Lind < X.saiNbases && iSA1noN && iSA2good) { i0 = iSA1; i1 = iSA2; Nrep = i1 - i0 + 1; maxL = Lind; }
+        else if (iSA1 == iSA2 && iSA1noN && iSA2good) {
+            i0 = i1 = iSA1; Nrep = 1; bool cr;
+            maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, Lind, iSA1, dirR, cr, cn);
+        } else {
+            maxL = (iSA2good && iSA1noN) ? Lind : 0;
+            Nrep = maxMappableLength(X, R, pieceStart, pieceLength, iSA1 & ~X.saiNbit, iSA2, dirR, maxL, i0, i1, cn);
+        }
+        if (maxL + iDist > maxLbest) maxLbest = maxL + iDist;
+        NrepAll[iDist] = Nrep; ind0All[iDist] = i0; maxLall[iDist] = maxL;
+    }
+    for (u32 iDist = 0; iDist < nD; iDist++)
+        if (maxLall[iDist] + iDist == maxLbest && NrepAll[iDist] > 0)
+            storeAligns(X, st, iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, NrepAll[iDist], maxLall[iDist], ind0All[iDist], iFrag);
+}
+
+extern "C" __global__ void __launch_bounds__(256) k_seed_search(DevIndex X, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
+    u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+    SeedState st; st.PC = scratch + (u64)lane * scratchPerLane; st.cap = scratchPerLane;
+    SeedCnt cn = {0, 0, 0}; u64 nSeedsTot = 0;
+    const staramd_params &P = X.P;
+    for (;;) {
+        u32 ir = atomicAdd(&B.cursors[8], 1u);
+        if (ir >= B.nReads) break;
+        const u8 *R = B.bases + B.readOffset[ir];
+        u32 Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
+        st.nP = 0; st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
+        // qualitySplit, SequenceFuns.cpp:411-444
+        u16 spStart[16], spLen[16]; u8 spFrag[16];
+        u32 Nsplit = 0, LgoodMin = 0;
+        {
+            u32 iR = 0, iFrag = 0;
+            while ((iR < Lread) & (Nsplit < P.maxNsplit)) {
+                while (iR < Lread && R[iR] > 3) { if (R[iR] == STARAMD_SPACER_BASE) iFrag++; iR++; }
+                if (iR == Lread) break;
+                u32 iR1 = iR;
+                while (iR < Lread && R[iR] <= 3) iR++;
+                if ((iR - iR1) > LgoodMin) LgoodMin = iR - iR1;
+                if ((iR - iR1) < P.seedSplitMin) continue;
+                spStart[Nsplit] = (u16)iR1; spLen[Nsplit] = (u16)(iR - iR1); spFrag[Nsplit] = (u8)iFrag; Nsplit++;
+            }
+        }
+        u32 seedSearchStartLmax = min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1)));
+        for (u32 ip = 0; ip < Nsplit; ip++) {
+            u32 pS = spStart[ip], pL = spLen[ip];
+            u32 Nstart = (P.seedSearchStartLmax > 0 && seedSearchStartLmax < pL) ? pL / seedSearchStartLmax + 1 : 1;
+            u32 Lstart = pL / Nstart;
+            bool flagDirMap = true;
+            for (u32 iDir = 0; iDir < 2; iDir++) {
+                for (u32 istart = 0; istart < Nstart; istart++) {
+                    u32 Lm;
+                    if (flagDirMap || istart > 0) {
+                        u32 Lmapped = 0;
+                        while (istart * Lstart + Lmapped + P.seedMapMin < pL) {
+                            u32 Shift = iDir == 0 ? (pS + istart * Lstart + Lmapped) : (pS + pL - istart * Lstart - 1 - Lmapped);
+                            u32 seedLength = pL - Lmapped - istart * Lstart;
+                            maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, spFrag[ip], cn);
+                            if (iDir == 0 && istart == 0 && Lmapped == 0 && Shift + Lm == pL) flagDirMap = false;
+                            Lmapped += Lm;
+                            if (Lm == 0) break;
+                        }
+                    }
+                    if (P.seedSearchLmax > 0) {
+                        u32 Shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1);
+                        u32 seedLength = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - Shift) : (Shift + 1));
+                        maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, spFrag[ip], cn);
+                    }
+                }
+            }
+        }
+        // classification, ReadAlign_mapOneRead.cpp:100-115
+        DRead rd;
+        rd.status = 0; rd.seedOffset = 0; rd.nSeeds = 0; rd.unmappedLength = 0; rd.winOffset = 0; rd.nWin = 0; rd.wtOffset = 0; rd.nWt = 0;
+        rd.maxScoreMate[0] = rd.maxScoreMate[1] = 0; rd.bestW = -1; rd.nTr = 0; rd.nEx = 0;
+        nSeedsTot += st.nP;
+        if (st.fatal) rd.status |= STARAMD_ST_FATAL_SEEDS_PER_READ;
+        else if (Lread < P.outFilterMatchNmin) { rd.status |= STARAMD_ST_READ_TOO_SHORT; rd.unmappedLength = 0; }
+        else if (Nsplit == 0) { rd.status |= STARAMD_ST_NO_GOOD_PIECES; rd.unmappedLength = LgoodMin; }
+        else if (st.nA == 0) { rd.status |= STARAMD_ST_ALL_PIECES_MULTI; rd.unmappedLength = st.multNminL; }
+        else {
+            u32 off = atomicAdd(&B.cursors[0], st.nP);
+            if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[6], 1u); rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; }
+            else {
+                rd.seedOffset = off; rd.nSeeds = st.nP;
+                for (u32 k = 0; k < st.nP; k++) B.seedPool[off + k] = st.PC[k];
+            }
+        }
+        B.reads[ir] = rd;
+    }
+    atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)cn.nSAi);
+    atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)cn.nSAprobe);
+    atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);
+    atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
+}
