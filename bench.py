@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the seed-search-and-stitch hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+  step      = one pass of the whole device hot path (seed search -> windows -> stitch -> gather, results copied back to
+              the host) over one batch of synthetic read pairs that is ALREADY RESIDENT in HBM when the timed region starts
+  metric    = BASELINE.json's: million reads (pairs) aligned per second, whole job
+  workload  = synthetic 2x101 bp PE reads on a synthetic genome with repeats + annotated/novel junctions (there is no
+              GRCh38 in the image and no network; the size is what an index build inside the run allows -- config.workload)
+  roofline  = dominant kernel (by HIP-event time inside the engine, on the engine's stream): algorithmic bytes / duration
+              vs the 8 TB/s HBM peak
+  cpu_baseline = the reference itself (oracle/_ref/STAR, all host cores) timed on a bounded sample of the same reads
+Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier, the max-over-ranks reduction and the final
+junction-table gather); reads are sharded, every rank holds a full index replica; no data-path collective (weak scaling).
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=int, default=int(os.environ.get("STARAMD_BENCH_GENOME_MB", "100")))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("STARAMD_BENCH_READS", "400000")), help="read pairs per GPU per step")
+    ap.add_argument("--read-len", type=int, default=101)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("STARAMD_BENCH_CPU_SAMPLE", "200000")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/tmp/star_amd_bench"))
+    return ap.parse_args()
+
+
+def prepare_data(args, world):
+    """Synthetic genome + index (reference genomeGenerate: index building is out of scope)
+    + one FASTQ shard per rank.  Cached by parameter hash."""
+    from star_amd import synth
+    from oracle import refstar
+    import numpy as np
+    key = hashlib.md5(("v3|%d|%d|%d|%d" % (args.genome_mb, args.reads, args.read_len, world)).encode()).hexdigest()[:12]
+    d = os.path.join(args.workdir, key)
+    done = os.path.join(d, "DONE")
+    if os.path.isfile(done):
+        return d
+    if not refstar.have_ref():
+        raise RuntimeError("oracle/_ref/STAR is missing: it is needed to build the benchmark index (python -c 'import __graft_entry__ as g; g.build()')")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(20260922)
+    nchr = max(1, args.genome_mb // 10)
+    chr_len = [args.genome_mb * 1000000 // nchr] * nchr
+    names = ["chr%d" % (i + 1) for i in range(nchr)]
+    mb = args.genome_mb
+    seqs = synth.make_genome(rng, chr_len, repeat_families=((300, 300 * mb, 0.08), (6000, 15 * mb, 0.05), (60, 50 * mb, 0.0)), n_runs=2 * mb)
+    trs = synth.make_transcripts(rng, seqs, 200 * mb)
+    synth._write_fasta(os.path.join(d, "genome.fa"), names, seqs)
+    synth.write_gtf(os.path.join(d, "annot.gtf"), names, trs, rng.random(len(trs)) < 0.7)
+    m1, m2 = synth.make_reads(rng, seqs, trs, args.reads * world, args.read_len, True, frac_spliced=0.85, sub_rate=0.01, n_rate=0.001)
+    for r in range(world):
+        lo, hi = r * args.reads, (r + 1) * args.reads
+        synth.write_fastq(os.path.join(d, "reads_r%d" % r), m1[lo:hi], m2[lo:hi])
+    import math
+    nb = max(4, min(14, int(math.log2(args.genome_mb * 1e6) / 2 - 1)))
+    refstar.genome_generate(os.path.join(d, "genome.fa"), os.path.join(d, "idx"), gtf=os.path.join(d, "annot.gtf"),
+                            sjdb_overhang=args.read_len - 1, sa_index_nbases=nb, threads=os.cpu_count() or 8)
+    open(done, "w").write("ok\n")
+    return d
+
+
+def cpu_baseline(d, args, n_sample):
+    """Reference STAR, all host cores, on the first n_sample pairs of rank 0's shard (mapping time only:
+    wall(run) - wall(index-load-only run))."""
+    from oracle import refstar
+    cores = os.cpu_count() or 1
+    fq = [os.path.join(d, "reads_r0_1.fq"), os.path.join(d, "reads_r0_2.fq")]
+    out = os.path.join(d, "cpu_")
+
+    def run(nmap):
+        t = time.perf_counter()
+        refstar.align(os.path.join(d, "idx"), fq, out, threads=cores, extra=["--readMapNumber", str(nmap)])
+        return time.perf_counter() - t
+    run(1)                      # warm the page cache
+    t_load = run(1)
+    t_full = run(n_sample)
+    t_map = max(t_full - t_load, 1e-3)
+    return {"value": n_sample / t_map / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
+            "sample": "first %d pairs of the same workload, STAR 2.7.11b --runThreadN %d, mapping time = wall(full) - wall(index load only) = %.2f s"
+                      % (n_sample, cores, t_map)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    from star_amd import capi
+    if rank == 0:
+        d = prepare_data(args, world)
+    barrier()
+    if rank != 0:
+        d = prepare_data(args, world)     # cached by rank 0
+    fq = [os.path.join(d, "reads_r%d_1.fq" % rank), os.path.join(d, "reads_r%d_2.fq" % rank)]
+    outp = os.path.join(d, "gpu_r%d_" % rank)
+    run = capi.HostRun(["--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", outp])
+    t0 = time.perf_counter()
+    eng = capi.Engine(run.genome, run.params, device=local_rank, max_reads=args.reads)
+    t_upload = time.perf_counter() - t0
+    batch = run.next_batch(args.reads)
+    n = batch.nReads
+    bufs = capi.ResultBuffers(n, tr_cap=n * 64)
+    # first call uploads the batch (host -> HBM); afterwards it is resident
+    t0 = time.perf_counter()
+    eng.map_batch(batch, bufs)
+    t_first = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        eng.map_resident(bufs)
+    ms = {"seed": 0.0, "windows": 0.0, "stitch": 0.0, "device": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.map_resident(bufs)
+        ms["seed"] += bufs.res.msSeed; ms["windows"] += bufs.res.msWindows; ms["stitch"] += bufs.res.msStitch; ms["device"] += bufs.res.msTotalDevice
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # post-map on the host for this rank's shard (SAM + junction table), then the end-of-run junction/stats merge
+    run.emit(bufs.res)
+    sj_merge_ms = None
+    if dist is not None:
+        from star_amd import multi_gpu
+        t1 = time.perf_counter()
+        multi_gpu.merge_run_outputs(run, dist, dev, rank, world)
+        sj_merge_ms = (time.perf_counter() - t1) * 1e3
+    if rank == 0:
+        run.finish()
+    cnt = eng.counters()
+    names = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut"]
+    c = dict(zip(names, cnt))
+    eng.close(); run.close()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    steps = max(args.steps, 1)
+    for k in ms:
+        ms[k] /= steps
+    lread = 2 * args.read_len + 1
+    # algorithmic bytes per launch: bytes the algorithm must fetch, not what the cache hierarchy moved
+    bytes_seed = 8 * c["nSAi"] + 8 * c["nSAprobe"] + c["nGcmp"] + n * lread + 24 * c["nSeeds"]
+    bytes_win = 8 * c["nSAenum"] + 24 * c["nSeeds"] + 24 * c["nWA"]
+    bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + n * lread + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
+    kernels = {"k_seed_search": (ms["seed"], bytes_seed), "k_windows": (ms["windows"], bytes_win), "k_stitch": (ms["stitch"], bytes_stitch)}
+    dom = max(kernels, key=lambda k: kernels[k][0])
+    dms, dbytes = kernels[dom]
+    achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+    value = world * n * steps / elapsed / 1e6
+    out = {
+        "metric": "million reads aligned/sec (whole node), 2x101 bp PE, seed-search-and-stitch hot path",
+        "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/u64 integer", "data": "synthetic",
+        "config": {"workload": "synthetic %d Mb genome (18%% repeats, sjdb from GTF), %d pairs 2x%d bp per GPU per step (85%% spliced, 1%% subs); "
+                               "stand-in for BASELINE config 2 (GRCh38 index cannot be built inside the run)" % (args.genome_mb, n, args.read_len),
+                   "reads_per_gpu_per_step": n, "genome_mb": args.genome_mb, "parallelism": "reads sharded over %d GPU(s), full index replica each" % world},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms,
+                     "per_kernel_ms": {"k_seed_search": ms["seed"], "k_windows": ms["windows"], "k_stitch": ms["stitch"], "device_total": ms["device"]},
+                     "algorithmic_bytes_per_pair_whole_path": (bytes_seed + bytes_win + bytes_stitch) / n},
+        "counters_per_pair": {k: v / n for k, v in c.items()},
+        "index_upload_s": t_upload, "first_batch_incl_h2d_s": t_first, "sj_merge_ms": sj_merge_ms,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(d, args, min(args.cpu_sample, n))
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,64 @@ int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {
 }
 int sah_emit(void *h, const staramd_results *res) { return ((Runner *)h)->emit(res) ? 0 : -1; }
 int sah_finish(void *h) { return ((Runner *)h)->finish() ? 0 : -1; }
+// ---- end-of-run exchange between ranks (one process per GPU) -------------------------------------
+// The reference merges per-thread junction tables and Stats inside one process (outputSJ.cpp:39-83 k-way merge,
+// ReadAlignChunk_mapChunk.cpp:124-127 Stats::addStats).  With one process per GPU the same two reductions go over
+// RCCL: every rank exports its COLLAPSED table as fixed 32-byte records + 32 counters, rank 0 imports them and then
+// runs the unchanged collapse/filter/write.
+struct SjWire { uint64_t start; uint32_t gap; uint32_t countUnique, countMultiple; uint16_t overhangLeft, overhangRight; int8_t strand, motif, annot; uint8_t pad[5]; };
+static_assert(sizeof(SjWire) == 32, "junction wire record is 32 bytes");
+
+uint64_t sah_sj_export(void *h, void *buf, uint64_t capRecords) {
+    Runner *r = (Runner *)h;
+    r->sj.collapse();
+    uint64_t n = r->sj.data.size();
+    if (!buf) return n;
+    if (n > capRecords) return (uint64_t)-1;
+    SjWire *w = (SjWire *)buf;
+    for (uint64_t i = 0; i < n; i++) {
+        const staramd::Junction &j = r->sj.data[i];
+        SjWire x; memset(&x, 0, sizeof(x));
+        x.start = j.start; x.gap = j.gap; x.countUnique = j.countUnique; x.countMultiple = j.countMultiple;
+        x.overhangLeft = j.overhangLeft; x.overhangRight = j.overhangRight; x.strand = j.strand; x.motif = j.motif; x.annot = j.annot;
+        w[i] = x;
+    }
+    return n;
+}
+int sah_sj_import(void *h, const void *buf, uint64_t nRecords) {
+    Runner *r = (Runner *)h;
+    const SjWire *w = (const SjWire *)buf;
+    for (uint64_t i = 0; i < nRecords; i++) {
+        staramd::Junction j; j.start = w[i].start; j.gap = w[i].gap; j.strand = w[i].strand; j.motif = w[i].motif; j.annot = w[i].annot;
+        j.countUnique = w[i].countUnique; j.countMultiple = w[i].countMultiple; j.overhangLeft = w[i].overhangLeft; j.overhangRight = w[i].overhangRight;
+        r->sj.data.push_back(j);
+    }
+    return 0;
+}
+void sah_sj_clear(void *h) { ((Runner *)h)->sj.data.clear(); }
+#define SAH_NSTAT 32
+// counters as 32 x u64; mappedPortion (double) travels as its bit pattern and is summed by the importer
+int sah_stats_export(void *h, uint64_t *out) {
+    const staramd::Stats &s = ((Runner *)h)->stats;
+    memset(out, 0, SAH_NSTAT * 8);
+    uint64_t v[] = {s.readN, s.readBases, s.mappedMismatchesN, s.mappedInsN, s.mappedDelN, s.mappedInsL, s.mappedDelL, s.mappedBases, s.mappedReadsU,
+                    s.mappedReadsM, s.unmappedOther, s.unmappedShort, s.unmappedMismatch, s.unmappedMulti, s.unmappedAll, s.chimericAll, s.splicesNsjdb,
+                    s.splicesN[0], s.splicesN[1], s.splicesN[2], s.splicesN[3], s.splicesN[4], s.splicesN[5], s.splicesN[6]};
+    for (size_t i = 0; i < sizeof(v) / 8; i++) out[i] = v[i];
+    memcpy(&out[24], &s.mappedPortion, 8);
+    return SAH_NSTAT;
+}
+int sah_stats_import_add(void *h, const uint64_t *in) {
+    staramd::Stats &s = ((Runner *)h)->stats;
+    staramd::Stats a;
+    a.readN = in[0]; a.readBases = in[1]; a.mappedMismatchesN = in[2]; a.mappedInsN = in[3]; a.mappedDelN = in[4]; a.mappedInsL = in[5]; a.mappedDelL = in[6];
+    a.mappedBases = in[7]; a.mappedReadsU = in[8]; a.mappedReadsM = in[9]; a.unmappedOther = in[10]; a.unmappedShort = in[11]; a.unmappedMismatch = in[12];
+    a.unmappedMulti = in[13]; a.unmappedAll = in[14]; a.chimericAll = in[15]; a.splicesNsjdb = in[16];
+    for (int i = 0; i < 7; i++) a.splicesN[i] = in[17 + i];
+    memcpy(&a.mappedPortion, &in[24], 8);
+    s.add(a);
+    return 0;
+}
 const char *sah_error(void *h) { return ((Runner *)h)->error.c_str(); }
 void sah_destroy(void *h) { delete (Runner *)h; }
 

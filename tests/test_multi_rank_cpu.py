@@ -1,0 +1,74 @@
+"""N>1 path on CPU: two ranks (gloo, world_size 2) each map their own shard of the reads, then the end-of-run
+junction/Stats exchange of star_amd/multi_gpu.py runs and rank 0 writes SJ.out.tab + Log.final.out.
+The union must be byte-identical to ONE reference run over all reads (SJ.out.tab, Log.final.out counters, sorted SAM).
+The per-rank mapping uses the CPU oracle here (tests only: there is no GPU in this tier); on the GPU box the same
+exchange is driven by bench.py with the HIP engine."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import DATASETS, ROOT, capi, oracle_lib, prepare, refstar
+
+pytestmark = pytest.mark.skipif(not refstar.have_ref(), reason="oracle/_ref/STAR not built")
+
+
+def _split_fastq(paths, world, outdir):
+    shards = [[] for _ in range(world)]
+    for im, p in enumerate(paths):
+        lines = open(p).read().split("\n")
+        if lines and lines[-1] == "":
+            lines.pop()
+        n = len(lines) // 4
+        per = (n + world - 1) // world
+        for r in range(world):
+            q = os.path.join(outdir, "shard%d_%d.fq" % (r, im + 1))
+            with open(q, "w") as f:
+                chunk = lines[4 * r * per: 4 * min(n, (r + 1) * per)]
+                f.write("\n".join(chunk) + ("\n" if chunk else ""))
+            shards[r].append(q)
+    return shards
+
+
+def _worker(rank, world, port, idx, shards, extra, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from star_amd import multi_gpu
+    prefix = os.path.join(outdir, "r%d_" % rank)
+    run = capi.HostRun(["--genomeDir", idx, "--readFilesIn"] + shards[rank] + ["--outFileNamePrefix", prefix] + list(extra))
+    eng = oracle_lib.Oracle(run.genome, run.params)
+    while True:
+        b = run.next_batch(500)
+        if b is None:
+            break
+        bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
+        eng.map_batch(b, bufs)
+        run.emit(bufs.res)
+    multi_gpu.merge_run_outputs(run, dist, torch.device("cpu"), rank, world)
+    run.finish()            # rank 0 holds the union; other ranks write their partial files (ignored)
+    eng.close(); run.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["pe101", "se50"])
+def test_two_ranks_match_single_reference_run(name, tmp_path, built):
+    info = prepare(name, str(tmp_path))
+    world = 2
+    shards = _split_fastq(info["fastq"], world, str(tmp_path))
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, info["idx"], shards, info["extra"], str(tmp_path)), nprocs=world, join=True)
+    ref = info["ref_prefix"]
+    r0 = os.path.join(str(tmp_path), "r0_")
+    assert open(ref + "SJ.out.tab", "rb").read() == open(r0 + "SJ.out.tab", "rb").read()
+    assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(r0 + "Log.final.out")
+    union = []
+    for r in range(world):
+        union += refstar.sam_body_sorted(os.path.join(str(tmp_path), "r%d_Aligned.out.sam" % r))
+    assert sorted(union) == refstar.sam_body_sorted(ref + "Aligned.out.sam")
