@@ -14,7 +14,7 @@ HOST_LIB_SRC := $(filter-out star_amd/csrc/host/main.cpp,$(HOST_SRC))
 HIP_SRC  := $(wildcard star_amd/csrc/engine/*.hip)
 HIP_HDR  := $(wildcard star_amd/csrc/engine/*.h) include/star_amd.h
 
-all: host engine cli oracle
+all: host engine shadow cli oracle
 
 host: star_amd/lib/libstaramd_host.so
 engine: star_amd/lib/libstaramd.so
@@ -28,6 +28,13 @@ star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h inclu
 star_amd/lib/libstaramd.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p star_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared $(HIP_SRC) -o $@
+
+# shadow-validation build of the engine (tests only): every cooperative stitch / extend call is re-run through the
+# scalar restatement on the GPU and disagreements are counted (tests/test_gpu_parity.py::test_shadow_validation)
+shadow: star_amd/lib/libstaramd_shadow.so
+star_amd/lib/libstaramd_shadow.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p star_amd/lib
+	$(HIPCC) $(HIPFLAGS) -DSTARAMD_SHADOW -shared $(HIP_SRC) -o $@
 
 star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so
 	@mkdir -p star_amd/bin
@@ -43,4 +50,4 @@ ref:
 clean:
 	rm -rf star_amd/lib star_amd/bin oracle/_build
 
-.PHONY: all host engine cli oracle ref clean
+.PHONY: all host engine shadow cli oracle ref clean

@@ -164,6 +164,7 @@ typedef struct staramd_transcript {
     uint16_t nUnique, nAnchor;
     uint16_t intronMotifs[3];
     uint16_t pad0;
+    uint32_t pad1;            /* explicit tail padding: records are compared byte for byte, always 0 */
 } staramd_transcript;
 
 typedef struct staramd_exon {
@@ -174,7 +175,7 @@ typedef struct staramd_exon {
     int8_t   canonSJ;         /* junction AFTER this exon (canonSJ[iex]); undefined for the last exon */
     uint8_t  sjAnnot, sjStr;
     uint16_t shiftSJ[2];
-    uint32_t pad0;
+    uint32_t pad0, pad1;      /* explicit tail padding, always 0 */
 } staramd_exon;
 
 typedef struct staramd_results {

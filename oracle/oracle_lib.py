@@ -15,9 +15,9 @@ def build():
 
 
 class Oracle:
-    N_COUNTERS = 14
+    N_COUNTERS = 16
     COUNTER_NAMES = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitchReread", "nGstitchSpan", "nSeeds", "nWindows",
-                     "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut"]
+                     "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut", "maxNodesWin", "maxWAWin"]
 
     def __init__(self, genome_p, params_p):
         from star_amd import capi

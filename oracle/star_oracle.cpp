@@ -27,7 +27,7 @@ typedef int64_t i64;
 namespace {
 
 enum { C_nSAi, C_nSAprobe, C_nGcmp, C_nSAenum, C_nGstitchReread, C_nGstitchSpan, C_nSeeds, C_nWindows,
-       C_nWA, C_nNodes, C_nLeaves, C_nStitchCalls, C_nExtendCalls, C_nTrOut, C_N };
+       C_nWA, C_nNodes, C_nLeaves, C_nStitchCalls, C_nExtendCalls, C_nTrOut, C_maxNodesWin, C_maxWAWin, C_N };
 
 // PC row: ReadAlign_storeAligns.cpp:138-144, IncludeDefine.h:181-189
 struct Seed { u64 rStart, L, dir, nrep, saStart, saEnd, iFrag; };
@@ -811,7 +811,9 @@ struct Oracle {
             std::vector<Tr> wTr(P.alignTranscriptsPerWindowNmax + 1, trA);
             nWinTrCur = 0;
             gSpanMin = ~0ull; gSpanMax = 0;
+            u64 nodes0 = cnt[C_nNodes];
             stitchWindowAligns(0, WA[iW].size(), 0, 0, 0, trA, WA[iW], Read1[trA.roStr == 0 ? 0 : 2], wTr);
+            if (cnt[C_nNodes] - nodes0 > cnt[C_maxNodesWin]) { cnt[C_maxNodesWin] = cnt[C_nNodes] - nodes0; cnt[C_maxWAWin] = WA[iW].size(); }   // profile of the heaviest window (work-distribution studies)
             if (gSpanMax >= gSpanMin) cnt[C_nGstitchSpan] += gSpanMax - gSpanMin + 1;
             if (nWinTrCur == 0) continue;
             if (wTr[0].maxScore > bestScore || (wTr[0].maxScore == bestScore && wTr[0].gLength < bestGlen)) {

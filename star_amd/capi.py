@@ -9,7 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-ENGINE_PATH = os.path.join(LIB_DIR, "libstaramd.so")
+# STARAMD_ENGINE_LIB=shadow selects the shadow-validation build (tests only; see star_amd/csrc/engine/stitch_scalar.h)
+ENGINE_PATH = os.path.join(LIB_DIR, "libstaramd_shadow.so" if os.environ.get("STARAMD_ENGINE_LIB") == "shadow" else "libstaramd.so")
 HOST_PATH = os.path.join(LIB_DIR, "libstaramd_host.so")
 
 u8p = C.POINTER(C.c_uint8)
@@ -79,12 +80,12 @@ class Transcript(C.Structure):
                 ("Chr", C.c_uint32), ("gStart", C.c_uint64), ("gLength", C.c_uint64), ("maxScore", C.c_int32),
                 ("nMatch", C.c_uint32), ("nMM", C.c_uint32), ("mappedLength", C.c_uint32),
                 ("nGap", C.c_uint32), ("lGap", C.c_uint32), ("nDel", C.c_uint32), ("lDel", C.c_uint32), ("nIns", C.c_uint32), ("lIns", C.c_uint32),
-                ("nUnique", C.c_uint16), ("nAnchor", C.c_uint16), ("intronMotifs", C.c_uint16 * 3), ("pad0", C.c_uint16)]
+                ("nUnique", C.c_uint16), ("nAnchor", C.c_uint16), ("intronMotifs", C.c_uint16 * 3), ("pad0", C.c_uint16), ("pad1", C.c_uint32)]
 
 
 class Exon(C.Structure):
     _fields_ = [("G", C.c_uint64), ("R", C.c_uint16), ("L", C.c_uint16), ("sjA", C.c_int32), ("iFrag", C.c_uint8),
-                ("canonSJ", C.c_int8), ("sjAnnot", C.c_uint8), ("sjStr", C.c_uint8), ("shiftSJ", C.c_uint16 * 2), ("pad0", C.c_uint32)]
+                ("canonSJ", C.c_int8), ("sjAnnot", C.c_uint8), ("sjStr", C.c_uint8), ("shiftSJ", C.c_uint16 * 2), ("pad0", C.c_uint32), ("pad1", C.c_uint32)]
 
 
 class Results(C.Structure):
@@ -225,7 +226,7 @@ class Engine:
         if rc != 0:
             raise RuntimeError("staramd_map_resident failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
 
-    def counters(self, n=16):
+    def counters(self, n=24):
         out = (C.c_uint64 * n)()
         k = self.L.staramd_get_counters(self.ctx, out, n)
         return list(out)[:k]

@@ -2,11 +2,13 @@
 //
 // Data layout in HBM:
 //   G     genome, 1 byte/base exactly as in genomeDir (codes 0..5), with GPAD bytes of code 5 on both
-//         sides so that extension / junction-repeat scans can run off either end without branches
+//         sides so that extension / junction-repeat scans can run off either end without branches;
+//         the device reads it in aligned 8-byte words (GCache) -- 8 bases per gather
 //   SA    packed suffix array, (GstrandBit+1) bits per entry, read as two aligned 64-bit words
 //   SAi   packed L-mer prefix table, (GstrandBit+3) bits per entry
-// Per batch: read bases (numeric, combined PE read), per-read seed tables (PC), window tables
-// (WC/WA) and window transcripts are handed from kernel to kernel through bump-allocated pools.
+// Per batch: read bases (numeric, combined PE read; plus a 4-bit packed copy for LDS staging),
+// per-read seed tables (PC), window tables (WC/WA) and window transcripts are handed from kernel to
+// kernel through bump-allocated pools.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,12 +22,13 @@ typedef uint16_t u16;
 typedef uint8_t u8;
 typedef int8_t i8;
 
-#define GPAD 1024                 // bytes of code 5 before and after the genome on the device
+#define GPAD 4096                 // bytes of code 5 before and after the genome on the device
 #define NBREAK_MAX 96             // break points of the genomic-length score term
+#define WA_MAX 64                 // device limit for --seedPerWindowNmax (one lane per window seed in k_windows)
 
 // read-only index + parameters, passed by value to every kernel
 struct DevIndex {
-    const u8 *G;                  // points at genome base 0 (GPAD bytes of 5 precede it)
+    const u8 *G;                  // points at genome base 0 (GPAD bytes of 5 precede it); 8-byte aligned
     const u64 *SA, *SAi;          // packed arrays as 64-bit words
     const u32 *chrBin;
     const u64 *chrStart, *chrLength;
@@ -51,44 +54,50 @@ struct DWin { u32 read; u32 chr; u32 waOffset; u16 nWA; u8 str; u8 pad; };
 struct DRead {
     u32 status; u32 seedOffset; u32 nSeeds; u32 unmappedLength;
     u32 winOffset; u32 nWin;            // windows with seeds (window pool)
-    u32 wtOffset; u32 nWt;              // window-transcript blocks (one per window that recorded transcripts)
+    u32 wtOffset; u32 nWt;              // nWt: windows that recorded transcripts (wtOffset unused)
     i32 maxScoreMate[2];
     i32 bestW;                          // ordinal of trBest's window among recorded windows, -1
     u32 nTr, nEx;                       // totals for the gather step
 };
 
-// working transcript on the device: exon rows are already in the output format
-struct DTr {
-    staramd_exon ex[STARAMD_MAX_N_EXONS];
-    u32 nExons; i32 maxScore;
-    u32 nMatch, nMM, nGap, lGap, nDel, lDel, nIns, lIns, nUnique, nAnchor;
-    u32 rStart, rLength, mappedLength, roStart;
-    u64 gStart, gLength;
-    i32 iFrag; u16 intronMotifs[3]; u8 sjMotifStrand; u8 pad;
-};
-#define DTR_HDR_BYTES (sizeof(DTr) - sizeof(staramd_exon) * STARAMD_MAX_N_EXONS)
-
-// one frame of the explicit depth-first walk of k_stitch (pushed only when a seed is included)
-struct Frame { DTr tr; i32 Score; u32 tR2; u64 tG2; u32 iA; u32 state; };
-// per-lane window scratch of k_windows
-struct WScr { u32 coreS, coreE, extS, extE; u32 chr; u32 waBlock; u32 lrec; u16 nWA; u8 str; u8 alive; };
-
-// block of transcripts recorded for one window, in the window-transcript pool
-struct DWinTr { u32 read; u32 trOffset; u32 nTr; u32 exOffset; u32 nEx; u32 chr; u8 str; u8 pad[3]; };
+// result of stitching one window (slot = index of the window in winPool)
+//   mm[f]   best score of a single-mate transcript of mate f among the leaves of this window (order independent)
+//   sens[f] smallest (Score + outFilterMultimapScoreRange) among the leaves of mate f whose recording was decided by the
+//           maxScoreMate clause alone (stitchWindowAligns.cpp:245-247); INT32_MAX if none.  The window was stitched with
+//           the incoming maxScoreMate of minIn[]; the result is exact iff sens[f] >= the true incoming value
+struct DWinOut { u32 trOffset, nTr, exOffset, nEx; i32 mm[2]; i32 sens[2]; i32 minIn[2]; i32 headScore; u32 done; u64 headGlen; };
 
 enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nWindows, DC_nWA, DC_nNodes, DC_nLeaves,
-       DC_nStitchCalls, DC_nExtendCalls, DC_nTrOut, DC_N };
+       DC_nStitchCalls, DC_nExtendCalls, DC_nTrOut, DC_nOvfWin, DC_nOvfStitch, DC_nRedoWin,
+       DC_shadowBad, DC_shadowN, DC_shadowExtBad, DC_shadowExtN,   // shadow-validation build only (see stitch_scalar.h)
+       DC_N };
+
+// cursors[] slots
+enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS = 6,
+       CUR_TICKET_SEED = 8, CUR_TICKET_WIN = 9, CUR_OVF_WIN = 11, CUR_TICKET_WIN2 = 13,
+       // stitch stage: work lists of window ids and their tickets
+       CUR_ST_TICKET0 = 16, CUR_ST_OVF0 = 17, CUR_ST_TICKET0B = 18,      // pass 0 (all windows, incoming maxScoreMate 0): fast / big
+       CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20, CUR_ST_OVF1 = 21, CUR_ST_TICKET1B = 22,   // pass 1 (windows whose result depends on the true incoming value)
+       CUR_N = 32 };
+// CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
+enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };
 
 // pools and cursors of one batch
 struct DevBatch {
     u32 nReads;
     const u8 *bases; const u64 *readOffset; const u16 *mate1Length; const u16 *mmMaxTotal;
+    const u32 *packed; u32 packWords;   // 4-bit packed reads, packWords 32-bit words per read (k_pack_reads)
     DRead *reads;
     DSeed *seedPool; u32 seedCap;
     DWin *winPool; u32 winCap; DWA *waPool; u32 waCap;
-    DWinTr *wtPool; u32 wtCap;
+    DWinOut *wout;                      // winCap slots
     staramd_transcript *trPool; u32 trCap; staramd_exon *exPool; u32 exCap;
-    u32 *cursors;      // [0] seed pool, [1] win pool, [2] wa pool, [3] wt pool, [4] tr pool, [5] ex pool, [6] overflow flags, [8..10] work queues
+    u32 *order;        // window ids in stitch order: sorted by estimated work, then dealt round-robin to groups of 64 tickets
+    u32 *costHist;     // 32 cost classes + 32 offsets
+    u8 *winClass;      // cost class of every window (winCap)
+    u32 *ovfWin;       // reads deferred to the big-work-space pass of k_windows
+    u32 *ovfSt0, *ovfSt1, *redoList;   // stitch work lists (window ids)
+    u32 *cursors;      // CUR_*
     u64 *counters;     // DC_N
 };
 
@@ -102,3 +111,31 @@ __device__ __forceinline__ u64 packedGet(const u64 *a, u64 i, u32 bits, u64 mask
 }
 
 __device__ __forceinline__ u8 compBase(u8 c) { return c < 4 ? (u8)(3 - c) : c; }   // complementSeqNumbers, SequenceFuns.cpp:4-14
+
+// ---- genome access in aligned 8-byte words: one gather serves 8 consecutive bases of a scan ----
+struct GCache { i64 base; u64 word; };
+__device__ __forceinline__ void gcInit(GCache &c) { c.base = (i64)0x7fffffffffffff00ll; c.word = 0; }
+__device__ __forceinline__ u8 gcGet(const u8 *G, GCache &c, i64 pos) {
+    i64 b = pos & ~7ll;
+    if (b != c.base) { c.word = *(const u64 *)(G + b); c.base = b; }
+    return (u8)(c.word >> ((u32)(pos & 7) * 8));
+}
+
+// ---- wave helpers (wave = 64 lanes on gfx950) ----
+__device__ __forceinline__ u32 laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 bcast32(u32 v, u32 srcLane) { return (u32)__shfl((int)v, (int)srcLane, 64); }
+__device__ __forceinline__ u64 bcast64(u64 v, u32 srcLane) {
+    u32 lo = bcast32((u32)v, srcLane), hi = bcast32((u32)(v >> 32), srcLane);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u32 first32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ i32 firstI(i32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 first64(u64 v) { return ((u64)first32((u32)(v >> 32)) << 32) | first32((u32)v); }
+// number of set bits of a 64-lane ballot mask in the lanes strictly below / up to and including this lane
+__device__ __forceinline__ u32 cntBelow(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+__device__ __forceinline__ u32 cntUpTo(u64 m, u32 lane) { return cntBelow(m) + (u32)((m >> lane) & 1ull); }
+__device__ __forceinline__ u32 waveMaxU32(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) { u32 w = (u32)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ u32 firstLane(u64 m) { return (u32)__ffsll((long long)m) - 1u; }   // m != 0

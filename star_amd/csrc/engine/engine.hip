@@ -9,12 +9,29 @@
 #include <string>
 #include <vector>
 
-extern "C" __global__ void k_seed_search(DevIndex X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
-extern "C" __global__ void k_windows(DevIndex X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks);
-extern "C" __global__ void k_stitch(DevIndex X, DevBatch B, u8 *scratch, u32 capDepth, u32 capTr);
+extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
+extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
+extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big);
+extern "C" __global__ void k_order_hist(DevBatch B);
+extern "C" __global__ void k_order_offsets(DevBatch B);
+extern "C" __global__ void k_order_scatter(DevBatch B);
+extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *scratch, u32 capDepth, u32 capRank, u32 arenaBytes, u32 ldsWords, u32 mode, u32 big);
+extern "C" __global__ void k_stitch_verify(const DevIndex *X, DevBatch B);
+extern "C" __global__ void k_stitch_finish(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_scan_offsets(DevBatch B, u32 *trBase, u32 *exBase, u32 *totals);
 extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *exBase, staramd_read_result *outReads,
                                     staramd_transcript *outTr, u32 outTrCap, staramd_exon *outEx, u32 outExCap);
+
+// per-lane / per-wave work-space sizes (same formulas as the kernels)
+static inline u32 stitchLaneBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
+    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + arenaBytes;
+    return (b + 127u) & ~127u;
+}
+static inline u64 winWaveBytesH(u32 capW, u32 capBlocks, u32 big) {
+    u64 b = (u64)capBlocks * WA_MAX * sizeof(DWA);
+    if (big) b += (u64)capW * 8 * sizeof(u32);
+    return (b + 255) & ~255ull;
+}
 
 static thread_local std::string g_err;
 extern "C" const char *staramd_last_error(void) { return g_err.c_str(); }
@@ -25,20 +42,27 @@ extern "C" const char *staramd_last_error(void) { return g_err.c_str(); }
 struct staramd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevIndex X;
+    DevIndex X;                 // host copy
+    DevIndex *dX = nullptr;     // device copy read by the kernels through scalar loads
     std::vector<void *> indexAllocs, workAllocs;
     u32 maxReads = 0; u64 maxBases = 0;
     DevBatch B;
     u8 *dBases = nullptr; u64 *dReadOffset = nullptr; u16 *dMate1 = nullptr, *dMM = nullptr;
-    u32 lanes = 0;
-    DSeed *scrSeed = nullptr; u32 seedPerLane = 0;
-    u8 *scrWin = nullptr; u32 capW = 0, capBlocks = 0;
-    u8 *scrStitch = nullptr; u32 capDepth = 0, capTr = 0;
+    u32 *dPacked = nullptr; u32 packWordsCap = 0;
+    int nCU = 256;
+    // seed kernel: one lane per read
+    u32 seedLanes = 0; DSeed *scrSeed = nullptr; u32 seedPerLane = 0;
+    // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
+    u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
+    // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
+    u32 stBlocks = 0, stBlocksBig = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
+    u32 capDepth = 0, capRank = 0, arenaFast = 0, arenaBig = 0, ldsWordsCap = 0;
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[6];
     u64 counters[DC_N];
-    u32 residentReads = 0;
+    u32 residentReads = 0; u32 residentMaxLread = 0;
+    u32 *hostScratch = nullptr;         // pinned: totals + cursors read-back
 };
 
 template <class T> static int devAlloc(std::vector<void *> &reg, T **p, u64 n) {
@@ -83,7 +107,9 @@ static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_pa
     memset(&X, 0, sizeof(X));
     if (g->gSAsparseD < 1 || g->gSAsparseD > 8) { g_err = "genomeSAsparseD must be in 1..8"; return STARAMD_ERR_ARG; }
     if (g->gSAindexNbases > 16 || g->GstrandBit + 3 > 63) { g_err = "unsupported index geometry"; return STARAMD_ERR_ARG; }
-    if (p->seedPerWindowNmax > 4096 || p->alignTranscriptsPerWindowNmax > 60000) { g_err = "seedPerWindowNmax/alignTranscriptsPerWindowNmax too large for the device work space"; return STARAMD_ERR_ARG; }
+    if (p->seedPerWindowNmax > WA_MAX || p->seedPerWindowNmax < 1) { g_err = "seedPerWindowNmax must be in 1..64 on the device (one lane per window seed)"; return STARAMD_ERR_ARG; }
+    if (p->alignTranscriptsPerWindowNmax > 2000 || p->alignTranscriptsPerWindowNmax < 1) { g_err = "alignTranscriptsPerWindowNmax must be in 1..2000 on the device"; return STARAMD_ERR_ARG; }
+    if (p->winAnchorMultimapNmax > 64) { /* anchors are enumerated in chunks of 64 loci: any value works */ }
     // genome with padding
     {
         u8 *dG = nullptr;
@@ -122,34 +148,51 @@ static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_pa
     X.sjdbOverhang = g->sjdbOverhang; X.sjdbLength = g->sjdbLength ? g->sjdbLength : 1; X.sjdbN = g->sjdbN; X.nChrReal = g->nChrReal;
     X.P = *p;
     buildGlBreaks(X, p->scoreGenomicLengthLog2scale);
+    { int rc2 = devAlloc(c->indexAllocs, &c->dX, (u64)1); if (rc2) return rc2; }
+    HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
     return 0;
 }
 
 static u32 envU32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)strtoul(s, nullptr, 10) : dflt; }
 
+template <class T> static int devRealloc(std::vector<void *> &reg, T **p, u64 n) {
+    for (size_t i = 0; i < reg.size(); i++) if (reg[i] == (void *)*p) { (void)hipFree(reg[i]); reg.erase(reg.begin() + i); break; }
+    *p = nullptr;
+    return devAlloc(reg, p, n);
+}
+
 static int allocWork(staramd_ctx *c) {
     std::vector<void *> &R = c->workAllocs;
     u32 N = c->maxReads; int rc;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->nCU = prop.multiProcessorCount;
     if ((rc = devAlloc(R, &c->dBases, c->maxBases + 64))) return rc;
     if ((rc = devAlloc(R, &c->dReadOffset, (u64)N + 1))) return rc;
     if ((rc = devAlloc(R, &c->dMate1, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dMM, (u64)N))) return rc;
+    c->packWordsCap = 0;
     DevBatch &B = c->B; memset(&B, 0, sizeof(B));
     B.bases = c->dBases; B.readOffset = c->dReadOffset; B.mate1Length = c->dMate1; B.mmMaxTotal = c->dMM;
     if ((rc = devAlloc(R, &B.reads, (u64)N))) return rc;
-    B.seedCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_SEEDS_PER_READ", 64) + 4096, 0xFFFFFFF0ull);
-    B.winCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WINDOWS_PER_READ", 40) + 4096, 0xFFFFFFF0ull);
-    B.waCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WA_PER_READ", 256) + 4096, 0xFFFFFFF0ull);
-    B.wtCap = B.winCap;
-    B.trCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_TR_PER_READ", 64) + 4096, 0xFFFFFFF0ull);
+    B.seedCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_SEEDS_PER_READ", 32) + 65536, 0xFFFFFFF0ull);
+    B.winCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WINDOWS_PER_READ", 24) + 65536, 0xFFFFFFF0ull);
+    B.waCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WA_PER_READ", 96) + 65536, 0xFFFFFFF0ull);
+    B.trCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_TR_PER_READ", 48) + 65536, 0xFFFFFFF0ull);
     B.exCap = (u32)std::min<u64>((u64)B.trCap * 3, 0xFFFFFFF0ull);
     if ((rc = devAlloc(R, &B.seedPool, (u64)B.seedCap))) return rc;
     if ((rc = devAlloc(R, &B.winPool, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.waPool, (u64)B.waCap))) return rc;
-    if ((rc = devAlloc(R, &B.wtPool, (u64)B.wtCap))) return rc;
+    if ((rc = devAlloc(R, &B.wout, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.winClass, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.order, (u64)B.winCap + 64))) return rc;
+    if ((rc = devAlloc(R, &B.ovfSt0, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.ovfSt1, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.trPool, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
-    if ((rc = devAlloc(R, &B.cursors, (u64)16))) return rc;
+    if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
+    if ((rc = devAlloc(R, &B.ovfWin, (u64)N))) return rc;
+    if ((rc = devAlloc(R, &B.cursors, (u64)CUR_N))) return rc;
     if ((rc = devAlloc(R, &B.counters, (u64)DC_N))) return rc;
     if ((rc = devAlloc(R, &c->dTrBase, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dExBase, (u64)N))) return rc;
@@ -157,21 +200,37 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->dOutReads, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dOutTr, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &c->dOutEx, (u64)B.exCap))) return rc;
-    // per-lane scratch sized by the reference's own per-read limits
+    if (hipHostMalloc((void **)&c->hostScratch, 64 * sizeof(u32)) != hipSuccess) { g_err = "hipHostMalloc failed"; return STARAMD_ERR_DEVICE; }
     const staramd_params &P = c->X.P;
-    u32 lanes = envU32("STARAMD_LANES", 65536);
+    // ---- seed kernel: one lane per read, PC table per lane sized by the reference's seedPerReadNmax
+    u32 lanes = envU32("STARAMD_SEED_LANES", 131072);
     lanes = std::max<u32>(256, std::min<u32>(lanes, ((N + 255) / 256) * 256));
-    lanes = (lanes / 256) * 256;
-    c->lanes = lanes;
+    c->seedLanes = (lanes / 256) * 256;
     c->seedPerLane = P.seedPerReadNmax + 1;
-    if ((rc = devAlloc(R, &c->scrSeed, (u64)lanes * c->seedPerLane))) return rc;
-    c->capW = envU32("STARAMD_CAP_WINDOWS", 512); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 96);
-    u64 perLaneW = (u64)c->capW * sizeof(WScr) + (u64)c->capBlocks * P.seedPerWindowNmax * sizeof(DWA);
-    if ((rc = devAlloc(R, &c->scrWin, (u64)lanes * perLaneW))) return rc;
-    c->capDepth = P.seedPerWindowNmax + 1; c->capTr = P.alignTranscriptsPerWindowNmax + 1;
-    u64 perLaneS = (u64)c->capDepth * sizeof(Frame) + (u64)c->capTr * sizeof(DTr) + (u64)c->capTr * sizeof(u16);
-    perLaneS = (perLaneS + 15) & ~15ull;
-    if ((rc = devAlloc(R, &c->scrStitch, (u64)lanes * perLaneS))) return rc;
+    if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
+    // ---- window kernel
+    c->capW = envU32("STARAMD_CAP_WINDOWS", 192); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
+    int winPerCU = 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * c->capW * 8 * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
+    c->winBlocks = (u32)c->nCU * envU32("STARAMD_WIN_BLOCKS_PER_CU", (u32)winPerCU);
+    c->winBlocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (N + 3) / 4));
+    if ((rc = devAlloc(R, &c->scrWin, (u64)c->winBlocks * 4 * winWaveBytesH(c->capW, c->capBlocks, 0)))) return rc;
+    c->capWBig = P.alignWindowsPerReadNmax; c->capBlocksBig = P.alignWindowsPerReadNmax;
+    c->winBlocksBig = envU32("STARAMD_WIN_BLOCKS_BIG", 64);
+    if ((rc = devAlloc(R, &c->scrWinBig, (u64)c->winBlocksBig * 4 * winWaveBytesH(c->capWBig, c->capBlocksBig, 1)))) return rc;
+    // ---- stitch kernel
+    c->capDepth = P.seedPerWindowNmax + 1; c->capRank = P.alignTranscriptsPerWindowNmax + 1;
+    c->arenaFast = envU32("STARAMD_STITCH_ARENA", 6144) & ~31u;
+    c->arenaBig = 2u * (P.alignTranscriptsPerWindowNmax + 2) * (96u + 32u * STARAMD_MAX_N_EXONS);      // twice the largest live set
+    if (c->arenaBig > 2000000u) { g_err = "alignTranscriptsPerWindowNmax too large for the device record arena"; return STARAMD_ERR_ARG; }
+    // fast pass: one worker per wavefront with its walk state in LDS; blocks of 4 wavefronts
+    int stPerCU = 2;
+    size_t ldsFast = 4 * (size_t)(stitchLaneBytesH(c->capDepth, c->capRank, c->arenaFast) + 27 * 4 + 16);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stPerCU, k_stitch_win, 256, ldsFast) != hipSuccess || stPerCU < 1) stPerCU = 2;
+    c->stBlocks = (u32)c->nCU * envU32("STARAMD_STITCH_BLOCKS_PER_CU", (u32)stPerCU);
+    if ((rc = devAlloc(R, &c->scrStitch, (u64)256))) return rc;
+    c->stBlocksBig = envU32("STARAMD_STITCH_BLOCKS_BIG", 2048);          // one active lane per 64-thread block
+    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)c->stBlocksBig * stitchLaneBytesH(c->capDepth, c->capRank, c->arenaBig)))) return rc;
     return 0;
 }
 
@@ -206,43 +265,107 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
     (void)hipDeviceSynchronize();
     freeAll(c->indexAllocs); freeAll(c->workAllocs);
     for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->hostScratch) (void)hipHostFree(c->hostScratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
-static int runDevice(staramd_ctx *c, staramd_results *r) {
+// grow a pool after an overflow of the bump allocator (the batch is then simply run again: inputs are resident)
+static int growPools(staramd_ctx *c, u32 flags) {
+    DevBatch &B = c->B; std::vector<void *> &R = c->workAllocs; int rc;
+    auto dbl = [](u32 v) { return (u32)std::min<u64>((u64)v * 2, 0xFFFFFFF0ull); };
+    if (flags & OVF_SEEDPOOL) { B.seedCap = dbl(B.seedCap); if ((rc = devRealloc(R, &B.seedPool, (u64)B.seedCap))) return rc; }
+    if (flags & OVF_WINPOOL) {
+        B.winCap = dbl(B.winCap); B.waCap = dbl(B.waCap);
+        if ((rc = devRealloc(R, &B.winPool, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.waPool, (u64)B.waCap))) return rc;
+        if ((rc = devRealloc(R, &B.wout, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.winClass, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.order, (u64)B.winCap + 64))) return rc;
+        if ((rc = devRealloc(R, &B.ovfSt0, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.ovfSt1, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
+    }
+    if (flags & OVF_TRPOOL) {
+        B.trCap = dbl(B.trCap); B.exCap = dbl(B.exCap);
+        if ((rc = devRealloc(R, &B.trPool, (u64)B.trCap))) return rc;
+        if ((rc = devRealloc(R, &B.exPool, (u64)B.exCap))) return rc;
+        if ((rc = devRealloc(R, &c->dOutTr, (u64)B.trCap))) return rc;
+        if ((rc = devRealloc(R, &c->dOutEx, (u64)B.exCap))) return rc;
+    }
+    return 0;
+}
+
+static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     DevBatch &B = c->B; hipStream_t s = c->stream;
     u32 n = B.nReads;
-    HIPCHK(hipMemsetAsync(B.cursors, 0, 16 * sizeof(u32), s));
+    HIPCHK(hipMemsetAsync(B.cursors, 0, CUR_N * sizeof(u32), s));
     HIPCHK(hipMemsetAsync(B.counters, 0, DC_N * sizeof(u64), s));
-    u32 lanes = std::min<u32>(c->lanes, ((n + 255) / 256) * 256);
-    dim3 grid(lanes / 256), block(256);
+    HIPCHK(hipMemsetAsync(B.costHist, 0, 64 * sizeof(u32), s));
+    dim3 block(256);
+    u32 ldsWords = ((c->residentMaxLread + 7) / 8) | 1u;              // odd stride: conflict-free LDS staging
     HIPCHK(hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(k_seed_search, grid, block, 0, s, c->X, B, c->scrSeed, c->seedPerLane);
+    {
+        u32 lanes = std::min<u32>(c->seedLanes, ((n + 255) / 256) * 256);
+        hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane);
+    }
     HIPCHK(hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(k_windows, grid, block, 0, s, c->X, B, c->scrWin, c->capW, c->capBlocks);
+    {
+        u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * c->capW * 8 * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u);
+        hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u);
+        hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
+        hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1), 0, s, B);
+        hipLaunchKernelGGL(k_order_scatter, dim3(1024), block, 0, s, B);
+    }
     HIPCHK(hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(k_stitch, grid, block, 0, s, c->X, B, c->scrStitch, c->capDepth, c->capTr);
+    {
+        size_t readBytes = (ldsWords * 4u + 15u) & ~15u;
+        size_t ldsFast = 4 * (readBytes + stitchLaneBytesH(c->capDepth, c->capRank, c->arenaFast)), ldsBig = readBytes;
+        for (u32 mode = 0; mode < 2; mode++) {
+            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitch, c->capDepth, c->capRank, c->arenaFast, ldsWords, mode, 0u);
+            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksBig), dim3(64), ldsBig, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaBig, ldsWords, mode, 1u);
+            if (mode == 0) hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);
+        }
+        hipLaunchKernelGGL(k_stitch_finish, dim3((n + 255) / 256), block, 0, s, c->dX, B);
+    }
     HIPCHK(hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, s, B, c->dTrBase, c->dExBase, c->dTotals);
     hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), block, 0, s, B, c->dTrBase, c->dExBase, c->dOutReads, c->dOutTr, B.trCap, c->dOutEx, B.exCap);
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipGetLastError());
-    u32 totals[4] = {0, 0, 0, 0}; u32 cursors[16];
-    HIPCHK(hipMemcpyAsync(totals, c->dTotals, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(cursors, B.cursors, 16 * sizeof(u32), hipMemcpyDeviceToHost, s));
+    u32 *hs = c->hostScratch;
+    HIPCHK(hipMemcpyAsync(hs, c->dTotals, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));
     HIPCHK(hipEventElapsedTime(&r->msTotalDevice, c->ev[0], c->ev[4]));
-    if (cursors[6] != 0) {
-        char buf[256];
-        snprintf(buf, sizeof(buf), "device work-space overflow (flags 0x%x): seeds %u/%u windows %u/%u WA %u/%u tr %u/%u ex %u/%u; raise STARAMD_*_PER_READ / STARAMD_CAP_* or lower the batch size",
-                 cursors[6], cursors[0], B.seedCap, cursors[1], B.winCap, cursors[2], B.waCap, cursors[4], B.trCap, cursors[5], B.exCap);
-        g_err = buf; return STARAMD_ERR_SCRATCH_OVERFLOW;
+    *flagsOut = hs[8 + CUR_FLAGS];
+    return STARAMD_OK;
+}
+
+static int runDevice(staramd_ctx *c, staramd_results *r) {
+    DevBatch &B = c->B; hipStream_t s = c->stream;
+    u32 n = B.nReads;
+    u32 flags = 0;
+    for (int attempt = 0;; attempt++) {
+        int rc = launchAll(c, r, &flags);
+        if (rc) return rc;
+        if (flags == 0) break;
+        const u32 *cur = c->hostScratch + 8;
+        if ((flags & OVF_HARD) || attempt >= 6) {
+            char buf[320];
+            snprintf(buf, sizeof(buf), "device work-space overflow (flags 0x%x): seeds %u/%u windows %u/%u WA %u/%u tr %u/%u ex %u/%u",
+                     flags, cur[CUR_SEED], B.seedCap, cur[CUR_WIN], B.winCap, cur[CUR_WA], B.waCap, cur[CUR_TR], B.trCap, cur[CUR_EX], B.exCap);
+            g_err = buf; return STARAMD_ERR_SCRATCH_OVERFLOW;
+        }
+        rc = growPools(c, flags);
+        if (rc) return rc;
     }
+    const u32 *totals = c->hostScratch;
     r->trCount = totals[0]; r->exCount = totals[1];
     if (totals[0] > r->trCapacity || totals[1] > r->exCapacity) { g_err = "result arrays too small: need " + std::to_string(totals[0]) + " transcripts, " + std::to_string(totals[1]) + " exons"; return STARAMD_ERR_RESULT_OVERFLOW; }
     HIPCHK(hipMemcpyAsync(r->reads, c->dOutReads, (u64)n * sizeof(staramd_read_result), hipMemcpyDeviceToHost, s));
@@ -258,11 +381,21 @@ extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd
     if (b->nReads > c->maxReads || b->readOffset[b->nReads] > c->maxBases) { g_err = "batch larger than the context's work space"; return STARAMD_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream; u32 n = b->nReads;
+    u32 maxL = 0;
+    for (u32 i = 0; i < n; i++) { u64 L = b->readOffset[i + 1] - b->readOffset[i]; if (L > maxL) maxL = (u32)L; }
+    if (maxL > 2 * STARAMD_READ_LEN_MAX + 1) { g_err = "read longer than DEF_readSeqLengthMax"; return STARAMD_ERR_ARG; }
+    u32 packWords = (maxL + 7) / 8;
+    if ((u64)packWords * n > c->packWordsCap) {
+        int rc = devRealloc(c->workAllocs, &c->dPacked, (u64)packWords * c->maxReads); if (rc) return rc;
+        c->packWordsCap = (u32)std::min<u64>((u64)packWords * c->maxReads, 0xFFFFFFFFull);
+    }
     HIPCHK(hipMemcpyAsync(c->dBases, b->bases, b->readOffset[n], hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->dReadOffset, b->readOffset, (u64)(n + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->dMate1, b->mate1Length, (u64)n * 2, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->dMM, b->mmMaxTotal, (u64)n * 2, hipMemcpyHostToDevice, s));
-    c->B.nReads = n; c->residentReads = n;
+    c->B.nReads = n; c->residentReads = n; c->residentMaxLread = maxL;
+    c->B.packed = c->dPacked; c->B.packWords = packWords;
+    hipLaunchKernelGGL(k_pack_reads, dim3(n), dim3(64), 0, s, c->B, c->dPacked, packWords);
     return runDevice(c, r);
 }
 

@@ -36,17 +36,19 @@ extern "C" __global__ void __launch_bounds__(256) k_gather(DevBatch B, const u32
     rr.maxScoreMate[0] = rd.maxScoreMate[0]; rr.maxScoreMate[1] = rd.maxScoreMate[1]; rr.unmappedLength = rd.unmappedLength;
     if (rd.nWt > 0) rr.status |= STARAMD_ST_MAPPED_WINDOWS;
     u32 to = trBase[ir], eo = exBase[ir];
-    if ((u64)to + rd.nTr <= outTrCap && (u64)eo + rd.nEx <= outExCap) {
-        for (u32 w = 0; w < rd.nWt; w++) {
-            const DWinTr d = B.wtPool[rd.wtOffset + w];
-            if ((i32)w == rd.bestW) rr.trBest = (i32)(to - trBase[ir]);
+    if (rd.nTr > 0 && (u64)to + rd.nTr <= outTrCap && (u64)eo + rd.nEx <= outExCap) {
+        u32 ord = 0;
+        for (u32 w = 0; w < rd.nWin; w++) {
+            const DWinOut d = B.wout[rd.winOffset + w];
+            if (d.nTr == 0) continue;
+            if ((i32)ord == rd.bestW) rr.trBest = (i32)(to - trBase[ir]);
             for (u32 k = 0; k < d.nTr; k++) {
                 staramd_transcript t = B.trPool[d.trOffset + k];
-                t.exonOffset += eo;
+                t.iW = ord; t.exonOffset += eo;
                 outTr[to + k] = t;
             }
             for (u32 k = 0; k < d.nEx; k++) outEx[eo + k] = B.exPool[d.exOffset + k];
-            to += d.nTr; eo += d.nEx;
+            to += d.nTr; eo += d.nEx; ord++;
         }
     }
     outReads[ir] = rr;

@@ -151,13 +151,14 @@ __device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R,
             storeAligns(X, st, iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, NrepAll[iDist], maxLall[iDist], ind0All[iDist], iFrag);
 }
 
-extern "C" __global__ void __launch_bounds__(256) k_seed_search(DevIndex X, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
+extern "C" __global__ void __launch_bounds__(256) k_seed_search(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
+    const DevIndex &X = *Xp;
     u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     SeedState st; st.PC = scratch + (u64)lane * scratchPerLane; st.cap = scratchPerLane;
     SeedCnt cn = {0, 0, 0}; u64 nSeedsTot = 0;
     const staramd_params &P = X.P;
     for (;;) {
-        u32 ir = atomicAdd(&B.cursors[8], 1u);
+        u32 ir = atomicAdd(&B.cursors[CUR_TICKET_SEED], 1u);
         if (ir >= B.nReads) break;
         const u8 *R = B.bases + B.readOffset[ir];
         u32 Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
@@ -215,8 +216,8 @@ extern "C" __global__ void __launch_bounds__(256) k_seed_search(DevIndex X, DevB
         else if (Nsplit == 0) { rd.status |= STARAMD_ST_NO_GOOD_PIECES; rd.unmappedLength = LgoodMin; }
         else if (st.nA == 0) { rd.status |= STARAMD_ST_ALL_PIECES_MULTI; rd.unmappedLength = st.multNminL; }
         else {
-            u32 off = atomicAdd(&B.cursors[0], st.nP);
-            if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[6], 1u); rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; }
+            u32 off = atomicAdd(&B.cursors[CUR_SEED], st.nP);
+            if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_SEEDPOOL); }
             else {
                 rd.seedOffset = off; rd.nSeeds = st.nP;
                 for (u32 k = 0; k < st.nP; k++) B.seedPool[off + k] = st.PC[k];

@@ -1,6 +1,6 @@
 // k_stitch.hip -- kernel 3: stitch the seeds of every window into transcripts, extend, score, filter, rank.
 //
-// Replaces, per read, the second half of ReadAlign::stitchPieces (source/ReadAlign_stitchPieces.cpp:260-348)
+// Replaces, per window, the second half of ReadAlign::stitchPieces (source/ReadAlign_stitchPieces.cpp:260-348)
 // and everything below it:
 //   stitchWindowAligns      source/stitchWindowAligns.cpp:8-353     include/exclude recursion + leaf filters + ranked insert
 //   stitchAlignToTranscript source/stitchAlignToTranscript.cpp:9-415 gap fill, junction / indel placement, sjdb scoring
@@ -8,52 +8,50 @@
 //   binarySearch2           source/binarySearch2.cpp:3-43
 //   blocksOverlap           source/blocksOverlap.cpp:3-40
 //
-// The recursion is run as an explicit depth-first walk: a frame is pushed only when a seed is
-// INCLUDED (the exclude branch is a tail call: same transcript, next seed), so the stack is at most
-// nWA+1 deep and a transcript is copied once per include instead of twice per node.  Transcripts
-// are 32-byte exon rows (already the output format) plus an 80-byte header; only the used exons
-// are copied.  Leaves are finalised in exactly the reference's order (include before exclude),
-// because de-duplication, the evolving window-best score and maxScoreMate[] depend on it, and
-// windows of one read are walked in window order for the same reason.
-// Mapping: one lane = one read, persistent lanes with a ticket counter.
-#include "dev.h"
-
-
-struct StitchCtx {
-    const DevIndex *X;
-    const u8 *R0; u32 Lread; u32 str;          // read accessor: Read1[0] for + windows, Read1[2] for - windows
-    u32 readLength[2]; u32 mmMaxTotal;
-    i32 maxScoreMate[2];
-    u64 nGstitch, nStitchCalls, nExtendCalls, nNodes, nLeaves;
-};
-
-__device__ __forceinline__ u8 RD(const StitchCtx &c, u32 i) {        // R[i], ReadAlign_stitchPieces.cpp:321
-    return c.str == 0 ? c.R0[i] : compBase(c.R0[c.Lread - 1 - i]);
-}
-__device__ __forceinline__ u8 GN(StitchCtx &c, u64 pos) { c.nGstitch++; return c.X->G[(i64)pos]; }
-
-__device__ static void copyTr(DTr *dst, const DTr *src) {
-    const u64 *s = (const u64 *)src; u64 *d = (u64 *)dst;
-    u32 nw = (u32)((sizeof(staramd_exon) * src->nExons) / 8);
-    for (u32 i = 0; i < nw; i++) d[i] = s[i];
-    const u64 *sh = (const u64 *)((const u8 *)src + sizeof(staramd_exon) * STARAMD_MAX_N_EXONS);
-    u64 *dh = (u64 *)((u8 *)dst + sizeof(staramd_exon) * STARAMD_MAX_N_EXONS);
-    for (u32 i = 0; i < DTR_HDR_BYTES / 8; i++) dh[i] = sh[i];
-}
-
+// Mapping: ONE WAVEFRONT PER WINDOW, all 64 lanes cooperating.
+//   * The include/exclude recursion is an explicit depth-first walk over ONE working transcript with an undo log
+//     (the reference copies a 1696-byte Transcript twice per node): the header lives in registers (wave-uniform),
+//     a frame of the undo stack is {header, previous last exon, seed index} = 112 bytes pushed only when an include
+//     succeeds, the exclude branch is a tail step.  Stack, exon rows and the record arena of the window live in the
+//     wavefront's LDS slice (~13 KB), so a walk step costs LDS latency, not L2/HBM latency.
+//   * Every per-base loop of the reference is a lane-parallel step, lane = read position:
+//       extendAlign            match / mismatch ballots, prefix counts with v_mbcnt, break point = first set bit,
+//                              best prefix = wave max of (score << 8 | 63 - lane)  (first position of the maximum)
+//       gap fill               two ballots + popcounts
+//       junction scan          (stitchAlignToTranscript.cpp:106-156) left scan = position of the k-th set bit of a ballot,
+//                              right scan = prefix counts of the two "votes" ballots + per-lane motif penalty + wave argmax
+//       repeat shifts jjL/jjR  first zero of an equality ballot
+//       sjdb lookup            64-ary search over sjdbStart with coalesced probes instead of 19 dependent bisection steps
+//       de-duplication         lane k runs blocksOverlap against recorded transcript k; block / remove / keep classes
+//                              are ballots, the rank list is compacted and shifted with lane-parallel copies
+//     Genome bytes of a scan are fetched by one coalesced load (64 consecutive bases per instruction), read bases come
+//     from the 4-bit packed copy of the read staged once per window in LDS.
+//   * Leaves are finalised in exactly the reference's order (include before exclude) because de-duplication and the
+//     evolving window-best score depend on it.  Windows of a read are independent except for maxScoreMate[]; see
+//     k_stitch_win for how that dependency is resolved exactly without serialising the windows of a read.
+//   * Windows that outgrow the LDS slice (record arena) are deferred to a second launch of the same kernel whose work
+//     space lives in global memory with worst-case sizes (big = 1).
+#include "stitch_common.h"
+#ifdef STARAMD_SHADOW
+#include "stitch_scalar.h"
+#else
 struct ExtRes { i32 maxScore; u32 extendL, nMatch, nMM; };
+#endif
 
-// extendAlign.cpp:6-93
-__device__ static bool extendAlign(StitchCtx &c, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
+#define NLANE 64u
+
+__device__ __forceinline__ u8 gByte(const StitchCtx &c, u64 pos) { return c.X->G[(i64)pos]; }
+
+// ---- extendAlign.cpp:6-93, lane = position of the scan -------------------------------------------------------------
+__device__ static bool coopExtend(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
     c.nExtendCalls++;
-    int Score = 0, nMatch = 0, nMM = 0;
     e.maxScore = 0; e.extendL = 0; e.nMatch = 0; e.nMM = 0;
-    if (extendToEnd) {
-        int iExt;
+    if (extendToEnd) {                      // --alignEndsType Extend*: rarely used, wave-uniform scalar loop (:18-56)
+        int Score = 0, nMatch = 0, nMM = 0, iExt;
         for (iExt = 0; iExt < (int)L; iExt++) {
             int iS = dR * iExt, iG = dG * iExt;
             u8 gc = 5;
-            if ((gStart + (i64)iG) == (u64)(-1) || (gc = GN(c, gStart + (i64)iG)) == 5) { e.extendL = 0; e.maxScore = -999999999; e.nMatch = 0; e.nMM = nMMmax + 1; return true; }
+            if ((gStart + (i64)iG) == (u64)(-1) || (gc = gByte(c, gStart + (i64)iG)) == 5) { e.extendL = 0; e.maxScore = -999999999; e.nMatch = 0; e.nMM = nMMmax + 1; return true; }
             u8 rc = RD(c, (u32)((int)rStart + iS));
             if (rc == STARAMD_SPACER_BASE) break;
             if (rc > 3 || gc > 3) continue;
@@ -62,73 +60,108 @@ __device__ static bool extendAlign(StitchCtx &c, u32 rStart, u64 gStart, int dR,
         if (iExt > 0) { e.extendL = (u32)iExt; e.maxScore = Score; e.nMatch = (u32)nMatch; e.nMM = (u32)nMM; return true; }
         return false;
     }
-    for (int i = 0; i < (int)L; i++) {
-        int iS = dR * i, iG = dG * i;
-        if ((gStart + (i64)iG) == (u64)(-1)) break;
-        u8 gc = GN(c, gStart + (i64)iG);
-        u8 rc = RD(c, (u32)((int)rStart + iS));
-        if (gc == 5 || rc == STARAMD_SPACER_BASE) break;
-        if (rc > 3 || gc > 3) continue;
-        if (gc == rc) {
-            nMatch++; Score += 1;
-            if (Score > e.maxScore) {
-                if ((double)(u32)(nMM + (int)nMMprev) <= fmin(pMMmax * (double)(u64)(Lprev + i + 1), (double)nMMmax)) {
-                    e.extendL = (u32)(i + 1); e.maxScore = Score; e.nMatch = (u32)nMatch; e.nMM = (u32)nMM;
-                }
-            }
-        } else {
-            if ((double)(u32)(nMM + (int)nMMprev) >= fmin(pMMmax * (double)(u64)(Lprev + L), (double)nMMmax)) break;
-            nMM++; Score -= 1;
+    const double thrBreak = fmin(pMMmax * (double)(u64)(Lprev + L), (double)nMMmax);
+    int scoreBase = 0; u32 nMatchBase = 0, nMMBase = 0; int best = 0;
+    for (u32 base = 0; base < L; base += NLANE) {
+        u32 i = base + lane;
+        bool act = i < L;
+        u64 gpos = gStart + (u64)(i64)(dG * (int)i);
+        u8 gc = 5, rc = STARAMD_SPACER_BASE;
+        if (act && gpos != (u64)(-1)) { gc = gByte(c, gpos); rc = RD(c, (u32)((int)rStart + dR * (int)i)); }
+        bool stop = !act || gc == 5 || rc == STARAMD_SPACER_BASE;            // :61-63 (and end of the scan)
+        u64 sm = __ballot(stop);
+        u32 Leff = sm ? firstLane(sm) : NLANE;
+        bool in = lane < Leff;
+        bool skip = rc > 3 || gc > 3;                                        // :65 N in read or genome: no score
+        bool isM = in && !skip && gc == rc, isX = in && !skip && gc != rc;
+        u64 mM = __ballot(isM), mX = __ballot(isX);
+        // :78 a mismatch stops the scan when the mismatches BEFORE it already exhaust the budget
+        bool brk = isX && ((double)(u32)(nMMBase + cntBelow(mX) + nMMprev) >= thrBreak);
+        u64 bm = __ballot(brk);
+        u32 lim = bm ? min(Leff, firstLane(bm)) : Leff;
+        u64 keep = lim >= NLANE ? ~0ull : ((1ull << lim) - 1ull);
+        mM &= keep; mX &= keep;
+        u32 cM = cntUpTo(mM, lane), cX = cntUpTo(mX, lane);
+        int score_i = scoreBase + (int)cM - (int)cX; u32 nMM_i = nMMBase + cX, nMatch_i = nMatchBase + cM;
+        // :69-75 a match records a new best prefix if the score beats the recorded one and the mismatch rate allows it
+        bool cand = isM && lane < lim && score_i > best
+                    && (double)(u32)(nMM_i + nMMprev) <= fmin(pMMmax * (double)(u64)(Lprev + i + 1), (double)nMMmax);
+        u32 key = cand ? ((((u32)score_i) << 8) | (63u - lane)) : 0u;
+        u32 kmax = waveMaxU32(key);
+        if (kmax) {
+            u32 bl = 63u - (kmax & 255u);
+            best = (int)(kmax >> 8);
+            e.extendL = base + bl + 1; e.maxScore = best; e.nMatch = bcast32(nMatch_i, bl); e.nMM = bcast32(nMM_i, bl);
         }
+        c.nGstitch += min(lim + 1u, NLANE);
+        if (lim < NLANE) break;
+        u32 pM = (u32)__popcll(mM), pX = (u32)__popcll(mX);
+        scoreBase += (int)pM - (int)pX; nMatchBase += pM; nMMBase += pX;
     }
     return e.extendL > 0;
 }
 
-// binarySearch2.cpp:3-43
-__device__ static int binarySearch2(u64 x, u64 y, const u64 *Xs, const u64 *Ys, int N) {
+#ifdef STARAMD_SHADOW
+__device__ static bool coopExtendChecked(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
+    bool r = coopExtend(c, lane, rStart, gStart, dR, dG, L, Lprev, nMMprev, nMMmax, pMMmax, extendToEnd, e);
+    ExtRes s; bool rs = extendAlign(c, rStart, gStart, dR, dG, L, Lprev, nMMprev, nMMmax, pMMmax, extendToEnd, s);
+    bool bad = r != rs || (r && (s.maxScore != e.maxScore || s.extendL != e.extendL || s.nMatch != e.nMatch || s.nMM != e.nMM));
+    if (lane == 0) { if (bad) atomicAdd((unsigned long long *)&c.shadow[2], 1ull); atomicAdd((unsigned long long *)&c.shadow[3], 1ull); }
+    return r;
+}
+#define COOP_EXTEND coopExtendChecked
+#else
+#define COOP_EXTEND coopExtend
+#endif
+
+// ---- binarySearch2.cpp:3-43: index of the junction (x = start, y = end) in the sorted sjdb arrays, < 0 if absent ----
+// 64-ary search: every round 64 lanes probe 64 evenly spaced starts, the count of "smaller" answers narrows the range
+// 64-fold; then the run of equal starts is compared against y by all lanes at once.  (sjdb junctions are unique
+// (start,end) pairs -- sjdbPrepare collapses duplicates -- so "the" match is well defined.)
+__device__ static int coopSjdbFind(u32 lane, u64 x, u64 y, const u64 *Xs, const u64 *Ys, u32 N) {
     if (N == 0 || x > Xs[N - 1] || x < Xs[0]) return -1;
-    int i1 = 0, i2 = N - 1, i3 = N / 2;
-    while (i2 > i1 + 1) { i3 = (i1 + i2) / 2; if (Xs[i3] > x) i2 = i3; else i1 = i3; }
-    if (x == Xs[i1]) i3 = i1; else if (x == Xs[i2]) i3 = i2; else return -1;
-    for (int jj = i3; jj >= 0; jj--) { if (x != Xs[jj]) break; else if (y == Ys[jj]) return jj; }
-    for (int jj = i3; jj < N; jj++) { if (x != Xs[jj]) return -1; else if (y == Ys[jj]) return jj; }
-    return -2;
-}
-
-// blocksOverlap.cpp:3-40
-__device__ static u32 blocksOverlap(const DTr &t1, const DTr &t2) {
-    u32 i1 = 0, i2 = 0, nOverlap = 0;
-    while (i1 < t1.nExons && i2 < t2.nExons) {
-        u64 rs1 = t1.ex[i1].R, rs2 = t2.ex[i2].R;
-        u64 re1 = rs1 + t1.ex[i1].L, re2 = rs2 + t2.ex[i2].L;
-        u64 gs1 = t1.ex[i1].G, gs2 = t2.ex[i2].G;
-        if (rs1 >= re2) i2++;
-        else if (rs2 >= re1) i1++;
-        else if (gs1 - rs1 != gs2 - rs2) { if (re1 >= re2) i2++; if (re2 >= re1) i1++; }
-        else { nOverlap += (u32)(min(re1, re2) - max(rs1, rs2)); if (re1 >= re2) i2++; if (re2 >= re1) i1++; }
+    u32 lo = 0, hi = N;                                   // first index with Xs[idx] >= x lies in [lo, hi]
+    while (hi - lo > NLANE) {
+        u32 step = (hi - lo + NLANE - 1) / NLANE;
+        u32 p = lo + lane * step;
+        bool less = p < hi && Xs[p] < x;
+        u32 cl = (u32)__popcll(__ballot(less));           // probes are sorted: lanes 0..cl-1 are "less"
+        u32 nProbe = (hi - lo + step - 1) / step;
+        u32 nlo = cl ? lo + (cl - 1) * step + 1 : lo;
+        u32 nhi = cl == 0 ? lo : (cl < nProbe ? lo + cl * step : hi);
+        lo = nlo; hi = nhi;
+        if (hi <= lo) { hi = lo; break; }
     }
-    return nOverlap;
+    if (hi > lo) { bool less = lo + lane < hi && Xs[lo + lane] < x; lo += (u32)__popcll(__ballot(less)); }
+    // lo = first index with Xs >= x
+    for (u32 base = lo; base < N; base += NLANE) {
+        u32 k = base + lane;
+        bool sameX = k < N && Xs[k] == x;
+        bool hit = sameX && Ys[k] == y;
+        u64 hm = __ballot(hit);
+        if (hm) return (int)(base + firstLane(hm));
+        if (__ballot(sameX) != ~0ull) break;               // run of equal starts ended inside this chunk
+    }
+    return -1;
 }
 
-__device__ __forceinline__ void addExt(DTr *t, const ExtRes &e) {      // Transcript::add of an extension (Transcript.cpp:31-39)
-    t->maxScore += e.maxScore; t->nMatch += e.nMatch; t->nMM += e.nMM;
-}
-
-// stitchAlignToTranscript.cpp:9-415
-__device__ static int stitchAlignToTranscript(StitchCtx &c, u32 rAend, u64 gAend, u32 rBstart, u64 gBstart, u32 L, u32 iFragB, i32 sjAB, DTr *trA) {
+// ---- stitchAlignToTranscript.cpp:9-415 ------------------------------------------------------------------------------
+// h / eA are working copies (wave-uniform): the caller commits them (and eN when added) only when the returned score is
+// > -1000000, so a failed stitch leaves the transcript untouched.  ex0R / ex0G = start of the first exon.
+__device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u32 rBstart, u64 gBstart, u32 L, u32 iFragB, i32 sjAB,
+                                 Hdr &h, staramd_exon &eA, staramd_exon &eN, bool &added, u32 ex0R, u64 ex0G) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
     c.nStitchCalls++;
-    if (trA->nExons >= STARAMD_MAX_N_EXONS) return -1000010;
+    added = false;
+    if (h.nExons >= STARAMD_MAX_N_EXONS) return -1000010;
     int Score = 0;
-    u32 ne = trA->nExons;
-    staramd_exon &eA = trA->ex[ne - 1];
     if (sjAB != -1 && eA.sjA == sjAB && eA.iFrag == iFragB && rBstart == rAend + 1 && gAend + 1 < gBstart) {
+        // both seeds come from the same inserted sjdb sequence: the junction is the annotated one (:18-34)
         if (X.sjdbMotif[sjAB] == 0 && (L <= X.sjdbShiftRight[sjAB] || eA.L <= X.sjdbShiftLeft[sjAB])) return -1000006;
-        staramd_exon &eN = trA->ex[ne];
         eN.L = (u16)L; eN.R = (u16)rBstart; eN.G = gBstart;
         eA.canonSJ = (i8)X.sjdbMotif[sjAB]; eA.shiftSJ[0] = X.sjdbShiftLeft[sjAB]; eA.shiftSJ[1] = X.sjdbShiftRight[sjAB];
         eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjAB];
-        trA->nExons++; trA->nMatch += L;
+        added = true; h.nMatch += L;
         Score += (int)L; Score += P.sjdbScore;
     } else {
         eA.sjAnnot = 0; eA.sjStr = 0;
@@ -145,183 +178,292 @@ __device__ static int stitchAlignToTranscript(StitchCtx &c, u32 rAend, u64 gAend
             u64 gBstart1 = gBstart - (u64)(i64)rGap - 1;
             if (gGap == 0 && rGap == 0) {
             } else if (gGap > 0 && rGap > 0 && rGap == gGap) {
-                for (int ii = 1; ii <= rGap; ii++) {
-                    u8 gc = GN(c, gAend + ii), rc = RD(c, rAend + ii);
-                    if (gc < 4 && rc < 4) { if (rc == gc) { Score += 1; nMatch++; } else { Score -= 1; nMM++; } }
+                // ---- equal gap: score the bases in between (:80-93)
+                for (int base = 1; base <= rGap; base += (int)NLANE) {
+                    int ii = base + (int)lane;
+                    bool act = ii <= rGap;
+                    u8 gc = 4, rc = 4;
+                    if (act) { gc = gByte(c, gAend + ii); rc = RD(c, rAend + ii); }
+                    bool ok = act && gc < 4 && rc < 4;
+                    u32 pm = (u32)__popcll(__ballot(ok && rc == gc)), px = (u32)__popcll(__ballot(ok && rc != gc));
+                    Score += (int)pm - (int)px; nMatch += pm; nMM += px;
                 }
+                c.nGstitch += (u32)rGap;
             } else if (gGap > rGap) {
+                // ---- deletion or junction (:95-253)
                 nDel = 1; Del = (u64)(i64)(gGap - rGap);
                 if (Del > P.alignIntronMax && P.alignIntronMax > 0) return -1000003;
-                int Score1 = 0, jR1 = 1;
-                do {
-                    jR1--;
-                    u8 rc = RD(c, (u32)((int)rAend + jR1)), gB = GN(c, gBstart1 + (i64)jR1);
-                    if (rc != gB && gB < 4 && rc == GN(c, gAend + (i64)jR1)) Score1 -= 1;
-                } while (Score1 + P.scoreStitchSJshift >= 0 && (int)eA.L + jR1 > 1);
-                int maxScore2 = -999999; Score1 = 0; int jPen = 0;
-                do {
-                    u8 ra = RD(c, (u32)((int)rAend + jR1)), gA = GN(c, gAend + (i64)jR1), gB = GN(c, gBstart1 + (i64)jR1);
-                    if (ra == gA && ra != gB) Score1 += 1;
-                    if (ra != gA && ra == gB) Score1 -= 1;
-                    int jCan1 = -1, jPen1 = 0, Score2 = Score1;
-                    if (Del >= P.alignIntronMin) {
-                        u8 d1 = GN(c, gAend + (i64)jR1 + 1), d2 = GN(c, gAend + (i64)jR1 + 2), a1 = GN(c, gBstart1 + (i64)jR1 - 1), a2 = gB;
-                        if (d1 == 2 && d2 == 3 && a1 == 0 && a2 == 2) jCan1 = 1;
-                        else if (d1 == 1 && d2 == 3 && a1 == 0 && a2 == 1) jCan1 = 2;
-                        else if (d1 == 2 && d2 == 1 && a1 == 0 && a2 == 2) { jCan1 = 3; jPen1 = P.scoreGapGCAG; }
-                        else if (d1 == 1 && d2 == 3 && a1 == 2 && a2 == 1) { jCan1 = 4; jPen1 = P.scoreGapGCAG; }
-                        else if (d1 == 0 && d2 == 3 && a1 == 0 && a2 == 1) { jCan1 = 5; jPen1 = P.scoreGapATAC; }
-                        else if (d1 == 2 && d2 == 3 && a1 == 0 && a2 == 3) { jCan1 = 6; jPen1 = P.scoreGapATAC; }
-                        else { jCan1 = 0; jPen1 = P.scoreGapNoncan; }
-                        Score2 += jPen1;
+                const int eAL = (int)eA.L;
+                // left scan (:104-109): walk left from the end of A while fewer than scoreStitchSJshift+1 positions
+                // favour A over B, never past the start of A's exon.  jStart = where the walk stops.
+                int jStart;
+                {
+                    const int need = P.scoreStitchSJshift + 1, lowLimit = 1 - eAL;
+                    if (need <= 0) jStart = 0;
+                    else {
+                        int cnt = 0; jStart = lowLimit;
+                        for (int base = 0;; base += (int)NLANE) {
+                            int j = -(base + (int)lane);
+                            bool valid = j >= lowLimit;
+                            bool bad = false;
+                            if (valid) {
+                                u8 rc = RD(c, (u32)((int)rAend + j)), gB = gByte(c, gBstart1 + (i64)j);
+                                bad = rc != gB && gB < 4 && rc == gByte(c, gAend + (i64)j);
+                            }
+                            u64 bmk = __ballot(bad);
+                            int pc = (int)__popcll(bmk);
+                            if (cnt + pc >= need) {
+                                for (int k = need - cnt; k > 1; k--) bmk &= bmk - 1;
+                                jStart = -(base + (int)firstLane(bmk));
+                                break;
+                            }
+                            cnt += pc;
+                            if (-(base + (int)NLANE - 1) <= lowLimit) break;      // reached the start of the exon
+                        }
                     }
-                    if (maxScore2 < Score2) { maxScore2 = Score2; jR = jR1; jCan = jCan1; jPen = jPen1; }
-                    jR1++;
-                } while (jR1 < (int)rBend - (int)rAend);
+                }
+                // right scan (:111-156): best junction position by votes of the bases + motif penalty
+                int maxScore2 = -999999; int jPen = 0;
+                const bool isIntron = Del >= P.alignIntronMin;
+                const int jEnd = (int)rBend - (int)rAend;
+                {
+                    int s1base = 0;
+                    for (int base = 0; jStart + base < jEnd; base += (int)NLANE) {
+                        int j = jStart + base + (int)lane;
+                        bool act = j < jEnd;
+                        u8 ra = 9, gA = 8, gB = 7;
+                        if (act) { ra = RD(c, (u32)((int)rAend + j)); gA = gByte(c, gAend + (i64)j); gB = gByte(c, gBstart1 + (i64)j); }
+                        bool plus = act && ra == gA && ra != gB, minus = act && ra != gA && ra == gB;
+                        u64 mp = __ballot(plus), mn = __ballot(minus);
+                        int s1 = s1base + (int)cntUpTo(mp, lane) - (int)cntUpTo(mn, lane);
+                        int jCan1 = -1, jPen1 = 0;
+                        if (isIntron && act) {
+                            u8 d1 = gByte(c, gAend + (i64)j + 1), d2 = gByte(c, gAend + (i64)j + 2), a1 = gByte(c, gBstart1 + (i64)j - 1), a2 = gB;
+                            if (d1 == 2 && d2 == 3 && a1 == 0 && a2 == 2) jCan1 = 1;
+                            else if (d1 == 1 && d2 == 3 && a1 == 0 && a2 == 1) jCan1 = 2;
+                            else if (d1 == 2 && d2 == 1 && a1 == 0 && a2 == 2) { jCan1 = 3; jPen1 = P.scoreGapGCAG; }
+                            else if (d1 == 1 && d2 == 3 && a1 == 2 && a2 == 1) { jCan1 = 4; jPen1 = P.scoreGapGCAG; }
+                            else if (d1 == 0 && d2 == 3 && a1 == 0 && a2 == 1) { jCan1 = 5; jPen1 = P.scoreGapATAC; }
+                            else if (d1 == 2 && d2 == 3 && a1 == 0 && a2 == 3) { jCan1 = 6; jPen1 = P.scoreGapATAC; }
+                            else { jCan1 = 0; jPen1 = P.scoreGapNoncan; }
+                        }
+                        int s2 = s1 + jPen1;
+                        u32 key = act ? ((((u32)(s2 + 1000000)) << 8) | (63u - lane)) : 0u;
+                        u32 kmax = waveMaxU32(key);
+                        int ms2 = (int)(kmax >> 8) - 1000000;
+                        if (kmax && ms2 > maxScore2) {                      // strict: the first position of the maximum wins
+                            u32 bl = 63u - (kmax & 255u);
+                            maxScore2 = ms2; jR = jStart + base + (int)bl; jCan = (int)bcast32((u32)jCan1, bl); jPen = (int)bcast32((u32)jPen1, bl);
+                        }
+                        s1base += (int)__popcll(mp) - (int)__popcll(mn);
+                    }
+                    c.nGstitch += (u32)(jEnd - jStart) * (isIntron ? 5u : 2u);
+                }
+                // repeat length left / right of the junction (:159-166)
                 u32 jjL = 0, jjR = 0;
-                while (gAend + (i64)jR >= jjL && GN(c, gAend - jjL + (i64)jR) == GN(c, gBstart1 - jjL + (i64)jR) && X.G[(i64)(gAend - jjL + (i64)jR)] < 4 && jjL <= 255) jjL++;
-                while (gAend + jjR + (i64)jR + 1 < X.nGenome && GN(c, gAend + jjR + (i64)jR + 1) == GN(c, gBstart1 + jjR + (i64)jR + 1) && X.G[(i64)(gAend + jjR + (i64)jR + 1)] < 4 && jjR <= 255) jjR++;
-                if (jCan <= 0) {
+                for (u32 base = 0;; base += NLANE) {
+                    u32 k = base + lane;
+                    bool ok = gAend + (i64)jR >= (u64)k;
+                    if (ok) { u8 x = gByte(c, gAend - k + (i64)jR); ok = x == gByte(c, gBstart1 - k + (i64)jR) && x < 4 && k <= 255; }
+                    u64 fm = __ballot(!ok);
+                    if (fm) { jjL = base + firstLane(fm); break; }
+                }
+                for (u32 base = 0;; base += NLANE) {
+                    u32 k = base + lane;
+                    bool ok = gAend + k + (i64)jR + 1 < X.nGenome;
+                    if (ok) { u8 x = gByte(c, gAend + k + (i64)jR + 1); ok = x == gByte(c, gBstart1 + k + (i64)jR + 1) && x < 4 && k <= 255; }
+                    u64 fm = __ballot(!ok);
+                    if (fm) { jjR = base + firstLane(fm); break; }
+                }
+                c.nGstitch += 2u * (jjL + jjR + 2u);
+                if (jCan <= 0) {                                     // flush a non-canonical junction left (:168-173)
                     jR -= (int)jjL;
-                    if ((int)eA.L + jR < 1) return -1000005;
+                    if (eAL + jR < 1) return -1000005;
                     jjR += jjL; jjL = 0;
                 }
-                for (int ii = min(1, jR + 1); ii <= max(rGap, jR); ii++) {
-                    u64 g1 = (ii <= jR) ? (gAend + (i64)ii) : (gBstart1 + (i64)ii);
-                    u8 gc = GN(c, g1), rc = RD(c, (u32)((int)rAend + ii));
-                    if (gc < 4 && rc < 4) {
-                        if (rc == gc) { if (ii >= 1 && ii <= rGap) { Score += 1; nMatch++; } }
-                        else { Score -= 1; nMM++; if (ii < 1 || ii > rGap) { Score -= 1; nMatch--; } }
+                // re-score the bases between the seeds with the junction in place (:177-195)
+                {
+                    const int i0 = min(1, jR + 1), i1 = max(rGap, jR);
+                    for (int base = 0; i0 + base <= i1; base += (int)NLANE) {
+                        int ii = i0 + base + (int)lane;
+                        bool act = ii <= i1;
+                        u8 gc = 4, rc = 4;
+                        if (act) { gc = (ii <= jR) ? gByte(c, gAend + (i64)ii) : gByte(c, gBstart1 + (i64)ii); rc = RD(c, (u32)((int)rAend + ii)); }
+                        bool ok = act && gc < 4 && rc < 4;
+                        bool inGap = ii >= 1 && ii <= rGap;
+                        u32 pa = (u32)__popcll(__ballot(ok && rc == gc && inGap));
+                        u32 pb = (u32)__popcll(__ballot(ok && rc != gc));
+                        u32 pc = (u32)__popcll(__ballot(ok && rc != gc && !inGap));
+                        Score += (int)pa - (int)pb - (int)pc; nMatch += pa; nMatch -= pc; nMM += pb;
                     }
+                    c.nGstitch += (u32)(i1 - i0 + 1);
                 }
-                if (X.sjdbN > 0) {
-                    u64 jS = gAend + (i64)jR + 1, jE = gBstart1 + (i64)jR;
-                    int sjdbInd = binarySearch2(jS, jE, X.sjdbStart, X.sjdbEnd, (int)X.sjdbN);
-                    if (sjdbInd < 0) {
-                        if (Del >= P.alignIntronMin) Score += P.scoreGap + jPen;
-                        else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }
-                    } else {
-                        jCan = X.sjdbMotif[sjdbInd];
-                        if (X.sjdbMotif[sjdbInd] == 0) {
-                            if (L <= X.sjdbShiftLeft[sjdbInd] || eA.L <= X.sjdbShiftLeft[sjdbInd]) return -1000006;
-                            jR += (int)X.sjdbShiftLeft[sjdbInd];
-                            if ((u64)rAend + (i64)jR >= rBend) return -1000006;
-                            jjL = X.sjdbShiftLeft[sjdbInd]; jjR = X.sjdbShiftRight[sjdbInd];
-                        }
-                        eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjdbInd];
-                        Score += P.sjdbScore;
-                    }
-                } else {
-                    if (Del >= P.alignIntronMin) Score += P.scoreGap + jPen;
+                int sjdbInd = -1;
+                if (X.sjdbN > 0) sjdbInd = coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN);
+                if (sjdbInd < 0) {
+                    if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }
+                } else {
+                    jCan = X.sjdbMotif[sjdbInd];
+                    if (X.sjdbMotif[sjdbInd] == 0) {
+                        if (L <= X.sjdbShiftLeft[sjdbInd] || eA.L <= X.sjdbShiftLeft[sjdbInd]) return -1000006;
+                        jR += (int)X.sjdbShiftLeft[sjdbInd];
+                        if ((u64)rAend + (i64)jR >= rBend) return -1000006;
+                        jjL = X.sjdbShiftLeft[sjdbInd]; jjR = X.sjdbShiftRight[sjdbInd];
+                    }
+                    eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjdbInd];
+                    Score += P.sjdbScore;
                 }
                 eA.shiftSJ[0] = (u16)jjL; eA.shiftSJ[1] = (u16)jjR; eA.canonSJ = (i8)jCan;
                 if (eA.sjAnnot == 0) eA.sjStr = (jCan > 0) ? (u8)(2 - jCan % 2) : 0;
             } else if (rGap > gGap) {
+                // ---- insertion (:255-305): short and rare; wave-uniform scalar loops
                 Ins = (u32)(rGap - gGap); nIns = 1;
                 if (gGap == 0) jR = 0;
                 else if (gGap < 0) { jR = 0; Score -= -gGap; }
                 else {
                     int Score1 = 0, maxScore1 = 0;
                     for (int jR1 = 1; jR1 <= gGap; jR1++) {
-                        u8 gc = GN(c, gAend + jR1);
+                        u8 gc = gByte(c, gAend + jR1);
                         if (gc < 4) { Score1 += (RD(c, rAend + jR1) == gc) ? 1 : -1; Score1 += (RD(c, rAend + Ins + jR1) == gc) ? -1 : +1; }
                         if (Score1 > maxScore1 || (Score1 == maxScore1 && P.alignInsertionFlushRight)) { maxScore1 = Score1; jR = jR1; }
                     }
                     for (int ii = 1; ii <= gGap; ii++) {
                         u32 r1 = rAend + ii + (ii <= jR ? 0 : Ins);
-                        u8 gc = GN(c, gAend + ii), rc = RD(c, r1);
+                        u8 gc = gByte(c, gAend + ii), rc = RD(c, r1);
                         if (gc < 4 && rc < 4) { if (rc == gc) { Score += 1; nMatch++; } else { Score -= 1; nMM++; } }
                     }
+                    c.nGstitch += 2u * (u32)gGap;
                 }
                 if (P.alignInsertionFlushRight) {
-                    for (; jR < (int)rBend - (int)rAend - (int)Ins; jR++) { u8 gc = GN(c, gAend + (i64)jR + 1); if (RD(c, (u32)((int)rAend + jR + 1)) != gc || gc == 4) break; }
+                    for (; jR < (int)rBend - (int)rAend - (int)Ins; jR++) { u8 gc = gByte(c, gAend + (i64)jR + 1); if (RD(c, (u32)((int)rAend + jR + 1)) != gc || gc == 4) break; }
                     if (jR == (int)rBend - (int)rAend - (int)Ins) return -1000009;
                 }
                 Score += (int)Ins * P.scoreInsBase + P.scoreInsOpen;
                 jCan = -2;
             }
-            if ((trA->nMM + nMM) <= c.mmMaxTotal && (jCan < 0 || (jCan < 7 && (u64)nMM <= (u64)(i64)P.alignSJstitchMismatchNmax[(jCan + 1) / 2]))) {
-                trA->nMM += nMM; trA->nMatch += nMatch;
-                if (Del >= P.alignIntronMin) { trA->nGap += nDel; trA->lGap += (u32)Del; } else { trA->nDel += nDel; trA->lDel += (u32)Del; }
+            if ((h.nMM + nMM) <= c.mmMaxTotal && (jCan < 0 || (jCan < 7 && (u64)nMM <= (u64)(i64)P.alignSJstitchMismatchNmax[(jCan + 1) / 2]))) {
+                h.nMM += nMM; h.nMatch += nMatch;
+                if (Del >= P.alignIntronMin) { h.nGap += nDel; h.lGap += (u32)Del; } else { h.nDel += nDel; h.lDel += (u32)Del; }
                 if (Del == 0 && Ins == 0) eA.L = (u16)(eA.L + (rBend - rAend));
                 else if (Del > 0) {
                     eA.L = (u16)((int)eA.L + jR);
-                    staramd_exon &eN = trA->ex[ne];
                     eN.L = (u16)((int)(rBend - rAend) - jR); eN.R = (u16)((int)rAend + jR + 1); eN.G = gBstart1 + (i64)jR + 1;
-                    trA->nExons++;
+                    added = true;
                 } else if (Ins > 0) {
-                    trA->nIns += nIns; trA->lIns += Ins;
+                    h.nIns += nIns; h.lIns += Ins;
                     eA.L = (u16)((int)eA.L + jR);
-                    staramd_exon &eN = trA->ex[ne];
                     eN.L = (u16)((int)(rBend - rAend) - jR - (int)Ins); eN.R = (u16)((int)rAend + jR + (int)Ins + 1); eN.G = gAend + 1 + (i64)jR;
                     eA.canonSJ = -2; eA.sjAnnot = 0;
-                    trA->nExons++;
+                    added = true;
                 }
             } else return -1000007;
-        } else if (gBstart + trA->ex[0].R + (i64)P.alignEndsProtrudeNbasesMax >= trA->ex[0].G || trA->ex[0].G < trA->ex[0].R) {
+        } else if (gBstart + ex0R + (i64)P.alignEndsProtrudeNbasesMax >= ex0G || ex0G < ex0R) {
+            // ---- mate 2 after mate 1 (:352-405)
             if (P.alignMatesGapMax > 0 && gBstart > eA.G + eA.L + P.alignMatesGapMax) return -1000004;
             Score += (int)L;
             ExtRes e;
-            if (extendAlign(c, rAend + 1, gAend + 1, 1, 1, STARAMD_READ_LEN_MAX, trA->nMatch, trA->nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax, P.alignEndsTypeExt[eA.iFrag][1] != 0, e)) {
-                addExt(trA, e); Score += e.maxScore; eA.L = (u16)(eA.L + e.extendL);
+            if (coopExtend(c, lane, rAend + 1, gAend + 1, 1, 1, STARAMD_READ_LEN_MAX, h.nMatch, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax, P.alignEndsTypeExt[eA.iFrag][1] != 0, e)) {
+                h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore; eA.L = (u16)(eA.L + e.extendL);
             }
-            staramd_exon &eN = trA->ex[ne];
-            eN.R = (u16)rBstart; eN.G = gBstart; eN.L = (u16)L; trA->nMatch += L;
-            u32 extlen = P.alignEndsTypeExt[iFragB][1] ? STARAMD_READ_LEN_MAX : (u32)(gBstart - trA->ex[0].G + trA->ex[0].R);
-            if (extendAlign(c, rBstart - 1, gBstart - 1, -1, -1, extlen, trA->nMatch, trA->nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax, P.alignEndsTypeExt[iFragB][1] != 0, e)) {
-                addExt(trA, e); Score += e.maxScore;
+            eN.R = (u16)rBstart; eN.G = gBstart; eN.L = (u16)L; h.nMatch += L;
+            u32 extlen = P.alignEndsTypeExt[iFragB][1] ? STARAMD_READ_LEN_MAX : (u32)(gBstart - ex0G + ex0R);
+            if (coopExtend(c, lane, rBstart - 1, gBstart - 1, -1, -1, extlen, h.nMatch, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax, P.alignEndsTypeExt[iFragB][1] != 0, e)) {
+                h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
                 eN.R = (u16)(eN.R - e.extendL); eN.G -= e.extendL; eN.L = (u16)(eN.L + e.extendL);
             }
             eA.canonSJ = -3; eA.sjAnnot = 0;
-            trA->nExons++;
+            added = true;
         } else return -1000008;
     }
-    trA->ex[trA->nExons - 1].iFrag = (u8)iFragB; trA->ex[trA->nExons - 1].sjA = sjAB;
+    // the last exon carries the mate / sjdb index of the last seed (:413-414)
+    if (added) { eN.iFrag = (u8)iFragB; eN.sjA = sjAB; eN.canonSJ = 0; eN.sjAnnot = 0; eN.sjStr = 0; eN.shiftSJ[0] = eN.shiftSJ[1] = 0; eN.pad0 = 0; eN.pad1 = 0; }
+    else { eA.iFrag = (u8)iFragB; eA.sjA = sjAB; }
     return Score;
 }
 
-struct WinRec { DTr *T; u16 *idx; u32 nWinTr; };
+// blocksOverlap.cpp:3-40 on two exon lists in the output record format (run by one lane)
+__device__ static u32 blocksOverlap(const staramd_exon *e1, u32 n1, const staramd_exon *e2, u32 n2) {
+    u32 i1 = 0, i2 = 0, nOverlap = 0;
+    while (i1 < n1 && i2 < n2) {
+        u64 rs1 = e1[i1].R, rs2 = e2[i2].R;
+        u64 re1 = rs1 + e1[i1].L, re2 = rs2 + e2[i2].L;
+        u64 gs1 = e1[i1].G, gs2 = e2[i2].G;
+        if (rs1 >= re2) i2++;
+        else if (rs2 >= re1) i1++;
+        else if (gs1 - rs1 != gs2 - rs2) { if (re1 >= re2) i2++; if (re2 >= re1) i1++; }
+        else { nOverlap += (u32)(min(re1, re2) - max(rs1, rs2)); if (re1 >= re2) i2++; if (re2 >= re1) i1++; }
+    }
+    return nOverlap;
+}
 
-// leaf of the recursion: stitchWindowAligns.cpp:16-307.  trA is modified in place (the frame is popped afterwards).
-__device__ static void finalizeTranscript(StitchCtx &c, DTr &trA, int Score, u32 tR2, u64 tG2, u32 chr, WinRec &wr) {
+// transcripts recorded for the current window: records in the OUTPUT format (staramd_transcript followed by its
+// exons) bump-allocated in the window's arena; rank[] holds their offsets (32-byte units), best first.
+struct WinRec { u8 *arena; u32 arenaBytes; u32 top; u16 *rank; u32 nWinTr; bool overflow; };
+#define REC_HDR 96
+static_assert(sizeof(staramd_transcript) == REC_HDR, "record header is the output transcript record");
+static_assert(sizeof(staramd_exon) == 32, "exon record is 32 bytes");
+__device__ __forceinline__ staramd_transcript *recAt(const WinRec &w, u32 off32) { return (staramd_transcript *)(w.arena + off32 * 32u); }
+__device__ __forceinline__ staramd_transcript *recT(const WinRec &w, u32 k) { return recAt(w, w.rank[k]); }
+
+// slide the live records to the front of the arena (only when the bump pointer hits the end); run by lane 0
+__device__ static u32 compactArena(WinRec &w) {
+    u32 newTop = 0; i32 lastOrig = -1;
+    for (u32 step = 0; step < w.nWinTr; step++) {
+        u32 best = 0xFFFFFFFFu, bk = 0;
+        for (u32 k = 0; k < w.nWinTr; k++) { u32 o = w.rank[k]; if ((i32)o > lastOrig && o < best) { best = o; bk = k; } }
+        if (best == 0xFFFFFFFFu) break;
+        const staramd_transcript *t = (const staramd_transcript *)(w.arena + best * 32u);
+        u32 words = (REC_HDR + 32u * t->nExons) / 8;
+        const u64 *s = (const u64 *)(w.arena + best * 32u); u64 *d = (u64 *)(w.arena + newTop);
+        if (d != s) for (u32 i = 0; i < words; i++) d[i] = s[i];
+        w.rank[bk] = (u16)(newTop / 32u);
+        lastOrig = (i32)best; newTop += words * 8;
+        // records moved so far now sit at offsets < newTop <= best, i.e. never "> lastOrig" again
+    }
+    return newTop;
+}
+
+// leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
+__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd_exon *ex, u32 chr, WinRec &wr) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
     c.nLeaves++;
     u32 Lread = c.Lread; u32 Str = c.str;
+    int Score = h.Score; u32 tR2 = h.tR2; u64 tG2 = h.tG2;
+    u32 ne = h.nExons;
     ExtRes e;
     int vOrder0 = (Str == 0) ? 0 : 1;                  // EXTEND_ORDER==1, roStr==Str
     for (int iOrd = 0; iOrd < 2; iOrd++) {
         int which = iOrd == 0 ? vOrder0 : 1 - vOrder0;
         if (which == 0) {
-            if (trA.rStart > 0) {
-                u32 imate = trA.ex[0].iFrag;
-                if (extendAlign(c, trA.rStart - 1, trA.gStart - 1, -1, -1, trA.rStart, tR2 - trA.rStart + 1, trA.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
-                                P.alignEndsTypeExt[imate][(int)(Str != imate)] != 0, e)) {
-                    addExt(&trA, e); Score += e.maxScore;
-                    trA.rStart -= e.extendL; trA.ex[0].R = (u16)trA.rStart;
-                    trA.gStart -= e.extendL; trA.ex[0].G = trA.gStart;
-                    trA.ex[0].L = (u16)(trA.ex[0].L + e.extendL);
+            if (h.rStart > 0) {
+                u32 imate = ex[0].iFrag;
+                if (COOP_EXTEND(c, lane, h.rStart - 1, h.gStart - 1, -1, -1, h.rStart, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
+                               P.alignEndsTypeExt[imate][(int)(Str != imate)] != 0, e)) {
+                    h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
+                    h.rStart -= e.extendL; h.gStart -= e.extendL;
+                    if (lane == 0) { ex[0].R = (u16)h.rStart; ex[0].G = h.gStart; ex[0].L = (u16)(ex[0].L + e.extendL); }
+                    __threadfence_block();
                 }
             }
         } else {
             if (tR2 < Lread) {
-                u32 imate = trA.ex[trA.nExons - 1].iFrag;
-                if (extendAlign(c, tR2 + 1, tG2 + 1, +1, +1, Lread - tR2 - 1, tR2 - trA.rStart + 1, trA.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
-                                P.alignEndsTypeExt[imate][(int)(imate == Str)] != 0, e)) {
-                    addExt(&trA, e); Score += e.maxScore;
+                u32 imate = ex[ne - 1].iFrag;
+                if (COOP_EXTEND(c, lane, tR2 + 1, tG2 + 1, +1, +1, Lread - tR2 - 1, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
+                               P.alignEndsTypeExt[imate][(int)(imate == Str)] != 0, e)) {
+                    h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
                     tR2 += e.extendL; tG2 += e.extendL;
-                    trA.ex[trA.nExons - 1].L = (u16)(trA.ex[trA.nExons - 1].L + e.extendL);
+                    if (lane == 0) ex[ne - 1].L = (u16)(ex[ne - 1].L + e.extendL);
+                    __threadfence_block();
                 }
             }
         }
     }
-    u32 ne = trA.nExons;
-    staramd_exon *ex = trA.ex;
     if (!P.alignSoftClipAtReferenceEnds &&
         ((ex[ne - 1].G + Lread - ex[ne - 1].R) > (X.chrStart[chr] + X.chrLength[chr]) || ex[0].G < (X.chrStart[chr] + ex[0].R))) return;
-    trA.rLength = 0;
-    for (u32 i = 0; i < ne; i++) trA.rLength += ex[i].L;
-    trA.gLength = tG2 + 1 - trA.gStart;
+    u32 rLength = 0;
+    for (u32 i = 0; i < ne; i++) rLength += ex[i].L;
+    u64 gLength = tG2 + 1 - h.gStart;
     for (u32 isj = 0; isj + 1 < ne; isj++) {
         if (ex[isj].canonSJ >= 0) {
             if (ex[isj].sjAnnot == 1) {
@@ -334,13 +476,14 @@ __device__ static void finalizeTranscript(StitchCtx &c, DTr &trA, int Score, u32
     }
     if (ne > 1 && ex[ne - 2].sjAnnot == 1 && ex[ne - 1].L < P.alignSJDBoverhangMin) return;
     u32 sjN = 0;
-    trA.intronMotifs[0] = trA.intronMotifs[1] = trA.intronMotifs[2] = 0;
-    for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ >= 0) { sjN++; trA.intronMotifs[ex[i].sjStr]++; }
-    if (trA.intronMotifs[1] > 0 && trA.intronMotifs[2] == 0) trA.sjMotifStrand = 1;
-    else if (trA.intronMotifs[1] == 0 && trA.intronMotifs[2] > 0) trA.sjMotifStrand = 2;
-    else trA.sjMotifStrand = 0;
-    if (trA.intronMotifs[1] > 0 && trA.intronMotifs[2] > 0 && P.outFilterIntronStrandsRemoveInconsistent) return;
-    if (sjN > 0 && trA.sjMotifStrand == 0 && P.outSAMstrandFieldIntronMotif) return;
+    u16 intronMotifs[3] = {0, 0, 0};
+    for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ >= 0) { sjN++; u32 s = ex[i].sjStr; if (s == 0) intronMotifs[0]++; else if (s == 1) intronMotifs[1]++; else intronMotifs[2]++; }
+    u8 sjMotifStrand;
+    if (intronMotifs[1] > 0 && intronMotifs[2] == 0) sjMotifStrand = 1;
+    else if (intronMotifs[1] == 0 && intronMotifs[2] > 0) sjMotifStrand = 2;
+    else sjMotifStrand = 0;
+    if (intronMotifs[1] > 0 && intronMotifs[2] > 0 && P.outFilterIntronStrandsRemoveInconsistent) return;
+    if (sjN > 0 && sjMotifStrand == 0 && P.outSAMstrandFieldIntronMotif) return;
     if (P.outFilterIntronMotifs == 1) { for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ == 0) return; }
     else if (P.outFilterIntronMotifs == 2) { for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ == 0 && ex[i].sjAnnot == 0) return; }
     {
@@ -377,156 +520,377 @@ __device__ static void finalizeTranscript(StitchCtx &c, DTr &trA, int Score, u32
         Score += term;
         Score = max(0, Score);
     }
-    trA.roStart = (Str == 0) ? trA.rStart : Lread - trA.rStart - trA.rLength;
-    trA.maxScore = Score;
-    if (ex[0].iFrag == ex[ne - 1].iFrag) { trA.iFrag = ex[0].iFrag; c.maxScoreMate[trA.iFrag] = max(c.maxScoreMate[trA.iFrag], Score); }
-    else trA.iFrag = -1;
-    DTr *T = wr.T; u16 *idx = wr.idx;
-    if (Score + P.outFilterMultimapScoreRange >= T[idx[0]].maxScore
-        || (trA.iFrag >= 0 && Score + P.outFilterMultimapScoreRange >= c.maxScoreMate[trA.iFrag]) || P.chimSegmentMinPositive) {
-        u32 iTr = 0;
-        trA.mappedLength = 0;
-        for (u32 i = 0; i < ne; i++) trA.mappedLength += ex[i].L;
-        u32 &nWinTr = wr.nWinTr;
-        while (iTr < nWinTr) {
-            DTr &o = T[idx[iTr]];
-            u32 nOverlap = blocksOverlap(trA, o);
-            u32 uNew = trA.mappedLength - nOverlap, uOld = o.mappedLength - nOverlap;
-            if (uNew == 0 && Score < o.maxScore) break;
-            else if (uOld == 0) { u16 p = idx[iTr]; for (u32 ii = iTr + 1; ii < nWinTr; ii++) idx[ii - 1] = idx[ii]; nWinTr--; idx[nWinTr] = p; }
-            else if (uOld > 0 && (uNew > 0 || Score >= o.maxScore)) iTr++;
+    i32 iFragT;
+    if (ex[0].iFrag == ex[ne - 1].iFrag) { iFragT = ex[0].iFrag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
+    else iFragT = -1;
+    i32 winBest = wr.nWinTr > 0 ? recT(wr, 0)->maxScore : 0;            // wTr[0]->maxScore (trA with score 0 before any record)
+    {
+        bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
+        bool c2 = iFragT >= 0 && Score + P.outFilterMultimapScoreRange >= c.maxScoreMate[iFragT];
+        if (!(c1 || c2)) return;
+        // decided by the maxScoreMate clause alone: the decision holds for any incoming maxScoreMate <= Score + range
+        if (!c1) c.sens[iFragT] = min(c.sens[iFragT], Score + P.outFilterMultimapScoreRange);
+    }
+    const u32 mappedLength = rLength;
+    // ---- de-duplication against the recorded transcripts (:267-285): lane k classifies record k
+    //   BLOCK  new one adds nothing to record k and scores lower  -> the walk over the list stops, new one is dropped
+    //   REMOVE record k adds nothing to the new one                -> record k is removed (if met before a BLOCK)
+    {
+        const u32 nW0 = wr.nWinTr;
+        u32 outN = 0; bool blocked = false; u32 base = 0;
+        for (; base < nW0 && !blocked; base += NLANE) {
+            u32 k = base + lane; bool have = k < nW0;
+            u16 rk = 0; u32 cls = 0;
+            if (have) {
+                rk = wr.rank[k];
+                const staramd_transcript *o = recAt(wr, rk);
+                u32 nOverlap = blocksOverlap(ex, ne, (const staramd_exon *)((const u8 *)o + REC_HDR), o->nExons);
+                u32 uNew = mappedLength - nOverlap, uOld = o->mappedLength - nOverlap;
+                if (uNew == 0 && Score < o->maxScore) cls = 1; else if (uOld == 0) cls = 2;
+            }
+            u64 mB = __ballot(cls == 1), mR = __ballot(cls == 2), mH = __ballot(have);
+            if (mB) { u32 fb = firstLane(mB); blocked = true; mR &= (1ull << fb) - 1ull; }
+            u64 keep = mH & ~mR;
+            if (have && ((keep >> lane) & 1ull)) wr.rank[outN + cntBelow(keep)] = rk;
+            outN += (u32)__popcll(keep);
         }
-        if (iTr == nWinTr) {
-            for (iTr = 0; iTr < nWinTr; iTr++) { DTr &o = T[idx[iTr]]; if (Score > o.maxScore || (Score == o.maxScore && trA.gLength < o.gLength)) break; }
-            u16 p = idx[nWinTr];
-            for (int ii = (int)nWinTr; ii > (int)iTr; ii--) idx[ii] = idx[ii - 1];
-            idx[iTr] = p;
-            copyTr(&T[p], &trA);
-            if (nWinTr < P.alignTranscriptsPerWindowNmax) nWinTr++;
+        if (blocked) {                                   // entries behind the blocking chunk keep their order
+            for (; base < nW0; base += NLANE) {
+                u32 k = base + lane; bool have = k < nW0;
+                u16 rk = have ? wr.rank[k] : (u16)0;
+                if (have) wr.rank[outN + lane] = rk;
+                outN += min(NLANE, nW0 - base);
+            }
+            wr.nWinTr = outN;
+            __threadfence_block();
+            return;
         }
+        wr.nWinTr = outN;
+        __threadfence_block();
+    }
+    // ---- ranked insert (:287-303)
+    u32 iTr = wr.nWinTr;
+    for (u32 base = 0; base < wr.nWinTr; base += NLANE) {
+        u32 k = base + lane; bool better = false;
+        if (k < wr.nWinTr) { const staramd_transcript *o = recT(wr, k); better = Score > o->maxScore || (Score == o->maxScore && gLength < o->gLength); }
+        u64 bm = __ballot(better);
+        if (bm) { iTr = base + firstLane(bm); break; }
+    }
+    if (iTr >= P.alignTranscriptsPerWindowNmax) return;          // ranks behind a full list: dropped
+    u32 need = REC_HDR + 32u * ne;
+    if (wr.top + need > wr.arenaBytes) {
+        u32 nt = 0;
+        if (lane == 0) nt = compactArena(wr);
+        wr.top = first32(nt);
+        __threadfence_block();
+        // also give up when the live set alone fills 3/4 of the arena: the next leaves would compact over and over
+        if (wr.top + need > wr.arenaBytes || wr.top * 4u > wr.arenaBytes * 3u) { wr.overflow = true; return; }
+    }
+    u32 off = wr.top; wr.top += need;
+    u32 newN = min(wr.nWinTr + 1, P.alignTranscriptsPerWindowNmax);
+    for (int top = (int)newN - 1; top > (int)iTr; top -= (int)NLANE) {        // shift ranks iTr..newN-2 up by one
+        int k = top - (int)lane;
+        u16 v = 0; bool mv = k > (int)iTr;
+        if (mv) v = wr.rank[k - 1];
+        if (mv) wr.rank[k] = v;
+    }
+    if (lane == 0) wr.rank[iTr] = (u16)(off / 32u);
+    wr.nWinTr = newN;
+    if (lane == 0) {
+        staramd_transcript o;
+        { u64 *z = (u64 *)&o; for (u32 i = 0; i < REC_HDR / 8; i++) z[i] = 0; }          // padding included: records are compared byte for byte
+        o.iW = 0; o.exonOffset = 0;
+        o.nExons = (u16)ne; o.rStart = (u16)h.rStart; o.rLength = (u16)rLength;
+        o.roStart = (u16)((Str == 0) ? h.rStart : Lread - h.rStart - rLength);
+        o.Str = (u8)Str; o.roStr = (u8)Str; o.iFrag = (i8)iFragT; o.sjMotifStrand = sjMotifStrand; o.Chr = chr;
+        o.gStart = h.gStart; o.gLength = gLength; o.maxScore = Score; o.nMatch = h.nMatch; o.nMM = h.nMM; o.mappedLength = mappedLength;
+        o.nGap = h.nGap; o.lGap = h.lGap; o.nDel = h.nDel; o.lDel = h.lDel; o.nIns = h.nIns; o.lIns = h.lIns;
+        o.nUnique = (u16)h.nUnique; o.nAnchor = (u16)h.nAnchor;
+        o.intronMotifs[0] = intronMotifs[0]; o.intronMotifs[1] = intronMotifs[1]; o.intronMotifs[2] = intronMotifs[2]; o.pad0 = 0; o.pad1 = 0;
+        *(staramd_transcript *)(wr.arena + off) = o;
+    }
+    if (lane < ne) {
+        staramd_exon x = ex[lane];
+        if (lane + 1 == ne) { x.canonSJ = 0; x.sjAnnot = 0; x.sjStr = 0; x.shiftSJ[0] = x.shiftSJ[1] = 0; }
+        else if (x.canonSJ < 0) { x.shiftSJ[0] = x.shiftSJ[1] = 0; }
+        x.pad0 = 0; x.pad1 = 0;
+        ((staramd_exon *)(wr.arena + off + REC_HDR))[lane] = x;
+    }
+    __threadfence_block();
+}
+
+// per-window work space, in bytes
+__host__ __device__ inline u32 stitchLaneBytes(u32 capDepth, u32 capRank, u32 arenaBytes) {
+    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + arenaBytes;
+    return (b + 127u) & ~127u;
+}
+
+struct LaneMem { SFrame *stack; staramd_exon *EX, *LEAF; };
+
+// depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321):
+// include seed iA (if it stitches), then exclude it.  Wave-uniform control flow.  Returns false when the arena overflowed.
+__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const DWA *WA, const LaneMem &m, WinRec &wr) {
+    const u32 nA = win.nWA;
+    c.str = win.str;
+    wr.nWinTr = 0; wr.top = 0; wr.overflow = false;
+    SFrame *stack = m.stack; staramd_exon *EX = m.EX, *LEAF = m.LEAF;
+    Hdr h; h.gStart = 0; h.tG2 = 0; h.nExons = 0; h.Score = 0; h.nMatch = h.nMM = h.nGap = h.lGap = h.nDel = h.lDel = h.nIns = h.lIns = 0;
+    h.nUnique = h.nAnchor = 0; h.rStart = 0; h.tR2 = 0;
+    u32 iA = 0; u32 sp = 0; u32 ex0R = 0; u64 ex0G = 0;
+    DWA a; a = WA[0];
+    for (;;) {
+        c.nNodes++;
+        if (iA >= nA) {                              // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
+            if (h.tR2 != 0) {
+                if (lane < h.nExons) LEAF[lane] = EX[lane];
+                __threadfence_block();
+                finalizeTranscript(c, lane, h, LEAF, win.chr, wr);
+                if (wr.overflow) return false;
+            }
+            if (sp == 0) break;
+            sp--;                                    // back to the frame that included a seed: now exclude it
+            const SFrame &f = stack[sp];
+            h = f.h; iA = f.iA + 1;
+            if (h.nExons > 0 && lane == 0) EX[h.nExons - 1] = f.eA;
+            __threadfence_block();
+            if (iA < nA) a = WA[iA];
+            continue;
+        }
+        // ---- include branch (:311-345)
+        Hdr hn = h; staramd_exon eA, eN; bool added = false; int dScore;
+        if (h.nExons > 0) {
+            eA = EX[h.nExons - 1];
+            staramd_exon eAold = eA;
+#ifdef STARAMD_SHADOW
+            Hdr hs = h; staramd_exon eAs = eA, eNs; bool addedS = false;
+#endif
+            dScore = coopStitch(c, lane, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G);
+#ifdef STARAMD_SHADOW
+            {   // every lane re-runs the call through the scalar restatement (same inputs): any disagreement is counted
+                int dS = stitchAlignToTranscript(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hs, eAs, eNs, addedS, ex0R, ex0G);
+                bool bad = dS != dScore;
+                if (!bad && dS > -1000000) {
+                    bad = hs.nMatch != hn.nMatch || hs.nMM != hn.nMM || hs.nGap != hn.nGap || hs.lGap != hn.lGap || hs.nDel != hn.nDel || hs.lDel != hn.lDel || hs.nIns != hn.nIns || hs.lIns != hn.lIns
+                          || addedS != added || eAs.L != eA.L || eAs.canonSJ != eA.canonSJ || eAs.sjAnnot != eA.sjAnnot || eAs.sjStr != eA.sjStr || eAs.iFrag != eA.iFrag || eAs.sjA != eA.sjA;
+                    if (!bad && eA.canonSJ >= 0 && added) bad = eAs.shiftSJ[0] != eA.shiftSJ[0] || eAs.shiftSJ[1] != eA.shiftSJ[1];
+                    if (!bad && added) bad = eNs.G != eN.G || eNs.R != eN.R || eNs.L != eN.L || eNs.iFrag != eN.iFrag || eNs.sjA != eN.sjA;
+                }
+                if (lane == 0) { if (bad) atomicAdd((unsigned long long *)&c.shadow[0], 1ull); atomicAdd((unsigned long long *)&c.shadow[1], 1ull); }
+            }
+#endif
+            if (dScore > -1000000) {
+                if (lane == 0) {
+                    SFrame &f = stack[sp]; f.h = h; f.iA = iA; f.pad = 0; f.eA = eAold;
+                    EX[h.nExons - 1] = eA;
+                    if (added) EX[h.nExons] = eN;
+                }
+                if (added) hn.nExons = h.nExons + 1;
+            }
+        } else {                                     // first seed of the transcript (:318-334)
+            eN.R = a.rStart; eN.G = a.gStart; eN.L = a.L; eN.iFrag = a.iFrag; eN.sjA = a.sjA;
+            eN.canonSJ = 0; eN.sjAnnot = 0; eN.sjStr = 0; eN.shiftSJ[0] = eN.shiftSJ[1] = 0; eN.pad0 = 0; eN.pad1 = 0;
+            if (lane == 0) { SFrame &f = stack[sp]; f.h = h; f.iA = iA; f.pad = 0; EX[0] = eN; }
+            hn.rStart = a.rStart; hn.gStart = a.gStart; hn.nExons = 1; hn.nMatch = a.L;
+            dScore = a.L;
+        }
+        if (dScore > -1000000) {
+            if (a.nrep == 1) hn.nUnique++;
+            if (a.anchor > 0) hn.nAnchor++;
+            hn.Score = h.Score + dScore; hn.tR2 = (u32)a.rStart + a.L - 1; hn.tG2 = a.gStart + a.L - 1;
+            if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; }
+            h = hn; sp++;
+            __threadfence_block();
+        }
+        // include succeeded: continue below it; include failed: exclude branch (:348-351) = same transcript, next seed
+        iA++;
+        if (iA < nA) a = WA[iA];
+    }
+    return true;
+}
+
+// copy the window's recorded transcripts (trAll[iW1][0..nWinTr-1]) into the result pools; false on pool overflow
+__device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o) {
+    u32 nTr = wr.nWinTr, nEx = 0;
+    o.trOffset = 0; o.nTr = 0; o.exOffset = 0; o.nEx = 0; o.headScore = 0; o.headGlen = 0;
+    if (nTr == 0) return true;
+    for (u32 k = 0; k < nTr; k++) nEx += recT(wr, k)->nExons;
+    u32 to = 0, eo = 0;
+    if (lane == 0) { to = atomicAdd(&B.cursors[CUR_TR], nTr); eo = atomicAdd(&B.cursors[CUR_EX], nEx); }
+    to = first32(to); eo = first32(eo);
+    if (to + nTr > B.trCap || eo + nEx > B.exCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_TRPOOL); return false; }
+    const staramd_transcript *hd = recT(wr, 0);
+    o.trOffset = to; o.nTr = nTr; o.exOffset = eo; o.nEx = nEx; o.headScore = hd->maxScore; o.headGlen = hd->gLength;
+    u32 eoff = 0;
+    for (u32 k = 0; k < nTr; k++) {
+        const u64 *s = (const u64 *)recT(wr, k);
+        u32 ne = recT(wr, k)->nExons;
+        u64 *dt = (u64 *)&B.trPool[to + k];
+        if (lane < REC_HDR / 8) {
+            u64 v = s[lane];
+            if (lane == 0) v = (v & 0xFFFFFFFFull) | ((u64)eoff << 32);       // exonOffset relative to the window block; k_gather rebases it and sets iW
+            dt[lane] = v;
+        }
+        u64 *de = (u64 *)&B.exPool[eo + eoff];
+        for (u32 i = lane; i < ne * 4; i += NLANE) de[i] = s[REC_HDR / 8 + i];
+        eoff += ne;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void laneSetup(u8 *mine, u32 capDepth, u32 capRank, u32 arenaBytes, LaneMem &m, WinRec &wr) {
+    m.stack = (SFrame *)mine;
+    m.EX = (staramd_exon *)(mine + (u64)capDepth * sizeof(SFrame));
+    m.LEAF = m.EX + STARAMD_MAX_N_EXONS;
+    wr.rank = (u16 *)(m.LEAF + STARAMD_MAX_N_EXONS); wr.arena = (u8 *)wr.rank + ((capRank * 2u + 31u) & ~31u); wr.arenaBytes = arenaBytes;
+}
+
+__device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
+    c.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
+    c.readLength[0] = B.mate1Length[ir]; c.readLength[1] = P.readNmates == 2 ? c.Lread - c.readLength[0] - 1 : 0;
+    c.mmMaxTotal = B.mmMaxTotal[ir];
+    const u32 *src = B.packed + (u64)ir * B.packWords;       // stage the 4-bit packed read in this wavefront's LDS slice
+    u32 nw = (c.Lread + 7) / 8;
+    u32 *dst = (u32 *)((u8 *)ldsReads + c.ldsByte);
+    for (u32 k = lane; k < nw; k += NLANE) dst[k] = src[k];
+    __threadfence_block();
+}
+
+// ---- stitch, one wavefront per WINDOW -------------------------------------------------------------------------------
+// Windows of a read are independent except for maxScoreMate[] (stitchWindowAligns.cpp:232-247), which a window only
+// consults to decide whether a single-mate transcript that is NOT within range of the window's best is still recorded.
+// Pass 0 stitches every window with an incoming maxScoreMate of 0 and remembers, per mate, the weakest leaf whose
+// recording hung on that clause (DWinOut::sens).  k_stitch_verify then forms the true incoming values (a prefix maximum
+// of DWinOut::mm over the windows of the read, which does not depend on what was recorded) and queues for pass 1 only
+// the windows whose decisions could differ.  mode: 0 = pass 0, 1 = pass 1; big: worst-case arena, reads the overflow list.
+extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capDepth, u32 capRank, u32 arenaBytes,
+                                                             u32 ldsWords, u32 mode, u32 big) {
+    const DevIndex &X = *Xp;
+    const staramd_params &P = X.P;
+    const u32 lane = threadIdx.x & 63u;
+    u32 waveInBlock = threadIdx.x >> 6, wavesPerBlock = blockDim.x >> 6;
+    u32 stateBytes = stitchLaneBytes(capDepth, capRank, arenaBytes);
+    u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
+    LaneMem m; WinRec wr;
+    StitchCtx c; c.X = &X; c.nGstitch = 0; c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = 0;
+#ifdef STARAMD_SHADOW
+    c.shadow = B.counters + DC_shadowBad;
+#endif
+    if (big) {
+        c.ldsByte = waveInBlock * readBytes;
+        laneSetup(scratch + (u64)(blockIdx.x * wavesPerBlock + waveInBlock) * stateBytes, capDepth, capRank, arenaBytes, m, wr);
+    } else {
+        c.ldsByte = waveInBlock * (readBytes + stateBytes);
+        laneSetup((u8 *)ldsReads + c.ldsByte + readBytes, capDepth, capRank, arenaBytes, m, wr);
+    }
+    gcInit(c.ca); gcInit(c.cb);
+    const u32 *list; u32 nItems, ticketSlot, ovfSlot; u32 *ovfList;
+    if (mode == 0) {
+        if (!big) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
+        else { list = B.ovfSt0; nItems = B.cursors[CUR_ST_OVF0]; ticketSlot = CUR_ST_TICKET0B; }
+        ovfSlot = CUR_ST_OVF0; ovfList = B.ovfSt0;
+    } else {
+        if (!big) { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
+        else { list = B.ovfSt1; nItems = B.cursors[CUR_ST_OVF1]; ticketSlot = CUR_ST_TICKET1B; }
+        ovfSlot = CUR_ST_OVF1; ovfList = B.ovfSt1;
+    }
+    u32 nOvf = 0, lastRead = 0xFFFFFFFFu;
+    for (;;) {
+        u32 it = 0;
+        if (lane == 0) it = atomicAdd(&B.cursors[ticketSlot], 1u);
+        it = first32(it);
+        if (it >= nItems) break;
+        u32 w = list[it];
+        if (w == 0xFFFFFFFFu) continue;                 // padding slot of the dealt order
+        const DWin win = B.winPool[w];
+        if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
+        DWinOut o = B.wout[w];
+        if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; }
+        c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
+        c.sens[0] = c.sens[1] = 0x7FFFFFFF;
+        if (win.nWA + 1u > capDepth) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+        bool ok = stitchWindow(c, lane, win, B.waPool + win.waOffset, m, wr);
+        if (!ok) {
+            if (lane == 0) {
+                if (big) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD);
+                else { u32 k = atomicAdd(&B.cursors[ovfSlot], 1u); ovfList[k] = w; }
+            }
+            nOvf++;
+            continue;
+        }
+        if (!flushWindow(B, lane, wr, o)) continue;
+        o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
+        o.sens[0] = c.sens[0]; o.sens[1] = c.sens[1]; o.done = 1;
+        if (lane == 0) B.wout[w] = o;
+    }
+    if (lane == 0) {
+        atomicAdd((unsigned long long *)&B.counters[DC_nGstitch], (unsigned long long)c.nGstitch);
+        atomicAdd((unsigned long long *)&B.counters[DC_nStitchCalls], (unsigned long long)c.nStitchCalls);
+        atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);
+        atomicAdd((unsigned long long *)&B.counters[DC_nNodes], (unsigned long long)c.nNodes);
+        atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
+        if (nOvf && !big) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256) k_stitch(DevIndex X, DevBatch B, u8 *scratch, u32 capDepth, u32 capTr) {
-    u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const staramd_params &P = X.P;
-    u64 perLane = (u64)capDepth * sizeof(Frame) + (u64)capTr * sizeof(DTr) + (u64)capTr * sizeof(u16);
-    perLane = (perLane + 15) & ~15ull;
-    Frame *stack = (Frame *)(scratch + (u64)lane * perLane);
-    WinRec wr; wr.T = (DTr *)((u8 *)stack + (u64)capDepth * sizeof(Frame)); wr.idx = (u16 *)((u8 *)wr.T + (u64)capTr * sizeof(DTr));
-    StitchCtx c; c.X = &X; c.nGstitch = c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = 0;
-    u64 nTrOut = 0;
-    for (;;) {
-        u32 ir = atomicAdd(&B.cursors[10], 1u);
-        if (ir >= B.nReads) break;
-        DRead rd = B.reads[ir];
-        if (rd.nWin == 0) {
-            if (rd.nSeeds > 0 && !(rd.status & (STARAMD_ST_SCRATCH_OVERFLOW | STARAMD_ST_NO_GOOD_WINDOW))) { rd.status |= STARAMD_ST_NO_GOOD_WINDOW; B.reads[ir] = rd; }
-            continue;
+// ---- per read: true incoming maxScoreMate of every window; queue the windows whose pass-0 result may differ ----
+extern "C" __global__ void __launch_bounds__(256) k_stitch_verify(const DevIndex *__restrict__ Xp, DevBatch B) {
+    u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ir >= B.nReads) return;
+    const DRead rd = B.reads[ir];
+    if (rd.nWin == 0) return;
+    i32 M0 = 0, M1 = 0; u32 nRedo = 0;
+    for (u32 iw = 0; iw < rd.nWin; iw++) {
+        u32 w = rd.winOffset + iw;
+        DWinOut o = B.wout[w];
+        if (o.sens[0] < M0 || o.sens[1] < M1) {
+            o.minIn[0] = M0; o.minIn[1] = M1; B.wout[w] = o;
+            u32 k = atomicAdd(&B.cursors[CUR_ST_REDO], 1u); B.redoList[k] = w; nRedo++;
         }
-        c.R0 = B.bases + B.readOffset[ir]; c.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
-        c.readLength[0] = B.mate1Length[ir]; c.readLength[1] = P.readNmates == 2 ? c.Lread - c.readLength[0] - 1 : 0;
-        c.mmMaxTotal = B.mmMaxTotal[ir];
-        c.maxScoreMate[0] = c.maxScoreMate[1] = 0;
-        u32 wtBase = atomicAdd(&B.cursors[3], rd.nWin);
-        if (wtBase + rd.nWin > B.wtCap) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[6], 8u); B.reads[ir] = rd; continue; }
-        u32 nWt = 0, trNtotal = 0, exTotal = 0; int bestScore = 0; u64 bestGlen = 0; i32 bestW = -1; bool overflow = false;
-        for (u32 iw = 0; iw < rd.nWin; iw++) {
-            const DWin win = B.winPool[rd.winOffset + iw];
-            const DWA *WA = B.waPool + win.waOffset;
-            u32 nA = win.nWA;
-            if (trNtotal + P.alignTranscriptsPerWindowNmax >= P.alignTranscriptsPerReadNmax) { rd.status |= STARAMD_ST_TR_PER_READ_LIMIT; break; }
-            if (nA + 1 > capDepth || P.alignTranscriptsPerWindowNmax + 1 > capTr) { overflow = true; break; }
-            c.str = win.str;
-            // wTr[0] = trA (maxScore 0, gLength 0): ReadAlign_stitchPieces.cpp:295
-            for (u32 k = 0; k <= P.alignTranscriptsPerWindowNmax; k++) wr.idx[k] = (u16)k;
-            wr.nWinTr = 0; wr.T[0].maxScore = 0; wr.T[0].gLength = 0; wr.T[0].nExons = 0; wr.T[0].mappedLength = 0;
-            // root frame
-            Frame *f = &stack[0];
-            {
-                u64 *z = (u64 *)&f->tr; for (u32 k = 0; k < sizeof(DTr) / 8; k++) z[k] = 0;
-                f->Score = 0; f->tR2 = 0; f->tG2 = 0; f->iA = 0; f->state = 0;
-            }
-            int sp = 0;
-            while (sp >= 0) {
-                f = &stack[sp];
-                c.nNodes++;
-                if (f->iA >= nA) {                       // stitchWindowAligns.cpp:14-16
-                    if (f->tR2 != 0) finalizeTranscript(c, f->tr, f->Score, f->tR2, f->tG2, win.chr, wr);
-                    sp--;
-                    continue;
-                }
-                if (f->state == 0) {
-                    f->state = 1;
-                    u32 iA = f->iA;
-                    const DWA a = WA[iA];
-                    Frame *n = &stack[sp + 1];
-                    copyTr(&n->tr, &f->tr);
-                    int dScore = 0;
-                    if (f->tr.nExons > 0) {
-                        dScore = stitchAlignToTranscript(c, f->tR2, f->tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, &n->tr);
-                    } else {                             // first align of the transcript (:318-334)
-                        staramd_exon &e0 = n->tr.ex[0];
-                        e0.R = a.rStart; e0.G = a.gStart; e0.L = a.L; e0.iFrag = a.iFrag; e0.sjA = a.sjA;
-                        e0.canonSJ = 0; e0.sjAnnot = 0; e0.sjStr = 0; e0.shiftSJ[0] = e0.shiftSJ[1] = 0; e0.pad0 = 0;
-                        n->tr.rStart = a.rStart; n->tr.gStart = a.gStart; n->tr.nExons = 1;
-                        dScore = a.L; n->tr.nMatch = a.L;
-                    }
-                    if (dScore > -1000000) {
-                        if (a.nrep == 1) n->tr.nUnique++;
-                        if (a.anchor > 0) n->tr.nAnchor++;
-                        n->Score = f->Score + dScore; n->tR2 = (u32)a.rStart + a.L - 1; n->tG2 = a.gStart + a.L - 1; n->iA = iA + 1; n->state = 0;
-                        sp++;
-                        continue;
-                    }
-                }
-                // exclude branch (:348-351): same transcript, next seed -- tail call
-                f->iA++; f->state = 0;
-            }
-            if (wr.nWinTr == 0) continue;
-            // ---- record the window's transcripts (trAll[iW1][0..nWinTr-1]) into the pools
-            u32 nTr = wr.nWinTr, nEx = 0;
-            for (u32 k = 0; k < nTr; k++) nEx += wr.T[wr.idx[k]].nExons;
-            u32 to = atomicAdd(&B.cursors[4], nTr), eo = atomicAdd(&B.cursors[5], nEx);
-            if (to + nTr > B.trCap || eo + nEx > B.exCap) { overflow = true; atomicOr(&B.cursors[6], 16u); break; }
-            const DTr &h = wr.T[wr.idx[0]];
-            if (h.maxScore > bestScore || (h.maxScore == bestScore && h.gLength < bestGlen)) { bestW = (i32)nWt; bestScore = h.maxScore; bestGlen = h.gLength; }
-            DWinTr d; d.read = ir; d.trOffset = to; d.nTr = nTr; d.exOffset = eo; d.nEx = nEx; d.chr = win.chr; d.str = win.str; d.pad[0] = d.pad[1] = d.pad[2] = 0;
-            B.wtPool[wtBase + nWt] = d;
-            u32 eoff = 0;
-            for (u32 k = 0; k < nTr; k++) {
-                const DTr &t = wr.T[wr.idx[k]];
-                staramd_transcript o;
-                o.iW = nWt; o.exonOffset = eoff;          // relative to the block; k_gather rebases it
-                o.nExons = (u16)t.nExons; o.rStart = (u16)t.rStart; o.rLength = (u16)t.rLength; o.roStart = (u16)t.roStart;
-                o.Str = win.str; o.roStr = win.str; o.iFrag = (i8)t.iFrag; o.sjMotifStrand = t.sjMotifStrand; o.Chr = win.chr;
-                o.gStart = t.gStart; o.gLength = t.gLength; o.maxScore = t.maxScore; o.nMatch = t.nMatch; o.nMM = t.nMM; o.mappedLength = t.mappedLength;
-                o.nGap = t.nGap; o.lGap = t.lGap; o.nDel = t.nDel; o.lDel = t.lDel; o.nIns = t.nIns; o.lIns = t.lIns;
-                o.nUnique = (u16)t.nUnique; o.nAnchor = (u16)t.nAnchor;
-                o.intronMotifs[0] = t.intronMotifs[0]; o.intronMotifs[1] = t.intronMotifs[1]; o.intronMotifs[2] = t.intronMotifs[2]; o.pad0 = 0;
-                B.trPool[to + k] = o;
-                for (u32 ie = 0; ie < t.nExons; ie++) {
-                    staramd_exon e = t.ex[ie];
-                    if (ie + 1 == t.nExons) { e.canonSJ = 0; e.sjAnnot = 0; e.sjStr = 0; e.shiftSJ[0] = e.shiftSJ[1] = 0; }
-                    else if (e.canonSJ < 0) { e.shiftSJ[0] = e.shiftSJ[1] = 0; }
-                    e.pad0 = 0;
-                    B.exPool[eo + eoff + ie] = e;
-                }
-                eoff += t.nExons;
-            }
-            nWt++; trNtotal += nTr; exTotal += nEx;
-        }
-        if (overflow) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[6], 32u); B.reads[ir] = rd; continue; }
-        if (bestScore == 0) { rd.status |= STARAMD_ST_NO_GOOD_WINDOW; nWt = 0; trNtotal = 0; exTotal = 0; bestW = -1; }   // :344-348
-        rd.wtOffset = wtBase; rd.nWt = nWt; rd.nTr = trNtotal; rd.nEx = exTotal; rd.bestW = bestW;
-        rd.maxScoreMate[0] = c.maxScoreMate[0]; rd.maxScoreMate[1] = c.maxScoreMate[1];
-        B.reads[ir] = rd;
-        nTrOut += trNtotal;
+        M0 = max(M0, o.mm[0]); M1 = max(M1, o.mm[1]);
     }
-    atomicAdd((unsigned long long *)&B.counters[DC_nGstitch], (unsigned long long)c.nGstitch);
-    atomicAdd((unsigned long long *)&B.counters[DC_nStitchCalls], (unsigned long long)c.nStitchCalls);
-    atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);
-    atomicAdd((unsigned long long *)&B.counters[DC_nNodes], (unsigned long long)c.nNodes);
-    atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
-    atomicAdd((unsigned long long *)&B.counters[DC_nTrOut], (unsigned long long)nTrOut);
+    if (nRedo) atomicAdd((unsigned long long *)&B.counters[DC_nRedoWin], (unsigned long long)nRedo);
+}
+
+// ---- per read: totals, trBest, maxScoreMate (ReadAlign_stitchPieces.cpp:288-348) ----
+// alignTranscriptsPerReadNmax (:290-294) stops the reference's walk before window k when the transcripts recorded so
+// far reach the limit; windows < k do not depend on windows >= k, so the exact result is the prefix.
+extern "C" __global__ void __launch_bounds__(256) k_stitch_finish(const DevIndex *__restrict__ Xp, DevBatch B) {
+    const staramd_params &P = Xp->P;
+    u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ir >= B.nReads) return;
+    DRead rd = B.reads[ir];
+    if (rd.nWin == 0) {
+        if (rd.nSeeds > 0 && !(rd.status & (STARAMD_ST_SCRATCH_OVERFLOW | STARAMD_ST_NO_GOOD_WINDOW))) { rd.status |= STARAMD_ST_NO_GOOD_WINDOW; B.reads[ir] = rd; }
+        return;
+    }
+    u32 nWt = 0, nTr = 0, nEx = 0; int bestScore = 0; u64 bestGlen = 0; i32 bestW = -1; i32 M0 = 0, M1 = 0;
+    for (u32 iw = 0; iw < rd.nWin; iw++) {
+        if (nTr + P.alignTranscriptsPerWindowNmax >= P.alignTranscriptsPerReadNmax) {
+            rd.status |= STARAMD_ST_TR_PER_READ_LIMIT;
+            for (; iw < rd.nWin; iw++) { B.wout[rd.winOffset + iw].nTr = 0; B.wout[rd.winOffset + iw].nEx = 0; }
+            break;
+        }
+        const DWinOut o = B.wout[rd.winOffset + iw];
+        M0 = max(M0, o.mm[0]); M1 = max(M1, o.mm[1]);
+        if (o.nTr == 0) continue;
+        if (o.headScore > bestScore || (o.headScore == bestScore && o.headGlen < bestGlen)) { bestW = (i32)nWt; bestScore = o.headScore; bestGlen = o.headGlen; }
+        nWt++; nTr += o.nTr; nEx += o.nEx;
+    }
+    if (bestScore == 0) { rd.status |= STARAMD_ST_NO_GOOD_WINDOW; nWt = 0; nTr = 0; nEx = 0; bestW = -1; }   // :344-348
+    rd.nWt = nWt; rd.nTr = nTr; rd.nEx = nEx; rd.bestW = bestW;
+    rd.maxScoreMate[0] = M0; rd.maxScoreMate[1] = M1;
+    B.reads[ir] = rd;
+    if (nTr) atomicAdd((unsigned long long *)&B.counters[DC_nTrOut], (unsigned long long)nTr);
+}
+
+// 4-bit packing of the combined reads for LDS staging: one block per read
+extern "C" __global__ void __launch_bounds__(64) k_pack_reads(DevBatch B, u32 *packed, u32 packWords) {
+    u32 ir = blockIdx.x;
+    const u8 *R = B.bases + B.readOffset[ir];
+    u32 L = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
+    for (u32 w = threadIdx.x; w < packWords; w += blockDim.x) {
+        u32 v = 0;
+        for (u32 k = 0; k < 8; k++) { u32 j = w * 8 + k; u32 cde = j < L ? (R[j] & 15u) : 15u; v |= cde << (4 * k); }
+        packed[(u64)ir * packWords + w] = v;
+    }
 }

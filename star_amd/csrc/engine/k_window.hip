@@ -1,4 +1,4 @@
-// k_window.hip -- kernel 2: alignment windows and seed-to-window assignment.
+// k_window.hip -- kernel 2: alignment windows and seed-to-window assignment, one wavefront per read.
 //
 // Replaces, per read, the first half of ReadAlign::stitchPieces (source/ReadAlign_stitchPieces.cpp:12-185):
 //   pass A  anchors create / merge windows     createExtendWindowsWithAlign (ReadAlign_createExtendWindowsWithAlign.cpp:7-84)
@@ -6,134 +6,155 @@
 //   pass B  every seed locus is assigned to a window  assignAlignToWindow   (ReadAlign_assignAlignToWindow.cpp:6-130)
 //   sjdb    loci inside the inserted junction sequences are split           (sjAlignSplit.cpp:3-15)
 //
-// The reference keeps a 2 x winBinN uint16 map (195 KB for human) that it memsets per read.  Here
-// the map is never materialised: during pass A live windows are disjoint bin intervals, so
-// "which window owns bin b" is an interval test over the read's (few) windows; after the flank
-// extension the owner is the LAST flank writer, else the core owner -- exactly what the
-// reference's write order into winBin produces.
-// Mapping: one lane = one read; the SA intervals of a seed are contiguous so neighbouring
-// iterations of a lane hit the same 64-byte line of the packed SA.
+// The reference keeps a 2 x winBinN uint16 map (195 KB for human) that it memsets per read.  Here the map is never
+// materialised: during pass A live windows are disjoint bin intervals, so "which window owns bin b" is an interval
+// test over the read's (few) windows; after the flank extension the owner is the LAST flank writer, else the core
+// owner -- exactly what the reference's write order into winBin produces.
+//
+// Mapping: one wavefront (64 lanes) per read.
+//   * the SA interval of a seed is enumerated 64 entries at a time: lane i reads entry i of the chunk, so a
+//     chunk is one or two coalesced 33-bit-packed loads per lane from consecutive words of SA;
+//   * every lane converts its locus (strand flip, sjdb split) and looks its bin up in the window table, which
+//     lives in LDS (all lanes read the same table row: broadcast, no bank conflicts);
+//   * a ballot collects the lanes whose locus hit a window; the hits are replayed one by one in SA order
+//     (the reference's order: replacement / eviction rules are order dependent), and each replay step is itself
+//     wave-parallel: lane j holds row j of the window's seed list (<= 64 rows), the overlap test is one ballot,
+//     the sorted insert is one shifted store;
+//   * pass A replays the anchor loci in order the same way; the search for the nearest window left/right of a
+//     new bin is a wave-wide max/min reduction over the table rows.
+// Reads that need more windows / seed-list blocks than the compact per-wave work space are deferred to a second
+// launch of the same kernel (big = 1) whose table lives in global memory with the reference's own limits.
 #include "dev.h"
-
-
-struct WinState {
-    const DevIndex *X;
-    WScr *W; u32 nW; u32 capW;
-    DWA *arena; u32 nBlocks; u32 capBlocks; u32 blockSize;
-    bool tooManyAnchors, windowsLimit, overflow;
-    u32 Lread;
-};
 
 #define NOWIN 0xFFFFFFFFu
 
-// pass-A owner: live windows are disjoint intervals [coreS,coreE]
-__device__ static u32 ownerA(const WinState &s, u32 str, u32 bin) {
-    for (u32 i = 0; i < s.nW; i++) { const WScr &w = s.W[i]; if (w.alive && w.str == str && bin >= w.coreS && bin <= w.coreE) return i; }
-    return NOWIN;
-}
-// pass-B owner: last flank writer wins, else the core owner (ReadAlign_stitchPieces.cpp:96-118 write order)
-__device__ static u32 ownerB(const WinState &s, u32 str, u32 bin) {
-    u32 core = NOWIN, flank = NOWIN;
-    for (u32 i = 0; i < s.nW; i++) {
-        const WScr &w = s.W[i];
-        if (!w.alive || w.str != str || bin < w.extS || bin > w.extE) continue;
-        if (bin >= w.coreS && bin <= w.coreE) core = i; else flank = i;
+struct WTab {                       // per-wave window table (structure of arrays; LDS or global)
+    u32 *coreS, *coreE, *extS, *extE, *meta, *blk, *lrec, *nwa;
+};
+// meta = chr << 2 | str << 1 | alive
+struct WS {
+    WTab t; DWA *arena;
+    u32 nW, capW, nBlocks, capBlocks, Lread;
+    bool overflow, tooMany, winLimit;
+};
+
+__device__ __forceinline__ void tabFence() { __threadfence_block(); }
+
+__device__ __forceinline__ u64 waveMax64(u64 v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        u32 lo = (u32)__shfl_xor((int)(u32)v, o, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), o, 64);
+        u64 w = ((u64)hi << 32) | lo; v = w > v ? w : v;
     }
-    return flank != NOWIN ? flank : core;
+    return v;
+}
+__device__ __forceinline__ u32 waveMin32(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) { u32 w = (u32)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
+    return v;
 }
 
-// ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; returns 1 on TOO_MANY_WINDOWS
-__device__ static int createExtendWindowsWithAlign(WinState &s, u64 a1, u32 aStr) {
-    const DevIndex &X = *s.X; const staramd_params &P = X.P;
+// ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; all arguments wave-uniform; returns 1 on TOO_MANY_WINDOWS / overflow
+__device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS &s, u64 a1, u32 aStr, u32 lane) {
+    const staramd_params &P = X.P;
     u32 aBin = (u32)(a1 >> P.winBinNbits);
-    if (ownerA(s, aStr, aBin) != NOWIN) return 0;
+    u32 lo = aBin > P.winAnchorDistNbins ? aBin - P.winAnchorDistNbins : 0;
+    u64 hi = min((u64)aBin + P.winAnchorDistNbins + 1, P.winBinN);     // exclusive
+    bool own = false;
+    u64 candL = 0;                       // (coreE+1) << 32 | index   ; 0 = none
+    u64 candR = 0;                       // (~coreS) << 32 | index    ; 0 = none (max of ~coreS = min coreS)
+    for (u32 j = lane; j < s.nW; j += 64) {
+        u32 m = s.t.meta[j];
+        if (!(m & 1u) || ((m >> 1) & 1u) != aStr) continue;
+        u32 cs = s.t.coreS[j], ce = s.t.coreE[j];
+        if (aBin >= cs && aBin <= ce) own = true;
+        if (aBin > 0 && ce < aBin && ce >= lo) { u64 v = ((u64)(ce + 1) << 32) | j; if (v > candL) candL = v; }
+        if (cs > aBin && (u64)cs < hi) { u64 v = ((u64)(~cs) << 32) | j; if (v > candR) candR = v; }
+    }
+    if (__any(own)) return 0;
+    candL = waveMax64(candL); candR = waveMax64(candR);
     u32 aChr = X.chrBin[aBin >> P.winBinChrNbits];
-    // nearest window on the left whose last bin lies in [aBin-dist, aBin-1]
     u32 iWinL = NOWIN, iWinR = NOWIN;
-    if (aBin > 0) {
-        u32 lo = aBin > P.winAnchorDistNbins ? aBin - P.winAnchorDistNbins : 0;
-        u32 best = 0; bool found = false;
-        for (u32 i = 0; i < s.nW; i++) {
-            const WScr &w = s.W[i];
-            if (w.alive && w.str == aStr && w.coreE < aBin && w.coreE >= lo && (!found || w.coreE > best)) { found = true; best = w.coreE; iWinL = i; }
-        }
-        if (found && X.chrBin[best >> P.winBinChrNbits] != aChr) iWinL = NOWIN;
-    }
-    if ((u64)aBin + 1 < P.winBinN) {
-        u64 hi = min((u64)aBin + P.winAnchorDistNbins + 1, P.winBinN);     // exclusive
-        u32 best = 0; bool found = false;
-        for (u32 i = 0; i < s.nW; i++) {
-            const WScr &w = s.W[i];
-            if (w.alive && w.str == aStr && w.coreS > aBin && (u64)w.coreS < hi && (!found || w.coreS < best)) { found = true; best = w.coreS; iWinR = i; }
-        }
-        if (found && X.chrBin[best >> P.winBinChrNbits] != aChr) iWinR = NOWIN;
-    }
+    if (candL) { u32 ce = (u32)(candL >> 32) - 1; if (X.chrBin[ce >> P.winBinChrNbits] == aChr) iWinL = (u32)candL; }
+    if (candR) { u32 cs = ~(u32)(candR >> 32); if (X.chrBin[cs >> P.winBinChrNbits] == aChr) iWinR = (u32)candR; }
     if (iWinL == NOWIN && iWinR == NOWIN) {
         u32 iWin = s.nW;
         if (iWin >= s.capW) { s.overflow = true; return 1; }
-        WScr &w = s.W[iWin];
-        w.chr = aChr; w.str = (u8)aStr; w.coreS = w.coreE = aBin; w.extS = w.extE = aBin; w.alive = 1; w.nWA = 0; w.lrec = 0; w.waBlock = NOWIN;
+        if (lane == 0) {
+            s.t.meta[iWin] = (aChr << 2) | (aStr << 1) | 1u;
+            s.t.coreS[iWin] = aBin; s.t.coreE[iWin] = aBin; s.t.extS[iWin] = aBin; s.t.extE[iWin] = aBin;
+            s.t.blk[iWin] = NOWIN; s.t.lrec[iWin] = 0; s.t.nwa[iWin] = 0;
+        }
         s.nW++;
-        if (s.nW >= P.alignWindowsPerReadNmax) { s.nW = P.alignWindowsPerReadNmax - 1; s.windowsLimit = true; return 1; }
+        tabFence();
+        if (s.nW >= P.alignWindowsPerReadNmax) { s.nW = P.alignWindowsPerReadNmax - 1; s.winLimit = true; return 1; }
     } else {
         u32 iWin = iWinL != NOWIN ? iWinL : iWinR;                            // left window overwrites right (:57)
-        u32 binLeft = iWinL != NOWIN ? s.W[iWinL].coreS : aBin;
-        u32 binRight = iWinR != NOWIN ? s.W[iWinR].coreE : aBin;
-        if (iWinL != NOWIN && iWinR != NOWIN) s.W[iWinR].alive = 0;           // kill right window (:77-80)
-        s.W[iWin].coreS = binLeft; s.W[iWin].coreE = binRight;
+        u32 binLeft = iWinL != NOWIN ? s.t.coreS[iWinL] : aBin;
+        u32 binRight = iWinR != NOWIN ? s.t.coreE[iWinR] : aBin;
+        if (lane == 0) {
+            if (iWinL != NOWIN && iWinR != NOWIN) s.t.meta[iWinR] &= ~1u;        // kill right window (:77-80)
+            s.t.coreS[iWin] = binLeft; s.t.coreE[iWin] = binRight;
+        }
+        tabFence();
     }
     return 0;
 }
 
-// ReadAlign_assignAlignToWindow.cpp:6-130
-__device__ static void assignAlignToWindow(WinState &s, u64 a1, u32 aLength, u32 aStr, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA) {
-    const DevIndex &X = *s.X; const staramd_params &P = X.P;
-    u32 iW = ownerB(s, aStr, (u32)(a1 >> P.winBinNbits));
-    if (iW == NOWIN) return;
-    WScr &w = s.W[iW];
-    if (!aAnchor && aLength < w.lrec) return;
-    if (w.waBlock == NOWIN) {
+// ReadAlign_assignAlignToWindow.cpp:6-130 ; all arguments wave-uniform; lane j holds row j of the window's list
+__device__ static void assignAlignToWindow(const DevIndex &X, WS &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
+    const staramd_params &P = X.P;
+    u32 n = s.t.nwa[iW]; u32 lrec = s.t.lrec[iW];
+    if (!aAnchor && aLength < lrec) return;
+    u32 b = s.t.blk[iW];
+    if (b == NOWIN) {
         if (s.nBlocks >= s.capBlocks) { s.overflow = true; return; }
-        w.waBlock = s.nBlocks++;
+        b = s.nBlocks++;
+        if (lane == 0) s.t.blk[iW] = b;
     }
-    DWA *A = s.arena + (u64)w.waBlock * s.blockSize;
-    u32 n = w.nWA;
+    DWA *A = s.arena + (u64)b * WA_MAX;
+    DWA nw; nw.gStart = a1; nw.nrep = aNrep; nw.L = (u16)aLength; nw.rStart = (u16)aRstart; nw.sjA = sjA; nw.anchor = aAnchor ? 1 : 0; nw.iFrag = (u8)aFrag; nw.pad[0] = nw.pad[1] = 0;
+    bool have = lane < n;
+    DWA e; e.gStart = 0; e.nrep = 0; e.L = 0; e.rStart = 0; e.sjA = 0; e.anchor = 0; e.iFrag = 0; e.pad[0] = e.pad[1] = 0;
+    if (have) e = A[lane];
     {
-        u32 iA;
-        for (iA = 0; iA < n; iA++) {
-            const DWA &o = A[iA];
-            if (aFrag == o.iFrag && o.sjA == sjA && a1 + o.rStart == o.gStart + aRstart
-                && ((aRstart >= o.rStart && aRstart < (u32)o.rStart + o.L) || (aRstart + aLength >= o.rStart && aRstart + aLength < (u32)o.rStart + o.L))) break;
-        }
-        if (iA < n) {
-            if (aLength > A[iA].L) {
-                u32 iA0;
-                for (iA0 = 0; iA0 < n; iA0++) if (iA0 != iA && aRstart < A[iA0].rStart) break;
+        bool ov = have && aFrag == e.iFrag && e.sjA == sjA && a1 + e.rStart == e.gStart + aRstart
+                  && ((aRstart >= e.rStart && aRstart < (u32)e.rStart + e.L) || (aRstart + aLength >= e.rStart && aRstart + aLength < (u32)e.rStart + e.L));
+        u64 m = __ballot(ov);
+        if (m) {
+            u32 iA = (u32)__ffsll((long long)m) - 1;
+            u32 Lold = bcast32(e.L, iA);
+            if (aLength > Lold) {
+                u64 m2 = __ballot(have && lane != iA && aRstart < e.rStart);
+                u32 iA0 = m2 ? (u32)__ffsll((long long)m2) - 1 : n;
                 if (iA0 > iA) --iA0;
-                if (iA0 < iA) { for (u32 i = iA; i > iA0; i--) A[i] = A[i - 1]; }
-                else if (iA0 > iA) { for (u32 i = iA; i < iA0; i++) A[i] = A[i + 1]; }
-                DWA e; e.gStart = a1; e.nrep = aNrep; e.L = (u16)aLength; e.rStart = (u16)aRstart; e.sjA = sjA; e.anchor = aAnchor ? 1 : 0; e.iFrag = (u8)aFrag; e.pad[0] = e.pad[1] = 0;
-                A[iA0] = e;
+                if (iA0 < iA) { if (lane >= iA0 && lane < iA) A[lane + 1] = e; }
+                else if (iA0 > iA) { if (lane > iA && lane <= iA0) A[lane - 1] = e; }
+                if (lane == 0) A[iA0] = nw;
+                tabFence();
             }
             return;
         }
     }
     if (n == P.seedPerWindowNmax) {
-        w.lrec = s.Lread + 1;
-        for (u32 iA = 0; iA < n; iA++) if (A[iA].anchor != 1) w.lrec = min(w.lrec, (u32)A[iA].L);
-        if (w.lrec == s.Lread + 1) { s.tooManyAnchors = true; return; }
-        if (!aAnchor && aLength < w.lrec) return;
-        u32 iA1 = 0;
-        for (u32 iA = 0; iA < n; iA++) if (A[iA].anchor == 1 || A[iA].L > w.lrec) { A[iA1] = A[iA]; iA1++; }
-        n = iA1; w.nWA = (u16)n;
+        lrec = waveMin32((have && e.anchor != 1) ? (u32)e.L : s.Lread + 1);
+        if (lane == 0) s.t.lrec[iW] = lrec;
+        if (lrec == s.Lread + 1) { s.tooMany = true; tabFence(); return; }
+        if (!aAnchor && aLength < lrec) { tabFence(); return; }
+        bool keep = have && (e.anchor == 1 || e.L > lrec);
+        u64 km = __ballot(keep);
+        u32 pos = (u32)__popcll(km & ((1ull << lane) - 1ull));
+        if (keep) A[pos] = e;
+        n = (u32)__popcll(km);
+        if (lane == 0) s.t.nwa[iW] = n;
+        tabFence();
+        have = lane < n;
+        if (have) e = A[lane];
     }
-    if (aAnchor || aLength > w.lrec) {
-        u32 iA;
-        for (iA = 0; iA < n; iA++) if (aRstart < A[iA].rStart) break;
-        for (u32 i = n; i > iA; i--) A[i] = A[i - 1];
-        DWA e; e.gStart = a1; e.nrep = aNrep; e.L = (u16)aLength; e.rStart = (u16)aRstart; e.sjA = sjA; e.anchor = aAnchor ? 1 : 0; e.iFrag = (u8)aFrag; e.pad[0] = e.pad[1] = 0;
-        A[iA] = e;
-        w.nWA = (u16)(n + 1);
+    if (aAnchor || aLength > lrec) {
+        u64 m3 = __ballot(have && aRstart < e.rStart);
+        u32 iA = m3 ? (u32)__ffsll((long long)m3) - 1 : n;
+        if (have && lane >= iA) A[lane + 1] = e;
+        if (lane == 0) { A[iA] = nw; s.t.nwa[iW] = n + 1; }
+        tabFence();
     }
 }
 
@@ -149,105 +170,217 @@ __device__ __forceinline__ bool sjAlignSplit(const DevIndex &X, u64 a1, u32 aLen
     return false;
 }
 
-extern "C" __global__ void __launch_bounds__(256) k_windows(DevIndex X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks) {
-    u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+// pass-B owner of a bin: last flank writer wins, else the core owner (ReadAlign_stitchPieces.cpp:96-118 write order)
+__device__ __forceinline__ u32 ownerB(const WS &s, u32 str, u32 bin) {
+    u32 core = NOWIN, flank = NOWIN;
+    for (u32 j = 0; j < s.nW; j++) {
+        u32 m = s.t.meta[j];
+        if (!(m & 1u) || ((m >> 1) & 1u) != str) continue;
+        if (bin < s.t.extS[j] || bin > s.t.extE[j]) continue;
+        if (bin >= s.t.coreS[j] && bin <= s.t.coreE[j]) core = j; else flank = j;
+    }
+    return flank != NOWIN ? flank : core;
+}
+
+// per-wave work space in global memory: [table rows (big pass only)] [seed-list blocks]
+__host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
+    u64 b = (u64)capBlocks * WA_MAX * sizeof(DWA);
+    if (big) b += (u64)capW * 8 * sizeof(u32);
+    return (b + 255) & ~255ull;
+}
+
+extern __shared__ u32 ldsTab[];     // fast pass: wavesPerBlock * capW * 8 words
+
+extern "C" __global__ void __launch_bounds__(256) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big) {
+    const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
-    u32 blockSize = P.seedPerWindowNmax;
-    u64 perLane = (u64)capW * sizeof(WScr) + (u64)capBlocks * blockSize * sizeof(DWA);
-    WinState s; s.X = &X;
-    s.W = (WScr *)(scratch + (u64)lane * perLane); s.capW = capW;
-    s.arena = (DWA *)(scratch + (u64)lane * perLane + (u64)capW * sizeof(WScr)); s.capBlocks = capBlocks; s.blockSize = blockSize;
-    u64 nSAenum = 0, nWindows = 0, nWAtot = 0;
+    u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
+    u32 wavesPerBlock = blockDim.x >> 6;
+    u32 wave = blockIdx.x * wavesPerBlock + waveInBlock;
+    WS s;
+    u8 *mine = scratch + (u64)wave * winWaveBytes(capW, capBlocks, big);
+    u32 *tab = big ? (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA)) : (ldsTab + (u64)waveInBlock * capW * 8);
+    s.t.coreS = tab; s.t.coreE = tab + capW; s.t.extS = tab + 2 * capW; s.t.extE = tab + 3 * capW;
+    s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + 6 * capW; s.t.nwa = tab + 7 * capW;
+    s.arena = (DWA *)mine; s.capW = capW; s.capBlocks = capBlocks;
+    u64 nSAenum = 0, nWindows = 0, nWAtot = 0; u32 nOvf = 0;
+    const u32 nItems = big ? B.cursors[CUR_OVF_WIN] : B.nReads;
+    const u32 ticketSlot = big ? CUR_TICKET_WIN2 : CUR_TICKET_WIN;
     for (;;) {
-        u32 ir = atomicAdd(&B.cursors[9], 1u);
-        if (ir >= B.nReads) break;
+        u32 it = 0;
+        if (lane == 0) it = atomicAdd(&B.cursors[ticketSlot], 1u);
+        it = first32(it);
+        if (it >= nItems) break;
+        u32 ir = big ? B.ovfWin[it] : it;
         DRead rd = B.reads[ir];
         if (rd.nSeeds == 0) continue;
         const DSeed *PC = B.seedPool + rd.seedOffset;
-        s.nW = 0; s.nBlocks = 0; s.tooManyAnchors = false; s.windowsLimit = false; s.overflow = false;
+        s.nW = 0; s.nBlocks = 0; s.tooMany = false; s.winLimit = false; s.overflow = false;
         s.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         // ---- pass A: anchors (ReadAlign_stitchPieces.cpp:41-93)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow; iP++) {
             const DSeed sd = PC[iP];
             if (sd.nrep > P.winAnchorMultimapNmax) continue;
             u32 aDir = sd.dir, aLength = sd.L;
-            for (u64 iSA = sd.saStart; iSA < sd.saStart + sd.nrep; iSA++) {
-                nSAenum++;
-                u64 a1 = packedGet(X.SA, iSA, X.saBits, X.saMask);
-                u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-                if (aDir == 1 && aStr == 0) aStr = 1;
-                else if (aDir == 0 && aStr == 1) a1 = X.nGenome - (aLength + a1);
-                else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
-                if (a1 >= X.sjGstart) {
-                    u64 a1D, a1A; u32 lD, lA, isj;
-                    if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
-                        if (createExtendWindowsWithAlign(s, a1D, aStr)) break;
-                        if (createExtendWindowsWithAlign(s, a1A, aStr)) break;
+            bool stop = false;
+            for (u32 base = 0; base < sd.nrep && !stop; base += 64) {
+                u32 cnt = min(64u, sd.nrep - base);
+                // lane i: locus i of the chunk
+                u64 a1 = 0, a1A = 0; u32 aStr = 0; u32 kind = 0;       // kind: 0 skip, 1 plain, 2 split (D then A)
+                if (lane < cnt) {
+                    a1 = packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
+                    aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
+                    if (aDir == 1 && aStr == 0) aStr = 1;
+                    else if (aDir == 0 && aStr == 1) a1 = X.nGenome - (aLength + a1);
+                    else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
+                    kind = 1;
+                    if (a1 >= X.sjGstart) {
+                        u64 a1D; u32 lD, lA, isj;
+                        if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) { a1 = a1D; kind = 2; } else kind = 0;
                     }
-                } else if (createExtendWindowsWithAlign(s, a1, aStr)) break;
+                }
+                nSAenum += cnt;
+                for (u32 l = 0; l < cnt; l++) {
+                    u32 k = bcast32(kind, l);
+                    if (k == 0) continue;
+                    u64 x1 = bcast64(a1, l); u32 xs = bcast32(aStr, l);
+                    if (createExtendWindowsWithAlign(X, s, x1, xs, lane)) { stop = true; break; }
+                    if (k == 2) { u64 x2 = bcast64(a1A, l); if (createExtendWindowsWithAlign(X, s, x2, xs, lane)) { stop = true; break; } }
+                }
             }
         }
-        // ---- flanks (:96-118)
-        for (u32 i = 0; i < s.nW; i++) {
-            WScr &w = s.W[i];
-            w.nWA = 0; w.lrec = 0; w.waBlock = NOWIN;
-            if (!w.alive) continue;
-            u32 wb = w.coreS;
-            for (u32 ii = 0; ii < P.winFlankNbins && wb > 0 && X.chrBin[(wb - 1) >> P.winBinChrNbits] == w.chr; ii++) wb--;
-            w.extS = wb;
-            wb = w.coreE;
-            for (u32 ii = 0; ii < P.winFlankNbins && (u64)wb + 1 < P.winBinN && X.chrBin[(wb + 1) >> P.winBinChrNbits] == w.chr; ii++) wb++;
-            w.extE = wb;
+        // ---- flanks (:96-118): one lane per window
+        if (!s.overflow) {
+            for (u32 j = lane; j < s.nW; j += 64) {
+                u32 m = s.t.meta[j];
+                s.t.nwa[j] = 0; s.t.lrec[j] = 0; s.t.blk[j] = NOWIN;
+                if (!(m & 1u)) continue;
+                u32 chr = m >> 2;
+                u32 wb = s.t.coreS[j];
+                for (u32 ii = 0; ii < P.winFlankNbins && wb > 0 && X.chrBin[(wb - 1) >> P.winBinChrNbits] == chr; ii++) wb--;
+                s.t.extS[j] = wb;
+                wb = s.t.coreE[j];
+                for (u32 ii = 0; ii < P.winFlankNbins && (u64)wb + 1 < P.winBinN && X.chrBin[(wb + 1) >> P.winBinChrNbits] == chr; ii++) wb++;
+                s.t.extE[j] = wb;
+            }
+            tabFence();
         }
         nWindows += s.nW;
         // ---- pass B: all seeds (:129-185)
-        for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooManyAnchors; iP++) {
+        for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooMany; iP++) {
             const DSeed sd = PC[iP];
             u32 aNrep = sd.nrep, aFrag = sd.iFrag, aLength = sd.L, aDir = sd.dir;
             bool aAnchor = aNrep <= P.winAnchorMultimapNmax;
-            for (u64 iSA = sd.saStart; iSA < sd.saStart + sd.nrep && !s.tooManyAnchors; iSA++) {
-                nSAenum++;
-                u64 a1 = packedGet(X.SA, iSA, X.saBits, X.saMask);
-                u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-                u32 aRstart = sd.rStart;
-                if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
-                else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
-                else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
-                if (a1 >= X.sjGstart) {
-                    u64 a1D, a1A; u32 lD, lA, isj;
-                    if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
-                        assignAlignToWindow(s, a1D, lD, aStr, aNrep, aFrag, aRstart, aAnchor, (i32)isj);
-                        if (!s.tooManyAnchors) assignAlignToWindow(s, a1A, lA, aStr, aNrep, aFrag, aRstart + lD, aAnchor, (i32)isj);
+            for (u32 base = 0; base < aNrep && !s.overflow && !s.tooMany; base += 64) {
+                u32 cnt = min(64u, aNrep - base);
+                u64 a1 = 0, a1A = 0; u32 aRstart = 0, lD = 0, lA = 0, isj = 0; u32 wD = NOWIN, wA = NOWIN; bool split = false;
+                if (lane < cnt) {
+                    a1 = packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
+                    u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
+                    aRstart = sd.rStart;
+                    if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
+                    else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
+                    else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
+                    if (a1 >= X.sjGstart) {
+                        u64 a1D;
+                        if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
+                            split = true; a1 = a1D;
+                            wD = ownerB(s, aStr, (u32)(a1D >> P.winBinNbits));
+                            wA = ownerB(s, aStr, (u32)(a1A >> P.winBinNbits));
+                        }
+                    } else {
+                        lD = aLength;
+                        wD = ownerB(s, aStr, (u32)(a1 >> P.winBinNbits));
                     }
-                } else assignAlignToWindow(s, a1, aLength, aStr, aNrep, aFrag, aRstart, aAnchor, -1);
+                }
+                nSAenum += cnt;
+                u64 hm = __ballot(wD != NOWIN || wA != NOWIN);
+                while (hm) {
+                    u32 l = (u32)__ffsll((long long)hm) - 1; hm &= hm - 1;
+                    u32 xwD = bcast32(wD, l), xwA = bcast32(wA, l);
+                    u32 xsplit = bcast32(split ? 1u : 0u, l);
+                    u32 xr = bcast32(aRstart, l), xlD = bcast32(lD, l);
+                    i32 xsj = xsplit ? (i32)bcast32(isj, l) : -1;
+                    if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, bcast64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
+                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, bcast64(a1A, l), bcast32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
+                    if (s.tooMany || s.overflow) break;
+                }
             }
         }
-        if (s.windowsLimit) rd.status |= STARAMD_ST_WINDOWS_LIMIT;
-        if (s.overflow) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[6], 2u); B.reads[ir] = rd; continue; }
-        if (s.tooManyAnchors) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
+        if (s.winLimit) rd.status |= STARAMD_ST_WINDOWS_LIMIT;
+        if (s.overflow) {
+            if (lane == 0) {
+                if (big) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); B.reads[ir] = rd; }
+                else { u32 k = atomicAdd(&B.cursors[CUR_OVF_WIN], 1u); B.ovfWin[k] = ir; nOvf++; }
+            }
+            continue;
+        }
+        if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
         // ---- emit windows that hold seeds, in window order
         u32 nOut = 0, nWA = 0;
-        for (u32 i = 0; i < s.nW; i++) if (s.W[i].nWA > 0) { nOut++; nWA += s.W[i].nWA; }
+        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; } }
+        for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); }
         if (nOut > 0) {
-            u32 wo = atomicAdd(&B.cursors[1], nOut), ao = atomicAdd(&B.cursors[2], nWA);
-            if (wo + nOut > B.winCap || ao + nWA > B.waCap) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[6], 4u); }
-            else {
-                rd.winOffset = wo; rd.nWin = nOut;
-                for (u32 i = 0; i < s.nW; i++) {
-                    const WScr &w = s.W[i];
-                    if (w.nWA == 0) continue;
-                    DWin d; d.read = ir; d.chr = w.chr; d.waOffset = ao; d.nWA = w.nWA; d.str = w.str; d.pad = 0;
-                    B.winPool[wo++] = d;
-                    const DWA *A = s.arena + (u64)w.waBlock * blockSize;
-                    for (u32 k = 0; k < w.nWA; k++) B.waPool[ao + k] = A[k];
-                    ao += w.nWA;
-                }
-                nWAtot += nWA;
+            u32 wo = 0, ao = 0;
+            if (lane == 0) { wo = atomicAdd(&B.cursors[CUR_WIN], nOut); ao = atomicAdd(&B.cursors[CUR_WA], nWA); }
+            wo = first32(wo); ao = first32(ao);
+            if (wo + nOut > B.winCap || ao + nWA > B.waCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_WINPOOL); continue; }
+            rd.winOffset = wo; rd.nWin = nOut;
+            for (u32 j = 0; j < s.nW; j++) {
+                u32 n = s.t.nwa[j];
+                if (n == 0) continue;
+                u32 m = s.t.meta[j];
+                if (lane == 0) { DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.pad = 0; B.winPool[wo] = d; B.winClass[wo] = (u8)min(n, 31u); }
+                const DWA *A = s.arena + (u64)s.t.blk[j] * WA_MAX;
+                if (lane < n) B.waPool[ao + lane] = A[lane];
+                wo++; ao += n;
             }
+            nWAtot += nWA;
         }
-        B.reads[ir] = rd;
+        if (lane == 0) B.reads[ir] = rd;
     }
-    atomicAdd((unsigned long long *)&B.counters[DC_nSAenum], (unsigned long long)nSAenum);
-    atomicAdd((unsigned long long *)&B.counters[DC_nWindows], (unsigned long long)nWindows);
-    atomicAdd((unsigned long long *)&B.counters[DC_nWA], (unsigned long long)nWAtot);
+    if (lane == 0) {
+        atomicAdd((unsigned long long *)&B.counters[DC_nSAenum], (unsigned long long)nSAenum);
+        atomicAdd((unsigned long long *)&B.counters[DC_nWindows], (unsigned long long)nWindows);
+        atomicAdd((unsigned long long *)&B.counters[DC_nWA], (unsigned long long)nWAtot);
+        if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfWin], (unsigned long long)nOvf);
+    }
+}
+
+// ---- stitch order: windows sorted by number of seeds (the stitcher's work grows with it), most seeds first (counting sort
+// over 32 classes), then dealt round-robin over groups of 64 consecutive tickets: a wavefront takes 64 consecutive tickets
+// per round, so every wavefront gets one window of each stratum instead of 64 heavy (mutually divergent) ones.
+extern "C" __global__ void __launch_bounds__(256) k_order_hist(DevBatch B) {
+    __shared__ u32 h[32];
+    if (threadIdx.x < 32) h[threadIdx.x] = 0;
+    __syncthreads();
+    u32 n = B.cursors[CUR_WIN]; u32 slots = ((n + 63u) / 64u) * 64u;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += gridDim.x * blockDim.x) {
+        B.order[i] = 0xFFFFFFFFu;
+        if (i < n) atomicAdd(&h[B.winClass[i] & 31u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&B.costHist[threadIdx.x], h[threadIdx.x]);
+}
+extern "C" __global__ void k_order_offsets(DevBatch B) {      // 1 thread: class offsets, heaviest class first
+    u32 off = 0;
+    for (int c = 31; c >= 0; c--) { u32 n = B.costHist[c]; B.costHist[32 + c] = off; off += n; }
+}
+extern "C" __global__ void __launch_bounds__(256) k_order_scatter(DevBatch B) {
+    // per block: histogram of its chunk in LDS, ONE global reservation per class, ranks inside the block from LDS atomics
+    __shared__ u32 h[32], base[32];
+    u32 n = B.cursors[CUR_WIN]; u32 G = (n + 63u) / 64u;
+    u32 perBlock = (n + gridDim.x - 1) / gridDim.x;
+    u32 lo = blockIdx.x * perBlock, hi = min(n, lo + perBlock);
+    if (threadIdx.x < 32) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[B.winClass[i] & 31u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 32) { u32 c = h[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(&B.costHist[32 + threadIdx.x], c) : 0; h[threadIdx.x] = 0; }
+    __syncthreads();
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        u32 cls = B.winClass[i] & 31u;
+        u32 pos = base[cls] + atomicAdd(&h[cls], 1u);
+        B.order[(pos % G) * 64u + pos / G] = i;
+    }
 }

@@ -63,3 +63,18 @@ def test_engine_matches_oracle_buffers(name, tmp_path, built):
         assert nb > 0
     finally:
         eng.close(); orc.close(); run.close()
+
+
+@pytest.mark.parametrize("name", ["pe101", "pe150_indel"])
+def test_shadow_validation(name, tmp_path, built):
+    """Shadow-validation build: every wave-cooperative stitch / extend call is re-run on the GPU through the scalar
+    restatement and compared; zero disagreements over all calls of the data set."""
+    import json, os, subprocess, sys
+    if not refstar.have_ref():
+        pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, STARAMD_ENGINE_LIB="shadow")
+    out = subprocess.check_output([sys.executable, os.path.join(here, "shadow_run.py"), name, str(tmp_path)], env=env)
+    c = json.loads(out.decode().strip().splitlines()[-1])
+    assert c["stitchN"] > 1000 and c["extendN"] > 1000, c
+    assert c["stitchBad"] == 0 and c["extendBad"] == 0, c
