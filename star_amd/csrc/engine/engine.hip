@@ -15,7 +15,7 @@ extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch,
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
-extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *scratch, u32 capDepth, u32 capRank, u32 arenaBytes, u32 ldsWords, u32 mode, u32 big);
+extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords, u32 mode);
 extern "C" __global__ void k_stitch_verify(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_stitch_finish(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_scan_offsets(DevBatch B, u32 *trBase, u32 *exBase, u32 *totals);
@@ -23,8 +23,8 @@ extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *ex
                                     staramd_transcript *outTr, u32 outTrCap, staramd_exon *outEx, u32 outExCap);
 
 // per-lane / per-wave work-space sizes (same formulas as the kernels)
-static inline u32 stitchLaneBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + arenaBytes;
+static inline u32 stitchStateBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
+    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_MAX * 24u + arenaBytes;
     return (b + 127u) & ~127u;
 }
 static inline u64 winWaveBytesH(u32 capW, u32 capBlocks, u32 big) {
@@ -223,14 +223,13 @@ static int allocWork(staramd_ctx *c) {
     c->arenaFast = envU32("STARAMD_STITCH_ARENA", 6144) & ~31u;
     c->arenaBig = 2u * (P.alignTranscriptsPerWindowNmax + 2) * (96u + 32u * STARAMD_MAX_N_EXONS);      // twice the largest live set
     if (c->arenaBig > 2000000u) { g_err = "alignTranscriptsPerWindowNmax too large for the device record arena"; return STARAMD_ERR_ARG; }
-    // fast pass: one worker per wavefront with its walk state in LDS; blocks of 4 wavefronts
+    // one wavefront per window, walk state in LDS; blocks of 4 wavefronts; one worst-case record arena per wavefront in HBM
+    c->arenaFast = envU32("STARAMD_STITCH_ARENA", 4096) & ~31u;
     int stPerCU = 2;
-    size_t ldsFast = 4 * (size_t)(stitchLaneBytesH(c->capDepth, c->capRank, c->arenaFast) + 27 * 4 + 16);
+    size_t ldsFast = 4 * (size_t)(stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast) + 27 * 4 + 16);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stPerCU, k_stitch_win, 256, ldsFast) != hipSuccess || stPerCU < 1) stPerCU = 2;
     c->stBlocks = (u32)c->nCU * envU32("STARAMD_STITCH_BLOCKS_PER_CU", (u32)stPerCU);
-    if ((rc = devAlloc(R, &c->scrStitch, (u64)256))) return rc;
-    c->stBlocksBig = envU32("STARAMD_STITCH_BLOCKS_BIG", 2048);          // one active lane per 64-thread block
-    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)c->stBlocksBig * stitchLaneBytesH(c->capDepth, c->capRank, c->arenaBig)))) return rc;
+    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)c->stBlocks * 4 * c->arenaBig))) return rc;
     return 0;
 }
 
@@ -321,10 +320,9 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[2], s));
     {
         size_t readBytes = (ldsWords * 4u + 15u) & ~15u;
-        size_t ldsFast = 4 * (readBytes + stitchLaneBytesH(c->capDepth, c->capRank, c->arenaFast)), ldsBig = readBytes;
+        size_t ldsFast = 4 * (readBytes + stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast));
         for (u32 mode = 0; mode < 2; mode++) {
-            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitch, c->capDepth, c->capRank, c->arenaFast, ldsWords, mode, 0u);
-            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksBig), dim3(64), ldsBig, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaBig, ldsWords, mode, 1u);
+            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, mode);
             if (mode == 0) hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);
         }
         hipLaunchKernelGGL(k_stitch_finish, dim3((n + 255) / 256), block, 0, s, c->dX, B);

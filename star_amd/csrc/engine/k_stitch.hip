@@ -40,7 +40,9 @@ struct ExtRes { i32 maxScore; u32 extendL, nMatch, nMM; };
 
 #define NLANE 64u
 
-__device__ __forceinline__ u8 gByte(const StitchCtx &c, u64 pos) { return c.X->G[(i64)pos]; }
+#define GLOBAL_AS __attribute__((address_space(1)))
+// the index arrays live in HBM: say so, otherwise the loads are FLAT (and every wait also drains the LDS counter)
+__device__ __forceinline__ u8 gByte(const StitchCtx &c, u64 pos) { return ((const GLOBAL_AS u8 *)c.X->G)[(i64)pos]; }
 
 // ---- extendAlign.cpp:6-93, lane = position of the scan -------------------------------------------------------------
 __device__ static bool coopExtend(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
@@ -118,7 +120,8 @@ __device__ static bool coopExtendChecked(StitchCtx &c, u32 lane, u32 rStart, u64
 // 64-ary search: every round 64 lanes probe 64 evenly spaced starts, the count of "smaller" answers narrows the range
 // 64-fold; then the run of equal starts is compared against y by all lanes at once.  (sjdb junctions are unique
 // (start,end) pairs -- sjdbPrepare collapses duplicates -- so "the" match is well defined.)
-__device__ static int coopSjdbFind(u32 lane, u64 x, u64 y, const u64 *Xs, const u64 *Ys, u32 N) {
+__device__ static int coopSjdbFind(u32 lane, u64 x, u64 y, const u64 *Xs_, const u64 *Ys_, u32 N) {
+    const GLOBAL_AS u64 *Xs = (const GLOBAL_AS u64 *)Xs_, *Ys = (const GLOBAL_AS u64 *)Ys_;
     if (N == 0 || x > Xs[N - 1] || x < Xs[0]) return -1;
     u32 lo = 0, hi = N;                                   // first index with Xs[idx] >= x lies in [lo, hi]
     while (hi - lo > NLANE) {
@@ -382,8 +385,29 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
     return Score;
 }
 
+// ---- address spaces -------------------------------------------------------------------------------------------------
+// The walk state of a window (undo stack, exon rows, leaf copy, rank list, seed list) ALWAYS lives in the wavefront's
+// LDS slice and is accessed through LDS-typed pointers (ds_read/ds_write, not flat).  Only the arena of recorded
+// transcripts has two homes: LDS (BIG = false) or, for the few windows that outgrow it, global memory (BIG = true).
+#define LDS __attribute__((address_space(3)))
+template <bool BIG> struct AS;
+template <> struct AS<false> { typedef LDS u8 *u8p; typedef LDS u64 *u64p; typedef LDS staramd_transcript *trp; typedef LDS staramd_exon *exp; };
+template <> struct AS<true> { typedef u8 *u8p; typedef u64 *u64p; typedef staramd_transcript *trp; typedef staramd_exon *exp; };
+// struct copies out of / into LDS (C++ copy constructors only take generic references)
+template <class T> __device__ __forceinline__ T ldsGet(const LDS T *p) {
+    T v; const LDS u32 *s = (const LDS u32 *)p; u32 *d = (u32 *)&v;
+#pragma unroll
+    for (u32 i = 0; i < sizeof(T) / 4; i++) d[i] = s[i];
+    return v;
+}
+template <class T> __device__ __forceinline__ void ldsPut(LDS T *p, const T &v) {
+    LDS u32 *d = (LDS u32 *)p; const u32 *s = (const u32 *)&v;
+#pragma unroll
+    for (u32 i = 0; i < sizeof(T) / 4; i++) d[i] = s[i];
+}
+
 // blocksOverlap.cpp:3-40 on two exon lists in the output record format (run by one lane)
-__device__ static u32 blocksOverlap(const staramd_exon *e1, u32 n1, const staramd_exon *e2, u32 n2) {
+template <class P1, class P2> __device__ static u32 blocksOverlap(P1 e1, u32 n1, P2 e2, u32 n2) {
     u32 i1 = 0, i2 = 0, nOverlap = 0;
     while (i1 < n1 && i2 < n2) {
         u64 rs1 = e1[i1].R, rs2 = e2[i2].R;
@@ -399,23 +423,22 @@ __device__ static u32 blocksOverlap(const staramd_exon *e1, u32 n1, const staram
 
 // transcripts recorded for the current window: records in the OUTPUT format (staramd_transcript followed by its
 // exons) bump-allocated in the window's arena; rank[] holds their offsets (32-byte units), best first.
-struct WinRec { u8 *arena; u32 arenaBytes; u32 top; u16 *rank; u32 nWinTr; bool overflow; };
+template <bool BIG> struct WinRec { typename AS<BIG>::u8p arena; u32 arenaBytes; u32 top; LDS u16 *rank; u32 nWinTr; bool overflow; };
 #define REC_HDR 96
 static_assert(sizeof(staramd_transcript) == REC_HDR, "record header is the output transcript record");
 static_assert(sizeof(staramd_exon) == 32, "exon record is 32 bytes");
-__device__ __forceinline__ staramd_transcript *recAt(const WinRec &w, u32 off32) { return (staramd_transcript *)(w.arena + off32 * 32u); }
-__device__ __forceinline__ staramd_transcript *recT(const WinRec &w, u32 k) { return recAt(w, w.rank[k]); }
+template <bool BIG> __device__ __forceinline__ typename AS<BIG>::trp recAt(const WinRec<BIG> &w, u32 off32) { return (typename AS<BIG>::trp)(w.arena + off32 * 32u); }
+template <bool BIG> __device__ __forceinline__ typename AS<BIG>::trp recT(const WinRec<BIG> &w, u32 k) { return recAt<BIG>(w, w.rank[k]); }
 
 // slide the live records to the front of the arena (only when the bump pointer hits the end); run by lane 0
-__device__ static u32 compactArena(WinRec &w) {
+template <bool BIG> __device__ static u32 compactArena(WinRec<BIG> &w) {
     u32 newTop = 0; i32 lastOrig = -1;
     for (u32 step = 0; step < w.nWinTr; step++) {
         u32 best = 0xFFFFFFFFu, bk = 0;
         for (u32 k = 0; k < w.nWinTr; k++) { u32 o = w.rank[k]; if ((i32)o > lastOrig && o < best) { best = o; bk = k; } }
         if (best == 0xFFFFFFFFu) break;
-        const staramd_transcript *t = (const staramd_transcript *)(w.arena + best * 32u);
-        u32 words = (REC_HDR + 32u * t->nExons) / 8;
-        const u64 *s = (const u64 *)(w.arena + best * 32u); u64 *d = (u64 *)(w.arena + newTop);
+        u32 words = (REC_HDR + 32u * recAt<BIG>(w, best)->nExons) / 8;
+        typename AS<BIG>::u64p s = (typename AS<BIG>::u64p)(w.arena + best * 32u), d = (typename AS<BIG>::u64p)(w.arena + newTop);
         if (d != s) for (u32 i = 0; i < words; i++) d[i] = s[i];
         w.rank[bk] = (u16)(newTop / 32u);
         lastOrig = (i32)best; newTop += words * 8;
@@ -425,7 +448,7 @@ __device__ static u32 compactArena(WinRec &w) {
 }
 
 // leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
-__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd_exon *ex, u32 chr, WinRec &wr) {
+template <bool BIG> __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec<BIG> &wr) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
     c.nLeaves++;
     u32 Lread = c.Lread; u32 Str = c.str;
@@ -439,22 +462,22 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
             if (h.rStart > 0) {
                 u32 imate = ex[0].iFrag;
                 if (COOP_EXTEND(c, lane, h.rStart - 1, h.gStart - 1, -1, -1, h.rStart, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
-                               P.alignEndsTypeExt[imate][(int)(Str != imate)] != 0, e)) {
+                                P.alignEndsTypeExt[imate][(int)(Str != imate)] != 0, e)) {
                     h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
                     h.rStart -= e.extendL; h.gStart -= e.extendL;
                     if (lane == 0) { ex[0].R = (u16)h.rStart; ex[0].G = h.gStart; ex[0].L = (u16)(ex[0].L + e.extendL); }
-                    __threadfence_block();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
             }
         } else {
             if (tR2 < Lread) {
                 u32 imate = ex[ne - 1].iFrag;
                 if (COOP_EXTEND(c, lane, tR2 + 1, tG2 + 1, +1, +1, Lread - tR2 - 1, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
-                               P.alignEndsTypeExt[imate][(int)(imate == Str)] != 0, e)) {
+                                P.alignEndsTypeExt[imate][(int)(imate == Str)] != 0, e)) {
                     h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
                     tR2 += e.extendL; tG2 += e.extendL;
                     if (lane == 0) ex[ne - 1].L = (u16)(ex[ne - 1].L + e.extendL);
-                    __threadfence_block();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
             }
         }
@@ -523,7 +546,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
     i32 iFragT;
     if (ex[0].iFrag == ex[ne - 1].iFrag) { iFragT = ex[0].iFrag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
     else iFragT = -1;
-    i32 winBest = wr.nWinTr > 0 ? recT(wr, 0)->maxScore : 0;            // wTr[0]->maxScore (trA with score 0 before any record)
+    i32 winBest = wr.nWinTr > 0 ? recT<BIG>(wr, 0)->maxScore : 0;            // wTr[0]->maxScore (trA with score 0 before any record)
     {
         bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
         bool c2 = iFragT >= 0 && Score + P.outFilterMultimapScoreRange >= c.maxScoreMate[iFragT];
@@ -543,8 +566,8 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
             u16 rk = 0; u32 cls = 0;
             if (have) {
                 rk = wr.rank[k];
-                const staramd_transcript *o = recAt(wr, rk);
-                u32 nOverlap = blocksOverlap(ex, ne, (const staramd_exon *)((const u8 *)o + REC_HDR), o->nExons);
+                typename AS<BIG>::trp o = recAt<BIG>(wr, rk);
+                u32 nOverlap = blocksOverlap(ex, ne, (typename AS<BIG>::exp)((typename AS<BIG>::u8p)o + REC_HDR), (u32)o->nExons);
                 u32 uNew = mappedLength - nOverlap, uOld = o->mappedLength - nOverlap;
                 if (uNew == 0 && Score < o->maxScore) cls = 1; else if (uOld == 0) cls = 2;
             }
@@ -562,17 +585,17 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
                 outN += min(NLANE, nW0 - base);
             }
             wr.nWinTr = outN;
-            __threadfence_block();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             return;
         }
         wr.nWinTr = outN;
-        __threadfence_block();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
     // ---- ranked insert (:287-303)
     u32 iTr = wr.nWinTr;
     for (u32 base = 0; base < wr.nWinTr; base += NLANE) {
         u32 k = base + lane; bool better = false;
-        if (k < wr.nWinTr) { const staramd_transcript *o = recT(wr, k); better = Score > o->maxScore || (Score == o->maxScore && gLength < o->gLength); }
+        if (k < wr.nWinTr) { typename AS<BIG>::trp o = recT<BIG>(wr, k); better = Score > o->maxScore || (Score == o->maxScore && gLength < o->gLength); }
         u64 bm = __ballot(better);
         if (bm) { iTr = base + firstLane(bm); break; }
     }
@@ -580,9 +603,9 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
     u32 need = REC_HDR + 32u * ne;
     if (wr.top + need > wr.arenaBytes) {
         u32 nt = 0;
-        if (lane == 0) nt = compactArena(wr);
+        if (lane == 0) nt = compactArena<BIG>(wr);
         wr.top = first32(nt);
-        __threadfence_block();
+        if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // also give up when the live set alone fills 3/4 of the arena: the next leaves would compact over and over
         if (wr.top + need > wr.arenaBytes || wr.top * 4u > wr.arenaBytes * 3u) { wr.overflow = true; return; }
     }
@@ -596,7 +619,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
     }
     if (lane == 0) wr.rank[iTr] = (u16)(off / 32u);
     wr.nWinTr = newN;
-    if (lane == 0) {
+    {   // record = output transcript header + exon rows, written as 8-byte words: word w of the header by lane w
         staramd_transcript o;
         { u64 *z = (u64 *)&o; for (u32 i = 0; i < REC_HDR / 8; i++) z[i] = 0; }          // padding included: records are compared byte for byte
         o.iW = 0; o.exonOffset = 0;
@@ -607,59 +630,65 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, staramd
         o.nGap = h.nGap; o.lGap = h.lGap; o.nDel = h.nDel; o.lDel = h.lDel; o.nIns = h.nIns; o.lIns = h.lIns;
         o.nUnique = (u16)h.nUnique; o.nAnchor = (u16)h.nAnchor;
         o.intronMotifs[0] = intronMotifs[0]; o.intronMotifs[1] = intronMotifs[1]; o.intronMotifs[2] = intronMotifs[2]; o.pad0 = 0; o.pad1 = 0;
-        *(staramd_transcript *)(wr.arena + off) = o;
+        if (lane == 0) {
+            typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(wr.arena + off); const u64 *sw = (const u64 *)&o;
+#pragma unroll
+            for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i];
+        }
     }
     if (lane < ne) {
-        staramd_exon x = ex[lane];
+        staramd_exon x = ldsGet(&ex[lane]);
         if (lane + 1 == ne) { x.canonSJ = 0; x.sjAnnot = 0; x.sjStr = 0; x.shiftSJ[0] = x.shiftSJ[1] = 0; }
         else if (x.canonSJ < 0) { x.shiftSJ[0] = x.shiftSJ[1] = 0; }
         x.pad0 = 0; x.pad1 = 0;
-        ((staramd_exon *)(wr.arena + off + REC_HDR))[lane] = x;
+        typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(wr.arena + off + REC_HDR + 32u * lane); const u64 *sw = (const u64 *)&x;
+        d[0] = sw[0]; d[1] = sw[1]; d[2] = sw[2]; d[3] = sw[3];
     }
-    __threadfence_block();
+    if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
-// per-window work space, in bytes
-__host__ __device__ inline u32 stitchLaneBytes(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + arenaBytes;
+// per-window LDS work space, in bytes: undo stack, exon rows, leaf copy, rank list, seed list (+ arena in the fast path)
+#define WA_LDS_BYTES (WA_MAX * 24u)
+__host__ __device__ inline u32 stitchStateBytes(u32 capDepth, u32 capRank, u32 arenaBytes) {
+    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_LDS_BYTES + arenaBytes;
     return (b + 127u) & ~127u;
 }
 
-struct LaneMem { SFrame *stack; staramd_exon *EX, *LEAF; };
+struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LDS u16 *rank; LDS u8 *arena; };
 
 // depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321):
 // include seed iA (if it stitches), then exclude it.  Wave-uniform control flow.  Returns false when the arena overflowed.
-__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const DWA *WA, const LaneMem &m, WinRec &wr) {
+template <bool BIG> __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec<BIG> &wr) {
     const u32 nA = win.nWA;
     c.str = win.str;
     wr.nWinTr = 0; wr.top = 0; wr.overflow = false;
-    SFrame *stack = m.stack; staramd_exon *EX = m.EX, *LEAF = m.LEAF;
+    LDS SFrame *stack = m.stack; LDS staramd_exon *EX = m.EX, *LEAF = m.LEAF; LDS DWA *WA = m.WA;
     Hdr h; h.gStart = 0; h.tG2 = 0; h.nExons = 0; h.Score = 0; h.nMatch = h.nMM = h.nGap = h.lGap = h.nDel = h.lDel = h.nIns = h.lIns = 0;
     h.nUnique = h.nAnchor = 0; h.rStart = 0; h.tR2 = 0;
     u32 iA = 0; u32 sp = 0; u32 ex0R = 0; u64 ex0G = 0;
-    DWA a; a = WA[0];
+    DWA a = ldsGet(&WA[0]);
     for (;;) {
         c.nNodes++;
         if (iA >= nA) {                              // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
             if (h.tR2 != 0) {
-                if (lane < h.nExons) LEAF[lane] = EX[lane];
-                __threadfence_block();
-                finalizeTranscript(c, lane, h, LEAF, win.chr, wr);
+                if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                finalizeTranscript<BIG>(c, lane, h, LEAF, win.chr, wr);
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
             sp--;                                    // back to the frame that included a seed: now exclude it
-            const SFrame &f = stack[sp];
+            SFrame f = ldsGet(&stack[sp]);
             h = f.h; iA = f.iA + 1;
-            if (h.nExons > 0 && lane == 0) EX[h.nExons - 1] = f.eA;
-            __threadfence_block();
-            if (iA < nA) a = WA[iA];
+            if (h.nExons > 0 && lane == 0) ldsPut(&EX[h.nExons - 1], f.eA);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (iA < nA) a = ldsGet(&WA[iA]);
             continue;
         }
         // ---- include branch (:311-345)
         Hdr hn = h; staramd_exon eA, eN; bool added = false; int dScore;
         if (h.nExons > 0) {
-            eA = EX[h.nExons - 1];
+            eA = ldsGet(&EX[h.nExons - 1]);
             staramd_exon eAold = eA;
 #ifdef STARAMD_SHADOW
             Hdr hs = h; staramd_exon eAs = eA, eNs; bool addedS = false;
@@ -680,16 +709,17 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
 #endif
             if (dScore > -1000000) {
                 if (lane == 0) {
-                    SFrame &f = stack[sp]; f.h = h; f.iA = iA; f.pad = 0; f.eA = eAold;
-                    EX[h.nExons - 1] = eA;
-                    if (added) EX[h.nExons] = eN;
+                    SFrame f; f.h = h; f.iA = iA; f.pad = 0; f.eA = eAold;
+                    ldsPut(&stack[sp], f);
+                    ldsPut(&EX[h.nExons - 1], eA);
+                    if (added) ldsPut(&EX[h.nExons], eN);
                 }
                 if (added) hn.nExons = h.nExons + 1;
             }
         } else {                                     // first seed of the transcript (:318-334)
             eN.R = a.rStart; eN.G = a.gStart; eN.L = a.L; eN.iFrag = a.iFrag; eN.sjA = a.sjA;
             eN.canonSJ = 0; eN.sjAnnot = 0; eN.sjStr = 0; eN.shiftSJ[0] = eN.shiftSJ[1] = 0; eN.pad0 = 0; eN.pad1 = 0;
-            if (lane == 0) { SFrame &f = stack[sp]; f.h = h; f.iA = iA; f.pad = 0; EX[0] = eN; }
+            if (lane == 0) { SFrame f; f.h = h; f.iA = iA; f.pad = 0; f.eA = eN; ldsPut(&stack[sp], f); ldsPut(&EX[0], eN); }
             hn.rStart = a.rStart; hn.gStart = a.gStart; hn.nExons = 1; hn.nMatch = a.L;
             dScore = a.L;
         }
@@ -699,31 +729,31 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             hn.Score = h.Score + dScore; hn.tR2 = (u32)a.rStart + a.L - 1; hn.tG2 = a.gStart + a.L - 1;
             if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; }
             h = hn; sp++;
-            __threadfence_block();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
         // include succeeded: continue below it; include failed: exclude branch (:348-351) = same transcript, next seed
         iA++;
-        if (iA < nA) a = WA[iA];
+        if (iA < nA) a = ldsGet(&WA[iA]);
     }
     return true;
 }
 
 // copy the window's recorded transcripts (trAll[iW1][0..nWinTr-1]) into the result pools; false on pool overflow
-__device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o) {
+template <bool BIG> __device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec<BIG> &wr, DWinOut &o) {
     u32 nTr = wr.nWinTr, nEx = 0;
     o.trOffset = 0; o.nTr = 0; o.exOffset = 0; o.nEx = 0; o.headScore = 0; o.headGlen = 0;
     if (nTr == 0) return true;
-    for (u32 k = 0; k < nTr; k++) nEx += recT(wr, k)->nExons;
+    for (u32 k = 0; k < nTr; k++) nEx += recT<BIG>(wr, k)->nExons;
     u32 to = 0, eo = 0;
     if (lane == 0) { to = atomicAdd(&B.cursors[CUR_TR], nTr); eo = atomicAdd(&B.cursors[CUR_EX], nEx); }
     to = first32(to); eo = first32(eo);
     if (to + nTr > B.trCap || eo + nEx > B.exCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_TRPOOL); return false; }
-    const staramd_transcript *hd = recT(wr, 0);
+    typename AS<BIG>::trp hd = recT<BIG>(wr, 0);
     o.trOffset = to; o.nTr = nTr; o.exOffset = eo; o.nEx = nEx; o.headScore = hd->maxScore; o.headGlen = hd->gLength;
     u32 eoff = 0;
     for (u32 k = 0; k < nTr; k++) {
-        const u64 *s = (const u64 *)recT(wr, k);
-        u32 ne = recT(wr, k)->nExons;
+        typename AS<BIG>::u64p s = (typename AS<BIG>::u64p)recT<BIG>(wr, k);
+        u32 ne = recT<BIG>(wr, k)->nExons;
         u64 *dt = (u64 *)&B.trPool[to + k];
         if (lane < REC_HDR / 8) {
             u64 v = s[lane];
@@ -737,11 +767,13 @@ __device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec &wr
     return true;
 }
 
-__device__ __forceinline__ void laneSetup(u8 *mine, u32 capDepth, u32 capRank, u32 arenaBytes, LaneMem &m, WinRec &wr) {
-    m.stack = (SFrame *)mine;
-    m.EX = (staramd_exon *)(mine + (u64)capDepth * sizeof(SFrame));
+__device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRank, LaneMem &m) {
+    m.stack = (LDS SFrame *)mine;
+    m.EX = (LDS staramd_exon *)(mine + capDepth * (u32)sizeof(SFrame));
     m.LEAF = m.EX + STARAMD_MAX_N_EXONS;
-    wr.rank = (u16 *)(m.LEAF + STARAMD_MAX_N_EXONS); wr.arena = (u8 *)wr.rank + ((capRank * 2u + 31u) & ~31u); wr.arenaBytes = arenaBytes;
+    m.rank = (LDS u16 *)(m.LEAF + STARAMD_MAX_N_EXONS);
+    m.WA = (LDS DWA *)((LDS u8 *)m.rank + ((capRank * 2u + 31u) & ~31u));
+    m.arena = (LDS u8 *)m.WA + WA_LDS_BYTES;
 }
 
 __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
@@ -750,9 +782,9 @@ __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBat
     c.mmMaxTotal = B.mmMaxTotal[ir];
     const u32 *src = B.packed + (u64)ir * B.packWords;       // stage the 4-bit packed read in this wavefront's LDS slice
     u32 nw = (c.Lread + 7) / 8;
-    u32 *dst = (u32 *)((u8 *)ldsReads + c.ldsByte);
+    LDS u32 *dst = (LDS u32 *)((LDS u8 *)ldsReads + c.ldsByte);
     for (u32 k = lane; k < nw; k += NLANE) dst[k] = src[k];
-    __threadfence_block();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
 // ---- stitch, one wavefront per WINDOW -------------------------------------------------------------------------------
@@ -761,38 +793,30 @@ __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBat
 // Pass 0 stitches every window with an incoming maxScoreMate of 0 and remembers, per mate, the weakest leaf whose
 // recording hung on that clause (DWinOut::sens).  k_stitch_verify then forms the true incoming values (a prefix maximum
 // of DWinOut::mm over the windows of the read, which does not depend on what was recorded) and queues for pass 1 only
-// the windows whose decisions could differ.  mode: 0 = pass 0, 1 = pass 1; big: worst-case arena, reads the overflow list.
-extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capDepth, u32 capRank, u32 arenaBytes,
-                                                             u32 ldsWords, u32 mode, u32 big) {
+// the windows whose decisions could differ.  mode: 0 = pass 0, 1 = pass 1.
+// A window whose recorded transcripts outgrow the LDS arena is walked again at once by the same wavefront with its
+// arena in global memory (bigArena: one worst-case arena per wavefront).
+extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
+                                                             u32 bigArenaBytes, u32 ldsWords, u32 mode) {
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     const u32 lane = threadIdx.x & 63u;
     u32 waveInBlock = threadIdx.x >> 6, wavesPerBlock = blockDim.x >> 6;
-    u32 stateBytes = stitchLaneBytes(capDepth, capRank, arenaBytes);
+    u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
     u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
-    LaneMem m; WinRec wr;
+    LaneMem m;
     StitchCtx c; c.X = &X; c.nGstitch = 0; c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = 0;
 #ifdef STARAMD_SHADOW
     c.shadow = B.counters + DC_shadowBad;
 #endif
-    if (big) {
-        c.ldsByte = waveInBlock * readBytes;
-        laneSetup(scratch + (u64)(blockIdx.x * wavesPerBlock + waveInBlock) * stateBytes, capDepth, capRank, arenaBytes, m, wr);
-    } else {
-        c.ldsByte = waveInBlock * (readBytes + stateBytes);
-        laneSetup((u8 *)ldsReads + c.ldsByte + readBytes, capDepth, capRank, arenaBytes, m, wr);
-    }
+    c.ldsByte = waveInBlock * (readBytes + stateBytes);
+    laneSetup((LDS u8 *)ldsReads + c.ldsByte + readBytes, capDepth, capRank, m);
+    WinRec<false> wr; wr.rank = m.rank; wr.arena = m.arena; wr.arenaBytes = arenaBytes;
+    WinRec<true> wrBig; wrBig.rank = m.rank; wrBig.arena = bigArena + (u64)(blockIdx.x * wavesPerBlock + waveInBlock) * bigArenaBytes; wrBig.arenaBytes = bigArenaBytes;
     gcInit(c.ca); gcInit(c.cb);
-    const u32 *list; u32 nItems, ticketSlot, ovfSlot; u32 *ovfList;
-    if (mode == 0) {
-        if (!big) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
-        else { list = B.ovfSt0; nItems = B.cursors[CUR_ST_OVF0]; ticketSlot = CUR_ST_TICKET0B; }
-        ovfSlot = CUR_ST_OVF0; ovfList = B.ovfSt0;
-    } else {
-        if (!big) { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
-        else { list = B.ovfSt1; nItems = B.cursors[CUR_ST_OVF1]; ticketSlot = CUR_ST_TICKET1B; }
-        ovfSlot = CUR_ST_OVF1; ovfList = B.ovfSt1;
-    }
+    const u32 *list; u32 nItems, ticketSlot;
+    if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
+    else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
     u32 nOvf = 0, lastRead = 0xFFFFFFFFu;
     for (;;) {
         u32 it = 0;
@@ -803,21 +827,28 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *_
         if (w == 0xFFFFFFFFu) continue;                 // padding slot of the dealt order
         const DWin win = B.winPool[w];
         if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
+        if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+        {   // stage the window's seed list in LDS (3 dwords x 2 per row)
+            const u32 *src = (const u32 *)(B.waPool + win.waOffset); LDS u32 *dst = (LDS u32 *)m.WA;
+            for (u32 k = lane; k < win.nWA * 6u; k += NLANE) dst[k] = src[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
         DWinOut o = B.wout[w];
         if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; }
         c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
         c.sens[0] = c.sens[1] = 0x7FFFFFFF;
-        if (win.nWA + 1u > capDepth) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-        bool ok = stitchWindow(c, lane, win, B.waPool + win.waOffset, m, wr);
-        if (!ok) {
-            if (lane == 0) {
-                if (big) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD);
-                else { u32 k = atomicAdd(&B.cursors[ovfSlot], 1u); ovfList[k] = w; }
-            }
+        bool ok = stitchWindow<false>(c, lane, win, m, wr);
+        bool flushed;
+        if (ok) flushed = flushWindow<false>(B, lane, wr, o);
+        else {
             nOvf++;
-            continue;
+            c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
+            c.sens[0] = c.sens[1] = 0x7FFFFFFF;
+            ok = stitchWindow<true>(c, lane, win, m, wrBig);
+            if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+            flushed = flushWindow<true>(B, lane, wrBig, o);
         }
-        if (!flushWindow(B, lane, wr, o)) continue;
+        if (!flushed) continue;
         o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
         o.sens[0] = c.sens[0]; o.sens[1] = c.sens[1]; o.done = 1;
         if (lane == 0) B.wout[w] = o;
@@ -828,7 +859,7 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *_
         atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);
         atomicAdd((unsigned long long *)&B.counters[DC_nNodes], (unsigned long long)c.nNodes);
         atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
-        if (nOvf && !big) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
+        if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
     }
 }
 

@@ -25,7 +25,7 @@ struct StitchCtx {
 };
 
 __device__ __forceinline__ u8 rdNib(const StitchCtx &c, u32 j) {
-    u8 b = ((const u8 *)ldsReads)[c.ldsByte + (j >> 1)];
+    u8 b = ((const __attribute__((address_space(3))) u8 *)ldsReads)[c.ldsByte + (j >> 1)];
     return (j & 1) ? (u8)(b >> 4) : (u8)(b & 15);
 }
 __device__ __forceinline__ u8 RD(const StitchCtx &c, u32 i) {        // R[i], ReadAlign_stitchPieces.cpp:321
