@@ -162,7 +162,7 @@ def main():
     if rank == 0:
         run.finish()
     cnt = eng.counters()
-    names = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut", "nOvfWin", "nOvfStitch"]
+    names = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut", "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
     c = dict(zip(names, cnt))
     eng.close(); run.close()
     if rank != 0:

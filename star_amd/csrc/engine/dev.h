@@ -65,10 +65,13 @@ struct DRead {
 //   sens[f] smallest (Score + outFilterMultimapScoreRange) among the leaves of mate f whose recording was decided by the
 //           maxScoreMate clause alone (stitchWindowAligns.cpp:245-247); INT32_MAX if none.  The window was stitched with
 //           the incoming maxScoreMate of minIn[]; the result is exact iff sens[f] >= the true incoming value
-struct DWinOut { u32 trOffset, nTr, exOffset, nEx; i32 mm[2]; i32 sens[2]; i32 minIn[2]; i32 headScore; u32 done; u64 headGlen; };
+//   candOff32 / nCand: the window's CANDIDATE LOG (every leaf that reached the record decision, as output-format records,
+//           in walk order) inside candPool, offset in 32-byte units; nCand = 0xFFFFFFFF: log not available.  Re-deciding
+//           the window for another incoming maxScoreMate only needs a replay of this log, not a second walk.
+struct DWinOut { u32 trOffset, nTr, exOffset, nEx; i32 mm[2]; i32 sens[2]; i32 minIn[2]; i32 headScore; u32 candOff32; u64 headGlen; u32 nCand; u32 pad; };
 
 enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nWindows, DC_nWA, DC_nNodes, DC_nLeaves,
-       DC_nStitchCalls, DC_nExtendCalls, DC_nTrOut, DC_nOvfWin, DC_nOvfStitch, DC_nRedoWin,
+       DC_nStitchCalls, DC_nExtendCalls, DC_nTrOut, DC_nOvfWin, DC_nOvfStitch, DC_nRedoWin, DC_nReplayWin,
        DC_shadowBad, DC_shadowN, DC_shadowExtBad, DC_shadowExtN,   // shadow-validation build only (see stitch_scalar.h)
        DC_N };
 
@@ -76,8 +79,9 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
 enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS = 6,
        CUR_TICKET_SEED = 8, CUR_TICKET_WIN = 9, CUR_OVF_WIN = 11, CUR_TICKET_WIN2 = 13,
        // stitch stage: work lists of window ids and their tickets
-       CUR_ST_TICKET0 = 16, CUR_ST_OVF0 = 17, CUR_ST_TICKET0B = 18,      // pass 0 (all windows, incoming maxScoreMate 0): fast / big
-       CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20, CUR_ST_OVF1 = 21, CUR_ST_TICKET1B = 22,   // pass 1 (windows whose result depends on the true incoming value)
+       CUR_ST_TICKET0 = 16,                                              // pass 0: all windows, incoming maxScoreMate 0
+       CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
+       CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
        CUR_N = 32 };
 // CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
 enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };
@@ -96,7 +100,8 @@ struct DevBatch {
     u32 *costHist;     // 32 cost classes + 32 offsets
     u8 *winClass;      // cost class of every window (winCap)
     u32 *ovfWin;       // reads deferred to the big-work-space pass of k_windows
-    u32 *ovfSt0, *ovfSt1, *redoList;   // stitch work lists (window ids)
+    u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
+    u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win
     u32 *cursors;      // CUR_*
     u64 *counters;     // DC_N
 };

@@ -16,6 +16,7 @@ extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
 extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords, u32 mode);
+extern "C" __global__ void k_stitch_replay(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords);
 extern "C" __global__ void k_stitch_verify(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_stitch_finish(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_scan_offsets(DevBatch B, u32 *trBase, u32 *exBase, u32 *totals);
@@ -185,9 +186,8 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.wout, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.winClass, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.order, (u64)B.winCap + 64))) return rc;
-    if ((rc = devAlloc(R, &B.ovfSt0, (u64)B.winCap))) return rc;
-    if ((rc = devAlloc(R, &B.ovfSt1, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.replayList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.trPool, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
     if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
@@ -230,6 +230,10 @@ static int allocWork(staramd_ctx *c) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stPerCU, k_stitch_win, 256, ldsFast) != hipSuccess || stPerCU < 1) stPerCU = 2;
     c->stBlocks = (u32)c->nCU * envU32("STARAMD_STITCH_BLOCKS_PER_CU", (u32)stPerCU);
     if ((rc = devAlloc(R, &c->scrStitchBig, (u64)c->stBlocks * 4 * c->arenaBig))) return rc;
+    // candidate logs: one private region per wavefront; sized so that a wavefront's share of a full batch fits
+    B.candWaveBytes = ((u64)envU32("STARAMD_CAND_KB_PER_WAVE", 0) * 1024) & ~31ull;
+    if (B.candWaveBytes == 0) { u64 per = (u64)N * 6144 / ((u64)c->stBlocks * 4) + 262144; B.candWaveBytes = std::min<u64>(per, 0xFFFF0000ull) & ~31ull; }
+    if ((rc = devAlloc(R, &B.candPool, (u64)c->stBlocks * 4 * B.candWaveBytes))) return rc;
     return 0;
 }
 
@@ -281,9 +285,8 @@ static int growPools(staramd_ctx *c, u32 flags) {
         if ((rc = devRealloc(R, &B.wout, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.winClass, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.order, (u64)B.winCap + 64))) return rc;
-        if ((rc = devRealloc(R, &B.ovfSt0, (u64)B.winCap))) return rc;
-        if ((rc = devRealloc(R, &B.ovfSt1, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;
     }
     if (flags & OVF_TRPOOL) {
         B.trCap = dbl(B.trCap); B.exCap = dbl(B.exCap);
@@ -323,7 +326,10 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         size_t ldsFast = 4 * (readBytes + stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast));
         for (u32 mode = 0; mode < 2; mode++) {
             hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, mode);
-            if (mode == 0) hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);
+            if (mode == 0) {
+                hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);
+                hipLaunchKernelGGL(k_stitch_replay, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords);
+            }
         }
         hipLaunchKernelGGL(k_stitch_finish, dim3((n + 255) / 256), block, 0, s, c->dX, B);
     }

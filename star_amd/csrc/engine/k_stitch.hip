@@ -423,22 +423,27 @@ template <class P1, class P2> __device__ static u32 blocksOverlap(P1 e1, u32 n1,
 
 // transcripts recorded for the current window: records in the OUTPUT format (staramd_transcript followed by its
 // exons) bump-allocated in the window's arena; rank[] holds their offsets (32-byte units), best first.
-template <bool BIG> struct WinRec { typename AS<BIG>::u8p arena; u32 arenaBytes; u32 top; LDS u16 *rank; u32 nWinTr; bool overflow; };
+// big = false: arena in the wavefront's LDS slice (arenaL); big = true: arena in HBM (arenaG).  The walk itself is
+// instantiated once; only the few routines that touch records are specialised on the address space.
+struct WinRec { LDS u8 *arenaL; u8 *arenaG; u32 arenaBytesL, arenaBytesG; bool big; u32 arenaBytes; u32 top; LDS u16 *rank; u32 nWinTr; bool overflow; i32 bestScore; };
+template <bool BIG> struct ArenaSel;
+template <> struct ArenaSel<false> { static __device__ __forceinline__ LDS u8 *get(const WinRec &w) { return w.arenaL; } };
+template <> struct ArenaSel<true> { static __device__ __forceinline__ u8 *get(const WinRec &w) { return w.arenaG; } };
 #define REC_HDR 96
 static_assert(sizeof(staramd_transcript) == REC_HDR, "record header is the output transcript record");
 static_assert(sizeof(staramd_exon) == 32, "exon record is 32 bytes");
-template <bool BIG> __device__ __forceinline__ typename AS<BIG>::trp recAt(const WinRec<BIG> &w, u32 off32) { return (typename AS<BIG>::trp)(w.arena + off32 * 32u); }
-template <bool BIG> __device__ __forceinline__ typename AS<BIG>::trp recT(const WinRec<BIG> &w, u32 k) { return recAt<BIG>(w, w.rank[k]); }
+template <bool BIG> __device__ __forceinline__ typename AS<BIG>::trp recAt(const WinRec &w, u32 off32) { return (typename AS<BIG>::trp)(ArenaSel<BIG>::get(w) + off32 * 32u); }
+template <bool BIG> __device__ __forceinline__ typename AS<BIG>::trp recT(const WinRec &w, u32 k) { return recAt<BIG>(w, w.rank[k]); }
 
 // slide the live records to the front of the arena (only when the bump pointer hits the end); run by lane 0
-template <bool BIG> __device__ static u32 compactArena(WinRec<BIG> &w) {
+template <bool BIG> __device__ static u32 compactArena(WinRec &w) {
     u32 newTop = 0; i32 lastOrig = -1;
     for (u32 step = 0; step < w.nWinTr; step++) {
         u32 best = 0xFFFFFFFFu, bk = 0;
         for (u32 k = 0; k < w.nWinTr; k++) { u32 o = w.rank[k]; if ((i32)o > lastOrig && o < best) { best = o; bk = k; } }
         if (best == 0xFFFFFFFFu) break;
         u32 words = (REC_HDR + 32u * recAt<BIG>(w, best)->nExons) / 8;
-        typename AS<BIG>::u64p s = (typename AS<BIG>::u64p)(w.arena + best * 32u), d = (typename AS<BIG>::u64p)(w.arena + newTop);
+        typename AS<BIG>::u64p s = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(w) + best * 32u), d = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(w) + newTop);
         if (d != s) for (u32 i = 0; i < words; i++) d[i] = s[i];
         w.rank[bk] = (u16)(newTop / 32u);
         lastOrig = (i32)best; newTop += words * 8;
@@ -447,8 +452,93 @@ template <bool BIG> __device__ static u32 compactArena(WinRec<BIG> &w) {
     return newTop;
 }
 
+// record decision is taken: de-duplicate candidate (o, exon rows ex / x) against the recorded transcripts and insert it
+// by rank (stitchWindowAligns.cpp:267-303).  Used by the walk (pass 0 / full re-walk) and by the replay of a candidate log.
+template <bool BIG, class EXP> __device__ static void recordCandidateImpl(const staramd_params &P, u32 lane, const staramd_transcript &o, const staramd_exon &x, EXP ex, WinRec &wr) {
+    const int Score = o.maxScore; const u64 gLength = o.gLength; const u32 mappedLength = o.mappedLength; const u32 ne = o.nExons;
+    // ---- de-duplication against the recorded transcripts (:267-285): lane k classifies record k
+    //   BLOCK  new one adds nothing to record k and scores lower  -> the walk over the list stops, new one is dropped
+    //   REMOVE record k adds nothing to the new one                -> record k is removed (if met before a BLOCK)
+    {
+        const u32 nW0 = wr.nWinTr;
+        u32 outN = 0; bool blocked = false; u32 base = 0;
+        for (; base < nW0 && !blocked; base += NLANE) {
+            u32 k = base + lane; bool have = k < nW0;
+            u16 rk = 0; u32 cls = 0;
+            if (have) {
+                rk = wr.rank[k];
+                typename AS<BIG>::trp r = recAt<BIG>(wr, rk);
+                u32 nOverlap = blocksOverlap(ex, ne, (typename AS<BIG>::exp)((typename AS<BIG>::u8p)r + REC_HDR), (u32)r->nExons);
+                u32 uNew = mappedLength - nOverlap, uOld = r->mappedLength - nOverlap;
+                if (uNew == 0 && Score < r->maxScore) cls = 1; else if (uOld == 0) cls = 2;
+            }
+            u64 mB = __ballot(cls == 1), mR = __ballot(cls == 2), mH = __ballot(have);
+            if (mB) { u32 fb = firstLane(mB); blocked = true; mR &= (1ull << fb) - 1ull; }
+            u64 keep = mH & ~mR;
+            if (have && ((keep >> lane) & 1ull)) wr.rank[outN + cntBelow(keep)] = rk;
+            outN += (u32)__popcll(keep);
+        }
+        if (blocked) {                                   // entries behind the blocking chunk keep their order
+            for (; base < nW0; base += NLANE) {
+                u32 k = base + lane; bool have = k < nW0;
+                u16 rk = have ? wr.rank[k] : (u16)0;
+                if (have) wr.rank[outN + lane] = rk;
+                outN += min(NLANE, nW0 - base);
+            }
+            wr.nWinTr = outN;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            return;
+        }
+        wr.nWinTr = outN;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    // ---- ranked insert (:287-303)
+    u32 iTr = wr.nWinTr;
+    for (u32 base = 0; base < wr.nWinTr; base += NLANE) {
+        u32 k = base + lane; bool better = false;
+        if (k < wr.nWinTr) { typename AS<BIG>::trp r = recT<BIG>(wr, k); better = Score > r->maxScore || (Score == r->maxScore && gLength < r->gLength); }
+        u64 bm = __ballot(better);
+        if (bm) { iTr = base + firstLane(bm); break; }
+    }
+    if (iTr >= P.alignTranscriptsPerWindowNmax) return;          // ranks behind a full list: dropped
+    u32 need = REC_HDR + 32u * ne;
+    if (wr.top + need > wr.arenaBytes) {
+        u32 nt = 0;
+        if (lane == 0) nt = compactArena<BIG>(wr);
+        wr.top = first32(nt);
+        if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // also give up when the live set alone fills 3/4 of the arena: the next leaves would compact over and over
+        if (wr.top + need > wr.arenaBytes || wr.top * 4u > wr.arenaBytes * 3u) { wr.overflow = true; return; }
+    }
+    u32 off = wr.top; wr.top += need;
+    u32 newN = min(wr.nWinTr + 1, P.alignTranscriptsPerWindowNmax);
+    for (int top = (int)newN - 1; top > (int)iTr; top -= (int)NLANE) {        // shift ranks iTr..newN-2 up by one
+        int k = top - (int)lane;
+        u16 v = 0; bool mv = k > (int)iTr;
+        if (mv) v = wr.rank[k - 1];
+        if (mv) wr.rank[k] = v;
+    }
+    if (lane == 0) wr.rank[iTr] = (u16)(off / 32u);
+    wr.nWinTr = newN;
+    if (lane == 0) {                                  // record = output transcript header + exon rows, 8-byte words
+        typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(wr) + off); const u64 *sw = (const u64 *)&o;
+#pragma unroll
+        for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i];
+    }
+    if (lane < ne) {
+        typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(wr) + off + REC_HDR + 32u * lane); const u64 *sw = (const u64 *)&x;
+        d[0] = sw[0]; d[1] = sw[1]; d[2] = sw[2]; d[3] = sw[3];
+    }
+    if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+template <class EXP> __device__ static void recordCandidate(const staramd_params &P, u32 lane, const staramd_transcript &o, const staramd_exon &x, EXP ex, WinRec &wr) {
+    if (wr.big) { recordCandidateImpl<true>(P, lane, o, x, ex, wr); wr.bestScore = wr.nWinTr > 0 ? recT<true>(wr, 0)->maxScore : 0; }
+    else { recordCandidateImpl<false>(P, lane, o, x, ex, wr); wr.bestScore = wr.nWinTr > 0 ? recT<false>(wr, 0)->maxScore : 0; }
+}
+
 // leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
-template <bool BIG> __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec<BIG> &wr) {
+__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
     c.nLeaves++;
     u32 Lread = c.Lread; u32 Str = c.str;
@@ -546,7 +636,7 @@ template <bool BIG> __device__ static void finalizeTranscript(StitchCtx &c, u32 
     i32 iFragT;
     if (ex[0].iFrag == ex[ne - 1].iFrag) { iFragT = ex[0].iFrag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
     else iFragT = -1;
-    i32 winBest = wr.nWinTr > 0 ? recT<BIG>(wr, 0)->maxScore : 0;            // wTr[0]->maxScore (trA with score 0 before any record)
+    i32 winBest = wr.bestScore;            // wTr[0]->maxScore (trA with score 0 before any record)
     {
         bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
         bool c2 = iFragT >= 0 && Score + P.outFilterMultimapScoreRange >= c.maxScoreMate[iFragT];
@@ -554,97 +644,39 @@ template <bool BIG> __device__ static void finalizeTranscript(StitchCtx &c, u32 
         // decided by the maxScoreMate clause alone: the decision holds for any incoming maxScoreMate <= Score + range
         if (!c1) c.sens[iFragT] = min(c.sens[iFragT], Score + P.outFilterMultimapScoreRange);
     }
-    const u32 mappedLength = rLength;
-    // ---- de-duplication against the recorded transcripts (:267-285): lane k classifies record k
-    //   BLOCK  new one adds nothing to record k and scores lower  -> the walk over the list stops, new one is dropped
-    //   REMOVE record k adds nothing to the new one                -> record k is removed (if met before a BLOCK)
-    {
-        const u32 nW0 = wr.nWinTr;
-        u32 outN = 0; bool blocked = false; u32 base = 0;
-        for (; base < nW0 && !blocked; base += NLANE) {
-            u32 k = base + lane; bool have = k < nW0;
-            u16 rk = 0; u32 cls = 0;
-            if (have) {
-                rk = wr.rank[k];
-                typename AS<BIG>::trp o = recAt<BIG>(wr, rk);
-                u32 nOverlap = blocksOverlap(ex, ne, (typename AS<BIG>::exp)((typename AS<BIG>::u8p)o + REC_HDR), (u32)o->nExons);
-                u32 uNew = mappedLength - nOverlap, uOld = o->mappedLength - nOverlap;
-                if (uNew == 0 && Score < o->maxScore) cls = 1; else if (uOld == 0) cls = 2;
-            }
-            u64 mB = __ballot(cls == 1), mR = __ballot(cls == 2), mH = __ballot(have);
-            if (mB) { u32 fb = firstLane(mB); blocked = true; mR &= (1ull << fb) - 1ull; }
-            u64 keep = mH & ~mR;
-            if (have && ((keep >> lane) & 1ull)) wr.rank[outN + cntBelow(keep)] = rk;
-            outN += (u32)__popcll(keep);
-        }
-        if (blocked) {                                   // entries behind the blocking chunk keep their order
-            for (; base < nW0; base += NLANE) {
-                u32 k = base + lane; bool have = k < nW0;
-                u16 rk = have ? wr.rank[k] : (u16)0;
-                if (have) wr.rank[outN + lane] = rk;
-                outN += min(NLANE, nW0 - base);
-            }
-            wr.nWinTr = outN;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            return;
-        }
-        wr.nWinTr = outN;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
-    // ---- ranked insert (:287-303)
-    u32 iTr = wr.nWinTr;
-    for (u32 base = 0; base < wr.nWinTr; base += NLANE) {
-        u32 k = base + lane; bool better = false;
-        if (k < wr.nWinTr) { typename AS<BIG>::trp o = recT<BIG>(wr, k); better = Score > o->maxScore || (Score == o->maxScore && gLength < o->gLength); }
-        u64 bm = __ballot(better);
-        if (bm) { iTr = base + firstLane(bm); break; }
-    }
-    if (iTr >= P.alignTranscriptsPerWindowNmax) return;          // ranks behind a full list: dropped
-    u32 need = REC_HDR + 32u * ne;
-    if (wr.top + need > wr.arenaBytes) {
-        u32 nt = 0;
-        if (lane == 0) nt = compactArena<BIG>(wr);
-        wr.top = first32(nt);
-        if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // also give up when the live set alone fills 3/4 of the arena: the next leaves would compact over and over
-        if (wr.top + need > wr.arenaBytes || wr.top * 4u > wr.arenaBytes * 3u) { wr.overflow = true; return; }
-    }
-    u32 off = wr.top; wr.top += need;
-    u32 newN = min(wr.nWinTr + 1, P.alignTranscriptsPerWindowNmax);
-    for (int top = (int)newN - 1; top > (int)iTr; top -= (int)NLANE) {        // shift ranks iTr..newN-2 up by one
-        int k = top - (int)lane;
-        u16 v = 0; bool mv = k > (int)iTr;
-        if (mv) v = wr.rank[k - 1];
-        if (mv) wr.rank[k] = v;
-    }
-    if (lane == 0) wr.rank[iTr] = (u16)(off / 32u);
-    wr.nWinTr = newN;
-    {   // record = output transcript header + exon rows, written as 8-byte words: word w of the header by lane w
-        staramd_transcript o;
-        { u64 *z = (u64 *)&o; for (u32 i = 0; i < REC_HDR / 8; i++) z[i] = 0; }          // padding included: records are compared byte for byte
-        o.iW = 0; o.exonOffset = 0;
-        o.nExons = (u16)ne; o.rStart = (u16)h.rStart; o.rLength = (u16)rLength;
-        o.roStart = (u16)((Str == 0) ? h.rStart : Lread - h.rStart - rLength);
-        o.Str = (u8)Str; o.roStr = (u8)Str; o.iFrag = (i8)iFragT; o.sjMotifStrand = sjMotifStrand; o.Chr = chr;
-        o.gStart = h.gStart; o.gLength = gLength; o.maxScore = Score; o.nMatch = h.nMatch; o.nMM = h.nMM; o.mappedLength = mappedLength;
-        o.nGap = h.nGap; o.lGap = h.lGap; o.nDel = h.nDel; o.lDel = h.lDel; o.nIns = h.nIns; o.lIns = h.lIns;
-        o.nUnique = (u16)h.nUnique; o.nAnchor = (u16)h.nAnchor;
-        o.intronMotifs[0] = intronMotifs[0]; o.intronMotifs[1] = intronMotifs[1]; o.intronMotifs[2] = intronMotifs[2]; o.pad0 = 0; o.pad1 = 0;
-        if (lane == 0) {
-            typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(wr.arena + off); const u64 *sw = (const u64 *)&o;
-#pragma unroll
-            for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i];
-        }
-    }
+    // ---- the candidate as an output record: header (wave-uniform) + this lane's exon row
+    staramd_transcript o;
+    { u64 *z = (u64 *)&o; for (u32 i = 0; i < REC_HDR / 8; i++) z[i] = 0; }          // padding included: records are compared byte for byte
+    o.iW = 0; o.exonOffset = 0;
+    o.nExons = (u16)ne; o.rStart = (u16)h.rStart; o.rLength = (u16)rLength;
+    o.roStart = (u16)((Str == 0) ? h.rStart : Lread - h.rStart - rLength);
+    o.Str = (u8)Str; o.roStr = (u8)Str; o.iFrag = (i8)iFragT; o.sjMotifStrand = sjMotifStrand; o.Chr = chr;
+    o.gStart = h.gStart; o.gLength = gLength; o.maxScore = Score; o.nMatch = h.nMatch; o.nMM = h.nMM; o.mappedLength = rLength;
+    o.nGap = h.nGap; o.lGap = h.lGap; o.nDel = h.nDel; o.lDel = h.lDel; o.nIns = h.nIns; o.lIns = h.lIns;
+    o.nUnique = (u16)h.nUnique; o.nAnchor = (u16)h.nAnchor;
+    o.intronMotifs[0] = intronMotifs[0]; o.intronMotifs[1] = intronMotifs[1]; o.intronMotifs[2] = intronMotifs[2]; o.pad0 = 0; o.pad1 = 0;
+    staramd_exon x;
+    { u64 *z = (u64 *)&x; z[0] = z[1] = z[2] = z[3] = 0; }
     if (lane < ne) {
-        staramd_exon x = ldsGet(&ex[lane]);
+        x = ldsGet(&ex[lane]);
         if (lane + 1 == ne) { x.canonSJ = 0; x.sjAnnot = 0; x.sjStr = 0; x.shiftSJ[0] = x.shiftSJ[1] = 0; }
         else if (x.canonSJ < 0) { x.shiftSJ[0] = x.shiftSJ[1] = 0; }
         x.pad0 = 0; x.pad1 = 0;
-        typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(wr.arena + off + REC_HDR + 32u * lane); const u64 *sw = (const u64 *)&x;
-        d[0] = sw[0]; d[1] = sw[1]; d[2] = sw[2]; d[3] = sw[3];
     }
-    if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- candidate log (pass 0): lets pass 1 re-decide this window without walking it again
+    if (c.logOn && !c.logOvf) {
+        u32 need = REC_HDR + 32u * ne;
+        if (c.candTop + need > c.candCap) c.logOvf = true;
+        else {
+            u64 *d = (u64 *)(c.candBase + c.candTop);
+            if (lane == 0) { const u64 *sw = (const u64 *)&o;
+#pragma unroll
+                for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i]; }
+            if (lane < ne) { const u64 *sw = (const u64 *)&x; u64 *de = d + REC_HDR / 8 + 4u * lane; de[0] = sw[0]; de[1] = sw[1]; de[2] = sw[2]; de[3] = sw[3]; }
+            c.candTop += need; c.nCand++;
+        }
+    }
+    recordCandidate(P, lane, o, x, ex, wr);
 }
 
 // per-window LDS work space, in bytes: undo stack, exon rows, leaf copy, rank list, seed list (+ arena in the fast path)
@@ -658,10 +690,10 @@ struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LD
 
 // depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321):
 // include seed iA (if it stitches), then exclude it.  Wave-uniform control flow.  Returns false when the arena overflowed.
-template <bool BIG> __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec<BIG> &wr) {
+__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec &wr) {
     const u32 nA = win.nWA;
     c.str = win.str;
-    wr.nWinTr = 0; wr.top = 0; wr.overflow = false;
+    wr.nWinTr = 0; wr.top = 0; wr.overflow = false; wr.bestScore = 0;
     LDS SFrame *stack = m.stack; LDS staramd_exon *EX = m.EX, *LEAF = m.LEAF; LDS DWA *WA = m.WA;
     Hdr h; h.gStart = 0; h.tG2 = 0; h.nExons = 0; h.Score = 0; h.nMatch = h.nMM = h.nGap = h.lGap = h.nDel = h.lDel = h.nIns = h.lIns = 0;
     h.nUnique = h.nAnchor = 0; h.rStart = 0; h.tR2 = 0;
@@ -673,7 +705,7 @@ template <bool BIG> __device__ static bool stitchWindow(StitchCtx &c, u32 lane, 
             if (h.tR2 != 0) {
                 if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                finalizeTranscript<BIG>(c, lane, h, LEAF, win.chr, wr);
+                finalizeTranscript(c, lane, h, LEAF, win.chr, wr);
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
@@ -739,7 +771,7 @@ template <bool BIG> __device__ static bool stitchWindow(StitchCtx &c, u32 lane, 
 }
 
 // copy the window's recorded transcripts (trAll[iW1][0..nWinTr-1]) into the result pools; false on pool overflow
-template <bool BIG> __device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec<BIG> &wr, DWinOut &o) {
+template <bool BIG> __device__ static bool flushWindowImpl(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o) {
     u32 nTr = wr.nWinTr, nEx = 0;
     o.trOffset = 0; o.nTr = 0; o.exOffset = 0; o.nEx = 0; o.headScore = 0; o.headGlen = 0;
     if (nTr == 0) return true;
@@ -765,6 +797,10 @@ template <bool BIG> __device__ static bool flushWindow(const DevBatch &B, u32 la
         eoff += ne;
     }
     return true;
+}
+
+__device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o) {
+    return wr.big ? flushWindowImpl<true>(B, lane, wr, o) : flushWindowImpl<false>(B, lane, wr, o);
 }
 
 __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRank, LaneMem &m) {
@@ -796,7 +832,7 @@ __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBat
 // the windows whose decisions could differ.  mode: 0 = pass 0, 1 = pass 1.
 // A window whose recorded transcripts outgrow the LDS arena is walked again at once by the same wavefront with its
 // arena in global memory (bigArena: one worst-case arena per wavefront).
-extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
+extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
                                                              u32 bigArenaBytes, u32 ldsWords, u32 mode) {
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
@@ -811,9 +847,10 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *_
 #endif
     c.ldsByte = waveInBlock * (readBytes + stateBytes);
     laneSetup((LDS u8 *)ldsReads + c.ldsByte + readBytes, capDepth, capRank, m);
-    WinRec<false> wr; wr.rank = m.rank; wr.arena = m.arena; wr.arenaBytes = arenaBytes;
-    WinRec<true> wrBig; wrBig.rank = m.rank; wrBig.arena = bigArena + (u64)(blockIdx.x * wavesPerBlock + waveInBlock) * bigArenaBytes; wrBig.arenaBytes = bigArenaBytes;
+    const u32 waveId = blockIdx.x * wavesPerBlock + waveInBlock;
+    WinRec wr; wr.rank = m.rank; wr.arenaL = m.arena; wr.arenaBytesL = arenaBytes; wr.arenaG = bigArena + (u64)waveId * bigArenaBytes; wr.arenaBytesG = bigArenaBytes;
     gcInit(c.ca); gcInit(c.cb);
+    c.candBase = B.candPool + (u64)waveId * B.candWaveBytes; c.candTop = 0; c.candCap = (u32)B.candWaveBytes; c.nCand = 0; c.logOn = mode == 0; c.logOvf = false;
     const u32 *list; u32 nItems, ticketSlot;
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
@@ -837,20 +874,27 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *_
         if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; }
         c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
         c.sens[0] = c.sens[1] = 0x7FFFFFFF;
-        bool ok = stitchWindow<false>(c, lane, win, m, wr);
-        bool flushed;
-        if (ok) flushed = flushWindow<false>(B, lane, wr, o);
-        else {
-            nOvf++;
+        const u32 candStart = c.candTop;
+        bool ok = false;
+        for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {         // 2nd attempt: same walk, record arena in HBM
+            wr.big = attempt != 0; wr.arenaBytes = wr.big ? wr.arenaBytesG : wr.arenaBytesL;
             c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
             c.sens[0] = c.sens[1] = 0x7FFFFFFF;
-            ok = stitchWindow<true>(c, lane, win, m, wrBig);
-            if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-            flushed = flushWindow<true>(B, lane, wrBig, o);
+            c.candTop = candStart; c.nCand = 0; c.logOvf = false;
+            ok = stitchWindow(c, lane, win, m, wr);
+            if (!ok) nOvf++;
         }
-        if (!flushed) continue;
+        if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+        if (!flushWindow(B, lane, wr, o)) continue;
         o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
-        o.sens[0] = c.sens[0]; o.sens[1] = c.sens[1]; o.done = 1;
+        o.sens[0] = c.sens[0]; o.sens[1] = c.sens[1];
+        // keep the candidate log only if some decision of this window depends on the incoming maxScoreMate
+        o.candOff32 = 0; o.nCand = 0; o.pad = 0;
+        if (c.logOn) {
+            bool sensitive = c.sens[0] != 0x7FFFFFFF || c.sens[1] != 0x7FFFFFFF;
+            if (sensitive && !c.logOvf) { o.candOff32 = (u32)(((u64)waveId * B.candWaveBytes + candStart) / 32u); o.nCand = c.nCand; }
+            else { c.candTop = candStart; if (sensitive) o.nCand = 0xFFFFFFFFu; }
+        }
         if (lane == 0) B.wout[w] = o;
     }
     if (lane == 0) {
@@ -863,23 +907,90 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_win(const DevIndex *_
     }
 }
 
+// ---- pass 1 by replay: re-decide a window from its candidate log with the true incoming maxScoreMate ---------------
+// The walk of a window (which leaves exist, their scores, the order) does not depend on maxScoreMate; only the record
+// decision of each candidate does.  The log holds every leaf that passed (window-best clause OR mate clause with
+// incoming 0), in walk order -- a superset, in order, of what any larger incoming value admits -- so replaying the
+// decision + de-duplication + ranked insert over the log reproduces the sequential result exactly, with no genome or
+// read access at all.
+__device__ static bool replayWindow(const staramd_params &P, u32 lane, const DWinOut &o, const u8 *log, WinRec &wr) {
+    wr.nWinTr = 0; wr.top = 0; wr.overflow = false; wr.bestScore = 0;
+    i32 M[2] = {o.minIn[0], o.minIn[1]};
+    const u8 *p = log;
+    for (u32 ic = 0; ic < o.nCand; ic++) {
+        staramd_transcript t;
+        { const u64 *sw = (const u64 *)p; u64 *d = (u64 *)&t;
+#pragma unroll
+          for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i]; }
+        const u32 ne = t.nExons;
+        const staramd_exon *ex = (const staramd_exon *)(p + REC_HDR);
+        staramd_exon x;
+        { u64 *z = (u64 *)&x; z[0] = z[1] = z[2] = z[3] = 0; }
+        if (lane < ne) { const u64 *sw = (const u64 *)(ex + lane); u64 *d = (u64 *)&x; d[0] = sw[0]; d[1] = sw[1]; d[2] = sw[2]; d[3] = sw[3]; }
+        p += REC_HDR + 32u * ne;
+        const int Score = t.maxScore; const int f = t.iFrag;
+        i32 Mf = 0;
+        if (f == 0) { M[0] = max(M[0], Score); Mf = M[0]; } else if (f == 1) { M[1] = max(M[1], Score); Mf = M[1]; }
+        i32 winBest = wr.bestScore;
+        bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
+        bool c2 = f >= 0 && Score + P.outFilterMultimapScoreRange >= Mf;
+        if (!(c1 || c2)) continue;
+        recordCandidate(P, lane, t, x, ex, wr);
+        if (wr.overflow) return false;
+    }
+    return true;
+}
+
+extern "C" __global__ void __launch_bounds__(256) k_stitch_replay(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
+                                                                u32 bigArenaBytes, u32 ldsWords) {
+    const staramd_params &P = Xp->P;
+    const u32 lane = threadIdx.x & 63u;
+    u32 waveInBlock = threadIdx.x >> 6, wavesPerBlock = blockDim.x >> 6;
+    u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
+    u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
+    LaneMem m;
+    laneSetup((LDS u8 *)ldsReads + waveInBlock * (readBytes + stateBytes) + readBytes, capDepth, capRank, m);
+    WinRec wr; wr.rank = m.rank; wr.arenaL = m.arena; wr.arenaBytesL = arenaBytes; wr.arenaG = bigArena + (u64)(blockIdx.x * wavesPerBlock + waveInBlock) * bigArenaBytes; wr.arenaBytesG = bigArenaBytes;
+    const u32 nItems = B.cursors[CUR_ST_REPLAY];
+    for (;;) {
+        u32 it = 0;
+        if (lane == 0) it = atomicAdd(&B.cursors[CUR_ST_TICKETR], 1u);
+        it = first32(it);
+        if (it >= nItems) break;
+        u32 w = B.replayList[it];
+        DWinOut o = B.wout[w];
+        const u8 *log = B.candPool + (u64)o.candOff32 * 32u;
+        bool ok = false;
+        for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {
+            wr.big = attempt != 0; wr.arenaBytes = wr.big ? wr.arenaBytesG : wr.arenaBytesL;
+            ok = replayWindow(P, lane, o, log, wr);
+        }
+        if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+        if (!flushWindow(B, lane, wr, o)) continue;
+        // mm (max over the leaves of this window) and the other fields keep their pass-0 values
+        if (lane == 0) B.wout[w] = o;
+    }
+}
+
 // ---- per read: true incoming maxScoreMate of every window; queue the windows whose pass-0 result may differ ----
 extern "C" __global__ void __launch_bounds__(256) k_stitch_verify(const DevIndex *__restrict__ Xp, DevBatch B) {
     u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
     if (ir >= B.nReads) return;
     const DRead rd = B.reads[ir];
     if (rd.nWin == 0) return;
-    i32 M0 = 0, M1 = 0; u32 nRedo = 0;
+    i32 M0 = 0, M1 = 0; u32 nRedo = 0, nReplay = 0;
     for (u32 iw = 0; iw < rd.nWin; iw++) {
         u32 w = rd.winOffset + iw;
         DWinOut o = B.wout[w];
         if (o.sens[0] < M0 || o.sens[1] < M1) {
             o.minIn[0] = M0; o.minIn[1] = M1; B.wout[w] = o;
-            u32 k = atomicAdd(&B.cursors[CUR_ST_REDO], 1u); B.redoList[k] = w; nRedo++;
+            if (o.nCand == 0xFFFFFFFFu) { u32 k = atomicAdd(&B.cursors[CUR_ST_REDO], 1u); B.redoList[k] = w; nRedo++; }
+            else { u32 k = atomicAdd(&B.cursors[CUR_ST_REPLAY], 1u); B.replayList[k] = w; nReplay++; }
         }
         M0 = max(M0, o.mm[0]); M1 = max(M1, o.mm[1]);
     }
     if (nRedo) atomicAdd((unsigned long long *)&B.counters[DC_nRedoWin], (unsigned long long)nRedo);
+    if (nReplay) atomicAdd((unsigned long long *)&B.counters[DC_nReplayWin], (unsigned long long)nReplay);
 }
 
 // ---- per read: totals, trBest, maxScoreMate (ReadAlign_stitchPieces.cpp:288-348) ----

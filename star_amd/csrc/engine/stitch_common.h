@@ -22,6 +22,7 @@ struct StitchCtx {
     GCache ca, cb;                         // donor-side and acceptor-side genome streams
     u64 nGstitch; u32 nStitchCalls, nExtendCalls, nNodes, nLeaves;
     u64 *shadow;                           // shadow-validation build: disagreement counters
+    u8 *candBase; u32 candTop, candCap, nCand; bool logOn, logOvf;   // candidate log of the current window (see DWinOut)
 };
 
 __device__ __forceinline__ u8 rdNib(const StitchCtx &c, u32 j) {

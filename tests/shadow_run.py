@@ -10,7 +10,7 @@ os.environ["STARAMD_ENGINE_LIB"] = "shadow"
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from util import capi, prepare  # noqa: E402
 
-IDX = {"stitchBad": 16, "stitchN": 17, "extendBad": 18, "extendN": 19}
+IDX = {"stitchBad": 17, "stitchN": 18, "extendBad": 19, "extendN": 20}
 
 
 def main():
