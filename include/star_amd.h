@@ -202,6 +202,10 @@ void staramd_destroy(staramd_ctx *ctx);
 const char *staramd_last_error(void);
 /* algorithmic counters of the last batch: nSAi, nSAprobe, nGcmp, nSAenum, nGstitch, ... */
 int  staramd_get_counters(staramd_ctx *ctx, uint64_t *out, int n);
+/* HIP-event times (ms) of the stages of the last batch, on the engine's stream:
+ * [0] seed search  [1] windows  [2] stitch order  [3] stitch walk (dominant kernel k_stitch_win)
+ * [4] verify + replay + finish  [5] scan + gather  [6] total */
+int  staramd_get_timings(staramd_ctx *ctx, float *out, int n);
 
 #ifdef __cplusplus
 }

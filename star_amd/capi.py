@@ -162,6 +162,8 @@ def engine_lib():
         L.staramd_map_resident.argtypes = [C.c_void_p, C.POINTER(Results)]
         L.staramd_destroy.restype = None; L.staramd_destroy.argtypes = [C.c_void_p]
         L.staramd_last_error.restype = C.c_char_p
+        L.staramd_get_timings.restype = C.c_int
+        L.staramd_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.staramd_get_counters.restype = C.c_int
         L.staramd_get_counters.argtypes = [C.c_void_p, u64p, C.c_int]
         _engine = L
@@ -230,6 +232,11 @@ class Engine:
         out = (C.c_uint64 * n)()
         k = self.L.staramd_get_counters(self.ctx, out, n)
         return list(out)[:k]
+
+    def timings(self):
+        out = (C.c_float * 7)()
+        k = self.L.staramd_get_timings(self.ctx, out, 7)
+        return dict(zip(["seed", "windows", "order", "stitch_walk", "stitch_redecide", "gather", "total"], list(out)[:k]))
 
     def close(self):
         if self.ctx:

@@ -60,7 +60,8 @@ struct staramd_ctx {
     u32 capDepth = 0, capRank = 0, arenaFast = 0, arenaBig = 0, ldsWordsCap = 0;
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
-    hipEvent_t ev[6];
+    hipEvent_t ev[10];
+    float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-stage HIP-event times of the last batch (staramd_get_timings)
     u64 counters[DC_N];
     u32 residentReads = 0; u32 residentMaxLread = 0;
     u32 *hostScratch = nullptr;         // pinned: totals + cursors read-back
@@ -203,7 +204,9 @@ static int allocWork(staramd_ctx *c) {
     if (hipHostMalloc((void **)&c->hostScratch, 64 * sizeof(u32)) != hipSuccess) { g_err = "hipHostMalloc failed"; return STARAMD_ERR_DEVICE; }
     const staramd_params &P = c->X.P;
     // ---- seed kernel: one lane per read, PC table per lane sized by the reference's seedPerReadNmax
-    u32 lanes = envU32("STARAMD_SEED_LANES", 131072);
+    int seedPerCU = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&seedPerCU, k_seed_search, 256, 0) != hipSuccess || seedPerCU < 1) seedPerCU = 2;
+    u32 lanes = envU32("STARAMD_SEED_LANES", (u32)c->nCU * (u32)seedPerCU * 256u);
     lanes = std::max<u32>(256, std::min<u32>(lanes, ((N + 255) / 256) * 256));
     c->seedLanes = (lanes / 256) * 256;
     c->seedPerLane = P.seedPerReadNmax + 1;
@@ -247,7 +250,7 @@ extern "C" int staramd_create(staramd_ctx **out, int device, const staramd_genom
     int rc = uploadIndex(c, g, p);
     if (!rc) rc = allocWork(c);
     if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
-    if (!rc) for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
+    if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (rc) { freeAll(c->indexAllocs); freeAll(c->workAllocs); delete c; return rc; }
     memset(c->counters, 0, sizeof(c->counters));
     *out = c;
@@ -267,7 +270,7 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     freeAll(c->indexAllocs); freeAll(c->workAllocs);
-    for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 10; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->hostScratch) (void)hipHostFree(c->hostScratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -316,6 +319,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
         hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * c->capW * 8 * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u);
         hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u);
+        HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
         hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1), 0, s, B);
         hipLaunchKernelGGL(k_order_scatter, dim3(1024), block, 0, s, B);
@@ -326,6 +330,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         size_t ldsFast = 4 * (readBytes + stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast));
         for (u32 mode = 0; mode < 2; mode++) {
             hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, mode);
+            if (mode == 0) HIPCHK(hipEventRecord(c->ev[6], s));
             if (mode == 0) {
                 hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);
                 hipLaunchKernelGGL(k_stitch_replay, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords);
@@ -347,6 +352,15 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));
     HIPCHK(hipEventElapsedTime(&r->msTotalDevice, c->ev[0], c->ev[4]));
+    // [0] k_seed_search  [1] k_windows (both passes)  [2] k_order_*  [3] k_stitch_win pass 0  [4] verify + replay + re-walk + finish
+    // [5] scan + gather  [6] total
+    c->ms[0] = r->msSeed;
+    HIPCHK(hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[5]));
+    HIPCHK(hipEventElapsedTime(&c->ms[2], c->ev[5], c->ev[2]));
+    HIPCHK(hipEventElapsedTime(&c->ms[3], c->ev[2], c->ev[6]));
+    HIPCHK(hipEventElapsedTime(&c->ms[4], c->ev[6], c->ev[3]));
+    HIPCHK(hipEventElapsedTime(&c->ms[5], c->ev[3], c->ev[4]));
+    c->ms[6] = r->msTotalDevice;
     *flagsOut = hs[8 + CUR_FLAGS];
     return STARAMD_OK;
 }
@@ -409,6 +423,13 @@ extern "C" int staramd_map_resident(staramd_ctx *c, staramd_results *r) {
     HIPCHK(hipSetDevice(c->device));
     c->B.nReads = c->residentReads;
     return runDevice(c, r);
+}
+
+extern "C" int staramd_get_timings(staramd_ctx *c, float *out, int n) {
+    if (!c || !out) return 0;
+    int k = n < 7 ? n : 7;
+    for (int i = 0; i < k; i++) out[i] = c->ms[i];
+    return k;
 }
 
 extern "C" int staramd_get_counters(staramd_ctx *c, uint64_t *out, int n) {

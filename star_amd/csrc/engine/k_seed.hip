@@ -151,7 +151,7 @@ __device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R,
             storeAligns(X, st, iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, NrepAll[iDist], maxLall[iDist], ind0All[iDist], iFrag);
 }
 
-extern "C" __global__ void __launch_bounds__(256) k_seed_search(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
+extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
     const DevIndex &X = *Xp;
     u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     SeedState st; st.PC = scratch + (u64)lane * scratchPerLane; st.cap = scratchPerLane;

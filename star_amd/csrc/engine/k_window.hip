@@ -191,7 +191,7 @@ __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
 
 extern __shared__ u32 ldsTab[];     // fast pass: wavesPerBlock * capW * 8 words
 
-extern "C" __global__ void __launch_bounds__(256) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big) {
+extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big) {
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
