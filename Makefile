@@ -50,4 +50,10 @@ ref:
 clean:
 	rm -rf star_amd/lib star_amd/bin oracle/_build
 
+# profiling build: shader-clock time per section of the stitch walk (bench.py --profile-sections)
+profile-lib: star_amd/lib/libstaramd_profile.so
+star_amd/lib/libstaramd_profile.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p star_amd/lib
+	$(HIPCC) $(HIPFLAGS) -DSTARAMD_PROFILE -shared $(HIP_SRC) -o $@
+
 .PHONY: all host engine shadow cli oracle ref clean

@@ -176,6 +176,10 @@ def main():
     names = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut",
              "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
     c = dict(zip(names, cnt))
+    prof = None
+    if os.environ.get("STARAMD_ENGINE_LIB") == "profile" and len(cnt) >= 29:
+        pn = ["walk", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime"]
+        prof = dict(zip(pn, cnt[21:29]))
     eng.close(); run.close()
     if rank != 0:
         if dist is not None:
@@ -221,6 +225,7 @@ def main():
                      "algorithmic_bytes_per_pair_whole_path": (bytes_seed + bytes_win + bytes_stitch) / n,
                      "note": "the dominant kernel is instruction-issue bound (branchy integer walk, state in LDS), not HBM bound: see DESIGN.md section 6"},
         "counters_per_pair": {k: v / n for k, v in c.items()},
+        "stitch_section_cycles": prof,
         "index_upload_s": t_upload, "first_batch_incl_h2d_s": t_first, "sj_merge_ms": sj_merge_ms,
     }
     if not args.no_cpu_baseline:

@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 # STARAMD_ENGINE_LIB=shadow selects the shadow-validation build (tests only; see star_amd/csrc/engine/stitch_scalar.h)
-ENGINE_PATH = os.path.join(LIB_DIR, "libstaramd_shadow.so" if os.environ.get("STARAMD_ENGINE_LIB") == "shadow" else "libstaramd.so")
+_VARIANT = os.environ.get("STARAMD_ENGINE_LIB", "")
+ENGINE_PATH = os.path.join(LIB_DIR, {"shadow": "libstaramd_shadow.so", "profile": "libstaramd_profile.so"}.get(_VARIANT, "libstaramd.so"))
 HOST_PATH = os.path.join(LIB_DIR, "libstaramd_host.so")
 
 u8p = C.POINTER(C.c_uint8)
@@ -228,7 +229,7 @@ class Engine:
         if rc != 0:
             raise RuntimeError("staramd_map_resident failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
 
-    def counters(self, n=24):
+    def counters(self, n=32):
         out = (C.c_uint64 * n)()
         k = self.L.staramd_get_counters(self.ctx, out, n)
         return list(out)[:k]

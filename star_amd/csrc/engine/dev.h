@@ -73,6 +73,7 @@ struct DWinOut { u32 trOffset, nTr, exOffset, nEx; i32 mm[2]; i32 sens[2]; i32 m
 enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nWindows, DC_nWA, DC_nNodes, DC_nLeaves,
        DC_nStitchCalls, DC_nExtendCalls, DC_nTrOut, DC_nOvfWin, DC_nOvfStitch, DC_nRedoWin, DC_nReplayWin,
        DC_shadowBad, DC_shadowN, DC_shadowExtBad, DC_shadowExtN,   // shadow-validation build only (see stitch_scalar.h)
+       DC_prof0, DC_prof1, DC_prof2, DC_prof3, DC_prof4, DC_prof5, DC_prof6, DC_prof7,   // -DSTARAMD_PROFILE build: shader-clock cycles per section of k_stitch_win
        DC_N };
 
 // cursors[] slots
@@ -139,8 +140,27 @@ __device__ __forceinline__ u64 first64(u64 v) { return ((u64)first32((u32)(v >> 
 // number of set bits of a 64-lane ballot mask in the lanes strictly below / up to and including this lane
 __device__ __forceinline__ u32 cntBelow(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 __device__ __forceinline__ u32 cntUpTo(u64 m, u32 lane) { return cntBelow(m) + (u32)((m >> lane) & 1ull); }
+// wave-wide max / sum through the DPP network (row shifts + row broadcasts, 6 VALU ops, no LDS round trips);
+// result returned in every lane (read from lane 63 as a scalar)
 __device__ __forceinline__ u32 waveMaxU32(u32 v) {
-    for (int o = 32; o > 0; o >>= 1) { u32 w = (u32)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
-    return v;
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:1
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:2
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:4
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;   // row_shr:8  -> lane 15 of each row = row max
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast:15 into rows 1,3
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast:31 into rows 2,3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ u32 waveSumU32(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);                      // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);                      // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);                      // row_shr:4 (banks 1-3)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);                      // row_shr:8 (banks 2-3) -> lane 15 = row sum
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);                      // row_bcast:15
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);                      // row_bcast:31
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// value of lane srcLane, srcLane wave-uniform
+__device__ __forceinline__ u32 laneGet32(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)srcLane)); }
 __device__ __forceinline__ u32 firstLane(u64 m) { return (u32)__ffsll((long long)m) - 1u; }   // m != 0

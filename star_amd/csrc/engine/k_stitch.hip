@@ -45,7 +45,14 @@ struct ExtRes { i32 maxScore; u32 extendL, nMatch, nMM; };
 __device__ __forceinline__ u8 gByte(const StitchCtx &c, u64 pos) { return ((const GLOBAL_AS u8 *)c.X->G)[(i64)pos]; }
 
 // ---- extendAlign.cpp:6-93, lane = position of the scan -------------------------------------------------------------
-__device__ static bool coopExtend(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
+__device__ static bool coopExtendBody(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e);
+__device__ __forceinline__ bool coopExtend(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
+    PROF_T0();
+    bool r = coopExtendBody(c, lane, rStart, gStart, dR, dG, L, Lprev, nMMprev, nMMmax, pMMmax, extendToEnd, e);
+    PROF_ADD(c, 2);
+    return r;
+}
+__device__ static bool coopExtendBody(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
     c.nExtendCalls++;
     e.maxScore = 0; e.extendL = 0; e.nMatch = 0; e.nMM = 0;
     if (extendToEnd) {                      // --alignEndsType Extend*: rarely used, wave-uniform scalar loop (:18-56)
@@ -93,7 +100,7 @@ __device__ static bool coopExtend(StitchCtx &c, u32 lane, u32 rStart, u64 gStart
         if (kmax) {
             u32 bl = 63u - (kmax & 255u);
             best = (int)(kmax >> 8);
-            e.extendL = base + bl + 1; e.maxScore = best; e.nMatch = bcast32(nMatch_i, bl); e.nMM = bcast32(nMM_i, bl);
+            e.extendL = base + bl + 1; e.maxScore = best; e.nMatch = laneGet32(nMatch_i, bl); e.nMM = laneGet32(nMM_i, bl);
         }
         c.nGstitch += min(lim + 1u, NLANE);
         if (lim < NLANE) break;
@@ -256,7 +263,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                         int ms2 = (int)(kmax >> 8) - 1000000;
                         if (kmax && ms2 > maxScore2) {                      // strict: the first position of the maximum wins
                             u32 bl = 63u - (kmax & 255u);
-                            maxScore2 = ms2; jR = jStart + base + (int)bl; jCan = (int)bcast32((u32)jCan1, bl); jPen = (int)bcast32((u32)jPen1, bl);
+                            maxScore2 = ms2; jR = jStart + base + (int)bl; jCan = (int)laneGet32((u32)jCan1, bl); jPen = (int)laneGet32((u32)jPen1, bl);
                         }
                         s1base += (int)__popcll(mp) - (int)__popcll(mn);
                     }
@@ -572,47 +579,65 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             }
         }
     }
+    // ---- leaf filters (:83-219), lane = exon row: every lane holds one exon of the transcript in registers, neighbours
+    // come over the DPP wave shift, sums are DPP reductions, "any exon fails" is a ballot
+    staramd_exon xe;
+    { u64 *z = (u64 *)&xe; z[0] = z[1] = z[2] = z[3] = 0; }
+    const bool isEx = lane < ne;
+    if (isEx) xe = ldsGet(&ex[lane]);
+    const int canon = isEx ? (int)xe.canonSJ : -9, canonPrev = __builtin_amdgcn_update_dpp(-9, canon, 0x138, 0xf, 0xf, false), canonNext = __builtin_amdgcn_update_dpp(-9, canon, 0x130, 0xf, 0xf, false);
+    const int annot = isEx ? (int)xe.sjAnnot : 0, annotPrev = __builtin_amdgcn_update_dpp(0, annot, 0x138, 0xf, 0xf, false), annotNext = __builtin_amdgcn_update_dpp(0, annot, 0x130, 0xf, 0xf, false);
+    const u32 exL = isEx ? (u32)xe.L : 0u, exLnext = (u32)__builtin_amdgcn_update_dpp(0, (int)exL, 0x130, 0xf, 0xf, false);
+    const u32 last = ne - 1;
+    const u64 ex0G = ((u64)laneGet32((u32)(xe.G >> 32), 0) << 32) | laneGet32((u32)xe.G, 0), exLG = ((u64)laneGet32((u32)(xe.G >> 32), last) << 32) | laneGet32((u32)xe.G, last);
+    const u32 ex0R = laneGet32(xe.R, 0), exLR = laneGet32(xe.R, last), exLL = laneGet32(exL, last);
+    const u32 ex0Frag = laneGet32(xe.iFrag, 0), exLFrag = laneGet32(xe.iFrag, last);
     if (!P.alignSoftClipAtReferenceEnds &&
-        ((ex[ne - 1].G + Lread - ex[ne - 1].R) > (X.chrStart[chr] + X.chrLength[chr]) || ex[0].G < (X.chrStart[chr] + ex[0].R))) return;
-    u32 rLength = 0;
-    for (u32 i = 0; i < ne; i++) rLength += ex[i].L;
+        ((exLG + Lread - exLR) > (X.chrStart[chr] + X.chrLength[chr]) || ex0G < (X.chrStart[chr] + ex0R))) return;
+    const u32 rLength = waveSumU32(exL);
     u64 gLength = tG2 + 1 - h.gStart;
-    for (u32 isj = 0; isj + 1 < ne; isj++) {
-        if (ex[isj].canonSJ >= 0) {
-            if (ex[isj].sjAnnot == 1) {
-                if ((ex[isj].L < P.alignSJDBoverhangMin && (isj == 0 || ex[isj - 1].canonSJ == -3 || (ex[isj - 1].sjAnnot == 0 && ex[isj - 1].canonSJ >= 0)))
-                    || (ex[isj + 1].L < P.alignSJDBoverhangMin && (isj == ne - 2 || ex[isj + 1].canonSJ == -3 || (ex[isj + 1].sjAnnot == 0 && ex[isj + 1].canonSJ >= 0)))) return;
+    {   // junction overhangs (:97-108)
+        bool fail = false;
+        if (lane < last && canon >= 0) {
+            if (annot == 1) {
+                fail = (exL < P.alignSJDBoverhangMin && (lane == 0 || canonPrev == -3 || (annotPrev == 0 && canonPrev >= 0)))
+                       || (exLnext < P.alignSJDBoverhangMin && (lane == ne - 2 || canonNext == -3 || (annotNext == 0 && canonNext >= 0)));
             } else {
-                if (ex[isj].L < P.alignSJoverhangMin + ex[isj].shiftSJ[0] || ex[isj + 1].L < P.alignSJoverhangMin + ex[isj].shiftSJ[1]) return;
+                fail = exL < P.alignSJoverhangMin + xe.shiftSJ[0] || exLnext < P.alignSJoverhangMin + xe.shiftSJ[1];
             }
         }
+        if (__ballot(fail)) return;
     }
-    if (ne > 1 && ex[ne - 2].sjAnnot == 1 && ex[ne - 1].L < P.alignSJDBoverhangMin) return;
-    u32 sjN = 0;
-    u16 intronMotifs[3] = {0, 0, 0};
-    for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ >= 0) { sjN++; u32 s = ex[i].sjStr; if (s == 0) intronMotifs[0]++; else if (s == 1) intronMotifs[1]++; else intronMotifs[2]++; }
+    if (ne > 1 && laneGet32((u32)annot, ne - 2) == 1 && exLL < P.alignSJDBoverhangMin) return;
+    const bool isJ = lane < last && canon >= 0;
+    const u32 sjN = (u32)__popcll(__ballot(isJ));
+    u16 intronMotifs[3];
+    intronMotifs[0] = (u16)__popcll(__ballot(isJ && xe.sjStr == 0)); intronMotifs[1] = (u16)__popcll(__ballot(isJ && xe.sjStr == 1)); intronMotifs[2] = (u16)__popcll(__ballot(isJ && xe.sjStr > 1));
     u8 sjMotifStrand;
     if (intronMotifs[1] > 0 && intronMotifs[2] == 0) sjMotifStrand = 1;
     else if (intronMotifs[1] == 0 && intronMotifs[2] > 0) sjMotifStrand = 2;
     else sjMotifStrand = 0;
     if (intronMotifs[1] > 0 && intronMotifs[2] > 0 && P.outFilterIntronStrandsRemoveInconsistent) return;
     if (sjN > 0 && sjMotifStrand == 0 && P.outSAMstrandFieldIntronMotif) return;
-    if (P.outFilterIntronMotifs == 1) { for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ == 0) return; }
-    else if (P.outFilterIntronMotifs == 2) { for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ == 0 && ex[i].sjAnnot == 0) return; }
-    {
-        u32 nsj = 0, exl = 0;
-        for (u32 i = 0; i < ne; i++) {
-            exl += ex[i].L;
-            if (i == ne - 1 || ex[i].canonSJ == -3) {
-                if (nsj > 0 && (exl < P.alignSplicedMateMapLmin || (u64)exl < (u64)(P.alignSplicedMateMapLminOverLmate * (double)(u64)c.readLength[ex[i].iFrag]))) return;
-                exl = 0; nsj = 0;
-            } else if (ex[i].canonSJ >= 0) nsj++;
+    if (P.outFilterIntronMotifs == 1) { if (__ballot(lane < last && canon == 0)) return; }
+    else if (P.outFilterIntronMotifs == 2) { if (__ballot(lane < last && canon == 0 && annot == 0)) return; }
+    {   // minimum mapped length of a spliced mate (:154-167): segments end at the mate gap (canonSJ == -3) or the last exon
+        u64 mEnd = __ballot(isEx && (lane == last || canon == -3));
+        u32 start = 0;
+        while (mEnd) {
+            u32 e = firstLane(mEnd); mEnd &= mEnd - 1;
+            bool inSeg = lane >= start && lane <= e;
+            u32 exl = waveSumU32(inSeg ? exL : 0u);
+            u32 nsj = (u32)__popcll(__ballot(inSeg && lane != e && canon >= 0));
+            u32 fragE = laneGet32(xe.iFrag, e);
+            if (nsj > 0 && (exl < P.alignSplicedMateMapLmin || (u64)exl < (u64)(P.alignSplicedMateMapLminOverLmate * (double)(u64)c.readLength[fragE]))) return;
+            start = e + 1;
         }
     }
-    if (ex[0].iFrag != ex[ne - 1].iFrag) {
-        if (ex[ne - 1].G + ex[ne - 1].L <= ex[0].G) return;
+    if (ex0Frag != exLFrag) {                                  // both mates (:179-219): rare inner loop kept scalar on the LDS rows
+        if (exLG + exLL <= ex0G) return;
         u32 iexM2 = ne;
-        for (u32 i = 0; i + 1 < ne; i++) if (ex[i].canonSJ == -3) { iexM2 = i + 1; break; }
+        { u64 mg = __ballot(lane < last && canon == -3); if (mg) iexM2 = firstLane(mg) + 1; }
         if (ex[iexM2 - 1].G + ex[iexM2 - 1].L > ex[iexM2].G) {
             if (ex[0].G > ex[iexM2].G + ex[0].R + (i64)P.alignEndsProtrudeNbasesMax) return;
             if (ex[iexM2 - 1].G + ex[iexM2 - 1].L > ex[ne - 1].G + Lread - ex[ne - 1].R + (i64)P.alignEndsProtrudeNbasesMax) return;
@@ -626,15 +651,15 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             }
         }
     }
-    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points
-        u64 gl = ex[ne - 1].G + ex[ne - 1].L - ex[0].G;
+    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points: lane k tests break point k
+        u64 gl = exLG + exLL - ex0G;
         i32 term = X.glScoreAt1;
-        for (u32 k = 0; k < X.nBreak; k++) if (gl >= X.glBreak[k]) term += X.glStep;
+        for (u32 kb = 0; kb < X.nBreak; kb += NLANE) { u32 k = kb + lane; term += X.glStep * (i32)__popcll(__ballot(k < X.nBreak && gl >= X.glBreak[k])); }
         Score += term;
         Score = max(0, Score);
     }
     i32 iFragT;
-    if (ex[0].iFrag == ex[ne - 1].iFrag) { iFragT = ex[0].iFrag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
+    if (ex0Frag == exLFrag) { iFragT = (i32)ex0Frag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
     else iFragT = -1;
     i32 winBest = wr.bestScore;            // wTr[0]->maxScore (trA with score 0 before any record)
     {
@@ -655,10 +680,8 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
     o.nGap = h.nGap; o.lGap = h.lGap; o.nDel = h.nDel; o.lDel = h.lDel; o.nIns = h.nIns; o.lIns = h.lIns;
     o.nUnique = (u16)h.nUnique; o.nAnchor = (u16)h.nAnchor;
     o.intronMotifs[0] = intronMotifs[0]; o.intronMotifs[1] = intronMotifs[1]; o.intronMotifs[2] = intronMotifs[2]; o.pad0 = 0; o.pad1 = 0;
-    staramd_exon x;
-    { u64 *z = (u64 *)&x; z[0] = z[1] = z[2] = z[3] = 0; }
+    staramd_exon x = xe;
     if (lane < ne) {
-        x = ldsGet(&ex[lane]);
         if (lane + 1 == ne) { x.canonSJ = 0; x.sjAnnot = 0; x.sjStr = 0; x.shiftSJ[0] = x.shiftSJ[1] = 0; }
         else if (x.canonSJ < 0) { x.shiftSJ[0] = x.shiftSJ[1] = 0; }
         x.pad0 = 0; x.pad1 = 0;
@@ -676,7 +699,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             c.candTop += need; c.nCand++;
         }
     }
-    recordCandidate(P, lane, o, x, ex, wr);
+    { PROF_T0(); recordCandidate(P, lane, o, x, ex, wr); PROF_ADD(c, 4); }
 }
 
 // per-window LDS work space, in bytes: undo stack, exon rows, leaf copy, rank list, seed list (+ arena in the fast path)
@@ -705,7 +728,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             if (h.tR2 != 0) {
                 if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                finalizeTranscript(c, lane, h, LEAF, win.chr, wr);
+                { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr); PROF_ADD(c, 3); }
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
@@ -725,7 +748,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
 #ifdef STARAMD_SHADOW
             Hdr hs = h; staramd_exon eAs = eA, eNs; bool addedS = false;
 #endif
-            dScore = coopStitch(c, lane, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G);
+            { PROF_T0(); dScore = coopStitch(c, lane, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G); PROF_ADD(c, 1); }
 #ifdef STARAMD_SHADOW
             {   // every lane re-runs the call through the scalar restatement (same inputs): any disagreement is counted
                 int dS = stitchAlignToTranscript(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hs, eAs, eNs, addedS, ex0R, ex0G);
@@ -855,6 +878,10 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
     u32 nOvf = 0, lastRead = 0xFFFFFFFFu;
+#ifdef STARAMD_PROFILE
+    for (int k = 0; k < 8; k++) c.prof[k] = 0;
+    const u64 profKernelStart = __builtin_readcyclecounter();
+#endif
     for (;;) {
         u32 it = 0;
         if (lane == 0) it = atomicAdd(&B.cursors[ticketSlot], 1u);
@@ -881,7 +908,7 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
             c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
             c.sens[0] = c.sens[1] = 0x7FFFFFFF;
             c.candTop = candStart; c.nCand = 0; c.logOvf = false;
-            ok = stitchWindow(c, lane, win, m, wr);
+            { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr); PROF_ADD(c, 0); }
             if (!ok) nOvf++;
         }
         if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
@@ -904,6 +931,10 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
         atomicAdd((unsigned long long *)&B.counters[DC_nNodes], (unsigned long long)c.nNodes);
         atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
+#ifdef STARAMD_PROFILE
+        c.prof[7] = __builtin_readcyclecounter() - profKernelStart;      // whole wave life time
+        for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);
+#endif
     }
 }
 

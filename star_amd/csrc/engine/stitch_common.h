@@ -22,6 +22,9 @@ struct StitchCtx {
     GCache ca, cb;                         // donor-side and acceptor-side genome streams
     u64 nGstitch; u32 nStitchCalls, nExtendCalls, nNodes, nLeaves;
     u64 *shadow;                           // shadow-validation build: disagreement counters
+#ifdef STARAMD_PROFILE
+    u64 prof[8];
+#endif
     u8 *candBase; u32 candTop, candCap, nCand; bool logOn, logOvf;   // candidate log of the current window (see DWinOut)
 };
 
@@ -36,3 +39,11 @@ __device__ __forceinline__ u8 RD(const StitchCtx &c, u32 i) {        // R[i], Re
 __device__ __forceinline__ u8 GA(StitchCtx &c, u64 pos) { c.nGstitch++; return gcGet(c.X->G, c.ca, (i64)pos); }
 __device__ __forceinline__ u8 GB(StitchCtx &c, u64 pos) { c.nGstitch++; return gcGet(c.X->G, c.cb, (i64)pos); }
 
+
+#ifdef STARAMD_PROFILE
+#define PROF_T0() u64 prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(c, k) (c).prof[k] += __builtin_readcyclecounter() - prof_t0_
+#else
+#define PROF_T0()
+#define PROF_ADD(c, k)
+#endif
