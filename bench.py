@@ -177,9 +177,11 @@ def main():
              "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
     c = dict(zip(names, cnt))
     prof = None
-    if os.environ.get("STARAMD_ENGINE_LIB") == "profile" and len(cnt) >= 29:
-        pn = ["walk", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime"]
-        prof = dict(zip(pn, cnt[21:29]))
+    if os.environ.get("STARAMD_ENGINE_LIB") == "profile" and len(cnt) >= 37:
+        pn = ["walk", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime",
+              "junction:left_scan", "junction:right_scan", "junction:repeats", "junction:rescore", "junction:sjdb_find",
+              "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
+        prof = dict(zip(pn, cnt[21:37]))
     eng.close(); run.close()
     if rank != 0:
         if dist is not None:

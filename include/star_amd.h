@@ -113,6 +113,12 @@ typedef struct staramd_params {
     int32_t  outFilterMultimapScoreRange;   /* 1 */
     double   outFilterMismatchNoverLmax;    /* 0.3 */
     uint32_t outFilterMatchNmin;            /* 0: Lread<outFilterMatchNmin => MARKER_READ_TOO_SHORT */
+    /* ours (no reference flag): which transcripts staramd_map_batch returns.
+     *   0  every transcript recorded in every window (the whole trAll[][] of the reference)
+     *   1  only the transcripts ReadAlign::multMapSelect can pick: maxScore + outFilterMultimapScoreRange >= trBest->maxScore
+     *      (ReadAlign_multMapSelect.cpp:26-44).  That is all the default post-map path reads; it cuts the result copy ~10x.
+     *      Must be 0 when chimeric detection (chimSegmentMin > 0) wants the other windows. */
+    uint32_t resultSelect;
 } staramd_params;
 
 /* ---- one batch of reads: what ReadAlign::oneRead prepares before calling mapOneRead

@@ -874,14 +874,18 @@ struct Oracle {
         else {
             int bw;
             rr.status |= stitchPieces(bw);
-            rr.nW = (uint32_t)trAll.size();
-            if (rr.nW > 0) rr.status |= STARAMD_ST_MAPPED_WINDOWS;
+            // staramd_params::resultSelect == 1: keep only what multMapSelect can pick (ReadAlign_multMapSelect.cpp:26-44)
+            const bool sel = P.resultSelect != 0 && bw >= 0;
+            const int selMin = sel ? trAll[bw][0].maxScore - P.outFilterMultimapScoreRange : 0;
+            u64 nWout = 0;
             for (u64 iW = 0; iW < trAll.size(); iW++) {
+                if (sel && trAll[iW][0].maxScore < selMin) continue;     // transcripts of a window are sorted best first
                 if ((int)iW == bw) rr.trBest = (int32_t)(otr.size() - rr.trOffset);
                 for (u64 it = 0; it < trAll[iW].size(); it++) {
                     const Tr &t = trAll[iW][it];
+                    if (sel && t.maxScore < selMin) break;
                     staramd_transcript o; memset(&o, 0, sizeof(o));
-                    o.iW = (uint32_t)iW; o.exonOffset = (uint32_t)oex.size(); o.nExons = (uint16_t)t.nExons;
+                    o.iW = (uint32_t)nWout; o.exonOffset = (uint32_t)oex.size(); o.nExons = (uint16_t)t.nExons;
                     o.rStart = (uint16_t)t.rStart; o.rLength = (uint16_t)t.rLength; o.roStart = (uint16_t)t.roStart;
                     o.Str = (uint8_t)trAll[iW][0].Str; o.roStr = (uint8_t)trAll[iW][0].roStr; o.iFrag = (int8_t)t.iFrag; o.sjMotifStrand = t.sjMotifStrand;
                     o.Chr = (uint32_t)trAll[iW][0].Chr; o.gStart = t.gStart; o.gLength = t.gLength; o.maxScore = t.maxScore;
@@ -902,7 +906,10 @@ struct Oracle {
                     }
                     otr.push_back(o);
                 }
+                nWout++;
             }
+            rr.nW = (uint32_t)nWout;
+            if (rr.nW > 0) rr.status |= STARAMD_ST_MAPPED_WINDOWS;
             rr.nTr = (uint32_t)(otr.size() - rr.trOffset);
             cnt[C_nTrOut] += rr.nTr;
         }

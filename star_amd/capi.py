@@ -62,6 +62,7 @@ class Params(C.Structure):
         ("outFilterMultimapScoreRange", C.c_int32),
         ("outFilterMismatchNoverLmax", C.c_double),
         ("outFilterMatchNmin", C.c_uint32),
+        ("resultSelect", C.c_uint32),
     ]
 
 
@@ -229,7 +230,7 @@ class Engine:
         if rc != 0:
             raise RuntimeError("staramd_map_resident failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
 
-    def counters(self, n=32):
+    def counters(self, n=40):
         out = (C.c_uint64 * n)()
         k = self.L.staramd_get_counters(self.ctx, out, n)
         return list(out)[:k]

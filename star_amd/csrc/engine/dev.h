@@ -74,6 +74,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_nStitchCalls, DC_nExtendCalls, DC_nTrOut, DC_nOvfWin, DC_nOvfStitch, DC_nRedoWin, DC_nReplayWin,
        DC_shadowBad, DC_shadowN, DC_shadowExtBad, DC_shadowExtN,   // shadow-validation build only (see stitch_scalar.h)
        DC_prof0, DC_prof1, DC_prof2, DC_prof3, DC_prof4, DC_prof5, DC_prof6, DC_prof7,   // -DSTARAMD_PROFILE build: shader-clock cycles per section of k_stitch_win
+       DC_prof8, DC_prof9, DC_prof10, DC_prof11, DC_prof12, DC_prof13, DC_prof14, DC_prof15,
        DC_N };
 
 // cursors[] slots
@@ -163,4 +164,13 @@ __device__ __forceinline__ u32 waveSumU32(u32 v) {
 }
 // value of lane srcLane, srcLane wave-uniform
 __device__ __forceinline__ u32 laneGet32(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)srcLane)); }
+// declare a wave-uniform value to the compiler: every dword goes through v_readfirstlane, so what is computed from it
+// lives in SGPRs and branches on it are scalar branches (s_cbranch_scc) instead of exec-mask sequences
+template <class T> __device__ __forceinline__ T uni(const T &v) {
+    static_assert(sizeof(T) % 4 == 0, "uni: dword multiple");
+    T r; const u32 *s = (const u32 *)&v; u32 *d = (u32 *)&r;
+#pragma unroll
+    for (u32 i = 0; i < sizeof(T) / 4; i++) d[i] = (u32)__builtin_amdgcn_readfirstlane((int)s[i]);
+    return r;
+}
 __device__ __forceinline__ u32 firstLane(u64 m) { return (u32)__ffsll((long long)m) - 1u; }   // m != 0

@@ -167,10 +167,11 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
     int Score = 0;
     if (sjAB != -1 && eA.sjA == sjAB && eA.iFrag == iFragB && rBstart == rAend + 1 && gAend + 1 < gBstart) {
         // both seeds come from the same inserted sjdb sequence: the junction is the annotated one (:18-34)
-        if (X.sjdbMotif[sjAB] == 0 && (L <= X.sjdbShiftRight[sjAB] || eA.L <= X.sjdbShiftLeft[sjAB])) return -1000006;
+        const u32 sMotif = first32(X.sjdbMotif[sjAB]), sShL = first32(X.sjdbShiftLeft[sjAB]), sShR = first32(X.sjdbShiftRight[sjAB]);
+        if (sMotif == 0 && (L <= sShR || eA.L <= sShL)) return -1000006;
         eN.L = (u16)L; eN.R = (u16)rBstart; eN.G = gBstart;
-        eA.canonSJ = (i8)X.sjdbMotif[sjAB]; eA.shiftSJ[0] = X.sjdbShiftLeft[sjAB]; eA.shiftSJ[1] = X.sjdbShiftRight[sjAB];
-        eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjAB];
+        eA.canonSJ = (i8)sMotif; eA.shiftSJ[0] = (u16)sShL; eA.shiftSJ[1] = (u16)sShR;
+        eA.sjAnnot = 1; eA.sjStr = (u8)first32(X.sjdbStrand[sjAB]);
         added = true; h.nMatch += L;
         Score += (int)L; Score += P.sjdbScore;
     } else {
@@ -204,6 +205,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                 nDel = 1; Del = (u64)(i64)(gGap - rGap);
                 if (Del > P.alignIntronMax && P.alignIntronMax > 0) return -1000003;
                 const int eAL = (int)eA.L;
+                PROF_T0();
                 // left scan (:104-109): walk left from the end of A while fewer than scoreStitchSJshift+1 positions
                 // favour A over B, never past the start of A's exon.  jStart = where the walk stops.
                 int jStart;
@@ -232,6 +234,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                         }
                     }
                 }
+                PROF_MARK(c, 8);
                 // right scan (:111-156): best junction position by votes of the bases + motif penalty
                 int maxScore2 = -999999; int jPen = 0;
                 const bool isIntron = Del >= P.alignIntronMin;
@@ -269,6 +272,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     }
                     c.nGstitch += (u32)(jEnd - jStart) * (isIntron ? 5u : 2u);
                 }
+                PROF_MARK(c, 9);
                 // repeat length left / right of the junction (:159-166)
                 u32 jjL = 0, jjR = 0;
                 for (u32 base = 0;; base += NLANE) {
@@ -286,6 +290,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     if (fm) { jjR = base + firstLane(fm); break; }
                 }
                 c.nGstitch += 2u * (jjL + jjR + 2u);
+                PROF_MARK(c, 10);
                 if (jCan <= 0) {                                     // flush a non-canonical junction left (:168-173)
                     jR -= (int)jjL;
                     if (eAL + jR < 1) return -1000005;
@@ -308,20 +313,23 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     }
                     c.nGstitch += (u32)(i1 - i0 + 1);
                 }
+                PROF_MARK(c, 11);
                 int sjdbInd = -1;
                 if (X.sjdbN > 0) sjdbInd = coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN);
+                PROF_MARK(c, 12);
                 if (sjdbInd < 0) {
                     if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }
                 } else {
-                    jCan = X.sjdbMotif[sjdbInd];
-                    if (X.sjdbMotif[sjdbInd] == 0) {
-                        if (L <= X.sjdbShiftLeft[sjdbInd] || eA.L <= X.sjdbShiftLeft[sjdbInd]) return -1000006;
-                        jR += (int)X.sjdbShiftLeft[sjdbInd];
+                    jCan = (int)first32(X.sjdbMotif[sjdbInd]);
+                    if (jCan == 0) {
+                        const u32 sShL = first32(X.sjdbShiftLeft[sjdbInd]);
+                        if (L <= sShL || eA.L <= sShL) return -1000006;
+                        jR += (int)sShL;
                         if ((u64)rAend + (i64)jR >= rBend) return -1000006;
-                        jjL = X.sjdbShiftLeft[sjdbInd]; jjR = X.sjdbShiftRight[sjdbInd];
+                        jjL = sShL; jjR = first32(X.sjdbShiftRight[sjdbInd]);
                     }
-                    eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjdbInd];
+                    eA.sjAnnot = 1; eA.sjStr = (u8)first32(X.sjdbStrand[sjdbInd]);
                     Score += P.sjdbScore;
                 }
                 eA.shiftSJ[0] = (u16)jjL; eA.shiftSJ[1] = (u16)jjR; eA.canonSJ = (i8)jCan;
@@ -545,13 +553,14 @@ template <class EXP> __device__ static void recordCandidate(const staramd_params
 }
 
 // leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
-__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr) {
+__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr, const u64 glb0, const u64 glb1) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
     c.nLeaves++;
     u32 Lread = c.Lread; u32 Str = c.str;
     int Score = h.Score; u32 tR2 = h.tR2; u64 tG2 = h.tG2;
     u32 ne = h.nExons;
     ExtRes e;
+    PROF_T0();
     int vOrder0 = (Str == 0) ? 0 : 1;                  // EXTEND_ORDER==1, roStr==Str
     for (int iOrd = 0; iOrd < 2; iOrd++) {
         int which = iOrd == 0 ? vOrder0 : 1 - vOrder0;
@@ -579,6 +588,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             }
         }
     }
+    PROF_MARK(c, 13);
     // ---- leaf filters (:83-219), lane = exon row: every lane holds one exon of the transcript in registers, neighbours
     // come over the DPP wave shift, sums are DPP reductions, "any exon fails" is a ballot
     staramd_exon xe;
@@ -651,16 +661,17 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             }
         }
     }
-    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points: lane k tests break point k
+    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points: lane k holds break points k, k+64
         u64 gl = exLG + exLL - ex0G;
-        i32 term = X.glScoreAt1;
-        for (u32 kb = 0; kb < X.nBreak; kb += NLANE) { u32 k = kb + lane; term += X.glStep * (i32)__popcll(__ballot(k < X.nBreak && gl >= X.glBreak[k])); }
+        const u32 nAbove = (u32)__popcll(__ballot(gl >= glb0)) + (u32)__popcll(__ballot(gl >= glb1));   // break points <= gl (this lane holds points lane, lane+64)
+        i32 term = X.glScoreAt1 + X.glStep * (i32)nAbove;
         Score += term;
         Score = max(0, Score);
     }
     i32 iFragT;
     if (ex0Frag == exLFrag) { iFragT = (i32)ex0Frag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
     else iFragT = -1;
+    PROF_MARK(c, 14);
     i32 winBest = wr.bestScore;            // wTr[0]->maxScore (trA with score 0 before any record)
     {
         bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
@@ -699,6 +710,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             c.candTop += need; c.nCand++;
         }
     }
+    PROF_MARK(c, 15);
     { PROF_T0(); recordCandidate(P, lane, o, x, ex, wr); PROF_ADD(c, 4); }
 }
 
@@ -713,7 +725,7 @@ struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LD
 
 // depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321):
 // include seed iA (if it stitches), then exclude it.  Wave-uniform control flow.  Returns false when the arena overflowed.
-__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec &wr) {
+__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec &wr, const u64 glb0, const u64 glb1) {
     const u32 nA = win.nWA;
     c.str = win.str;
     wr.nWinTr = 0; wr.top = 0; wr.overflow = false; wr.bestScore = 0;
@@ -721,29 +733,29 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
     Hdr h; h.gStart = 0; h.tG2 = 0; h.nExons = 0; h.Score = 0; h.nMatch = h.nMM = h.nGap = h.lGap = h.nDel = h.lDel = h.nIns = h.lIns = 0;
     h.nUnique = h.nAnchor = 0; h.rStart = 0; h.tR2 = 0;
     u32 iA = 0; u32 sp = 0; u32 ex0R = 0; u64 ex0G = 0;
-    DWA a = ldsGet(&WA[0]);
+    DWA a = uni(ldsGet(&WA[0]));
     for (;;) {
         c.nNodes++;
         if (iA >= nA) {                              // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
             if (h.tR2 != 0) {
                 if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr); PROF_ADD(c, 3); }
+                { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr, glb0, glb1); PROF_ADD(c, 3); }
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
             sp--;                                    // back to the frame that included a seed: now exclude it
-            SFrame f = ldsGet(&stack[sp]);
+            SFrame f = uni(ldsGet(&stack[sp]));
             h = f.h; iA = f.iA + 1;
             if (h.nExons > 0 && lane == 0) ldsPut(&EX[h.nExons - 1], f.eA);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (iA < nA) a = ldsGet(&WA[iA]);
+            if (iA < nA) a = uni(ldsGet(&WA[iA]));
             continue;
         }
         // ---- include branch (:311-345)
         Hdr hn = h; staramd_exon eA, eN; bool added = false; int dScore;
         if (h.nExons > 0) {
-            eA = ldsGet(&EX[h.nExons - 1]);
+            eA = uni(ldsGet(&EX[h.nExons - 1]));
             staramd_exon eAold = eA;
 #ifdef STARAMD_SHADOW
             Hdr hs = h; staramd_exon eAs = eA, eNs; bool addedS = false;
@@ -788,7 +800,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
         }
         // include succeeded: continue below it; include failed: exclude branch (:348-351) = same transcript, next seed
         iA++;
-        if (iA < nA) a = ldsGet(&WA[iA]);
+        if (iA < nA) a = uni(ldsGet(&WA[iA]));
     }
     return true;
 }
@@ -836,9 +848,9 @@ __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRan
 }
 
 __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
-    c.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
-    c.readLength[0] = B.mate1Length[ir]; c.readLength[1] = P.readNmates == 2 ? c.Lread - c.readLength[0] - 1 : 0;
-    c.mmMaxTotal = B.mmMaxTotal[ir];
+    c.Lread = first32((u32)(B.readOffset[ir + 1] - B.readOffset[ir]));
+    c.readLength[0] = first32(B.mate1Length[ir]); c.readLength[1] = P.readNmates == 2 ? c.Lread - c.readLength[0] - 1 : 0;
+    c.mmMaxTotal = first32(B.mmMaxTotal[ir]);
     const u32 *src = B.packed + (u64)ir * B.packWords;       // stage the 4-bit packed read in this wavefront's LDS slice
     u32 nw = (c.Lread + 7) / 8;
     LDS u32 *dst = (LDS u32 *)((LDS u8 *)ldsReads + c.ldsByte);
@@ -874,12 +886,14 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
     WinRec wr; wr.rank = m.rank; wr.arenaL = m.arena; wr.arenaBytesL = arenaBytes; wr.arenaG = bigArena + (u64)waveId * bigArenaBytes; wr.arenaBytesG = bigArenaBytes;
     gcInit(c.ca); gcInit(c.cb);
     c.candBase = B.candPool + (u64)waveId * B.candWaveBytes; c.candTop = 0; c.candCap = (u32)B.candWaveBytes; c.nCand = 0; c.logOn = mode == 0; c.logOvf = false;
+    // break points of the genomic-length score term: lane k keeps points k and k+64 in registers for the whole kernel
+    const u64 glb0 = lane < X.nBreak ? X.glBreak[lane] : ~0ull, glb1 = lane + 64u < X.nBreak ? X.glBreak[lane + 64u] : ~0ull;
     const u32 *list; u32 nItems, ticketSlot;
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
     u32 nOvf = 0, lastRead = 0xFFFFFFFFu;
 #ifdef STARAMD_PROFILE
-    for (int k = 0; k < 8; k++) c.prof[k] = 0;
+    for (int k = 0; k < 16; k++) c.prof[k] = 0;
     const u64 profKernelStart = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -887,9 +901,9 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
         if (lane == 0) it = atomicAdd(&B.cursors[ticketSlot], 1u);
         it = first32(it);
         if (it >= nItems) break;
-        u32 w = list[it];
+        u32 w = first32(list[it]);
         if (w == 0xFFFFFFFFu) continue;                 // padding slot of the dealt order
-        const DWin win = B.winPool[w];
+        const DWin win = uni(B.winPool[w]);
         if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
         if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
         {   // stage the window's seed list in LDS (3 dwords x 2 per row)
@@ -897,7 +911,7 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
             for (u32 k = lane; k < win.nWA * 6u; k += NLANE) dst[k] = src[k];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-        DWinOut o = B.wout[w];
+        DWinOut o = uni(B.wout[w]);
         if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; }
         c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
         c.sens[0] = c.sens[1] = 0x7FFFFFFF;
@@ -908,7 +922,7 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
             c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
             c.sens[0] = c.sens[1] = 0x7FFFFFFF;
             c.candTop = candStart; c.nCand = 0; c.logOvf = false;
-            { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr); PROF_ADD(c, 0); }
+            { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr, glb0, glb1); PROF_ADD(c, 0); }
             if (!ok) nOvf++;
         }
         if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
@@ -933,7 +947,7 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
 #ifdef STARAMD_PROFILE
         c.prof[7] = __builtin_readcyclecounter() - profKernelStart;      // whole wave life time
-        for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);
+        for (int k = 0; k < 16; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);
 #endif
     }
 }
@@ -1050,6 +1064,23 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_finish(const DevIndex
         nWt++; nTr += o.nTr; nEx += o.nEx;
     }
     if (bestScore == 0) { rd.status |= STARAMD_ST_NO_GOOD_WINDOW; nWt = 0; nTr = 0; nEx = 0; bestW = -1; }   // :344-348
+    else if (P.resultSelect) {
+        // staramd_params::resultSelect: return only what multMapSelect can pick (ReadAlign_multMapSelect.cpp:26-44):
+        // per window the best-first prefix with maxScore + outFilterMultimapScoreRange >= trBest->maxScore
+        const int selMin = bestScore - P.outFilterMultimapScoreRange;
+        i32 bestOrd = -1; u32 ord = 0, kept = 0; nTr = 0; nEx = 0;
+        for (u32 iw = 0; iw < rd.nWin; iw++) {
+            DWinOut o = B.wout[rd.winOffset + iw];
+            if (o.nTr == 0) continue;
+            u32 sel = 0, selEx = 0;
+            for (; sel < o.nTr; sel++) { const staramd_transcript &t = B.trPool[o.trOffset + sel]; if (t.maxScore < selMin) break; selEx += t.nExons; }
+            if ((i32)ord == bestW) bestOrd = (i32)kept;
+            ord++;
+            if (sel != o.nTr) { B.wout[rd.winOffset + iw].nTr = sel; B.wout[rd.winOffset + iw].nEx = selEx; }
+            if (sel) { kept++; nTr += sel; nEx += selEx; }
+        }
+        nWt = kept; bestW = bestOrd;
+    }
     rd.nWt = nWt; rd.nTr = nTr; rd.nEx = nEx; rd.bestW = bestW;
     rd.maxScoreMate[0] = M0; rd.maxScoreMate[1] = M1;
     B.reads[ir] = rd;

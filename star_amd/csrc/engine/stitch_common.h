@@ -23,7 +23,7 @@ struct StitchCtx {
     u64 nGstitch; u32 nStitchCalls, nExtendCalls, nNodes, nLeaves;
     u64 *shadow;                           // shadow-validation build: disagreement counters
 #ifdef STARAMD_PROFILE
-    u64 prof[8];
+    u64 prof[16];
 #endif
     u8 *candBase; u32 candTop, candCap, nCand; bool logOn, logOvf;   // candidate log of the current window (see DWinOut)
 };
@@ -43,7 +43,9 @@ __device__ __forceinline__ u8 GB(StitchCtx &c, u64 pos) { c.nGstitch++; return g
 #ifdef STARAMD_PROFILE
 #define PROF_T0() u64 prof_t0_ = __builtin_readcyclecounter()
 #define PROF_ADD(c, k) (c).prof[k] += __builtin_readcyclecounter() - prof_t0_
+#define PROF_MARK(c, k) { u64 prof_t1_ = __builtin_readcyclecounter(); (c).prof[k] += prof_t1_ - prof_t0_; prof_t0_ = prof_t1_; }
 #else
 #define PROF_T0()
 #define PROF_ADD(c, k)
+#define PROF_MARK(c, k)
 #endif

@@ -31,7 +31,7 @@ RunParams::RunParams() {
     dev.scoreGap = 0; dev.scoreGapNoncan = -8; dev.scoreGapGCAG = -4; dev.scoreGapATAC = -8;
     dev.scoreDelOpen = -2; dev.scoreDelBase = -2; dev.scoreInsOpen = -2; dev.scoreInsBase = -2;
     dev.scoreStitchSJshift = 1; dev.sjdbScore = 2; dev.scoreGenomicLengthLog2scale = -0.25;
-    dev.outFilterMultimapScoreRange = 1; dev.outFilterMismatchNoverLmax = 0.3; dev.outFilterMatchNmin = 0;
+    dev.outFilterMultimapScoreRange = 1; dev.outFilterMismatchNoverLmax = 0.3; dev.outFilterMatchNmin = 0; dev.resultSelect = 1;
 }
 
 std::string RunParams::parse(int argc, char **argv) {
@@ -96,6 +96,7 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outFilterScoreMinOverLread") outFilterScoreMinOverLread = D(k, v);
         else if (k == "outFilterMatchNmin") { outFilterMatchNmin = (uint32_t)U(k, v); dev.outFilterMatchNmin = outFilterMatchNmin; }
         else if (k == "outFilterMatchNminOverLread") outFilterMatchNminOverLread = D(k, v);
+        else if (k == "gpuResultSelect") { const std::string &s = one(k, v); if (s == "All") dev.resultSelect = 0; else if (s == "Selected") dev.resultSelect = 1; else err = "EXITING: --gpuResultSelect takes All or Selected"; }
         else if (k == "outFilterIntronMotifs") { const std::string &s = one(k, v); if (s == "None") dev.outFilterIntronMotifs = 0; else if (s == "RemoveNoncanonical") dev.outFilterIntronMotifs = 1; else if (s == "RemoveNoncanonicalUnannotated") dev.outFilterIntronMotifs = 2; else err = "EXITING because of FATAL INPUT error: unrecognized value of --outFilterIntronMotifs=" + s; }
         else if (k == "outFilterIntronStrands") { const std::string &s = one(k, v); if (s == "RemoveInconsistentStrands") dev.outFilterIntronStrandsRemoveInconsistent = 1; else if (s == "None") dev.outFilterIntronStrandsRemoveInconsistent = 0; else err = "EXITING: unsupported --outFilterIntronStrands " + s; }
         else if (k == "outSJtype") { if (one(k, v) != "Standard") err = "EXITING: only --outSJtype Standard is implemented"; }

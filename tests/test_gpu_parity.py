@@ -26,12 +26,13 @@ def test_engine_matches_reference_outputs(name, tmp_path, built):
     assert not problems, problems
 
 
-@pytest.mark.parametrize("name", sorted(DATASETS))
-def test_engine_matches_oracle_buffers(name, tmp_path, built):
+@pytest.mark.parametrize("name,select", [(n, "Selected") for n in sorted(DATASETS)] + [("pe101", "All"), ("pe150_indel", "All")])
+def test_engine_matches_oracle_buffers(name, select, tmp_path, built):
+    """select = Selected: only the transcripts multMapSelect can pick are returned (default); All: the whole trAll[][]."""
     if not refstar.have_ref():
         pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
     info = prepare(name, str(tmp_path), need_ref=False)
-    argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "x_")] + info["extra"]
+    argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "x_")] + info["extra"] + ["--gpuResultSelect", select]
     run = capi.HostRun(argv)
     eng = _engine(run.genome, run.params)
     orc = oracle_lib.Oracle(run.genome, run.params)
