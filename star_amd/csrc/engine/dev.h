@@ -20,6 +20,7 @@ typedef uint32_t u32;
 typedef int32_t i32;
 typedef uint16_t u16;
 typedef uint8_t u8;
+typedef int16_t i16;
 typedef int8_t i8;
 
 #define GPAD 4096                 // bytes of code 5 before and after the genome on the device
