@@ -25,7 +25,7 @@ extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *ex
 
 // per-lane / per-wave work-space sizes (same formulas as the kernels)
 static inline u32 stitchStateBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_MAX * 24u + arenaBytes;
+    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_MAX * 24u + WA_MAX * 8u + arenaBytes;
     return (b + 127u) & ~127u;
 }
 static inline u64 winWaveBytesH(u32 capW, u32 capBlocks, u32 big) {
@@ -227,11 +227,12 @@ static int allocWork(staramd_ctx *c) {
     c->arenaBig = 2u * (P.alignTranscriptsPerWindowNmax + 2) * (96u + 32u * STARAMD_MAX_N_EXONS);      // twice the largest live set
     if (c->arenaBig > 2000000u) { g_err = "alignTranscriptsPerWindowNmax too large for the device record arena"; return STARAMD_ERR_ARG; }
     // one wavefront per window, walk state in LDS; blocks of 4 wavefronts; one worst-case record arena per wavefront in HBM
-    c->arenaFast = envU32("STARAMD_STITCH_ARENA", 4096) & ~31u;
+    c->arenaFast = envU32("STARAMD_STITCH_ARENA", 3584) & ~31u;
     int stPerCU = 2;
     size_t ldsFast = 4 * (size_t)(stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast) + 27 * 4 + 16);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stPerCU, k_stitch_win, 256, ldsFast) != hipSuccess || stPerCU < 1) stPerCU = 2;
     c->stBlocks = (u32)c->nCU * envU32("STARAMD_STITCH_BLOCKS_PER_CU", (u32)stPerCU);
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win %d blocks/CU (LDS %zu B/block), k_windows %d blocks/CU, k_seed_search %d blocks/CU\n", stPerCU, ldsFast, winPerCU, seedPerCU);
     if ((rc = devAlloc(R, &c->scrStitchBig, (u64)c->stBlocks * 4 * c->arenaBig))) return rc;
     // candidate logs: one private region per wavefront; sized so that a wavefront's share of a full batch fits
     B.candWaveBytes = ((u64)envU32("STARAMD_CAND_KB_PER_WAVE", 0) * 1024) & ~31ull;

@@ -716,12 +716,20 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
 
 // per-window LDS work space, in bytes: undo stack, exon rows, leaf copy, rank list, seed list (+ arena in the fast path)
 #define WA_LDS_BYTES (WA_MAX * 24u)
+#define COMPAT_LDS_BYTES (WA_MAX * 8u)              // u64 compat[WA_MAX]: which later seeds can follow seed A at all
 __host__ __device__ inline u32 stitchStateBytes(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_LDS_BYTES + arenaBytes;
+    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_LDS_BYTES + COMPAT_LDS_BYTES + arenaBytes;
     return (b + 127u) & ~127u;
 }
 
-struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LDS u16 *rank; LDS u8 *arena; };
+struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LDS u64 *compat; LDS u16 *rank; LDS u8 *arena; };
+
+// next seed index > i whose bit is set in mask, nA if none
+__device__ __forceinline__ u32 nextSeed(u64 mask, u32 i, u32 nA) {
+    u64 mk = i >= 63u ? 0ull : (mask & ~((2ull << i) - 1ull));
+    if (nA < 64u) mk &= (1ull << nA) - 1ull;
+    return mk ? firstLane(mk) : nA;
+}
 
 // depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321):
 // include seed iA (if it stitches), then exclude it.  Wave-uniform control flow.  Returns false when the arena overflowed.
@@ -733,6 +741,24 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
     Hdr h; h.gStart = 0; h.tG2 = 0; h.nExons = 0; h.Score = 0; h.nMatch = h.nMM = h.nGap = h.lGap = h.nDel = h.lDel = h.nIns = h.lIns = 0;
     h.nUnique = h.nAnchor = 0; h.rStart = 0; h.tR2 = 0;
     u32 iA = 0; u32 sp = 0; u32 ex0R = 0; u64 ex0G = 0;
+    // Seed B can never follow seed A of the same mate when it does not end behind A in the read and in the genome
+    // (stitchAlignToTranscript.cpp:44-51 returns -1000001 / -1000002 before touching anything): ~3/4 of the reference's
+    // stitch calls.  The pairs are known up front -- lane A builds the bit mask of the seeds that CAN follow A -- and the
+    // walk steps over the others without visiting them (a failed include followed by the exclude changes nothing).
+    if (lane < nA) {
+        const DWA sa = ldsGet(&WA[lane]);
+        const u32 rAe = (u32)sa.rStart + sa.L - 1; const u64 gAe = sa.gStart + sa.L - 1;
+        u64 mk = 0;
+        for (u32 b = lane + 1; b < nA; b++) {
+            const u32 rBe = (u32)WA[b].rStart + WA[b].L - 1; const u64 gBe = WA[b].gStart + WA[b].L - 1;
+            const bool fail = WA[b].iFrag == sa.iFrag && (rBe <= rAe || gBe <= gAe);
+            if (!fail) mk |= 1ull << b;
+        }
+        m.compat[lane] = mk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    u32 iLast = 0;                                   // last included seed of the working transcript
+    u64 follow = ~0ull;                              // seeds that can follow the last included one (all, while the transcript is empty)
     DWA a = uni(ldsGet(&WA[0]));
     for (;;) {
         c.nNodes++;
@@ -746,7 +772,8 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             if (sp == 0) break;
             sp--;                                    // back to the frame that included a seed: now exclude it
             SFrame f = uni(ldsGet(&stack[sp]));
-            h = f.h; iA = f.iA + 1;
+            h = f.h; iLast = f.pad; follow = h.nExons > 0 ? first64(m.compat[iLast]) : ~0ull;   // f.pad = last included seed of the restored transcript
+            iA = nextSeed(follow, f.iA, nA);
             if (h.nExons > 0 && lane == 0) ldsPut(&EX[h.nExons - 1], f.eA);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (iA < nA) a = uni(ldsGet(&WA[iA]));
@@ -776,7 +803,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
 #endif
             if (dScore > -1000000) {
                 if (lane == 0) {
-                    SFrame f; f.h = h; f.iA = iA; f.pad = 0; f.eA = eAold;
+                    SFrame f; f.h = h; f.iA = iA; f.pad = iLast; f.eA = eAold;
                     ldsPut(&stack[sp], f);
                     ldsPut(&EX[h.nExons - 1], eA);
                     if (added) ldsPut(&EX[h.nExons], eN);
@@ -786,7 +813,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
         } else {                                     // first seed of the transcript (:318-334)
             eN.R = a.rStart; eN.G = a.gStart; eN.L = a.L; eN.iFrag = a.iFrag; eN.sjA = a.sjA;
             eN.canonSJ = 0; eN.sjAnnot = 0; eN.sjStr = 0; eN.shiftSJ[0] = eN.shiftSJ[1] = 0; eN.pad0 = 0; eN.pad1 = 0;
-            if (lane == 0) { SFrame f; f.h = h; f.iA = iA; f.pad = 0; f.eA = eN; ldsPut(&stack[sp], f); ldsPut(&EX[0], eN); }
+            if (lane == 0) { SFrame f; f.h = h; f.iA = iA; f.pad = 0; f.eA = eN; ldsPut(&stack[sp], f); ldsPut(&EX[0], eN); }     // empty transcript: pad unused
             hn.rStart = a.rStart; hn.gStart = a.gStart; hn.nExons = 1; hn.nMatch = a.L;
             dScore = a.L;
         }
@@ -796,10 +823,11 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             hn.Score = h.Score + dScore; hn.tR2 = (u32)a.rStart + a.L - 1; hn.tG2 = a.gStart + a.L - 1;
             if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; }
             h = hn; sp++;
+            iLast = iA; follow = first64(m.compat[iA]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
         // include succeeded: continue below it; include failed: exclude branch (:348-351) = same transcript, next seed
-        iA++;
+        iA = nextSeed(follow, iA, nA);
         if (iA < nA) a = uni(ldsGet(&WA[iA]));
     }
     return true;
@@ -844,7 +872,8 @@ __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRan
     m.LEAF = m.EX + STARAMD_MAX_N_EXONS;
     m.rank = (LDS u16 *)(m.LEAF + STARAMD_MAX_N_EXONS);
     m.WA = (LDS DWA *)((LDS u8 *)m.rank + ((capRank * 2u + 31u) & ~31u));
-    m.arena = (LDS u8 *)m.WA + WA_LDS_BYTES;
+    m.compat = (LDS u64 *)((LDS u8 *)m.WA + WA_LDS_BYTES);
+    m.arena = (LDS u8 *)m.compat + COMPAT_LDS_BYTES;
 }
 
 __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
