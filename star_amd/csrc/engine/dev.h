@@ -82,7 +82,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
 enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS = 6,
        CUR_TICKET_SEED = 8, CUR_TICKET_WIN = 9, CUR_OVF_WIN = 11, CUR_TICKET_WIN2 = 13,
        // stitch stage: work lists of window ids and their tickets
-       CUR_ST_TICKET0 = 16,                                              // pass 0: all windows, incoming maxScoreMate 0
+       CUR_ST_TICKET0 = 16, CUR_ITEM = 25,                               // pass 0: all work items (reads or windows)
        CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
        CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
        CUR_N = 32 };
@@ -99,9 +99,10 @@ struct DevBatch {
     DWin *winPool; u32 winCap; DWA *waPool; u32 waCap;
     DWinOut *wout;                      // winCap slots
     staramd_transcript *trPool; u32 trCap; staramd_exon *exPool; u32 exCap;
-    u32 *order;        // window ids in stitch order: sorted by estimated work, then dealt round-robin to groups of 64 tickets
+    u32 *order;        // work items in stitch order: sorted by estimated work, then dealt round-robin to groups of 64 tickets
     u32 *costHist;     // 32 cost classes + 32 offsets
-    u8 *winClass;      // cost class of every window (winCap)
+    // stitch work items: bit 31 set = a whole (light) read, its windows walked in order by one wavefront; else a window id
+    u32 *items; u8 *itemClass;   // winCap entries; itemClass ~ log2(estimated walk size)
     u32 *ovfWin;       // reads deferred to the big-work-space pass of k_windows
     u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
     u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win

@@ -185,7 +185,8 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.winPool, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.waPool, (u64)B.waCap))) return rc;
     if ((rc = devAlloc(R, &B.wout, (u64)B.winCap))) return rc;
-    if ((rc = devAlloc(R, &B.winClass, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.items, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.itemClass, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.order, (u64)B.winCap + 64))) return rc;
     if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.replayList, (u64)B.winCap))) return rc;
@@ -287,7 +288,8 @@ static int growPools(staramd_ctx *c, u32 flags) {
         if ((rc = devRealloc(R, &B.winPool, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.waPool, (u64)B.waCap))) return rc;
         if ((rc = devRealloc(R, &B.wout, (u64)B.winCap))) return rc;
-        if ((rc = devRealloc(R, &B.winClass, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.items, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.itemClass, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.order, (u64)B.winCap + 64))) return rc;
         if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;

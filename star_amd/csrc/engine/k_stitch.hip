@@ -918,7 +918,7 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
     // break points of the genomic-length score term: lane k keeps points k and k+64 in registers for the whole kernel
     const u64 glb0 = lane < X.nBreak ? X.glBreak[lane] : ~0ull, glb1 = lane + 64u < X.nBreak ? X.glBreak[lane + 64u] : ~0ull;
     const u32 *list; u32 nItems, ticketSlot;
-    if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_WIN] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
+    if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_ITEM] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
     u32 nOvf = 0, lastRead = 0xFFFFFFFFu;
 #ifdef STARAMD_PROFILE
@@ -930,42 +930,52 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
         if (lane == 0) it = atomicAdd(&B.cursors[ticketSlot], 1u);
         it = first32(it);
         if (it >= nItems) break;
-        u32 w = first32(list[it]);
-        if (w == 0xFFFFFFFFu) continue;                 // padding slot of the dealt order
-        const DWin win = uni(B.winPool[w]);
-        if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
-        if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-        {   // stage the window's seed list in LDS (3 dwords x 2 per row)
-            const u32 *src = (const u32 *)(B.waPool + win.waOffset); LDS u32 *dst = (LDS u32 *)m.WA;
-            for (u32 k = lane; k < win.nWA * 6u; k += NLANE) dst[k] = src[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const u32 item = first32(list[it]);
+        if (item == 0xFFFFFFFFu) continue;              // padding slot of the dealt order
+        // a work item is a window, or (bit 31) a light read whose windows are walked in order with maxScoreMate carried
+        const bool wholeRead = (item & 0x80000000u) != 0;
+        u32 w0 = item, nWin = 1;
+        i32 carry[2] = {0, 0};
+        if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; }
+        for (u32 iw = 0; iw < nWin; iw++) {
+            const u32 w = w0 + iw;
+            const DWin win = uni(B.winPool[w]);
+            if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
+            if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+            {   // stage the window's seed list in LDS (6 dwords per row)
+                const u32 *src = (const u32 *)(B.waPool + win.waOffset); LDS u32 *dst = (LDS u32 *)m.WA;
+                for (u32 k = lane; k < win.nWA * 6u; k += NLANE) dst[k] = src[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            DWinOut o;
+            if (wholeRead) { o.minIn[0] = carry[0]; o.minIn[1] = carry[1]; }
+            else { o = uni(B.wout[w]); if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; } }
+            c.logOn = mode == 0 && !wholeRead;
+            const u32 candStart = c.candTop;
+            bool ok = false;
+            for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {         // 2nd attempt: same walk, record arena in HBM
+                wr.big = attempt != 0; wr.arenaBytes = wr.big ? wr.arenaBytesG : wr.arenaBytesL;
+                c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
+                c.sens[0] = c.sens[1] = 0x7FFFFFFF;
+                c.candTop = candStart; c.nCand = 0; c.logOvf = false;
+                { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr, glb0, glb1); PROF_ADD(c, 0); }
+                if (!ok) nOvf++;
+            }
+            if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+            if (!flushWindow(B, lane, wr, o)) continue;
+            o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
+            carry[0] = c.maxScoreMate[0]; carry[1] = c.maxScoreMate[1];
+            // the incoming maxScoreMate of a whole-read item is exact: its result is final
+            o.sens[0] = wholeRead ? 0x7FFFFFFF : c.sens[0]; o.sens[1] = wholeRead ? 0x7FFFFFFF : c.sens[1];
+            // keep the candidate log only if some decision of this window depends on the incoming maxScoreMate
+            o.candOff32 = 0; o.nCand = 0; o.pad = 0;
+            if (c.logOn) {
+                bool sensitive = c.sens[0] != 0x7FFFFFFF || c.sens[1] != 0x7FFFFFFF;
+                if (sensitive && !c.logOvf) { o.candOff32 = (u32)(((u64)waveId * B.candWaveBytes + candStart) / 32u); o.nCand = c.nCand; }
+                else { c.candTop = candStart; if (sensitive) o.nCand = 0xFFFFFFFFu; }
+            }
+            if (lane == 0) B.wout[w] = o;
         }
-        DWinOut o = uni(B.wout[w]);
-        if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; }
-        c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
-        c.sens[0] = c.sens[1] = 0x7FFFFFFF;
-        const u32 candStart = c.candTop;
-        bool ok = false;
-        for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {         // 2nd attempt: same walk, record arena in HBM
-            wr.big = attempt != 0; wr.arenaBytes = wr.big ? wr.arenaBytesG : wr.arenaBytesL;
-            c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
-            c.sens[0] = c.sens[1] = 0x7FFFFFFF;
-            c.candTop = candStart; c.nCand = 0; c.logOvf = false;
-            { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr, glb0, glb1); PROF_ADD(c, 0); }
-            if (!ok) nOvf++;
-        }
-        if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-        if (!flushWindow(B, lane, wr, o)) continue;
-        o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
-        o.sens[0] = c.sens[0]; o.sens[1] = c.sens[1];
-        // keep the candidate log only if some decision of this window depends on the incoming maxScoreMate
-        o.candOff32 = 0; o.nCand = 0; o.pad = 0;
-        if (c.logOn) {
-            bool sensitive = c.sens[0] != 0x7FFFFFFF || c.sens[1] != 0x7FFFFFFF;
-            if (sensitive && !c.logOvf) { o.candOff32 = (u32)(((u64)waveId * B.candWaveBytes + candStart) / 32u); o.nCand = c.nCand; }
-            else { c.candTop = candStart; if (sensitive) o.nCand = 0xFFFFFFFFu; }
-        }
-        if (lane == 0) B.wout[w] = o;
     }
     if (lane == 0) {
         atomicAdd((unsigned long long *)&B.counters[DC_nGstitch], (unsigned long long)c.nGstitch);

@@ -317,20 +317,29 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
         }
         if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
         // ---- emit windows that hold seeds, in window order
-        u32 nOut = 0, nWA = 0;
-        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; } }
-        for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); }
+        u32 nOut = 0, nWA = 0; u32 est = 0;
+        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 12u); } }
+        for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); est += (u32)__shfl_xor((int)est, o, 64); }
         if (nOut > 0) {
-            u32 wo = 0, ao = 0;
-            if (lane == 0) { wo = atomicAdd(&B.cursors[CUR_WIN], nOut); ao = atomicAdd(&B.cursors[CUR_WA], nWA); }
-            wo = first32(wo); ao = first32(ao);
-            if (wo + nOut > B.winCap || ao + nWA > B.waCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_WINPOOL); continue; }
+            // stitch work items: a light read (its walks are bounded by est = sum over windows of 2^seeds) is ONE item -- its
+            // windows are walked in order by one wavefront, so maxScoreMate is carried exactly and nothing has to be
+            // re-decided; the windows of a heavy read are separate items (k_stitch_win / k_stitch_verify / k_stitch_replay)
+            const bool light = est <= 512u;
+            const u32 nIt = light ? 1u : nOut;
+            u32 wo = 0, ao = 0, io = 0;
+            if (lane == 0) { wo = atomicAdd(&B.cursors[CUR_WIN], nOut); ao = atomicAdd(&B.cursors[CUR_WA], nWA); io = atomicAdd(&B.cursors[CUR_ITEM], nIt); }
+            wo = first32(wo); ao = first32(ao); io = first32(io);
+            if (wo + nOut > B.winCap || ao + nWA > B.waCap || io + nIt > B.winCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_WINPOOL); continue; }
             rd.winOffset = wo; rd.nWin = nOut;
+            if (light && lane == 0) { B.items[io] = 0x80000000u | ir; B.itemClass[io] = (u8)(32 - __clz((int)est)); }
             for (u32 j = 0; j < s.nW; j++) {
                 u32 n = s.t.nwa[j];
                 if (n == 0) continue;
                 u32 m = s.t.meta[j];
-                if (lane == 0) { DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.pad = 0; B.winPool[wo] = d; B.winClass[wo] = (u8)min(n, 31u); }
+                if (lane == 0) {
+                    DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.pad = 0; B.winPool[wo] = d;
+                    if (!light) { B.items[io] = wo; B.itemClass[io] = (u8)min(n + 1u, 31u); io++; }
+                }
                 const DWA *A = s.arena + (u64)s.t.blk[j] * WA_MAX;
                 if (lane < n) B.waPool[ao + lane] = A[lane];
                 wo++; ao += n;
@@ -347,17 +356,17 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
     }
 }
 
-// ---- stitch order: windows sorted by number of seeds (the stitcher's work grows with it), most seeds first (counting sort
+// ---- stitch order: work items sorted by class ~ log2(estimated walk size), largest first (counting sort
 // over 32 classes), then dealt round-robin over groups of 64 consecutive tickets: a wavefront takes 64 consecutive tickets
 // per round, so every wavefront gets one window of each stratum instead of 64 heavy (mutually divergent) ones.
 extern "C" __global__ void __launch_bounds__(256) k_order_hist(DevBatch B) {
     __shared__ u32 h[32];
     if (threadIdx.x < 32) h[threadIdx.x] = 0;
     __syncthreads();
-    u32 n = B.cursors[CUR_WIN]; u32 slots = ((n + 63u) / 64u) * 64u;
+    u32 n = B.cursors[CUR_ITEM]; u32 slots = ((n + 63u) / 64u) * 64u;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += gridDim.x * blockDim.x) {
         B.order[i] = 0xFFFFFFFFu;
-        if (i < n) atomicAdd(&h[B.winClass[i] & 31u], 1u);
+        if (i < n) atomicAdd(&h[B.itemClass[i] & 31u], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&B.costHist[threadIdx.x], h[threadIdx.x]);
@@ -369,18 +378,18 @@ extern "C" __global__ void k_order_offsets(DevBatch B) {      // 1 thread: class
 extern "C" __global__ void __launch_bounds__(256) k_order_scatter(DevBatch B) {
     // per block: histogram of its chunk in LDS, ONE global reservation per class, ranks inside the block from LDS atomics
     __shared__ u32 h[32], base[32];
-    u32 n = B.cursors[CUR_WIN]; u32 G = (n + 63u) / 64u;
+    u32 n = B.cursors[CUR_ITEM]; u32 G = (n + 63u) / 64u;
     u32 perBlock = (n + gridDim.x - 1) / gridDim.x;
     u32 lo = blockIdx.x * perBlock, hi = min(n, lo + perBlock);
     if (threadIdx.x < 32) h[threadIdx.x] = 0;
     __syncthreads();
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[B.winClass[i] & 31u], 1u);
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[B.itemClass[i] & 31u], 1u);
     __syncthreads();
     if (threadIdx.x < 32) { u32 c = h[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(&B.costHist[32 + threadIdx.x], c) : 0; h[threadIdx.x] = 0; }
     __syncthreads();
     for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        u32 cls = B.winClass[i] & 31u;
+        u32 cls = B.itemClass[i] & 31u;
         u32 pos = base[cls] + atomicAdd(&h[cls], 1u);
-        B.order[(pos % G) * 64u + pos / G] = i;
+        B.order[(pos % G) * 64u + pos / G] = B.items[i];
     }
 }
