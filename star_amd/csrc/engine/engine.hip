@@ -11,7 +11,7 @@
 
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
-extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big);
+extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big, u32 lightEst);
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
@@ -56,6 +56,7 @@ struct staramd_ctx {
     // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
+    u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
     u32 stBlocks = 0, stBlocksBig = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
     u32 capDepth = 0, capRank = 0, arenaFast = 0, arenaBig = 0, ldsWordsCap = 0;
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr;
@@ -213,6 +214,7 @@ static int allocWork(staramd_ctx *c) {
     c->seedPerLane = P.seedPerReadNmax + 1;
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
     // ---- window kernel
+    c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
     c->capW = envU32("STARAMD_CAP_WINDOWS", 192); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
     int winPerCU = 3;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * c->capW * 8 * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
@@ -320,8 +322,8 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[1], s));
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
-        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * c->capW * 8 * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u);
-        hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u);
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * c->capW * 8 * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst);
+        hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u, c->lightEst);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
         hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1), 0, s, B);

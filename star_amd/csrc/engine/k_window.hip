@@ -191,7 +191,7 @@ __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
 
 extern __shared__ u32 ldsTab[];     // fast pass: wavesPerBlock * capW * 8 words
 
-extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big) {
+extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big, u32 lightEst) {
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
@@ -318,13 +318,13 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
         if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
         // ---- emit windows that hold seeds, in window order
         u32 nOut = 0, nWA = 0; u32 est = 0;
-        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 12u); } }
+        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 20u); } }
         for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); est += (u32)__shfl_xor((int)est, o, 64); }
         if (nOut > 0) {
             // stitch work items: a light read (its walks are bounded by est = sum over windows of 2^seeds) is ONE item -- its
             // windows are walked in order by one wavefront, so maxScoreMate is carried exactly and nothing has to be
             // re-decided; the windows of a heavy read are separate items (k_stitch_win / k_stitch_verify / k_stitch_replay)
-            const bool light = est <= 512u;
+            const bool light = est <= lightEst;
             const u32 nIt = light ? 1u : nOut;
             u32 wo = 0, ao = 0, io = 0;
             if (lane == 0) { wo = atomicAdd(&B.cursors[CUR_WIN], nOut); ao = atomicAdd(&B.cursors[CUR_WA], nWA); io = atomicAdd(&B.cursors[CUR_ITEM], nIt); }
