@@ -177,10 +177,11 @@ static int allocWork(staramd_ctx *c) {
     DevBatch &B = c->B; memset(&B, 0, sizeof(B));
     B.bases = c->dBases; B.readOffset = c->dReadOffset; B.mate1Length = c->dMate1; B.mmMaxTotal = c->dMM;
     if ((rc = devAlloc(R, &B.reads, (u64)N))) return rc;
-    B.seedCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_SEEDS_PER_READ", 32) + 65536, 0xFFFFFFF0ull);
-    B.winCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WINDOWS_PER_READ", 24) + 65536, 0xFFFFFFF0ull);
-    B.waCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WA_PER_READ", 96) + 65536, 0xFFFFFFF0ull);
-    B.trCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_TR_PER_READ", 48) + 65536, 0xFFFFFFF0ull);
+    const u64 slack = envU32("STARAMD_POOL_SLACK", 65536);
+    B.seedCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_SEEDS_PER_READ", 32) + slack, 0xFFFFFFF0ull);
+    B.winCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WINDOWS_PER_READ", 24) + slack, 0xFFFFFFF0ull);
+    B.waCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_WA_PER_READ", 96) + slack, 0xFFFFFFF0ull);
+    B.trCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_TR_PER_READ", 48) + slack, 0xFFFFFFF0ull);
     B.exCap = (u32)std::min<u64>((u64)B.trCap * 3, 0xFFFFFFF0ull);
     if ((rc = devAlloc(R, &B.seedPool, (u64)B.seedCap))) return rc;
     if ((rc = devAlloc(R, &B.winPool, (u64)B.winCap))) return rc;

@@ -79,3 +79,30 @@ def test_shadow_validation(name, tmp_path, built):
     c = json.loads(out.decode().strip().splitlines()[-1])
     assert c["stitchN"] > 1000 and c["extendN"] > 1000, c
     assert c["stitchBad"] == 0 and c["extendBad"] == 0, c
+
+
+# Rarely taken paths of the engine, forced by shrinking its work space through the STARAMD_* knobs:
+#   tiny pools            -> bump allocators overflow, the host doubles the pool and re-runs the batch
+#   2 windows / 2 blocks  -> every read with more windows goes through the second k_windows launch (table in global memory)
+#   256-byte record arena -> windows re-walked with the record arena in HBM
+#   tiny candidate logs   -> maxScoreMate-sensitive windows re-walked (k_stitch_win mode 1) instead of replayed
+#   every read heavy / every read light -> both kinds of stitch work items
+FORCED = {
+    "tiny_pools": {"STARAMD_POOL_SLACK": "64", "STARAMD_SEEDS_PER_READ": "1", "STARAMD_WINDOWS_PER_READ": "1", "STARAMD_WA_PER_READ": "1", "STARAMD_TR_PER_READ": "1"},
+    "window_overflow": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2"},
+    "arena_overflow": {"STARAMD_STITCH_ARENA": "256"},
+    "log_overflow": {"STARAMD_CAND_KB_PER_WAVE": "1"},
+    "all_heavy": {"STARAMD_LIGHT_EST": "0"},
+    "all_light": {"STARAMD_LIGHT_EST": "4000000000"},
+}
+
+
+@pytest.mark.parametrize("case", sorted(FORCED))
+def test_forced_rare_paths(case, tmp_path, built):
+    import os, subprocess, sys
+    if not refstar.have_ref():
+        pytest.skip("oracle/_ref/STAR missing")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ); env.update(FORCED[case])
+    out = subprocess.check_output([sys.executable, os.path.join(here, "engine_run.py"), "pe150_indel", str(tmp_path)], env=env)
+    assert out.decode().strip().splitlines()[-1] == "OK", out.decode()[-2000:]
