@@ -282,12 +282,14 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
 }
 
 // grow a pool after an overflow of the bump allocator (the batch is then simply run again: inputs are resident)
-static int growPools(staramd_ctx *c, u32 flags) {
+// grow a pool after an overflow of the bump allocator (the batch is then simply run again: inputs are resident).
+// The cursors keep counting past the capacity, so they tell the demand of the stage that overflowed.
+static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
     DevBatch &B = c->B; std::vector<void *> &R = c->workAllocs; int rc;
-    auto dbl = [](u32 v) { return (u32)std::min<u64>((u64)v * 2, 0xFFFFFFF0ull); };
-    if (flags & OVF_SEEDPOOL) { B.seedCap = dbl(B.seedCap); if ((rc = devRealloc(R, &B.seedPool, (u64)B.seedCap))) return rc; }
+    auto grow = [](u32 cap, u32 demand) { return (u32)std::min<u64>(std::max<u64>((u64)cap * 2, (u64)demand + demand / 4 + 1024), 0xFFFFFFF0ull); };
+    if (flags & OVF_SEEDPOOL) { B.seedCap = grow(B.seedCap, cur[CUR_SEED]); if ((rc = devRealloc(R, &B.seedPool, (u64)B.seedCap))) return rc; }
     if (flags & OVF_WINPOOL) {
-        B.winCap = dbl(B.winCap); B.waCap = dbl(B.waCap);
+        B.winCap = grow(B.winCap, std::max(cur[CUR_WIN], cur[CUR_ITEM])); B.waCap = grow(B.waCap, cur[CUR_WA]);
         if ((rc = devRealloc(R, &B.winPool, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.waPool, (u64)B.waCap))) return rc;
         if ((rc = devRealloc(R, &B.wout, (u64)B.winCap))) return rc;
@@ -298,7 +300,7 @@ static int growPools(staramd_ctx *c, u32 flags) {
         if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;
     }
     if (flags & OVF_TRPOOL) {
-        B.trCap = dbl(B.trCap); B.exCap = dbl(B.exCap);
+        B.trCap = grow(B.trCap, cur[CUR_TR]); B.exCap = grow(B.exCap, cur[CUR_EX]);
         if ((rc = devRealloc(R, &B.trPool, (u64)B.trCap))) return rc;
         if ((rc = devRealloc(R, &B.exPool, (u64)B.exCap))) return rc;
         if ((rc = devRealloc(R, &c->dOutTr, (u64)B.trCap))) return rc;
@@ -380,13 +382,13 @@ static int runDevice(staramd_ctx *c, staramd_results *r) {
         if (rc) return rc;
         if (flags == 0) break;
         const u32 *cur = c->hostScratch + 8;
-        if ((flags & OVF_HARD) || attempt >= 6) {
+        if ((flags & OVF_HARD) || attempt >= 12) {
             char buf[320];
             snprintf(buf, sizeof(buf), "device work-space overflow (flags 0x%x): seeds %u/%u windows %u/%u WA %u/%u tr %u/%u ex %u/%u",
                      flags, cur[CUR_SEED], B.seedCap, cur[CUR_WIN], B.winCap, cur[CUR_WA], B.waCap, cur[CUR_TR], B.trCap, cur[CUR_EX], B.exCap);
             g_err = buf; return STARAMD_ERR_SCRATCH_OVERFLOW;
         }
-        rc = growPools(c, flags);
+        rc = growPools(c, flags, cur);
         if (rc) return rc;
     }
     const u32 *totals = c->hostScratch;

@@ -6,6 +6,7 @@
 
 // exclusive scan of (nTr, nEx) over reads: one block, each thread scans a contiguous chunk
 extern "C" __global__ void __launch_bounds__(1024) k_scan_offsets(DevBatch B, u32 *trBase, u32 *exBase, u32 *totals) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     __shared__ u32 sT[1024], sE[1024];
     u32 t = threadIdx.x, n = B.nReads;
     u32 chunk = (n + 1023) / 1024;
@@ -28,6 +29,7 @@ extern "C" __global__ void __launch_bounds__(1024) k_scan_offsets(DevBatch B, u3
 extern "C" __global__ void __launch_bounds__(256) k_gather(DevBatch B, const u32 *trBase, const u32 *exBase,
                                                           staramd_read_result *outReads, staramd_transcript *outTr, u32 outTrCap,
                                                           staramd_exon *outEx, u32 outExCap) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
     if (ir >= B.nReads) return;
     const DRead rd = B.reads[ir];

@@ -898,6 +898,7 @@ __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBat
 // arena in global memory (bigArena: one worst-case arena per wavefront).
 extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
                                                              u32 bigArenaBytes, u32 ldsWords, u32 mode) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     const u32 lane = threadIdx.x & 63u;
@@ -1027,6 +1028,7 @@ __device__ static bool replayWindow(const staramd_params &P, u32 lane, const DWi
 
 extern "C" __global__ void __launch_bounds__(256) k_stitch_replay(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
                                                                 u32 bigArenaBytes, u32 ldsWords) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const staramd_params &P = Xp->P;
     const u32 lane = threadIdx.x & 63u;
     u32 waveInBlock = threadIdx.x >> 6, wavesPerBlock = blockDim.x >> 6;
@@ -1058,6 +1060,7 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_replay(const DevIndex
 
 // ---- per read: true incoming maxScoreMate of every window; queue the windows whose pass-0 result may differ ----
 extern "C" __global__ void __launch_bounds__(256) k_stitch_verify(const DevIndex *__restrict__ Xp, DevBatch B) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
     if (ir >= B.nReads) return;
     const DRead rd = B.reads[ir];
@@ -1081,6 +1084,7 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_verify(const DevIndex
 // alignTranscriptsPerReadNmax (:290-294) stops the reference's walk before window k when the transcripts recorded so
 // far reach the limit; windows < k do not depend on windows >= k, so the exact result is the prefix.
 extern "C" __global__ void __launch_bounds__(256) k_stitch_finish(const DevIndex *__restrict__ Xp, DevBatch B) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const staramd_params &P = Xp->P;
     u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
     if (ir >= B.nReads) return;

@@ -360,6 +360,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
 // over 32 classes), then dealt round-robin over groups of 64 consecutive tickets: a wavefront takes 64 consecutive tickets
 // per round, so every wavefront gets one window of each stratum instead of 64 heavy (mutually divergent) ones.
 extern "C" __global__ void __launch_bounds__(256) k_order_hist(DevBatch B) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     __shared__ u32 h[32];
     if (threadIdx.x < 32) h[threadIdx.x] = 0;
     __syncthreads();
@@ -371,11 +372,13 @@ extern "C" __global__ void __launch_bounds__(256) k_order_hist(DevBatch B) {
     __syncthreads();
     if (threadIdx.x < 32 && h[threadIdx.x]) atomicAdd(&B.costHist[threadIdx.x], h[threadIdx.x]);
 }
-extern "C" __global__ void k_order_offsets(DevBatch B) {      // 1 thread: class offsets, heaviest class first
+extern "C" __global__ void k_order_offsets(DevBatch B) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch      // 1 thread: class offsets, heaviest class first
     u32 off = 0;
     for (int c = 31; c >= 0; c--) { u32 n = B.costHist[c]; B.costHist[32 + c] = off; off += n; }
 }
 extern "C" __global__ void __launch_bounds__(256) k_order_scatter(DevBatch B) {
+    if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     // per block: histogram of its chunk in LDS, ONE global reservation per class, ranks inside the block from LDS atomics
     __shared__ u32 h[32], base[32];
     u32 n = B.cursors[CUR_ITEM]; u32 G = (n + 63u) / 64u;
