@@ -242,7 +242,7 @@ def main():
         "stitch_section_cycles": prof,
         "index_upload_s": t_upload, "first_batch_incl_h2d_s": t_first, "sj_merge_ms": sj_merge_ms,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
         out["cpu_baseline"] = cpu_baseline(d, args, min(args.cpu_sample, n))
     print(json.dumps(out))
     if dist is not None:
