@@ -124,6 +124,7 @@ public:
     PostMap(const RunParams &P, const GenomeIndex &gi) : P(P), gi(gi) {}
     // consumes the device (or oracle) results of one batch; appends SAM text to `sam`
     std::string process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st);
+    std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st) const;
     std::string samHeader() const;                   // samHeaders.cpp:27-106
 private:
     const RunParams &P;

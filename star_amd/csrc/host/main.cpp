@@ -2,11 +2,21 @@
 // Same flags (the subset that reaches the hot path or its outputs; anything else is rejected),
 // same genomeDir, same Aligned.out.sam / SJ.out.tab / Log.final.out.  The per-read hot path runs on
 // the MI355X through the C ABI of include/star_amd.h; there is no CPU path.
+//
+// Pipeline (the reference interleaves these per thread, ReadAlignChunk_processChunks.cpp / _mapChunk.cpp):
+//   reader thread   FASTQ text -> numeric batch k+1            (sah_parse_slot)
+//   main thread     batch k through the engine                 (staramd_map_batch)
+//   writer thread   post-map + SAM text of batch k-1 on --runThreadN host threads, in input order (sah_emit_slot)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <string>
 #include "../../../include/star_amd.h"
 
 extern "C" {
@@ -15,41 +25,93 @@ const staramd_genome *sah_genome(void *h);
 const staramd_params *sah_params(void *h);
 uint64_t sah_batch_reads(void *h);
 int sah_device(void *h);
-int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out);
-int sah_emit(void *h, const staramd_results *res);
+int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
+int sah_emit_slot(void *h, int slot, const staramd_results *res);
 int sah_finish(void *h);
 const char *sah_error(void *h);
 void sah_destroy(void *h);
+}
+
+namespace {
+struct Msg { int slot; int n; staramd_batch b; int resIdx; };
+struct Queue {                                   // bounded hand-off between two pipeline stages
+    std::mutex m; std::condition_variable cv; std::deque<Msg> q; bool closed = false;
+    void push(const Msg &x) { { std::lock_guard<std::mutex> l(m); q.push_back(x); } cv.notify_all(); }
+    void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+    bool pop(Msg &x) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; x = q.front(); q.pop_front(); return true; }
+};
+struct Tokens {                                  // counting semaphore over a small set of buffer indices
+    std::mutex m; std::condition_variable cv; std::deque<int> free;
+    int take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free.empty(); }); int v = free.front(); free.pop_front(); return v; }
+    void give(int v) { { std::lock_guard<std::mutex> l(m); free.push_back(v); } cv.notify_all(); }
+};
+struct ResBuf { std::vector<staramd_read_result> reads; std::vector<staramd_transcript> tr; std::vector<staramd_exon> ex; staramd_results res; };
 }
 
 int main(int argc, char **argv) {
     char err[4096];
     void *h = sah_create(argc, argv, err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }
-    uint64_t batchReads = sah_batch_reads(h);
+    const uint64_t batchReads = sah_batch_reads(h);
     staramd_ctx *ctx = nullptr;
     int rc = staramd_create(&ctx, sah_device(h), sah_genome(h), sah_params(h), (uint32_t)batchReads, 0);
     if (rc) { fprintf(stderr, "\nEXITING because of FATAL ERROR: cannot initialise the MI355X engine: %s\n", staramd_last_error()); sah_destroy(h); return 105; }
-    std::vector<staramd_read_result> reads(batchReads);
-    std::vector<staramd_transcript> tr(batchReads * 64 + 4096);
-    std::vector<staramd_exon> ex(tr.size() * 3);
-    staramd_results res; memset(&res, 0, sizeof(res));
-    res.reads = reads.data(); res.tr = tr.data(); res.trCapacity = tr.size(); res.ex = ex.data(); res.exCapacity = ex.size();
-    uint64_t nReads = 0; double msDevice = 0;
-    auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        staramd_batch b;
-        int n = sah_next_batch(h, batchReads, &b);
-        if (n < 0) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
-        if (n == 0) break;
-        rc = staramd_map_batch(ctx, &b, &res);
-        if (rc) { fprintf(stderr, "\nEXITING because of FATAL ERROR in the MI355X engine (%d): %s\n", rc, staramd_last_error()); return 105; }
-        if (sah_emit(h, &res)) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
-        nReads += (uint64_t)n; msDevice += res.msTotalDevice;
+    ResBuf rb[2];
+    for (auto &r : rb) {
+        r.reads.resize(batchReads); r.tr.resize(batchReads * 16 + 4096); r.ex.resize(r.tr.size() * 3);
+        memset(&r.res, 0, sizeof(r.res));
+        r.res.reads = r.reads.data(); r.res.tr = r.tr.data(); r.res.trCapacity = r.tr.size(); r.res.ex = r.ex.data(); r.res.exCapacity = r.ex.size();
     }
+    Queue parsed, mapped; Tokens slots, results;
+    for (int i = 0; i < 3; i++) slots.give(i);
+    for (int i = 0; i < 2; i++) results.give(i);
+    std::string failure; std::mutex failM;
+    auto fail = [&](const std::string &s) { std::lock_guard<std::mutex> l(failM); if (failure.empty()) failure = s; };
+    auto t0 = std::chrono::steady_clock::now();
+
+    std::thread reader([&] {
+        for (;;) {
+            Msg m; m.slot = slots.take(); m.resIdx = -1;
+            m.n = sah_parse_slot(h, m.slot, batchReads, &m.b);
+            if (m.n < 0) { fail(sah_error(h)); break; }
+            if (m.n == 0) break;
+            parsed.push(m);
+        }
+        parsed.close();
+    });
+    std::thread writer([&] {
+        Msg m;
+        while (mapped.pop(m)) {
+            if (failure.empty() && sah_emit_slot(h, m.slot, &rb[m.resIdx].res)) fail(sah_error(h));
+            results.give(m.resIdx); slots.give(m.slot);
+        }
+    });
+    uint64_t nReads = 0; double msDevice = 0;
+    {
+        Msg m;
+        while (parsed.pop(m)) {
+            if (!failure.empty()) { slots.give(m.slot); continue; }
+            m.resIdx = results.take();
+            staramd_results &res = rb[m.resIdx].res;
+            rc = staramd_map_batch(ctx, &m.b, &res);
+            if (rc == STARAMD_ERR_RESULT_OVERFLOW) {             // rare: more transcripts than the buffers hold -> grow and retry
+                ResBuf &r = rb[m.resIdx];
+                r.tr.resize(res.trCount + res.trCount / 4 + 4096); r.ex.resize(res.exCount + res.exCount / 4 + 4096);
+                res.tr = r.tr.data(); res.trCapacity = r.tr.size(); res.ex = r.ex.data(); res.exCapacity = r.ex.size();
+                rc = staramd_map_batch(ctx, &m.b, &res);
+            }
+            if (rc) { fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error()); results.give(m.resIdx); slots.give(m.slot); continue; }
+            nReads += (uint64_t)m.n; msDevice += res.msTotalDevice;
+            mapped.push(m);
+        }
+        mapped.close();
+    }
+    reader.join(); writer.join();
+    if (!failure.empty()) { fprintf(stderr, "\n%s\n", failure.c_str()); return 104; }
     if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device)\n", (unsigned long long)nReads, sec, msDevice / 1e3);
+    fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end\n",
+            (unsigned long long)nReads, sec, msDevice / 1e3, sec > 0 ? (double)nReads / sec / 1e6 : 0.0);
     staramd_destroy(ctx);
     sah_destroy(h);
     return 0;

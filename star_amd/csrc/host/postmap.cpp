@@ -163,8 +163,14 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
 }
 
 std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st) {
+    return processRange(b, r, 0, b.n, sam, sj, st);
+}
+
+// reads [lo, hi) of the batch: the reference's per-thread ReadAlign loop body (ReadAlign_oneRead.cpp:87-111); ranges of one
+// batch are independent (per-thread SAM buffer, junction table and Stats, merged by the caller in read order)
+std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st) const {
     std::vector<TrView> trMult;
-    for (uint32_t ir = 0; ir < b.n; ir++) {
+    for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];
         if (rr.status & STARAMD_ST_FATAL_SEEDS_PER_READ)
             return "EXITING because of FATAL error: too many pieces pere read\nSOLUTION: increase input parameter --seedPerReadNmax";

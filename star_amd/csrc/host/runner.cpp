@@ -7,6 +7,7 @@
 #include <cstring>
 #include <ctime>
 #include <memory>
+#include <thread>
 
 namespace staramd {
 
@@ -16,6 +17,7 @@ struct Runner {
     FastqReader reader;
     ReadBatch batch;
     staramd_batch batchView;
+    ReadBatch slots[3];                 // pipelined CLI: parse / map / post-map work on different slots
     std::unique_ptr<PostMap> post;
     OutSJ sj;
     Stats stats;
@@ -50,14 +52,33 @@ struct Runner {
         batchView = batch.view();
         return (int)batch.n;
     }
-    bool emit(const staramd_results *r) {
-        samBuf.clear();
-        error = post->process(batch, *r, samBuf, sj, stats);
-        if (!error.empty()) return false;
-        fwrite(samBuf.data(), 1, samBuf.size(), samOut);
+    // post-map of one batch on --runThreadN host threads: contiguous read ranges, per-thread SAM text / junctions / Stats
+    // (what the reference keeps per ReadAlignChunk), concatenated in read order
+    bool emitBatch(const ReadBatch &bt, const staramd_results *r) {
+        uint32_t T = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
+        T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per thread
+        if (T == 1) {
+            samBuf.clear();
+            error = post->process(bt, *r, samBuf, sj, stats);
+            if (!error.empty()) return false;
+            fwrite(samBuf.data(), 1, samBuf.size(), samOut);
+        } else {
+            std::vector<std::string> sams(T), errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
+            std::vector<std::thread> th;
+            uint32_t per = (bt.n + T - 1) / T;
+            for (uint32_t t = 0; t < T; t++)
+                th.emplace_back([&, t]() { uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per); errs[t] = post->processRange(bt, *r, lo, hi, sams[t], sjs[t], sts[t]); });
+            for (auto &x : th) x.join();
+            for (uint32_t t = 0; t < T; t++) {
+                if (!errs[t].empty()) { error = errs[t]; return false; }
+                fwrite(sams[t].data(), 1, sams[t].size(), samOut);
+                sj.mergeFrom(sjs[t]); stats.add(sts[t]);
+            }
+        }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
         return true;
     }
+    bool emit(const staramd_results *r) { return emitBatch(batch, r); }
     bool finish() {
         if (samOut) { fclose(samOut); samOut = nullptr; }
         error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab");
@@ -95,6 +116,19 @@ int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {
     return n;
 }
 int sah_emit(void *h, const staramd_results *res) { return ((Runner *)h)->emit(res) ? 0 : -1; }
+// pipelined variant (star_amd CLI): three batch slots so that FASTQ parsing of batch k+1, the device mapping of batch k and
+// the post-map / SAM writing of batch k-1 overlap.  parse and emit are each called from ONE thread, in batch order.
+int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
+    Runner *r = (Runner *)h;
+    std::string err;
+    bool ok = r->reader.nextBatch(r->slots[slot], r->P, maxReads, err);
+    if (!err.empty()) { r->error = err; return -1; }
+    if (!ok) return 0;
+    if (out) *out = r->slots[slot].view();
+    return (int)r->slots[slot].n;
+}
+int sah_emit_slot(void *h, int slot, const staramd_results *res) { Runner *r = (Runner *)h; return r->emitBatch(r->slots[slot], res) ? 0 : -1; }
+int sah_threads(void *h) { return ((Runner *)h)->P.runThreadN; }
 int sah_finish(void *h) { return ((Runner *)h)->finish() ? 0 : -1; }
 // ---- end-of-run exchange between ranks (one process per GPU) -------------------------------------
 // The reference merges per-thread junction tables and Stats inside one process (outputSJ.cpp:39-83 k-way merge,

@@ -15,3 +15,16 @@ def test_oracle_matches_reference(name, tmp_path, built):
     new = run_with_engine(info, str(tmp_path / name / "orc_"), lambda g, p: oracle_lib.Oracle(g, p))
     problems = compare_outputs(info["ref_prefix"], new)
     assert not problems, problems
+
+
+def test_threaded_postmap_matches_reference(tmp_path, built):
+    """--runThreadN > 1: the host post-map (multMapSelect ... SAM / SJ / Stats) runs on several threads over read ranges
+    of a batch; SAM text is concatenated in read order, so the OUTPUT FILE is identical to the single-thread one."""
+    info = dict(prepare("pe101", str(tmp_path)))
+    one = run_with_engine(info, str(tmp_path / "pe101" / "t1_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=3000)
+    info["extra"] = list(info["extra"]) + ["--runThreadN", "5"]
+    many = run_with_engine(info, str(tmp_path / "pe101" / "t5_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=3000)
+    assert not compare_outputs(info["ref_prefix"], many)
+    a = [l for l in open(one + "Aligned.out.sam", "rb") if not l.startswith(b"@")]
+    b = [l for l in open(many + "Aligned.out.sam", "rb") if not l.startswith(b"@")]
+    assert a == b                     # same records in the same (input) order
