@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("STARAMD_BENCH_CPU_SAMPLE", "400000")))
     ap.add_argument("--cpu-repeat", type=int, default=int(os.environ.get("STARAMD_BENCH_CPU_REPEAT", "4")), help="the CPU baseline maps the sample this many times over (longer run: STAR's threads reach steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cli-e2e", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/tmp/star_amd_bench"))
     return ap.parse_args()
 
@@ -115,6 +116,30 @@ def cpu_baseline(d, args, n_sample):
     return {"value": best[0], "unit": "Mreads/s", "cores": best[1], "kind": "reference",
             "sample": "%d pairs (the first pairs of the same workload, repeated to fill the run), STAR 2.7.11b; mapping time = wall(full) - wall(index load only); "
                       "threads tried (Mreads/s): %s; host has %d cores" % (n_sample, ", ".join("%d: %.4f" % (th, v) for v, th, _ in tried), ncpu)}
+
+
+def cli_end_to_end(d, args):
+    """The drop-in itself: star_amd/bin/star_amd (FASTQ parsing, engine, post-map, SAM/SJ/Log writing; pipelined, post-map on
+    host threads) on the same input the CPU baseline maps.  Wall time of its mapping loop, index load excluded -- the same
+    interval the reference reports between "Started mapping" and "Finished"."""
+    import re
+    rep = max(1, args.cpu_repeat)
+    fq = [os.path.join(d, "cpu_in_%d_%d.fq" % (rep, i + 1)) if rep > 1 else os.path.join(d, "reads_r0_%d.fq" % (i + 1)) for i in range(2)]
+    if not all(os.path.isfile(f) for f in fq):
+        return None
+    exe = os.path.join(ROOT, "star_amd", "bin", "star_amd")
+    if not os.path.isfile(exe):
+        return None
+    threads = min(os.cpu_count() or 1, 64)
+    cmd = [exe, "--runMode", "alignReads", "--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + \
+          ["--outFileNamePrefix", os.path.join(d, "cli_"), "--runThreadN", str(threads), "--gpuBatchReads", str(min(args.reads, 200000))]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    m = re.search(r"star_amd: (\d+) reads, ([0-9.]+) s wall in the mapping loop \(([0-9.]+) s on the device\)", p.stderr)
+    if p.returncode != 0 or not m:
+        return {"error": (p.stderr or "")[-400:]}
+    n, wall, dev = int(m.group(1)), float(m.group(2)), float(m.group(3))
+    return {"value": n / wall / 1e6, "unit": "Mreads/s", "reads": n, "wall_s": wall, "device_s": dev, "host_threads": threads,
+            "what": "star_amd CLI end to end: FASTQ in -> Aligned.out.sam + SJ.out.tab out (index load excluded)"}
 
 
 def main():
@@ -244,6 +269,8 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
         out["cpu_baseline"] = cpu_baseline(d, args, min(args.cpu_sample, n))
+        if not args.no_cli_e2e:
+            out["cli_end_to_end"] = cli_end_to_end(d, args)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

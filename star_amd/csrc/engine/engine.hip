@@ -169,7 +169,8 @@ static int allocWork(staramd_ctx *c) {
     u32 N = c->maxReads; int rc;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->nCU = prop.multiProcessorCount;
-    if ((rc = devAlloc(R, &c->dBases, c->maxBases + 64))) return rc;
+    // 64 bytes of padding either side: the seed search compares 8 bases per step and may read a few bytes past a read
+    { u8 *raw = nullptr; if ((rc = devAlloc(R, &raw, c->maxBases + 192))) return rc; if (hipMemset(raw, 4, c->maxBases + 192) != hipSuccess) { g_err = "hipMemset failed"; return STARAMD_ERR_DEVICE; } c->dBases = raw + 64; }
     if ((rc = devAlloc(R, &c->dReadOffset, (u64)N + 1))) return rc;
     if ((rc = devAlloc(R, &c->dMate1, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dMM, (u64)N))) return rc;

@@ -15,7 +15,23 @@
 
 struct SeedCnt { u64 nSAi, nSAprobe, nGcmp; };
 
-// SuffixArrayFuns.cpp:10-104 -- the four read/genome direction variants folded into one loop
+// 8 bytes starting at an arbitrary address, little endian, through aligned 8-byte loads (the arrays are padded)
+__device__ __forceinline__ u64 load8(const u8 *p) {
+    const u64 a = (u64)p; const u64 *q = (const u64 *)(a & ~7ull); const u32 sh = (u32)(a & 7ull) * 8u;
+    const u64 w0 = q[0];
+    if (sh == 0) return w0;
+    return (w0 >> sh) | (q[1] << (64u - sh));
+}
+// bytes p[0], p[-1], ..., p[-7] as a little-endian sequence (a scan that walks backwards)
+__device__ __forceinline__ u64 load8rev(const u8 *p) { return __builtin_bswap64(load8(p - 7)); }
+// complementSeqNumbers on 8 codes at once: c < 4 -> 3 - c (== 3 ^ c), others unchanged
+__device__ __forceinline__ u64 comp8(u64 x) {
+    const u64 ge4 = ((x + 0x7C7C7C7C7C7C7C7Cull) & 0x8080808080808080ull) >> 7;       // 1 in bytes >= 4 (codes <= 11: no carry between bytes)
+    return x ^ (0x0303030303030303ull & ~(ge4 * 0xFFull));
+}
+
+// SuffixArrayFuns.cpp:10-104 -- the four read/genome direction variants folded into one loop, 8 bases per step:
+// read and genome are both 1 byte/base, so a step is two 8-byte words, one XOR and a count-trailing-zeros
 __device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, u32 N, u32 L, u64 iSA, bool dirR, bool &compRes, SeedCnt &cn) {
     cn.nSAprobe++;
     u64 SAstr = packedGet(X.SA, iSA, X.saBits, X.saMask);
@@ -24,15 +40,20 @@ __device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, 
     bool useComp = dirR != dirG;
     const u8 *g = dirG ? X.G + SAstr + L : X.G + (X.nGenome - 1 - SAstr) - L;
     const u8 *s = dirR ? R + S + L : R + S - L;
-    int sgnG = dirG ? 1 : -1, sgnR = dirR ? 1 : -1;
-    u32 n = N - L;
-    for (u32 ii = 0; ii < n; ii++) {
-        u8 sc = s[sgnR * (int)ii]; if (useComp) sc = compBase(sc);
-        u8 gc = g[sgnG * (int)ii];
-        if (sc != gc) {
-            cn.nGcmp += ii + 1;
+    const u32 n = N - L;
+    for (u32 ii = 0; ii < n; ii += 8) {
+        u64 s8 = dirR ? load8(s + ii) : load8rev(s - ii);
+        const u64 g8 = dirG ? load8(g + ii) : load8rev(g - ii);
+        if (useComp) s8 = comp8(s8);
+        u64 d = s8 ^ g8;
+        const u32 rem = n - ii;
+        if (rem < 8) d &= (1ull << (rem * 8)) - 1ull;                   // bases behind the end of the piece do not count
+        if (d) {
+            const u32 k = (u32)__builtin_ctzll(d) >> 3;
+            const u8 sc = (u8)(s8 >> (k * 8)), gc = (u8)(g8 >> (k * 8));
+            cn.nGcmp += ii + k + 1;
             compRes = dirG ? (sc > gc) : !(sc > gc || gc > 3);
-            return ii + L;
+            return ii + k + L;
         }
     }
     cn.nGcmp += n;

@@ -40,17 +40,17 @@ struct WS {
 
 __device__ __forceinline__ void tabFence() { __threadfence_block(); }
 
+// max of (key << 32 | payload) over the wave, keys distinct where non-zero: DPP max of the keys, then the payload of the
+// lane that holds the maximum
 __device__ __forceinline__ u64 waveMax64(u64 v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        u32 lo = (u32)__shfl_xor((int)(u32)v, o, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), o, 64);
-        u64 w = ((u64)hi << 32) | lo; v = w > v ? w : v;
-    }
-    return v;
+    u32 key = (u32)(v >> 32);
+    u32 kmax = waveMaxU32(key);
+    if (kmax == 0) return 0;
+    u64 m = __ballot(key == kmax);
+    return ((u64)kmax << 32) | laneGet32((u32)v, firstLane(m));
 }
-__device__ __forceinline__ u32 waveMin32(u32 v) {
-    for (int o = 32; o > 0; o >>= 1) { u32 w = (u32)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
-    return v;
-}
+__device__ __forceinline__ u64 laneGet64(u64 v, u32 l) { return ((u64)laneGet32((u32)(v >> 32), l) << 32) | laneGet32((u32)v, l); }
+__device__ __forceinline__ u32 waveMin32(u32 v) { return ~waveMaxU32(~v); }
 
 // ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; all arguments wave-uniform; returns 1 on TOO_MANY_WINDOWS / overflow
 __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS &s, u64 a1, u32 aStr, u32 lane) {
@@ -121,7 +121,7 @@ __device__ static void assignAlignToWindow(const DevIndex &X, WS &s, u32 iW, u64
         u64 m = __ballot(ov);
         if (m) {
             u32 iA = (u32)__ffsll((long long)m) - 1;
-            u32 Lold = bcast32(e.L, iA);
+            u32 Lold = laneGet32(e.L, iA);
             if (aLength > Lold) {
                 u64 m2 = __ballot(have && lane != iA && aRstart < e.rStart);
                 u32 iA0 = m2 ? (u32)__ffsll((long long)m2) - 1 : n;
@@ -241,11 +241,11 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                 }
                 nSAenum += cnt;
                 for (u32 l = 0; l < cnt; l++) {
-                    u32 k = bcast32(kind, l);
+                    u32 k = laneGet32(kind, l);
                     if (k == 0) continue;
-                    u64 x1 = bcast64(a1, l); u32 xs = bcast32(aStr, l);
+                    u64 x1 = laneGet64(a1, l); u32 xs = laneGet32(aStr, l);
                     if (createExtendWindowsWithAlign(X, s, x1, xs, lane)) { stop = true; break; }
-                    if (k == 2) { u64 x2 = bcast64(a1A, l); if (createExtendWindowsWithAlign(X, s, x2, xs, lane)) { stop = true; break; } }
+                    if (k == 2) { u64 x2 = laneGet64(a1A, l); if (createExtendWindowsWithAlign(X, s, x2, xs, lane)) { stop = true; break; } }
                 }
             }
         }
@@ -297,12 +297,12 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                 u64 hm = __ballot(wD != NOWIN || wA != NOWIN);
                 while (hm) {
                     u32 l = (u32)__ffsll((long long)hm) - 1; hm &= hm - 1;
-                    u32 xwD = bcast32(wD, l), xwA = bcast32(wA, l);
-                    u32 xsplit = bcast32(split ? 1u : 0u, l);
-                    u32 xr = bcast32(aRstart, l), xlD = bcast32(lD, l);
-                    i32 xsj = xsplit ? (i32)bcast32(isj, l) : -1;
-                    if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, bcast64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
-                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, bcast64(a1A, l), bcast32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
+                    u32 xwD = laneGet32(wD, l), xwA = laneGet32(wA, l);
+                    u32 xsplit = laneGet32(split ? 1u : 0u, l);
+                    u32 xr = laneGet32(aRstart, l), xlD = laneGet32(lD, l);
+                    i32 xsj = xsplit ? (i32)laneGet32(isj, l) : -1;
+                    if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
+                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
                     if (s.tooMany || s.overflow) break;
                 }
             }
