@@ -139,8 +139,18 @@ __device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R,
         u32 pieceStart; u32 pieceLength = pieceLengthIn - iDist;
         u32 Lmax = min(X.saiNbases, pieceLength);
         u64 ind1 = 0;
-        if (dirR) { pieceStart = pieceStartIn + iDist; for (u32 ii = 0; ii < Lmax; ii++) { ind1 <<= 2; ind1 += (u64)R[pieceStart + ii]; } }
-        else { pieceStart = pieceStartIn - iDist; for (u32 ii = 0; ii < Lmax; ii++) { ind1 <<= 2; ind1 += 3 - (u64)R[pieceStart - ii]; } }
+        // L-mer prefix (ReadAlign_maxMappableLength2strands.cpp:23-37): 2 bits per base, first base most significant;
+        // the bases of a piece are all 0..3, so 8 of them are packed from one 8-byte word with shifts and masks
+        if (dirR) pieceStart = pieceStartIn + iDist; else pieceStart = pieceStartIn - iDist;
+        for (u32 ii = 0; ii < Lmax; ii += 8) {
+            u64 x = dirR ? load8(R + pieceStart + ii) : (load8rev(R + pieceStart - ii) ^ 0x0303030303030303ull);   // 3 - base == 3 ^ base
+            u64 z = __builtin_bswap64(x & 0x0303030303030303ull); // first base in the top byte (bytes behind the prefix may hold N / spacer codes)
+            z = (z | (z >> 6)) & 0x000F000F000F000Full;
+            z = (z | (z >> 12)) & 0x000000FF000000FFull;
+            z = (z | (z >> 24)) & 0xFFFFull;                    // 8 bases -> 16 bits, first base most significant
+            u32 nb = min(8u, Lmax - ii);
+            ind1 = (ind1 << (2 * nb)) | (z >> (2 * (8 - nb)));
+        }
         u32 Lind = Lmax; u64 iSA1 = 0, iSA2;
         while (Lind > 0) {
             iSA1 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1, X.saiBits, X.saiMask); cn.nSAi++;
