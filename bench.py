@@ -216,7 +216,7 @@ def main():
     prof = None
     if os.environ.get("STARAMD_ENGINE_LIB") == "profile" and len(cnt) >= 37:
         pn = ["walk", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime",
-              "junction:left_scan", "junction:right_scan", "junction:repeats", "junction:rescore", "junction:sjdb_find",
+              "windows:passA", "windows:flanks", "windows:passB_enumerate+owner", "windows:passB_assign", "windows:emission",
               "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
         prof = dict(zip(pn, cnt[21:37]))
     eng.close(); run.close()

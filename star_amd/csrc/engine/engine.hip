@@ -30,7 +30,7 @@ static inline u32 stitchStateBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
 }
 static inline u64 winWaveBytesH(u32 capW, u32 capBlocks, u32 big) {
     u64 b = (u64)capBlocks * WA_MAX * sizeof(DWA);
-    if (big) b += (u64)capW * 8 * sizeof(u32);
+    if (big) b += (u64)capW * 8 * sizeof(u32) + 4096 / 8;
     return (b + 255) & ~255ull;
 }
 
@@ -219,7 +219,7 @@ static int allocWork(staramd_ctx *c) {
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
     c->capW = envU32("STARAMD_CAP_WINDOWS", 192); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
     int winPerCU = 3;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * c->capW * 8 * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * (c->capW * 8 + 128) * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
     c->winBlocks = (u32)c->nCU * envU32("STARAMD_WIN_BLOCKS_PER_CU", (u32)winPerCU);
     c->winBlocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (N + 3) / 4));
     if ((rc = devAlloc(R, &c->scrWin, (u64)c->winBlocks * 4 * winWaveBytesH(c->capW, c->capBlocks, 0)))) return rc;
@@ -326,7 +326,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[1], s));
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
-        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * c->capW * 8 * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst);
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst);
         hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u, c->lightEst);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);

@@ -234,7 +234,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                         }
                     }
                 }
-                PROF_MARK(c, 8);
+                
                 // right scan (:111-156): best junction position by votes of the bases + motif penalty
                 int maxScore2 = -999999; int jPen = 0;
                 const bool isIntron = Del >= P.alignIntronMin;
@@ -272,7 +272,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     }
                     c.nGstitch += (u32)(jEnd - jStart) * (isIntron ? 5u : 2u);
                 }
-                PROF_MARK(c, 9);
+                
                 // repeat length left / right of the junction (:159-166)
                 u32 jjL = 0, jjR = 0;
                 for (u32 base = 0;; base += NLANE) {
@@ -290,7 +290,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     if (fm) { jjR = base + firstLane(fm); break; }
                 }
                 c.nGstitch += 2u * (jjL + jjR + 2u);
-                PROF_MARK(c, 10);
+                
                 if (jCan <= 0) {                                     // flush a non-canonical junction left (:168-173)
                     jR -= (int)jjL;
                     if (eAL + jR < 1) return -1000005;
@@ -313,10 +313,10 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     }
                     c.nGstitch += (u32)(i1 - i0 + 1);
                 }
-                PROF_MARK(c, 11);
+                
                 int sjdbInd = -1;
                 if (X.sjdbN > 0) sjdbInd = coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN);
-                PROF_MARK(c, 12);
+                
                 if (sjdbInd < 0) {
                     if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }

@@ -27,13 +27,21 @@
 #include "dev.h"
 
 #define NOWIN 0xFFFFFFFFu
+#ifdef STARAMD_PROFILE
+#define WPROF_T0() u64 wprof_t0_ = __builtin_readcyclecounter()
+#define WPROF_MARK(k) { u64 t1_ = __builtin_readcyclecounter(); wprof[k] += t1_ - wprof_t0_; wprof_t0_ = t1_; }
+#else
+#define WPROF_T0()
+#define WPROF_MARK(k)
+#endif
 
 struct WTab {                       // per-wave window table (structure of arrays; LDS or global)
     u32 *coreS, *coreE, *extS, *extE, *meta, *blk, *lrec, *nwa;
 };
 // meta = chr << 2 | str << 1 | alive
+#define WBITS 4096u                 // per-read hash bitmap of the bins covered by windows (quick reject of loci outside every window)
 struct WS {
-    WTab t; DWA *arena;
+    WTab t; DWA *arena; u32 *bitmap;
     u32 nW, capW, nBlocks, capBlocks, Lread;
     bool overflow, tooMany, winLimit;
 };
@@ -160,9 +168,12 @@ __device__ static void assignAlignToWindow(const DevIndex &X, WS &s, u32 iW, u64
 
 // sjAlignSplit.cpp:3-15
 __device__ __forceinline__ bool sjAlignSplit(const DevIndex &X, u64 a1, u32 aLength, u64 &a1D, u32 &aLengthD, u64 &a1A, u32 &aLengthA, u32 &isj) {
-    u64 sj1 = (a1 - X.sjGstart) % X.sjdbLength;
+    const u64 off = a1 - X.sjGstart;
+    u64 q, sj1;
+    if (off < 0x100000000ull) { const u32 q32 = (u32)off / X.sjdbLength; q = q32; sj1 = (u32)off - q32 * X.sjdbLength; }   // 32-bit divide: the inserted region is small
+    else { q = off / X.sjdbLength; sj1 = off - q * X.sjdbLength; }
     if (sj1 < X.sjdbOverhang && sj1 + aLength > X.sjdbOverhang) {
-        isj = (u32)((a1 - X.sjGstart) / X.sjdbLength);
+        isj = (u32)q;
         aLengthD = (u32)(X.sjdbOverhang - sj1); aLengthA = aLength - aLengthD;
         a1D = X.sjDstart[isj] + sj1; a1A = X.sjAstart[isj];
         return true;
@@ -170,22 +181,29 @@ __device__ __forceinline__ bool sjAlignSplit(const DevIndex &X, u64 a1, u32 aLen
     return false;
 }
 
-// pass-B owner of a bin: last flank writer wins, else the core owner (ReadAlign_stitchPieces.cpp:96-118 write order)
-__device__ __forceinline__ u32 ownerB(const WS &s, u32 str, u32 bin) {
+__device__ __forceinline__ u32 binHash(u32 str, u32 bin) { return (bin * 2u + str) & (WBITS - 1u); }
+
+// pass-B owner of a bin, wave-parallel (lane j tests window j): last flank writer wins, else the core owner
+// (ReadAlign_stitchPieces.cpp:96-118 write order)
+__device__ static u32 ownerWave(const WS &s, u32 str, u32 bin, u32 lane) {
     u32 core = NOWIN, flank = NOWIN;
-    for (u32 j = 0; j < s.nW; j++) {
-        u32 m = s.t.meta[j];
-        if (!(m & 1u) || ((m >> 1) & 1u) != str) continue;
-        if (bin < s.t.extS[j] || bin > s.t.extE[j]) continue;
-        if (bin >= s.t.coreS[j] && bin <= s.t.coreE[j]) core = j; else flank = j;
+    for (u32 j0 = 0; j0 < s.nW; j0 += 64) {
+        u32 j = j0 + lane; bool inExt = false, inCore = false;
+        if (j < s.nW) {
+            u32 m = s.t.meta[j];
+            if ((m & 1u) && ((m >> 1) & 1u) == str && bin >= s.t.extS[j] && bin <= s.t.extE[j]) { inExt = true; inCore = bin >= s.t.coreS[j] && bin <= s.t.coreE[j]; }
+        }
+        u64 mc = __ballot(inExt && inCore), mf = __ballot(inExt && !inCore);
+        if (mc) core = j0 + 63u - (u32)__clzll((long long)mc);
+        if (mf) flank = j0 + 63u - (u32)__clzll((long long)mf);
     }
     return flank != NOWIN ? flank : core;
 }
 
-// per-wave work space in global memory: [table rows (big pass only)] [seed-list blocks]
+// per-wave work space in global memory: [table rows + bitmap (big pass only)] [seed-list blocks]
 __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
     u64 b = (u64)capBlocks * WA_MAX * sizeof(DWA);
-    if (big) b += (u64)capW * 8 * sizeof(u32);
+    if (big) b += (u64)capW * 8 * sizeof(u32) + WBITS / 8;
     return (b + 255) & ~255ull;
 }
 
@@ -199,11 +217,15 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
     u32 wave = blockIdx.x * wavesPerBlock + waveInBlock;
     WS s;
     u8 *mine = scratch + (u64)wave * winWaveBytes(capW, capBlocks, big);
-    u32 *tab = big ? (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA)) : (ldsTab + (u64)waveInBlock * capW * 8);
+    u32 *tab = big ? (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA)) : (ldsTab + (u64)waveInBlock * (capW * 8 + WBITS / 32));
+    s.bitmap = tab + capW * 8;
     s.t.coreS = tab; s.t.coreE = tab + capW; s.t.extS = tab + 2 * capW; s.t.extE = tab + 3 * capW;
     s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + 6 * capW; s.t.nwa = tab + 7 * capW;
     s.arena = (DWA *)mine; s.capW = capW; s.capBlocks = capBlocks;
     u64 nSAenum = 0, nWindows = 0, nWAtot = 0; u32 nOvf = 0;
+#ifdef STARAMD_PROFILE
+    u64 wprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const u32 nItems = big ? B.cursors[CUR_OVF_WIN] : B.nReads;
     const u32 ticketSlot = big ? CUR_TICKET_WIN2 : CUR_TICKET_WIN;
     for (;;) {
@@ -217,6 +239,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
         const DSeed *PC = B.seedPool + rd.seedOffset;
         s.nW = 0; s.nBlocks = 0; s.tooMany = false; s.winLimit = false; s.overflow = false;
         s.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
+        WPROF_T0();
         // ---- pass A: anchors (ReadAlign_stitchPieces.cpp:41-93)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow; iP++) {
             const DSeed sd = PC[iP];
@@ -249,6 +272,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                 }
             }
         }
+        WPROF_MARK(0);
         // ---- flanks (:96-118): one lane per window
         if (!s.overflow) {
             for (u32 j = lane; j < s.nW; j += 64) {
@@ -263,9 +287,17 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                 for (u32 ii = 0; ii < P.winFlankNbins && (u64)wb + 1 < P.winBinN && X.chrBin[(wb + 1) >> P.winBinChrNbits] == chr; ii++) wb++;
                 s.t.extE[j] = wb;
             }
+            for (u32 k = lane; k < WBITS / 32; k += 64) s.bitmap[k] = 0;
+            tabFence();
+            for (u32 j = lane; j < s.nW; j += 64) {
+                u32 m = s.t.meta[j];
+                if (!(m & 1u)) continue;
+                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) { u32 hsh = binHash((m >> 1) & 1u, b); atomicOr(&s.bitmap[hsh >> 5], 1u << (hsh & 31u)); }
+            }
             tabFence();
         }
         nWindows += s.nW;
+        WPROF_MARK(1);
         // ---- pass B: all seeds (:129-185)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooMany; iP++) {
             const DSeed sd = PC[iP];
@@ -274,6 +306,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
             for (u32 base = 0; base < aNrep && !s.overflow && !s.tooMany; base += 64) {
                 u32 cnt = min(64u, aNrep - base);
                 u64 a1 = 0, a1A = 0; u32 aRstart = 0, lD = 0, lA = 0, isj = 0; u32 wD = NOWIN, wA = NOWIN; bool split = false;
+                u32 binD = 0, binA = 0, lStr = 0; bool candD = false, candA = false;
                 if (lane < cnt) {
                     a1 = packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
                     u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
@@ -285,15 +318,22 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                         u64 a1D;
                         if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
                             split = true; a1 = a1D;
-                            wD = ownerB(s, aStr, (u32)(a1D >> P.winBinNbits));
-                            wA = ownerB(s, aStr, (u32)(a1A >> P.winBinNbits));
+                            binD = (u32)(a1D >> P.winBinNbits); binA = (u32)(a1A >> P.winBinNbits); lStr = aStr;
+                            u32 hD = binHash(aStr, binD), hA = binHash(aStr, binA);
+                            candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u; candA = (s.bitmap[hA >> 5] >> (hA & 31u)) & 1u;
                         }
                     } else {
                         lD = aLength;
-                        wD = ownerB(s, aStr, (u32)(a1 >> P.winBinNbits));
+                        binD = (u32)(a1 >> P.winBinNbits); lStr = aStr;
+                        u32 hD = binHash(aStr, binD);
+                        candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u;
                     }
                 }
+                // loci that pass the bitmap are looked up one by one, all lanes testing one window each
+                for (u64 cm = __ballot(candD); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binD, l), lane); if (lane == l) wD = w; }
+                for (u64 cm = __ballot(candA); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binA, l), lane); if (lane == l) wA = w; }
                 nSAenum += cnt;
+                WPROF_MARK(2);
                 u64 hm = __ballot(wD != NOWIN || wA != NOWIN);
                 while (hm) {
                     u32 l = (u32)__ffsll((long long)hm) - 1; hm &= hm - 1;
@@ -305,6 +345,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                     if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
                     if (s.tooMany || s.overflow) break;
                 }
+                WPROF_MARK(3);
             }
         }
         if (s.winLimit) rd.status |= STARAMD_ST_WINDOWS_LIMIT;
@@ -347,8 +388,12 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
             nWAtot += nWA;
         }
         if (lane == 0) B.reads[ir] = rd;
+        WPROF_MARK(4);
     }
     if (lane == 0) {
+#ifdef STARAMD_PROFILE
+        if (!big) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof8 + k], (unsigned long long)wprof[k]);
+#endif
         atomicAdd((unsigned long long *)&B.counters[DC_nSAenum], (unsigned long long)nSAenum);
         atomicAdd((unsigned long long *)&B.counters[DC_nWindows], (unsigned long long)nWindows);
         atomicAdd((unsigned long long *)&B.counters[DC_nWA], (unsigned long long)nWAtot);
