@@ -36,6 +36,11 @@ class Oracle:
         self.L = L
         self.h = L.oracle_create(genome_p, params_p)
 
+    def update_index(self, genome_p, params_p):
+        """the index was rewritten on the host (junction insertion): start over on the new arrays"""
+        self.L.oracle_destroy(self.h)
+        self.h = self.L.oracle_create(genome_p, params_p)
+
     def map_batch(self, batch, bufs):
         rc = self.L.oracle_map_batch(self.h, C.byref(batch), C.byref(bufs.res))
         if rc != 0:

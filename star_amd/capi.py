@@ -145,6 +145,9 @@ def host_lib():
         L.sah_finish.restype = C.c_int; L.sah_finish.argtypes = [C.c_void_p]
         L.sah_error.restype = C.c_char_p; L.sah_error.argtypes = [C.c_void_p]
         L.sah_destroy.restype = None; L.sah_destroy.argtypes = [C.c_void_p]
+        L.sah_in_pass1.restype = C.c_int; L.sah_in_pass1.argtypes = [C.c_void_p]
+        L.sah_pass1_end.restype = C.c_int; L.sah_pass1_end.argtypes = [C.c_void_p]
+        L.sah_insert_log.restype = C.c_char_p; L.sah_insert_log.argtypes = [C.c_void_p]
         _host = L
     return _host
 
@@ -198,6 +201,16 @@ class HostRun:
         if self.L.sah_emit(self.h, C.byref(results)) != 0:
             raise RuntimeError(self.L.sah_error(self.h).decode())
 
+    def in_pass1(self):
+        """True while the 1st pass of --twopassMode Basic is running (map every batch, then call pass1_end())."""
+        return bool(self.L.sah_in_pass1(self.h))
+
+    def pass1_end(self):
+        """Write _STARpass1/, insert the junctions into the host index, rewind the reads; the engine must then be
+        given the new index (Engine.update_index(run.genome, run.params))."""
+        if self.L.sah_pass1_end(self.h) != 0:
+            raise RuntimeError(self.L.sah_error(self.h).decode())
+
     def finish(self):
         if self.L.sah_finish(self.h) != 0:
             raise RuntimeError(self.L.sah_error(self.h).decode())
@@ -219,6 +232,11 @@ class Engine:
         rc = L.staramd_create(C.byref(self.ctx), device, genome_p, params_p, max_reads, max_bases)
         if rc != 0:
             raise RuntimeError("staramd_create failed (%d): %s" % (rc, L.staramd_last_error().decode()))
+
+    def update_index(self, genome_p, params_p):
+        rc = self.L.staramd_update_index(self.ctx, genome_p, params_p)
+        if rc != 0:
+            raise RuntimeError("staramd_update_index failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
 
     def map_batch(self, batch, bufs):
         rc = self.L.staramd_map_batch(self.ctx, C.byref(batch), C.byref(bufs.res))

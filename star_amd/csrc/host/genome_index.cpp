@@ -100,6 +100,7 @@ std::string GenomeIndex::load(const std::string &genomeDir) {
         chrBin[ii] = (uint32_t)(ichr - 1);
     }
     view.chrBin = chrBin.data(); view.chrBinN = chrBinN;
+    { struct stat st1; sjdbInfoExists = stat((dir + "/sjdbInfo.txt").c_str(), &st1) == 0; }
     // --- loadSJDB (:471-521)
     view.sjdbOverhang = sjdbOverhang;
     view.sjdbLength = sjdbOverhang == 0 ? 0 : sjdbOverhang * 2 + 1;

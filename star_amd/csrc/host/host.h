@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <cstdio>
+#include <istream>
 #include "../../../include/star_amd.h"
 
 namespace staramd {
@@ -23,8 +24,10 @@ struct GenomeIndex {
     std::vector<std::string> chrName;
     staramd_genome view;      // pointers into the vectors above
     double loadSeconds = 0;
+    bool sjdbInfoExists = false;
     // returns empty string on success, else the error text
     std::string load(const std::string &genomeDir);
+    void refreshView();       // re-point `view` at the vectors after they were rewritten (sjdb insertion)
 };
 
 // ---- Parameters: defaults of source/parametersDefault + command-line subset ----
@@ -60,6 +63,15 @@ struct RunParams {
     std::string readNameSeparator = "/";
     uint64_t gpuBatchReads = 65536;      // reads per device batch (ours; --gpuBatchReads)
     int gpuDevice = 0;
+    // 2-pass mapping and junction insertion at the mapping stage (Parameters.cpp:779-826, 1000-1034)
+    bool twopass = false;                // --twopassMode Basic
+    int64_t twopass1readsN = -1; bool twopass1Set = false;
+    std::vector<std::string> sjdbFileChrStartEnd;
+    uint32_t sjdbOverhang = 100; bool sjdbOverhangSet = false;
+    bool sjdbInsertSaveAll = false;      // --sjdbInsertSave Basic | All
+    uint64_t limitSjdbInsertNsj = 1000000;
+    std::string sjdbInsertOutDir, twopassDir;
+    bool sjdbInsertYes() const { return twopass || !sjdbFileChrStartEnd.empty(); }
 
     RunParams();
     // STAR-style "--name v1 v2 ..." ; returns error text or ""
@@ -86,6 +98,7 @@ class FastqReader {
 public:
     ~FastqReader();
     std::string open(const std::vector<std::string> &paths);
+    std::string reopen();                 // rewind to the first read (Parameters::closeReadsFiles/openReadsFiles between the two passes)
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
     // + the PE concatenation of ReadAlign::oneRead (ReadAlign_oneRead.cpp:35-78)
     bool nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err);
@@ -96,6 +109,13 @@ private:
     std::vector<char> lineBuf;
     bool getLine(int im, std::string &out);
 };
+
+// ---- junction insertion into the loaded index (sjdb_insert.cpp) ----
+struct SjdbLoci { std::vector<std::string> chr; std::vector<uint64_t> start, end; std::vector<char> str; std::vector<uint8_t> priority; };
+void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci);            // sjdbLoadFromStream.cpp:2-28
+// sjdbInsertJunctions.cpp:11-102: rewrites gi (G, SA, SAi, junction table) and P.dev.winBinN; returns error text or ""
+std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, bool pass2, const std::string &pass1sjFile, std::string &log);
+std::string makeRunDir(const std::string &d);
 
 // ---- Stats (source/Stats.{h,cpp}) ----
 struct Stats {
@@ -126,6 +146,7 @@ public:
     std::string process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st);
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st) const;
     std::string samHeader() const;                   // samHeaders.cpp:27-106
+    bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:
     const RunParams &P;
     const GenomeIndex &gi;

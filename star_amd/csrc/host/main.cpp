@@ -28,6 +28,8 @@ int sah_device(void *h);
 int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
 int sah_emit_slot(void *h, int slot, const staramd_results *res);
 int sah_finish(void *h);
+int sah_in_pass1(void *h);
+int sah_pass1_end(void *h);
 const char *sah_error(void *h);
 void sah_destroy(void *h);
 }
@@ -62,32 +64,32 @@ int main(int argc, char **argv) {
         memset(&r.res, 0, sizeof(r.res));
         r.res.reads = r.reads.data(); r.res.tr = r.tr.data(); r.res.trCapacity = r.tr.size(); r.res.ex = r.ex.data(); r.res.exCapacity = r.ex.size();
     }
-    Queue parsed, mapped; Tokens slots, results;
-    for (int i = 0; i < 3; i++) slots.give(i);
-    for (int i = 0; i < 2; i++) results.give(i);
     std::string failure; std::mutex failM;
     auto fail = [&](const std::string &s) { std::lock_guard<std::mutex> l(failM); if (failure.empty()) failure = s; };
-    auto t0 = std::chrono::steady_clock::now();
-
-    std::thread reader([&] {
-        for (;;) {
-            Msg m; m.slot = slots.take(); m.resIdx = -1;
-            m.n = sah_parse_slot(h, m.slot, batchReads, &m.b);
-            if (m.n < 0) { fail(sah_error(h)); break; }
-            if (m.n == 0) break;
-            parsed.push(m);
-        }
-        parsed.close();
-    });
-    std::thread writer([&] {
-        Msg m;
-        while (mapped.pop(m)) {
-            if (failure.empty() && sah_emit_slot(h, m.slot, &rb[m.resIdx].res)) fail(sah_error(h));
-            results.give(m.resIdx); slots.give(m.slot);
-        }
-    });
     uint64_t nReads = 0; double msDevice = 0;
-    {
+    auto t0 = std::chrono::steady_clock::now();
+    // one pass over the reads through the three-stage pipeline
+    auto mapAllBatches = [&]() {
+        Queue parsed, mapped; Tokens slots, results;
+        for (int i = 0; i < 3; i++) slots.give(i);
+        for (int i = 0; i < 2; i++) results.give(i);
+        std::thread reader([&] {
+            for (;;) {
+                Msg m; m.slot = slots.take(); m.resIdx = -1;
+                m.n = sah_parse_slot(h, m.slot, batchReads, &m.b);
+                if (m.n < 0) { fail(sah_error(h)); break; }
+                if (m.n == 0) break;
+                parsed.push(m);
+            }
+            parsed.close();
+        });
+        std::thread writer([&] {
+            Msg m;
+            while (mapped.pop(m)) {
+                if (failure.empty() && sah_emit_slot(h, m.slot, &rb[m.resIdx].res)) fail(sah_error(h));
+                results.give(m.resIdx); slots.give(m.slot);
+            }
+        });
         Msg m;
         while (parsed.pop(m)) {
             if (!failure.empty()) { slots.give(m.slot); continue; }
@@ -105,8 +107,17 @@ int main(int argc, char **argv) {
             mapped.push(m);
         }
         mapped.close();
+        reader.join(); writer.join();
+    };
+    if (sah_in_pass1(h)) {
+        // --twopassMode Basic (twoPassRunPass1.cpp:9-96): 1st pass without SAM, the junctions it finds are inserted into the
+        // index on the host (sjdb_insert.cpp), the HBM copy is replaced, then the reads are mapped again
+        mapAllBatches();
+        if (failure.empty() && sah_pass1_end(h)) fail(sah_error(h));
+        if (failure.empty() && staramd_update_index(ctx, sah_genome(h), sah_params(h))) fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + staramd_last_error());
+        if (failure.empty()) { double s1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); fprintf(stderr, "star_amd: 1st pass + junction insertion + index re-upload: %.3f s (%llu reads)\n", s1, (unsigned long long)nReads); }
     }
-    reader.join(); writer.join();
+    if (failure.empty()) mapAllBatches();
     if (!failure.empty()) { fprintf(stderr, "\n%s\n", failure.c_str()); return 104; }
     if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

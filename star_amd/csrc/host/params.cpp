@@ -68,6 +68,13 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "runThreadN") runThreadN = (int)I(k, v);
         else if (k == "readMapNumber") readMapNumber = I(k, v);
         else if (k == "gpuBatchReads") gpuBatchReads = U(k, v);
+        else if (k == "twopassMode") { const std::string &m = one(k, v); if (m == "Basic") twopass = true; else if (m != "None") err = "EXITING because of fatal PARAMETERS error: unrecognized value of --twopassMode=" + m + "\nSOLUTION: for the 2-pass mode, use allowed values --twopassMode: Basic"; }
+        else if (k == "twopass1readsN") { twopass1readsN = I(k, v); twopass1Set = true; }
+        else if (k == "sjdbFileChrStartEnd") { if (!(v.size() == 1 && v[0] == "-")) sjdbFileChrStartEnd = v; }
+        else if (k == "sjdbOverhang") { sjdbOverhang = (uint32_t)U(k, v); sjdbOverhangSet = true; }
+        else if (k == "sjdbInsertSave") { const std::string &m = one(k, v); if (m == "All") sjdbInsertSaveAll = true; else if (m != "Basic") err = "EXITING: unsupported --sjdbInsertSave " + m; }
+        else if (k == "limitSjdbInsertNsj") limitSjdbInsertNsj = U(k, v);
+        else if (k == "sjdbGTFfile") { if (one(k, v) != "-") err = "EXITING: --sjdbGTFfile at the mapping stage is not implemented; convert the annotation with reference STAR (genomeGenerate) or pass the junctions with --sjdbFileChrStartEnd"; }
         else if (k == "gpuDevice") gpuDevice = (int)I(k, v);
         else if (k == "genomeLoad") { if (one(k, v) != "NoSharedMemory") err = "EXITING: --genomeLoad: the index lives in HBM; only NoSharedMemory is accepted"; }
         else if (k == "outSAMtype") { if (v.empty() || v[0] != "SAM") err = "EXITING: only --outSAMtype SAM is implemented (BAM: SURVEY.md 8f next #3)"; }
@@ -159,6 +166,10 @@ std::string RunParams::parse(int argc, char **argv) {
         if (hasXS) dev.outSAMstrandFieldIntronMotif = 1;
         else if (dev.outSAMstrandFieldIntronMotif) outSAMattrOrder.push_back("XS");
     }
+    // Parameters.cpp:779-826
+    if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
+    if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
+    if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";
     dev.readNmates = (uint32_t)readFilesIn.size();

@@ -242,12 +242,12 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                 }
             }
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
-            for (uint64_t it = 0; it < nTr; it++) samMapped(sam, P, gi, rc, trMult[it], nTr, it);
+            if (!samOff) for (uint64_t it = 0; it < nTr; it++) samMapped(sam, P, gi, rc, trMult[it], nTr, it);
             const staramd_exon *exB = r.ex + trBest->exonOffset;
             mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
             if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
-            if (unmapType == 4 && P.outSAMunmappedWithin) samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
-        } else if (P.outSAMunmappedWithin) {
+            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff) samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
+        } else if (P.outSAMunmappedWithin && !samOff) {
             staramd_transcript t0; memset(&t0, 0, sizeof(t0));
             samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
         }

@@ -35,6 +35,12 @@ std::string FastqReader::open(const std::vector<std::string> &paths) {
     return "";
 }
 
+std::string FastqReader::reopen() {
+    for (int i = 0; i < nMates; i++) if (fseek(f[i], 0, SEEK_SET) != 0) return "EXITING because of fatal input ERROR: could not rewind the read file";
+    readsSoFar = 0;
+    return "";
+}
+
 bool FastqReader::getLine(int im, std::string &out) {
     out.clear();
     for (;;) {

@@ -5,6 +5,7 @@
 // in tests only, by the CPU oracle.
 #include "host.h"
 #include <cstring>
+#include <algorithm>
 #include <ctime>
 #include <memory>
 #include <thread>
@@ -24,6 +25,10 @@ struct Runner {
     FILE *samOut = nullptr;
     std::string samBuf;
     std::string error;
+    SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
+    std::string insertLog;
+    bool pass1 = false;
+    int64_t readMapNumberUser = -1;
 
     bool init(int argc, char **argv) {
         time(&stats.timeStart);
@@ -31,10 +36,33 @@ struct Runner {
         if (!error.empty()) return false;
         error = gi.load(P.genomeDir);
         if (!error.empty()) return false;
+        if (P.sjdbInsertYes()) {
+            // sjdbOverhang of the run (Genome_genomeLoad.cpp:113-125) and the run-time directories (Parameters.cpp:817-824,1019-1034)
+            uint32_t gov = gi.view.sjdbOverhang;
+            if (!P.sjdbOverhangSet && gov > 0) P.sjdbOverhang = gov;
+            else if (gi.sjdbInfoExists && P.sjdbOverhangSet && P.sjdbOverhang != gov) {
+                error = "EXITING because of fatal PARAMETERS error: present --sjdbOverhang=" + std::to_string(P.sjdbOverhang) + " is not equal to the value at the genome generation step =" + std::to_string(gov) + "\nSOLUTION: \n";
+                return false;
+            }
+            if (P.sjdbOverhang == 0 || P.sjdbOverhang > 500) { error = "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 (or > 500) while junctions are inserted on the fly"; return false; }
+            gi.view.sjdbOverhang = P.sjdbOverhang; gi.view.sjdbLength = 2 * P.sjdbOverhang + 1;
+            P.sjdbInsertOutDir = P.outFileNamePrefix + "_STARgenome/";
+            error = makeRunDir(P.sjdbInsertOutDir);
+            if (!error.empty()) return false;
+            if (P.twopass) { P.twopassDir = P.outFileNamePrefix + "_STARpass1/"; error = makeRunDir(P.twopassDir); if (!error.empty()) return false; }
+        }
         P.finalize(gi);
+        if (!P.sjdbFileChrStartEnd.empty()) {                       // STAR.cpp:147-150: insertion before the (1st) mapping pass
+            error = sjdbInsertJunctions(P, gi, sjdbLoci, false, "", insertLog);
+            if (!error.empty()) return false;
+        }
         error = reader.open(P.readFilesIn);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
+        if (P.twopass) {                                            // twoPassRunPass1.cpp:14-47: no SAM, own read limit
+            pass1 = true; post->samOff = true; readMapNumberUser = P.readMapNumber;
+            if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
+        }
         std::string samPath = P.outFileNamePrefix + "Aligned.out.sam";
         samOut = fopen(samPath.c_str(), "wb");
         if (!samOut) { error = "EXITING because of fatal ERROR: could not create output file " + samPath; return false; }
@@ -79,6 +107,23 @@ struct Runner {
         return true;
     }
     bool emit(const staramd_results *r) { return emitBatch(batch, r); }
+    // end of the 1st pass (twoPassRunPass1.cpp:75-96): junctions + Log.final.out of the pass into _STARpass1/, insertion of the
+    // junctions into the index, reads rewound.  The caller then re-uploads the index (staramd_update_index).
+    bool endPass1() {
+        if (!pass1) { error = "not in the 1st pass"; return false; }
+        error = sj.filterAndWrite(P, gi, P.twopassDir + "SJ.out.tab");
+        if (!error.empty()) return false;
+        stats.reportFinal(P.twopassDir + "Log.final.out");
+        error = sjdbInsertJunctions(P, gi, sjdbLoci, true, P.twopassDir + "SJ.out.tab", insertLog);
+        if (!error.empty()) return false;
+        error = reader.reopen();
+        if (!error.empty()) return false;
+        time_t t0 = stats.timeStart;
+        stats = Stats(); stats.timeStart = t0; time(&stats.timeStartMap);
+        sj.data.clear();
+        P.readMapNumber = readMapNumberUser; post->samOff = false; pass1 = false;
+        return true;
+    }
     bool finish() {
         if (samOut) { fclose(samOut); samOut = nullptr; }
         error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab");
@@ -129,6 +174,11 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
 }
 int sah_emit_slot(void *h, int slot, const staramd_results *res) { Runner *r = (Runner *)h; return r->emitBatch(r->slots[slot], res) ? 0 : -1; }
 int sah_threads(void *h) { return ((Runner *)h)->P.runThreadN; }
+// 2-pass mapping: sah_in_pass1() is 1 after sah_create when --twopassMode Basic was given; map all batches, call sah_pass1_end()
+// (junction insertion on the host), re-upload sah_genome()/sah_params() with staramd_update_index(), map all batches again.
+int sah_in_pass1(void *h) { return ((Runner *)h)->pass1 ? 1 : 0; }
+int sah_pass1_end(void *h) { return ((Runner *)h)->endPass1() ? 0 : -1; }
+const char *sah_insert_log(void *h) { return ((Runner *)h)->insertLog.c_str(); }
 int sah_finish(void *h) { return ((Runner *)h)->finish() ? 0 : -1; }
 // ---- end-of-run exchange between ranks (one process per GPU) -------------------------------------
 // The reference merges per-thread junction tables and Stats inside one process (outputSJ.cpp:39-83 k-way merge,

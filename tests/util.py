@@ -55,12 +55,17 @@ def run_with_engine(info, prefix, engine_factory, batch_reads=777):
     eng = engine_factory(run.genome, run.params)
     try:
         while True:
-            b = run.next_batch(batch_reads)
-            if b is None:
+            while True:
+                b = run.next_batch(batch_reads)
+                if b is None:
+                    break
+                bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
+                eng.map_batch(b, bufs)
+                run.emit(bufs.res)
+            if not run.in_pass1():
                 break
-            bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
-            eng.map_batch(b, bufs)
-            run.emit(bufs.res)
+            run.pass1_end()                       # --twopassMode Basic: junction insertion, then the 2nd pass
+            eng.update_index(run.genome, run.params)
         run.finish()
     finally:
         eng.close()
