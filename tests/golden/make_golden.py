@@ -6,6 +6,8 @@
                   reads_1.fq, reads_2.fq   600 synthetic 2x76 pairs (repeats, Ns, indels, annotated + novel junctions)
                   ref_Aligned.sorted.sam   body of the reference's Aligned.out.sam, sorted
                   ref_SJ.out.tab, ref_Log.final.counters.json
+                  ref2p_*                  the same for `--twopassMode Basic --sjdbInsertSave All`, plus the 1st-pass SJ.out.tab and
+                                           the sha256 of the index the reference left in _STARgenome/ after junction insertion
   digests.json  sha256 of the same three reference outputs for every data set of tests/util.py:DATASETS
                 (the data sets are regenerated from fixed seeds by star_amd/synth.py)
 
@@ -59,6 +61,15 @@ def main():
             f.write(b"".join(refstar.sam_body_sorted(os.path.join(tmp, "ref_Aligned.out.sam"))))
         shutil.copy(os.path.join(tmp, "ref_SJ.out.tab"), os.path.join(out, "ref_SJ.out.tab"))
         json.dump(refstar.final_log_counters(os.path.join(tmp, "ref_Log.final.out")), open(os.path.join(out, "ref_Log.final.counters.json"), "w"), indent=1, sort_keys=True)
+        # 2-pass run of the reference on the same tiny case
+        refstar.align(idx, info["fastq"], os.path.join(tmp, "ref2p_"), threads=1, extra=["--twopassMode", "Basic", "--sjdbInsertSave", "All"])
+        with open(os.path.join(out, "ref2p_Aligned.sorted.sam"), "wb") as f:
+            f.write(b"".join(refstar.sam_body_sorted(os.path.join(tmp, "ref2p_Aligned.out.sam"))))
+        shutil.copy(os.path.join(tmp, "ref2p_SJ.out.tab"), os.path.join(out, "ref2p_SJ.out.tab"))
+        shutil.copy(os.path.join(tmp, "ref2p__STARpass1", "SJ.out.tab"), os.path.join(out, "ref2p_pass1_SJ.out.tab"))
+        json.dump(refstar.final_log_counters(os.path.join(tmp, "ref2p_Log.final.out")), open(os.path.join(out, "ref2p_Log.final.counters.json"), "w"), indent=1, sort_keys=True)
+        json.dump({f: hashlib.sha256(open(os.path.join(tmp, "ref2p__STARgenome", f), "rb").read()).hexdigest() for f in ("Genome", "SA", "SAindex", "sjdbInfo.txt", "sjdbList.out.tab")},
+                  open(os.path.join(out, "ref2p_index_sha256.json"), "w"), indent=1, sort_keys=True)
         dig = {}
         for name in sorted(util.DATASETS):
             i2 = util.prepare(name, tmp)
