@@ -10,6 +10,7 @@
 #include <vector>
 #include <cstdio>
 #include <istream>
+#include <string_view>
 #include "../../../include/star_amd.h"
 
 namespace staramd {
@@ -81,15 +82,20 @@ struct RunParams {
 };
 
 // ---- one batch of reads in the layout of staramd_batch + the text needed for SAM ----
+struct TextSpan { uint64_t off; uint32_t len; };
 struct ReadBatch {
     uint32_t n = 0;
     std::vector<uint8_t> bases;           // combined numeric reads
     std::vector<uint64_t> readOffset;     // n+1
     std::vector<uint16_t> mate1Length, mmMaxTotal;
-    std::vector<std::string> name;        // without '@', trimmed at readNameSeparator
-    std::vector<std::string> seq[2], qual[2];
+    std::vector<char> text[2];            // the FASTQ text of the batch as read from each mate file; the spans below point into it
+    std::vector<TextSpan> nameSpan;       // read ID without '@', trimmed at readNameSeparator (from mate 1's ID line)
+    std::vector<TextSpan> seqSpan[2], qualSpan[2];
     std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
     uint64_t firstReadIndex = 0;
+    std::string_view name(uint32_t i) const { return std::string_view(text[0].data() + nameSpan[i].off, nameSpan[i].len); }
+    std::string_view seq(int m, uint32_t i) const { return std::string_view(text[m].data() + seqSpan[m][i].off, seqSpan[m][i].len); }
+    std::string_view qual(int m, uint32_t i) const { return std::string_view(text[m].data() + qualSpan[m][i].off, qualSpan[m][i].len); }
     staramd_batch view() const;
     void clear();
 };
@@ -100,14 +106,19 @@ public:
     std::string open(const std::vector<std::string> &paths);
     std::string reopen();                 // rewind to the first read (Parameters::closeReadsFiles/openReadsFiles between the two passes)
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
-    // + the PE concatenation of ReadAlign::oneRead (ReadAlign_oneRead.cpp:35-78)
+    // + the PE concatenation of ReadAlign::oneRead (ReadAlign_oneRead.cpp:35-78).
+    // The text is read in blocks and the records of a batch are converted on --runThreadN threads.
     bool nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err);
     uint64_t readsSoFar = 0;
 private:
     FILE *f[2] = {nullptr, nullptr};
     int nMates = 0;
-    std::vector<char> lineBuf;
-    bool getLine(int im, std::string &out);
+    std::vector<char> carry[2];           // text read from the file but not yet part of a batch
+    bool eof[2] = {false, false};
+    double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
+    std::vector<uint64_t> lineStart[2], lineEnd[2];
+    // moves text of up to `want` records into `text`; fills lineStart/lineEnd; returns the number of complete lines
+    uint64_t fill(int m, uint64_t want, std::vector<char> &text);
 };
 
 // ---- junction insertion into the loaded index (sjdb_insert.cpp) ----

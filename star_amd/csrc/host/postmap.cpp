@@ -106,7 +106,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         if (trimR1 > 0) { appendUint(cigar, trimR1); cigar.push_back('S'); }
         int MAPQ = P.outSAMmapqUnique;
         if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
-        out += b.name[ir]; out.push_back('\t');
+        out += b.name(ir); out.push_back('\t');
         appendUint(out, (samFLAG & P.outSAMflagAND) | P.outSAMflagOR); out.push_back('\t');
         out += gi.chrName[t.Chr]; out.push_back('\t');
         appendUint(out, ex[iEx1].G + 1 - chrS); out.push_back('\t');
@@ -118,7 +118,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             appendUint(out, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);
         } else out += "\t*\t0\t0";
         out.push_back('\t');
-        const std::string &sq = b.seq[Mate][ir]; const std::string &ql = b.qual[Mate][ir];
+        const std::string_view sq = b.seq((int)Mate, ir), ql = b.qual((int)Mate, ir);
         if (Mate == Str) { out += sq; out.push_back('\t'); if (!P.outSAMmodeNoQS) out += ql; else out.push_back('*'); }
         else {
             size_t n = sq.size();
@@ -152,10 +152,10 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
             else samFLAG |= 0x8;
         }
         if (b.filter[ir] == 'Y') samFLAG |= 0x200;
-        out += b.name[ir]; out.push_back('\t'); appendUint(out, samFLAG); out += "\t*\t0\t0\t*";
+        out += b.name(ir); out.push_back('\t'); appendUint(out, samFLAG); out += "\t*\t0\t0\t*";
         if (rc.nMates == 2 && mateMap[1 - imate]) { out.push_back('\t'); out += gi.chrName[trBest->Chr]; out.push_back('\t'); appendUint(out, exBest[0].G + 1 - gi.chrStart[trBest->Chr]); }
         else out += "\t*\t0";
-        out += "\t0\t"; out += b.seq[imate][ir]; out.push_back('\t'); out += b.qual[imate][ir];
+        out += "\t0\t"; out += b.seq(imate, ir); out.push_back('\t'); out += b.qual(imate, ir);
         out += "\tNH:i:0\tHI:i:0\tAS:i:"; appendInt(out, trBest ? trBest->maxScore : 0);
         out += "\tnM:i:"; appendUint(out, trBest ? trBest->nMM : 0); out += "\tuT:A:"; appendInt(out, unmapType);
         out.push_back('\n');
@@ -175,7 +175,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         if (rr.status & STARAMD_ST_FATAL_SEEDS_PER_READ)
             return "EXITING because of FATAL error: too many pieces pere read\nSOLUTION: increase input parameter --seedPerReadNmax";
         if (rr.status & STARAMD_ST_SCRATCH_OVERFLOW)
-            return "EXITING because of FATAL error: a device work-space cap was exceeded for read " + b.name[ir];
+            return "EXITING because of FATAL error: a device work-space cap was exceeded for read " + std::string(b.name(ir));
         ReadCtx rc; rc.b = &b; rc.i = ir; rc.nMates = (int)P.dev.readNmates;
         rc.Lread = b.readOffset[ir + 1] - b.readOffset[ir];
         rc.readLength[0] = b.mate1Length[ir]; rc.readLength[1] = rc.nMates == 2 ? rc.Lread - rc.readLength[0] - 1 : 0;

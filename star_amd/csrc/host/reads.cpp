@@ -4,9 +4,17 @@
 //   readLoad                                      source/readLoad.cpp:4-100
 //   convertNucleotidesToNumbers                   source/SequenceFuns.cpp:131-146
 //   PE concatenation in ReadAlign::oneRead        source/ReadAlign_oneRead.cpp:35-78
+// The reference reads line by line under a mutex; here the text comes in blocks, line boundaries are
+// found with memchr, and the records of a batch are converted on --runThreadN threads.  The batch keeps the text itself;
+// names, sequences and qualities are spans into it (nothing is copied per read until the SAM line is formatted).
 #include "host.h"
 #include <cstring>
 #include <algorithm>
+#include <thread>
+#include <atomic>
+#include <functional>
+#include <immintrin.h>
+#include <chrono>
 
 namespace staramd {
 
@@ -18,8 +26,8 @@ staramd_batch ReadBatch::view() const {
 }
 void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
-    name.clear(); filter.clear();
-    for (int i = 0; i < 2; i++) { seq[i].clear(); qual[i].clear(); }
+    nameSpan.clear(); filter.clear();
+    for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); }
 }
 
 FastqReader::~FastqReader() { for (int i = 0; i < 2; i++) if (f[i]) fclose(f[i]); }
@@ -29,89 +37,201 @@ std::string FastqReader::open(const std::vector<std::string> &paths) {
     for (int i = 0; i < nMates; i++) {
         f[i] = fopen(paths[i].c_str(), "rb");
         if (!f[i]) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + paths[i];
-        setvbuf(f[i], nullptr, _IOFBF, 1 << 22);
+        setvbuf(f[i], nullptr, _IONBF, 0);          // blocks are read straight into the batch text
+        carry[i].clear(); eof[i] = false;
     }
-    lineBuf.resize(1 << 16);
     return "";
 }
 
 std::string FastqReader::reopen() {
-    for (int i = 0; i < nMates; i++) if (fseek(f[i], 0, SEEK_SET) != 0) return "EXITING because of fatal input ERROR: could not rewind the read file";
+    for (int i = 0; i < nMates; i++) {
+        if (fseek(f[i], 0, SEEK_SET) != 0) return "EXITING because of fatal input ERROR: could not rewind the read file";
+        carry[i].clear(); eof[i] = false;
+    }
     readsSoFar = 0;
     return "";
 }
 
-bool FastqReader::getLine(int im, std::string &out) {
-    out.clear();
-    for (;;) {
-        if (!fgets(lineBuf.data(), (int)lineBuf.size(), f[im])) return !out.empty();
-        size_t l = strlen(lineBuf.data());
-        bool eol = l > 0 && lineBuf[l - 1] == '\n';
-        out.append(lineBuf.data(), eol ? l - 1 : l);
-        if (eol) break;
+// offsets of the '\n' bytes in [p+from, p+to), appended to `out` until `out` holds `maxOut` entries; returns the offset where
+// the scan stopped.  32 bytes per step when the CPU has AVX2 (lines are ~100 bytes: one memchr call per line is mostly call overhead).
+__attribute__((target("avx2"))) static uint64_t scanNewlinesAvx2(const char *p, uint64_t from, uint64_t to, std::vector<uint64_t> &out, uint64_t maxOut) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    uint64_t i = from;
+    for (; i + 32 <= to && out.size() < maxOut; i += 32) {
+        uint32_t mask = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nl));
+        while (mask) {
+            out.push_back(i + (uint64_t)__builtin_ctz(mask));
+            mask &= mask - 1;
+            if (out.size() >= maxOut) return out.back() + 1;
+        }
     }
-    // fastqReadOneLine strips a trailing control character (\r)
-    if (!out.empty() && (unsigned char)out.back() < 33) out.pop_back();
-    return true;
+    for (; i < to && out.size() < maxOut; i++) if (p[i] == '\n') out.push_back(i);
+    return out.size() >= maxOut ? out.back() + 1 : i;
+}
+static uint64_t scanNewlines(const char *p, uint64_t from, uint64_t to, std::vector<uint64_t> &out, uint64_t maxOut) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return scanNewlinesAvx2(p, from, to, out, maxOut);
+    uint64_t i = from;
+    while (i < to && out.size() < maxOut) {
+        const char *q = (const char *)memchr(p + i, '\n', to - i);
+        if (!q) return to;
+        out.push_back((uint64_t)(q - p)); i = (uint64_t)(q - p) + 1;
+    }
+    return i;
 }
 
-static inline uint8_t nt2num(char c) {
-    switch (c) {
-        case 'A': case 'a': return 0;
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2;
-        case 'T': case 't': return 3;
-        default: return 4;
+uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
+    std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
+    ls.clear(); le.clear();
+    text.assign(carry[m].begin(), carry[m].end());      // (not swap: every buffer keeps its capacity, so no fresh pages per batch)
+    carry[m].clear();
+    uint64_t scanned = 0;
+    const uint64_t wantLines = want * 4;
+    for (;;) {
+        scanned = scanNewlines(text.data(), scanned, text.size(), le, wantLines);
+        if (le.size() >= wantLines || eof[m]) break;
+        // read about as much as the missing records need (little is left over to carry into the next batch)
+        uint64_t missing = (wantLines - le.size() + 3) / 4;
+        uint64_t block = std::max<uint64_t>(1u << 16, std::min<uint64_t>(64u << 20, (uint64_t)((double)missing * bytesPerRecord[m] * 1.01) + 4096));
+        size_t old = text.size();
+        text.resize(old + block);
+        size_t got = fread(text.data() + old, 1, block, f[m]);
+        text.resize(old + got);
+        if (got < block) eof[m] = true;
     }
+    if (le.size() >= 4) bytesPerRecord[m] = (double)(le.back() + 1) / (double)(le.size() / 4);
+    ls.resize(le.size());
+    for (size_t k = 0; k < le.size(); k++) ls[k] = k ? le[k - 1] + 1 : 0;
+    uint64_t lineBeg = le.empty() ? 0 : le.back() + 1;
+    if (le.size() >= wantLines) {                       // the rest belongs to the next batches
+        carry[m].assign(text.begin() + lineBeg, text.end());
+        text.resize(lineBeg);
+    } else if (lineBeg < text.size()) {                 // end of file without a final newline: the tail is a line
+        ls.push_back(lineBeg); le.push_back(text.size());
+    }
+    // fastqReadOneLine strips one trailing control character (\r) from every line
+    for (size_t k = 0; k < ls.size(); k++) if (le[k] > ls[k] && (unsigned char)text[le[k] - 1] < 33) le[k]--;
+    return ls.size();
 }
+
+struct NtTable {               // convertNucleotidesToNumbers (SequenceFuns.cpp:131-146) as a table; [1] = code of the complement
+    uint8_t fwd[256], rc[256];
+    NtTable() {
+        memset(fwd, 4, 256); memset(rc, 4, 256);
+        const char *nt = "ACGTacgt";
+        for (int k = 0; k < 8; k++) { fwd[(uint8_t)nt[k]] = (uint8_t)(k & 3); rc[(uint8_t)nt[k]] = (uint8_t)(3 - (k & 3)); }
+    }
+};
+static const NtTable NT;
 
 bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err) {
     b.clear();
     b.firstReadIndex = readsSoFar;
-    std::string l1[2], s[2], plus, q[2];
-    while (b.n < maxReads) {
-        if (P.readMapNumber >= 0 && (int64_t)readsSoFar >= P.readMapNumber) break;
-        if (!getLine(0, l1[0]) || l1[0].empty()) break;
-        if (l1[0][0] != '@') { err = "EXITING because of FATAL ERROR in input reads: wrong read ID line format: the read ID lines should start with @ (FASTA/SAM input: out of scope)"; return false; }
-        if (nMates == 2 && !getLine(1, l1[1])) { err = "EXITING because of FATAL ERROR: read files are not consistent, reached the end of the one before the other one"; return false; }
-        for (int im = 0; im < nMates; im++) {
-            if (!getLine(im, s[im]) || !getLine(im, plus) || !getLine(im, q[im])) { err = "EXITING because of FATAL ERROR in reads input: truncated FASTQ record"; return false; }
-            if (s[im].size() < 1) { err = "EXITING because of FATAL ERROR in reads input: short read sequence line: 0"; return false; }
-            if (s[im].size() > STARAMD_READ_LEN_MAX) { err = "EXITING because of FATAL ERROR in reads input: Lread>DEF_readSeqLengthMax"; return false; }
-            if (q[im].size() != s[im].size()) { err = "EXITING because of FATAL ERROR in reads input: quality string length is not equal to sequence length"; return false; }
+    uint64_t want = maxReads;
+    if (P.readMapNumber >= 0) {
+        if ((int64_t)readsSoFar >= P.readMapNumber) return false;
+        want = std::min<uint64_t>(want, (uint64_t)P.readMapNumber - readsSoFar);
+    }
+    if (want == 0) return false;
+    static const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
+    uint64_t nLines[2] = {0, 0};
+    for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
+    lap("fill");
+    // records of mate 1 decide the batch; an empty ID line ends the input
+    uint64_t n = nLines[0] / 4;
+    bool partial = nLines[0] % 4 != 0;
+    for (uint64_t i = 0; i < n; i++) if (lineEnd[0][4 * i] == lineStart[0][4 * i]) { n = i; partial = false; eof[0] = true; carry[0].clear(); break; }
+    if (partial && lineEnd[0][4 * n] == lineStart[0][4 * n]) partial = false;
+    if (partial) { err = "EXITING because of FATAL ERROR in reads input: truncated FASTQ record"; return false; }
+    if (n == 0) return false;
+    if (nMates == 2 && nLines[1] < 4 * n) {
+        err = nLines[1] / 4 < n && nLines[1] % 4 == 0 ? "EXITING because of FATAL ERROR: read files are not consistent, reached the end of the one before the other one"
+                                                       : "EXITING because of FATAL ERROR in reads input: truncated FASTQ record";
+        return false;
+    }
+    b.n = (uint32_t)n;
+    b.readOffset.assign(n + 1, 0); b.mate1Length.assign(n, 0); b.mmMaxTotal.assign(n, 0);
+    b.nameSpan.assign(n, TextSpan{0, 0}); b.filter.assign(n, 'N');
+    for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); }
+    lap("alloc");
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(std::max(P.runThreadN, 1), 32), n / 2048));
+    std::vector<uint32_t> Lread(n);
+    std::atomic<uint64_t> firstBad(UINT64_MAX);
+    std::vector<std::string> errs(T);
+    auto inRanges = [&](const std::function<void(uint64_t, uint64_t, int)> &fn) {
+        if (T == 1) { fn(0, n, 0); return; }
+        std::vector<std::thread> th;
+        uint64_t per = (n + T - 1) / T;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t] { uint64_t lo = std::min<uint64_t>(n, t * per), hi = std::min<uint64_t>(n, lo + per); fn(lo, hi, t); });
+        for (auto &x : th) x.join();
+    };
+    // pass 1: spans, checks, lengths
+    inRanges([&](uint64_t lo, uint64_t hi, int t) {
+        auto bad = [&](uint64_t i, const char *msg) { uint64_t cur = firstBad.load(); while (i < cur && !firstBad.compare_exchange_weak(cur, i)) {} if (errs[t].empty()) errs[t] = msg; };
+        for (uint64_t i = lo; i < hi; i++) {
+            const char *t0 = b.text[0].data();
+            uint64_t s0 = lineStart[0][4 * i], e0 = lineEnd[0][4 * i];
+            if (t0[s0] != '@') { bad(i, "EXITING because of FATAL ERROR in input reads: wrong read ID line format: the read ID lines should start with @ (FASTA/SAM input: out of scope)"); return; }
+            uint64_t len[2] = {0, 0};
+            for (int m = 0; m < nMates; m++) {
+                uint64_t ss = lineStart[m][4 * i + 1], se = lineEnd[m][4 * i + 1], qs = lineStart[m][4 * i + 3], qe = lineEnd[m][4 * i + 3];
+                len[m] = se - ss;
+                if (len[m] < 1) { bad(i, "EXITING because of FATAL ERROR in reads input: short read sequence line: 0"); return; }
+                if (len[m] > STARAMD_READ_LEN_MAX) { bad(i, "EXITING because of FATAL ERROR in reads input: Lread>DEF_readSeqLengthMax"); return; }
+                if (qe - qs != len[m]) { bad(i, "EXITING because of FATAL ERROR in reads input: quality string length is not equal to sequence length"); return; }
+                b.seqSpan[m][i] = TextSpan{ss, (uint32_t)len[m]}; b.qualSpan[m][i] = TextSpan{qs, (uint32_t)len[m]};
+            }
+            // read ID: first white-space token of mate 1's line, then trimmed at readNameSeparator chars
+            uint64_t p = s0 + 1, e = p;
+            while (e < e0 && t0[e] != ' ' && t0[e] != '\t') e++;
+            if (e < e0) {
+                uint64_t f2 = e;
+                while (f2 < e0 && (t0[f2] == ' ' || t0[f2] == '\t')) f2++;
+                uint64_t f3 = f2;
+                while (f3 < e0 && t0[f3] != ' ' && t0[f3] != '\t') f3++;
+                if (f3 - f2 >= 3 && t0[f2 + 1] == ':' && t0[f2 + 2] == 'Y' && (f2 + 3 < f3 ? t0[f2 + 3] == ':' : false)) b.filter[i] = 'Y';
+            }
+            uint64_t ne = e;
+            for (char c : P.readNameSeparator) { const void *q = memchr(t0 + p, c, ne - p); if (q) ne = (uint64_t)((const char *)q - t0); }
+            b.nameSpan[i] = TextSpan{p, (uint32_t)(ne - p)};
+            uint64_t L = nMates == 2 ? len[0] + len[1] + 1 : len[0];
+            if (L > STARAMD_READ_LEN_MAX) { bad(i, "EXITING because of FATAL ERROR in reads input: Lread of the pair > DEF_readSeqLengthMax"); return; }
+            Lread[i] = (uint32_t)L;
+            b.mate1Length[i] = (uint16_t)len[0];
+            // ReadAlign_oneRead.cpp:78
+            b.mmMaxTotal[i] = (uint16_t)std::min<uint64_t>(P.outFilterMismatchNmax, (uint64_t)(P.outFilterMismatchNoverReadLmax * (double)(len[0] + len[1])));
         }
-        // read ID: first white-space token of mate 1's line, then trimmed at readNameSeparator chars
-        size_t e = l1[0].find_first_of(" \t");
-        std::string id = l1[0].substr(1, e == std::string::npos ? std::string::npos : e - 1);
-        char pf = 'N';
-        if (e != std::string::npos) {
-            size_t f2 = l1[0].find_first_not_of(" \t", e);
-            if (f2 != std::string::npos) {
-                std::string field2 = l1[0].substr(f2, l1[0].find_first_of(" \t", f2) - f2);
-                if (field2.length() >= 3 && field2[1] == ':' && field2[2] == 'Y' && field2[3] == ':') pf = 'Y';
+    });
+    if (firstBad.load() != UINT64_MAX) {
+        // report the error of the earliest offending read (each range stops at its first one)
+        uint64_t per = (n + T - 1) / T;
+        err = errs[T == 1 ? 0 : (int)(firstBad.load() / per)];
+        return false;
+    }
+    lap("pass1");
+    for (uint64_t i = 0; i < n; i++) b.readOffset[i + 1] = b.readOffset[i] + Lread[i];
+    b.bases.resize(b.readOffset[n]);
+    lap("prefix");
+    // pass 2: numeric combined reads
+    inRanges([&](uint64_t lo, uint64_t hi, int) {
+        for (uint64_t i = lo; i < hi; i++) {
+            uint8_t *r = b.bases.data() + b.readOffset[i];
+            const char *s0 = b.text[0].data() + b.seqSpan[0][i].off;
+            uint64_t len0 = b.seqSpan[0][i].len;
+            for (uint64_t k = 0; k < len0; k++) r[k] = NT.fwd[(uint8_t)s0[k]];
+            if (nMates == 2) {
+                const char *s1 = b.text[1].data() + b.seqSpan[1][i].off;
+                uint64_t len1 = b.seqSpan[1][i].len;
+                r[len0] = STARAMD_SPACER_BASE;
+                for (uint64_t k = 0; k < len1; k++) r[len0 + 1 + k] = NT.rc[(uint8_t)s1[len1 - 1 - k]];
             }
         }
-        for (char c : P.readNameSeparator) { size_t p = id.find(c); if (p != std::string::npos) id.resize(p); }
-        uint64_t len0 = s[0].size(), len1 = nMates == 2 ? s[1].size() : 0;
-        uint64_t Lread = nMates == 2 ? len0 + len1 + 1 : len0;
-        if (Lread > STARAMD_READ_LEN_MAX) { err = "EXITING because of FATAL ERROR in reads input: Lread of the pair > DEF_readSeqLengthMax"; return false; }
-        size_t off = b.bases.size();
-        b.bases.resize(off + Lread);
-        uint8_t *r = b.bases.data() + off;
-        for (uint64_t i = 0; i < len0; i++) r[i] = nt2num(s[0][i]);
-        if (nMates == 2) {
-            r[len0] = STARAMD_SPACER_BASE;
-            for (uint64_t i = 0; i < len1; i++) { uint8_t c = nt2num(s[1][len1 - 1 - i]); r[len0 + 1 + i] = c < 4 ? 3 - c : c; }
-        }
-        b.readOffset.push_back(off + Lread);
-        b.mate1Length.push_back((uint16_t)len0);
-        // ReadAlign_oneRead.cpp:78
-        b.mmMaxTotal.push_back((uint16_t)std::min<uint64_t>(P.outFilterMismatchNmax, (uint64_t)(P.outFilterMismatchNoverReadLmax * (double)(len0 + len1))));
-        b.name.push_back(id); b.filter.push_back(pf);
-        for (int im = 0; im < nMates; im++) { b.seq[im].push_back(s[im]); b.qual[im].push_back(q[im]); }
-        b.n++; readsSoFar++;
-    }
-    return b.n > 0;
+    });
+    lap("pass2");
+    readsSoFar += n;
+    return true;
 }
 
 } // namespace staramd

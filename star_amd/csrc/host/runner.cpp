@@ -9,6 +9,10 @@
 #include <ctime>
 #include <memory>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <chrono>
 
 namespace staramd {
 
@@ -23,7 +27,6 @@ struct Runner {
     OutSJ sj;
     Stats stats;
     FILE *samOut = nullptr;
-    std::string samBuf;
     std::string error;
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
     std::string insertLog;
@@ -69,6 +72,7 @@ struct Runner {
         setvbuf(samOut, nullptr, _IOFBF, 1 << 22);
         std::string h = post->samHeader();
         fwrite(h.data(), 1, h.size(), samOut);
+        startWriter();
         time(&stats.timeStartMap);
         return true;
     }
@@ -80,29 +84,58 @@ struct Runner {
         batchView = batch.view();
         return (int)batch.n;
     }
-    // post-map of one batch on --runThreadN host threads: contiguous read ranges, per-thread SAM text / junctions / Stats
-    // (what the reference keeps per ReadAlignChunk), concatenated in read order
+    // ---- SAM text goes to the file on its own thread: formatting of batch k+1 overlaps the write of batch k.  Two sets of
+    // per-thread text buffers alternate and keep their capacity (no fresh pages per batch).
+    struct OutSet { std::vector<std::string> sams; uint32_t used = 0; };
+    OutSet outSets[2];
+    std::mutex wm; std::condition_variable wcv;
+    std::deque<int> freeSets, fullSets; bool writerStop = false, writerFailed = false;
+    std::thread writerThread;
+    void writerLoop() {
+        for (;;) {
+            int k;
+            { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !fullSets.empty() || writerStop; }); if (fullSets.empty()) return; k = fullSets.front(); fullSets.pop_front(); }
+            OutSet &o = outSets[k];
+            for (uint32_t t = 0; t < o.used; t++)
+                if (!o.sams[t].empty() && fwrite(o.sams[t].data(), 1, o.sams[t].size(), samOut) != o.sams[t].size()) writerFailed = true;
+            { std::lock_guard<std::mutex> l(wm); freeSets.push_back(k); }
+            wcv.notify_all();
+        }
+    }
+    void startWriter() { freeSets = {0, 1}; writerThread = std::thread([this] { writerLoop(); }); }
+    void stopWriter() {
+        if (!writerThread.joinable()) return;
+        { std::lock_guard<std::mutex> l(wm); writerStop = true; }
+        wcv.notify_all();
+        writerThread.join();
+    }
+    // post-map of one batch on --runThreadN host threads: contiguous read ranges, per-thread SAM buffer / junctions / Stats
+    // (what the reference keeps per ReadAlignChunk), SAM text written in read order
     bool emitBatch(const ReadBatch &bt, const staramd_results *r) {
         uint32_t T = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
         T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per thread
-        if (T == 1) {
-            samBuf.clear();
-            error = post->process(bt, *r, samBuf, sj, stats);
-            if (!error.empty()) return false;
-            fwrite(samBuf.data(), 1, samBuf.size(), samOut);
-        } else {
-            std::vector<std::string> sams(T), errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
+        int k;
+        { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !freeSets.empty(); }); k = freeSets.front(); freeSets.pop_front(); }
+        OutSet &o = outSets[k];
+        if (o.sams.size() < T) o.sams.resize(T);
+        o.used = T;
+        std::vector<std::string> errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
+        uint32_t per = (bt.n + T - 1) / T;
+        auto work = [&](uint32_t t) { uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per); o.sams[t].clear(); errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t]); };
+        if (T == 1) work(0);
+        else {
             std::vector<std::thread> th;
-            uint32_t per = (bt.n + T - 1) / T;
-            for (uint32_t t = 0; t < T; t++)
-                th.emplace_back([&, t]() { uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per); errs[t] = post->processRange(bt, *r, lo, hi, sams[t], sjs[t], sts[t]); });
+            for (uint32_t t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
             for (auto &x : th) x.join();
-            for (uint32_t t = 0; t < T; t++) {
-                if (!errs[t].empty()) { error = errs[t]; return false; }
-                fwrite(sams[t].data(), 1, sams[t].size(), samOut);
-                sj.mergeFrom(sjs[t]); stats.add(sts[t]);
-            }
         }
+        for (uint32_t t = 0; t < T; t++) if (!errs[t].empty() && error.empty()) error = errs[t];
+        if (!error.empty()) o.used = 0;
+        { std::lock_guard<std::mutex> l(wm); fullSets.push_back(k); }
+        wcv.notify_all();
+        if (!error.empty()) return false;
+        for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); }
+        if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
         return true;
     }
@@ -125,13 +158,15 @@ struct Runner {
         return true;
     }
     bool finish() {
+        stopWriter();
+        if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (samOut) { fclose(samOut); samOut = nullptr; }
         error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab");
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
         return true;
     }
-    ~Runner() { if (samOut) fclose(samOut); }
+    ~Runner() { stopWriter(); if (samOut) fclose(samOut); }
 };
 
 } // namespace staramd
