@@ -40,7 +40,11 @@ std::string RunParams::parse(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         commandLine += (i > 1 ? " " : "") + a;
-        if (a.size() > 2 && a[0] == '-' && a[1] == '-') { cur = a.substr(2); kv[cur]; }
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            cur = a.substr(2);
+            if (kv.count(cur)) return "EXITING: FATAL INPUT ERROR: duplicate parameter \"" + cur + "\" in input \"Command-Line\"\nSOLUTION: keep only one definition of input parameters in each input source\n";
+            kv[cur];
+        }
         else if (cur.empty()) return "EXITING: fatal input ERROR: unrecognized parameter name \"" + a + "\" in input \"Command-Line-Initial\"";
         else kv[cur].push_back(a);
     }

@@ -7,7 +7,7 @@ import ctypes as C
 
 import pytest
 
-from util import DATASETS, capi, compare_outputs, oracle_lib, prepare, refstar, run_with_engine
+from util import DATASETS, PARAM_SWEEP, capi, compare_outputs, oracle_lib, prepare, refstar, run_with_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,11 @@ def test_engine_matches_oracle_buffers(name, select, tmp_path, built):
     if not refstar.have_ref():
         pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
     info = prepare(name, str(tmp_path), need_ref=False)
-    argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "x_")] + info["extra"] + ["--gpuResultSelect", select]
+    _compare_buffers(info, ["--gpuResultSelect", select], str(tmp_path / "x_"))
+
+
+def _compare_buffers(info, more, prefix):
+    argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", prefix] + info["extra"] + more
     run = capi.HostRun(argv)
     eng = _engine(run.genome, run.params)
     orc = oracle_lib.Oracle(run.genome, run.params)
@@ -58,12 +62,24 @@ def test_engine_matches_oracle_buffers(name, select, tmp_path, built):
                     assert fa == fo, "read %d of batch %d: gpu %r oracle %r" % (i, nb, fa, fo)
             assert tg == to, "transcript records differ in batch %d" % nb
             assert eg == eo, "exon records differ in batch %d" % nb
-            # counters of the algorithmic work must agree too (same algorithm, same order)
-            cg = eng.counters()
             nb += 1
         assert nb > 0
     finally:
         eng.close(); orc.close(); run.close()
+
+
+@pytest.fixture(scope="module")
+def sweep_data(tmp_path_factory, built):
+    if not refstar.have_ref():
+        pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
+    return prepare("pe150_indel", str(tmp_path_factory.mktemp("sweep")), need_ref=False)
+
+
+@pytest.mark.parametrize("combo", sorted(PARAM_SWEEP))
+def test_engine_matches_oracle_with_flags(combo, sweep_data, tmp_path, built):
+    """non-default flags (util.PARAM_SWEEP; the oracle is pinned against the reference with the same flags in
+    test_oracle_vs_reference.py): result buffers byte for byte, all recorded transcripts"""
+    _compare_buffers(sweep_data, PARAM_SWEEP[combo] + ["--gpuResultSelect", "All"], str(tmp_path / "x_"))
 
 
 @pytest.mark.parametrize("name", ["pe101", "pe150_indel"])

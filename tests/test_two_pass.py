@@ -101,6 +101,7 @@ def test_two_pass_parameter_errors(tmp_path, built):
     for extra, text in [(["--twopass1readsN", "10"], "--twopass1readsN is defined, but --twoPassMode is not defined"),
                         (["--twopassMode", "Basic", "--twopass1readsN", "0"], "--twopass1readsN = 0 in the 2-pass mode"),
                         (["--twopassMode", "Fancy"], "unrecognized value of --twopassMode=Fancy"),
+                        (["--twopassMode", "Basic", "--twopassMode", "Basic"], "duplicate parameter \"twopassMode\""),
                         (["--sjdbFileChrStartEnd", str(tmp_path / "missing.tab")], "could not open input file pGe.sjdbFileChrStartEnd")]:
         with pytest.raises(RuntimeError) as e:
             capi.HostRun(base + extra)

@@ -31,6 +31,34 @@ DATASETS = {
 }
 
 
+# non-default alignReads flags, one group per entry: every branch the flags of SURVEY.md 5.6 switch on the hot path and in post-map
+PARAM_SWEEP = {
+    "e2e": ["--alignEndsType", "EndToEnd"],
+    "ext5p": ["--alignEndsType", "Extend5pOfRead1"],
+    "ext5p12": ["--alignEndsType", "Extend5pOfReads12"],
+    "intronmax": ["--alignIntronMax", "20000", "--alignMatesGapMax", "30000"],
+    "motifs": ["--outFilterIntronMotifs", "RemoveNoncanonical"],
+    "motifsU": ["--outFilterIntronMotifs", "RemoveNoncanonicalUnannotated", "--outSAMstrandField", "intronMotif"],
+    "log2zero": ["--scoreGenomicLengthLog2scale", "0"],
+    "scores": ["--scoreGap", "-1", "--scoreGapNoncan", "-6", "--scoreDelOpen", "-3", "--scoreInsBase", "-1", "--sjdbScore", "3", "--scoreStitchSJshift", "2"],
+    "seeds": ["--seedSearchStartLmax", "30", "--seedPerWindowNmax", "30", "--winAnchorMultimapNmax", "100", "--seedMultimapNmax", "2000"],
+    "lmax": ["--seedSearchLmax", "25"],
+    "filters": ["--outFilterMismatchNmax", "3", "--outFilterScoreMinOverLread", "0.5", "--outFilterMatchNminOverLread", "0.5", "--outFilterMultimapNmax", "3",
+                "--outFilterMultimapScoreRange", "3"],
+    "sjo": ["--alignSJoverhangMin", "12", "--alignSJDBoverhangMin", "1", "--alignSplicedMateMapLmin", "20", "--alignSplicedMateMapLminOverLmate", "0.3"],
+    "protrude": ["--alignEndsProtrude", "10", "ConcordantPair"],
+    "insflush": ["--alignInsertionFlush", "Right"],
+    "noclipref": ["--alignSoftClipAtReferenceEnds", "No"],
+    "trN": ["--alignTranscriptsPerWindowNmax", "20", "--alignTranscriptsPerReadNmax", "200", "--alignWindowsPerReadNmax", "50"],
+    "stitchmm": ["--alignSJstitchMismatchNmax", "1", "1", "1", "1"],
+    "strands": ["--outFilterIntronStrands", "None"],
+    "primary": ["--outSAMprimaryFlag", "AllBestScore", "--outSAMmapqUnique", "60", "--outSAMattrIHstart", "0", "--outSAMflagOR", "1024", "--outSAMunmapped", "Within"],
+    "sjfilt": ["--outSJfilterReads", "Unique", "--outSJfilterOverhangMin", "20", "8", "8", "8", "--outSJfilterCountUniqueMin", "2", "1", "1", "1",
+               "--outSJfilterDistToOtherSJmin", "5", "0", "3", "5"],
+    "winbin": ["--winBinNbits", "14", "--winAnchorDistNbins", "5", "--winFlankNbins", "2"],
+}
+
+
 def prepare(name, workdir, need_ref=True):
     """Generate data set + reference index (+ reference outputs). Returns dict of paths."""
     ds_kw, gg_kw, extra = DATASETS[name]
