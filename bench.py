@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cpu-repeat", type=int, default=int(os.environ.get("STARAMD_BENCH_CPU_REPEAT", "4")), help="the CPU baseline maps the sample this many times over (longer run: STAR's threads reach steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli-e2e", action="store_true")
+    ap.add_argument("--no-two-pass-e2e", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/tmp/star_amd_bench"))
     return ap.parse_args()
 
@@ -145,6 +146,29 @@ def cli_end_to_end(d, args):
     n, wall, dev = int(m.group(1)), float(m.group(2)), float(m.group(3))
     return {"value": n / wall / 1e6, "unit": "Mreads/s", "reads": n, "wall_s": wall, "device_s": dev, "host_threads": threads,
             "what": "star_amd CLI end to end: FASTQ in -> Aligned.out.sam + SJ.out.tab out (index load excluded)"}
+
+
+def two_pass_end_to_end(d, args):
+    """the CLI with --twopassMode Basic on one batch-worth of the workload (reads_r0): 1st pass on the GPU
+    without SAM, junction insertion on the host (sjdb_insert.cpp), index re-upload (staramd_update_index), 2nd pass."""
+    import re
+    fq = [os.path.join(d, "reads_r0_%d.fq" % (i + 1)) for i in range(2)]
+    exe = os.path.join(ROOT, "star_amd", "bin", "star_amd")
+    if not os.path.isfile(exe) or not all(os.path.isfile(f) for f in fq):
+        return None
+    threads = min(os.cpu_count() or 1, 64)
+    cmd = [exe, "--runMode", "alignReads", "--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + \
+          ["--outFileNamePrefix", os.path.join(d, "cli2p_"), "--runThreadN", str(threads), "--gpuBatchReads", str(min(args.reads, 200000)), "--twopassMode", "Basic"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    m1 = re.search(r"1st pass \+ junction insertion \+ index re-upload: ([0-9.]+) s \((\d+) reads\)", p.stderr)
+    m2 = re.search(r"star_amd: (\d+) reads, ([0-9.]+) s wall in the mapping loop \(([0-9.]+) s on the device\)", p.stderr)
+    if p.returncode != 0 or not m1 or not m2:
+        return {"error": (p.stderr or "")[-400:]}
+    n1 = int(m1.group(2)); wall = float(m2.group(2))
+    sjdb = sum(1 for _ in open(os.path.join(d, "cli2p__STARgenome", "sjdbList.out.tab")))
+    return {"value": n1 / wall / 1e6, "unit": "Mreads/s (each read counted once, both passes + insertion in the wall time)", "reads": n1, "wall_s": wall,
+            "pass1_plus_insertion_plus_reupload_s": float(m1.group(1)), "device_s_both_passes": float(m2.group(3)), "junctions_in_index_after_pass1": sjdb,
+            "host_threads": threads, "what": "star_amd CLI --twopassMode Basic end to end (index load excluded)"}
 
 
 def main():
@@ -276,6 +300,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, args, min(args.cpu_sample, n))
     if not args.no_cli_e2e and world == 1:
         out["cli_end_to_end"] = cli_end_to_end(d, args)
+    if not args.no_two_pass_e2e and world == 1:
+        try:
+            out["two_pass_end_to_end"] = two_pass_end_to_end(d, args)
+        except Exception as e:                      # an informational leg must not take the bench line down
+            out["two_pass_end_to_end"] = {"error": repr(e)[:300]}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

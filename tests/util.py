@@ -116,3 +116,81 @@ def compare_outputs(ref_prefix, new_prefix):
     if refstar.final_log_counters(ref_prefix + "Log.final.out") != refstar.final_log_counters(new_prefix + "Log.final.out"):
         problems.append("Log.final.out counters differ")
     return problems
+
+
+def _read_fasta(path):
+    seqs, cur = [], []
+    for l in open(path):
+        if l.startswith(">"):
+            if cur:
+                seqs.append("".join(cur))
+            cur = []
+        else:
+            cur.append(l.strip())
+    seqs.append("".join(cur))
+    return seqs
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGTNacgtn", "TGCANtgcan"))
+
+
+def make_edge_reads(info, outdir, paired=True, seed=7):
+    """Hand-made reads for the corner cases of the hot path, on the genome of a prepared data set: shortest / longest reads,
+    all-N, homopolymers, N-riddled, chromosome ends, fully overlapping / chimeric / junk mates, lower case and IUPAC codes,
+    heavy mismatches, tiny middle exon -- mixed into ordinary reads.  Returns the FASTQ paths."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    G = _read_fasta(info["fasta"])
+    g0 = G[0]
+
+    def pick(L, c=None):
+        c = G[int(rng.integers(len(G)))] if c is None else c
+        p = int(rng.integers(0, len(c) - L))
+        return c[p:p + L]
+
+    def mutate(s, n):
+        s = list(s)
+        for p in rng.choice(len(s), size=min(n, len(s)), replace=False):
+            s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + int(rng.integers(3))) % 4] if s[p] in "ACGT" else "A"
+        return "".join(s)
+
+    junk = "".join("ACGT"[i] for i in rng.integers(0, 4, 150))
+    frag = pick(400)
+    pairs = [
+        ("A", _rc(frag[250:400])),                                    # 1-base mate
+        ("N" * 50, "N" * 50),                                         # nothing mappable
+        (pick(325, g0), _rc(pick(324, g0))),                          # Lread = 650, the maximum
+        (frag[:12], _rc(frag[200:213])),                              # seedSplitMin edges
+        ("A" * 150, "T" * 150), ("AC" * 75, "GT" * 75),              # low complexity: very many loci
+        ("".join(c if i % 10 else "N" for i, c in enumerate(frag[:150])), _rc(frag[250:400])),
+        (frag[:150], _rc(frag[:150])),                                # mates overlap completely
+        (pick(150, G[0]), _rc(pick(150, G[-1]))),                     # mates from different chromosomes
+        (frag[:150], junk),                                           # one mate is junk
+        (frag[:150].lower(), _rc(frag[250:400]).replace("A", "R", 2).replace("C", "Y", 1)),
+        (mutate(frag[:150], 20), _rc(mutate(frag[250:400], 25))),     # far too many mismatches
+        (g0[:120], _rc(g0[150:300])), (G[-1][-300:-160], _rc(G[-1][-140:])),      # chromosome start / end
+        (g0[5000:5060] + g0[6000:6006] + g0[7000:7084], _rc(g0[7100:7250])),      # 6-base middle exon
+        (frag[:30], _rc(frag[250:400])), (frag[:150], _rc(frag[370:400])),        # very different mate lengths
+    ]
+    for _ in range(300):                                              # ordinary company, some with indels / mismatches
+        f = pick(int(rng.integers(160, 420)))
+        a, b = f[:int(rng.integers(40, 151))], _rc(f[-int(rng.integers(40, 151)):])
+        if rng.random() < 0.3:
+            a = mutate(a, int(rng.integers(1, 6)))
+        if rng.random() < 0.2 and len(b) > 60:
+            b = b[:30] + b[33:]
+        if rng.random() < 0.2 and len(a) > 60:
+            a = a[:40] + "GATTACA"[:int(rng.integers(1, 8))] + a[40:]
+        pairs.append((a, b))
+    order = rng.permutation(len(pairs))
+    os.makedirs(outdir, exist_ok=True)
+    paths = [os.path.join(outdir, "edge_1.fq")] + ([os.path.join(outdir, "edge_2.fq")] if paired else [])
+    fo = [open(p, "w") for p in paths]
+    for k, i in enumerate(order):
+        for m in range(len(paths)):
+            s = pairs[i][m]
+            fo[m].write("@edge%d/%d\n%s\n+\n%s\n" % (k, m + 1, s, "".join(chr(33 + (7 * j + k) % 40) for j in range(len(s)))))
+    for f in fo:
+        f.close()
+    return paths
