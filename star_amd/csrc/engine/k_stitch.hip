@@ -341,10 +341,11 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                 else if (gGap < 0) { jR = 0; Score -= -gGap; }
                 else {
                     int Score1 = 0, maxScore1 = 0;
+                    const int tieStep = P.alignInsertionFlushRight ? 0 : 1;
                     for (int jR1 = 1; jR1 <= gGap; jR1++) {
                         u8 gc = gByte(c, gAend + jR1);
                         if (gc < 4) { Score1 += (RD(c, rAend + jR1) == gc) ? 1 : -1; Score1 += (RD(c, rAend + Ins + jR1) == gc) ? -1 : +1; }
-                        if (Score1 > maxScore1 || (Score1 == maxScore1 && P.alignInsertionFlushRight)) { maxScore1 = Score1; jR = jR1; }
+                        if (Score1 >= maxScore1 + tieStep) { maxScore1 = Score1; jR = jR1; }     // flush right: an equal score moves the insertion right (:273)
                     }
                     for (int ii = 1; ii <= gGap; ii++) {
                         u32 r1 = rAend + ii + (ii <= jR ? 0 : Ins);
