@@ -61,6 +61,7 @@ struct RunParams {
     bool outSAMprimaryAllBest = false;
     bool outSAMmodeNoQS = false;
     std::vector<std::string> outSAMattrOrder = {"NH", "HI", "AS", "nM"};   // Standard
+    bool attrNMorMD = false;
     std::string readNameSeparator = "/";
     uint64_t gpuBatchReads = 65536;      // reads per device batch (ours; --gpuBatchReads)
     int gpuDevice = 0;

@@ -88,7 +88,8 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMattributes") {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
-            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
+            else if (v.size() >= 1 && v[0] == "All") err = "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC") outSAMattrOrder.push_back(t); else if (t == "ch") err = "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n"; else err = "EXITING: unsupported SAM attribute " + t; } }
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
@@ -174,6 +175,7 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
+    attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";
     dev.readNmates = (uint32_t)readFilesIn.size();

@@ -74,15 +74,12 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     uint32_t Str = t.Str;
     uint32_t leftMate = flagPaired ? Str : 0;
     uint64_t chrS = gi.chrStart[t.Chr];
+    // ReadAlign::calcCIGAR (ReadAlign_calcCIGAR.cpp:3-58): the CIGAR of both mates first, the MC tag needs the other mate's
+    std::string matesCIGAR[2];
     for (uint32_t imate = 0; imate < nMates; imate++) {
-        uint32_t samFLAG = samFlagCommon;
         uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
         uint32_t Mate = ex[iEx1].iFrag;
-        if (Mate == 0) { samFLAG |= Str * 0x10; if (nMates == 2) samFLAG |= (1 - Str) * 0x20; }
-        else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
-        if (flagPaired) samFLAG |= (Mate == 0 ? 0x0040 : 0x0080);
-        if (!tv.primary) samFLAG |= 0x100;
-        std::string cigar, SJmotif, SJintron;
+        std::string &cigar = matesCIGAR[imate];
         uint64_t trimL = 0;    // no clipping implemented (defaults clip nothing: parametersDefault:201-224)
         uint64_t trimL1 = trimL + ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
         if (trimL1 > 0) { appendUint(cigar, trimL1); cigar.push_back('S'); }
@@ -91,19 +88,58 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
                 uint64_t gapG = ex[ii].G - (ex[ii - 1].G + ex[ii - 1].L);
                 uint64_t gapR = (uint64_t)ex[ii].R - ex[ii - 1].R - ex[ii - 1].L;
                 if (gapR > 0) { appendUint(cigar, gapR); cigar.push_back('I'); }
-                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) {
-                    appendUint(cigar, gapG); cigar.push_back('N');
-                    SJmotif.push_back(','); appendInt(SJmotif, ex[ii - 1].canonSJ + (ex[ii - 1].sjAnnot == 0 ? 0 : 20));   // SJ_SAM_AnnotatedMotifShift
-                    SJintron.push_back(','); appendUint(SJintron, ex[ii - 1].G + ex[ii - 1].L + 1 - chrS);
-                    SJintron.push_back(','); appendUint(SJintron, ex[ii].G - chrS);
-                } else if (gapG > 0) { appendUint(cigar, gapG); cigar.push_back('D'); }
+                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) { appendUint(cigar, gapG); cigar.push_back('N'); }
+                else if (gapG > 0) { appendUint(cigar, gapG); cigar.push_back('D'); }
             }
             appendUint(cigar, ex[ii].L); cigar.push_back('M');
         }
-        if (SJmotif.empty()) { SJmotif = ",-1"; SJintron = ",-1"; }
         uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLength[leftMate] : rc.readLength[leftMate] + 1 + rc.readLength[Mate])
                           - ex[iEx2].R - ex[iEx2].L - trimL;
         if (trimR1 > 0) { appendUint(cigar, trimR1); cigar.push_back('S'); }
+    }
+    for (uint32_t imate = 0; imate < nMates; imate++) {
+        uint32_t samFLAG = samFlagCommon;
+        uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
+        uint32_t Mate = ex[iEx1].iFrag;
+        if (Mate == 0) { samFLAG |= Str * 0x10; if (nMates == 2) samFLAG |= (1 - Str) * 0x20; }
+        else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
+        if (flagPaired) samFLAG |= (Mate == 0 ? 0x0040 : 0x0080);
+        if (!tv.primary) samFLAG |= 0x100;
+        const std::string &cigar = matesCIGAR[imate];
+        std::string SJmotif, SJintron;
+        for (uint32_t ii = iEx1 + 1; ii <= iEx2; ii++) {
+            if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) {
+                SJmotif.push_back(','); appendInt(SJmotif, ex[ii - 1].canonSJ + (ex[ii - 1].sjAnnot == 0 ? 0 : 20));   // SJ_SAM_AnnotatedMotifShift
+                SJintron.push_back(','); appendUint(SJintron, ex[ii - 1].G + ex[ii - 1].L + 1 - chrS);
+                SJintron.push_back(','); appendUint(SJintron, ex[ii].G - chrS);
+            }
+        }
+        if (SJmotif.empty()) { SJmotif = ",-1"; SJintron = ",-1"; }
+        // NM / MD (ReadAlign_outputTranscriptSAM.cpp:242-276): read in the orientation of the alignment against the genome text
+        uint64_t tagNM = 0; std::string tagMD;
+        if (P.attrNMorMD) {
+            const uint8_t *rd = b.bases.data() + b.readOffset[ir];
+            uint64_t matchN = 0;
+            for (uint32_t iex = iEx1; iex <= iEx2; iex++) {
+                for (uint32_t ii = 0; ii < ex[iex].L; ii++) {
+                    uint64_t rp = (uint64_t)ex[iex].R + ii;
+                    uint8_t r1 = t.roStr == 0 ? rd[rp] : rd[Lread - 1 - rp];
+                    if (t.roStr != 0 && r1 < 4) r1 = 3 - r1;
+                    uint8_t g1 = gi.G[ex[iex].G + ii];
+                    if (r1 != g1 || r1 == 4 || g1 == 4) { ++tagNM; appendUint(tagMD, matchN); tagMD.push_back("ACGTN"[g1 < 5 ? g1 : 4]); matchN = 0; }
+                    else matchN++;
+                }
+                if (iex < iEx2) {
+                    if (ex[iex].canonSJ == -1) {
+                        tagNM += ex[iex + 1].G - (ex[iex].G + ex[iex].L);
+                        appendUint(tagMD, matchN); tagMD.push_back('^');
+                        for (uint64_t ii = ex[iex].G + ex[iex].L; ii < ex[iex + 1].G; ii++) { uint8_t g1 = gi.G[ii]; tagMD.push_back("ACGTN"[g1 < 5 ? g1 : 4]); }
+                        matchN = 0;
+                    } else if (ex[iex].canonSJ == -2) tagNM += (uint64_t)ex[iex + 1].R - ex[iex].R - ex[iex].L;
+                }
+            }
+            appendUint(tagMD, matchN);
+        }
         int MAPQ = P.outSAMmapqUnique;
         if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
         out += b.name(ir); out.push_back('\t');
@@ -134,6 +170,9 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "jM") { out += "\tjM:B:c"; out += SJmotif; }
             else if (a == "jI") { out += "\tjI:B:i"; out += SJintron; }
             else if (a == "XS") { if (t.sjMotifStrand == 1) out += "\tXS:A:+"; else if (t.sjMotifStrand == 2) out += "\tXS:A:-"; }
+            else if (a == "NM") { out += "\tNM:i:"; appendUint(out, tagNM); }
+            else if (a == "MD") { out += "\tMD:Z:"; out += tagMD; }
+            else if (a == "MC") { if (nMates > 1) { out += "\tMC:Z:"; out += matesCIGAR[1 - imate]; } }
         }
         out.push_back('\n');
     }

@@ -56,6 +56,7 @@ PARAM_SWEEP = {
     "sjfilt": ["--outSJfilterReads", "Unique", "--outSJfilterOverhangMin", "20", "8", "8", "8", "--outSJfilterCountUniqueMin", "2", "1", "1", "1",
                "--outSJfilterDistToOtherSJmin", "5", "0", "3", "5"],
     "winbin": ["--winBinNbits", "14", "--winAnchorDistNbins", "5", "--winFlankNbins", "2"],
+    "attrs": ["--outSAMattributes", "NH", "HI", "NM", "MD", "AS", "nM", "jM", "jI", "MC", "--outSAMunmapped", "Within"],
 }
 
 
