@@ -104,7 +104,7 @@ typedef struct staramd_params {
     uint8_t  outFilterIntronMotifs;         /* 0 None, 1 RemoveNoncanonical, 2 RemoveNoncanonicalUnannotated */
     uint8_t  outSAMstrandFieldIntronMotif;  /* 0 */
     uint8_t  chimSegmentMinPositive;        /* P.pCh.segmentMin>0: record every transcript */
-    uint8_t  outFilterBySJoutStage;         /* 0 (2 => sjNovel whitelist, not supported on device yet) */
+    uint8_t  outFilterBySJoutStage;         /* 0; 1 / 2 = stages of --outFilterType BySJout (2: whitelist of staramd_set_novel_junctions) */
     int32_t  scoreGap, scoreGapNoncan, scoreGapGCAG, scoreGapATAC;   /* 0 -8 -4 -8 */
     int32_t  scoreDelOpen, scoreDelBase, scoreInsOpen, scoreInsBase; /* -2 -2 -2 -2 */
     int32_t  scoreStitchSJshift;            /* 1 */
@@ -199,6 +199,13 @@ int  staramd_create(staramd_ctx **out, int device, const staramd_genome *g, cons
                     uint32_t maxBatchReads, uint64_t maxBatchBases);
 /* Replace the index after sjdbInsertJunctions (two-pass); same semantics as create's upload. */
 int  staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p);
+/* 2nd stage of --outFilterType BySJout.  Replaces the mutation of P.sjNovelStart / P.sjNovelEnd / P.sjNovelN and
+ * P.outFilterBySJoutStage between the two mapping stages (source/STAR.cpp:203-220, source/outputSJ.cpp:139-161): with
+ * stage == 2 a transcript is recorded only if each of its unannotated junctions (start = first intron base, end = last
+ * intron base, genome coordinates) is in this list (source/stitchWindowAligns.cpp:169-177).  The list must be sorted by
+ * (start, end) -- the order of the collapsed junction table it is built from.  stage 0 / 1 turn the check off again.
+ * Only the two small arrays and the parameter block are uploaded; the index stays where it is. */
+int  staramd_set_novel_junctions(staramd_ctx *ctx, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage);
 /* Map one batch: replaces the per-read loop around ReadAlign::mapOneRead. */
 int  staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results *r);
 /* Same, but the batch is taken from the copy already resident in HBM from the previous call with

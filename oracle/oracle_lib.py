@@ -33,6 +33,8 @@ class Oracle:
         L.oracle_get_counters.argtypes = [C.c_void_p, capi.u64p, C.c_int]
         L.oracle_reset_counters.argtypes = [C.c_void_p]
         L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_novel_junctions.restype = C.c_int
+        L.oracle_set_novel_junctions.argtypes = [C.c_void_p, capi.u64p, capi.u64p, C.c_uint64, C.c_uint32]
         self.L = L
         self.h = L.oracle_create(genome_p, params_p)
 
@@ -40,6 +42,9 @@ class Oracle:
         """the index was rewritten on the host (junction insertion): start over on the new arrays"""
         self.L.oracle_destroy(self.h)
         self.h = self.L.oracle_create(genome_p, params_p)
+
+    def set_novel_junctions(self, start, end, n, stage=2):
+        self.L.oracle_set_novel_junctions(self.h, start, end, n, stage)
 
     def map_batch(self, batch, bufs):
         rc = self.L.oracle_map_batch(self.h, C.byref(batch), C.byref(bufs.res))

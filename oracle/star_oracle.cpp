@@ -70,6 +70,7 @@ struct Oracle {
     char *G;
     u64 saMask, saiMask, GstrandMask, SAiMarkAbsentMaskC, SAiMarkNmask, SAiMarkNmaskC;
     u64 cnt[C_N];
+    std::vector<u64> sjNovelStart, sjNovelEnd;   // P.sjNovelStart/End (2nd stage of BySJout)
 
     // per-read state (class ReadAlign)
     std::vector<char> R0, R1, R2; // Read1[0..2]
@@ -667,7 +668,14 @@ struct Oracle {
                     } else if (trA.canonSJ[iex] >= 0) nsj++;
                 }
             }
-            // outFilterBySJoutStage==2 whitelist (:169-177) not part of the configs
+            if (P.outFilterBySJoutStage == 2) {                 // :169-177: unannotated junctions must be in the filtered novel set
+                for (u64 iex = 0; iex + 1 < ne; iex++) {
+                    if (trA.canonSJ[iex] >= 0 && trA.sjAnnot[iex] == 0) {
+                        u64 jS = trA.ex[iex][EX_G] + trA.ex[iex][EX_L], jE = trA.ex[iex + 1][EX_G] - 1;
+                        if (binarySearch2(jS, jE, sjNovelStart.data(), sjNovelEnd.data(), (int)sjNovelStart.size()) < 0) return;
+                    }
+                }
+            }
             if (trA.ex[0][EX_iFrag] != trA.ex[ne - 1][EX_iFrag]) {
                 if (trA.ex[ne - 1][EX_G] + trA.ex[ne - 1][EX_L] <= trA.ex[0][EX_G]) return;
                 u64 iexM2 = ne;
@@ -925,6 +933,13 @@ void *oracle_create(const staramd_genome *g, const staramd_params *p) {
     Oracle *o = new Oracle(); o->init(g, p); return o;
 }
 void oracle_destroy(void *h) { delete (Oracle *)h; }
+// P.sjNovelStart/End + P.outFilterBySJoutStage between the stages of --outFilterType BySJout (outputSJ.cpp:139-161)
+int oracle_set_novel_junctions(void *h, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage) {
+    Oracle *o = (Oracle *)h;
+    o->sjNovelStart.assign(start, start + n); o->sjNovelEnd.assign(end, end + n);
+    o->P.outFilterBySJoutStage = (uint8_t)stage;
+    return 0;
+}
 
 int oracle_map_batch(void *h, const staramd_batch *b, staramd_results *r) {
     Oracle *o = (Oracle *)h;

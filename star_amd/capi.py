@@ -148,6 +148,8 @@ def host_lib():
         L.sah_in_pass1.restype = C.c_int; L.sah_in_pass1.argtypes = [C.c_void_p]
         L.sah_pass1_end.restype = C.c_int; L.sah_pass1_end.argtypes = [C.c_void_p]
         L.sah_insert_log.restype = C.c_char_p; L.sah_insert_log.argtypes = [C.c_void_p]
+        L.sah_next_phase.restype = C.c_int; L.sah_next_phase.argtypes = [C.c_void_p]
+        L.sah_novel_junctions.restype = C.c_uint64; L.sah_novel_junctions.argtypes = [C.c_void_p, C.POINTER(u64p), C.POINTER(u64p)]
         _host = L
     return _host
 
@@ -161,6 +163,8 @@ def engine_lib():
         L.staramd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Genome), C.POINTER(Params), C.c_uint32, C.c_uint64]
         L.staramd_update_index.restype = C.c_int
         L.staramd_update_index.argtypes = [C.c_void_p, C.POINTER(Genome), C.POINTER(Params)]
+        L.staramd_set_novel_junctions.restype = C.c_int
+        L.staramd_set_novel_junctions.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.c_uint32]
         L.staramd_map_batch.restype = C.c_int
         L.staramd_map_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Results)]
         L.staramd_map_resident.restype = C.c_int
@@ -211,6 +215,20 @@ class HostRun:
         if self.L.sah_pass1_end(self.h) != 0:
             raise RuntimeError(self.L.sah_error(self.h).decode())
 
+    def next_phase(self):
+        """After the last batch: 0 = done (finish()); 1 = the index was rewritten by junction insertion (engine.update_index(run.genome,
+        run.params), then map every batch again); 2 = the whitelist of the 2nd BySJout stage was built
+        (engine.set_novel_junctions(*run.novel_junctions()), then map every batch again)."""
+        r = self.L.sah_next_phase(self.h)
+        if r < 0:
+            raise RuntimeError(self.L.sah_error(self.h).decode())
+        return r
+
+    def novel_junctions(self):
+        a, b = u64p(), u64p()
+        n = self.L.sah_novel_junctions(self.h, C.byref(a), C.byref(b))
+        return a, b, n
+
     def finish(self):
         if self.L.sah_finish(self.h) != 0:
             raise RuntimeError(self.L.sah_error(self.h).decode())
@@ -237,6 +255,11 @@ class Engine:
         rc = self.L.staramd_update_index(self.ctx, genome_p, params_p)
         if rc != 0:
             raise RuntimeError("staramd_update_index failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
+
+    def set_novel_junctions(self, start, end, n, stage=2):
+        rc = self.L.staramd_set_novel_junctions(self.ctx, start, end, n, stage)
+        if rc != 0:
+            raise RuntimeError("staramd_set_novel_junctions failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
 
     def map_batch(self, batch, bufs):
         rc = self.L.staramd_map_batch(self.ctx, C.byref(batch), C.byref(bufs.res))

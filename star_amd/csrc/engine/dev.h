@@ -35,6 +35,7 @@ struct DevIndex {
     const u64 *chrStart, *chrLength;
     const u64 *sjDstart, *sjAstart, *sjdbStart, *sjdbEnd;
     const u8 *sjdbMotif, *sjdbShiftLeft, *sjdbShiftRight, *sjdbStrand;
+    const u64 *sjNovelStart, *sjNovelEnd; u64 sjNovelN;       // whitelist of the 2nd stage of BySJout (staramd_set_novel_junctions)
     u64 nGenome, nSA, sjGstart;
     u64 saiStart[17];
     u64 saMask, saiMask, strandMask, saiAbsentBit, saiNbit;
@@ -166,6 +167,7 @@ __device__ __forceinline__ u32 waveSumU32(u32 v) {
 }
 // value of lane srcLane, srcLane wave-uniform
 __device__ __forceinline__ u32 laneGet32(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)srcLane)); }
+__device__ __forceinline__ u64 laneGet64(u64 v, u32 l) { return ((u64)laneGet32((u32)(v >> 32), l) << 32) | laneGet32((u32)v, l); }
 // declare a wave-uniform value to the compiler: every dword goes through v_readfirstlane, so what is computed from it
 // lives in SGPRs and branches on it are scalar branches (s_cbranch_scc) instead of exec-mask sequences
 template <class T> __device__ __forceinline__ T uni(const T &v) {

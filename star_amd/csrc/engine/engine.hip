@@ -150,6 +150,7 @@ static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_pa
     X.saiNbases = g->gSAindexNbases; X.sparseD = g->gSAsparseD;
     X.sjdbOverhang = g->sjdbOverhang; X.sjdbLength = g->sjdbLength ? g->sjdbLength : 1; X.sjdbN = g->sjdbN; X.nChrReal = g->nChrReal;
     X.P = *p;
+    X.sjNovelStart = X.sjNovelEnd = nullptr; X.sjNovelN = 0;
     buildGlBreaks(X, p->scoreGenomicLengthLog2scale);
     { int rc2 = devAlloc(c->indexAllocs, &c->dX, (u64)1); if (rc2) return rc2; }
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
@@ -269,6 +270,23 @@ extern "C" int staramd_update_index(staramd_ctx *c, const staramd_genome *g, con
     HIPCHK(hipDeviceSynchronize());
     freeAll(c->indexAllocs);
     return uploadIndex(c, g, p);
+}
+
+extern "C" int staramd_set_novel_junctions(staramd_ctx *c, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage) {
+    if (!c || (n && (!start || !end))) { g_err = "staramd_set_novel_junctions: null argument"; return STARAMD_ERR_ARG; }
+    if (n > 0xFFFFFFF0ull) { g_err = "staramd_set_novel_junctions: too many junctions"; return STARAMD_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    DevIndex &X = c->X; int rc;
+    for (const u64 *old : {X.sjNovelStart, X.sjNovelEnd})
+        for (size_t i = 0; old && i < c->indexAllocs.size(); i++) if (c->indexAllocs[i] == (void *)old) { (void)hipFree(c->indexAllocs[i]); c->indexAllocs.erase(c->indexAllocs.begin() + i); break; }
+    X.sjNovelStart = X.sjNovelEnd = nullptr; X.sjNovelN = 0;
+    if ((rc = devUpload(c->indexAllocs, &X.sjNovelStart, (const u64 *)start, (u64)n, 1))) return rc;
+    if ((rc = devUpload(c->indexAllocs, &X.sjNovelEnd, (const u64 *)end, (u64)n, 1))) return rc;
+    X.sjNovelN = n;
+    X.P.outFilterBySJoutStage = (uint8_t)stage;
+    HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    return 0;
 }
 
 extern "C" void staramd_destroy(staramd_ctx *c) {

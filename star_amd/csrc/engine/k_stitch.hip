@@ -645,6 +645,13 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             start = e + 1;
         }
     }
+    if (P.outFilterBySJoutStage == 2) {                        // unannotated junctions must be on the whitelist (:169-177)
+        for (u64 nov = __ballot(lane < last && canon >= 0 && annot == 0); nov; nov &= nov - 1) {
+            const u32 l = firstLane(nov);
+            const u64 jS = laneGet64(xe.G, l) + laneGet32(exL, l), jE = laneGet64(xe.G, l + 1) - 1;
+            if (coopSjdbFind(lane, jS, jE, X.sjNovelStart, X.sjNovelEnd, (u32)X.sjNovelN) < 0) return;
+        }
+    }
     if (ex0Frag != exLFrag) {                                  // both mates (:179-219): rare inner loop kept scalar on the LDS rows
         if (exLG + exLL <= ex0G) return;
         u32 iexM2 = ne;

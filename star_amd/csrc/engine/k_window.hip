@@ -57,7 +57,6 @@ __device__ __forceinline__ u64 waveMax64(u64 v) {
     u64 m = __ballot(key == kmax);
     return ((u64)kmax << 32) | laneGet32((u32)v, firstLane(m));
 }
-__device__ __forceinline__ u64 laneGet64(u64 v, u32 l) { return ((u64)laneGet32((u32)(v >> 32), l) << 32) | laneGet32((u32)v, l); }
 __device__ __forceinline__ u32 waveMin32(u32 v) { return ~waveMaxU32(~v); }
 
 // ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; all arguments wave-uniform; returns 1 on TOO_MANY_WINDOWS / overflow

@@ -74,6 +74,7 @@ struct RunParams {
     uint64_t limitSjdbInsertNsj = 1000000;
     std::string sjdbInsertOutDir, twopassDir;
     bool sjdbInsertYes() const { return twopass || !sjdbFileChrStartEnd.empty(); }
+    bool outFilterBySJout = false;       // --outFilterType BySJout
 
     RunParams();
     // STAR-style "--name v1 v2 ..." ; returns error text or ""
@@ -105,6 +106,7 @@ class FastqReader {
 public:
     ~FastqReader();
     std::string open(const std::vector<std::string> &paths);
+    void openMemory(std::string mate1, std::string mate2, int nMatesIn);   // FASTQ text held in memory (2nd stage of BySJout)
     std::string reopen();                 // rewind to the first read (Parameters::closeReadsFiles/openReadsFiles between the two passes)
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
     // + the PE concatenation of ReadAlign::oneRead (ReadAlign_oneRead.cpp:35-78).
@@ -114,6 +116,7 @@ public:
 private:
     FILE *f[2] = {nullptr, nullptr};
     int nMates = 0;
+    std::string mem[2]; size_t memPos[2] = {0, 0}; bool fromMemory = false;
     std::vector<char> carry[2];           // text read from the file but not yet part of a batch
     bool eof[2] = {false, false};
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
@@ -146,8 +149,10 @@ struct OutSJ {
     std::vector<Junction> data;
     void collapse();                                 // OutSJ::collapseSJ, OutSJ.cpp:42-72
     void mergeFrom(const OutSJ &o) { data.insert(data.end(), o.data.begin(), o.data.end()); }
+    std::vector<Junction> filtered(const RunParams &P, bool skipDistanceFilter);
+    void novelWhitelist(const RunParams &P, std::vector<uint64_t> &start, std::vector<uint64_t> &end);
     // outputSJ filter + write (outputSJ.cpp:56-138); returns error text or ""
-    std::string filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path);
+    std::string filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path, bool skipDistanceFilter = false);
 };
 
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
@@ -156,7 +161,10 @@ public:
     PostMap(const RunParams &P, const GenomeIndex &gi) : P(P), gi(gi) {}
     // consumes the device (or oracle) results of one batch; appends SAM text to `sam`
     std::string process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st);
-    std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st) const;
+    // sj1 / held: 1st stage of --outFilterType BySJout (ReadAlign_outputAlignments.cpp:90-124): junctions of every read go to sj1,
+    // reads with an unannotated junction are not output but listed in `held` for the 2nd stage
+    std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
+                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr) const;
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:

@@ -28,8 +28,8 @@ int sah_device(void *h);
 int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
 int sah_emit_slot(void *h, int slot, const staramd_results *res);
 int sah_finish(void *h);
-int sah_in_pass1(void *h);
-int sah_pass1_end(void *h);
+int sah_next_phase(void *h);
+uint64_t sah_novel_junctions(void *h, const uint64_t **start, const uint64_t **end);
 const char *sah_error(void *h);
 void sah_destroy(void *h);
 }
@@ -109,15 +109,25 @@ int main(int argc, char **argv) {
         mapped.close();
         reader.join(); writer.join();
     };
-    if (sah_in_pass1(h)) {
-        // --twopassMode Basic (twoPassRunPass1.cpp:9-96): 1st pass without SAM, the junctions it finds are inserted into the
-        // index on the host (sjdb_insert.cpp), the HBM copy is replaced, then the reads are mapped again
+    // phases (sah_next_phase): plain run = one; --twopassMode Basic adds a 1st pass without SAM, after which the junctions it found
+    // are inserted into the index on the host (sjdb_insert.cpp) and the HBM copy is replaced (twoPassRunPass1.cpp:9-96);
+    // --outFilterType BySJout adds a 2nd stage over the held reads with the filtered novel junctions as a whitelist (STAR.cpp:203-220)
+    for (;;) {
         mapAllBatches();
-        if (failure.empty() && sah_pass1_end(h)) fail(sah_error(h));
-        if (failure.empty() && staramd_update_index(ctx, sah_genome(h), sah_params(h))) fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + staramd_last_error());
-        if (failure.empty()) { double s1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); fprintf(stderr, "star_amd: 1st pass + junction insertion + index re-upload: %.3f s (%llu reads)\n", s1, (unsigned long long)nReads); }
+        if (!failure.empty()) break;
+        int phase = sah_next_phase(h);
+        if (phase < 0) { fail(sah_error(h)); break; }
+        if (phase == 0) break;
+        if (phase == 1) {
+            if (staramd_update_index(ctx, sah_genome(h), sah_params(h))) { fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + staramd_last_error()); break; }
+            double s1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "star_amd: 1st pass + junction insertion + index re-upload: %.3f s (%llu reads)\n", s1, (unsigned long long)nReads);
+        } else {
+            const uint64_t *ns, *ne; uint64_t nn = sah_novel_junctions(h, &ns, &ne);
+            if (staramd_set_novel_junctions(ctx, ns, ne, nn, 2)) { fail(std::string("EXITING because of FATAL ERROR: ") + staramd_last_error()); break; }
+            fprintf(stderr, "star_amd: BySJout stage 1 done (%llu reads so far), %llu novel junctions passed filtering\n", (unsigned long long)nReads, (unsigned long long)nn);
+        }
     }
-    if (failure.empty()) mapAllBatches();
     if (!failure.empty()) { fprintf(stderr, "\n%s\n", failure.c_str()); return 104; }
     if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

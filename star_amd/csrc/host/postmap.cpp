@@ -207,7 +207,34 @@ std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::
 
 // reads [lo, hi) of the batch: the reference's per-thread ReadAlign loop body (ReadAlign_oneRead.cpp:87-111); ranges of one
 // batch are independent (per-thread SAM buffer, junction table and Stats, merged by the caller in read order)
-std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st) const {
+// recordSJ (ReadAlign_outputAlignments.cpp:76-87) -> outputTranscriptSJ (ReadAlign_outputTranscriptSJ.cpp:14-55)
+static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint64_t nTr, OutSJ &sj) {
+    if (P.outSJfilterReadsUnique && nTr != 1) return;
+    size_t sjReadStartN = sj.data.size();
+    for (uint64_t it = 0; it < nTr; it++) {
+        const staramd_transcript &t = *trMult[it].t; const staramd_exon *ex = trMult[it].ex;
+        for (uint32_t iex = 0; iex + 1 < t.nExons; iex++) {
+            if (ex[iex].canonSJ < 0) continue;
+            Junction j; j.start = ex[iex].G + ex[iex].L; j.gap = (uint32_t)(ex[iex + 1].G - j.start);
+            j.overhangLeft = (uint16_t)std::min<uint32_t>(ex[iex].L, ex[iex + 1].L); j.overhangRight = j.overhangLeft;
+            bool dup = false;
+            for (size_t ii = sjReadStartN; ii < sj.data.size(); ii++) {
+                if (sj.data[ii].start == j.start && sj.data[ii].gap == j.gap) {
+                    dup = true;
+                    if (sj.data[ii].overhangLeft < j.overhangLeft) { sj.data[ii].overhangLeft = j.overhangLeft; sj.data[ii].overhangRight = j.overhangLeft; }
+                    break;
+                }
+            }
+            if (dup) continue;
+            j.motif = ex[iex].canonSJ; j.strand = (int8_t)(ex[iex].canonSJ == 0 ? 0 : (ex[iex].canonSJ + 1) % 2 + 1); j.annot = (int8_t)ex[iex].sjAnnot;
+            if (nTr == 1) { j.countUnique = 1; j.countMultiple = 0; } else { j.countMultiple = 1; j.countUnique = 0; }
+            sj.data.push_back(j);
+        }
+    }
+}
+
+std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
+                                  OutSJ *sj1, std::vector<uint32_t> *held) const {
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];
@@ -243,6 +270,14 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                  || (trBest->nMatch < P.outFilterMatchNmin) || (trBest->nMatch < (uint64_t)(P.outFilterMatchNminOverLread * (double)(rc.Lread - 1)))) { st.unmappedShort++; unmapType = 1; }
         else if ((trBest->nMM > b.mmMaxTotal[ir]) || (double(trBest->nMM) / double(trBest->rLength) > P.dev.outFilterMismatchNoverLmax)) { st.unmappedMismatch++; unmapType = 2; }
         else if (nTr > P.outFilterMultimapNmax) { st.unmappedMulti++; unmapType = 3; }
+        // ---- outFilterBySJout, 1st stage (ReadAlign_outputAlignments.cpp:90-124)
+        if (sj1 && unmapType <= 0) {
+            bool pass = true;
+            for (uint64_t it = 0; it < nTr && pass; it++)
+                for (uint32_t k = 0; k + 1 < trMult[it].t->nExons; k++) if (trMult[it].ex[k].canonSJ >= 0 && trMult[it].ex[k].sjAnnot == 0) { pass = false; break; }
+            recordSJ(P, trMult, nTr, *sj1);                 // junctions of every read, held or not
+            if (!pass) { st.readN--; st.readBases -= rc.readLength[0] + rc.readLength[1]; held->push_back(ir); continue; }
+        }
         // ---- outputAlignments
         bool mateMapped[2] = {false, false};
         if (unmapType < 0) {
@@ -256,30 +291,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                 for (uint32_t k = 0; k + 1 < t.nExons; k++) { if (ex[k].canonSJ >= 0) st.splicesN[ex[k].canonSJ]++; if (ex[k].sjAnnot == 1) st.splicesNsjdb++; }
                 st.mappedBases += mappedL; st.mappedPortion += double(mappedL) / double(rc.Lread);
             }
-            // recordSJ (:76-87) -> outputTranscriptSJ
-            if (!P.outSJfilterReadsUnique || nTr == 1) {
-                size_t sjReadStartN = sj.data.size();
-                for (uint64_t it = 0; it < nTr; it++) {
-                    const staramd_transcript &t = *trMult[it].t; const staramd_exon *ex = trMult[it].ex;
-                    for (uint32_t iex = 0; iex + 1 < t.nExons; iex++) {
-                        if (ex[iex].canonSJ < 0) continue;
-                        Junction j; j.start = ex[iex].G + ex[iex].L; j.gap = (uint32_t)(ex[iex + 1].G - j.start);
-                        j.overhangLeft = (uint16_t)std::min<uint32_t>(ex[iex].L, ex[iex + 1].L); j.overhangRight = j.overhangLeft;
-                        bool dup = false;
-                        for (size_t ii = sjReadStartN; ii < sj.data.size(); ii++) {
-                            if (sj.data[ii].start == j.start && sj.data[ii].gap == j.gap) {
-                                dup = true;
-                                if (sj.data[ii].overhangLeft < j.overhangLeft) { sj.data[ii].overhangLeft = j.overhangLeft; sj.data[ii].overhangRight = j.overhangLeft; }
-                                break;
-                            }
-                        }
-                        if (dup) continue;
-                        j.motif = ex[iex].canonSJ; j.strand = (int8_t)(ex[iex].canonSJ == 0 ? 0 : (ex[iex].canonSJ + 1) % 2 + 1); j.annot = (int8_t)ex[iex].sjAnnot;
-                        if (nTr == 1) { j.countUnique = 1; j.countMultiple = 0; } else { j.countMultiple = 1; j.countUnique = 0; }
-                        sj.data.push_back(j);
-                    }
-                }
-            }
+            recordSJ(P, trMult, nTr, sj);
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
             if (!samOff) for (uint64_t it = 0; it < nTr; it++) samMapped(sam, P, gi, rc, trMult[it], nTr, it);
             const staramd_exon *exB = r.ex + trBest->exonOffset;

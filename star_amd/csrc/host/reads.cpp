@@ -43,7 +43,15 @@ std::string FastqReader::open(const std::vector<std::string> &paths) {
     return "";
 }
 
+void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn) {
+    nMates = nMatesIn; fromMemory = true;
+    mem[0].swap(mate1); mem[1].swap(mate2);
+    for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; }
+    readsSoFar = 0;
+}
+
 std::string FastqReader::reopen() {
+    if (fromMemory) { for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; } readsSoFar = 0; return ""; }
     for (int i = 0; i < nMates; i++) {
         if (fseek(f[i], 0, SEEK_SET) != 0) return "EXITING because of fatal input ERROR: could not rewind the read file";
         carry[i].clear(); eof[i] = false;
@@ -95,7 +103,9 @@ uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
         uint64_t block = std::max<uint64_t>(1u << 16, std::min<uint64_t>(64u << 20, (uint64_t)((double)missing * bytesPerRecord[m] * 1.01) + 4096));
         size_t old = text.size();
         text.resize(old + block);
-        size_t got = fread(text.data() + old, 1, block, f[m]);
+        size_t got;
+        if (fromMemory) { got = std::min<size_t>(block, mem[m].size() - memPos[m]); memcpy(text.data() + old, mem[m].data() + memPos[m], got); memPos[m] += got; }
+        else got = fread(text.data() + old, 1, block, f[m]);
         text.resize(old + got);
         if (got < block) eof[m] = true;
     }

@@ -31,6 +31,12 @@ struct Runner {
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
     std::string insertLog;
     bool pass1 = false;
+    // --outFilterType BySJout (STAR.cpp:203-220): stage 1 maps everything and holds reads with unannotated junctions, stage 2 maps
+    // the held reads again with the filtered novel junctions as a whitelist inside the stitcher
+    int bySJoutStage = 0;               // 0 off, 1, 2
+    OutSJ sj1;                          // junctions of every read of stage 1 (chunkOutSJ1)
+    std::string heldText[2];            // held reads as FASTQ text
+    std::vector<uint64_t> novelStart, novelEnd;
     int64_t readMapNumberUser = -1;
 
     bool init(int argc, char **argv) {
@@ -62,6 +68,7 @@ struct Runner {
         error = reader.open(P.readFilesIn);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
+        if (P.outFilterBySJout && !P.twopass) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         if (P.twopass) {                                            // twoPassRunPass1.cpp:14-47: no SAM, own read limit
             pass1 = true; post->samOff = true; readMapNumberUser = P.readMapNumber;
             if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
@@ -120,8 +127,14 @@ struct Runner {
         if (o.sams.size() < T) o.sams.resize(T);
         o.used = T;
         std::vector<std::string> errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
+        const bool stage1 = bySJoutStage == 1;
+        std::vector<OutSJ> sj1s(stage1 ? T : 0); std::vector<std::vector<uint32_t> > helds(stage1 ? T : 0);
         uint32_t per = (bt.n + T - 1) / T;
-        auto work = [&](uint32_t t) { uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per); o.sams[t].clear(); errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t]); };
+        auto work = [&](uint32_t t) {
+            uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
+            o.sams[t].clear();
+            errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr);
+        };
         if (T == 1) work(0);
         else {
             std::vector<std::thread> th;
@@ -135,6 +148,18 @@ struct Runner {
         wcv.notify_all();
         if (!error.empty()) return false;
         for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); }
+        if (stage1) {
+            for (uint32_t t = 0; t < T; t++) {
+                sj1.mergeFrom(sj1s[t]);
+                for (uint32_t ir : helds[t])                         // held reads, in input order (ReadAlign_outputAlignments.cpp:108-121)
+                    for (uint32_t m = 0; m < P.dev.readNmates; m++) {
+                        std::string &x = heldText[m];
+                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0\n" : " 0:N:0\n";
+                        x += bt.seq((int)m, ir); x += "\n+\n"; x += bt.qual((int)m, ir); x.push_back('\n');
+                    }
+            }
+            if (sj1.data.size() > 4000000) sj1.collapse();
+        }
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
         return true;
@@ -155,13 +180,32 @@ struct Runner {
         stats = Stats(); stats.timeStart = t0; time(&stats.timeStartMap);
         sj.data.clear();
         P.readMapNumber = readMapNumberUser; post->samOff = false; pass1 = false;
+        if (P.outFilterBySJout) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         return true;
+    }
+    // end of the 1st stage of BySJout (STAR.cpp:203-216, outputSJ.cpp:139-161): whitelist = filtered unannotated junctions of
+    // ALL reads of stage 1; the held reads become the input of stage 2.  The caller hands the whitelist to the engine.
+    bool endStage1() {
+        if (bySJoutStage != 1) { error = "not in the 1st stage of BySJout"; return false; }
+        sj1.novelWhitelist(P, novelStart, novelEnd);
+        sj1.data.clear(); sj1.data.shrink_to_fit();
+        reader.openMemory(std::move(heldText[0]), std::move(heldText[1]), (int)P.dev.readNmates);
+        P.readMapNumber = -1;
+        bySJoutStage = 2; P.dev.outFilterBySJoutStage = 2;
+        return true;
+    }
+    // what the caller has to do after the last batch of a phase: 0 = finish(); 1 = the index changed (staramd_update_index), map
+    // again; 2 = the junction whitelist changed (staramd_set_novel_junctions), map again
+    int nextPhase() {
+        if (pass1) return endPass1() ? 1 : -1;
+        if (bySJoutStage == 1) return endStage1() ? 2 : -1;
+        return 0;
     }
     bool finish() {
         stopWriter();
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (samOut) { fclose(samOut); samOut = nullptr; }
-        error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab");
+        error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
         return true;
@@ -213,6 +257,15 @@ int sah_threads(void *h) { return ((Runner *)h)->P.runThreadN; }
 // (junction insertion on the host), re-upload sah_genome()/sah_params() with staramd_update_index(), map all batches again.
 int sah_in_pass1(void *h) { return ((Runner *)h)->pass1 ? 1 : 0; }
 int sah_pass1_end(void *h) { return ((Runner *)h)->endPass1() ? 0 : -1; }
+// general form (2-pass and/or --outFilterType BySJout): after the last batch call sah_next_phase(): 0 = done, call sah_finish();
+// 1 = the index was rewritten: staramd_update_index(sah_genome(), sah_params()) and map every batch again; 2 = the junction
+// whitelist was built: staramd_set_novel_junctions(sah_novel_junctions(...), stage 2) and map every batch again; < 0 = error
+int sah_next_phase(void *h) { return ((Runner *)h)->nextPhase(); }
+uint64_t sah_novel_junctions(void *h, const uint64_t **start, const uint64_t **end) {
+    Runner *r = (Runner *)h;
+    *start = r->novelStart.data(); *end = r->novelEnd.data();
+    return r->novelStart.size();
+}
 const char *sah_insert_log(void *h) { return ((Runner *)h)->insertLog.c_str(); }
 int sah_finish(void *h) { return ((Runner *)h)->finish() ? 0 : -1; }
 // ---- end-of-run exchange between ranks (one process per GPU) -------------------------------------

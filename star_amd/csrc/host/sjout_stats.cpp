@@ -24,7 +24,9 @@ void OutSJ::collapse() {
     data.resize(k + 1);
 }
 
-std::string OutSJ::filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path) {
+// outputSJ.cpp:56-120: collapse, per-junction filter, then (unless `skipDistanceFilter`, 2nd stage of BySJout :84) the distance
+// to other junctions' donors / acceptors
+std::vector<Junction> OutSJ::filtered(const RunParams &P, bool skipDistanceFilter) {
     collapse();
     // per-junction filter (outputSJ.cpp:59-65)
     std::vector<Junction> all;
@@ -37,6 +39,7 @@ std::string OutSJ::filterAndWrite(const RunParams &P, const GenomeIndex &gi, con
                    && (tot > P.outSJfilterIntronMaxVsReadN.size() || j.gap <= (uint32_t)P.outSJfilterIntronMaxVsReadN[tot - 1]));
         if (ok) all.push_back(j);
     }
+    if (skipDistanceFilter) return all;
     // distance to other junctions' donors / acceptors (:85-120)
     size_t N = all.size();
     std::vector<char> keep(N, 0);
@@ -64,6 +67,21 @@ std::string OutSJ::filterAndWrite(const RunParams &P, const GenomeIndex &gi, con
             keep[sjA[ii].idx] = keep[sjA[ii].idx] && (minDist >= (uint64_t)P.outSJfilterDistToOtherSJmin[(sjA[ii].motif + 1) / 2]);
         }
     }
+    std::vector<Junction> out;
+    for (size_t ii = 0; ii < N; ii++) if (keep[ii]) out.push_back(all[ii]);
+    return out;
+}
+
+// P.sjNovelStart/End after the 1st stage of --outFilterType BySJout (outputSJ.cpp:139-161): unannotated junctions that pass
+void OutSJ::novelWhitelist(const RunParams &P, std::vector<uint64_t> &start, std::vector<uint64_t> &end) {
+    start.clear(); end.clear();
+    for (const Junction &j : filtered(P, false)) if (j.annot == 0) { start.push_back(j.start); end.push_back(j.start + (uint64_t)j.gap - 1); }
+}
+
+std::string OutSJ::filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path, bool skipDistanceFilter) {
+    std::vector<Junction> all = filtered(P, skipDistanceFilter);
+    size_t N = all.size();
+    std::vector<char> keep(N, 1);
     std::ofstream out(path.c_str());
     if (!out.good()) return "EXITING because of fatal ERROR: could not create output file " + path;
     for (size_t ii = 0; ii < N; ii++) {

@@ -91,10 +91,13 @@ def run_with_engine(info, prefix, engine_factory, batch_reads=777):
                 bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
                 eng.map_batch(b, bufs)
                 run.emit(bufs.res)
-            if not run.in_pass1():
+            phase = run.next_phase()
+            if phase == 0:
                 break
-            run.pass1_end()                       # --twopassMode Basic: junction insertion, then the 2nd pass
-            eng.update_index(run.genome, run.params)
+            if phase == 1:                        # --twopassMode Basic: junctions were inserted into the host index
+                eng.update_index(run.genome, run.params)
+            else:                                 # --outFilterType BySJout: 2nd stage, held reads against the filtered junctions
+                eng.set_novel_junctions(*run.novel_junctions())
         run.finish()
     finally:
         eng.close()
