@@ -138,7 +138,7 @@ def _fastq_block(prefix, ids, seq, qual_char=b"I"):
 
 
 def make_reads(rng, seqs, trs, n_reads, read_len, paired, frac_spliced=0.7, sub_rate=0.01,
-               n_rate=0.001, frag=(200, 500), indel_rate=0.0):
+               n_rate=0.001, frag=(200, 500), indel_rate=0.0, chim_rate=0.0):
     """Sample reads (or pairs).  Spliced reads come from the concatenated transcript
     sequences ("transcriptome"), genomic reads from the chromosomes.  Returns
     (mate1[n,L], mate2[n,L] or None) as uint8 ASCII matrices.  Mate 2 is the reverse
@@ -236,6 +236,18 @@ def make_reads(rng, seqs, trs, n_reads, read_len, paired, frac_spliced=0.7, sub_
     m1 = m1[perm]
     if paired:
         m2 = m2[perm]
+    if chim_rate > 0:
+        # chimeric pairs: mates from different loci, or a read whose two halves come from different
+        # loci.  Own generator: data sets without chimeras keep their random stream.
+        rng2 = np.random.default_rng(977)
+        rows = np.flatnonzero(rng2.random(n_reads) < chim_rate)
+        other = rng2.integers(0, n_reads, size=rows.shape[0])
+        for r, o in zip(rows, other):
+            if paired and rng2.random() < 0.5:
+                m2[r] = m2[o].copy()
+            else:
+                cut = int(rng2.integers(L // 4, 3 * L // 4))
+                m1[r, cut:] = m1[o, cut:].copy()
     return m1, m2
 
 
