@@ -37,6 +37,7 @@ struct RunParams {
     // run
     std::string genomeDir, outFileNamePrefix = "./";
     std::vector<std::string> readFilesIn;
+    std::string readFilesCommand;        // --readFilesCommand, "" = read the files directly
     int runThreadN = 1;
     int64_t readMapNumber = -1;
     std::string commandLine;
@@ -105,7 +106,8 @@ struct ReadBatch {
 class FastqReader {
 public:
     ~FastqReader();
-    std::string open(const std::vector<std::string> &paths);
+    // readCommand: --readFilesCommand (e.g. "zcat", "gunzip -c"); the text then comes from a pipe (Parameters_openReadsFiles.cpp:23-96)
+    std::string open(const std::vector<std::string> &paths, const std::string &readCommand = "");
     void openMemory(std::string mate1, std::string mate2, int nMatesIn);   // FASTQ text held in memory (2nd stage of BySJout)
     std::string reopen();                 // rewind to the first read (Parameters::closeReadsFiles/openReadsFiles between the two passes)
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
@@ -116,6 +118,8 @@ public:
 private:
     FILE *f[2] = {nullptr, nullptr};
     int nMates = 0;
+    std::vector<std::string> paths_; std::string command_;
+    void closeFiles();
     std::string mem[2]; size_t memPos[2] = {0, 0}; bool fromMemory = false;
     std::vector<char> carry[2];           // text read from the file but not yet part of a batch
     bool eof[2] = {false, false};

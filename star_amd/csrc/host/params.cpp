@@ -69,6 +69,7 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "genomeDir") genomeDir = one(k, v);
         else if (k == "readFilesIn") readFilesIn = v;
         else if (k == "outFileNamePrefix") outFileNamePrefix = one(k, v);
+        else if (k == "readFilesCommand") { readFilesCommand.clear(); if (!(v.size() == 1 && v[0] == "-")) for (auto &t : v) readFilesCommand += (readFilesCommand.empty() ? "" : " ") + t; }
         else if (k == "runThreadN") runThreadN = (int)I(k, v);
         else if (k == "readMapNumber") readMapNumber = I(k, v);
         else if (k == "gpuBatchReads") gpuBatchReads = U(k, v);

@@ -15,6 +15,7 @@
 #include <functional>
 #include <immintrin.h>
 #include <chrono>
+#include <unistd.h>
 
 namespace staramd {
 
@@ -30,16 +31,27 @@ void ReadBatch::clear() {
     for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); }
 }
 
-FastqReader::~FastqReader() { for (int i = 0; i < 2; i++) if (f[i]) fclose(f[i]); }
+void FastqReader::closeFiles() {
+    for (int i = 0; i < 2; i++) if (f[i]) { if (command_.empty()) fclose(f[i]); else pclose(f[i]); f[i] = nullptr; }
+}
+FastqReader::~FastqReader() { closeFiles(); }
 
-std::string FastqReader::open(const std::vector<std::string> &paths) {
-    nMates = (int)paths.size();
+std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand) {
+    closeFiles();
+    nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false;
     for (int i = 0; i < nMates; i++) {
-        f[i] = fopen(paths[i].c_str(), "rb");
+        if (command_.empty()) f[i] = fopen(paths[i].c_str(), "rb");
+        else {
+            if (access(paths[i].c_str(), R_OK) != 0) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + paths[i];
+            std::string q = paths[i], esc;
+            for (char c : q) { if (c == '\'') esc += "'\\''"; else esc.push_back(c); }
+            f[i] = popen((command_ + " '" + esc + "'").c_str(), "r");
+        }
         if (!f[i]) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + paths[i];
         setvbuf(f[i], nullptr, _IONBF, 0);          // blocks are read straight into the batch text
         carry[i].clear(); eof[i] = false;
     }
+    readsSoFar = 0;
     return "";
 }
 
@@ -52,6 +64,7 @@ void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn)
 
 std::string FastqReader::reopen() {
     if (fromMemory) { for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; } readsSoFar = 0; return ""; }
+    if (!command_.empty()) return open(paths_, command_);      // a pipe cannot be rewound: run the command again
     for (int i = 0; i < nMates; i++) {
         if (fseek(f[i], 0, SEEK_SET) != 0) return "EXITING because of fatal input ERROR: could not rewind the read file";
         carry[i].clear(); eof[i] = false;
@@ -105,7 +118,7 @@ uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
         text.resize(old + block);
         size_t got;
         if (fromMemory) { got = std::min<size_t>(block, mem[m].size() - memPos[m]); memcpy(text.data() + old, mem[m].data() + memPos[m], got); memPos[m] += got; }
-        else got = fread(text.data() + old, 1, block, f[m]);
+        else got = fread(text.data() + old, 1, block, f[m]);      // (fread itself loops over short pipe reads until EOF)
         text.resize(old + got);
         if (got < block) eof[m] = true;
     }

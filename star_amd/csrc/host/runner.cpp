@@ -65,7 +65,7 @@ struct Runner {
             error = sjdbInsertJunctions(P, gi, sjdbLoci, false, "", insertLog);
             if (!error.empty()) return false;
         }
-        error = reader.open(P.readFilesIn);
+        error = reader.open(P.readFilesIn, P.readFilesCommand);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
         if (P.outFilterBySJout && !P.twopass) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }

@@ -106,3 +106,20 @@ def test_two_pass_parameter_errors(tmp_path, built):
         with pytest.raises(RuntimeError) as e:
             capi.HostRun(base + extra)
         assert text in str(e.value)
+
+
+def test_compressed_input_through_read_command(tmp_path, built):
+    """--readFilesCommand zcat / gunzip -c: the text comes from a pipe; the 2nd pass runs the command again"""
+    import subprocess
+    info = dict(prepare("pe101", str(tmp_path), need_ref=False))
+    gz = []
+    for f in info["fastq"]:
+        subprocess.check_call("gzip -c '%s' > '%s.gz'" % (f, f), shell=True)
+        gz.append(f + ".gz")
+    info["fastq"] = gz
+    d = os.path.dirname(gz[0])
+    for k, cmd in enumerate((["zcat"], ["gunzip", "-c"])):
+        info["extra"] = ["--readFilesCommand"] + cmd + ["--twopassMode", "Basic"]
+        ref = refstar.align(info["idx"], gz, os.path.join(d, "refgz%d_" % k), threads=1, extra=info["extra"])
+        new = run_with_engine(info, os.path.join(d, "newgz%d_" % k), _oracle)
+        assert not compare_outputs(ref, new)
