@@ -70,11 +70,14 @@ struct RunParams {
     bool twopass = false;                // --twopassMode Basic
     int64_t twopass1readsN = -1; bool twopass1Set = false;
     std::vector<std::string> sjdbFileChrStartEnd;
+    std::string sjdbGTFfile, sjdbGTFchrPrefix = "-", sjdbGTFfeatureExon = "exon", sjdbGTFtagExonParentTranscript = "transcript_id", sjdbGTFtagExonParentGene = "gene_id";
+    std::vector<std::string> sjdbGTFtagExonParentGeneName = {"gene_name"}, sjdbGTFtagExonParentGeneType = {"gene_type", "gene_biotype"};
     uint32_t sjdbOverhang = 100; bool sjdbOverhangSet = false;
     bool sjdbInsertSaveAll = false;      // --sjdbInsertSave Basic | All
     uint64_t limitSjdbInsertNsj = 1000000;
     std::string sjdbInsertOutDir, twopassDir;
-    bool sjdbInsertYes() const { return twopass || !sjdbFileChrStartEnd.empty(); }
+    bool sjdbInsertPass1() const { return !sjdbFileChrStartEnd.empty() || !sjdbGTFfile.empty(); }
+    bool sjdbInsertYes() const { return twopass || sjdbInsertPass1(); }
     bool outFilterBySJout = false;       // --outFilterType BySJout
 
     RunParams();
@@ -135,6 +138,8 @@ void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci);            // sjdbLoa
 // sjdbInsertJunctions.cpp:11-102: rewrites gi (G, SA, SAi, junction table) and P.dev.winBinN; returns error text or ""
 std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, bool pass2, const std::string &pass1sjFile, std::string &log);
 std::string makeRunDir(const std::string &d);
+// --sjdbGTFfile at the mapping stage (gtf.cpp): junctions of the annotation appended to `loci` with priority 20
+std::string loadGTFjunctions(const RunParams &P, const GenomeIndex &gi, SjdbLoci &loci, const std::string &dirOut, std::string &log);
 
 // ---- Stats (source/Stats.{h,cpp}) ----
 struct Stats {

@@ -79,7 +79,13 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "sjdbOverhang") { sjdbOverhang = (uint32_t)U(k, v); sjdbOverhangSet = true; }
         else if (k == "sjdbInsertSave") { const std::string &m = one(k, v); if (m == "All") sjdbInsertSaveAll = true; else if (m != "Basic") err = "EXITING: unsupported --sjdbInsertSave " + m; }
         else if (k == "limitSjdbInsertNsj") limitSjdbInsertNsj = U(k, v);
-        else if (k == "sjdbGTFfile") { if (one(k, v) != "-") err = "EXITING: --sjdbGTFfile at the mapping stage is not implemented; convert the annotation with reference STAR (genomeGenerate) or pass the junctions with --sjdbFileChrStartEnd"; }
+        else if (k == "sjdbGTFfile") { if (one(k, v) != "-") sjdbGTFfile = one(k, v); }
+        else if (k == "sjdbGTFchrPrefix") sjdbGTFchrPrefix = one(k, v);
+        else if (k == "sjdbGTFfeatureExon") sjdbGTFfeatureExon = one(k, v);
+        else if (k == "sjdbGTFtagExonParentTranscript") sjdbGTFtagExonParentTranscript = one(k, v);
+        else if (k == "sjdbGTFtagExonParentGene") sjdbGTFtagExonParentGene = one(k, v);
+        else if (k == "sjdbGTFtagExonParentGeneName") sjdbGTFtagExonParentGeneName = v;
+        else if (k == "sjdbGTFtagExonParentGeneType") sjdbGTFtagExonParentGeneType = v;
         else if (k == "gpuDevice") gpuDevice = (int)I(k, v);
         else if (k == "genomeLoad") { if (one(k, v) != "NoSharedMemory") err = "EXITING: --genomeLoad: the index lives in HBM; only NoSharedMemory is accepted"; }
         else if (k == "outSAMtype") { if (v.empty() || v[0] != "SAM") err = "EXITING: only --outSAMtype SAM is implemented (BAM: SURVEY.md 8f next #3)"; }

@@ -61,7 +61,7 @@ struct Runner {
             if (P.twopass) { P.twopassDir = P.outFileNamePrefix + "_STARpass1/"; error = makeRunDir(P.twopassDir); if (!error.empty()) return false; }
         }
         P.finalize(gi);
-        if (!P.sjdbFileChrStartEnd.empty()) {                       // STAR.cpp:147-150: insertion before the (1st) mapping pass
+        if (P.sjdbInsertPass1()) {                                  // STAR.cpp:147-150: insertion before the (1st) mapping pass
             error = sjdbInsertJunctions(P, gi, sjdbLoci, false, "", insertLog);
             if (!error.empty()) return false;
         }

@@ -443,6 +443,8 @@ std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, b
             sjdbLoadFromStream(in, loci);
             loci.priority.resize(loci.chr.size(), 10);
         }
+        std::string e = loadGTFjunctions(P, gi, loci, outDir, log);        // GTF gtf(...); gtf.transcriptGeneSJ(...) (:45-46)
+        if (!e.empty()) return e;
     }
     std::string err = sjdbPrepareAndBuild(P, gi, loci, outDir, log);
     if (!err.empty()) return err;

@@ -123,3 +123,22 @@ def test_compressed_input_through_read_command(tmp_path, built):
         ref = refstar.align(info["idx"], gz, os.path.join(d, "refgz%d_" % k), threads=1, extra=info["extra"])
         new = run_with_engine(info, os.path.join(d, "newgz%d_" % k), _oracle)
         assert not compare_outputs(ref, new)
+
+
+GTF_FILES = INDEX_FILES + ["sjdbList.fromGTF.out.tab", "exonInfo.tab", "transcriptInfo.tab", "geneInfo.tab", "exonGeTrInfo.tab"]
+
+
+@pytest.mark.parametrize("name,more", [("se50", []), ("pe101", ["--twopassMode", "Basic"])])
+def test_gtf_at_the_mapping_stage(name, more, tmp_path, built):
+    """--sjdbGTFfile with alignReads (star_amd/csrc/host/gtf.cpp): junctions of the annotation inserted before mapping; the tables
+    the reference derives from the GTF are written too and must be identical"""
+    info = dict(prepare(name, str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    info["extra"] = list(info["extra"]) + ["--sjdbGTFfile", info["gtf"], "--sjdbInsertSave", "All"] + more
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refG_"), threads=1, extra=info["extra"])
+    new = run_with_engine(info, os.path.join(d, "newG_"), _oracle)
+    problems = compare_outputs(ref, new)
+    for f in GTF_FILES:
+        if open(ref + "_STARgenome/" + f, "rb").read() != open(new + "_STARgenome/" + f, "rb").read():
+            problems.append("_STARgenome/%s differs" % f)
+    assert not problems, problems
