@@ -138,7 +138,8 @@ def cli_end_to_end(d, args):
         return None
     threads = min(os.cpu_count() or 1, 64)
     cmd = [exe, "--runMode", "alignReads", "--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + \
-          ["--outFileNamePrefix", os.path.join(d, "cli_"), "--runThreadN", str(threads), "--gpuBatchReads", str(min(args.reads, 200000))]
+          ["--outFileNamePrefix", os.path.join(d, "cli_"), "--runThreadN", str(threads), "--gpuBatchReads", str(min(args.reads, 200000)),
+           "--readMapNumber", str(min(args.cpu_sample, args.reads) * rep)]           # the same reads the CPU baseline leg maps
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     m = re.search(r"star_amd: (\d+) reads, ([0-9.]+) s wall in the mapping loop \(([0-9.]+) s on the device\)", p.stderr)
     if p.returncode != 0 or not m:
@@ -146,6 +147,32 @@ def cli_end_to_end(d, args):
     n, wall, dev = int(m.group(1)), float(m.group(2)), float(m.group(3))
     return {"value": n / wall / 1e6, "unit": "Mreads/s", "reads": n, "wall_s": wall, "device_s": dev, "host_threads": threads,
             "what": "star_amd CLI end to end: FASTQ in -> Aligned.out.sam + SJ.out.tab out (index load excluded)"}
+
+
+def full_size_parity(d):
+    """Parity at the size of the bench run (size-independent properties): the reference's outputs of the cpu_baseline leg and the
+    CLI's outputs of the cli_end_to_end leg come from the same FASTQ -- SJ.out.tab and the Log.final.out counters must be identical,
+    and the SAM bodies must be the same multiset of records (thread interleaving reorders them): record count + order-independent
+    sum of 64-bit record hashes."""
+    import hashlib
+    from oracle import refstar
+    ref, new = os.path.join(d, "cpu_"), os.path.join(d, "cli_")
+    if not all(os.path.isfile(p + f) for p in (ref, new) for f in ("Aligned.out.sam", "SJ.out.tab", "Log.final.out")):
+        return None
+
+    def digest(path):
+        n, acc = 0, 0
+        with open(path, "rb") as f:
+            for l in f:
+                if l[:1] == b"@":
+                    continue
+                acc = (acc + int.from_bytes(hashlib.blake2b(l, digest_size=8).digest(), "little")) & 0xFFFFFFFFFFFFFFFF
+                n += 1
+        return n, acc
+    (na, ha), (nb, hb) = digest(ref + "Aligned.out.sam"), digest(new + "Aligned.out.sam")
+    return {"sam_records_reference": na, "sam_records_star_amd": nb, "sam_multiset_identical": na == nb and ha == hb,
+            "sj_out_tab_identical": open(ref + "SJ.out.tab", "rb").read() == open(new + "SJ.out.tab", "rb").read(),
+            "log_final_counters_identical": refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(new + "Log.final.out")}
 
 
 def two_pass_end_to_end(d, args):
@@ -300,6 +327,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, args, min(args.cpu_sample, n))
     if not args.no_cli_e2e and world == 1:
         out["cli_end_to_end"] = cli_end_to_end(d, args)
+    if world == 1 and isinstance(out.get("cpu_baseline"), dict) and isinstance(out.get("cli_end_to_end"), dict) and "error" not in out["cli_end_to_end"]:
+        try:
+            out["full_size_parity"] = full_size_parity(d)
+        except Exception as e:
+            out["full_size_parity"] = {"error": repr(e)[:300]}
     if not args.no_two_pass_e2e and world == 1:
         try:
             out["two_pass_end_to_end"] = two_pass_end_to_end(d, args)
