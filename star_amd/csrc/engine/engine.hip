@@ -19,8 +19,9 @@ extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *bigAr
 extern "C" __global__ void k_stitch_replay(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords);
 extern "C" __global__ void k_stitch_verify(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_stitch_finish(const DevIndex *X, DevBatch B);
-extern "C" __global__ void k_scan_offsets(DevBatch B, u32 *trBase, u32 *exBase, u32 *totals);
-extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *exBase, staramd_read_result *outReads,
+extern "C" __global__ void k_scan_local(DevBatch B, u32 *trBase, u32 *exBase, u32 *blockTot);
+extern "C" __global__ void k_scan_offsets(DevBatch B, u32 *blockTot, u32 nBlocks, u32 *totals);
+extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *exBase, const u32 *blockBase, staramd_read_result *outReads,
                                     staramd_transcript *outTr, u32 outTrCap, staramd_exon *outEx, u32 outExCap);
 
 // per-lane / per-wave work-space sizes (same formulas as the kernels)
@@ -57,9 +58,9 @@ struct staramd_ctx {
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
     u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
-    u32 stBlocks = 0, stBlocksBig = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
+    u32 stBlocks = 0, stBlocksBig = 0, replayBlocks = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
     u32 capDepth = 0, capRank = 0, arenaFast = 0, arenaBig = 0, ldsWordsCap = 0;
-    u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr;
+    u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
     float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-stage HIP-event times of the last batch (staramd_get_timings)
@@ -203,6 +204,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->dTrBase, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dExBase, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dTotals, (u64)4))) return rc;
+    if ((rc = devAlloc(R, &c->dBlockTot, (u64)2 * ((N + 255) / 256) + 2))) return rc;
     if ((rc = devAlloc(R, &c->dOutReads, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dOutTr, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &c->dOutEx, (u64)B.exCap))) return rc;
@@ -239,7 +241,15 @@ static int allocWork(staramd_ctx *c) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stPerCU, k_stitch_win, 256, ldsFast) != hipSuccess || stPerCU < 1) stPerCU = 2;
     c->stBlocks = (u32)c->nCU * envU32("STARAMD_STITCH_BLOCKS_PER_CU", (u32)stPerCU);
     if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win %d blocks/CU (LDS %zu B/block), k_windows %d blocks/CU, k_seed_search %d blocks/CU\n", stPerCU, ldsFast, winPerCU, seedPerCU);
-    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)c->stBlocks * 4 * c->arenaBig))) return rc;
+    // the replay kernel needs no walk stack and no read in LDS: more blocks per CU hide the latency of its candidate-log reads
+    {
+        int rpPerCU = stPerCU;
+        size_t ldsReplay = 4 * (size_t)stitchStateBytesH(0, c->capRank, c->arenaFast);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&rpPerCU, k_stitch_replay, 256, ldsReplay) != hipSuccess || rpPerCU < 1) rpPerCU = stPerCU;
+        c->replayBlocks = (u32)c->nCU * envU32("STARAMD_REPLAY_BLOCKS_PER_CU", (u32)std::min(rpPerCU, 8));
+        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_replay %d blocks/CU (LDS %zu B/block)\n", rpPerCU, ldsReplay);
+    }
+    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)std::max(c->stBlocks, c->replayBlocks) * 4 * c->arenaBig))) return rc;
     // candidate logs: one private region per wavefront; sized so that a wavefront's share of a full batch fits
     B.candWaveBytes = ((u64)envU32("STARAMD_CAND_KB_PER_WAVE", 0) * 1024) & ~31ull;
     if (B.candWaveBytes == 0) { u64 per = (u64)N * 6144 / ((u64)c->stBlocks * 4) + 262144; B.candWaveBytes = std::min<u64>(per, 0xFFFF0000ull) & ~31ull; }
@@ -360,14 +370,15 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
             if (mode == 0) HIPCHK(hipEventRecord(c->ev[6], s));
             if (mode == 0) {
                 hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);
-                hipLaunchKernelGGL(k_stitch_replay, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords);
+                hipLaunchKernelGGL(k_stitch_replay, dim3(c->replayBlocks), block, 4 * (size_t)stitchStateBytesH(0, c->capRank, c->arenaFast), s, c->dX, B, c->scrStitchBig, 0u, c->capRank, c->arenaFast, c->arenaBig, 0u);
             }
         }
         hipLaunchKernelGGL(k_stitch_finish, dim3((n + 255) / 256), block, 0, s, c->dX, B);
     }
     HIPCHK(hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, s, B, c->dTrBase, c->dExBase, c->dTotals);
-    hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), block, 0, s, B, c->dTrBase, c->dExBase, c->dOutReads, c->dOutTr, B.trCap, c->dOutEx, B.exCap);
+    hipLaunchKernelGGL(k_scan_local, dim3((n + 255) / 256), block, 0, s, B, c->dTrBase, c->dExBase, c->dBlockTot);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, s, B, c->dBlockTot, (n + 255) / 256, c->dTotals);
+    hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), block, 0, s, B, c->dTrBase, c->dExBase, c->dBlockTot, c->dOutReads, c->dOutTr, B.trCap, c->dOutEx, B.exCap);
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipGetLastError());
     u32 *hs = c->hostScratch;
