@@ -16,6 +16,7 @@
 #include <fstream>
 #include <sstream>
 #include <thread>
+#include <chrono>
 #include <array>
 #include <sys/stat.h>
 
@@ -153,6 +154,9 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     const std::vector<uint64_t> oldStart = gi.sjdbStart, oldEnd = gi.sjdbEnd;
     const uint64_t oldSjdbN = V.sjdbN, oldNSA = V.nSA, oldNGenome = V.nGenome;
 
+    const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  sjdb insert %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     // ---------------- sjdbPrepare (sjdbPrepare.cpp:5-225)
     std::vector<uint64_t> sjdbS(nLoci), sjdbE(nLoci);
     std::vector<uint8_t> motif(nLoci), shL(nLoci), shR(nLoci);
@@ -258,6 +262,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
             list << gi.chrName[chr1] << "\t" << nStart[ii] - gi.chrStart[chr1] + 1 + back << "\t" << nEnd[ii] - gi.chrStart[chr1] + 1 + back << "\t" << strandChar[nStrand[ii]] << "\n";
         }
     }
+    lap("prepare");
     if (sjdbN == 0) return "";                                           // sjdbBuildIndex.cpp:20-23
 
     // ---------------- sjdbBuildIndex (sjdbBuildIndex.cpp:16-333)
@@ -303,6 +308,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
         ind.reserve(tot + 1);
         for (auto &p : part) ind.insert(ind.end(), p.begin(), p.end());
     }
+    lap("search");
     log += "   Finished SA search: number of new junctions=" + std::to_string(sjNew) + ", old junctions=" + std::to_string(sjdbN - sjNew) + "\n";
     const uint8_t *gs = Gsj.data();
     std::sort(ind.begin(), ind.end(), [gs](const T2 &a, const T2 &b) {      // funCompareUintAndSuffixes: a total order
@@ -313,6 +319,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
             if (ga[ig] == SPACER) return a[1] < b[1];
         }
     });
+    lap("sort");
     const uint64_t nInd = ind.size();
     ind.push_back({(uint64_t)-999ll, (uint64_t)-999ll});                  // sentinel (:103-104)
     const uint64_t nGenomeNew = nGenomeReal + nGsj, nSAnew = oldNSA + nInd;
@@ -328,9 +335,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     const uint64_t nGsjNew = sjNew * sjdbLength, N2bit = 1ull << V.GstrandBit, strandMask = ~N2bit;
     {
         auto sjEntry = [&](uint64_t off) { return off < nGsj ? off + nGenomeReal : ((off - nGsj) | N2bit); };
-        uint64_t isj = 0, isa2 = 0;
-        for (uint64_t isa = 0; isa < oldNSA; isa++) {
-            while (isa == ind[isj][0]) { SA2.put(isa2++, sjEntry(ind[isj][1])); ++isj; }
+        auto oldEntry = [&](uint64_t isa) {
             uint64_t ind1 = X.SA.get(isa);
             if (ind1 & N2bit) {
                 uint64_t ind1s = oldNGenome - (ind1 & strandMask);
@@ -343,10 +348,40 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
                 uint64_t sj1 = (ind1 - nGenomeReal) / sjdbLength;
                 ind1 += ((uint64_t)oldSJind[sj1] - sj1) * sjdbLength;
             }
-            SA2.put(isa2++, ind1);
+            return ind1;
+        };
+        // The merge (:141-196) is a single pass in the reference.  Here the old SA is cut into slices that are merged by threads:
+        // the inserts in front of old entry `isa` are those with insertion point == isa, so a slice that starts at old index a
+        // starts at output position a + (number of inserts with insertion point < a).  Packed entries of neighbouring slices
+        // share 64-bit words, so the few entries next to a slice boundary are written after the threads have joined.
+        const uint64_t sliceMin = getenv("STARAMD_SJDB_SLICE") ? std::max<uint64_t>(16, strtoull(getenv("STARAMD_SJDB_SLICE"), nullptr, 10)) : 1000000;
+        const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(P.runThreadN, 64)), oldNSA / sliceMin + 1));
+        std::vector<uint64_t> cutA(T + 1), cutJ(T + 1);
+        for (int t = 0; t <= T; t++) {
+            cutA[t] = t == T ? oldNSA : oldNSA / T * t;
+            cutJ[t] = (uint64_t)(std::lower_bound(ind.begin(), ind.begin() + nInd, cutA[t], [](const T2 &x, uint64_t v) { return x[0] < v; }) - ind.begin());
         }
-        for (; isj < nInd; isj++) SA2.put(isa2++, sjEntry(ind[isj][1]));
+        std::vector<std::vector<T2> > deferred(T);
+        auto slice = [&](int t) {
+            uint64_t isj = cutJ[t], isa2 = cutA[t] + cutJ[t];
+            const uint64_t outLo = isa2, outHi = cutA[t + 1] + cutJ[t + 1];
+            auto emit = [&](uint64_t v) { if (isa2 < outLo + 3 || isa2 + 3 >= outHi) deferred[t].push_back({isa2, v}); else SA2.put(isa2, v); isa2++; };
+            for (uint64_t isa = cutA[t]; isa < cutA[t + 1]; isa++) {
+                while (isa == ind[isj][0]) { emit(sjEntry(ind[isj][1])); ++isj; }
+                emit(oldEntry(isa));
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back(slice, t);
+            slice(0);
+            for (auto &x : th) x.join();
+        }
+        for (auto &dv : deferred) for (const T2 &e : dv) SA2.put(e[0], e[1]);
+        uint64_t isa2 = oldNSA + cutJ[T];
+        for (uint64_t isj = cutJ[T]; isj < nInd; isj++) SA2.put(isa2++, sjEntry(ind[isj][1]));     // suffixes larger than every old one
     }
+    lap("SA merge");
     // SAi (:209-284)
     const uint32_t nb = V.gSAindexNbases, wSAi = V.GstrandBit + 3;
     const uint64_t absentC = 1ull << (V.GstrandBit + 2), NmaskC = 1ull << (V.GstrandBit + 1);        // Genome_genomeLoad.cpp:157-169
@@ -400,6 +435,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
             } else ind1 += g;
         }
     }
+    lap("SAi");
     // ---------------- the index is now the new one
     gi.G.assign(nGenomeNew, 0);
     memcpy(gi.G.data(), G, nGenomeReal);

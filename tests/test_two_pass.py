@@ -142,3 +142,20 @@ def test_gtf_at_the_mapping_stage(name, more, tmp_path, built):
         if open(ref + "_STARgenome/" + f, "rb").read() != open(new + "_STARgenome/" + f, "rb").read():
             problems.append("_STARgenome/%s differs" % f)
     assert not problems, problems
+
+
+def test_threaded_junction_insertion(tmp_path, built, monkeypatch):
+    """--runThreadN 7 with tiny slices: the suffix searches and the SA merge of the insertion run on threads, slice boundaries fall
+    inside packed words; the index must still be byte-identical to the reference's"""
+    monkeypatch.setenv("STARAMD_SJDB_SLICE", "5000")
+    info = dict(prepare("pe150_indel", str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    flags = ["--twopassMode", "Basic", "--sjdbInsertSave", "All"]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refT_"), threads=1, extra=flags)
+    info["extra"] = flags + ["--runThreadN", "7"]
+    new = run_with_engine(info, os.path.join(d, "newT_"), _oracle)
+    problems = compare_outputs(ref, new)
+    for f in INDEX_FILES:
+        if open(ref + "_STARgenome/" + f, "rb").read() != open(new + "_STARgenome/" + f, "rb").read():
+            problems.append("_STARgenome/%s differs" % f)
+    assert not problems, problems
