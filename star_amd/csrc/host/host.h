@@ -79,6 +79,7 @@ struct RunParams {
     bool sjdbInsertPass1() const { return !sjdbFileChrStartEnd.empty() || !sjdbGTFfile.empty(); }
     bool sjdbInsertYes() const { return twopass || sjdbInsertPass1(); }
     bool outFilterBySJout = false;       // --outFilterType BySJout
+    bool quantGeneCounts = false;        // --quantMode GeneCounts
 
     RunParams();
     // STAR-style "--name v1 v2 ..." ; returns error text or ""
@@ -164,6 +165,22 @@ struct OutSJ {
     std::string filterAndWrite(const RunParams &P, const GenomeIndex &gi, const std::string &path, bool skipDistanceFilter = false);
 };
 
+// ---- --quantMode GeneCounts (quant.cpp) ----
+struct GeneAnnotation {                   // geneInfo.tab + exonGeTrInfo.tab of the genome (or of _STARgenome/ with --sjdbGTFfile)
+    std::vector<std::string> geID;
+    std::vector<uint64_t> s, e, eMax; std::vector<uint8_t> str; std::vector<uint32_t> g;
+    std::string load(const std::string &dir);
+};
+struct GeneCounts {
+    uint64_t cMulti = 0, cAmbig[3] = {0, 0, 0}, cNone[3] = {0, 0, 0};
+    std::vector<uint64_t> gCount[3];
+    GeneCounts() {}
+    explicit GeneCounts(size_t nGe);
+    void add(const GeneCounts &o);
+    void addAlign(const GeneAnnotation &A, uint64_t nA, const staramd_transcript &a, const staramd_exon *ex);   // Transcriptome_geneCountsAddAlign.cpp:4-63
+    std::string write(const std::string &path, const GeneAnnotation &A, const Stats &st) const;                  // Transcriptome.cpp:158-190
+};
+
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
 public:
@@ -173,7 +190,8 @@ public:
     // sj1 / held: 1st stage of --outFilterType BySJout (ReadAlign_outputAlignments.cpp:90-124): junctions of every read go to sj1,
     // reads with an unannotated junction are not output but listed in `held` for the 2nd stage
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr) const;
+                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr) const;
+    const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:

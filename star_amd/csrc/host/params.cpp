@@ -105,6 +105,9 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMflagOR") outSAMflagOR = (uint32_t)U(k, v);
         else if (k == "outSAMflagAND") outSAMflagAND = (uint32_t)U(k, v);
         else if (k == "readNameSeparator") readNameSeparator = one(k, v);
+        else if (k == "quantMode") {
+            for (auto &t : v) { if (t == "GeneCounts") quantGeneCounts = true; else if (t != "-") err = "EXITING because of fatal INPUT error: unrecognized option in --quantMode=" + t + "\nSOLUTION: use one of the allowed values of --quantMode : GeneCounts or - (TranscriptomeSAM is not implemented by the MI355X engine).\n"; }
+        }
         else if (k == "outFilterType") { const std::string &m = one(k, v); if (m == "BySJout") outFilterBySJout = true; else if (m != "Normal") err = "EXITING because of FATAL input ERROR: unknown value of parameter outFilterType: " + m + "\nSOLUTION: specify one of the allowed values: Normal | BySJout\n"; }
         else if (k == "outFilterMultimapScoreRange") dev.outFilterMultimapScoreRange = (int32_t)I(k, v);
         else if (k == "outFilterMultimapNmax") outFilterMultimapNmax = (uint32_t)U(k, v);

@@ -234,7 +234,7 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 }
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                                  OutSJ *sj1, std::vector<uint32_t> *held) const {
+                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc) const {
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];
@@ -292,6 +292,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                 st.mappedBases += mappedL; st.mappedPortion += double(mappedL) / double(rc.Lread);
             }
             recordSJ(P, trMult, nTr, sj);
+            if (gc && nTr > 0) gc->addAlign(*genes, nTr, *trMult[0].t, trMult[0].ex);        // alignedAnnotation (ReadAlign_outputAlignments.cpp:298-308)
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
             if (!samOff) for (uint64_t it = 0; it < nTr; it++) samMapped(sam, P, gi, rc, trMult[it], nTr, it);
             const staramd_exon *exB = r.ex + trBest->exonOffset;

@@ -37,6 +37,7 @@ struct Runner {
     OutSJ sj1;                          // junctions of every read of stage 1 (chunkOutSJ1)
     std::string heldText[2];            // held reads as FASTQ text
     std::vector<uint64_t> novelStart, novelEnd;
+    GeneAnnotation genes; GeneCounts geneCounts;      // --quantMode GeneCounts
     int64_t readMapNumberUser = -1;
 
     bool init(int argc, char **argv) {
@@ -68,6 +69,12 @@ struct Runner {
         error = reader.open(P.readFilesIn, P.readFilesCommand);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
+        if (P.quantGeneCounts) {                                    // Transcriptome.cpp:12-16: a GTF given at the mapping stage wins
+            error = genes.load(P.sjdbGTFfile.empty() ? P.genomeDir : P.sjdbInsertOutDir);
+            if (!error.empty()) return false;
+            geneCounts = GeneCounts(genes.geID.size());
+            post->genes = &genes;
+        }
         if (P.outFilterBySJout && !P.twopass) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         if (P.twopass) {                                            // twoPassRunPass1.cpp:14-47: no SAM, own read limit
             pass1 = true; post->samOff = true; readMapNumberUser = P.readMapNumber;
@@ -129,11 +136,13 @@ struct Runner {
         std::vector<std::string> errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
         const bool stage1 = bySJoutStage == 1;
         std::vector<OutSJ> sj1s(stage1 ? T : 0); std::vector<std::vector<uint32_t> > helds(stage1 ? T : 0);
+        const bool quant = P.quantGeneCounts && !pass1;             // twoPassRunPass1.cpp:24-29: no quantification in the 1st pass
+        std::vector<GeneCounts> gcs(quant ? T : 0, GeneCounts(quant ? genes.geID.size() : 0));
         uint32_t per = (bt.n + T - 1) / T;
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
             o.sams[t].clear();
-            errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr);
+            errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr);
         };
         if (T == 1) work(0);
         else {
@@ -147,7 +156,7 @@ struct Runner {
         { std::lock_guard<std::mutex> l(wm); fullSets.push_back(k); }
         wcv.notify_all();
         if (!error.empty()) return false;
-        for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); }
+        for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); if (quant) geneCounts.add(gcs[t]); }
         if (stage1) {
             for (uint32_t t = 0; t < T; t++) {
                 sj1.mergeFrom(sj1s[t]);
@@ -208,6 +217,7 @@ struct Runner {
         error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
+        if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
     ~Runner() { stopWriter(); if (samOut) fclose(samOut); }
