@@ -38,6 +38,8 @@ struct Runner {
     std::string heldText[2];            // held reads as FASTQ text
     std::vector<uint64_t> novelStart, novelEnd;
     GeneAnnotation genes; GeneCounts geneCounts;      // --quantMode GeneCounts
+    int wireTable = 0;                                // which junction table sah_sj_export / import / clear address: 0 = sj, 1 = sj1
+    OutSJ &wire() { return wireTable == 1 ? sj1 : sj; }
     int64_t readMapNumberUser = -1;
 
     bool init(int argc, char **argv) {
@@ -288,13 +290,13 @@ static_assert(sizeof(SjWire) == 32, "junction wire record is 32 bytes");
 
 uint64_t sah_sj_export(void *h, void *buf, uint64_t capRecords) {
     Runner *r = (Runner *)h;
-    r->sj.collapse();
-    uint64_t n = r->sj.data.size();
+    r->wire().collapse();
+    uint64_t n = r->wire().data.size();
     if (!buf) return n;
     if (n > capRecords) return (uint64_t)-1;
     SjWire *w = (SjWire *)buf;
     for (uint64_t i = 0; i < n; i++) {
-        const staramd::Junction &j = r->sj.data[i];
+        const staramd::Junction &j = r->wire().data[i];
         SjWire x; memset(&x, 0, sizeof(x));
         x.start = j.start; x.gap = j.gap; x.countUnique = j.countUnique; x.countMultiple = j.countMultiple;
         x.overhangLeft = j.overhangLeft; x.overhangRight = j.overhangRight; x.strand = j.strand; x.motif = j.motif; x.annot = j.annot;
@@ -308,11 +310,33 @@ int sah_sj_import(void *h, const void *buf, uint64_t nRecords) {
     for (uint64_t i = 0; i < nRecords; i++) {
         staramd::Junction j; j.start = w[i].start; j.gap = w[i].gap; j.strand = w[i].strand; j.motif = w[i].motif; j.annot = w[i].annot;
         j.countUnique = w[i].countUnique; j.countMultiple = w[i].countMultiple; j.overhangLeft = w[i].overhangLeft; j.overhangRight = w[i].overhangRight;
-        r->sj.data.push_back(j);
+        r->wire().data.push_back(j);
     }
     return 0;
 }
-void sah_sj_clear(void *h) { ((Runner *)h)->sj.data.clear(); }
+void sah_sj_clear(void *h) { ((Runner *)h)->wire().data.clear(); }
+// which table the three calls above address: 0 = the output table, 1 = the table of the 1st BySJout stage (all reads' junctions)
+void sah_sj_select(void *h, int which) { ((Runner *)h)->wireTable = which; }
+int sah_in_stage1(void *h) { return ((Runner *)h)->bySJoutStage == 1 ? 1 : 0; }
+// --quantMode GeneCounts across ranks: 7 counters + 3 x nGe gene counts
+uint64_t sah_quant_export(void *h, uint64_t *out, uint64_t cap) {
+    Runner *r = (Runner *)h;
+    if (!r->P.quantGeneCounts) return 0;
+    const staramd::GeneCounts &g = r->geneCounts;
+    uint64_t nGe = g.gCount[0].size(), n = 7 + 3 * nGe;
+    if (!out) return n;
+    if (cap < n) return (uint64_t)-1;
+    out[0] = g.cMulti; for (int t = 0; t < 3; t++) { out[1 + t] = g.cAmbig[t]; out[4 + t] = g.cNone[t]; for (uint64_t i = 0; i < nGe; i++) out[7 + t * nGe + i] = g.gCount[t][i]; }
+    return n;
+}
+int sah_quant_import_add(void *h, const uint64_t *in, uint64_t n) {
+    Runner *r = (Runner *)h;
+    staramd::GeneCounts &g = r->geneCounts;
+    uint64_t nGe = g.gCount[0].size();
+    if (n != 7 + 3 * nGe) return -1;
+    g.cMulti += in[0]; for (int t = 0; t < 3; t++) { g.cAmbig[t] += in[1 + t]; g.cNone[t] += in[4 + t]; for (uint64_t i = 0; i < nGe; i++) g.gCount[t][i] += in[7 + t * nGe + i]; }
+    return 0;
+}
 #define SAH_NSTAT 32
 // counters as 32 x u64; mappedPortion (double) travels as its bit pattern and is summed by the importer
 int sah_stats_export(void *h, uint64_t *out) {

@@ -26,6 +26,10 @@ def _bind(L):
     L.sah_sj_clear.restype = None; L.sah_sj_clear.argtypes = [C.c_void_p]
     L.sah_stats_export.restype = C.c_int; L.sah_stats_export.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.sah_stats_import_add.restype = C.c_int; L.sah_stats_import_add.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.sah_sj_select.restype = None; L.sah_sj_select.argtypes = [C.c_void_p, C.c_int]
+    L.sah_in_stage1.restype = C.c_int; L.sah_in_stage1.argtypes = [C.c_void_p]
+    L.sah_quant_export.restype = C.c_uint64; L.sah_quant_export.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64]
+    L.sah_quant_import_add.restype = C.c_int; L.sah_quant_import_add.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64]
     L._mg_bound = True
 
 
@@ -53,8 +57,9 @@ def import_rank_tables(run, sj_bytes, stats):
     L.sah_stats_import_add(run.h, st)
 
 
-def merge_run_outputs(run, dist, dev, rank, world):
-    """all_gather of (padded junction table, counters); rank 0 ends up holding the union.  Returns bytes moved per rank."""
+def _gather_tables(run, dist, dev, rank, world, everyone, with_stats=True):
+    """all_gather of (padded junction table, counters) of the table selected with sah_sj_select; imported by rank 0 only, or by
+    every rank (everyone=True: all ranks continue with the same union)."""
     sj, st = export_rank_tables(run)
     n = torch.tensor([len(sj)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n) for _ in range(world)]
@@ -67,8 +72,51 @@ def merge_run_outputs(run, dist, dev, rank, world):
     payload[cap:] = torch.from_numpy(st.view(np.uint8)).to(dev)
     gathered = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(gathered, payload)
+    if rank == 0 or everyone:
+        for r in range(world):
+            if r == rank:
+                continue
+            g = gathered[r].cpu().numpy()
+            import_rank_tables(run, g[:sizes[r]], g[cap:].view(np.int64) if (rank == 0 and with_stats) else np.zeros(NSTAT, dtype=np.int64))
+    return int(payload.numel())
+
+
+def next_phase(run, dist, dev, rank, world):
+    """Multi-rank form of HostRun.next_phase() for --twopassMode Basic and --outFilterType BySJout: what the reference merges across its
+    threads between the phases has to be merged across ranks first -- the junctions of the 1st pass before
+    they are inserted into every rank's index replica, the junctions of all reads of BySJout stage 1 before the whitelist is built.
+    Every rank imports every other rank's table, so all ranks go on with the same index / whitelist.  Returns HostRun.next_phase()."""
+    L = run.L
+    _bind(L)
+    if run.in_pass1():
+        L.sah_sj_select(run.h, 0)
+        _gather_tables(run, dist, dev, rank, world, everyone=True)
+    elif L.sah_in_stage1(run.h):
+        L.sah_sj_select(run.h, 1)
+        _gather_tables(run, dist, dev, rank, world, everyone=True, with_stats=False)     # Stats travel once, at the end of the run
+        L.sah_sj_select(run.h, 0)
+    return run.next_phase()
+
+
+def _merge_gene_counts(run, dist, dev, rank, world):
+    L = run.L
+    n = int(L.sah_quant_export(run.h, None, 0))
+    if n == 0:
+        return
+    buf = (C.c_uint64 * n)()
+    L.sah_quant_export(run.h, buf, n)
+    t = torch.from_numpy(np.frombuffer(bytes(buf), dtype=np.int64).copy()).to(dev)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
     if rank == 0:
         for r in range(1, world):
-            g = gathered[r].cpu().numpy()
-            import_rank_tables(run, g[:sizes[r]], g[cap:].view(np.int64))
-    return int(payload.numel())
+            a = gathered[r].cpu().numpy().astype(np.uint64)
+            L.sah_quant_import_add(run.h, (C.c_uint64 * n)(*[int(x) for x in a]), n)
+
+
+def merge_run_outputs(run, dist, dev, rank, world):
+    """all_gather of (padded junction table, counters); rank 0 ends up holding the union.  Returns bytes moved per rank."""
+    _bind(run.L)
+    run.L.sah_sj_select(run.h, 0)
+    _merge_gene_counts(run, dist, dev, rank, world)
+    return _gather_tables(run, dist, dev, rank, world, everyone=False)

@@ -44,12 +44,20 @@ def _worker(rank, world, port, idx, shards, extra, outdir):
     run = capi.HostRun(["--genomeDir", idx, "--readFilesIn"] + shards[rank] + ["--outFileNamePrefix", prefix] + list(extra))
     eng = oracle_lib.Oracle(run.genome, run.params)
     while True:
-        b = run.next_batch(500)
-        if b is None:
+        while True:
+            b = run.next_batch(500)
+            if b is None:
+                break
+            bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
+            eng.map_batch(b, bufs)
+            run.emit(bufs.res)
+        phase = multi_gpu.next_phase(run, dist, torch.device("cpu"), rank, world)     # exchanges what the next phase needs
+        if phase == 0:
             break
-        bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
-        eng.map_batch(b, bufs)
-        run.emit(bufs.res)
+        if phase == 1:
+            eng.update_index(run.genome, run.params)
+        else:
+            eng.set_novel_junctions(*run.novel_junctions())
     multi_gpu.merge_run_outputs(run, dist, torch.device("cpu"), rank, world)
     run.finish()            # rank 0 holds the union; other ranks write their partial files (ignored)
     eng.close(); run.close()
@@ -68,6 +76,27 @@ def test_two_ranks_match_single_reference_run(name, tmp_path, built):
     r0 = os.path.join(str(tmp_path), "r0_")
     assert open(ref + "SJ.out.tab", "rb").read() == open(r0 + "SJ.out.tab", "rb").read()
     assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(r0 + "Log.final.out")
+    union = []
+    for r in range(world):
+        union += refstar.sam_body_sorted(os.path.join(str(tmp_path), "r%d_Aligned.out.sam" % r))
+    assert sorted(union) == refstar.sam_body_sorted(ref + "Aligned.out.sam")
+
+
+def test_two_ranks_two_pass_by_sjout_gene_counts(tmp_path, built):
+    """phases across ranks: the junctions of pass 1 and of BySJout stage 1 are exchanged before every rank inserts / filters with the
+    union; gene counts are summed on rank 0.  One reference run over all reads is the truth."""
+    info = prepare("pe101", str(tmp_path), need_ref=False)
+    flags = ["--twopassMode", "Basic", "--outFilterType", "BySJout", "--quantMode", "GeneCounts"]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(str(tmp_path), "ref_"), threads=1, extra=flags)
+    world = 2
+    shards = _split_fastq(info["fastq"], world, str(tmp_path))
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, info["idx"], shards, flags, str(tmp_path)), nprocs=world, join=True)
+    r0 = os.path.join(str(tmp_path), "r0_")
+    assert open(ref + "SJ.out.tab", "rb").read() == open(r0 + "SJ.out.tab", "rb").read()
+    assert open(ref + "ReadsPerGene.out.tab", "rb").read() == open(r0 + "ReadsPerGene.out.tab", "rb").read()
+    assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(r0 + "Log.final.out")
+    assert open(ref + "_STARpass1/SJ.out.tab", "rb").read() == open(r0 + "_STARpass1/SJ.out.tab", "rb").read()
     union = []
     for r in range(world):
         union += refstar.sam_body_sorted(os.path.join(str(tmp_path), "r%d_Aligned.out.sam" % r))
