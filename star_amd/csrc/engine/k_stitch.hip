@@ -641,7 +641,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             u32 exl = waveSumU32(inSeg ? exL : 0u);
             u32 nsj = (u32)__popcll(__ballot(inSeg && lane != e && canon >= 0));
             u32 fragE = laneGet32(xe.iFrag, e);
-            if (nsj > 0 && (exl < P.alignSplicedMateMapLmin || (u64)exl < (u64)(P.alignSplicedMateMapLminOverLmate * (double)(u64)c.readLength[fragE]))) return;
+            if (nsj > 0 && (exl < P.alignSplicedMateMapLmin || (u64)exl < (u64)(P.alignSplicedMateMapLminOverLmate * (double)(u64)(fragE ? c.readLength[1] : c.readLength[0])))) return;
             start = e + 1;
         }
     }
@@ -677,16 +677,17 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
         Score = max(0, Score);
     }
     i32 iFragT;
-    if (ex0Frag == exLFrag) { iFragT = (i32)ex0Frag; c.maxScoreMate[iFragT] = max(c.maxScoreMate[iFragT], Score); }
+    // (constant indices only: a dynamic index would pin the whole context in scratch memory)
+    if (ex0Frag == exLFrag) { iFragT = (i32)ex0Frag; if (iFragT == 0) c.maxScoreMate[0] = max(c.maxScoreMate[0], Score); else c.maxScoreMate[1] = max(c.maxScoreMate[1], Score); }
     else iFragT = -1;
     PROF_MARK(c, 14);
     i32 winBest = wr.bestScore;            // wTr[0]->maxScore (trA with score 0 before any record)
     {
         bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
-        bool c2 = iFragT >= 0 && Score + P.outFilterMultimapScoreRange >= c.maxScoreMate[iFragT];
+        bool c2 = iFragT >= 0 && Score + P.outFilterMultimapScoreRange >= (iFragT == 0 ? c.maxScoreMate[0] : c.maxScoreMate[1]);
         if (!(c1 || c2)) return;
         // decided by the maxScoreMate clause alone: the decision holds for any incoming maxScoreMate <= Score + range
-        if (!c1) c.sens[iFragT] = min(c.sens[iFragT], Score + P.outFilterMultimapScoreRange);
+        if (!c1) { if (iFragT == 0) c.sens[0] = min(c.sens[0], Score + P.outFilterMultimapScoreRange); else c.sens[1] = min(c.sens[1], Score + P.outFilterMultimapScoreRange); }
     }
     // ---- the candidate as an output record: header (wave-uniform) + this lane's exon row
     staramd_transcript o;
