@@ -128,58 +128,68 @@ __device__ static void storeAligns(const DevIndex &X, SeedState &st, u32 iDir, u
     if (Nrep != 1) { if (Nrep < st.multNmin || st.multNmin == 0) { st.multNmin = (u32)Nrep; st.multNminL = L; } }
 }
 
-// ReadAlign_maxMappableLength2strands.cpp:5-115
-__device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R, SeedState &st, u32 pieceStartIn, u32 pieceLengthIn, u32 iDir, u32 &maxLbest, u32 iFrag, SeedCnt &cn) {
-    const u32 DMAX = 8;           // gSAsparseD values above 8 are rejected at context creation
-    u64 NrepAll[DMAX], ind0All[DMAX]; u32 maxLall[DMAX];
-    maxLbest = 0;
-    bool dirR = iDir == 0;
-    u32 nD = min(pieceLengthIn, X.sparseD);
-    for (u32 iDist = 0; iDist < nD; iDist++) {
-        u32 pieceStart; u32 pieceLength = pieceLengthIn - iDist;
-        u32 Lmax = min(X.saiNbases, pieceLength);
-        u64 ind1 = 0;
-        // L-mer prefix (ReadAlign_maxMappableLength2strands.cpp:23-37): 2 bits per base, first base most significant;
-        // the bases of a piece are all 0..3, so 8 of them are packed from one 8-byte word with shifts and masks
-        if (dirR) pieceStart = pieceStartIn + iDist; else pieceStart = pieceStartIn - iDist;
-        for (u32 ii = 0; ii < Lmax; ii += 8) {
-            u64 x = dirR ? load8(R + pieceStart + ii) : (load8rev(R + pieceStart - ii) ^ 0x0303030303030303ull);   // 3 - base == 3 ^ base
-            u64 z = __builtin_bswap64(x & 0x0303030303030303ull); // first base in the top byte (bytes behind the prefix may hold N / spacer codes)
-            z = (z | (z >> 6)) & 0x000F000F000F000Full;
-            z = (z | (z >> 12)) & 0x000000FF000000FFull;
-            z = (z | (z >> 24)) & 0xFFFFull;                    // 8 bases -> 16 bits, first base most significant
-            u32 nb = min(8u, Lmax - ii);
-            ind1 = (ind1 << (2 * nb)) | (z >> (2 * (8 - nb)));
-        }
-        u32 Lind = Lmax; u64 iSA1 = 0, iSA2;
-        while (Lind > 0) {
-            iSA1 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1, X.saiBits, X.saiMask); cn.nSAi++;
-            if ((iSA1 & X.saiAbsentBit) == 0) break;
-            --Lind; ind1 >>= 2;
-        }
-        if (Lind == 0) { NrepAll[iDist] = 0; ind0All[iDist] = 0; maxLall[iDist] = 0; continue; }   // base absent from the genome (reference: out-of-bounds)
-        bool iSA2good = true;
-        if (X.saiStart[Lind - 1] + ind1 + 1 < X.saiStart[Lind]) {
-            iSA2 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1 + 1, X.saiBits, X.saiMask); cn.nSAi++;
-            if ((iSA2 & X.saiAbsentBit) == 0) iSA2 = (iSA2 & ~X.saiNbit) - 1;
-            else { iSA2 = X.nSA - 1; iSA2good = false; }
-        } else { iSA2 = X.nSA - 1; iSA2good = false; }
-        bool iSA1noN = (iSA1 & X.saiNbit) == 0;
-        u64 Nrep, i0, i1; u32 maxL;
-        if (Lind < X.saiNbases && iSA1noN && iSA2good) { i0 = iSA1; i1 = iSA2; Nrep = i1 - i0 + 1; maxL = Lind; }
-        else if (iSA1 == iSA2 && iSA1noN && iSA2good) {
-            i0 = i1 = iSA1; Nrep = 1; bool cr;
-            maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, Lind, iSA1, dirR, cr, cn);
-        } else {
-            maxL = (iSA2good && iSA1noN) ? Lind : 0;
-            Nrep = maxMappableLength(X, R, pieceStart, pieceLength, iSA1 & ~X.saiNbit, iSA2, dirR, maxL, i0, i1, cn);
-        }
-        if (maxL + iDist > maxLbest) maxLbest = maxL + iDist;
-        NrepAll[iDist] = Nrep; ind0All[iDist] = i0; maxLall[iDist] = maxL;
+// ReadAlign_maxMappableLength2strands.cpp:12-109: one start offset iDist of the sparse-SA loop
+__device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u32 pieceStartIn, u32 pieceLengthIn, bool dirR, u32 iDist, u64 &Nrep, u64 &i0, u32 &maxL, SeedCnt &cn) {
+    u32 pieceStart; u32 pieceLength = pieceLengthIn - iDist;
+    u32 Lmax = min(X.saiNbases, pieceLength);
+    u64 ind1 = 0;
+    // L-mer prefix (ReadAlign_maxMappableLength2strands.cpp:23-37): 2 bits per base, first base most significant;
+    // the bases of a piece are all 0..3, so 8 of them are packed from one 8-byte word with shifts and masks
+    if (dirR) pieceStart = pieceStartIn + iDist; else pieceStart = pieceStartIn - iDist;
+    for (u32 ii = 0; ii < Lmax; ii += 8) {
+        u64 x = dirR ? load8(R + pieceStart + ii) : (load8rev(R + pieceStart - ii) ^ 0x0303030303030303ull);   // 3 - base == 3 ^ base
+        u64 z = __builtin_bswap64(x & 0x0303030303030303ull); // first base in the top byte (bytes behind the prefix may hold N / spacer codes)
+        z = (z | (z >> 6)) & 0x000F000F000F000Full;
+        z = (z | (z >> 12)) & 0x000000FF000000FFull;
+        z = (z | (z >> 24)) & 0xFFFFull;                    // 8 bases -> 16 bits, first base most significant
+        u32 nb = min(8u, Lmax - ii);
+        ind1 = (ind1 << (2 * nb)) | (z >> (2 * (8 - nb)));
     }
-    for (u32 iDist = 0; iDist < nD; iDist++)
-        if (maxLall[iDist] + iDist == maxLbest && NrepAll[iDist] > 0)
-            storeAligns(X, st, iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, NrepAll[iDist], maxLall[iDist], ind0All[iDist], iFrag);
+    u32 Lind = Lmax; u64 iSA1 = 0, iSA2;
+    while (Lind > 0) {
+        iSA1 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1, X.saiBits, X.saiMask); cn.nSAi++;
+        if ((iSA1 & X.saiAbsentBit) == 0) break;
+        --Lind; ind1 >>= 2;
+    }
+    if (Lind == 0) { Nrep = 0; i0 = 0; maxL = 0; return; }   // base absent from the genome (reference: out-of-bounds)
+    bool iSA2good = true;
+    if (X.saiStart[Lind - 1] + ind1 + 1 < X.saiStart[Lind]) {
+        iSA2 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1 + 1, X.saiBits, X.saiMask); cn.nSAi++;
+        if ((iSA2 & X.saiAbsentBit) == 0) iSA2 = (iSA2 & ~X.saiNbit) - 1;
+        else { iSA2 = X.nSA - 1; iSA2good = false; }
+    } else { iSA2 = X.nSA - 1; iSA2good = false; }
+    bool iSA1noN = (iSA1 & X.saiNbit) == 0;
+    u64 i1;
+    if (Lind < X.saiNbases && iSA1noN && iSA2good) { i0 = iSA1; i1 = iSA2; Nrep = i1 - i0 + 1; maxL = Lind; }
+    else if (iSA1 == iSA2 && iSA1noN && iSA2good) {
+        i0 = i1 = iSA1; Nrep = 1; bool cr;
+        maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, Lind, iSA1, dirR, cr, cn);
+    } else {
+        maxL = (iSA2good && iSA1noN) ? Lind : 0;
+        Nrep = maxMappableLength(X, R, pieceStart, pieceLength, iSA1 & ~X.saiNbit, iSA2, dirR, maxL, i0, i1, cn);
+    }
+}
+
+// ReadAlign_maxMappableLength2strands.cpp:5-115.  The reference keeps (Nrep, ind0, maxL) of every start offset of a sparse suffix
+// array in small tables and stores the best ones afterwards; indexed local tables would live in scratch memory here, so with
+// genomeSAsparseD > 1 the offsets are simply searched twice (first for the best length, then to store) -- with the default
+// full suffix array there is one offset and one search.
+__device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R, SeedState &st, u32 pieceStartIn, u32 pieceLengthIn, u32 iDir, u32 &maxLbest, u32 iFrag, SeedCnt &cn) {
+    const bool dirR = iDir == 0;
+    const u32 nD = min(pieceLengthIn, X.sparseD);
+    maxLbest = 0;
+    for (u32 it = 0; it < 2 * nD; it++) {
+        const u32 phase = it >= nD ? 1u : 0u, iDist = phase ? it - nD : it;
+        u64 Nrep, i0; u32 maxL;
+        searchOneDist(X, R, pieceStartIn, pieceLengthIn, dirR, iDist, Nrep, i0, maxL, cn);
+        if (phase == 0) {
+            if (maxL + iDist > maxLbest) maxLbest = maxL + iDist;
+            if (nD > 1) continue;
+        }
+        if (maxL + iDist == maxLbest && Nrep > 0)
+            storeAligns(X, st, iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, Nrep, maxL, i0, iFrag);
+        if (nD == 1) break;
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {

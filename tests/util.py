@@ -28,6 +28,9 @@ DATASETS = {
                      dict(sa_index_nbases=7, use_gtf=True, sjdb_overhang=75),
                      ["--outFilterMultimapNmax", "20", "--alignSJoverhangMin", "8", "--outSAMattributes", "NH", "HI", "AS", "nM", "jM", "jI", "XS",
                       "--outSAMunmapped", "Within"]),
+    # sparse suffix array (--genomeSAsparseD 3): every seed start is searched at 3 offsets (ReadAlign_maxMappableLength2strands.cpp:12-114)
+    "pe101_sparse3": (dict(seed=6, chr_lengths=(300000, 200000, 150000), n_tr=120, n_reads=2500, read_len=101, paired=True),
+                      dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=100, extra=("--genomeSAsparseD", "3")), []),
     # 2x150, 1 % errors, 5 % chimeric pairs (mates or read halves from different loci); chimeric detection stays
     # off by default, so these exercise multi-window stitching, soft clips and the "too short" path
     "pe150_chim": (dict(seed=5, chr_lengths=(350000, 250000, 200000), n_tr=110, n_reads=3000, read_len=150, paired=True, sub_rate=0.01, chim_rate=0.05),
