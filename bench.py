@@ -269,6 +269,9 @@ def main():
     names = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut",
              "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
     c = dict(zip(names, cnt))
+    if os.environ.get("STARAMD_ENGINE_LIB") not in ("profile", "shadow"):
+        for k in ("nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"):      # diagnostics kept by the profile / shadow builds only
+            c.pop(k, None)
     prof = None
     if os.environ.get("STARAMD_ENGINE_LIB") == "profile" and len(cnt) >= 37:
         pn = ["walk", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime",

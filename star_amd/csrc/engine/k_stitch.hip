@@ -53,7 +53,7 @@ __device__ __forceinline__ bool coopExtend(StitchCtx &c, u32 lane, u32 rStart, u
     return r;
 }
 __device__ static bool coopExtendBody(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
-    c.nExtendCalls++;
+    DIAG(c.nExtendCalls++);
     e.maxScore = 0; e.extendL = 0; e.nMatch = 0; e.nMM = 0;
     if (extendToEnd) {                      // --alignEndsType Extend*: rarely used, wave-uniform scalar loop (:18-56)
         int Score = 0, nMatch = 0, nMM = 0, iExt;
@@ -161,7 +161,7 @@ __device__ static int coopSjdbFind(u32 lane, u64 x, u64 y, const u64 *Xs_, const
 __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u32 rBstart, u64 gBstart, u32 L, u32 iFragB, i32 sjAB,
                                  Hdr &h, staramd_exon &eA, staramd_exon &eN, bool &added, u32 ex0R, u64 ex0G) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
-    c.nStitchCalls++;
+    DIAG(c.nStitchCalls++);
     added = false;
     if (h.nExons >= STARAMD_MAX_N_EXONS) return -1000010;
     int Score = 0;
@@ -556,7 +556,7 @@ template <class EXP> __device__ static void recordCandidate(const staramd_params
 // leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
 __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr, const u64 glb0, const u64 glb1) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
-    c.nLeaves++;
+    DIAG(c.nLeaves++);
     u32 Lread = c.Lread; u32 Str = c.str;
     int Score = h.Score; u32 tR2 = h.tR2; u64 tG2 = h.tG2;
     u32 ne = h.nExons;
@@ -770,7 +770,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
     u64 follow = ~0ull;                              // seeds that can follow the last included one (all, while the transcript is empty)
     DWA a = uni(ldsGet(&WA[0]));
     for (;;) {
-        c.nNodes++;
+        DIAG(c.nNodes++);
         if (iA >= nA) {                              // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
             if (h.tR2 != 0) {
                 if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }

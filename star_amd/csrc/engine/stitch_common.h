@@ -12,6 +12,14 @@ struct Hdr {                               // transcript header + walk position,
 };
 struct SFrame { Hdr h; u32 iA; u32 pad; staramd_exon eA; };      // 112 bytes
 
+// nodes / leaves / stitch / extend call counters are diagnostics: they cost registers in a kernel that is 37 VGPRs over its budget,
+// so only the profile and shadow builds keep them (bench.py --profile-sections reports them); the genome-bytes counter stays
+#if defined(STARAMD_PROFILE) || defined(STARAMD_SHADOW)
+#define DIAG(x) x
+#else
+#define DIAG(x)
+#endif
+
 struct StitchCtx {
     const DevIndex *X;
     u32 ldsByte;                           // byte offset of this lane's packed read inside ldsReads
