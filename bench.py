@@ -58,6 +58,11 @@ def prepare_data(args, world):
     if not refstar.have_ref():
         raise RuntimeError("oracle/_ref/STAR is missing: it is needed to build the benchmark index (python -c 'import __graft_entry__ as g; g.build()')")
     os.makedirs(d, exist_ok=True)
+    # genome + annotation + index depend on (genome_mb, read_len) only: shared by the runs with 1, 2, 4, 8 GPUs
+    gkey = hashlib.md5(("v3g|%d|%d" % (args.genome_mb, args.read_len)).encode()).hexdigest()[:12]
+    gdir = os.path.join(args.workdir, "genome_" + gkey)
+    gdone = os.path.join(gdir, "DONE")
+    os.makedirs(gdir, exist_ok=True)
     rng = np.random.default_rng(20260922)
     nchr = max(1, args.genome_mb // 10)
     chr_len = [args.genome_mb * 1000000 // nchr] * nchr
@@ -65,16 +70,24 @@ def prepare_data(args, world):
     mb = args.genome_mb
     seqs = synth.make_genome(rng, chr_len, repeat_families=((300, 300 * mb, 0.08), (6000, 15 * mb, 0.05), (60, 50 * mb, 0.0)), n_runs=2 * mb)
     trs = synth.make_transcripts(rng, seqs, 200 * mb)
-    synth._write_fasta(os.path.join(d, "genome.fa"), names, seqs)
-    synth.write_gtf(os.path.join(d, "annot.gtf"), names, trs, rng.random(len(trs)) < 0.7)
+    annotated = rng.random(len(trs)) < 0.7
+    if not os.path.isfile(gdone):
+        synth._write_fasta(os.path.join(gdir, "genome.fa"), names, seqs)
+        synth.write_gtf(os.path.join(gdir, "annot.gtf"), names, trs, annotated)
     m1, m2 = synth.make_reads(rng, seqs, trs, args.reads * world, args.read_len, True, frac_spliced=0.85, sub_rate=0.01, n_rate=0.001)
     for r in range(world):
         lo, hi = r * args.reads, (r + 1) * args.reads
         synth.write_fastq(os.path.join(d, "reads_r%d" % r), m1[lo:hi], m2[lo:hi])
-    import math
-    nb = max(4, min(14, int(math.log2(args.genome_mb * 1e6) / 2 - 1)))
-    refstar.genome_generate(os.path.join(d, "genome.fa"), os.path.join(d, "idx"), gtf=os.path.join(d, "annot.gtf"),
-                            sjdb_overhang=args.read_len - 1, sa_index_nbases=nb, threads=os.cpu_count() or 8)
+    if not os.path.isfile(gdone):
+        import math
+        nb = max(4, min(14, int(math.log2(args.genome_mb * 1e6) / 2 - 1)))
+        refstar.genome_generate(os.path.join(gdir, "genome.fa"), os.path.join(gdir, "idx"), gtf=os.path.join(gdir, "annot.gtf"),
+                                sjdb_overhang=args.read_len - 1, sa_index_nbases=nb, threads=os.cpu_count() or 8)
+        open(gdone, "w").write("ok\n")
+    for f in ("idx", "genome.fa", "annot.gtf"):
+        link = os.path.join(d, f)
+        if not os.path.lexists(link):
+            os.symlink(os.path.join(gdir, f), link)
     open(done, "w").write("ok\n")
     return d
 
