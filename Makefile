@@ -23,7 +23,7 @@ oracle: oracle/_build/liboracle.so
 
 star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
 	@mkdir -p star_amd/lib
-	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@
+	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@ -lz
 
 star_amd/lib/libstaramd.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p star_amd/lib

@@ -61,8 +61,9 @@ struct RunParams {
     bool outSAMunmappedWithin = false;
     bool outSAMprimaryAllBest = false;
     bool outSAMmodeNoQS = false;
+    bool outBAMunsorted = false; bool outSAMnone = false; int outBAMcompression = 1;   // --outSAMtype BAM Unsorted | None, --outBAMcompression
     std::vector<std::string> outSAMattrOrder = {"NH", "HI", "AS", "nM"};   // Standard
-    bool attrNMorMD = false;
+    bool attrNMorMD = false, attrHasCh = false;
     std::string readNameSeparator = "/";
     uint64_t gpuBatchReads = 65536;      // reads per device batch (ours; --gpuBatchReads)
     int gpuDevice = 0;
@@ -181,6 +182,10 @@ struct GeneCounts {
     std::string write(const std::string &path, const GeneAnnotation &A, const Stats &st) const;                  // Transcriptome.cpp:158-190
 };
 
+// ---- BGZF framing of BAM output (bgzf.cpp) ----
+bool bgzfCompress(const std::string &raw, int level, std::string &out);
+void bgzfEof(std::string &out);
+
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
 public:
@@ -193,6 +198,7 @@ public:
                              OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr) const;
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     std::string samHeader() const;                   // samHeaders.cpp:27-106
+    std::string bamHeader() const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:
     const RunParams &P;

@@ -88,15 +88,28 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "sjdbGTFtagExonParentGeneType") sjdbGTFtagExonParentGeneType = v;
         else if (k == "gpuDevice") gpuDevice = (int)I(k, v);
         else if (k == "genomeLoad") { if (one(k, v) != "NoSharedMemory") err = "EXITING: --genomeLoad: the index lives in HBM; only NoSharedMemory is accepted"; }
-        else if (k == "outSAMtype") { if (v.empty() || v[0] != "SAM") err = "EXITING: only --outSAMtype SAM is implemented (BAM: SURVEY.md 8f next #3)"; }
+        else if (k == "outSAMtype") {                   // Parameters.cpp:611-683
+            if (v.empty()) err = "EXITING because of fatal input ERROR: --outSAMtype needs a value";
+            else if (v[0] == "SAM") { if (v.size() > 1) err = "EXITING because of fatal PARAMETER error: --outSAMtype SAM can cannot be combined with " + v[1] + " or any other options\nSOLUTION: re-run STAR with with '--outSAMtype SAM' only, or with --outSAMtype BAM Unsorted|SortedByCoordinate\n"; }
+            else if (v[0] == "None") outSAMnone = true;
+            else if (v[0] == "BAM") {
+                if (v.size() < 2) err = "EXITING because of fatal PARAMETER error: missing BAM option\nSOLUTION: re-run STAR with one of the allowed values of --outSAMtype BAM Unsorted OR SortedByCoordinate OR both\n";
+                for (size_t i = 1; i < v.size() && err.empty(); i++) {
+                    if (v[i] == "Unsorted") outBAMunsorted = true;
+                    else if (v[i] == "SortedByCoordinate") err = "EXITING: --outSAMtype BAM SortedByCoordinate is not implemented by star_amd (use BAM Unsorted and sort downstream)";
+                    else err = "EXITING because of fatal input ERROR: unknown value for the word " + std::to_string(i + 1) + " of outSAMtype: " + v[i] + "\nSOLUTION: re-run STAR with one of the allowed values of --outSAMtype BAM Unsorted or SortedByCoordinate or both\n";
+                }
+            } else err = "EXITING because of fatal input ERROR: unknown value for the first word of outSAMtype: " + v[0] + "\nSOLUTION: re-run STAR with one of the allowed values of outSAMtype: BAM or SAM \n";
+        }
+        else if (k == "outBAMcompression") outBAMcompression = (int)I(k, v);
         else if (k == "outStd") { if (one(k, v) != "Log") err = "EXITING: only --outStd Log is implemented"; }
         else if (k == "outSAMmode") { const std::string &s = one(k, v); if (s == "NoQS") outSAMmodeNoQS = true; else if (s != "Full") err = "EXITING: unsupported --outSAMmode " + s; }
         else if (k == "outSAMunmapped") { if (v.size() >= 1 && v[0] == "Within") { outSAMunmappedWithin = true; if (v.size() > 1) err = "EXITING: --outSAMunmapped Within KeepPairs is not implemented"; } else if (!(v.size() == 1 && v[0] == "None")) err = "EXITING: unsupported --outSAMunmapped"; }
         else if (k == "outSAMattributes") {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
-            else if (v.size() >= 1 && v[0] == "All") err = "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
-            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC") outSAMattrOrder.push_back(t); else if (t == "ch") err = "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n"; else err = "EXITING: unsupported SAM attribute " + t; } }
+            else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC"}; attrHasCh = true; }   // + ch (Parameters_samAttributes.cpp:51-52)
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC") outSAMattrOrder.push_back(t); else if (t == "ch") attrHasCh = true; else err = "EXITING: unsupported SAM attribute " + t; } }
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
@@ -185,6 +198,8 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
+    // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
+    if (attrHasCh && !outBAMunsorted) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";

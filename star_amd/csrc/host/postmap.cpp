@@ -178,6 +178,201 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     }
 }
 
+// ================= BAM records (ReadAlign::alignBAM, source/ReadAlign_alignBAM.cpp:49-614; BAMfunctions.cpp) =================
+namespace {
+inline void put32(std::string &o, uint32_t v) { o.append((const char *)&v, 4); }
+inline int reg2bin(int beg, int end) {                   // BAMfunctions.cpp:101-110
+    --end;
+    if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (beg >> 14);
+    if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (beg >> 17);
+    if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (beg >> 20);
+    if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (beg >> 23);
+    if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (beg >> 26);
+    return 0;
+}
+inline void attrInt(std::string &a, const char *tag, int64_t x) {        // bamAttrArrayWriteInt (BAMfunctions.h:45-81): smallest type that holds x
+    a.push_back(tag[0]); a.push_back(tag[1]);
+    if (x < 0) {
+        if (x >= -127) { a.push_back('c'); int8_t v = (int8_t)x; a.append((const char *)&v, 1); }
+        else if (x >= -32767) { a.push_back('s'); int16_t v = (int16_t)x; a.append((const char *)&v, 2); }
+        else { a.push_back('i'); int32_t v = (int32_t)x; a.append((const char *)&v, 4); }
+    } else {
+        if (x <= 255) { a.push_back('C'); uint8_t v = (uint8_t)x; a.append((const char *)&v, 1); }
+        else if (x <= 65535) { a.push_back('S'); uint16_t v = (uint16_t)x; a.append((const char *)&v, 2); }
+        else { a.push_back('I'); uint32_t v = (uint32_t)x; a.append((const char *)&v, 4); }
+    }
+}
+inline void attrChar(std::string &a, const char *tag, char c) { a.push_back(tag[0]); a.push_back(tag[1]); a.push_back('A'); a.push_back(c); }
+inline void attrStr(std::string &a, const char *tag, const std::string &s) { a.push_back(tag[0]); a.push_back(tag[1]); a.push_back('Z'); a += s; a.push_back(0); }
+inline uint8_t nuclToNumBAM(char c) {                    // SequenceFuns.cpp:99-120  =ACMGRSVTWYHKDBN
+    switch (c) {
+        case '=': return 0; case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'M': case 'm': return 3; case 'G': case 'g': return 4;
+        case 'R': case 'r': return 5; case 'S': case 's': return 6; case 'V': case 'v': return 7; case 'T': case 't': return 8; case 'W': case 'w': return 9;
+        case 'Y': case 'y': return 10; case 'H': case 'h': return 11; case 'K': case 'k': return 12; case 'D': case 'd': return 13; case 'B': case 'b': return 14;
+        default: return 15;
+    }
+}
+// tail of a record: name, CIGAR, packed sequence, qualities, attributes (:547-590); the 9 core words come first
+void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, const std::vector<uint32_t> &cigar, std::string_view seq, std::string_view qual, bool rev,
+               bool noQS, const std::string &attr) {
+    size_t L = seq.size();
+    uint32_t recSize = 8 * 4 + (uint32_t)name.size() + 1 + (uint32_t)cigar.size() * 4 + (uint32_t)(L + 1) / 2 + (uint32_t)L + (uint32_t)attr.size();
+    put32(out, recSize);
+    out.append((const char *)core, 32);
+    out += name; out.push_back(0);
+    if (!cigar.empty()) out.append((const char *)cigar.data(), cigar.size() * 4);
+    auto base = [&](size_t k) { return rev ? rcNt(seq[L - 1 - k]) : seq[k]; };
+    for (size_t j = 0; j < L / 2; j++) out.push_back((char)(nuclToNumBAM(base(2 * j)) << 4 | nuclToNumBAM(base(2 * j + 1))));
+    if (L % 2 == 1) out.push_back((char)(nuclToNumBAM(base(L - 1)) << 4));
+    if (!noQS) { for (size_t k = 0; k < L; k++) out.push_back((char)((rev ? qual[L - 1 - k] : qual[k]) - 33)); }
+    else out.append(L, (char)0xFF);
+    out += attr;
+}
+} // namespace
+
+// mapped mates of one alignment (alignType -1)
+static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut) {
+    const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
+    const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
+    const bool flagPaired = rc.nMates == 2;
+    const uint32_t nEx = t.nExons;
+    uint32_t iExMate, nMates = 1;
+    for (iExMate = 0; iExMate + 1 < nEx; iExMate++) if (ex[iExMate].canonSJ == -3) { nMates = 2; break; }
+    const uint32_t Str = t.Str, leftMate = flagPaired ? Str : 0;
+    const uint64_t chrS = gi.chrStart[t.Chr], Lread = rc.Lread;
+    // CIGAR strings of both mates for MC (calcCIGAR)
+    std::string matesCIGAR[2];
+    std::vector<uint32_t> packed[2]; std::vector<int32_t> SJintron[2]; std::vector<char> SJmotif[2];
+    for (uint32_t imate = 0; imate < nMates; imate++) {
+        uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
+        uint32_t Mate = ex[iEx1].iFrag;
+        std::string &cg = matesCIGAR[imate]; std::vector<uint32_t> &pc = packed[imate];
+        auto op = [&](uint64_t len, char c, uint32_t code, bool inString) { pc.push_back((uint32_t)len << 4 | code); if (inString) { appendUint(cg, len); cg.push_back(c); } };
+        uint64_t trimL1 = ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
+        if (trimL1 > 0) op(trimL1, 'S', 4, true);
+        for (uint32_t ii = iEx1; ii <= iEx2; ii++) {
+            if (ii > iEx1) {
+                uint64_t gapG = ex[ii].G - (ex[ii - 1].G + ex[ii - 1].L);
+                uint64_t gapR = (uint64_t)ex[ii].R - ex[ii - 1].R - ex[ii - 1].L;
+                if (gapR > 0) op(gapR, 'I', 1, true);
+                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) {
+                    op(gapG, 'N', 3, true);
+                    SJmotif[imate].push_back((char)(ex[ii - 1].canonSJ + (ex[ii - 1].sjAnnot == 0 ? 0 : 20)));
+                    SJintron[imate].push_back((int32_t)(ex[ii - 1].G + ex[ii - 1].L + 1 - chrS)); SJintron[imate].push_back((int32_t)(ex[ii].G - chrS));
+                } else if (gapG > 0) op(gapG, 'D', 2, true);
+            }
+            // the CIGAR string of calcCIGAR always has the M; the packed one skips 0-length blocks (:223-224)
+            appendUint(cg, ex[ii].L); cg.push_back('M');
+            if (ex[ii].L > 0) pc.push_back((uint32_t)ex[ii].L << 4 | 0);
+        }
+        if (SJmotif[imate].empty()) { SJmotif[imate].push_back(-1); SJintron[imate].push_back(-1); }
+        uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLength[leftMate] : rc.readLength[leftMate] + 1 + rc.readLength[Mate]) - ex[iEx2].R - ex[iEx2].L;
+        if (trimR1 > 0) op(trimR1, 'S', 4, true);
+    }
+    for (uint32_t imate = 0; imate < nMates; imate++) {
+        uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
+        uint32_t Mate = ex[iEx1].iFrag;
+        uint32_t samFLAG = 0;
+        if (flagPaired) { samFLAG = 0x0001; if (iExMate == nEx - 1) samFLAG |= 0x0008; else samFLAG |= 0x0002; }     // mateChr == (uint)-1 > nChrReal
+        if (b.filter[ir] == 'Y') samFLAG |= 0x200;
+        if (!tv.primary) samFLAG |= 0x100;
+        if (Mate == 0) { samFLAG |= Str * 0x10; if (nMates == 2) samFLAG |= (1 - Str) * 0x20; }
+        else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
+        if (flagPaired) samFLAG |= (Mate == 0 ? 0x0040 : 0x0080);
+        int MAPQ = P.outSAMmapqUnique;
+        if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
+        // NM / MD of the BAM path (samAttrNM_MD :8-47): insertions of every gap and deletions of every non-junction gap count
+        uint64_t tagNM = 0; std::string tagMD;
+        if (P.attrNMorMD) {
+            const uint8_t *rd = b.bases.data() + b.readOffset[ir];
+            uint64_t matchN = 0, nMM = 0, nI = 0, nD = 0;
+            for (uint32_t iex = iEx1; iex <= iEx2; iex++) {
+                for (uint32_t ii = 0; ii < ex[iex].L; ii++) {
+                    uint64_t rp = (uint64_t)ex[iex].R + ii;
+                    uint8_t r1 = t.roStr == 0 ? rd[rp] : rd[Lread - 1 - rp];
+                    if (t.roStr != 0 && r1 < 4) r1 = 3 - r1;
+                    uint8_t g1 = gi.G[ex[iex].G + ii];
+                    if (r1 != g1 || r1 == 4 || g1 == 4) { ++nMM; appendUint(tagMD, matchN); tagMD.push_back("ACGTN"[g1 < 5 ? g1 : 4]); matchN = 0; }
+                    else matchN++;
+                }
+                if (iex < iEx2) {
+                    if (ex[iex].canonSJ < 0) nD += ex[iex + 1].G - (ex[iex].G + ex[iex].L);
+                    nI += (uint64_t)ex[iex + 1].R - ex[iex].R - ex[iex].L;
+                    if (ex[iex].canonSJ == -1) {
+                        appendUint(tagMD, matchN); tagMD.push_back('^');
+                        for (uint64_t ii = ex[iex].G + ex[iex].L; ii < ex[iex + 1].G; ii++) { uint8_t g1 = gi.G[ii]; tagMD.push_back("ACGTN"[g1 < 5 ? g1 : 4]); }
+                        matchN = 0;
+                    }
+                }
+            }
+            appendUint(tagMD, matchN);
+            tagNM = nMM + nI + nD;
+        }
+        std::string attr;
+        for (const std::string &a : P.outSAMattrOrder) {
+            if (a == "NH") attrInt(attr, "NH", (int64_t)nTrOut);
+            else if (a == "HI") attrInt(attr, "HI", (int64_t)iTrOut + P.outSAMattrIHstart);
+            else if (a == "AS") attrInt(attr, "AS", t.maxScore);
+            else if (a == "nM") attrInt(attr, "nM", t.nMM);
+            else if (a == "jM") { attr += "jMBc"; uint32_t n = (uint32_t)SJmotif[imate].size(); attr.append((const char *)&n, 4); attr.append(SJmotif[imate].data(), n); }
+            else if (a == "jI") { attr += "jIBi"; uint32_t n = (uint32_t)SJintron[imate].size(); attr.append((const char *)&n, 4); attr.append((const char *)SJintron[imate].data(), 4 * (size_t)n); }
+            else if (a == "XS") { if (t.sjMotifStrand == 1) attrChar(attr, "XS", '+'); else if (t.sjMotifStrand == 2) attrChar(attr, "XS", '-'); }
+            else if (a == "NM") attrInt(attr, "NM", (int64_t)tagNM);
+            else if (a == "MD") attrStr(attr, "MD", tagMD);
+            else if (a == "MC") { if (nMates > 1) attrStr(attr, "MC", matesCIGAR[1 - imate]); }
+        }
+        uint32_t core[8];
+        core[0] = t.Chr;
+        core[1] = (uint32_t)(ex[iEx1].G - chrS);
+        core[2] = ((uint32_t)reg2bin((int)(ex[iEx1].G - chrS), (int)(ex[iEx2].G + ex[iEx2].L - chrS)) << 16) | ((uint32_t)MAPQ << 8) | (uint32_t)(b.name(ir).size() + 1);
+        core[3] = (((samFLAG & P.outSAMflagAND) | P.outSAMflagOR) << 16) | (uint32_t)packed[imate].size();
+        core[4] = (uint32_t)b.seq((int)Mate, ir).size();
+        if (nMates > 1) {
+            core[5] = t.Chr; core[6] = (uint32_t)(ex[imate == 0 ? iExMate + 1 : 0].G - chrS);
+            int32_t tlen = (int32_t)(ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);                 // outSAMtlen 1
+            core[7] = (uint32_t)(imate == 0 ? tlen : -tlen);
+        } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
+        bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr);
+    }
+}
+
+// unmapped mates (alignType >= 0): both mates of an unmapped read, or the missing mate of a single-end alignment (:120-188)
+static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const staramd_transcript *trBest, const staramd_exon *exBest,
+                        int unmapType, const bool mateMap[2]) {
+    const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
+    for (int imate = 0; imate < rc.nMates; imate++) {
+        if (mateMap[imate]) continue;
+        uint32_t samFLAG = 0x4; uint32_t mateChr = (uint32_t)-1, mateStart = (uint32_t)-1;
+        if (rc.nMates == 2) {
+            samFLAG |= 0x1 + (imate == 0 ? 0x40 : 0x80);
+            if (mateMap[1 - imate]) {
+                if (trBest->Str != (uint32_t)(1 - imate)) samFLAG |= 0x20;
+                mateChr = trBest->Chr; mateStart = (uint32_t)(exBest[0].G - gi.chrStart[mateChr]);
+            } else samFLAG |= 0x8;
+        }
+        if (b.filter[ir] == 'Y') samFLAG |= 0x200;
+        std::string attr;
+        attrInt(attr, "NH", 0); attrInt(attr, "HI", 0); attrInt(attr, "AS", trBest ? trBest->maxScore : 0); attrInt(attr, "nM", trBest ? trBest->nMM : 0);
+        attrChar(attr, "uT", (char)('0' + unmapType));
+        uint32_t core[8];
+        core[0] = (uint32_t)-1; core[1] = (uint32_t)-1;
+        core[2] = ((uint32_t)reg2bin(-1, 0) << 16) | (uint32_t)(b.name(ir).size() + 1);
+        core[3] = (((samFLAG & P.outSAMflagAND) | P.outSAMflagOR) << 16);
+        core[4] = (uint32_t)b.seq(imate, ir).size();
+        if (mateChr < gi.view.nChrReal) { core[5] = mateChr; core[6] = mateStart; } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; }
+        core[7] = 0;
+        bamFinish(out, core, b.name(ir), std::vector<uint32_t>(), b.seq(imate, ir), b.qual(imate, ir), false, P.outSAMmodeNoQS, attr);
+    }
+}
+
+std::string PostMap::bamHeader() const {
+    std::string samh = samHeader(), h = "BAM\1";
+    put32(h, (uint32_t)samh.size()); h += samh;
+    put32(h, gi.view.nChrReal);
+    for (uint32_t i = 0; i < gi.view.nChrReal; i++) { put32(h, (uint32_t)gi.chrName[i].size() + 1); h += gi.chrName[i]; h.push_back(0); put32(h, (uint32_t)gi.chrLength[i]); }
+    return h;
+}
+
 // ---- ReadAlign::outputTranscriptSAM, unmapped branch (:11-54) ----
 static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const staramd_transcript *trBest, const staramd_exon *exBest,
                         int unmapType, const bool mateMap[2]) {
@@ -294,14 +489,15 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             recordSJ(P, trMult, nTr, sj);
             if (gc && nTr > 0) gc->addAlign(*genes, nTr, *trMult[0].t, trMult[0].ex);        // alignedAnnotation (ReadAlign_outputAlignments.cpp:298-308)
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
-            if (!samOff) for (uint64_t it = 0; it < nTr; it++) samMapped(sam, P, gi, rc, trMult[it], nTr, it);
+            if (!samOff) for (uint64_t it = 0; it < nTr; it++) { if (P.outBAMunsorted) bamMapped(sam, P, gi, rc, trMult[it], nTr, it); else samMapped(sam, P, gi, rc, trMult[it], nTr, it); }
             const staramd_exon *exB = r.ex + trBest->exonOffset;
             mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
             if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
-            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff) samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
+            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff) { if (P.outBAMunsorted) bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped); else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped); }
         } else if (P.outSAMunmappedWithin && !samOff) {
             staramd_transcript t0; memset(&t0, 0, sizeof(t0));
-            samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
+            if (P.outBAMunsorted) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
+            else samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
         }
         if (unmapType >= 0) st.unmappedAll++;
     }

@@ -82,12 +82,17 @@ struct Runner {
             pass1 = true; post->samOff = true; readMapNumberUser = P.readMapNumber;
             if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
         }
-        std::string samPath = P.outFileNamePrefix + "Aligned.out.sam";
-        samOut = fopen(samPath.c_str(), "wb");
-        if (!samOut) { error = "EXITING because of fatal ERROR: could not create output file " + samPath; return false; }
-        setvbuf(samOut, nullptr, _IOFBF, 1 << 22);
-        std::string h = post->samHeader();
-        fwrite(h.data(), 1, h.size(), samOut);
+        if (P.outSAMnone) post->samOff = true;                      // --outSAMtype None
+        else {
+            std::string samPath = P.outFileNamePrefix + (P.outBAMunsorted ? "Aligned.out.bam" : "Aligned.out.sam");
+            samOut = fopen(samPath.c_str(), "wb");
+            if (!samOut) { error = "EXITING because of fatal ERROR: could not create output file " + samPath; return false; }
+            setvbuf(samOut, nullptr, _IOFBF, 1 << 22);
+            std::string h;
+            if (P.outBAMunsorted) { if (!bgzfCompress(post->bamHeader(), P.outBAMcompression, h)) { error = "EXITING because of fatal ERROR: BGZF compression failed"; return false; } }
+            else h = post->samHeader();
+            fwrite(h.data(), 1, h.size(), samOut);
+        }
         startWriter();
         time(&stats.timeStartMap);
         return true;
@@ -102,7 +107,7 @@ struct Runner {
     }
     // ---- SAM text goes to the file on its own thread: formatting of batch k+1 overlaps the write of batch k.  Two sets of
     // per-thread text buffers alternate and keep their capacity (no fresh pages per batch).
-    struct OutSet { std::vector<std::string> sams; uint32_t used = 0; };
+    struct OutSet { std::vector<std::string> sams, raws; uint32_t used = 0; };
     OutSet outSets[2];
     std::mutex wm; std::condition_variable wcv;
     std::deque<int> freeSets, fullSets; bool writerStop = false, writerFailed = false;
@@ -113,7 +118,7 @@ struct Runner {
             { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !fullSets.empty() || writerStop; }); if (fullSets.empty()) return; k = fullSets.front(); fullSets.pop_front(); }
             OutSet &o = outSets[k];
             for (uint32_t t = 0; t < o.used; t++)
-                if (!o.sams[t].empty() && fwrite(o.sams[t].data(), 1, o.sams[t].size(), samOut) != o.sams[t].size()) writerFailed = true;
+                if (!o.sams[t].empty() && samOut && fwrite(o.sams[t].data(), 1, o.sams[t].size(), samOut) != o.sams[t].size()) writerFailed = true;
             { std::lock_guard<std::mutex> l(wm); freeSets.push_back(k); }
             wcv.notify_all();
         }
@@ -133,7 +138,7 @@ struct Runner {
         int k;
         { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !freeSets.empty(); }); k = freeSets.front(); freeSets.pop_front(); }
         OutSet &o = outSets[k];
-        if (o.sams.size() < T) o.sams.resize(T);
+        if (o.sams.size() < T) { o.sams.resize(T); o.raws.resize(T); }
         o.used = T;
         std::vector<std::string> errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
         const bool stage1 = bySJoutStage == 1;
@@ -144,6 +149,13 @@ struct Runner {
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
             o.sams[t].clear();
+            if (P.outBAMunsorted && !post->samOff) {                 // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
+                std::string &raw = o.raws[t];
+                raw.clear();
+                errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr);
+                if (errs[t].empty() && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
+                return;
+            }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr);
         };
         if (T == 1) work(0);
@@ -190,7 +202,7 @@ struct Runner {
         time_t t0 = stats.timeStart;
         stats = Stats(); stats.timeStart = t0; time(&stats.timeStartMap);
         sj.data.clear();
-        P.readMapNumber = readMapNumberUser; post->samOff = false; pass1 = false;
+        P.readMapNumber = readMapNumberUser; post->samOff = P.outSAMnone; pass1 = false;
         if (P.outFilterBySJout) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         return true;
     }
@@ -215,7 +227,10 @@ struct Runner {
     bool finish() {
         stopWriter();
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
-        if (samOut) { fclose(samOut); samOut = nullptr; }
+        if (samOut) {
+            if (P.outBAMunsorted) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), samOut); }
+            fclose(samOut); samOut = nullptr;
+        }
         error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");

@@ -205,3 +205,26 @@ def make_edge_reads(info, outdir, paired=True, seed=7):
     for f in fo:
         f.close()
     return paths
+
+
+def bam_parts(path):
+    """(header text, reference block, list of records) of a BAM file, BGZF blocks decompressed with Python's gzip module."""
+    import gzip
+    import struct
+    d = gzip.open(path, "rb").read()
+    assert d[:4] == b"BAM\x01"
+    lt = struct.unpack("<i", d[4:8])[0]
+    text = d[8:8 + lt]
+    p0 = p = 8 + lt
+    nref = struct.unpack("<i", d[p:p + 4])[0]
+    p += 4
+    for _ in range(nref):
+        ln = struct.unpack("<i", d[p:p + 4])[0]
+        p += 4 + ln + 4
+    recs = []
+    q = p
+    while q < len(d):
+        bs = struct.unpack("<i", d[q:q + 4])[0]
+        recs.append(d[q:q + 4 + bs])
+        q += 4 + bs
+    return text, d[p0:p], recs
