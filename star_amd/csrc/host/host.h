@@ -61,7 +61,7 @@ struct RunParams {
     bool outSAMunmappedWithin = false;
     bool outSAMprimaryAllBest = false;
     bool outSAMmodeNoQS = false;
-    bool outBAMunsorted = false; bool outSAMnone = false; int outBAMcompression = 1;   // --outSAMtype BAM Unsorted | None, --outBAMcompression
+    bool outBAMunsorted = false, outBAMcoord = false; bool outSAMnone = false; int outBAMcompression = 1;   // --outSAMtype BAM Unsorted | None, --outBAMcompression
     std::vector<std::string> outSAMattrOrder = {"NH", "HI", "AS", "nM"};   // Standard
     bool attrNMorMD = false, attrHasCh = false;
     std::string readNameSeparator = "/";
@@ -101,6 +101,8 @@ struct ReadBatch {
     std::vector<TextSpan> seqSpan[2], qualSpan[2];
     std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
     uint64_t firstReadIndex = 0;
+    std::vector<uint64_t> origIndex;      // 2nd stage of BySJout: index of the read in the original input (empty otherwise)
+    uint64_t readIndex(uint32_t i) const { return origIndex.empty() ? firstReadIndex + i : origIndex[i]; }
     std::string_view name(uint32_t i) const { return std::string_view(text[0].data() + nameSpan[i].off, nameSpan[i].len); }
     std::string_view seq(int m, uint32_t i) const { return std::string_view(text[m].data() + seqSpan[m][i].off, seqSpan[m][i].len); }
     std::string_view qual(int m, uint32_t i) const { return std::string_view(text[m].data() + qualSpan[m][i].off, qualSpan[m][i].len); }
@@ -186,19 +188,23 @@ struct GeneCounts {
 bool bgzfCompress(const std::string &raw, int level, std::string &out);
 void bgzfEof(std::string &out);
 
+// sort key of one BAM record (BAMoutput::coordOneAlign, BAMbinSortByCoordinate.cpp:45-56): (refID << 32 | pos, read order, order of production)
+struct BamKey { uint64_t g, r; uint64_t off; uint32_t len; uint32_t chunk; };
+
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
 public:
     PostMap(const RunParams &P, const GenomeIndex &gi) : P(P), gi(gi) {}
     // consumes the device (or oracle) results of one batch; appends SAM text to `sam`
     std::string process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st);
+    // bamKeys (with --outSAMtype BAM SortedByCoordinate): one entry per BAM record appended to `sam`
     // sj1 / held: 1st stage of --outFilterType BySJout (ReadAlign_outputAlignments.cpp:90-124): junctions of every read go to sj1,
     // reads with an unannotated junction are not output but listed in `held` for the 2nd stage
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr) const;
+                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr) const;
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     std::string samHeader() const;                   // samHeaders.cpp:27-106
-    std::string bamHeader() const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)
+    std::string bamHeader(bool sortedByCoordinate = false) const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:
     const RunParams &P;

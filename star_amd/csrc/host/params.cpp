@@ -96,7 +96,7 @@ std::string RunParams::parse(int argc, char **argv) {
                 if (v.size() < 2) err = "EXITING because of fatal PARAMETER error: missing BAM option\nSOLUTION: re-run STAR with one of the allowed values of --outSAMtype BAM Unsorted OR SortedByCoordinate OR both\n";
                 for (size_t i = 1; i < v.size() && err.empty(); i++) {
                     if (v[i] == "Unsorted") outBAMunsorted = true;
-                    else if (v[i] == "SortedByCoordinate") err = "EXITING: --outSAMtype BAM SortedByCoordinate is not implemented by star_amd (use BAM Unsorted and sort downstream)";
+                    else if (v[i] == "SortedByCoordinate") outBAMcoord = true;
                     else err = "EXITING because of fatal input ERROR: unknown value for the word " + std::to_string(i + 1) + " of outSAMtype: " + v[i] + "\nSOLUTION: re-run STAR with one of the allowed values of --outSAMtype BAM Unsorted or SortedByCoordinate or both\n";
                 }
             } else err = "EXITING because of fatal input ERROR: unknown value for the first word of outSAMtype: " + v[0] + "\nSOLUTION: re-run STAR with one of the allowed values of outSAMtype: BAM or SAM \n";
@@ -199,7 +199,7 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
-    if (attrHasCh && !outBAMunsorted) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
+    if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";

@@ -231,7 +231,7 @@ void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, 
 } // namespace
 
 // mapped mates of one alignment (alignType -1)
-static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut) {
+static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, std::vector<BamKey> *keys) {
     const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     const bool flagPaired = rc.nMates == 2;
@@ -332,13 +332,16 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             int32_t tlen = (int32_t)(ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);                 // outSAMtlen 1
             core[7] = (uint32_t)(imate == 0 ? tlen : -tlen);
         } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
+        const size_t off0 = out.size();
         bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr);
+        // BAMoutput::coordOneAlign key (ReadAlign_outputAlignments.cpp:196-199): iReadAll << 32 | iTr << 8 | mate of the first exon
+        if (keys) keys->push_back(BamKey{((uint64_t)core[0] << 32) | core[1], (b.readIndex(ir) << 32) | (iTrOut << 8) | ex[0].iFrag, off0, (uint32_t)(out.size() - off0), 0});
     }
 }
 
 // unmapped mates (alignType >= 0): both mates of an unmapped read, or the missing mate of a single-end alignment (:120-188)
 static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const staramd_transcript *trBest, const staramd_exon *exBest,
-                        int unmapType, const bool mateMap[2]) {
+                        int unmapType, const bool mateMap[2], std::vector<BamKey> *keys) {
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     for (int imate = 0; imate < rc.nMates; imate++) {
         if (mateMap[imate]) continue;
@@ -361,12 +364,15 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         core[4] = (uint32_t)b.seq(imate, ir).size();
         if (mateChr < gi.view.nChrReal) { core[5] = mateChr; core[6] = mateStart; } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; }
         core[7] = 0;
+        const size_t off0 = out.size();
         bamFinish(out, core, b.name(ir), std::vector<uint32_t>(), b.seq(imate, ir), b.qual(imate, ir), false, P.outSAMmodeNoQS, attr);
+        if (keys) keys->push_back(BamKey{~0ull, b.readIndex(ir) << 32, off0, (uint32_t)(out.size() - off0), 0});      // unmapped: last, in read order
     }
 }
 
-std::string PostMap::bamHeader() const {
+std::string PostMap::bamHeader(bool sortedByCoordinate) const {
     std::string samh = samHeader(), h = "BAM\1";
+    if (sortedByCoordinate) samh.insert(samh.find('\n'), "\tSO:coordinate");     // samHeaders.cpp:99
     put32(h, (uint32_t)samh.size()); h += samh;
     put32(h, gi.view.nChrReal);
     for (uint32_t i = 0; i < gi.view.nChrReal; i++) { put32(h, (uint32_t)gi.chrName[i].size() + 1); h += gi.chrName[i]; h.push_back(0); put32(h, (uint32_t)gi.chrLength[i]); }
@@ -429,7 +435,8 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 }
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc) const {
+                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys) const {
+    const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];
@@ -489,14 +496,14 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             recordSJ(P, trMult, nTr, sj);
             if (gc && nTr > 0) gc->addAlign(*genes, nTr, *trMult[0].t, trMult[0].ex);        // alignedAnnotation (ReadAlign_outputAlignments.cpp:298-308)
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
-            if (!samOff) for (uint64_t it = 0; it < nTr; it++) { if (P.outBAMunsorted) bamMapped(sam, P, gi, rc, trMult[it], nTr, it); else samMapped(sam, P, gi, rc, trMult[it], nTr, it); }
+            if (!samOff) for (uint64_t it = 0; it < nTr; it++) { if (bam) bamMapped(sam, P, gi, rc, trMult[it], nTr, it, bamKeys); else samMapped(sam, P, gi, rc, trMult[it], nTr, it); }
             const staramd_exon *exB = r.ex + trBest->exonOffset;
             mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
             if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
-            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff) { if (P.outBAMunsorted) bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped); else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped); }
+            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff) { if (bam) bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped, bamKeys); else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped); }
         } else if (P.outSAMunmappedWithin && !samOff) {
             staramd_transcript t0; memset(&t0, 0, sizeof(t0));
-            if (P.outBAMunsorted) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
+            if (bam) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped, bamKeys);
             else samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
         }
         if (unmapType >= 0) st.unmappedAll++;

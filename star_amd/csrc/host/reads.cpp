@@ -27,7 +27,7 @@ staramd_batch ReadBatch::view() const {
 }
 void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
-    nameSpan.clear(); filter.clear();
+    nameSpan.clear(); filter.clear(); origIndex.clear();
     for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); }
 }
 
@@ -177,6 +177,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     b.n = (uint32_t)n;
     b.readOffset.assign(n + 1, 0); b.mate1Length.assign(n, 0); b.mmMaxTotal.assign(n, 0);
     b.nameSpan.assign(n, TextSpan{0, 0}); b.filter.assign(n, 'N');
+    if (fromMemory) b.origIndex.assign(n, 0);
     for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); }
     lap("alloc");
     const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(std::max(P.runThreadN, 1), 32), n / 2048));
@@ -215,6 +216,11 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
                 uint64_t f3 = f2;
                 while (f3 < e0 && t0[f3] != ' ' && t0[f3] != '\t') f3++;
                 if (f3 - f2 >= 3 && t0[f2 + 1] == ':' && t0[f2 + 2] == 'Y' && (f2 + 3 < f3 ? t0[f2 + 3] == ':' : false)) b.filter[i] = 'Y';
+                if (fromMemory) {                       // held reads carry their index in the original input as a third field
+                    uint64_t f4 = f3; while (f4 < e0 && (t0[f4] == ' ' || t0[f4] == '\t')) f4++;
+                    uint64_t v = 0; while (f4 < e0 && t0[f4] >= '0' && t0[f4] <= '9') { v = v * 10 + (uint64_t)(t0[f4] - '0'); f4++; }
+                    b.origIndex[i] = v;
+                }
             }
             uint64_t ne = e;
             for (char c : P.readNameSeparator) { const void *q = memchr(t0 + p, c, ne - p); if (q) ne = (uint64_t)((const char *)q - t0); }

@@ -38,6 +38,7 @@ struct Runner {
     std::string heldText[2];            // held reads as FASTQ text
     std::vector<uint64_t> novelStart, novelEnd;
     GeneAnnotation genes; GeneCounts geneCounts;      // --quantMode GeneCounts
+    std::vector<std::string> coordChunks; std::vector<BamKey> coordKeys;     // --outSAMtype BAM SortedByCoordinate: every record, until finish()
     int wireTable = 0;                                // which junction table sah_sj_export / import / clear address: 0 = sj, 1 = sj1
     OutSJ &wire() { return wireTable == 1 ? sj1 : sj; }
     int64_t readMapNumberUser = -1;
@@ -83,6 +84,7 @@ struct Runner {
             if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
         }
         if (P.outSAMnone) post->samOff = true;                      // --outSAMtype None
+        else if (P.outBAMcoord && !P.outBAMunsorted) {}             // only Aligned.sortedByCoord.out.bam, written at the end of the run
         else {
             std::string samPath = P.outFileNamePrefix + (P.outBAMunsorted ? "Aligned.out.bam" : "Aligned.out.sam");
             samOut = fopen(samPath.c_str(), "wb");
@@ -145,15 +147,17 @@ struct Runner {
         std::vector<OutSJ> sj1s(stage1 ? T : 0); std::vector<std::vector<uint32_t> > helds(stage1 ? T : 0);
         const bool quant = P.quantGeneCounts && !pass1;             // twoPassRunPass1.cpp:24-29: no quantification in the 1st pass
         std::vector<GeneCounts> gcs(quant ? T : 0, GeneCounts(quant ? genes.geID.size() : 0));
+        std::vector<std::vector<BamKey> > keyss(P.outBAMcoord ? T : 0);
         uint32_t per = (bt.n + T - 1) / T;
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
             o.sams[t].clear();
-            if (P.outBAMunsorted && !post->samOff) {                 // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
+            if ((P.outBAMunsorted || P.outBAMcoord) && !post->samOff) {     // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
                 std::string &raw = o.raws[t];
                 raw.clear();
-                errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr);
-                if (errs[t].empty() && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
+                errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
+                                             P.outBAMcoord ? &keyss[t] : nullptr);
+                if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr);
@@ -171,13 +175,20 @@ struct Runner {
         wcv.notify_all();
         if (!error.empty()) return false;
         for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); if (quant) geneCounts.add(gcs[t]); }
+        if (P.outBAMcoord && !post->samOff)                         // keep the records for the coordinate sort at the end of the run (in memory)
+            for (uint32_t t = 0; t < T; t++) {
+                if (keyss[t].empty()) continue;
+                uint32_t chunk = (uint32_t)coordChunks.size();
+                for (BamKey &k : keyss[t]) { k.chunk = chunk; coordKeys.push_back(k); }
+                coordChunks.emplace_back(P.outBAMunsorted ? o.raws[t] : std::move(o.raws[t]));
+            }
         if (stage1) {
             for (uint32_t t = 0; t < T; t++) {
                 sj1.mergeFrom(sj1s[t]);
                 for (uint32_t ir : helds[t])                         // held reads, in input order (ReadAlign_outputAlignments.cpp:108-121)
                     for (uint32_t m = 0; m < P.dev.readNmates; m++) {
                         std::string &x = heldText[m];
-                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0\n" : " 0:N:0\n";
+                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0 " : " 0:N:0 "; x += std::to_string(bt.readIndex(ir)); x.push_back('\n');
                         x += bt.seq((int)m, ir); x += "\n+\n"; x += bt.qual((int)m, ir); x.push_back('\n');
                     }
             }
@@ -186,6 +197,42 @@ struct Runner {
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
         return true;
+    }
+    // Aligned.sortedByCoord.out.bam (BAMbinSortByCoordinate.cpp, BAMbinSortUnmapped.cpp): mapped records by (refID << 32 | pos, read order,
+    // order of production), then the unmapped ones in read order.  The reference sorts genomic bins from temporary files; here all
+    // records of the run are held in memory, ordered once and compressed on the host threads, slice by slice.
+    std::string writeSortedBam() {
+        std::string path = P.outFileNamePrefix + "Aligned.sortedByCoord.out.bam";
+        FILE *f = fopen(path.c_str(), "wb");
+        if (!f) return "EXITING because of fatal ERROR: could not create output file " + path;
+        std::string h;
+        if (!bgzfCompress(post->bamHeader(true), P.outBAMcompression, h)) { fclose(f); return "EXITING because of fatal ERROR: BGZF compression failed"; }
+        fwrite(h.data(), 1, h.size(), f);
+        std::vector<uint64_t> ord(coordKeys.size());
+        for (uint64_t i = 0; i < ord.size(); i++) ord[i] = i;
+        const std::vector<BamKey> &K = coordKeys;
+        std::sort(ord.begin(), ord.end(), [&K](uint64_t a, uint64_t b) { return K[a].g != K[b].g ? K[a].g < K[b].g : K[a].r != K[b].r ? K[a].r < K[b].r : a < b; });
+        const uint64_t n = ord.size();
+        const uint64_t T = (uint64_t)std::max(1, std::min(P.runThreadN, 64));
+        const uint64_t per = std::max<uint64_t>(4096, (n + 4 * T - 1) / (4 * T));          // records per slice; slices are written in order
+        bool failed = false;
+        for (uint64_t base = 0; base < n && !failed; base += per * T) {
+            std::vector<std::string> outS(T); std::vector<std::thread> th;
+            auto work = [&](uint64_t t) {
+                uint64_t lo = std::min(n, base + t * per), hi = std::min(n, lo + per);
+                std::string raw;
+                for (uint64_t i = lo; i < hi; i++) { const BamKey &k = K[ord[i]]; raw.append(coordChunks[k.chunk], k.off, k.len); }
+                if (!bgzfCompress(raw, P.outBAMcompression, outS[t])) failed = true;
+            };
+            for (uint64_t t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            for (uint64_t t = 0; t < T; t++) if (!outS[t].empty() && fwrite(outS[t].data(), 1, outS[t].size(), f) != outS[t].size()) failed = true;
+        }
+        std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), f);
+        fclose(f);
+        coordChunks.clear(); coordKeys.clear();
+        return failed ? "EXITING because of fatal ERROR: could not write " + path : "";
     }
     bool emit(const staramd_results *r) { return emitBatch(batch, r); }
     // end of the 1st pass (twoPassRunPass1.cpp:75-96): junctions + Log.final.out of the pass into _STARpass1/, insertion of the
@@ -231,6 +278,7 @@ struct Runner {
             if (P.outBAMunsorted) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), samOut); }
             fclose(samOut); samOut = nullptr;
         }
+        if (P.outBAMcoord && !P.outSAMnone) { error = writeSortedBam(); if (!error.empty()) return false; }
         error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
