@@ -36,7 +36,7 @@ struct RunParams {
     staramd_params dev;                 // what reaches the device hot path
     // run
     std::string genomeDir, outFileNamePrefix = "./";
-    std::vector<std::string> readFilesIn;
+    std::vector<std::string> readFilesIn;   // one entry per mate; each may be a comma-separated list of files (read in turn)
     std::string readFilesCommand;        // --readFilesCommand, "" = read the files directly
     int runThreadN = 1;
     int64_t readMapNumber = -1;
@@ -80,6 +80,11 @@ struct RunParams {
     bool sjdbInsertPass1() const { return !sjdbFileChrStartEnd.empty() || !sjdbGTFfile.empty(); }
     bool sjdbInsertYes() const { return twopass || sjdbInsertPass1(); }
     bool outFilterBySJout = false;       // --outFilterType BySJout
+    std::vector<std::string> outSAMattrRG, outSAMattrRGlineSplit;   // --outSAMattrRGline (Parameters_readFilesInit.cpp:64-93)
+    bool outReadsUnmappedFastx = false;  // --outReadsUnmapped Fastx
+    bool outSAMreadIDnumber = false;     // --outSAMreadID Number
+    int outSAMtlen = 1;                  // --outSAMtlen 1 | 2
+    int64_t outSAMmultNmax = -1;         // --outSAMmultNmax
     bool quantGeneCounts = false;        // --quantMode GeneCounts
 
     RunParams();
@@ -102,6 +107,7 @@ struct ReadBatch {
     std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
     uint64_t firstReadIndex = 0;
     std::vector<uint64_t> origIndex;      // 2nd stage of BySJout: index of the read in the original input (empty otherwise)
+    uint32_t fileIndex = 0;               // which of the comma-separated input files the batch came from (a batch never spans two)
     uint64_t readIndex(uint32_t i) const { return origIndex.empty() ? firstReadIndex + i : origIndex[i]; }
     std::string_view name(uint32_t i) const { return std::string_view(text[0].data() + nameSpan[i].off, nameSpan[i].len); }
     std::string_view seq(int m, uint32_t i) const { return std::string_view(text[m].data() + seqSpan[m][i].off, seqSpan[m][i].len); }
@@ -114,7 +120,7 @@ class FastqReader {
 public:
     ~FastqReader();
     // readCommand: --readFilesCommand (e.g. "zcat", "gunzip -c"); the text then comes from a pipe (Parameters_openReadsFiles.cpp:23-96)
-    std::string open(const std::vector<std::string> &paths, const std::string &readCommand = "");
+    std::string open(const std::vector<std::string> &paths, const std::string &readCommand = "");   // paths[m] = comma-separated list for mate m
     void openMemory(std::string mate1, std::string mate2, int nMatesIn);   // FASTQ text held in memory (2nd stage of BySJout)
     std::string reopen();                 // rewind to the first read (Parameters::closeReadsFiles/openReadsFiles between the two passes)
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
@@ -126,6 +132,8 @@ private:
     FILE *f[2] = {nullptr, nullptr};
     int nMates = 0;
     std::vector<std::string> paths_; std::string command_;
+    std::vector<std::string> files_[2]; size_t curFile = 0;
+    std::string openCurrent();
     void closeFiles();
     std::string mem[2]; size_t memPos[2] = {0, 0}; bool fromMemory = false;
     std::vector<char> carry[2];           // text read from the file but not yet part of a batch
@@ -201,7 +209,8 @@ public:
     // sj1 / held: 1st stage of --outFilterType BySJout (ReadAlign_outputAlignments.cpp:90-124): junctions of every read go to sj1,
     // reads with an unannotated junction are not output but listed in `held` for the 2nd stage
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr) const;
+                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr,
+                             std::string *unmappedFastx = nullptr) const;      // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     std::string bamHeader(bool sortedByCoordinate = false) const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)

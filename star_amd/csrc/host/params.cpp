@@ -109,7 +109,7 @@ std::string RunParams::parse(int argc, char **argv) {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
             else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC"}; attrHasCh = true; }   // + ch (Parameters_samAttributes.cpp:51-52)
-            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC") outSAMattrOrder.push_back(t); else if (t == "ch") attrHasCh = true; else err = "EXITING: unsupported SAM attribute " + t; } }
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG") outSAMattrOrder.push_back(t); else if (t == "ch") attrHasCh = true; else err = "EXITING: unsupported SAM attribute " + t; } }
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
@@ -118,6 +118,23 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMflagOR") outSAMflagOR = (uint32_t)U(k, v);
         else if (k == "outSAMflagAND") outSAMflagAND = (uint32_t)U(k, v);
         else if (k == "readNameSeparator") readNameSeparator = one(k, v);
+        else if (k == "outSAMattrRGline") {                // Parameters_readFilesInit.cpp:64-82
+            if (!(v.size() == 1 && v[0] == "-")) {
+                for (size_t ii = 0; ii < v.size(); ii++) {
+                    if (ii == 0 || v[ii] == ",") {
+                        if (ii > 0) ++ii;
+                        if (ii >= v.size()) break;
+                        outSAMattrRGlineSplit.push_back(v[ii]);
+                        if (v[ii].substr(0, 3) != "ID:") { err = "EXITING because of FATAL INPUT ERROR: the first word of a line from --outSAMattrRGline=" + v[ii] + " does not start with ID:xxx read group identifier\nSOLUTION: re-run STAR with all lines in --outSAMattrRGline starting with ID:xxx\n"; break; }
+                        outSAMattrRG.push_back(v[ii].substr(3));
+                    } else outSAMattrRGlineSplit.back() += "\t" + v[ii];
+                }
+            }
+        }
+        else if (k == "outReadsUnmapped") { const std::string &m = one(k, v); if (m == "Fastx") outReadsUnmappedFastx = true; else if (m != "None") err = "EXITING because of fatal input ERROR: unknown value of --outReadsUnmapped " + m; }
+        else if (k == "outSAMreadID") { const std::string &m = one(k, v); if (m == "Number") outSAMreadIDnumber = true; else if (m != "Standard") err = "EXITING because of fatal input ERROR: unknown value of --outSAMreadID " + m; }
+        else if (k == "outSAMtlen") { outSAMtlen = (int)I(k, v); if (outSAMtlen != 1 && outSAMtlen != 2) err = "EXITING because of fatal PARAMETERS error: --outSAMtlen can only be 1 or 2"; }
+        else if (k == "outSAMmultNmax") outSAMmultNmax = I(k, v);
         else if (k == "quantMode") {
             for (auto &t : v) { if (t == "GeneCounts") quantGeneCounts = true; else if (t != "-") err = "EXITING because of fatal INPUT error: unrecognized option in --quantMode=" + t + "\nSOLUTION: use one of the allowed values of --quantMode : GeneCounts or - (TranscriptomeSAM is not implemented by the MI355X engine).\n"; }
         }
@@ -198,6 +215,15 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
+    {   // read groups: one for all input files or one per file; the RG attribute comes with them (Parameters_readFilesInit.cpp:84-93, Parameters_samAttributes.cpp:201-206)
+        size_t nFiles = readFilesIn.empty() ? 0 : (size_t)std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') + 1;
+        if (outSAMattrRG.size() > 1 && outSAMattrRG.size() != nFiles)
+            return "EXITING: because of fatal INPUT ERROR: number of input read files: " + std::to_string(nFiles) + " does not agree with number of read group RG entries: " + std::to_string(outSAMattrRG.size()) + "\nMake sure that the number of RG lines in --outSAMattrRGline is equal to either 1, or the number of input read files in --readFilesIn\n";
+        if (outSAMattrRG.size() == 1) for (size_t i = 1; i < nFiles; i++) outSAMattrRG.push_back(outSAMattrRG[0]);
+        bool hasRG = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "RG") != outSAMattrOrder.end();
+        if (!outSAMattrRG.empty() && !hasRG) outSAMattrOrder.push_back("RG");
+        if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
+    }
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();

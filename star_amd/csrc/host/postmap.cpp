@@ -49,6 +49,7 @@ std::string PostMap::samHeader() const {
     std::string h = "@HD\tVN:1.4\n";
     for (uint32_t i = 0; i < gi.view.nChrReal; i++) { h += "@SQ\tSN:" + gi.chrName[i] + "\tLN:"; appendUint(h, gi.chrLength[i]); h += "\n"; }
     h += "@PG\tID:STAR\tPN:STAR\tVN:2.7.11b\tCL:" + P.commandLine + "\n";
+    for (const std::string &rg : P.outSAMattrRGlineSplit) h += "@RG\t" + rg + "\n";                  // samHeaders.cpp:78-80
     h += "@CO\tuser command line: " + P.commandLine + "\n";
     return h;
 }
@@ -151,7 +152,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         if (nMates > 1) {
             out += "\t=\t"; appendUint(out, ex[imate == 0 ? iExMate + 1 : 0].G + 1 - chrS); out.push_back('\t');
             if (imate != 0) out.push_back('-');
-            appendUint(out, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);
+            appendUint(out, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);        // (--outSAMtlen 2 changes BAM output only, as in the reference)
         } else out += "\t*\t0\t0";
         out.push_back('\t');
         const std::string_view sq = b.seq((int)Mate, ir), ql = b.qual((int)Mate, ir);
@@ -173,6 +174,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "NM") { out += "\tNM:i:"; appendUint(out, tagNM); }
             else if (a == "MD") { out += "\tMD:Z:"; out += tagMD; }
             else if (a == "MC") { if (nMates > 1) { out += "\tMC:Z:"; out += matesCIGAR[1 - imate]; } }
+            else if (a == "RG") { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
         }
         out.push_back('\n');
     }
@@ -320,6 +322,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "NM") attrInt(attr, "NM", (int64_t)tagNM);
             else if (a == "MD") attrStr(attr, "MD", tagMD);
             else if (a == "MC") { if (nMates > 1) attrStr(attr, "MC", matesCIGAR[1 - imate]); }
+            else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
         }
         uint32_t core[8];
         core[0] = t.Chr;
@@ -330,7 +333,10 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         if (nMates > 1) {
             core[5] = t.Chr; core[6] = (uint32_t)(ex[imate == 0 ? iExMate + 1 : 0].G - chrS);
             int32_t tlen = (int32_t)(ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);                 // outSAMtlen 1
-            core[7] = (uint32_t)(imate == 0 ? tlen : -tlen);
+            if (P.outSAMtlen == 2) {                                                             // :78-82: leftmost base of any mate to rightmost base of any mate
+                tlen = (int32_t)(std::max(ex[nEx - 1].G + ex[nEx - 1].L, ex[iExMate].G + ex[iExMate].L) - std::min(ex[0].G, ex[iExMate + 1].G));
+                core[7] = (uint32_t)(imate == (ex[0].G <= ex[iExMate + 1].G ? 0u : 1u) ? tlen : -tlen);
+            } else core[7] = (uint32_t)(imate == 0 ? tlen : -tlen);
         } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
         const size_t off0 = out.size();
         bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr);
@@ -357,6 +363,7 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         std::string attr;
         attrInt(attr, "NH", 0); attrInt(attr, "HI", 0); attrInt(attr, "AS", trBest ? trBest->maxScore : 0); attrInt(attr, "nM", trBest ? trBest->nMM : 0);
         attrChar(attr, "uT", (char)('0' + unmapType));
+        if (!P.outSAMattrRG.empty()) attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
         uint32_t core[8];
         core[0] = (uint32_t)-1; core[1] = (uint32_t)-1;
         core[2] = ((uint32_t)reg2bin(-1, 0) << 16) | (uint32_t)(b.name(ir).size() + 1);
@@ -398,6 +405,7 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         out += "\t0\t"; out += b.seq(imate, ir); out.push_back('\t'); out += b.qual(imate, ir);
         out += "\tNH:i:0\tHI:i:0\tAS:i:"; appendInt(out, trBest ? trBest->maxScore : 0);
         out += "\tnM:i:"; appendUint(out, trBest ? trBest->nMM : 0); out += "\tuT:A:"; appendInt(out, unmapType);
+        if (!P.outSAMattrRG.empty()) { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
         out.push_back('\n');
     }
 }
@@ -435,7 +443,7 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 }
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys) const {
+                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
@@ -461,8 +469,15 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             nTr = trMult.size();
             if (!(nTr > P.outFilterMultimapNmax || nTr == 0)) {
                 if (nTr == 1) trMult[0].primary = true;
-                else if (P.outSAMprimaryAllBest) { for (auto &v : trMult) if (v.t->maxScore == maxScore) v.primary = true; }
-                else { for (auto &v : trMult) if (v.t == trBest) v.primary = true; }
+                else {
+                    if (P.outSAMmultNmax >= 0) {             // :61-68 the best alignments move to the top of the list (they are the ones that get written)
+                        uint64_t nbest = 0;
+                        for (uint64_t it = 0; it < nTr; it++) if (trMult[it].t->maxScore == maxScore) { std::swap(trMult[it], trMult[nbest]); ++nbest; }
+                    }
+                    if (P.outSAMprimaryAllBest) { for (auto &v : trMult) if (v.t->maxScore == maxScore) v.primary = true; }
+                    else if (P.outSAMmultNmax >= 0) trMult[0].primary = true;
+                    else { for (auto &v : trMult) if (v.t == trBest) v.primary = true; }
+                }
             }
         }
         // ---- mappedFilter
@@ -496,7 +511,9 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             recordSJ(P, trMult, nTr, sj);
             if (gc && nTr > 0) gc->addAlign(*genes, nTr, *trMult[0].t, trMult[0].ex);        // alignedAnnotation (ReadAlign_outputAlignments.cpp:298-308)
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
-            if (!samOff) for (uint64_t it = 0; it < nTr; it++) { if (bam) bamMapped(sam, P, gi, rc, trMult[it], nTr, it, bamKeys); else samMapped(sam, P, gi, rc, trMult[it], nTr, it); }
+            // writeSAM (:132-256): at most --outSAMmultNmax alignments are written (NH keeps the full count)
+            const uint64_t nTrWrite = P.outSAMmultNmax < 0 ? nTr : std::min<uint64_t>(nTr, (uint64_t)P.outSAMmultNmax);
+            if (!samOff) for (uint64_t it = 0; it < nTrWrite; it++) { if (bam) bamMapped(sam, P, gi, rc, trMult[it], nTr, it, bamKeys); else samMapped(sam, P, gi, rc, trMult[it], nTr, it); }
             const staramd_exon *exB = r.ex + trBest->exonOffset;
             mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
             if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
@@ -506,7 +523,17 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             if (bam) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped, bamKeys);
             else samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
         }
-        if (unmapType >= 0) st.unmappedAll++;
+        if (unmapType >= 0) {
+            st.unmappedAll++;
+            if (unmappedFastx) {                 // outReadsUnmapped (ReadAlign_outputAlignments.cpp:259-275): both mates, also of one-mate alignments
+                for (int im = 0; im < rc.nMates; im++) {
+                    std::string &u = unmappedFastx[im];
+                    u.push_back('@'); u += b.name(ir); u.push_back(' '); u.push_back((char)('0' + im)); u.push_back(':'); u.push_back(b.filter[ir]); u += ": ";
+                    if (rc.nMates > 1) { u.push_back(' '); u.push_back(mateMapped[0] ? '1' : '0'); u.push_back(mateMapped[1] ? '1' : '0'); }
+                    u.push_back('\n'); u += b.seq(im, ir); u += "\n+\n"; u += b.qual(im, ir); u.push_back('\n');
+                }
+            }
+        }
     }
     return "";
 }

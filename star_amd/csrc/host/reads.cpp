@@ -36,23 +36,34 @@ void FastqReader::closeFiles() {
 }
 FastqReader::~FastqReader() { closeFiles(); }
 
-std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand) {
-    closeFiles();
-    nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false;
+std::string FastqReader::openCurrent() {
     for (int i = 0; i < nMates; i++) {
-        if (command_.empty()) f[i] = fopen(paths[i].c_str(), "rb");
+        const std::string &path = files_[i][curFile];
+        if (command_.empty()) f[i] = fopen(path.c_str(), "rb");
         else {
-            if (access(paths[i].c_str(), R_OK) != 0) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + paths[i];
-            std::string q = paths[i], esc;
-            for (char c : q) { if (c == '\'') esc += "'\\''"; else esc.push_back(c); }
+            if (access(path.c_str(), R_OK) != 0) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + path;
+            std::string esc;
+            for (char c : path) { if (c == '\'') esc += "'\\''"; else esc.push_back(c); }
             f[i] = popen((command_ + " '" + esc + "'").c_str(), "r");
         }
-        if (!f[i]) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + paths[i];
+        if (!f[i]) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + path;
         setvbuf(f[i], nullptr, _IONBF, 0);          // blocks are read straight into the batch text
         carry[i].clear(); eof[i] = false;
     }
-    readsSoFar = 0;
     return "";
+}
+
+std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand) {
+    closeFiles();
+    nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false;
+    for (int i = 0; i < nMates; i++) {              // --readFilesIn a1,a2,... b1,b2,...: the files of a mate are read one after the other
+        files_[i].clear();
+        size_t p0 = 0;
+        for (;;) { size_t c = paths[i].find(',', p0); files_[i].push_back(paths[i].substr(p0, c == std::string::npos ? std::string::npos : c - p0)); if (c == std::string::npos) break; p0 = c + 1; }
+    }
+    if (nMates == 2 && files_[0].size() != files_[1].size()) return "EXITING: because of fatal INPUT ERROR: number of input files for mate 1 is not equal to that for mate 2";
+    curFile = 0; readsSoFar = 0;
+    return openCurrent();
 }
 
 void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn) {
@@ -64,13 +75,7 @@ void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn)
 
 std::string FastqReader::reopen() {
     if (fromMemory) { for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; } readsSoFar = 0; return ""; }
-    if (!command_.empty()) return open(paths_, command_);      // a pipe cannot be rewound: run the command again
-    for (int i = 0; i < nMates; i++) {
-        if (fseek(f[i], 0, SEEK_SET) != 0) return "EXITING because of fatal input ERROR: could not rewind the read file";
-        carry[i].clear(); eof[i] = false;
-    }
-    readsSoFar = 0;
-    return "";
+    return open(paths_, command_);      // first file again (a pipe cannot be rewound: the command is run again)
 }
 
 // offsets of the '\n' bytes in [p+from, p+to), appended to `out` until `out` holds `maxOut` entries; returns the offset where
@@ -160,7 +165,13 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     uint64_t nLines[2] = {0, 0};
-    for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
+    for (;;) {
+        for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
+        b.fileIndex = (uint32_t)curFile;
+        // a batch never spans two input files: when this one is exhausted the next batch starts with the next file
+        if (!fromMemory && nLines[0] == 0 && curFile + 1 < files_[0].size()) { closeFiles(); curFile++; std::string e = openCurrent(); if (!e.empty()) { err = e; return false; } continue; }
+        break;
+    }
     lap("fill");
     // records of mate 1 decide the batch; an empty ID line ends the input
     uint64_t n = nLines[0] / 4;
@@ -240,6 +251,12 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
         return false;
     }
     lap("pass1");
+    if (P.outSAMreadIDnumber && !fromMemory)           // --outSAMreadID Number: the read's 1-based index in the input (ReadAlignChunk_processChunks.cpp:117-119)
+        for (uint64_t i = 0; i < n; i++) {
+            std::string nm = std::to_string(readsSoFar + i + 1);
+            b.nameSpan[i] = TextSpan{(uint64_t)b.text[0].size(), (uint32_t)nm.size()};
+            b.text[0].insert(b.text[0].end(), nm.begin(), nm.end());
+        }
     for (uint64_t i = 0; i < n; i++) b.readOffset[i + 1] = b.readOffset[i] + Lread[i];
     b.bases.resize(b.readOffset[n]);
     lap("prefix");

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <deque>
+#include <array>
 #include <chrono>
 
 namespace staramd {
@@ -27,6 +28,7 @@ struct Runner {
     OutSJ sj;
     Stats stats;
     FILE *samOut = nullptr;
+    FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
     std::string error;
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
     std::string insertLog;
@@ -83,6 +85,12 @@ struct Runner {
             pass1 = true; post->samOff = true; readMapNumberUser = P.readMapNumber;
             if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
         }
+        if (P.outReadsUnmappedFastx)
+            for (uint32_t m = 0; m < P.dev.readNmates; m++) {
+                std::string up = P.outFileNamePrefix + "Unmapped.out.mate" + std::to_string(m + 1);
+                unmappedOut[m] = fopen(up.c_str(), "wb");
+                if (!unmappedOut[m]) { error = "EXITING because of fatal ERROR: could not create output file " + up; return false; }
+            }
         if (P.outSAMnone) post->samOff = true;                      // --outSAMtype None
         else if (P.outBAMcoord && !P.outBAMunsorted) {}             // only Aligned.sortedByCoord.out.bam, written at the end of the run
         else {
@@ -148,6 +156,8 @@ struct Runner {
         const bool quant = P.quantGeneCounts && !pass1;             // twoPassRunPass1.cpp:24-29: no quantification in the 1st pass
         std::vector<GeneCounts> gcs(quant ? T : 0, GeneCounts(quant ? genes.geID.size() : 0));
         std::vector<std::vector<BamKey> > keyss(P.outBAMcoord ? T : 0);
+        const bool unm = P.outReadsUnmappedFastx && !pass1;
+        std::vector<std::array<std::string, 2> > unms(unm ? T : 0);
         uint32_t per = (bt.n + T - 1) / T;
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
@@ -156,11 +166,12 @@ struct Runner {
                 std::string &raw = o.raws[t];
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                             P.outBAMcoord ? &keyss[t] : nullptr);
+                                             P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr);
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
-            errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr);
+            errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
+                                         nullptr, unm ? unms[t].data() : nullptr);
         };
         if (T == 1) work(0);
         else {
@@ -175,6 +186,8 @@ struct Runner {
         wcv.notify_all();
         if (!error.empty()) return false;
         for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); if (quant) geneCounts.add(gcs[t]); }
+        if (unm) for (uint32_t t = 0; t < T; t++) for (uint32_t m = 0; m < P.dev.readNmates; m++)
+            if (!unms[t][m].empty() && unmappedOut[m]) fwrite(unms[t][m].data(), 1, unms[t][m].size(), unmappedOut[m]);
         if (P.outBAMcoord && !post->samOff)                         // keep the records for the coordinate sort at the end of the run (in memory)
             for (uint32_t t = 0; t < T; t++) {
                 if (keyss[t].empty()) continue;
@@ -273,6 +286,7 @@ struct Runner {
     }
     bool finish() {
         stopWriter();
+        for (FILE *&u : unmappedOut) if (u) { fclose(u); u = nullptr; }
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (samOut) {
             if (P.outBAMunsorted) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), samOut); }
@@ -285,7 +299,7 @@ struct Runner {
         if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
-    ~Runner() { stopWriter(); if (samOut) fclose(samOut); }
+    ~Runner() { stopWriter(); if (samOut) fclose(samOut); for (FILE *u : unmappedOut) if (u) fclose(u); }
 };
 
 } // namespace staramd
