@@ -8,6 +8,18 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -pthread
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
+# k_stitch_win is 168 VGPRs at 3 waves/SIMD with spills: without loop unrolling it spills 9 registers instead of 26 and is 3 % faster
+# (measured, same box: 163.7 -> 158.4 ms); the other kernels keep the default
+STITCH_FLAGS := -fno-unroll-loops
+
+# $(call build_engine,<variant>,<extra defines>): every .hip file to its own object (in parallel), then one shared library
+define build_engine
+	@mkdir -p star_amd/lib/obj/$(1)
+	@set -e; for f in $(HIP_SRC); do b=$$(basename $$f .hip); extra=""; if [ $$b = k_stitch ]; then extra="$(STITCH_FLAGS)"; fi; \
+	  $(HIPCC) $(HIPFLAGS) $(2) $$extra -c $$f -o star_amd/lib/obj/$(1)/$$b.o & done; wait; \
+	  for f in $(HIP_SRC); do test -s star_amd/lib/obj/$(1)/$$(basename $$f .hip).o; done
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(patsubst star_amd/csrc/engine/%.hip,star_amd/lib/obj/$(1)/%.o,$(HIP_SRC)) -o $@
+endef
 
 HOST_SRC := $(wildcard star_amd/csrc/host/*.cpp)
 HOST_LIB_SRC := $(filter-out star_amd/csrc/host/main.cpp,$(HOST_SRC))
@@ -26,15 +38,13 @@ star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h inclu
 	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@ -lz
 
 star_amd/lib/libstaramd.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p star_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared $(HIP_SRC) -o $@
+	$(call build_engine,prod,)
 
 # shadow-validation build of the engine (tests only): every cooperative stitch / extend call is re-run through the
 # scalar restatement on the GPU and disagreements are counted (tests/test_gpu_parity.py::test_shadow_validation)
 shadow: star_amd/lib/libstaramd_shadow.so
 star_amd/lib/libstaramd_shadow.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p star_amd/lib
-	$(HIPCC) $(HIPFLAGS) -DSTARAMD_SHADOW -shared $(HIP_SRC) -o $@
+	$(call build_engine,shadow,-DSTARAMD_SHADOW)
 
 star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so
 	@mkdir -p star_amd/bin
@@ -53,7 +63,6 @@ clean:
 # profiling build: shader-clock time per section of the stitch walk (bench.py --profile-sections)
 profile-lib: star_amd/lib/libstaramd_profile.so
 star_amd/lib/libstaramd_profile.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p star_amd/lib
-	$(HIPCC) $(HIPFLAGS) -DSTARAMD_PROFILE -shared $(HIP_SRC) -o $@
+	$(call build_engine,profile,-DSTARAMD_PROFILE)
 
 .PHONY: all host engine shadow cli oracle ref clean

@@ -12,6 +12,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 # STARAMD_ENGINE_LIB=shadow selects the shadow-validation build (tests only; see star_amd/csrc/engine/stitch_scalar.h)
 _VARIANT = os.environ.get("STARAMD_ENGINE_LIB", "")
 ENGINE_PATH = os.path.join(LIB_DIR, {"shadow": "libstaramd_shadow.so", "profile": "libstaramd_profile.so"}.get(_VARIANT, "libstaramd.so"))
+if "/" in _VARIANT:                      # an explicit library path (build experiments)
+    ENGINE_PATH = _VARIANT
 HOST_PATH = os.path.join(LIB_DIR, "libstaramd_host.so")
 
 u8p = C.POINTER(C.c_uint8)
