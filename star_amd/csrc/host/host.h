@@ -32,6 +32,14 @@ struct GenomeIndex {
 };
 
 // ---- Parameters: defaults of source/parametersDefault + command-line subset ----
+// ---- chimeric detection parameters (source/parametersDefault:682-729, ParametersChimeric_initialize.cpp) ----
+struct ChimParams {
+    uint64_t segmentMin = 0, junctionOverhangMin = 20, segmentReadGapMax = 0, mainSegmentMultNmax = 10;
+    int scoreMin = 0, scoreDropMax = 20, scoreSeparation = 10, scoreJunctionNonGTAG = -1;
+    bool filterGenomicN = true;
+    int outJunctionFormat = 0;
+};
+
 struct RunParams {
     staramd_params dev;                 // what reaches the device hot path
     // run
@@ -80,6 +88,7 @@ struct RunParams {
     bool sjdbInsertPass1() const { return !sjdbFileChrStartEnd.empty() || !sjdbGTFfile.empty(); }
     bool sjdbInsertYes() const { return twopass || sjdbInsertPass1(); }
     bool outFilterBySJout = false;       // --outFilterType BySJout
+    ChimParams chim;                     // --chim* (chimeric.cpp)
     std::vector<std::string> outSAMattrRG, outSAMattrRGlineSplit;   // --outSAMattrRGline (Parameters_readFilesInit.cpp:64-93)
     bool outReadsUnmappedFastx = false;  // --outReadsUnmapped Fastx
     bool outSAMreadIDnumber = false;     // --outSAMreadID Number
@@ -199,6 +208,11 @@ void bgzfEof(std::string &out);
 // sort key of one BAM record (BAMoutput::coordOneAlign, BAMbinSortByCoordinate.cpp:45-56): (refID << 32 | pos, read order, order of production)
 struct BamKey { uint64_t g, r; uint64_t off; uint32_t len; uint32_t chunk; };
 
+struct ReadBatch;
+// chimeric.cpp: ReadAlign::chimericDetectionOld + the Chimeric.out.junction line; true = a chimeric alignment was recorded
+bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r,
+                          const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out);
+
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
 public:
@@ -210,7 +224,8 @@ public:
     // reads with an unannotated junction are not output but listed in `held` for the 2nd stage
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                              OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr,
-                             std::string *unmappedFastx = nullptr) const;      // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
+                             std::string *unmappedFastx = nullptr,              // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
+                             std::string *chimJunction = nullptr) const;        // Chimeric.out.junction lines (--chimSegmentMin > 0)
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     std::string bamHeader(bool sortedByCoordinate = false) const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)

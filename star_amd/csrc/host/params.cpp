@@ -135,6 +135,21 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMreadID") { const std::string &m = one(k, v); if (m == "Number") outSAMreadIDnumber = true; else if (m != "Standard") err = "EXITING because of fatal input ERROR: unknown value of --outSAMreadID " + m; }
         else if (k == "outSAMtlen") { outSAMtlen = (int)I(k, v); if (outSAMtlen != 1 && outSAMtlen != 2) err = "EXITING because of fatal PARAMETERS error: --outSAMtlen can only be 1 or 2"; }
         else if (k == "outSAMmultNmax") outSAMmultNmax = I(k, v);
+        else if (k == "chimSegmentMin") chim.segmentMin = U(k, v);
+        else if (k == "chimScoreMin") chim.scoreMin = (int)I(k, v);
+        else if (k == "chimScoreDropMax") chim.scoreDropMax = (int)I(k, v);
+        else if (k == "chimScoreSeparation") chim.scoreSeparation = (int)I(k, v);
+        else if (k == "chimScoreJunctionNonGTAG") chim.scoreJunctionNonGTAG = (int)I(k, v);
+        else if (k == "chimJunctionOverhangMin") chim.junctionOverhangMin = U(k, v);
+        else if (k == "chimSegmentReadGapMax") chim.segmentReadGapMax = U(k, v);
+        else if (k == "chimMainSegmentMultNmax") chim.mainSegmentMultNmax = U(k, v);
+        else if (k == "chimOutJunctionFormat") chim.outJunctionFormat = (int)I(k, v);
+        else if (k == "chimMultimapNmax") { if (U(k, v) != 0) err = "EXITING: --chimMultimapNmax > 0 (the multimapping chimeric detection) is not implemented; only the default 0"; }
+        else if (k == "chimOutType") { for (auto &t : v) if (t != "Junctions") err = "EXITING: only --chimOutType Junctions is implemented (Chimeric.out.junction)"; }
+        else if (k == "chimFilter") {
+            chim.filterGenomicN = false;
+            for (auto &t : v) { if (t == "banGenomicN") chim.filterGenomicN = true; else if (t != "None") err = "EXITING because of fatal PARAMETERS error: unrecognized value of --chimFilter=" + t + "\nSOLUTION: use allowed values: banGenomicN || None"; }
+        }
         else if (k == "quantMode") {
             for (auto &t : v) { if (t == "GeneCounts") quantGeneCounts = true; else if (t != "-") err = "EXITING because of fatal INPUT error: unrecognized option in --quantMode=" + t + "\nSOLUTION: use one of the allowed values of --quantMode : GeneCounts or - (TranscriptomeSAM is not implemented by the MI355X engine).\n"; }
         }
@@ -224,6 +239,7 @@ std::string RunParams::parse(int argc, char **argv) {
         if (!outSAMattrRG.empty() && !hasRG) outSAMattrOrder.push_back("RG");
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
+    if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();

@@ -443,7 +443,7 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 }
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx) const {
+                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
@@ -487,6 +487,9 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                  || (trBest->nMatch < P.outFilterMatchNmin) || (trBest->nMatch < (uint64_t)(P.outFilterMatchNminOverLread * (double)(rc.Lread - 1)))) { st.unmappedShort++; unmapType = 1; }
         else if ((trBest->nMM > b.mmMaxTotal[ir]) || (double(trBest->nMM) / double(trBest->rLength) > P.dev.outFilterMismatchNoverLmax)) { st.unmappedMismatch++; unmapType = 2; }
         else if (nTr > P.outFilterMultimapNmax) { st.unmappedMulti++; unmapType = 3; }
+        // ---- chimericDetection (ReadAlign_oneRead.cpp:95-97; not in the 2nd stage of BySJout, ReadAlign_chimericDetection.cpp:23)
+        if (chimJunction && nW > 0 && P.dev.outFilterBySJoutStage <= 1)
+            if (chimericDetectionOld(P, gi, b, ir, r, trBest, nTr, nTr > 0 ? trMult[0].t : nullptr, nTr > 1 ? trMult[1].t : nullptr, *chimJunction)) st.chimericAll++;
         // ---- outFilterBySJout, 1st stage (ReadAlign_outputAlignments.cpp:90-124)
         if (sj1 && unmapType <= 0) {
             bool pass = true;

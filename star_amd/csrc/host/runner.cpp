@@ -28,6 +28,7 @@ struct Runner {
     OutSJ sj;
     Stats stats;
     FILE *samOut = nullptr;
+    FILE *chimOut = nullptr;                        // Chimeric.out.junction
     FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
     std::string error;
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
@@ -83,7 +84,13 @@ struct Runner {
         if (P.outFilterBySJout && !P.twopass) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         if (P.twopass) {                                            // twoPassRunPass1.cpp:14-47: no SAM, own read limit
             pass1 = true; post->samOff = true; readMapNumberUser = P.readMapNumber;
+            P.dev.chimSegmentMinPositive = 0;                       // twoPassRunPass1.cpp:24 (restored with the index re-upload after the pass)
             if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
+        }
+        if (P.chim.segmentMin > 0) {
+            std::string cp = P.outFileNamePrefix + "Chimeric.out.junction";
+            chimOut = fopen(cp.c_str(), "wb");
+            if (!chimOut) { error = "EXITING because of fatal ERROR: could not create output file " + cp; return false; }
         }
         if (P.outReadsUnmappedFastx)
             for (uint32_t m = 0; m < P.dev.readNmates; m++) {
@@ -156,6 +163,8 @@ struct Runner {
         const bool quant = P.quantGeneCounts && !pass1;             // twoPassRunPass1.cpp:24-29: no quantification in the 1st pass
         std::vector<GeneCounts> gcs(quant ? T : 0, GeneCounts(quant ? genes.geID.size() : 0));
         std::vector<std::vector<BamKey> > keyss(P.outBAMcoord ? T : 0);
+        const bool chimOn = P.chim.segmentMin > 0 && !pass1;        // twoPassRunPass1.cpp:24: no chimeric detection in the 1st pass
+        std::vector<std::string> chims(chimOn ? T : 0);
         const bool unm = P.outReadsUnmappedFastx && !pass1;
         std::vector<std::array<std::string, 2> > unms(unm ? T : 0);
         uint32_t per = (bt.n + T - 1) / T;
@@ -166,12 +175,12 @@ struct Runner {
                 std::string &raw = o.raws[t];
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                             P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr);
+                                             P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr);
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                         nullptr, unm ? unms[t].data() : nullptr);
+                                         nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr);
         };
         if (T == 1) work(0);
         else {
@@ -186,6 +195,7 @@ struct Runner {
         wcv.notify_all();
         if (!error.empty()) return false;
         for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); if (quant) geneCounts.add(gcs[t]); }
+        if (chimOn && chimOut) for (uint32_t t = 0; t < T; t++) if (!chims[t].empty()) fwrite(chims[t].data(), 1, chims[t].size(), chimOut);
         if (unm) for (uint32_t t = 0; t < T; t++) for (uint32_t m = 0; m < P.dev.readNmates; m++)
             if (!unms[t][m].empty() && unmappedOut[m]) fwrite(unms[t][m].data(), 1, unms[t][m].size(), unmappedOut[m]);
         if (P.outBAMcoord && !post->samOff)                         // keep the records for the coordinate sort at the end of the run (in memory)
@@ -263,6 +273,7 @@ struct Runner {
         stats = Stats(); stats.timeStart = t0; time(&stats.timeStartMap);
         sj.data.clear();
         P.readMapNumber = readMapNumberUser; post->samOff = P.outSAMnone; pass1 = false;
+        P.dev.chimSegmentMinPositive = P.chim.segmentMin > 0 ? 1 : 0;
         if (P.outFilterBySJout) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         return true;
     }
@@ -287,6 +298,12 @@ struct Runner {
     bool finish() {
         stopWriter();
         for (FILE *&u : unmappedOut) if (u) { fclose(u); u = nullptr; }
+        if (chimOut) {
+            if (P.chim.outJunctionFormat == 1)              // Stats::writeLines (Stats.cpp:147-155, STAR.cpp:285)
+                fprintf(chimOut, "# 2.7.11b   %s\n# Nreads %llu\tNreadsUnique %llu\tNreadsMulti %llu\n", P.commandLine.c_str(), (unsigned long long)stats.readN,
+                        (unsigned long long)stats.mappedReadsU, (unsigned long long)stats.mappedReadsM);
+            fclose(chimOut); chimOut = nullptr;
+        }
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (samOut) {
             if (P.outBAMunsorted) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), samOut); }
@@ -299,7 +316,7 @@ struct Runner {
         if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
-    ~Runner() { stopWriter(); if (samOut) fclose(samOut); for (FILE *u : unmappedOut) if (u) fclose(u); }
+    ~Runner() { stopWriter(); if (samOut) fclose(samOut); for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); }
 };
 
 } // namespace staramd

@@ -47,8 +47,8 @@ def _compare_buffers(info, more, prefix):
             if b is None:
                 break
             n = b.nReads
-            bg = capi.ResultBuffers(n, tr_cap=n * 200)     # All mode + EndToEnd records ~80 transcripts per read
-            bo = capi.ResultBuffers(n, tr_cap=n * 200)
+            bg = capi.ResultBuffers(n, tr_cap=n * 400)     # All mode + EndToEnd / chimeric mode record ~80+ transcripts per read
+            bo = capi.ResultBuffers(n, tr_cap=n * 400)
             eng.map_batch(b, bg)
             orc.map_batch(b, bo)
             rg, tg, eg = bg.as_bytes(n)

@@ -95,8 +95,14 @@ def run_with_engine(info, prefix, engine_factory, batch_reads=777):
                 b = run.next_batch(batch_reads)
                 if b is None:
                     break
-                bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
-                eng.map_batch(b, bufs)
+                for per_read in (64, 256, 1024):          # the caller owns the result arrays: grow and call again when they are too small
+                    bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * per_read)
+                    try:
+                        eng.map_batch(b, bufs)
+                        break
+                    except RuntimeError as e:
+                        if per_read == 1024 or not ("-3" in str(e) or "too small" in str(e)):
+                            raise
                 run.emit(bufs.res)
             phase = run.next_phase()
             if phase == 0:
