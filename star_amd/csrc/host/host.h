@@ -72,6 +72,7 @@ struct RunParams {
     bool outBAMunsorted = false, outBAMcoord = false; bool outSAMnone = false; int outBAMcompression = 1;   // --outSAMtype BAM Unsorted | None, --outBAMcompression
     std::vector<std::string> outSAMattrOrder = {"NH", "HI", "AS", "nM"};   // Standard
     bool attrNMorMD = false, attrHasCh = false;
+    std::vector<std::string> outSAMattrOrderQuant;   // attributes of Aligned.toTranscriptome.out.bam: NH HI, then RG / MC if requested (Parameters_samAttributes.cpp:43-47,96-111)
     std::string readNameSeparator = "/";
     uint64_t gpuBatchReads = 65536;      // reads per device batch (ours; --gpuBatchReads)
     int gpuDevice = 0;
@@ -95,6 +96,9 @@ struct RunParams {
     int outSAMtlen = 1;                  // --outSAMtlen 1 | 2
     int64_t outSAMmultNmax = -1;         // --outSAMmultNmax
     bool quantGeneCounts = false;        // --quantMode GeneCounts
+    bool quantTrSAM = false, quantTrIndel = false, quantTrSoftClip = false, quantTrSingleEnd = false;   // --quantMode TranscriptomeSAM, --quantTranscriptomeSAMoutput
+    int quantTrBAMcompression = 1;       // --quantTranscriptomeBAMcompression
+    int runRNGseed = 777;                // --runRNGseed
 
     RunParams();
     // STAR-style "--name v1 v2 ..." ; returns error text or ""
@@ -201,6 +205,20 @@ struct GeneCounts {
     std::string write(const std::string &path, const GeneAnnotation &A, const Stats &st) const;                  // Transcriptome.cpp:158-190
 };
 
+// ---- --quantMode TranscriptomeSAM (quant.cpp) ----
+struct GenomicAlign { uint32_t nExons; uint32_t Str; uint64_t Lread; staramd_exon ex[STARAMD_MAX_N_EXONS]; };   // one alignment in genome coordinates (a working copy)
+struct ProjectedAlign { uint32_t tr; uint32_t Str; uint32_t nExons; staramd_exon ex[STARAMD_MAX_N_EXONS]; };      // the same alignment on transcript `tr`
+struct TranscriptAnnotation {             // transcriptInfo.tab + exonInfo.tab
+    std::vector<std::string> trID;
+    std::vector<uint64_t> trS, trE, trEmax; std::vector<uint8_t> trStr; std::vector<uint16_t> trExN; std::vector<uint32_t> trExI, trLen;
+    std::vector<uint32_t> exSE, exLenCum;
+    std::string load(const std::string &dir);
+    uint32_t quantAlign(const GenomicAlign &aG, std::vector<ProjectedAlign> &out) const;
+};
+// primary flag of the transcriptomic alignments of one read: chosen with one random number per mapped read, in read order
+// (ReadAlign_quantTranscriptome.cpp:69), so it is patched into the records after the threads of a batch have joined
+struct QuantPatch { uint32_t nAlignT; std::vector<uint64_t> recOffset; std::vector<uint32_t> recAlign; };
+
 // ---- BGZF framing of BAM output (bgzf.cpp) ----
 bool bgzfCompress(const std::string &raw, int level, std::string &out);
 void bgzfEof(std::string &out);
@@ -225,8 +243,11 @@ public:
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                              OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr,
                              std::string *unmappedFastx = nullptr,              // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
-                             std::string *chimJunction = nullptr) const;        // Chimeric.out.junction lines (--chimSegmentMin > 0)
+                             std::string *chimJunction = nullptr,               // Chimeric.out.junction lines (--chimSegmentMin > 0)
+                             std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr) const;   // TranscriptomeSAM records
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
+    const TranscriptAnnotation *transcripts = nullptr;   // --quantMode TranscriptomeSAM
+    std::string quantBamHeader() const;              // samHeaders.cpp:8-20
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     std::string bamHeader(bool sortedByCoordinate = false) const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)

@@ -151,8 +151,17 @@ std::string RunParams::parse(int argc, char **argv) {
             for (auto &t : v) { if (t == "banGenomicN") chim.filterGenomicN = true; else if (t != "None") err = "EXITING because of fatal PARAMETERS error: unrecognized value of --chimFilter=" + t + "\nSOLUTION: use allowed values: banGenomicN || None"; }
         }
         else if (k == "quantMode") {
-            for (auto &t : v) { if (t == "GeneCounts") quantGeneCounts = true; else if (t != "-") err = "EXITING because of fatal INPUT error: unrecognized option in --quantMode=" + t + "\nSOLUTION: use one of the allowed values of --quantMode : GeneCounts or - (TranscriptomeSAM is not implemented by the MI355X engine).\n"; }
+            for (auto &t : v) { if (t == "GeneCounts") quantGeneCounts = true; else if (t == "TranscriptomeSAM") quantTrSAM = true; else if (t != "-") err = "EXITING because of fatal INPUT error: unrecognized option in --quantMode=" + t + "\nSOLUTION: use one of the allowed values of --quantMode : TranscriptomeSAM or GeneCounts or - .\n"; }
         }
+        else if (k == "quantTranscriptomeBAMcompression") quantTrBAMcompression = (int)I(k, v);
+        else if (k == "quantTranscriptomeSAMoutput") {     // Parameters.cpp:912-924
+            const std::string &m = one(k, v);
+            if (m == "BanSingleEnd_BanIndels_ExtendSoftclip") { quantTrIndel = false; quantTrSoftClip = false; }
+            else if (m == "BanSingleEnd") { quantTrIndel = true; quantTrSoftClip = true; }
+            else if (m == "BanSingleEnd_ExtendSoftclip") { quantTrIndel = true; quantTrSoftClip = false; }
+            else err = "EXITING because of fatal INPUT error: unrecognized option in --quantTranscriptomeSAMoutput=" + m;
+        }
+        else if (k == "runRNGseed") runRNGseed = (int)I(k, v);
         else if (k == "outFilterType") { const std::string &m = one(k, v); if (m == "BySJout") outFilterBySJout = true; else if (m != "Normal") err = "EXITING because of FATAL input ERROR: unknown value of parameter outFilterType: " + m + "\nSOLUTION: specify one of the allowed values: Normal | BySJout\n"; }
         else if (k == "outFilterMultimapScoreRange") dev.outFilterMultimapScoreRange = (int32_t)I(k, v);
         else if (k == "outFilterMultimapNmax") outFilterMultimapNmax = (uint32_t)U(k, v);
@@ -242,6 +251,8 @@ std::string RunParams::parse(int argc, char **argv) {
     if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
+    outSAMattrOrderQuant = {"NH", "HI"};
+    for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC") outSAMattrOrderQuant.push_back(a);
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";

@@ -233,7 +233,9 @@ void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, 
 } // namespace
 
 // mapped mates of one alignment (alignType -1)
-static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, std::vector<BamKey> *keys) {
+// quant = a projection onto a transcript (ReadAlign_quantTranscriptome.cpp:71-76): coordinates start at 0, attributes NH HI (+ RG, MC)
+static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, std::vector<BamKey> *keys,
+                      bool quant = false, std::vector<uint64_t> *recOffsets = nullptr) {
     const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     const bool flagPaired = rc.nMates == 2;
@@ -241,7 +243,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     uint32_t iExMate, nMates = 1;
     for (iExMate = 0; iExMate + 1 < nEx; iExMate++) if (ex[iExMate].canonSJ == -3) { nMates = 2; break; }
     const uint32_t Str = t.Str, leftMate = flagPaired ? Str : 0;
-    const uint64_t chrS = gi.chrStart[t.Chr], Lread = rc.Lread;
+    const uint64_t chrS = quant ? 0 : gi.chrStart[t.Chr], Lread = rc.Lread;
     // CIGAR strings of both mates for MC (calcCIGAR)
     std::string matesCIGAR[2];
     std::vector<uint32_t> packed[2]; std::vector<int32_t> SJintron[2]; std::vector<char> SJmotif[2];
@@ -285,7 +287,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
         // NM / MD of the BAM path (samAttrNM_MD :8-47): insertions of every gap and deletions of every non-junction gap count
         uint64_t tagNM = 0; std::string tagMD;
-        if (P.attrNMorMD) {
+        if (P.attrNMorMD && !quant) {
             const uint8_t *rd = b.bases.data() + b.readOffset[ir];
             uint64_t matchN = 0, nMM = 0, nI = 0, nD = 0;
             for (uint32_t iex = iEx1; iex <= iEx2; iex++) {
@@ -311,7 +313,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             tagNM = nMM + nI + nD;
         }
         std::string attr;
-        for (const std::string &a : P.outSAMattrOrder) {
+        for (const std::string &a : (quant ? P.outSAMattrOrderQuant : P.outSAMattrOrder)) {
             if (a == "NH") attrInt(attr, "NH", (int64_t)nTrOut);
             else if (a == "HI") attrInt(attr, "HI", (int64_t)iTrOut + P.outSAMattrIHstart);
             else if (a == "AS") attrInt(attr, "AS", t.maxScore);
@@ -339,6 +341,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             } else core[7] = (uint32_t)(imate == 0 ? tlen : -tlen);
         } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
         const size_t off0 = out.size();
+        if (recOffsets) recOffsets->push_back(off0);
         bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr);
         // BAMoutput::coordOneAlign key (ReadAlign_outputAlignments.cpp:196-199): iReadAll << 32 | iTr << 8 | mate of the first exon
         if (keys) keys->push_back(BamKey{((uint64_t)core[0] << 32) | core[1], (b.readIndex(ir) << 32) | (iTrOut << 8) | ex[0].iFrag, off0, (uint32_t)(out.size() - off0), 0});
@@ -375,6 +378,16 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         bamFinish(out, core, b.name(ir), std::vector<uint32_t>(), b.seq(imate, ir), b.qual(imate, ir), false, P.outSAMmodeNoQS, attr);
         if (keys) keys->push_back(BamKey{~0ull, b.readIndex(ir) << 32, off0, (uint32_t)(out.size() - off0), 0});      // unmapped: last, in read order
     }
+}
+
+std::string PostMap::quantBamHeader() const {
+    std::string samh, h = "BAM\1";
+    for (size_t i = 0; i < transcripts->trID.size(); i++) { samh += "@SQ\tSN:" + transcripts->trID[i] + "\tLN:"; appendUint(samh, transcripts->trLen[i]); samh += "\n"; }
+    for (const std::string &rg : P.outSAMattrRGlineSplit) samh += "@RG\t" + rg + "\n";
+    put32(h, (uint32_t)samh.size()); h += samh;
+    put32(h, (uint32_t)transcripts->trID.size());
+    for (size_t i = 0; i < transcripts->trID.size(); i++) { put32(h, (uint32_t)transcripts->trID[i].size() + 1); h += transcripts->trID[i]; h.push_back(0); put32(h, transcripts->trLen[i]); }
+    return h;
 }
 
 std::string PostMap::bamHeader(bool sortedByCoordinate) const {
@@ -416,6 +429,52 @@ std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::
 
 // reads [lo, hi) of the batch: the reference's per-thread ReadAlign loop body (ReadAlign_oneRead.cpp:87-111); ranges of one
 // batch are independent (per-thread SAM buffer, junction table and Stats, merged by the caller in read order)
+// ReadAlign::quantTranscriptome (ReadAlign_quantTranscriptome.cpp:7-91): every alignment of the read projected onto the transcripts that
+// contain it; BAM records with the primary flag left off (it is chosen afterwards, see QuantPatch)
+static void quantTranscriptome(const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TranscriptAnnotation &A, const std::vector<TrView> &trMult, uint64_t nTr,
+                               uint64_t mmMaxTotal, std::string &out, std::vector<QuantPatch> &patches) {
+    const ReadBatch &b = *rc.b; const uint32_t ir = rc.i;
+    const uint64_t Lread = rc.Lread;
+    std::vector<ProjectedAlign> alignT;
+    std::vector<const staramd_transcript *> src;
+    for (uint64_t iag = 0; iag < nTr; iag++) {
+        const staramd_transcript &t = *trMult[iag].t; const staramd_exon *ex = trMult[iag].ex;
+        if (!P.quantTrIndel && (t.nDel > 0 || t.nIns > 0)) continue;
+        if (!P.quantTrSingleEnd && rc.nMates == 2 && ex[0].iFrag == ex[t.nExons - 1].iFrag) continue;
+        GenomicAlign g; g.nExons = t.nExons; g.Str = t.Str; g.Lread = Lread;
+        memcpy(g.ex, ex, sizeof(staramd_exon) * t.nExons);
+        if (!P.quantTrSoftClip) {                                          // soft clips are extended instead (:23-61)
+            uint64_t nMM1 = 0;
+            const uint8_t *rd = b.bases.data() + b.readOffset[ir];
+            auto R = [&](uint64_t p) -> uint8_t { uint8_t c = t.roStr == 0 ? rd[p] : rd[Lread - 1 - p]; return (t.roStr != 0 && c < 4) ? (uint8_t)(3 - c) : c; };
+            for (uint32_t iab = 0; iab < g.nExons; iab++) {
+                uint64_t left1 = 0, right1 = 0;
+                if (iab == 0) left1 = g.ex[iab].R;
+                else if (g.ex[iab - 1].canonSJ == -3) left1 = g.ex[iab].R - rc.readLength[g.ex[iab - 1].iFrag] - 1;
+                if (iab == g.nExons - 1) right1 = Lread - g.ex[iab].R - g.ex[iab].L;
+                else if (g.ex[iab].canonSJ == -3) right1 = rc.readLength[g.ex[iab].iFrag] - g.ex[iab].R - g.ex[iab].L;
+                for (uint64_t k = 1; k <= left1; k++) { uint8_t r1 = R(g.ex[iab].R - k), g1 = gi.G[g.ex[iab].G - k]; if (r1 != g1 && r1 < 4 && g1 < 4) ++nMM1; }
+                for (uint64_t k = 0; k < right1; k++) { uint8_t r1 = R((uint64_t)g.ex[iab].R + g.ex[iab].L + k), g1 = gi.G[g.ex[iab].G + g.ex[iab].L + k]; if (r1 != g1 && r1 < 4 && g1 < 4) ++nMM1; }
+                g.ex[iab].R = (uint16_t)(g.ex[iab].R - left1); g.ex[iab].G -= left1; g.ex[iab].L = (uint16_t)(g.ex[iab].L + left1 + right1);
+            }
+            if (t.nMM + nMM1 > std::min<uint64_t>(mmMaxTotal, (uint64_t)(P.dev.outFilterMismatchNoverLmax * (double)(Lread - 1)))) continue;
+        }
+        size_t n0 = alignT.size();
+        A.quantAlign(g, alignT);
+        for (size_t k = n0; k < alignT.size(); k++) src.push_back(&t);
+    }
+    QuantPatch qp; qp.nAlignT = (uint32_t)alignT.size();
+    for (size_t iatr = 0; iatr < alignT.size(); iatr++) {
+        staramd_transcript tq = *src[iatr];
+        tq.Chr = alignT[iatr].tr; tq.Str = (uint8_t)alignT[iatr].Str; tq.nExons = (uint16_t)alignT[iatr].nExons;
+        TrView v; v.t = &tq; v.ex = alignT[iatr].ex; v.primary = false;
+        size_t nBefore = qp.recOffset.size();
+        bamMapped(out, P, gi, rc, v, alignT.size(), iatr, nullptr, true, &qp.recOffset);
+        for (size_t k = nBefore; k < qp.recOffset.size(); k++) qp.recAlign.push_back((uint32_t)iatr);
+    }
+    patches.push_back(std::move(qp));
+}
+
 // recordSJ (ReadAlign_outputAlignments.cpp:76-87) -> outputTranscriptSJ (ReadAlign_outputTranscriptSJ.cpp:14-55)
 static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint64_t nTr, OutSJ &sj) {
     if (P.outSJfilterReadsUnique && nTr != 1) return;
@@ -443,7 +502,8 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 }
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction) const {
+                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
+                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
@@ -513,6 +573,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             }
             recordSJ(P, trMult, nTr, sj);
             if (gc && nTr > 0) gc->addAlign(*genes, nTr, *trMult[0].t, trMult[0].ex);        // alignedAnnotation (ReadAlign_outputAlignments.cpp:298-308)
+            if (quantBam) quantTranscriptome(P, gi, rc, *transcripts, trMult, nTr, b.mmMaxTotal[ir], *quantBam, *quantPatches);
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
             // writeSAM (:132-256): at most --outSAMmultNmax alignments are written (NH keeps the full count)
             const uint64_t nTrWrite = P.outSAMmultNmax < 0 ? nTr : std::min<uint64_t>(nTr, (uint64_t)P.outSAMmultNmax);

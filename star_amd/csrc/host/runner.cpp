@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <deque>
 #include <array>
+#include <random>
 #include <chrono>
 
 namespace staramd {
@@ -41,6 +42,8 @@ struct Runner {
     std::string heldText[2];            // held reads as FASTQ text
     std::vector<uint64_t> novelStart, novelEnd;
     GeneAnnotation genes; GeneCounts geneCounts;      // --quantMode GeneCounts
+    TranscriptAnnotation transcripts; FILE *quantOut = nullptr;     // --quantMode TranscriptomeSAM -> Aligned.toTranscriptome.out.bam
+    std::mt19937 rngMultOrder; std::uniform_real_distribution<double> rngUniformReal0to1{0.0, 1.0};   // ReadAlign.cpp:11-12 (one stream: iChunk 0)
     std::vector<std::string> coordChunks; std::vector<BamKey> coordKeys;     // --outSAMtype BAM SortedByCoordinate: every record, until finish()
     int wireTable = 0;                                // which junction table sah_sj_export / import / clear address: 0 = sj, 1 = sj1
     OutSJ &wire() { return wireTable == 1 ? sj1 : sj; }
@@ -75,6 +78,20 @@ struct Runner {
         error = reader.open(P.readFilesIn, P.readFilesCommand);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
+        if (P.quantTrSAM) {
+            error = transcripts.load(P.sjdbGTFfile.empty() ? P.genomeDir : P.sjdbInsertOutDir);
+            if (!error.empty()) return false;
+            post->transcripts = &transcripts;
+            rngMultOrder.seed((unsigned)P.runRNGseed);
+            if (P.quantTrBAMcompression > -2) {
+                std::string qp = P.outFileNamePrefix + "Aligned.toTranscriptome.out.bam";
+                quantOut = fopen(qp.c_str(), "wb");
+                if (!quantOut) { error = "EXITING because of fatal ERROR: could not create output file " + qp; return false; }
+                std::string h;
+                if (!bgzfCompress(post->quantBamHeader(), P.quantTrBAMcompression, h)) { error = "EXITING because of fatal ERROR: BGZF compression failed"; return false; }
+                fwrite(h.data(), 1, h.size(), quantOut);
+            }
+        }
         if (P.quantGeneCounts) {                                    // Transcriptome.cpp:12-16: a GTF given at the mapping stage wins
             error = genes.load(P.sjdbGTFfile.empty() ? P.genomeDir : P.sjdbInsertOutDir);
             if (!error.empty()) return false;
@@ -163,6 +180,8 @@ struct Runner {
         const bool quant = P.quantGeneCounts && !pass1;             // twoPassRunPass1.cpp:24-29: no quantification in the 1st pass
         std::vector<GeneCounts> gcs(quant ? T : 0, GeneCounts(quant ? genes.geID.size() : 0));
         std::vector<std::vector<BamKey> > keyss(P.outBAMcoord ? T : 0);
+        const bool trSAM = P.quantTrSAM && quantOut && !pass1;       // twoPassRunPass1.cpp:24-29
+        std::vector<std::string> qraws(trSAM ? T : 0); std::vector<std::vector<QuantPatch> > qpatches(trSAM ? T : 0);
         const bool chimOn = P.chim.segmentMin > 0 && !pass1;        // twoPassRunPass1.cpp:24: no chimeric detection in the 1st pass
         std::vector<std::string> chims(chimOn ? T : 0);
         const bool unm = P.outReadsUnmappedFastx && !pass1;
@@ -175,12 +194,14 @@ struct Runner {
                 std::string &raw = o.raws[t];
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                             P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr);
+                                             P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr);
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                         nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr);
+                                         nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr);
         };
         if (T == 1) work(0);
         else {
@@ -195,6 +216,21 @@ struct Runner {
         wcv.notify_all();
         if (!error.empty()) return false;
         for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); if (quant) geneCounts.add(gcs[t]); }
+        if (trSAM) {
+            // one random number per mapped read, in read order, picks the primary transcriptomic alignment (ReadAlign_quantTranscriptome.cpp:69);
+            // the flag is patched into the records (FLAG is the high half of the 5th word), then the text is compressed and written
+            for (uint32_t t = 0; t < T; t++) {
+                for (const QuantPatch &qp : qpatches[t]) {
+                    uint32_t pick = (uint32_t)(int)(rngUniformReal0to1(rngMultOrder) * qp.nAlignT);
+                    for (size_t k = 0; k < qp.recOffset.size(); k++) {
+                        uint8_t &hi = (uint8_t &)qraws[t][qp.recOffset[k] + 19];
+                        if (qp.recAlign[k] == pick) hi &= (uint8_t)~1u; else hi |= 1u;
+                    }
+                }
+                std::string z;
+                if (!bgzfCompress(qraws[t], P.quantTrBAMcompression, z) || fwrite(z.data(), 1, z.size(), quantOut) != z.size()) { error = "EXITING because of fatal ERROR: could not write Aligned.toTranscriptome.out.bam"; return false; }
+            }
+        }
         if (chimOn && chimOut) for (uint32_t t = 0; t < T; t++) if (!chims[t].empty()) fwrite(chims[t].data(), 1, chims[t].size(), chimOut);
         if (unm) for (uint32_t t = 0; t < T; t++) for (uint32_t m = 0; m < P.dev.readNmates; m++)
             if (!unms[t][m].empty() && unmappedOut[m]) fwrite(unms[t][m].data(), 1, unms[t][m].size(), unmappedOut[m]);
@@ -298,6 +334,7 @@ struct Runner {
     bool finish() {
         stopWriter();
         for (FILE *&u : unmappedOut) if (u) { fclose(u); u = nullptr; }
+        if (quantOut) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), quantOut); fclose(quantOut); quantOut = nullptr; }
         if (chimOut) {
             if (P.chim.outJunctionFormat == 1)              // Stats::writeLines (Stats.cpp:147-155, STAR.cpp:285)
                 fprintf(chimOut, "# 2.7.11b   %s\n# Nreads %llu\tNreadsUnique %llu\tNreadsMulti %llu\n", P.commandLine.c_str(), (unsigned long long)stats.readN,
@@ -316,7 +353,7 @@ struct Runner {
         if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
-    ~Runner() { stopWriter(); if (samOut) fclose(samOut); for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); }
+    ~Runner() { stopWriter(); if (samOut) fclose(samOut); for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); if (quantOut) fclose(quantOut); }
 };
 
 } // namespace staramd
