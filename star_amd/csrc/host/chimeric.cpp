@@ -203,14 +203,16 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
         || (trChim[0].t.Str == 0 ? chimJ1 - chimJ0 + 1ull : chimJ0 - chimJ1 + 1ull) > (chimMotif >= 0 ? P.dev.alignIntronMax : P.dev.alignMatesGapMax)) {
         if (chimMotif >= 0 && (x0.L < C.junctionOverhangMin + chimRepeat0 || x1.L < C.junctionOverhangMin + chimRepeat1)) return false;
         // Chimeric.out.junction (chimericDetectionOldOutput :61-71)
-        const uint64_t readLengthPair = nMates == 2 ? readLength[0] + readLength[1] + 1 : readLength[0];
+        // the CIGARp is written against the lengths before clipping (ReadAlign_outputTranscriptCIGARp.cpp:13,25,55)
+        const uint64_t readLengthOriginal[2] = {b.seqSpan[0][ir].len, nMates == 2 ? (uint64_t)b.seqSpan[1][ir].len : 0};
+        const uint64_t readLengthPair = nMates == 2 ? readLengthOriginal[0] + readLengthOriginal[1] + 1 : readLengthOriginal[0];
         const uint64_t c0 = gi.chrStart[trChim[0].t.Chr], c1 = gi.chrStart[trChim[1].t.Chr];
         out += gi.chrName[trChim[0].t.Chr]; out.push_back('\t'); appendU(out, chimJ0 - c0 + 1); out.push_back('\t'); out.push_back(trChim[0].t.Str == 0 ? '+' : '-'); out.push_back('\t');
         out += gi.chrName[trChim[1].t.Chr]; out.push_back('\t'); appendU(out, chimJ1 - c1 + 1); out.push_back('\t'); out.push_back(trChim[1].t.Str == 0 ? '+' : '-'); out.push_back('\t');
         if (chimMotif < 0) { out.push_back('-'); appendU(out, (uint64_t)(-chimMotif)); } else appendU(out, (uint64_t)chimMotif);
         out.push_back('\t'); appendU(out, chimRepeat0); out.push_back('\t'); appendU(out, chimRepeat1); out.push_back('\t'); out += b.name(ir);
-        out.push_back('\t'); appendU(out, trChim[0].ex[0].G - c0 + 1); out.push_back('\t'); out += cigarP(trChim[0], readLength, readLengthPair, nMates);
-        out.push_back('\t'); appendU(out, trChim[1].ex[0].G - c1 + 1); out.push_back('\t'); out += cigarP(trChim[1], readLength, readLengthPair, nMates);
+        out.push_back('\t'); appendU(out, trChim[0].ex[0].G - c0 + 1); out.push_back('\t'); out += cigarP(trChim[0], readLengthOriginal, readLengthPair, nMates);
+        out.push_back('\t'); appendU(out, trChim[1].ex[0].G - c1 + 1); out.push_back('\t'); out += cigarP(trChim[1], readLengthOriginal, readLengthPair, nMates);
         if (!P.outSAMattrRG.empty()) { out.push_back('\t'); out += P.outSAMattrRG.at(b.fileIndex); }
         out.push_back('\n');
         return true;

@@ -99,6 +99,9 @@ struct RunParams {
     bool quantTrSAM = false, quantTrIndel = false, quantTrSoftClip = false, quantTrSingleEnd = false;   // --quantMode TranscriptomeSAM, --quantTranscriptomeSAMoutput
     int quantTrBAMcompression = 1;       // --quantTranscriptomeBAMcompression
     int runRNGseed = 777;                // --runRNGseed
+    // read clipping, Hamming adapter type (ParametersClip_initialize.cpp, ClipMate_clip.cpp): per mate
+    struct ClipEnd { bool active = false; uint32_t N = 0, NafterAd = 0; std::string adSeq; double adMMp = 0; } clip[2][2];   // [mate][0 = 5', 1 = 3']
+    bool clipYes = false;
 
     RunParams();
     // STAR-style "--name v1 v2 ..." ; returns error text or ""
@@ -118,6 +121,8 @@ struct ReadBatch {
     std::vector<TextSpan> nameSpan;       // read ID without '@', trimmed at readNameSeparator (from mate 1's ID line)
     std::vector<TextSpan> seqSpan[2], qualSpan[2];
     std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
+    std::vector<uint16_t> clipN[2][2];    // [mate][0 = 5', 1 = 3']: bases clipped off before mapping (--clip*); empty when nothing is clipped
+    uint32_t clipped(int m, int p, uint32_t i) const { return clipN[m][p].empty() ? 0u : clipN[m][p][i]; }
     uint64_t firstReadIndex = 0;
     std::vector<uint64_t> origIndex;      // 2nd stage of BySJout: index of the read in the original input (empty otherwise)
     uint32_t fileIndex = 0;               // which of the comma-separated input files the batch came from (a batch never spans two)

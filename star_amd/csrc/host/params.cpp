@@ -63,6 +63,7 @@ std::string RunParams::parse(int argc, char **argv) {
         for (int j = 0; j < 4; j++) out[j] = (int32_t)strtol(v[j].c_str(), nullptr, 10);
     };
     std::string alignEndsType = "Local";
+    std::map<std::string, std::vector<std::string> > clipArgs;
     for (auto &e : kv) {
         const std::string &k = e.first; const std::vector<std::string> &v = e.second;
         if (k == "runMode") { if (one(k, v) != "alignReads") err = "EXITING: only --runMode alignReads is implemented by the MI355X engine (index generation: use reference STAR)"; }
@@ -162,6 +163,8 @@ std::string RunParams::parse(int argc, char **argv) {
             else err = "EXITING because of fatal INPUT error: unrecognized option in --quantTranscriptomeSAMoutput=" + m;
         }
         else if (k == "runRNGseed") runRNGseed = (int)I(k, v);
+        else if (k.compare(0, 5, "clip5") == 0 || k.compare(0, 5, "clip3") == 0) clipArgs[k] = v;
+        else if (k == "clipAdapterType") { if (one(k, v) != "Hamming") err = "EXITING because of fatal PARAMETER error: --clipAdapterType = " + one(k, v) + " is not implemented here (Hamming only)\n"; }
         else if (k == "outFilterType") { const std::string &m = one(k, v); if (m == "BySJout") outFilterBySJout = true; else if (m != "Normal") err = "EXITING because of FATAL input ERROR: unknown value of parameter outFilterType: " + m + "\nSOLUTION: specify one of the allowed values: Normal | BySJout\n"; }
         else if (k == "outFilterMultimapScoreRange") dev.outFilterMultimapScoreRange = (int32_t)I(k, v);
         else if (k == "outFilterMultimapNmax") outFilterMultimapNmax = (uint32_t)U(k, v);
@@ -257,6 +260,31 @@ std::string RunParams::parse(int argc, char **argv) {
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";
     dev.readNmates = (uint32_t)readFilesIn.size();
+    {   // ParametersClip::initialize (ParametersClip_initialize.cpp:33-82): a lone 0 / "-" is repeated for all mates, anything else needs one value per mate
+        const std::string nm = std::to_string(dev.readNmates);
+        const char *p53[2] = {"5", "3"};
+        for (int ip = 0; ip < 2; ip++) {
+            auto get = [&](const char *name, const char *def) { auto it = clipArgs.find(std::string("clip") + p53[ip] + "p" + name); return it == clipArgs.end() ? std::vector<std::string>{def} : it->second; };
+            std::vector<std::string> adSeq = get("AdapterSeq", "-"), adMMp = get("AdapterMMp", "0.1"), N = get("Nbases", "0"), NafterAd = get("AfterAdapterNbases", "0");
+            if (ip == 0) for (auto &x : adSeq) if (x != "-")
+                return std::string("EXITING because of fatal PARAMETER error: --clip5pAdapterSeq is not supported yet, except for --clipAdapterType CellRanger4.                            \nSOLUTION: Do not use --clip5pAdapter* options without --clipAdapterType CellRanger4.\n");
+            if (adSeq[0] == "-") { adSeq.resize(dev.readNmates, "-"); adMMp.resize(dev.readNmates, "0"); }
+            if (strtoul(N[0].c_str(), nullptr, 10) == 0) N.resize(dev.readNmates, "0");
+            if (strtoul(NafterAd[0].c_str(), nullptr, 10) == 0) NafterAd.resize(dev.readNmates, "0");
+            auto bad = [&](const char *name, const char *tail) { return std::string("EXITING because of fatal PARAMETER error: --clip") + p53[ip] + "p" + name + " has to contain " + nm + " values to match the number of mates.\nSOLUTION: specify " + nm + "values in --clip" + p53[ip] + "p" + name + tail; };
+            if (adSeq.size() != dev.readNmates) return bad("AdapterSeq", " , for no clipping use -");
+            if (adMMp.size() != dev.readNmates) return bad("AdapterMMp", "");
+            if (NafterAd.size() != dev.readNmates) return bad("AfterAdapterNbases", " , for no clipping use 0");
+            if (N.size() != dev.readNmates) return bad("Nbases", " , for no clipping use 0");
+            for (uint32_t m = 0; m < dev.readNmates; m++) {   // ClipMate::initialize (ClipMate_initialize.cpp:5-31): no N and no adapter = no clipping at this end at all
+                ClipEnd &c = clip[m][ip];
+                c.N = (uint32_t)strtoul(N[m].c_str(), nullptr, 10); c.NafterAd = (uint32_t)strtoul(NafterAd[m].c_str(), nullptr, 10); c.adMMp = strtod(adMMp[m].c_str(), nullptr);
+                c.adSeq = adSeq[m] == "-" ? "" : adSeq[m] == "polyA" ? std::string(650, 'A') : adSeq[m];
+                c.active = c.N > 0 || !c.adSeq.empty();
+                if (c.active) clipYes = true;
+            }
+        }
+    }
     return "";
 }
 

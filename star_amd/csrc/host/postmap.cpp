@@ -41,7 +41,10 @@ struct TrView {                 // one candidate alignment = header + exon slice
 struct ReadCtx {
     const ReadBatch *b; uint32_t i;
     uint64_t Lread, readLength[2];
+    uint64_t readLengthOriginal[2], clip[2][2];   // lengths before clipping; clip[mate][0 = 5', 1 = 3']
     int nMates;
+    // bases soft-clipped on the left of the mate's alignment because of --clip* (ReadAlign_calcCIGAR.cpp:14-23)
+    uint64_t trimL(uint32_t Str, uint32_t Mate) const { return clip[Mate][Str == Mate ? 0 : 1]; }
 };
 } // namespace
 
@@ -81,7 +84,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
         uint32_t Mate = ex[iEx1].iFrag;
         std::string &cigar = matesCIGAR[imate];
-        uint64_t trimL = 0;    // no clipping implemented (defaults clip nothing: parametersDefault:201-224)
+        const uint64_t trimL = rc.trimL(Str, Mate);
         uint64_t trimL1 = trimL + ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
         if (trimL1 > 0) { appendUint(cigar, trimL1); cigar.push_back('S'); }
         for (uint32_t ii = iEx1; ii <= iEx2; ii++) {
@@ -94,7 +97,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             }
             appendUint(cigar, ex[ii].L); cigar.push_back('M');
         }
-        uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLength[leftMate] : rc.readLength[leftMate] + 1 + rc.readLength[Mate])
+        uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLengthOriginal[leftMate] : rc.readLength[leftMate] + 1 + rc.readLengthOriginal[Mate])
                           - ex[iEx2].R - ex[iEx2].L - trimL;
         if (trimR1 > 0) { appendUint(cigar, trimR1); cigar.push_back('S'); }
     }
@@ -252,7 +255,8 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         uint32_t Mate = ex[iEx1].iFrag;
         std::string &cg = matesCIGAR[imate]; std::vector<uint32_t> &pc = packed[imate];
         auto op = [&](uint64_t len, char c, uint32_t code, bool inString) { pc.push_back((uint32_t)len << 4 | code); if (inString) { appendUint(cg, len); cg.push_back(c); } };
-        uint64_t trimL1 = ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
+        const uint64_t trimL = rc.trimL(Str, Mate);
+        uint64_t trimL1 = trimL + ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
         if (trimL1 > 0) op(trimL1, 'S', 4, true);
         for (uint32_t ii = iEx1; ii <= iEx2; ii++) {
             if (ii > iEx1) {
@@ -270,7 +274,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             if (ex[ii].L > 0) pc.push_back((uint32_t)ex[ii].L << 4 | 0);
         }
         if (SJmotif[imate].empty()) { SJmotif[imate].push_back(-1); SJintron[imate].push_back(-1); }
-        uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLength[leftMate] : rc.readLength[leftMate] + 1 + rc.readLength[Mate]) - ex[iEx2].R - ex[iEx2].L;
+        uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLengthOriginal[leftMate] : rc.readLength[leftMate] + 1 + rc.readLengthOriginal[Mate]) - ex[iEx2].R - ex[iEx2].L - trimL;
         if (trimR1 > 0) op(trimR1, 'S', 4, true);
     }
     for (uint32_t imate = 0; imate < nMates; imate++) {
@@ -515,6 +519,10 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         ReadCtx rc; rc.b = &b; rc.i = ir; rc.nMates = (int)P.dev.readNmates;
         rc.Lread = b.readOffset[ir + 1] - b.readOffset[ir];
         rc.readLength[0] = b.mate1Length[ir]; rc.readLength[1] = rc.nMates == 2 ? rc.Lread - rc.readLength[0] - 1 : 0;
+        for (int m = 0; m < 2; m++) {
+            rc.readLengthOriginal[m] = m < rc.nMates ? b.seqSpan[m][ir].len : 0;
+            for (int q = 0; q < 2; q++) rc.clip[m][q] = m < rc.nMates ? b.clipped(m, q, ir) : 0;
+        }
         st.readN++; st.readBases += rc.readLength[0] + rc.readLength[1];
         const staramd_transcript *T = r.tr + rr.trOffset;
         uint64_t nW = rr.nW;

@@ -28,6 +28,7 @@ staramd_batch ReadBatch::view() const {
 void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
     nameSpan.clear(); filter.clear(); origIndex.clear();
+    for (int m = 0; m < 2; m++) for (int q = 0; q < 2; q++) clipN[m][q].clear();
     for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); }
 }
 
@@ -189,6 +190,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     b.readOffset.assign(n + 1, 0); b.mate1Length.assign(n, 0); b.mmMaxTotal.assign(n, 0);
     b.nameSpan.assign(n, TextSpan{0, 0}); b.filter.assign(n, 'N');
     if (fromMemory) b.origIndex.assign(n, 0);
+    if (P.clipYes) for (int m = 0; m < nMates; m++) for (int q = 0; q < 2; q++) b.clipN[m][q].assign(n, 0);
     for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); }
     lap("alloc");
     const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(std::max(P.runThreadN, 1), 32), n / 2048));
@@ -217,6 +219,33 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
                 if (len[m] > STARAMD_READ_LEN_MAX) { bad(i, "EXITING because of FATAL ERROR in reads input: Lread>DEF_readSeqLengthMax"); return; }
                 if (qe - qs != len[m]) { bad(i, "EXITING because of FATAL ERROR in reads input: quality string length is not equal to sequence length"); return; }
                 b.seqSpan[m][i] = TextSpan{ss, (uint32_t)len[m]}; b.qualSpan[m][i] = TextSpan{qs, (uint32_t)len[m]};
+                if (P.clipYes) {                        // ClipMate::clip (ClipMate_clip.cpp:5-78), 5' then 3' (readLoad.cpp:57-58); len[] becomes the clipped length
+                    const char *sq = b.text[m].data() + ss;
+                    uint64_t L = len[m], cN[2] = {0, 0};
+                    for (int ip = 0; ip < 2; ip++) {
+                        const RunParams::ClipEnd &c = P.clip[m][ip];
+                        if (!c.active) continue;
+                        const uint64_t Lold = L;
+                        if (c.N > 0) { if (L > c.N) { L -= c.N; cN[ip] += c.N; } else { L = 0; cN[ip] = Lold; } }
+                        if (!c.adSeq.empty()) {          // 3' only. localSearch (SequenceFuns.cpp:293-315): best ungapped placement of the adapter, Ns of the read skipped
+                            uint64_t nMatchBest = 0, nMMbest = 0, ixBest = L;
+                            for (uint64_t ix = 0; ix < L; ix++) {
+                                uint64_t nMatch = 0, nMM = 0;
+                                for (uint64_t iy = 0; iy < std::min<uint64_t>(c.adSeq.size(), L - ix); iy++) {
+                                    uint8_t x = NT.fwd[(uint8_t)sq[cN[0] + ix + iy]];
+                                    if (x > 3) continue;
+                                    if (x == NT.fwd[(uint8_t)c.adSeq[iy]]) nMatch++; else nMM++;
+                                }
+                                if ((nMatch > nMatchBest || (nMatch == nMatchBest && nMM < nMMbest)) && double(nMM) / double(nMatch) <= c.adMMp) { ixBest = ix; nMatchBest = nMatch; nMMbest = nMM; }
+                            }
+                            cN[ip] += L - ixBest; L = ixBest;
+                        }
+                        if (c.NafterAd > 0) { if (L > c.NafterAd) { L -= c.NafterAd; cN[ip] += c.NafterAd; } else { L = 0; cN[ip] = Lold; } }
+                    }
+                    const uint64_t c5 = cN[0], c3 = cN[1];
+                    b.clipN[m][0][i] = (uint16_t)c5; b.clipN[m][1][i] = (uint16_t)c3;
+                    len[m] = L;
+                }
             }
             // read ID: first white-space token of mate 1's line, then trimmed at readNameSeparator chars
             uint64_t p = s0 + 1, e = p;
@@ -264,12 +293,12 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     inRanges([&](uint64_t lo, uint64_t hi, int) {
         for (uint64_t i = lo; i < hi; i++) {
             uint8_t *r = b.bases.data() + b.readOffset[i];
-            const char *s0 = b.text[0].data() + b.seqSpan[0][i].off;
-            uint64_t len0 = b.seqSpan[0][i].len;
+            const char *s0 = b.text[0].data() + b.seqSpan[0][i].off + b.clipped(0, 0, (uint32_t)i);
+            uint64_t len0 = b.mate1Length[i];
             for (uint64_t k = 0; k < len0; k++) r[k] = NT.fwd[(uint8_t)s0[k]];
             if (nMates == 2) {
-                const char *s1 = b.text[1].data() + b.seqSpan[1][i].off;
-                uint64_t len1 = b.seqSpan[1][i].len;
+                const char *s1 = b.text[1].data() + b.seqSpan[1][i].off + b.clipped(1, 0, (uint32_t)i);
+                uint64_t len1 = Lread[i] - len0 - 1;
                 r[len0] = STARAMD_SPACER_BASE;
                 for (uint64_t k = 0; k < len1; k++) r[len0 + 1 + k] = NT.rc[(uint8_t)s1[len1 - 1 - k]];
             }
