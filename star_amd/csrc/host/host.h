@@ -102,6 +102,14 @@ struct RunParams {
     // read clipping, Hamming adapter type (ParametersClip_initialize.cpp, ClipMate_clip.cpp): per mate
     struct ClipEnd { bool active = false; uint32_t N = 0, NafterAd = 0; std::string adSeq; double adMMp = 0; } clip[2][2];   // [mate][0 = 5', 1 = 3']
     bool clipYes = false;
+    std::string readFilesPrefix, readFilesManifest;         // --readFilesPrefix, --readFilesManifest (Parameters_readFilesInit.cpp:41-139)
+    std::vector<std::string> outSAMheaderHD, outSAMheaderPG; std::string outSAMheaderCommentFile;   // samHeaders.cpp:56-96
+    bool runDirPermAll = false, genomeLoadShared = false;
+    bool outSJnone = false;              // --outSJtype None
+    int outQSconversionAdd = 0;          // --outQSconversionAdd (readLoad.cpp:71-82)
+    bool outMultimapperRandom = false;   // --outMultimapperOrder Random (ReadAlign_multMapSelect.cpp:62-92)
+    bool outSAMunmappedKeepPairs = false;   // --outSAMunmapped Within KeepPairs
+    std::string outStd = "Log";          // --outStd Log | SAM | BAM_Unsorted | BAM_SortedByCoordinate | BAM_Quant
 
     RunParams();
     // STAR-style "--name v1 v2 ..." ; returns error text or ""
@@ -167,7 +175,7 @@ struct SjdbLoci { std::vector<std::string> chr; std::vector<uint64_t> start, end
 void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci);            // sjdbLoadFromStream.cpp:2-28
 // sjdbInsertJunctions.cpp:11-102: rewrites gi (G, SA, SAi, junction table) and P.dev.winBinN; returns error text or ""
 std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, bool pass2, const std::string &pass1sjFile, std::string &log);
-std::string makeRunDir(const std::string &d);
+std::string makeRunDir(const std::string &d, bool allRWX = false);
 // --sjdbGTFfile at the mapping stage (gtf.cpp): junctions of the annotation appended to `loci` with priority 20
 std::string loadGTFjunctions(const RunParams &P, const GenomeIndex &gi, SjdbLoci &loci, const std::string &dirOut, std::string &log);
 
@@ -236,6 +244,10 @@ struct ReadBatch;
 bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r,
                           const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out);
 
+// --outMultimapperOrder Random: the swap partners of the two Fisher-Yates shuffles of every multimapping read of a batch, drawn in read
+// order from the run's one random stream before the batch is formatted on threads (ReadAlign_multMapSelect.cpp:71-80)
+struct MultOrder { std::vector<uint64_t> offset; std::vector<uint32_t> partner; };
+
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
 public:
@@ -249,7 +261,24 @@ public:
                              OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr,
                              std::string *unmappedFastx = nullptr,              // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
                              std::string *chimJunction = nullptr,               // Chimeric.out.junction lines (--chimSegmentMin > 0)
-                             std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr) const;   // TranscriptomeSAM records
+                             std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr,           // TranscriptomeSAM records
+                             const MultOrder *order = nullptr) const;
+    template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o) const {
+        o.offset.assign(b.n + 1, 0); o.partner.clear();
+        for (uint32_t ir = 0; ir < b.n; ir++) {
+            const staramd_read_result &rr = r.reads[ir];
+            o.offset[ir] = o.partner.size();
+            if (rr.nW == 0 || rr.trBest < 0) continue;
+            const staramd_transcript *T = r.tr + rr.trOffset;
+            const int maxScore = T[rr.trBest].maxScore;
+            uint64_t nTr = 0, nbest = 0;
+            for (uint32_t k = 0; k < rr.nTr; k++) if (T[k].maxScore + P.dev.outFilterMultimapScoreRange >= maxScore) { nTr++; if (T[k].maxScore == maxScore) nbest++; }
+            if (nTr > P.outFilterMultimapNmax || nTr < 2) continue;
+            for (int itr = (int)nbest - 1; itr >= 1; itr--) o.partner.push_back((uint32_t)int(uniform01() * itr + 0.5));
+            for (int itr = (int)(nTr - nbest) - 1; itr >= 1; itr--) o.partner.push_back((uint32_t)int(uniform01() * itr + 0.5));
+        }
+        o.offset[b.n] = o.partner.size();
+    }
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     const TranscriptAnnotation *transcripts = nullptr;   // --quantMode TranscriptomeSAM
     std::string quantBamHeader() const;              // samHeaders.cpp:8-20

@@ -3,6 +3,7 @@
 // (alignEndsType :966-983) and Genome_genomeLoad.cpp:382-410 (window geometry).
 // Every other STAR flag is rejected loudly rather than silently ignored.
 #include "host.h"
+#include <fstream>
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
@@ -35,19 +36,55 @@ RunParams::RunParams() {
 }
 
 std::string RunParams::parse(int argc, char **argv) {
-    std::map<std::string, std::vector<std::string> > kv;
+    // Parameters::inputParameters (Parameters.cpp:311-441): command line first (--name value ... or --name=value), then the files of
+    // --parametersFiles in turn, then the command line again on top; one definition per name and source
+    std::map<std::string, std::vector<std::string> > kv, kvCommandLine;
     std::string cur;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         commandLine += (i > 1 ? " " : "") + a;
         if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
-            cur = a.substr(2);
-            if (kv.count(cur)) return "EXITING: FATAL INPUT ERROR: duplicate parameter \"" + cur + "\" in input \"Command-Line\"\nSOLUTION: keep only one definition of input parameters in each input source\n";
-            kv[cur];
+            size_t eq = a.find('=');
+            cur = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            if (kvCommandLine.count(cur)) return "EXITING: FATAL INPUT ERROR: duplicate parameter \"" + cur + "\" in input \"Command-Line\"\nSOLUTION: keep only one definition of input parameters in each input source\n";
+            kvCommandLine[cur];
+            if (eq != std::string::npos) kvCommandLine[cur].push_back(a.substr(eq + 1));
         }
         else if (cur.empty()) return "EXITING: fatal input ERROR: unrecognized parameter name \"" + a + "\" in input \"Command-Line-Initial\"";
-        else kv[cur].push_back(a);
+        else kvCommandLine[cur].push_back(a);
     }
+    for (auto &e : kvCommandLine) if (e.second.empty()) return "EXITING: FATAL INPUT ERROR: empty value for parameter \"" + e.first + "\" in input \"Command-Line\"\nSOLUTION: use non-empty value for this parameter\n";
+    std::map<std::string, std::string> source;
+    if (kvCommandLine.count("parametersFiles") && kvCommandLine["parametersFiles"][0] != "-") {
+        for (const std::string &path : kvCommandLine["parametersFiles"]) {
+            std::ifstream in(path.c_str());
+            if (!in.good()) return "EXITING because of fatal input ERROR: could not open user-defined parameters file " + path + "\n";
+            std::map<std::string, std::vector<std::string> > kvFile;
+            std::string line;
+            while (std::getline(in, line)) {                // Parameters::scanOneLine (:1205-1264), values as inputOneValue <string> reads them (ParameterInfo.h:31-42)
+                size_t q = line.find_first_not_of(" \t\r");
+                if (q == std::string::npos) continue;
+                size_t q1 = line.find_first_of(" \t\r", q);
+                std::string name = line.substr(q, q1 == std::string::npos ? std::string::npos : q1 - q);
+                if (name.compare(0, 2, "//") == 0 || name[0] == '#') continue;
+                std::vector<std::string> vals;
+                while (q1 != std::string::npos) {
+                    q = line.find_first_not_of(" \t\r", q1);
+                    if (q == std::string::npos) break;
+                    if (line[q] == '"') { q1 = line.find('"', q + 1); vals.push_back(line.substr(q + 1, q1 == std::string::npos ? std::string::npos : q1 - q - 1)); if (q1 != std::string::npos) q1++; }
+                    else { q1 = line.find_first_of(" \t\r", q); vals.push_back(line.substr(q, q1 == std::string::npos ? std::string::npos : q1 - q)); }
+                }
+                if (vals.empty()) return "EXITING: FATAL INPUT ERROR: empty value for parameter \"" + name + "\" in input \"" + path + "\"\nSOLUTION: use non-empty value for this parameter\n";
+                if (name == "parametersFiles" || name == "outFileNamePrefix" || name == "outTmpDir" || name == "outTmpKeep" || name == "outStd")
+                    return "EXITING: FATAL INPUT ERROR: parameter \"" + name + "\" cannot be defined at the input level \"" + path + "\"\nSOLUTION: define parameter \"" + name + "\" in \"Command-Line\"\n";
+                if (kvFile.count(name)) return "EXITING: FATAL INPUT ERROR: duplicate parameter \"" + name + "\" in input \"" + path + "\"\nSOLUTION: keep only one definition of input parameters in each input source\n";
+                kvFile[name] = vals;
+            }
+            for (auto &e : kvFile) { kv[e.first] = e.second; source[e.first] = path; }
+        }
+    }
+    for (auto &e : kvCommandLine) { kv[e.first] = e.second; source[e.first] = "Command-Line"; }
+    kv.erase("parametersFiles");
     commandLine = std::string(argc > 0 ? argv[0] : "star_amd") + " " + commandLine;
     std::string err;
     auto one = [&](const std::string &k, const std::vector<std::string> &v) -> const std::string & {
@@ -88,7 +125,11 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "sjdbGTFtagExonParentGeneName") sjdbGTFtagExonParentGeneName = v;
         else if (k == "sjdbGTFtagExonParentGeneType") sjdbGTFtagExonParentGeneType = v;
         else if (k == "gpuDevice") gpuDevice = (int)I(k, v);
-        else if (k == "genomeLoad") { if (one(k, v) != "NoSharedMemory") err = "EXITING: --genomeLoad: the index lives in HBM; only NoSharedMemory is accepted"; }
+        else if (k == "genomeLoad") {           // the index lives in HBM, host shared memory does not come into it: the two values that only say how long to keep it are accepted
+            const std::string &m = one(k, v);
+            if (m == "LoadAndKeep" || m == "LoadAndRemove") genomeLoadShared = true;
+            else if (m != "NoSharedMemory") err = "EXITING: --genomeLoad " + m + ": there is no shared-memory copy of the index to load or remove (it lives in HBM); use NoSharedMemory, LoadAndKeep or LoadAndRemove";
+        }
         else if (k == "outSAMtype") {                   // Parameters.cpp:611-683
             if (v.empty()) err = "EXITING because of fatal input ERROR: --outSAMtype needs a value";
             else if (v[0] == "SAM") { if (v.size() > 1) err = "EXITING because of fatal PARAMETER error: --outSAMtype SAM can cannot be combined with " + v[1] + " or any other options\nSOLUTION: re-run STAR with with '--outSAMtype SAM' only, or with --outSAMtype BAM Unsorted|SortedByCoordinate\n"; }
@@ -103,9 +144,29 @@ std::string RunParams::parse(int argc, char **argv) {
             } else err = "EXITING because of fatal input ERROR: unknown value for the first word of outSAMtype: " + v[0] + "\nSOLUTION: re-run STAR with one of the allowed values of outSAMtype: BAM or SAM \n";
         }
         else if (k == "outBAMcompression") outBAMcompression = (int)I(k, v);
-        else if (k == "outStd") { if (one(k, v) != "Log") err = "EXITING: only --outStd Log is implemented"; }
+        else if (k == "outStd") { outStd = one(k, v); if (outStd != "Log" && outStd != "SAM" && outStd != "BAM_Unsorted" && outStd != "BAM_SortedByCoordinate" && outStd != "BAM_Quant") err = "EXITING because of FATAL PARAMETER error: outStd=" + outStd + " is not a valid value of the parameter\nSOLUTION: provide a valid value fot outStd: Log / SAM / BAM_Unsorted / BAM_SortedByCoordinate"; }
+        else if (k == "readFilesPrefix") { if (one(k, v) != "-") readFilesPrefix = one(k, v); }
+        else if (k == "readFilesManifest") { if (one(k, v) != "-") readFilesManifest = one(k, v); }
+        else if (k == "outSAMheaderHD") { if (v[0] != "-") outSAMheaderHD = v; }
+        else if (k == "outSAMheaderPG") { if (v[0] != "-") outSAMheaderPG = v; }
+        else if (k == "outSAMheaderCommentFile") { if (one(k, v) != "-") outSAMheaderCommentFile = one(k, v); }
+        else if (k == "outSJtype") { const std::string &m = v[0]; if (m == "None") outSJnone = true; else if (m != "Standard") err = "EXITING because of FATAL input ERROR: unrecognized option in --outSJtype   " + m + "\nSOLUTION: use one of the allowed options: --outSJtype   Standard    OR    None\n"; }
+        else if (k == "outQSconversionAdd") outQSconversionAdd = (int)I(k, v);
+        else if (k == "outMultimapperOrder") { const std::string &m = one(k, v); if (m == "Random") outMultimapperRandom = true; else if (m != "Old_2.4") err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --outMultimapperOrder: " + m + "\nSOLUTION: specify one of the allowed values: Old_2.4 or Random\n"; }
+        else if (k == "outSAMorder") { const std::string &m = one(k, v); if (m != "Paired" && m != "PairedKeepInputOrder") err = "EXITING because of FATAL INPUT ERROR: unknown value for --outSAMorder: " + m; }   // batches are always written in input order here
+        else if (k == "readMatesLengthsIn") { const std::string &m = one(k, v); if (m != "NotEqual" && m != "Equal") err = "EXITING: unknown value for --readMatesLengthsIn: " + m; }
+        else if (k == "readQualityScoreBase") { (void)I(k, v); }       // only STARsolo's statistics look at it (SoloFeature_statsOutput.cpp:18)
+        else if (k == "runDirPerm") { const std::string &m = one(k, v); if (m == "All_RWX") runDirPermAll = true; else if (m != "User_RWX") err = "EXITING because of FATAL INPUT ERROR: unrecognized option in --runDirPerm=" + m + "\nSOLUTION: use one of the allowed values of --runDirPerm : 'User_RWX' or 'All_RWX' \n"; }
+        // limits and knobs of the reference's own buffers, temporary files and sorting threads: nothing here is sized by them
+        else if (k == "limitBAMsortRAM" || k == "limitIObufferSize" || k == "limitOutSAMoneReadBytes" || k == "limitOutSJcollapsed" || k == "limitOutSJoneRead" || k == "limitNreadsSoft"
+                 || k == "outBAMsortingThreadN" || k == "outBAMsortingBinsN" || k == "outTmpDir" || k == "outTmpKeep" || k == "sysShell") { if (v.empty()) err = "EXITING: --" + k + " needs a value"; }
         else if (k == "outSAMmode") { const std::string &s = one(k, v); if (s == "NoQS") outSAMmodeNoQS = true; else if (s != "Full") err = "EXITING: unsupported --outSAMmode " + s; }
-        else if (k == "outSAMunmapped") { if (v.size() >= 1 && v[0] == "Within") { outSAMunmappedWithin = true; if (v.size() > 1) err = "EXITING: --outSAMunmapped Within KeepPairs is not implemented"; } else if (!(v.size() == 1 && v[0] == "None")) err = "EXITING: unsupported --outSAMunmapped"; }
+        else if (k == "outSAMunmapped") {       // Parameters.cpp:1062-1082
+            if (v.size() == 1 && v[0] == "None") {}
+            else if (v.size() == 1 && v[0] == "Within") outSAMunmappedWithin = true;
+            else if (v.size() >= 2 && v[0] == "Within" && v[1] == "KeepPairs") { outSAMunmappedWithin = true; outSAMunmappedKeepPairs = true; }
+            else { err = "EXITING because of fatal PARAMETERS error: unrecognized option for --outSAMunmapped="; for (auto &t : v) err += " " + t; err += "\nSOLUTION: use allowed options: None OR Within OR Within KeepPairs"; }
+        }
         else if (k == "outSAMattributes") {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
@@ -242,13 +303,51 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
+    if (!readFilesManifest.empty()) {        // Parameters_readFilesInit.cpp:100-139: Read1 <tab> Read2 (or -) <tab> read group line
+        std::ifstream rfM(readFilesManifest.c_str());
+        if (!rfM.good()) return "EXITING because of fatal INPUT error: could not open input file " + readFilesManifest + "\nSOLUTION: check the path and permissions for readFilesManifest = " + readFilesManifest + "\n";
+        std::vector<std::string> names[2]; std::string line;
+        outSAMattrRG.clear(); outSAMattrRGlineSplit.clear();
+        while (std::getline(rfM, line)) {
+            if (line.find_first_not_of(" \t") >= line.size()) continue;
+            size_t itab1 = 0, itab2 = 0;
+            for (int im = 0; im < 2; im++) {
+                itab2 = line.find('\t', itab1);
+                if (itab2 >= line.size()) return "EXITING because of FATAL INPUT FILE error: readFileManifest file " + readFilesManifest + " has to contain at least 3 tab separated columns\nSOLUTION: fix the formatting of the readFileManifest file: Read1 <tab> Read2 <tab> ReadGroup. For single-end reads, use - in the 2nd column.\n";
+                names[im].push_back(line.substr(itab1, itab2 - itab1));
+                itab1 = itab2 + 1;
+            }
+            std::string rg = line.substr(itab2 + 1);
+            if (rg.substr(0, 3) != "ID:") rg.insert(0, "ID:");
+            outSAMattrRGlineSplit.push_back(rg);
+            size_t t = rg.find('\t');
+            outSAMattrRG.push_back(rg.substr(3, t == std::string::npos ? std::string::npos : t - 3));
+        }
+        if (names[0].empty()) return "EXITING because of FATAL INPUT FILE error: readFileManifest file " + readFilesManifest + " has no lines";
+        const int nEnds = names[1][0].back() == '-' ? 1 : 2;
+        readFilesIn.assign(nEnds, "");
+        for (int im = 0; im < nEnds; im++) for (size_t i = 0; i < names[im].size(); i++) readFilesIn[im] += (i ? "," : "") + names[im][i];
+    }
+    if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";
+    for (std::string &list : readFilesIn) {                // a trailing comma is dropped, the prefix goes in front of every name (:46-61)
+        if (!list.empty() && list.back() == ',') list.pop_back();
+        if (!readFilesPrefix.empty()) { std::string o = readFilesPrefix; for (char c : list) { o.push_back(c); if (c == ',') o += readFilesPrefix; } list = o; }
+    }
+    if (readFilesIn.size() == 2 && std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') != std::count(readFilesIn[1].begin(), readFilesIn[1].end(), ','))
+        return "EXITING: because of fatal INPUT ERROR: number of input files for mate2=" + std::to_string(std::count(readFilesIn[1].begin(), readFilesIn[1].end(), ',') + 1) + " is not equal to that for mate0="
+               + std::to_string(std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') + 1) + "\nMake sure that the number of files in --readFilesIn is the same for both mates\n";
+    if (outSJnone && outFilterBySJout) return "EXITING because of FATAL input ERROR: --outFilterType BySJout requires --outSJtype Standard\nSOLUTION: --outFilterType Normal    OR   --outFilterType BySJout --outSJtype Standard\n";
+    if (outSJnone && twopass) return "EXITING because of FATAL input ERROR: --twopassMode Basic needs the junctions of the 1st pass, i.e. --outSJtype Standard\n";
+    if (twopass && genomeLoadShared) return "EXITING because of fatal PARAMETERS error: 2-pass method is not compatible with genomeLoad shared memory options\nSOLUTION: re-run STAR with --genomeLoad NoSharedMemory ; this is the only option compatible with --twopassMode Basic .\n";
+    if (outMultimapperRandom && quantTrSAM) return "EXITING: --outMultimapperOrder Random together with --quantMode TranscriptomeSAM is not implemented (both draw from one random stream in read order)";
+    if (outSAMunmappedKeepPairs && outBAMunsorted && outBAMcoord) return "EXITING: --outSAMunmapped Within KeepPairs with both BAM Unsorted and SortedByCoordinate in one run is not implemented; run one of the two";
     {   // read groups: one for all input files or one per file; the RG attribute comes with them (Parameters_readFilesInit.cpp:84-93, Parameters_samAttributes.cpp:201-206)
         size_t nFiles = readFilesIn.empty() ? 0 : (size_t)std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') + 1;
         if (outSAMattrRG.size() > 1 && outSAMattrRG.size() != nFiles)
             return "EXITING: because of fatal INPUT ERROR: number of input read files: " + std::to_string(nFiles) + " does not agree with number of read group RG entries: " + std::to_string(outSAMattrRG.size()) + "\nMake sure that the number of RG lines in --outSAMattrRGline is equal to either 1, or the number of input read files in --readFilesIn\n";
         if (outSAMattrRG.size() == 1) for (size_t i = 1; i < nFiles; i++) outSAMattrRG.push_back(outSAMattrRG[0]);
         bool hasRG = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "RG") != outSAMattrOrder.end();
-        if (!outSAMattrRG.empty() && !hasRG) outSAMattrOrder.push_back("RG");
+        if (!outSAMattrRG.empty() && !hasRG && readFilesManifest.empty()) outSAMattrOrder.push_back("RG");   // only --outSAMattrRGline adds the attribute by itself (Parameters_samAttributes.cpp:201)
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
     if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
@@ -258,8 +357,8 @@ std::string RunParams::parse(int argc, char **argv) {
     for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC") outSAMattrOrderQuant.push_back(a);
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
-    if (readFilesIn.empty() || readFilesIn.size() > 2) return "EXITING: --readFilesIn expects 1 or 2 FASTQ files";
     dev.readNmates = (uint32_t)readFilesIn.size();
+    if (dev.readNmates != 2) outSAMunmappedKeepPairs = false;     // Parameters.cpp:1074
     {   // ParametersClip::initialize (ParametersClip_initialize.cpp:33-82): a lone 0 / "-" is repeated for all mates, anything else needs one value per mate
         const std::string nm = std::to_string(dev.readNmates);
         const char *p53[2] = {"5", "3"};

@@ -7,6 +7,7 @@
 //   Stats::transcriptStats source/Stats.cpp:35-56
 // Host-side integer code; defines the parity surface (Aligned.out.sam, SJ.out.tab, Log.final.out).
 #include "host.h"
+#include <fstream>
 #include <cstring>
 #include <algorithm>
 
@@ -48,10 +49,19 @@ struct ReadCtx {
 };
 } // namespace
 
-std::string PostMap::samHeader() const {
-    std::string h = "@HD\tVN:1.4\n";
+std::string PostMap::samHeader() const {                 // samHeaders.cpp:27-98
+    std::string h;
+    if (P.outSAMheaderHD.empty()) h = "@HD\tVN:1.4";
+    else for (size_t i = 0; i < P.outSAMheaderHD.size(); i++) { if (i) h.push_back('\t'); h += P.outSAMheaderHD[i]; }
+    h.push_back('\n');
     for (uint32_t i = 0; i < gi.view.nChrReal; i++) { h += "@SQ\tSN:" + gi.chrName[i] + "\tLN:"; appendUint(h, gi.chrLength[i]); h += "\n"; }
+    if (!P.outSAMheaderPG.empty()) { for (size_t i = 0; i < P.outSAMheaderPG.size(); i++) { if (i) h.push_back('\t'); h += P.outSAMheaderPG[i]; } h.push_back('\n'); }
     h += "@PG\tID:STAR\tPN:STAR\tVN:2.7.11b\tCL:" + P.commandLine + "\n";
+    if (!P.outSAMheaderCommentFile.empty()) {            // non-blank lines of the file, as they are
+        std::ifstream com(P.outSAMheaderCommentFile.c_str());
+        std::string line;
+        while (std::getline(com, line)) if (line.find_first_not_of(" \t\n\v\f\r") != std::string::npos) h += line + "\n";
+    }
     for (const std::string &rg : P.outSAMattrRGlineSplit) h += "@RG\t" + rg + "\n";                  // samHeaders.cpp:78-80
     h += "@CO\tuser command line: " + P.commandLine + "\n";
     return h;
@@ -354,7 +364,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
 
 // unmapped mates (alignType >= 0): both mates of an unmapped read, or the missing mate of a single-end alignment (:120-188)
 static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const staramd_transcript *trBest, const staramd_exon *exBest,
-                        int unmapType, const bool mateMap[2], std::vector<BamKey> *keys) {
+                        int unmapType, const bool mateMap[2], std::vector<BamKey> *keys, bool mappedMateSecondary = false) {
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     for (int imate = 0; imate < rc.nMates; imate++) {
         if (mateMap[imate]) continue;
@@ -364,6 +374,7 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
             if (mateMap[1 - imate]) {
                 if (trBest->Str != (uint32_t)(1 - imate)) samFLAG |= 0x20;
                 mateChr = trBest->Chr; mateStart = (uint32_t)(exBest[0].G - gi.chrStart[mateChr]);
+                if (mappedMateSecondary) samFLAG |= 0x100;       // KeepPairs: the unmapped mate of a secondary alignment is secondary too (:136-139)
             } else samFLAG |= 0x8;
         }
         if (b.filter[ir] == 'Y') samFLAG |= 0x200;
@@ -405,7 +416,7 @@ std::string PostMap::bamHeader(bool sortedByCoordinate) const {
 
 // ---- ReadAlign::outputTranscriptSAM, unmapped branch (:11-54) ----
 static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const staramd_transcript *trBest, const staramd_exon *exBest,
-                        int unmapType, const bool mateMap[2]) {
+                        int unmapType, const bool mateMap[2], bool mappedMateSecondary = false) {
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     for (int imate = 0; imate < rc.nMates; imate++) {
         if (mateMap[imate]) continue;
@@ -416,6 +427,7 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
             else samFLAG |= 0x8;
         }
         if (b.filter[ir] == 'Y') samFLAG |= 0x200;
+        if (rc.nMates == 2 && mateMap[1 - imate] && mappedMateSecondary) samFLAG |= 0x100;      // :31-33 (KeepPairs)
         out += b.name(ir); out.push_back('\t'); appendUint(out, samFLAG); out += "\t*\t0\t0\t*";
         if (rc.nMates == 2 && mateMap[1 - imate]) { out.push_back('\t'); out += gi.chrName[trBest->Chr]; out.push_back('\t'); appendUint(out, exBest[0].G + 1 - gi.chrStart[trBest->Chr]); }
         else out += "\t*\t0";
@@ -507,7 +519,7 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                                   OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
-                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches) const {
+                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
@@ -538,12 +550,17 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             if (!(nTr > P.outFilterMultimapNmax || nTr == 0)) {
                 if (nTr == 1) trMult[0].primary = true;
                 else {
-                    if (P.outSAMmultNmax >= 0) {             // :61-68 the best alignments move to the top of the list (they are the ones that get written)
+                    if (P.outSAMmultNmax >= 0 || P.outMultimapperRandom) {      // :61-68 the best alignments move to the top of the list (they are the ones that get written)
                         uint64_t nbest = 0;
                         for (uint64_t it = 0; it < nTr; it++) if (trMult[it].t->maxScore == maxScore) { std::swap(trMult[it], trMult[nbest]); ++nbest; }
+                        if (P.outMultimapperRandom && order) {                  // :71-80 the best ones and the rest are shuffled separately
+                            const uint32_t *partner = order->partner.data() + order->offset[ir];
+                            for (int itr = (int)nbest - 1; itr >= 1; itr--) std::swap(trMult[itr], trMult[*partner++]);
+                            for (int itr = (int)(nTr - nbest) - 1; itr >= 1; itr--) std::swap(trMult[nbest + itr], trMult[nbest + *partner++]);
+                        }
                     }
                     if (P.outSAMprimaryAllBest) { for (auto &v : trMult) if (v.t->maxScore == maxScore) v.primary = true; }
-                    else if (P.outSAMmultNmax >= 0) trMult[0].primary = true;
+                    else if (P.outSAMmultNmax >= 0 || P.outMultimapperRandom) trMult[0].primary = true;
                     else { for (auto &v : trMult) if (v.t == trBest) v.primary = true; }
                 }
             }
@@ -585,11 +602,26 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             // writeSAM (:132-256), default outSAMmultNmax=-1: all nTr
             // writeSAM (:132-256): at most --outSAMmultNmax alignments are written (NH keeps the full count)
             const uint64_t nTrWrite = P.outSAMmultNmax < 0 ? nTr : std::min<uint64_t>(nTr, (uint64_t)P.outSAMmultNmax);
-            if (!samOff) for (uint64_t it = 0; it < nTrWrite; it++) { if (bam) bamMapped(sam, P, gi, rc, trMult[it], nTr, it, bamKeys); else samMapped(sam, P, gi, rc, trMult[it], nTr, it); }
+            const bool keepPairs = P.outSAMunmappedKeepPairs;
+            if (!samOff) for (uint64_t it = 0; it < nTrWrite; it++) {
+                if (bam) bamMapped(sam, P, gi, rc, trMult[it], nTr, it, bamKeys); else samMapped(sam, P, gi, rc, trMult[it], nTr, it);
+                if (keepPairs && !P.outBAMcoord) {   // ReadAlign_outputAlignments.cpp:178-195: the unmapped mate right after every one-mate alignment (not in the sorted BAM)
+                    const staramd_transcript &t = *trMult[it].t;
+                    bool mateMapped1[2] = {false, false};
+                    mateMapped1[trMult[it].ex[0].iFrag] = true; mateMapped1[trMult[it].ex[t.nExons - 1].iFrag] = true;
+                    if (!(mateMapped1[0] && mateMapped1[1])) {
+                        if (bam) bamUnmapped(sam, P, gi, rc, &t, trMult[it].ex, 4, mateMapped1, nullptr, !trMult[it].primary); else samUnmapped(sam, P, gi, rc, &t, trMult[it].ex, 4, mateMapped1, !trMult[it].primary);
+                    }
+                }
+            }
             const staramd_exon *exB = r.ex + trBest->exonOffset;
             mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
             if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
-            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff) { if (bam) bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped, bamKeys); else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped); }
+            if (unmapType == 4 && P.outSAMunmappedWithin && !samOff && (!keepPairs || P.outBAMcoord)) {     // :216-233
+                bool trBestSecondary = false;
+                if (keepPairs) { trBestSecondary = true; for (uint64_t it = 0; it < nTr; it++) if (trMult[it].t == trBest && trMult[it].primary) trBestSecondary = false; }
+                if (bam) bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped, bamKeys, trBestSecondary); else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
+            }
         } else if (P.outSAMunmappedWithin && !samOff) {
             staramd_transcript t0; memset(&t0, 0, sizeof(t0));
             if (bam) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped, bamKeys);

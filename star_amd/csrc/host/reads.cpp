@@ -219,6 +219,10 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
                 if (len[m] > STARAMD_READ_LEN_MAX) { bad(i, "EXITING because of FATAL ERROR in reads input: Lread>DEF_readSeqLengthMax"); return; }
                 if (qe - qs != len[m]) { bad(i, "EXITING because of FATAL ERROR in reads input: quality string length is not equal to sequence length"); return; }
                 b.seqSpan[m][i] = TextSpan{ss, (uint32_t)len[m]}; b.qualSpan[m][i] = TextSpan{qs, (uint32_t)len[m]};
+                if (P.outQSconversionAdd != 0) {        // readLoad.cpp:71-82, in place: every output of the qualities sees the converted ones
+                    char *q = &b.text[m][qs];
+                    for (uint64_t k = 0; k < len[m]; k++) { int v = int(q[k]) + P.outQSconversionAdd; q[k] = (char)(v < 33 ? 33 : v > 126 ? 126 : v); }
+                }
                 if (P.clipYes) {                        // ClipMate::clip (ClipMate_clip.cpp:5-78), 5' then 3' (readLoad.cpp:57-58); len[] becomes the clipped length
                     const char *sq = b.text[m].data() + ss;
                     uint64_t L = len[m], cN[2] = {0, 0};

@@ -43,6 +43,7 @@ struct Runner {
     std::vector<uint64_t> novelStart, novelEnd;
     GeneAnnotation genes; GeneCounts geneCounts;      // --quantMode GeneCounts
     TranscriptAnnotation transcripts; FILE *quantOut = nullptr;     // --quantMode TranscriptomeSAM -> Aligned.toTranscriptome.out.bam
+    MultOrder multOrder;
     std::mt19937 rngMultOrder; std::uniform_real_distribution<double> rngUniformReal0to1{0.0, 1.0};   // ReadAlign.cpp:11-12 (one stream: iChunk 0)
     std::vector<std::string> coordChunks; std::vector<BamKey> coordKeys;     // --outSAMtype BAM SortedByCoordinate: every record, until finish()
     int wireTable = 0;                                // which junction table sah_sj_export / import / clear address: 0 = sj, 1 = sj1
@@ -66,9 +67,9 @@ struct Runner {
             if (P.sjdbOverhang == 0 || P.sjdbOverhang > 500) { error = "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 (or > 500) while junctions are inserted on the fly"; return false; }
             gi.view.sjdbOverhang = P.sjdbOverhang; gi.view.sjdbLength = 2 * P.sjdbOverhang + 1;
             P.sjdbInsertOutDir = P.outFileNamePrefix + "_STARgenome/";
-            error = makeRunDir(P.sjdbInsertOutDir);
+            error = makeRunDir(P.sjdbInsertOutDir, P.runDirPermAll);
             if (!error.empty()) return false;
-            if (P.twopass) { P.twopassDir = P.outFileNamePrefix + "_STARpass1/"; error = makeRunDir(P.twopassDir); if (!error.empty()) return false; }
+            if (P.twopass) { P.twopassDir = P.outFileNamePrefix + "_STARpass1/"; error = makeRunDir(P.twopassDir, P.runDirPermAll); if (!error.empty()) return false; }
         }
         P.finalize(gi);
         if (P.sjdbInsertPass1()) {                                  // STAR.cpp:147-150: insertion before the (1st) mapping pass
@@ -78,14 +79,14 @@ struct Runner {
         error = reader.open(P.readFilesIn, P.readFilesCommand);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
+        rngMultOrder.seed((unsigned)P.runRNGseed);                  // ReadAlign.cpp:11 (iChunk 0)
         if (P.quantTrSAM) {
             error = transcripts.load(P.sjdbGTFfile.empty() ? P.genomeDir : P.sjdbInsertOutDir);
             if (!error.empty()) return false;
             post->transcripts = &transcripts;
-            rngMultOrder.seed((unsigned)P.runRNGseed);
             if (P.quantTrBAMcompression > -2) {
                 std::string qp = P.outFileNamePrefix + "Aligned.toTranscriptome.out.bam";
-                quantOut = fopen(qp.c_str(), "wb");
+                quantOut = P.outStd == "BAM_Quant" ? stdout : fopen(qp.c_str(), "wb");
                 if (!quantOut) { error = "EXITING because of fatal ERROR: could not create output file " + qp; return false; }
                 std::string h;
                 if (!bgzfCompress(post->quantBamHeader(), P.quantTrBAMcompression, h)) { error = "EXITING because of fatal ERROR: BGZF compression failed"; return false; }
@@ -119,7 +120,7 @@ struct Runner {
         else if (P.outBAMcoord && !P.outBAMunsorted) {}             // only Aligned.sortedByCoord.out.bam, written at the end of the run
         else {
             std::string samPath = P.outFileNamePrefix + (P.outBAMunsorted ? "Aligned.out.bam" : "Aligned.out.sam");
-            samOut = fopen(samPath.c_str(), "wb");
+            samOut = (P.outBAMunsorted ? P.outStd == "BAM_Unsorted" : P.outStd == "SAM") ? stdout : fopen(samPath.c_str(), "wb");
             if (!samOut) { error = "EXITING because of fatal ERROR: could not create output file " + samPath; return false; }
             setvbuf(samOut, nullptr, _IOFBF, 1 << 22);
             std::string h;
@@ -186,6 +187,8 @@ struct Runner {
         std::vector<std::string> chims(chimOn ? T : 0);
         const bool unm = P.outReadsUnmappedFastx && !pass1;
         std::vector<std::array<std::string, 2> > unms(unm ? T : 0);
+        const bool randomOrder = P.outMultimapperRandom;
+        if (randomOrder) post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder);
         uint32_t per = (bt.n + T - 1) / T;
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
@@ -195,13 +198,13 @@ struct Runner {
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                              P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr);
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                          nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr);
         };
         if (T == 1) work(0);
         else {
@@ -262,10 +265,11 @@ struct Runner {
     // records of the run are held in memory, ordered once and compressed on the host threads, slice by slice.
     std::string writeSortedBam() {
         std::string path = P.outFileNamePrefix + "Aligned.sortedByCoord.out.bam";
-        FILE *f = fopen(path.c_str(), "wb");
+        const bool toStdout = P.outStd == "BAM_SortedByCoordinate";
+        FILE *f = toStdout ? stdout : fopen(path.c_str(), "wb");
         if (!f) return "EXITING because of fatal ERROR: could not create output file " + path;
         std::string h;
-        if (!bgzfCompress(post->bamHeader(true), P.outBAMcompression, h)) { fclose(f); return "EXITING because of fatal ERROR: BGZF compression failed"; }
+        if (!bgzfCompress(post->bamHeader(true), P.outBAMcompression, h)) { if (!toStdout) fclose(f); return "EXITING because of fatal ERROR: BGZF compression failed"; }
         fwrite(h.data(), 1, h.size(), f);
         std::vector<uint64_t> ord(coordKeys.size());
         for (uint64_t i = 0; i < ord.size(); i++) ord[i] = i;
@@ -289,7 +293,7 @@ struct Runner {
             for (uint64_t t = 0; t < T; t++) if (!outS[t].empty() && fwrite(outS[t].data(), 1, outS[t].size(), f) != outS[t].size()) failed = true;
         }
         std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), f);
-        fclose(f);
+        if (toStdout) fflush(stdout); else fclose(f);
         coordChunks.clear(); coordKeys.clear();
         return failed ? "EXITING because of fatal ERROR: could not write " + path : "";
     }
@@ -309,6 +313,7 @@ struct Runner {
         stats = Stats(); stats.timeStart = t0; time(&stats.timeStartMap);
         sj.data.clear();
         P.readMapNumber = readMapNumberUser; post->samOff = P.outSAMnone; pass1 = false;
+        rngMultOrder.seed((unsigned)P.runRNGseed);                  // the 2nd pass runs on fresh ReadAlign objects (twoPassRunPass1.cpp:31-37)
         P.dev.chimSegmentMinPositive = P.chim.segmentMin > 0 ? 1 : 0;
         if (P.outFilterBySJout) { bySJoutStage = 1; P.dev.outFilterBySJoutStage = 1; }
         return true;
@@ -334,7 +339,7 @@ struct Runner {
     bool finish() {
         stopWriter();
         for (FILE *&u : unmappedOut) if (u) { fclose(u); u = nullptr; }
-        if (quantOut) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), quantOut); fclose(quantOut); quantOut = nullptr; }
+        if (quantOut) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), quantOut); if (quantOut == stdout) fflush(stdout); else fclose(quantOut); quantOut = nullptr; }
         if (chimOut) {
             if (P.chim.outJunctionFormat == 1)              // Stats::writeLines (Stats.cpp:147-155, STAR.cpp:285)
                 fprintf(chimOut, "# 2.7.11b   %s\n# Nreads %llu\tNreadsUnique %llu\tNreadsMulti %llu\n", P.commandLine.c_str(), (unsigned long long)stats.readN,
@@ -344,16 +349,17 @@ struct Runner {
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (samOut) {
             if (P.outBAMunsorted) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), samOut); }
-            fclose(samOut); samOut = nullptr;
+            if (samOut == stdout) fflush(stdout); else fclose(samOut);
+            samOut = nullptr;
         }
         if (P.outBAMcoord && !P.outSAMnone) { error = writeSortedBam(); if (!error.empty()) return false; }
-        error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129
+        if (!P.outSJnone) error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129; STAR.cpp:251
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
         if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
-    ~Runner() { stopWriter(); if (samOut) fclose(samOut); for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); if (quantOut) fclose(quantOut); }
+    ~Runner() { stopWriter(); if (samOut && samOut != stdout) fclose(samOut); if (quantOut == stdout) quantOut = nullptr; for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); if (quantOut) fclose(quantOut); }
 };
 
 } // namespace staramd

@@ -518,9 +518,9 @@ std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, b
     return "";
 }
 
-std::string makeRunDir(const std::string &d) {                             // Parameters.cpp:817-824, 1027-1034
+std::string makeRunDir(const std::string &d, bool allRWX) {               // Parameters.cpp:817-824, 1027-1034; --runDirPerm User_RWX | All_RWX (:471-481)
     removeDirRecursive(d);
-    if (mkdir(d.c_str(), 0755) != 0) return "EXITING because of fatal ERROR: could not make run-time directory: " + d + "\nSOLUTION: please check the path and writing permissions \n";
+    if (mkdir(d.c_str(), allRWX ? (S_IRWXU | S_IRWXG | S_IRWXO) : S_IRWXU) != 0) return "EXITING because of fatal ERROR: could not make run-time directory: " + d + "\nSOLUTION: please check the path and writing permissions \n";
     return "";
 }
 
