@@ -230,7 +230,7 @@ struct TranscriptAnnotation {             // transcriptInfo.tab + exonInfo.tab
 };
 // primary flag of the transcriptomic alignments of one read: chosen with one random number per mapped read, in read order
 // (ReadAlign_quantTranscriptome.cpp:69), so it is patched into the records after the threads of a batch have joined
-struct QuantPatch { uint32_t nAlignT; std::vector<uint64_t> recOffset; std::vector<uint32_t> recAlign; };
+struct QuantPatch { uint32_t ir; uint32_t nAlignT; std::vector<uint64_t> recOffset; std::vector<uint32_t> recAlign; };
 
 // ---- BGZF framing of BAM output (bgzf.cpp) ----
 bool bgzfCompress(const std::string &raw, int level, std::string &out);
@@ -246,7 +246,7 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
 
 // --outMultimapperOrder Random: the swap partners of the two Fisher-Yates shuffles of every multimapping read of a batch, drawn in read
 // order from the run's one random stream before the batch is formatted on threads (ReadAlign_multMapSelect.cpp:71-80)
-struct MultOrder { std::vector<uint64_t> offset; std::vector<uint32_t> partner; };
+struct MultOrder { std::vector<uint64_t> offset; std::vector<uint32_t> partner; std::vector<uint32_t> quantPick; };
 
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
@@ -262,12 +262,15 @@ public:
                              std::string *unmappedFastx = nullptr,              // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
                              std::string *chimJunction = nullptr,               // Chimeric.out.junction lines (--chimSegmentMin > 0)
                              std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr,           // TranscriptomeSAM records
-                             const MultOrder *order = nullptr) const;
-    template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o) const {
-        o.offset.assign(b.n + 1, 0); o.partner.clear();
+                             const MultOrder *order = nullptr, bool dry = false) const;   // dry: no alignment records, only the side outputs asked for
+    // nAlignT (with --quantMode TranscriptomeSAM): per read, the number of transcriptomic alignments + 1 where the read draws its primary one
+    // right after its shuffles (ReadAlign_quantTranscriptome.cpp:69), 0 where it does not
+    template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr) const {
+        o.offset.assign(b.n + 1, 0); o.partner.clear(); o.quantPick.assign(nAlignT ? b.n : 0, 0);
         for (uint32_t ir = 0; ir < b.n; ir++) {
             const staramd_read_result &rr = r.reads[ir];
             o.offset[ir] = o.partner.size();
+            struct AtExit { const std::vector<uint32_t> *n; MultOrder &o; uint32_t ir; Rng &u; ~AtExit() { if (n && (*n)[ir]) o.quantPick[ir] = (uint32_t)(int)(u() * ((*n)[ir] - 1)); } } quantDraw{nAlignT, o, ir, uniform01};
             if (rr.nW == 0 || rr.trBest < 0) continue;
             const staramd_transcript *T = r.tr + rr.trOffset;
             const int maxScore = T[rr.trBest].maxScore;

@@ -479,7 +479,7 @@ static void quantTranscriptome(const RunParams &P, const GenomeIndex &gi, const 
         A.quantAlign(g, alignT);
         for (size_t k = n0; k < alignT.size(); k++) src.push_back(&t);
     }
-    QuantPatch qp; qp.nAlignT = (uint32_t)alignT.size();
+    QuantPatch qp; qp.ir = ir; qp.nAlignT = (uint32_t)alignT.size();
     for (size_t iatr = 0; iatr < alignT.size(); iatr++) {
         staramd_transcript tq = *src[iatr];
         tq.Chr = alignT[iatr].tr; tq.Str = (uint8_t)alignT[iatr].Str; tq.nExons = (uint16_t)alignT[iatr].nExons;
@@ -519,8 +519,9 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                                   OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
-                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order) const {
+                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order, bool dry) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
+    const bool samOff = this->samOff || dry;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];

@@ -188,8 +188,29 @@ struct Runner {
         const bool unm = P.outReadsUnmappedFastx && !pass1;
         std::vector<std::array<std::string, 2> > unms(unm ? T : 0);
         const bool randomOrder = P.outMultimapperRandom;
-        if (randomOrder) post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder);
         uint32_t per = (bt.n + T - 1) / T;
+        if (randomOrder) {
+            // with TranscriptomeSAM the shuffles of a read and its draw of the primary transcriptomic alignment alternate in one random stream: the
+            // number of transcriptomic alignments of every read is needed first (it does not depend on the order), so the quantification runs
+            // once into throw-away buffers, then all draws of the batch are made in read order, then the batch is formatted for real
+            std::vector<uint32_t> nAlignT;
+            if (trSAM) {
+                nAlignT.assign(bt.n, 0);
+                auto count = [&](uint32_t t) {
+                    uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
+                    std::string sam0, q0; OutSJ sj0, sj10; Stats st0; std::vector<uint32_t> held0; std::vector<QuantPatch> qp0;
+                    const bool samOff0 = post->samOff;
+                    (void)samOff0;
+                    errs[t] = post->processRange(bt, *r, lo, hi, sam0, sj0, st0, stage1 ? &sj10 : nullptr, stage1 ? &held0 : nullptr, nullptr, nullptr, nullptr, nullptr, &q0, &qp0, nullptr, true);
+                    for (const QuantPatch &p : qp0) nAlignT[p.ir] = p.nAlignT + 1;
+                };
+                std::vector<std::thread> th;
+                for (uint32_t t = 1; t < T; t++) th.emplace_back(count, t);
+                count(0);
+                for (auto &x : th) x.join();
+            }
+            post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder, trSAM ? &nAlignT : nullptr);
+        }
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
             o.sams[t].clear();
@@ -224,7 +245,7 @@ struct Runner {
             // the flag is patched into the records (FLAG is the high half of the 5th word), then the text is compressed and written
             for (uint32_t t = 0; t < T; t++) {
                 for (const QuantPatch &qp : qpatches[t]) {
-                    uint32_t pick = (uint32_t)(int)(rngUniformReal0to1(rngMultOrder) * qp.nAlignT);
+                    uint32_t pick = randomOrder ? multOrder.quantPick[qp.ir] : (uint32_t)(int)(rngUniformReal0to1(rngMultOrder) * qp.nAlignT);
                     for (size_t k = 0; k < qp.recOffset.size(); k++) {
                         uint8_t &hi = (uint8_t &)qraws[t][qp.recOffset[k] + 19];
                         if (qp.recAlign[k] == pick) hi &= (uint8_t)~1u; else hi |= 1u;

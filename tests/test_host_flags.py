@@ -189,6 +189,27 @@ def test_random_order_in_bam(tmp_path, built):
     assert open(ref + "ReadsPerGene.out.tab", "rb").read() == open(new + "ReadsPerGene.out.tab", "rb").read()
 
 
+@pytest.mark.parametrize("paired,more", [(True, []), (False, ["--outFilterType", "BySJout"]), (True, ["--twopassMode", "Basic", "--runThreadN", "3", "--outSAMmultNmax", "2"])])
+def test_random_order_with_transcriptome_bam(paired, more, tmp_path, built):
+    """Random order + --quantMode TranscriptomeSAM: the shuffles of a read and its draw of the primary transcriptomic alignment alternate in
+    one random stream; Aligned.toTranscriptome.out.bam and the SAM must still equal the reference's 1-thread run"""
+    info = _multicopy(tmp_path, paired)
+    d = os.path.dirname(info["fastq"][0])
+    info["extra"] = ["--outMultimapperOrder", "Random", "--quantMode", "TranscriptomeSAM", "GeneCounts", "--outFilterMultimapScoreRange", "3"] + more
+    rf = list(info["extra"])
+    if "--runThreadN" in rf:
+        k = rf.index("--runThreadN"); del rf[k:k + 2]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refRT_"), threads=1, extra=rf)
+    new = run_with_engine(info, os.path.join(d, "newRT_"), _oracle, batch_reads=1500)
+    a, b = _body(ref + "Aligned.out.sam"), _body(new + "Aligned.out.sam")
+    if "BySJout" in more:
+        a, b = sorted(a), sorted(b)
+    assert a == b
+    (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + "Aligned.toTranscriptome.out.bam"), bam_parts(new + "Aligned.toTranscriptome.out.bam")
+    assert ta == tb and ra == rb and rr == nr and len(rr) > 500
+    assert open(ref + "ReadsPerGene.out.tab", "rb").read() == open(new + "ReadsPerGene.out.tab", "rb").read()
+
+
 @pytest.mark.parametrize("mode", ["sam", "bam_unsorted", "bam_sorted", "sam_random"])
 def test_keep_pairs(mode, tmp_path, built):
     """--outSAMunmapped Within KeepPairs: the unmapped mate follows every one-mate alignment of a multimapper (secondary where the alignment is);
