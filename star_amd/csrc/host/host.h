@@ -38,6 +38,8 @@ struct ChimParams {
     int scoreMin = 0, scoreDropMax = 20, scoreSeparation = 10, scoreJunctionNonGTAG = -1;
     bool filterGenomicN = true;
     int outJunctionFormat = 0;
+    uint64_t multimapNmax = 0, multimapScoreRange = 1, nonchimScoreDropMin = 20;   // --chimMultimapNmax > 0: the multimapping algorithm
+    bool outJunctions = true, outBam = false, bamHardClip = true;                   // --chimOutType Junctions | WithinBAM [HardClip | SoftClip]
 };
 
 struct RunParams {
@@ -241,12 +243,19 @@ struct BamKey { uint64_t g, r; uint64_t off; uint32_t len; uint32_t chunk; };
 
 struct ReadBatch;
 // chimeric.cpp: ReadAlign::chimericDetectionOld + the Chimeric.out.junction line; true = a chimeric alignment was recorded
+// one segment of a chimeric alignment: a copy of the alignment whose block next to the chimeric junction was cut / extended to it
+struct ChimTr { staramd_transcript t; staramd_exon ex[STARAMD_MAX_N_EXONS]; };
+struct ChimPair { ChimTr a1, a2; bool best; };   // the two segments, in read order; best = the top-scoring chimera of the read (the primary one in the BAM)
 bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r,
-                          const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out);
+                          const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out,
+                          std::vector<ChimPair> *bamOut = nullptr);
 
 // --outMultimapperOrder Random: the swap partners of the two Fisher-Yates shuffles of every multimapping read of a batch, drawn in read
 // order from the run's one random stream before the batch is formatted on threads (ReadAlign_multMapSelect.cpp:71-80)
 struct MultOrder { std::vector<uint64_t> offset; std::vector<uint32_t> partner; std::vector<uint32_t> quantPick; };
+
+bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r, const staramd_transcript *trBest, std::string &out,
+                           std::vector<ChimPair> *bamOut = nullptr);
 
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {

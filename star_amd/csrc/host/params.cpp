@@ -170,8 +170,8 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMattributes") {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
-            else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC"}; attrHasCh = true; }   // + ch (Parameters_samAttributes.cpp:51-52)
-            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG") outSAMattrOrder.push_back(t); else if (t == "ch") attrHasCh = true; else err = "EXITING: unsupported SAM attribute " + t; } }
+            else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC", "ch"}; }   // + ch (Parameters_samAttributes.cpp:51-52)
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG" || t == "ch") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
@@ -206,8 +206,17 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "chimSegmentReadGapMax") chim.segmentReadGapMax = U(k, v);
         else if (k == "chimMainSegmentMultNmax") chim.mainSegmentMultNmax = U(k, v);
         else if (k == "chimOutJunctionFormat") chim.outJunctionFormat = (int)I(k, v);
-        else if (k == "chimMultimapNmax") { if (U(k, v) != 0) err = "EXITING: --chimMultimapNmax > 0 (the multimapping chimeric detection) is not implemented; only the default 0"; }
-        else if (k == "chimOutType") { for (auto &t : v) if (t != "Junctions") err = "EXITING: only --chimOutType Junctions is implemented (Chimeric.out.junction)"; }
+        else if (k == "chimMultimapNmax") chim.multimapNmax = U(k, v);
+        else if (k == "chimMultimapScoreRange") chim.multimapScoreRange = U(k, v);
+        else if (k == "chimNonchimScoreDropMin") chim.nonchimScoreDropMin = U(k, v);
+        else if (k == "chimOutType") {          // ParametersChimeric_initialize.cpp:20-37
+            chim.outJunctions = false;
+            for (auto &t : v) {
+                if (t == "Junctions") chim.outJunctions = true; else if (t == "WithinBAM") chim.outBam = true; else if (t == "HardClip") chim.bamHardClip = true; else if (t == "SoftClip") chim.bamHardClip = false;
+                else if (t == "SeparateSAMold") err = "EXITING: --chimOutType SeparateSAMold (Chimeric.out.sam) is not implemented; use Junctions and / or WithinBAM";
+                else err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --chimOutType: " + t + "\nSOLUTION: re-run STAR with --chimOutType Junctions , SeparateSAMold  , WithinBAM , HardClip \n";
+            }
+        }
         else if (k == "chimFilter") {
             chim.filterGenomicN = false;
             for (auto &t : v) { if (t == "banGenomicN") chim.filterGenomicN = true; else if (t != "None") err = "EXITING because of fatal PARAMETERS error: unrecognized value of --chimFilter=" + t + "\nSOLUTION: use allowed values: banGenomicN || None"; }
@@ -351,6 +360,12 @@ std::string RunParams::parse(int argc, char **argv) {
     }
     if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
+    attrHasCh = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "ch") != outSAMattrOrder.end();
+    if (chim.segmentMin > 0 && chim.outBam) {               // ParametersChimeric_initialize.cpp:76-101
+        if (!outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETERS error: --chimOutType WithinBAM requires BAM output\nSOLUTION: re-run with --outSAMtype BAM Unsorted/SortedByCoordinate\n";
+        if (std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") == outSAMattrOrder.end()) outSAMattrOrder.push_back("NM");
+    }
+    if (chim.segmentMin == 0) { chim.outBam = false; chim.outJunctions = false; }
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     outSAMattrOrderQuant = {"NH", "HI"};
     for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC") outSAMattrOrderQuant.push_back(a);

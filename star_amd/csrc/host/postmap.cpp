@@ -229,7 +229,9 @@ inline uint8_t nuclToNumBAM(char c) {                    // SequenceFuns.cpp:99-
 }
 // tail of a record: name, CIGAR, packed sequence, qualities, attributes (:547-590); the 9 core words come first
 void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, const std::vector<uint32_t> &cigar, std::string_view seq, std::string_view qual, bool rev,
-               bool noQS, const std::string &attr) {
+               bool noQS, const std::string &attr, size_t hardL = 0, size_t hardR = 0) {
+    if (rev) std::swap(hardL, hardR);                    // hard clips are counted on the sequence as it is written (ReadAlign_alignBAM.cpp:503-510)
+    seq = seq.substr(hardL, seq.size() - hardL - hardR); qual = qual.substr(hardL, qual.size() - hardL - hardR);
     size_t L = seq.size();
     uint32_t recSize = 8 * 4 + (uint32_t)name.size() + 1 + (uint32_t)cigar.size() * 4 + (uint32_t)(L + 1) / 2 + (uint32_t)L + (uint32_t)attr.size();
     put32(out, recSize);
@@ -247,8 +249,13 @@ void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, 
 
 // mapped mates of one alignment (alignType -1)
 // quant = a projection onto a transcript (ReadAlign_quantTranscriptome.cpp:71-76): coordinates start at 0, attributes NH HI (+ RG, MC)
+// chim (--chimOutType WithinBAM): a segment of a chimeric alignment; alignType -10 = the representative one, -11 / -12 = supplementary with the hard clip on
+// the left / right, -13 = supplementary with soft clips; mateChr (> nChrReal: none), mateStart (0-based in the chromosome), mateStrand describe the other segment
+struct ChimBam { int alignType; uint32_t mateChr, mateStart; uint8_t mateStrand; };
 static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, std::vector<BamKey> *keys,
-                      bool quant = false, std::vector<uint64_t> *recOffsets = nullptr) {
+                      bool quant = false, std::vector<uint64_t> *recOffsets = nullptr, const ChimBam *chim = nullptr) {
+    const int alignType = chim ? chim->alignType : -1;
+    const uint32_t mateChr = chim ? chim->mateChr : (uint32_t)-1;
     const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     const bool flagPaired = rc.nMates == 2;
@@ -260,6 +267,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     // CIGAR strings of both mates for MC (calcCIGAR)
     std::string matesCIGAR[2];
     std::vector<uint32_t> packed[2]; std::vector<int32_t> SJintron[2]; std::vector<char> SJmotif[2];
+    uint64_t hardClip[2][2];
     for (uint32_t imate = 0; imate < nMates; imate++) {
         uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
         uint32_t Mate = ex[iEx1].iFrag;
@@ -267,7 +275,8 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         auto op = [&](uint64_t len, char c, uint32_t code, bool inString) { pc.push_back((uint32_t)len << 4 | code); if (inString) { appendUint(cg, len); cg.push_back(c); } };
         const uint64_t trimL = rc.trimL(Str, Mate);
         uint64_t trimL1 = trimL + ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
-        if (trimL1 > 0) op(trimL1, 'S', 4, true);
+        hardClip[imate][0] = hardClip[imate][1] = 0;
+        if (trimL1 > 0) { op(trimL1, 'S', 4, true); if (alignType == -11) { pc.back() = (uint32_t)trimL1 << 4 | 5; hardClip[imate][0] = trimL1; } }     // H in the record, S in the MC string of calcCIGAR
         for (uint32_t ii = iEx1; ii <= iEx2; ii++) {
             if (ii > iEx1) {
                 uint64_t gapG = ex[ii].G - (ex[ii - 1].G + ex[ii - 1].L);
@@ -285,18 +294,19 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         }
         if (SJmotif[imate].empty()) { SJmotif[imate].push_back(-1); SJintron[imate].push_back(-1); }
         uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLengthOriginal[leftMate] : rc.readLength[leftMate] + 1 + rc.readLengthOriginal[Mate]) - ex[iEx2].R - ex[iEx2].L - trimL;
-        if (trimR1 > 0) op(trimR1, 'S', 4, true);
+        if (trimR1 > 0) { op(trimR1, 'S', 4, true); if (alignType == -12) { pc.back() = (uint32_t)trimR1 << 4 | 5; hardClip[imate][1] = trimR1; } }
     }
     for (uint32_t imate = 0; imate < nMates; imate++) {
         uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
         uint32_t Mate = ex[iEx1].iFrag;
         uint32_t samFLAG = 0;
-        if (flagPaired) { samFLAG = 0x0001; if (iExMate == nEx - 1) samFLAG |= 0x0008; else samFLAG |= 0x0002; }     // mateChr == (uint)-1 > nChrReal
+        if (flagPaired) { samFLAG = 0x0001; if (iExMate == nEx - 1) { if (mateChr > gi.view.nChrReal) samFLAG |= 0x0008; } else samFLAG |= 0x0002; }     // without a chimeric mate: (uint)-1 > nChrReal
         if (b.filter[ir] == 'Y') samFLAG |= 0x200;
+        if (alignType == -11 || alignType == -12 || alignType == -13) samFLAG |= 0x800;
         if (!tv.primary) samFLAG |= 0x100;
         if (Mate == 0) { samFLAG |= Str * 0x10; if (nMates == 2) samFLAG |= (1 - Str) * 0x20; }
         else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
-        if (flagPaired) samFLAG |= (Mate == 0 ? 0x0040 : 0x0080);
+        if (flagPaired) { samFLAG |= (Mate == 0 ? 0x0040 : 0x0080); if (nMates == 1 && chim && chim->mateStrand == 1) samFLAG |= 0x20; }
         int MAPQ = P.outSAMmapqUnique;
         if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
         // NM / MD of the BAM path (samAttrNM_MD :8-47): insertions of every gap and deletions of every non-junction gap count
@@ -339,13 +349,14 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "MD") attrStr(attr, "MD", tagMD);
             else if (a == "MC") { if (nMates > 1) attrStr(attr, "MC", matesCIGAR[1 - imate]); }
             else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
+            else if (a == "ch") { if (alignType <= -10) attrChar(attr, "ch", '1'); }
         }
         uint32_t core[8];
         core[0] = t.Chr;
         core[1] = (uint32_t)(ex[iEx1].G - chrS);
         core[2] = ((uint32_t)reg2bin((int)(ex[iEx1].G - chrS), (int)(ex[iEx2].G + ex[iEx2].L - chrS)) << 16) | ((uint32_t)MAPQ << 8) | (uint32_t)(b.name(ir).size() + 1);
         core[3] = (((samFLAG & P.outSAMflagAND) | P.outSAMflagOR) << 16) | (uint32_t)packed[imate].size();
-        core[4] = (uint32_t)b.seq((int)Mate, ir).size();
+        core[4] = (uint32_t)(b.seq((int)Mate, ir).size() - hardClip[imate][0] - hardClip[imate][1]);
         if (nMates > 1) {
             core[5] = t.Chr; core[6] = (uint32_t)(ex[imate == 0 ? iExMate + 1 : 0].G - chrS);
             int32_t tlen = (int32_t)(ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);                 // outSAMtlen 1
@@ -353,12 +364,105 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
                 tlen = (int32_t)(std::max(ex[nEx - 1].G + ex[nEx - 1].L, ex[iExMate].G + ex[iExMate].L) - std::min(ex[0].G, ex[iExMate + 1].G));
                 core[7] = (uint32_t)(imate == (ex[0].G <= ex[iExMate + 1].G ? 0u : 1u) ? tlen : -tlen);
             } else core[7] = (uint32_t)(imate == 0 ? tlen : -tlen);
-        } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
+        } else if (mateChr < gi.view.nChrReal) { core[5] = mateChr; core[6] = chim->mateStart; core[7] = 0; }
+        else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
         const size_t off0 = out.size();
         if (recOffsets) recOffsets->push_back(off0);
-        bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr);
-        // BAMoutput::coordOneAlign key (ReadAlign_outputAlignments.cpp:196-199): iReadAll << 32 | iTr << 8 | mate of the first exon
-        if (keys) keys->push_back(BamKey{((uint64_t)core[0] << 32) | core[1], (b.readIndex(ir) << 32) | (iTrOut << 8) | ex[0].iFrag, off0, (uint32_t)(out.size() - off0), 0});
+        bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr, hardClip[imate][0], hardClip[imate][1]);
+        // BAMoutput::coordOneAlign key (ReadAlign_outputAlignments.cpp:196-199): iReadAll << 32 | iTr << 8 | mate of the first exon; chimeric segments: iReadAll << 32
+        if (keys && !chim) keys->push_back(BamKey{((uint64_t)core[0] << 32) | core[1], (b.readIndex(ir) << 32) | (iTrOut << 8) | ex[0].iFrag, off0, (uint32_t)(out.size() - off0), 0});
+    }
+}
+
+// ChimericAlign::chimericBAMoutput (ChimericAlign_chimericBAMoutput.cpp:7-105): the two segments of a chimeric alignment as BAM records.  The segment
+// that holds both mates (or, for single-end reads, the better one) is the representative alignment, the other one is supplementary (0x800, hard- or
+// soft-clipped); two one-mate segments are written as an ordinary, if distant, pair.  The chimerically split mate and the supplementary record point at
+// each other through SA tags.
+static uint32_t rd32(const char *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static std::string saTagOf(const GenomeIndex &gi, const char *rec) {
+    const uint32_t tid = rd32(rec + 4), pos = rd32(rec + 8), bmn = rd32(rec + 12), fnc = rd32(rec + 16), lseq = rd32(rec + 20), recSize = rd32(rec);
+    const uint32_t lname = bmn & 0xff, mapq = (bmn >> 8) & 0xff, ncig = fnc & 0xffff, flag = fnc >> 16;
+    const char *cig = rec + 36 + lname;
+    std::string s = "SAZ" + gi.chrName[tid] + ","; appendUint(s, (uint64_t)pos + 1); s.push_back(','); s.push_back((flag & 0x10) == 0 ? '+' : '-'); s.push_back(',');
+    for (uint32_t k = 0; k < ncig; k++) { uint32_t c = rd32(cig + 4 * k); appendUint(s, c >> 4); s.push_back("MIDNSHP=X"[c & 0xf]); }
+    s.push_back(','); appendUint(s, mapq); s.push_back(',');
+    // NM of that record (bam_aux_get + bam_aux2i)
+    const char *a = cig + 4 * ncig + (lseq + 1) / 2 + lseq, *end = rec + 4 + recSize;
+    int64_t nm = 0;
+    while (a + 3 <= end) {
+        const char t = a[2]; const bool isNM = a[0] == 'N' && a[1] == 'M';
+        a += 3;
+        size_t w = 0;
+        switch (t) {
+            case 'A': case 'c': case 'C': w = 1; break;
+            case 's': case 'S': w = 2; break;
+            case 'i': case 'I': case 'f': w = 4; break;
+            case 'Z': case 'H': w = strlen(a) + 1; break;
+            case 'B': { const char bt = a[0]; const uint32_t n = rd32(a + 1); w = 5 + (size_t)n * (bt == 'c' || bt == 'C' ? 1 : bt == 's' || bt == 'S' ? 2 : 4); break; }
+            default: w = (size_t)(end - a); break;
+        }
+        if (isNM) {
+            if (t == 'c') nm = (int8_t)a[0]; else if (t == 'C') nm = (uint8_t)a[0];
+            else if (t == 's') { int16_t v; memcpy(&v, a, 2); nm = v; } else if (t == 'S') { uint16_t v; memcpy(&v, a, 2); nm = v; }
+            else if (t == 'i') { int32_t v; memcpy(&v, a, 4); nm = v; } else if (t == 'I') { uint32_t v; memcpy(&v, a, 4); nm = v; }
+            break;
+        }
+        a += w;
+    }
+    appendUint(s, (uint64_t)(uint32_t)nm); s.push_back(';');
+    return s;
+}
+static void chimBamOutput(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const ChimPair &cp, uint64_t iTr, uint64_t chimN, std::vector<BamKey> *keys) {
+    const ChimTr *trChim[2] = {&cp.a1, &cp.a2};
+    auto frag0 = [&](int i) { return trChim[i]->ex[0].iFrag; };
+    auto fragN = [&](int i) { return trChim[i]->ex[trChim[i]->t.nExons - 1].iFrag; };
+    int chimRepresent, chimType;
+    if (frag0(0) != fragN(0)) { chimRepresent = 0; chimType = 1; }
+    else if (frag0(1) != fragN(1)) { chimRepresent = 1; chimType = 1; }
+    else if (frag0(0) != frag0(1)) { chimRepresent = -1; chimType = 2; }
+    else { chimRepresent = trChim[0]->t.maxScore > trChim[1]->t.maxScore ? 0 : 1; chimType = 3; }
+    std::vector<std::string> recs;                       // one BAM record each, in the order of production
+    int bamIsuppl = -1, bamIrepr = -1;
+    for (int itr = 0; itr < 2; itr++) {
+        ChimBam cb; uint64_t mateStartG = 0;
+        if (chimType == 2) {
+            cb.mateChr = trChim[1 - itr]->t.Chr; mateStartG = trChim[1 - itr]->ex[0].G; cb.mateStrand = (uint8_t)(trChim[1 - itr]->t.Str != trChim[1 - itr]->ex[0].iFrag); cb.alignType = -10;
+        } else {
+            cb.mateChr = (uint32_t)-1; cb.mateStrand = 0;
+            if (chimRepresent == itr) {
+                cb.alignType = -10;
+                bamIrepr = (int)recs.size();
+                if (frag0(itr) != frag0(1 - itr)) ++bamIrepr;           // the next mate is the chimerically split one
+            } else {
+                cb.alignType = P.chim.bamHardClip ? ((uint32_t)(itr % 2) == trChim[itr]->t.Str ? -12 : -11) : -13;
+                bamIsuppl = (int)recs.size();
+                if (chimType == 1) {                                 // the supplementary record of a paired read points at the other mate in the representative alignment
+                    const ChimTr &rp = *trChim[chimRepresent];
+                    uint32_t iex = 0;
+                    for (; iex + 1 < rp.t.nExons; iex++) if (rp.ex[iex].iFrag != frag0(itr)) break;
+                    cb.mateChr = rp.t.Chr; mateStartG = rp.ex[iex].G; cb.mateStrand = (uint8_t)(rp.t.Str != rp.ex[iex].iFrag);
+                }
+            }
+        }
+        cb.mateStart = (uint32_t)(mateStartG - gi.chrStart[cb.mateChr < gi.view.nChrReal ? cb.mateChr : 0]);
+        if (!(cb.mateChr < gi.view.nChrReal)) cb.mateStart = (uint32_t)((uint64_t)-1 - gi.chrStart[0]);
+        TrView v; v.t = &trChim[itr]->t; v.ex = trChim[itr]->ex; v.primary = cp.best;
+        std::string raw; std::vector<uint64_t> offs;
+        bamMapped(raw, P, gi, rc, v, chimN, iTr, nullptr, false, &offs, &cb);
+        for (size_t k = 0; k < offs.size(); k++) recs.push_back(raw.substr(offs[k], (k + 1 < offs.size() ? offs[k + 1] : raw.size()) - offs[k]));
+    }
+    const std::vector<std::string> plain = recs;
+    for (int ii = 0; ii < (int)recs.size(); ii++) {
+        int tagI = -1;
+        if (ii == bamIrepr) tagI = bamIsuppl; else if (ii == bamIsuppl) tagI = bamIrepr;
+        if (tagI >= 0) {
+            std::string sa = saTagOf(gi, plain[tagI].data());
+            recs[ii] += sa; recs[ii].push_back(0);
+            uint32_t sz = (uint32_t)recs[ii].size() - 4; memcpy(&recs[ii][0], &sz, 4);
+        }
+        const size_t off0 = out.size();
+        out += recs[ii];
+        if (keys) keys->push_back(BamKey{((uint64_t)rd32(recs[ii].data() + 4) << 32) | rd32(recs[ii].data() + 8), rc.b->readIndex(rc.i) << 32, off0, (uint32_t)recs[ii].size(), 0});
     }
 }
 
@@ -574,8 +678,18 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         else if ((trBest->nMM > b.mmMaxTotal[ir]) || (double(trBest->nMM) / double(trBest->rLength) > P.dev.outFilterMismatchNoverLmax)) { st.unmappedMismatch++; unmapType = 2; }
         else if (nTr > P.outFilterMultimapNmax) { st.unmappedMulti++; unmapType = 3; }
         // ---- chimericDetection (ReadAlign_oneRead.cpp:95-97; not in the 2nd stage of BySJout, ReadAlign_chimericDetection.cpp:23)
-        if (chimJunction && nW > 0 && P.dev.outFilterBySJoutStage <= 1)
-            if (chimericDetectionOld(P, gi, b, ir, r, trBest, nTr, nTr > 0 ? trMult[0].t : nullptr, nTr > 1 ? trMult[1].t : nullptr, *chimJunction)) st.chimericAll++;
+        if (chimJunction && nW > 0 && P.dev.outFilterBySJoutStage <= 1) {
+            bool chimRecord = false;
+            std::vector<ChimPair> chimPairs, *cpp = P.chim.outBam ? &chimPairs : nullptr;
+            if (P.chim.multimapNmax == 0) chimRecord = chimericDetectionOld(P, gi, b, ir, r, trBest, nTr, nTr > 0 ? trMult[0].t : nullptr, nTr > 1 ? trMult[1].t : nullptr, *chimJunction, cpp);
+            else if (trBest->maxScore <= (int)(rc.readLength[0] + rc.readLength[1]) - (int)P.chim.nonchimScoreDropMin)       // ReadAlign_chimericDetection.cpp:48
+                chimRecord = chimericDetectionMult(P, gi, b, ir, r, trBest, *chimJunction, cpp);
+            if (chimRecord) st.chimericAll++;
+            if (chimRecord && P.chim.outBam) {          // the chimera stands for the read in the BAM: nothing else is output or counted for it (ReadAlign_oneRead.cpp:99-101)
+                if (!samOff) for (size_t k = 0; k < chimPairs.size(); k++) chimBamOutput(sam, P, gi, rc, chimPairs[k], k, chimPairs.size(), bamKeys);
+                continue;
+            }
+        }
         // ---- outFilterBySJout, 1st stage (ReadAlign_outputAlignments.cpp:90-124)
         if (sj1 && unmapType <= 0) {
             bool pass = true;

@@ -105,10 +105,13 @@ struct Runner {
             P.dev.chimSegmentMinPositive = 0;                       // twoPassRunPass1.cpp:24 (restored with the index re-upload after the pass)
             if (P.twopass1readsN >= 0) P.readMapNumber = P.readMapNumber < 0 ? P.twopass1readsN : std::min(P.readMapNumber, P.twopass1readsN);
         }
-        if (P.chim.segmentMin > 0) {
+        if (P.chim.segmentMin > 0 && P.chim.outJunctions) {
             std::string cp = P.outFileNamePrefix + "Chimeric.out.junction";
             chimOut = fopen(cp.c_str(), "wb");
             if (!chimOut) { error = "EXITING because of fatal ERROR: could not create output file " + cp; return false; }
+            if (P.chim.multimapNmax > 0)                            // column names of the multimapping algorithm's table (ParametersChimeric_initialize.cpp:48-72)
+                fputs("chr_donorA\tbrkpt_donorA\tstrand_donorA\tchr_acceptorB\tbrkpt_acceptorB\tstrand_acceptorB\tjunction_type\trepeat_left_lenA\trepeat_right_lenB\tread_name\t"
+                      "start_alnA\tcigar_alnA\tstart_alnB\tcigar_alnB\tnum_chim_aln\tmax_poss_aln_score\tnon_chim_aln_score\tthis_chim_aln_score\tbestall_chim_aln_score\tPEmerged_bool\treadgrp\n", chimOut);
         }
         if (P.outReadsUnmappedFastx)
             for (uint32_t m = 0; m < P.dev.readNmates; m++) {

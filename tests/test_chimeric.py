@@ -18,6 +18,97 @@ CASES = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", 
          ("pe150_indel", ["--chimSegmentMin", "15", "--runThreadN", "3"]),
          ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMainSegmentMultNmax", "1"])]
 
+MULT = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--chimMultimapNmax", "10"]),
+        ("pe150_chim", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "8", "--chimOutJunctionFormat", "1", "--chimMultimapNmax", "20", "--chimMultimapScoreRange", "3",
+                        "--chimScoreJunctionNonGTAG", "-4", "--chimNonchimScoreDropMin", "10", "--alignSJstitchMismatchNmax", "5", "-1", "5", "5", "--outSAMattrRGline", "ID:GRPundef",
+                        "--alignInsertionFlush", "Right", "--alignSplicedMateMapLminOverLmate", "0", "--alignSplicedMateMapLmin", "30"]),      # STAR-Fusion's options (without mate merging)
+        ("se50", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--chimMultimapNmax", "5", "--chimFilter", "None", "--chimScoreDropMax", "30"]),
+        ("pe101", ["--chimSegmentMin", "12", "--chimMultimapNmax", "2", "--chimMultimapScoreRange", "0", "--outFilterType", "BySJout", "--twopassMode", "Basic"]),
+        ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMultimapNmax", "50", "--chimScoreMin", "1", "--chimScoreSeparation", "1",
+                          "--chimScoreJunctionNonGTAG", "0", "--chimSegmentReadGapMax", "3", "--runThreadN", "3"])]                     # Arriba's options (without mate merging)
+
+
+@pytest.mark.parametrize("name,more", MULT)
+def test_chimeric_multimapping_oracle(name, more, tmp_path, built):
+    """--chimMultimapNmax > 0: every pair of recorded alignments is a candidate, the junction is re-located and both sides re-scored; all chimeras
+    within --chimMultimapScoreRange of the best are reported (table with a header line and six more columns)"""
+    info = dict(prepare(name, str(tmp_path), need_ref=False))
+    info["extra"] = list(info["extra"]) + more
+    _compare(info, os.path.dirname(info["fastq"][0]), lambda g, p: oracle_lib.Oracle(g, p))
+
+
+@pytest.mark.parametrize("tag", ["pe", "se"])
+def test_chimeric_multimapping_stress_oracle(tag, tmp_path, built):
+    kw, flags = STRESS[tag]
+    d = str(tmp_path / tag)
+    info = synth.make_dataset(d, **kw)
+    info["idx"] = os.path.join(d, "idx")
+    refstar.genome_generate(info["fasta"], info["idx"], gtf=info["gtf"], sa_index_nbases=8, sjdb_overhang=100)
+    info["extra"] = flags + ["--chimMultimapNmax", "10", "--chimMultimapScoreRange", "2", "--chimNonchimScoreDropMin", "15"]
+    _compare(info, d, lambda g, p: oracle_lib.Oracle(g, p), min_lines=500)
+
+
+WITHIN = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--chimOutType", "WithinBAM"], "Unsorted"),
+          ("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--chimOutType", "Junctions", "WithinBAM", "SoftClip", "--outSAMattributes", "NH", "HI", "AS", "nM", "ch", "MC"], "SortedByCoordinate"),
+          ("pe150_chim", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "8", "--chimMultimapNmax", "20", "--chimMultimapScoreRange", "3", "--chimNonchimScoreDropMin", "10",
+                          "--chimOutType", "WithinBAM", "Junctions", "--outSAMunmapped", "Within"], "Unsorted"),
+          ("se50", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--chimOutType", "WithinBAM", "HardClip", "--outSAMattributes", "All"], "Unsorted"),
+          ("se50", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--chimMultimapNmax", "5", "--chimOutType", "WithinBAM", "SoftClip", "--chimScoreDropMax", "30"], "SortedByCoordinate"),
+          ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimOutType", "WithinBAM", "--outFilterType", "BySJout", "--quantMode", "GeneCounts"], "Unsorted")]
+
+
+def _within(info, d, kind, min_suppl):
+    from util import bam_parts
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refW_"), threads=1, extra=info["extra"])
+    new = run_with_engine(info, os.path.join(d, "newW_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=800)
+    f = "Aligned.out.bam" if kind == "Unsorted" else "Aligned.sortedByCoord.out.bam"
+    (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + f), bam_parts(new + f)
+    assert ra == rb
+    assert len(rr) == len(nr)
+    for x, y in zip(rr, nr):
+        assert x == y
+    flag = lambda rec: int.from_bytes(rec[18:20], "little")
+    n_chim = [int(l.split("|")[1]) for l in open(ref + "Log.final.out") if "Number of chimeric reads" in l][0]
+    print("chimeric reads %d, supplementary records %d, records with SA %d" % (n_chim, sum(1 for x in rr if flag(x) & 0x800), sum(1 for x in rr if b"SAZ" in x)))
+    assert n_chim >= min_suppl
+    assert open(ref + "SJ.out.tab", "rb").read() == open(new + "SJ.out.tab", "rb").read()
+    assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(new + "Log.final.out")
+    if "Junctions" in info["extra"]:
+        lines = lambda p: [l for l in open(p + "Chimeric.out.junction") if not l.startswith("# 2.7.11b")]
+        assert lines(ref) == lines(new)
+    else:
+        assert not os.path.exists(new + "Chimeric.out.junction")
+    if "GeneCounts" in info["extra"]:
+        assert open(ref + "ReadsPerGene.out.tab", "rb").read() == open(new + "ReadsPerGene.out.tab", "rb").read()
+
+
+@pytest.mark.parametrize("name,more,kind", WITHIN)
+def test_chimeric_within_bam(name, more, kind, tmp_path, built):
+    """--chimOutType WithinBAM: the chimera replaces the read's linear alignments in the BAM: representative + supplementary records (hard / soft clips,
+    0x800, mate fields of the other segment, SA tags both ways); nothing else is output or counted for such a read"""
+    info = dict(prepare(name, str(tmp_path), need_ref=False))
+    info["extra"] = [x for x in info["extra"]] + more + ["--outSAMtype", "BAM", kind]
+    if "--outSAMattributes" in more:          # the data set's own attribute list goes
+        k = info["extra"].index("--outSAMattributes")
+        if k < len(info["extra"]) - len(more) - 3:
+            j = k + 1
+            while j < len(info["extra"]) and not info["extra"][j].startswith("--"):
+                j += 1
+            del info["extra"][k:j]
+    _within(info, os.path.dirname(info["fastq"][0]), kind, 1)
+
+
+@pytest.mark.parametrize("tag", ["pe", "se"])
+@pytest.mark.parametrize("mult", [False, True])
+def test_chimeric_within_bam_stress(tag, mult, tmp_path, built):
+    info, d = _stress(tag, tmp_path)
+    info["extra"] = list(info["extra"]) + ["--chimOutType", "WithinBAM", "Junctions", "--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate"] + \
+        (["--chimMultimapNmax", "10", "--chimMultimapScoreRange", "2", "--chimNonchimScoreDropMin", "15"] if mult else [])
+    _within(info, d, "Unsorted", 300)
+    from util import bam_parts
+    assert bam_parts(d + "/refW_Aligned.sortedByCoord.out.bam")[1:] == bam_parts(d + "/newW_Aligned.sortedByCoord.out.bam")[1:]
+
+
 # data sets made of chimeras: mates from different loci (junction type -1) and reads whose halves come from different loci (types 0 / 1 / 2)
 STRESS = {"pe": (dict(seed=9, chr_lengths=(300000, 250000, 200000), n_tr=100, n_reads=3000, read_len=125, paired=True, sub_rate=0.005, chim_rate=0.6),
                  ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "10", "--chimScoreDropMax", "80", "--chimScoreSeparation", "1", "--chimSegmentReadGapMax", "5"]),
