@@ -144,6 +144,8 @@ def host_lib():
         L.sah_genome_load_seconds.restype = C.c_double; L.sah_genome_load_seconds.argtypes = [C.c_void_p]
         L.sah_next_batch.restype = C.c_int; L.sah_next_batch.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Batch)]
         L.sah_emit.restype = C.c_int; L.sah_emit.argtypes = [C.c_void_p, C.POINTER(Results)]
+        L.sah_merged_batch.restype = C.c_int; L.sah_merged_batch.argtypes = [C.c_void_p, C.POINTER(Batch)]
+        L.sah_emit_merged.restype = C.c_int; L.sah_emit_merged.argtypes = [C.c_void_p, C.POINTER(Results), C.POINTER(Results)]
         L.sah_finish.restype = C.c_int; L.sah_finish.argtypes = [C.c_void_p]
         L.sah_error.restype = C.c_char_p; L.sah_error.argtypes = [C.c_void_p]
         L.sah_destroy.restype = None; L.sah_destroy.argtypes = [C.c_void_p]
@@ -203,8 +205,16 @@ class HostRun:
             raise RuntimeError(self.L.sah_error(self.h).decode())
         return b if n > 0 else None
 
-    def emit(self, results):
-        if self.L.sah_emit(self.h, C.byref(results)) != 0:
+    def merged_batch(self):
+        """--peOverlapNbasesMin > 0: the pairs of the current batch whose mates overlap, merged into single reads (None when there are none).
+        Map it with the same engine and pass its results to emit() as `merged`."""
+        b = Batch()
+        n = self.L.sah_merged_batch(self.h, C.byref(b))
+        return b if n > 0 else None
+
+    def emit(self, results, merged=None):
+        rc = self.L.sah_emit(self.h, C.byref(results)) if merged is None else self.L.sah_emit_merged(self.h, C.byref(results), C.byref(merged))
+        if rc != 0:
             raise RuntimeError(self.L.sah_error(self.h).decode())
 
     def in_pass1(self):

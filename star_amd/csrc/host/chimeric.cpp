@@ -123,7 +123,8 @@ void shiftToJunction(GenomeAt &G, ChimTr &t0, ChimTr &t1, uint32_t e0, uint32_t 
     chimRepeat0 = jR;
 }
 // score of an alignment recomputed from its blocks (after the junction shift)
-int alignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, ChimTr &c) {
+} // namespace
+int chimAlignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, ChimTr &c) {
     int maxScore = 0; uint32_t nMM = 0;
     c.t.maxScore = 0; c.t.nMM = 0;
     const uint32_t ne = c.t.nExons;
@@ -156,15 +157,17 @@ int alignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Re
     c.t.maxScore = maxScore; c.t.nMM = nMM;
     return maxScore;
 }
+namespace {
 } // namespace
 
 // returns true when a chimeric alignment was recorded (Stats::chimericAll); the junction line is appended to `out`
-bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r,
+bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra,
                           const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out,
                           std::vector<ChimPair> *bamOut) {
     const ChimParams &C = P.chim;
-    const staramd_read_result &rr = r.reads[ir];
-    const staramd_transcript *T = r.tr + rr.trOffset;
+    const struct { uint32_t nTr; } rr = {ra.nTr};
+    const staramd_transcript *T = ra.T;
+    const struct { const staramd_exon *ex; } r = {ra.ex};
     const uint64_t Lread = b.readOffset[ir + 1] - b.readOffset[ir];
     const int nMates = (int)P.dev.readNmates;
     const uint64_t readLength[2] = {b.mate1Length[ir], nMates == 2 ? Lread - b.mate1Length[ir] - 1 : 0};
@@ -258,7 +261,7 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
         || (trChim[0].t.Str == 0 ? chimJ1 - chimJ0 + 1ull : chimJ0 - chimJ1 + 1ull) > (chimMotif >= 0 ? P.dev.alignIntronMax : P.dev.alignMatesGapMax)) {
         if (chimMotif >= 0 && (x0.L < C.junctionOverhangMin + chimRepeat0 || x1.L < C.junctionOverhangMin + chimRepeat1)) return false;
         if (bamOut) {                                                // chimericDetectionOldOutput :11-16: both segments re-scored, one chimera, the best by definition
-            alignScore(P.dev, gi, Read1, Lread, trChim[0]); alignScore(P.dev, gi, Read1, Lread, trChim[1]);
+            chimAlignScore(P.dev, gi, Read1, Lread, trChim[0]); chimAlignScore(P.dev, gi, Read1, Lread, trChim[1]);
             bamOut->push_back(ChimPair{trChim[0], trChim[1], true});
         }
         if (!C.outJunctions) return true;
@@ -295,13 +298,16 @@ struct ChimAlign { ChimTr a1, a2; uint64_t chimJ1, chimJ2, chimRepeat1, chimRepe
 
 } // namespace
 
-bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r, const staramd_transcript *trBest, std::string &out,
-                           std::vector<ChimPair> *bamOut) {
+bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra, const staramd_transcript *trBest, std::string &out,
+                           std::vector<ChimPair> *bamOut, const ReadBatch *nameBatch, uint32_t nameIr) {
     const ChimParams &C = P.chim;
-    const staramd_read_result &rr = r.reads[ir];
-    const staramd_transcript *T = r.tr + rr.trOffset;
+    const struct { uint32_t nTr; } rr = {ra.nTr};
+    const staramd_transcript *T = ra.T;
+    const struct { const staramd_exon *ex; } r = {ra.ex};
     const uint64_t Lread = b.readOffset[ir + 1] - b.readOffset[ir];
-    const int nMates = (int)P.dev.readNmates;
+    const bool merged = nameBatch != nullptr;                 // b holds merged mates: a single-end read as far as the detection goes
+    const int nMates = merged ? 1 : (int)P.dev.readNmates;
+    const ReadBatch &nb = merged ? *nameBatch : b; const uint32_t nir = merged ? nameIr : ir;
     const uint64_t readLength[2] = {b.mate1Length[ir], nMates == 2 ? Lread - b.mate1Length[ir] - 1 : 0};
     const uint8_t *Read1 = b.bases.data() + b.readOffset[ir];
     const int64_t nG = (int64_t)gi.G.size();
@@ -369,7 +375,7 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
             }
             if (alive) {
                 if (ca.chimMotif >= 0 && (x1.L < C.junctionOverhangMin || x2.L < C.junctionOverhangMin)) ca.chimScore = 0;   // a linear junction too close to the chimeric one
-                else ca.chimScore = alignScore(P.dev, gi, Read1, Lread, ca.a1) + alignScore(P.dev, gi, Read1, Lread, ca.a2) + (ca.chimMotif == 0 ? C.scoreJunctionNonGTAG : 0);
+                else ca.chimScore = chimAlignScore(P.dev, gi, Read1, Lread, ca.a1) + chimAlignScore(P.dev, gi, Read1, Lread, ca.a2) + (ca.chimMotif == 0 ? C.scoreJunctionNonGTAG : 0);
             }
             if (ca.chimScore >= minScoreToConsider) {
                 chimAligns.push_back(ca);
@@ -384,7 +390,7 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
     uint64_t chimN = 0;
     for (const ChimAlign &ca : chimAligns) if (ca.chimScore >= minScoreToConsider) ++chimN;
     if (chimN > C.multimapNmax) return false;
-    const uint64_t readLengthOriginal[2] = {b.seqSpan[0][ir].len, nMates == 2 ? (uint64_t)b.seqSpan[1][ir].len : 0};
+    const uint64_t readLengthOriginal[2] = {merged ? Lread : (uint64_t)b.seqSpan[0][ir].len, nMates == 2 ? (uint64_t)b.seqSpan[1][ir].len : 0};
     const uint64_t readLengthPair = nMates == 2 ? readLengthOriginal[0] + readLengthOriginal[1] + 1 : readLengthOriginal[0];
     const bool rgColumn = std::find(P.outSAMattrOrder.begin(), P.outSAMattrOrder.end(), "RG") != P.outSAMattrOrder.end();
     auto appendI = [&](int v) { if (v < 0) { out.push_back('-'); appendU(out, (uint64_t)(-(int64_t)v)); } else appendU(out, (uint64_t)v); };
@@ -396,12 +402,12 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
         const uint64_t c1 = gi.chrStart[ca.a1.t.Chr], c2 = gi.chrStart[ca.a2.t.Chr];
         out += gi.chrName[ca.a1.t.Chr]; out.push_back('\t'); appendU(out, ca.chimJ1 - c1 + 1); out.push_back('\t'); out.push_back(ca.a1.t.Str == 0 ? '+' : '-'); out.push_back('\t');
         out += gi.chrName[ca.a2.t.Chr]; out.push_back('\t'); appendU(out, ca.chimJ2 - c2 + 1); out.push_back('\t'); out.push_back(ca.a2.t.Str == 0 ? '+' : '-'); out.push_back('\t');
-        appendI(ca.chimMotif); out.push_back('\t'); appendU(out, ca.chimRepeat1); out.push_back('\t'); appendU(out, ca.chimRepeat2); out.push_back('\t'); out += b.name(ir);
+        appendI(ca.chimMotif); out.push_back('\t'); appendU(out, ca.chimRepeat1); out.push_back('\t'); appendU(out, ca.chimRepeat2); out.push_back('\t'); out += nb.name(nir);
         out.push_back('\t'); appendU(out, ca.a1.ex[0].G - c1 + 1); out.push_back('\t'); out += cigarP(ca.a1, readLengthOriginal, readLengthPair, nMates);
         out.push_back('\t'); appendU(out, ca.a2.ex[0].G - c2 + 1); out.push_back('\t'); out += cigarP(ca.a2, readLengthOriginal, readLengthPair, nMates);
         out.push_back('\t'); appendU(out, chimN); out.push_back('\t'); appendI(maxPossibleAlignScore); out.push_back('\t'); appendI(maxNonChimAlignScore);
-        out.push_back('\t'); appendI(ca.chimScore); out.push_back('\t'); appendI(chimScoreBest); out += "\t0";       // PEmerged_bool: mates are never merged here
-        if (rgColumn) { out.push_back('\t'); out += P.outSAMattrRG.at(b.fileIndex); }
+        out.push_back('\t'); appendI(ca.chimScore); out.push_back('\t'); appendI(chimScoreBest); out += merged ? "\t1" : "\t0";       // PEmerged_bool
+        if (rgColumn) { out.push_back('\t'); out += P.outSAMattrRG.at(nb.fileIndex); }
         out.push_back('\n');
     }
     return chimN > 0;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <array>
 #include <cstdio>
 #include <istream>
 #include <string_view>
@@ -107,6 +108,7 @@ struct RunParams {
     std::string readFilesPrefix, readFilesManifest;         // --readFilesPrefix, --readFilesManifest (Parameters_readFilesInit.cpp:41-139)
     std::vector<std::string> outSAMheaderHD, outSAMheaderPG; std::string outSAMheaderCommentFile;   // samHeaders.cpp:56-96
     bool runDirPermAll = false, genomeLoadShared = false;
+    uint32_t peOverlapNbasesMin = 0; double peOverlapMMp = 0.01;   // --peOverlapNbasesMin, --peOverlapMMp
     bool outSJnone = false;              // --outSJtype None
     int outQSconversionAdd = 0;          // --outQSconversionAdd (readLoad.cpp:71-82)
     bool outMultimapperRandom = false;   // --outMultimapperOrder Random (ReadAlign_multMapSelect.cpp:62-92)
@@ -142,6 +144,14 @@ struct ReadBatch {
     std::string_view qual(int m, uint32_t i) const { return std::string_view(text[m].data() + qualSpan[m][i].off, qualSpan[m][i].len); }
     staramd_batch view() const;
     void clear();
+};
+
+// --peOverlapNbasesMin > 0: the pairs of a batch whose mates overlap, merged into single-end reads that are mapped as a second batch
+// (ReadAlign::peMergeMates, ReadAlign_peOverlapMergeMap.cpp:77-134).  index[i] = position of pair i in `reads`, or -1
+struct MergedBatch {
+    ReadBatch reads;
+    std::vector<int32_t> index; std::vector<uint32_t> nOv; std::vector<std::array<uint32_t, 2> > mateStart;
+    void build(const ReadBatch &b, const RunParams &P);
 };
 
 class FastqReader {
@@ -246,7 +256,9 @@ struct ReadBatch;
 // one segment of a chimeric alignment: a copy of the alignment whose block next to the chimeric junction was cut / extended to it
 struct ChimTr { staramd_transcript t; staramd_exon ex[STARAMD_MAX_N_EXONS]; };
 struct ChimPair { ChimTr a1, a2; bool best; };   // the two segments, in read order; best = the top-scoring chimera of the read (the primary one in the BAM)
-bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r,
+// the recorded alignments of one read, window by window, best first in each: T[k].exonOffset indexes ex
+struct ReadAligns { const staramd_transcript *T; uint32_t nTr; const staramd_exon *ex; };
+bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra,
                           const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out,
                           std::vector<ChimPair> *bamOut = nullptr);
 
@@ -254,8 +266,11 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
 // order from the run's one random stream before the batch is formatted on threads (ReadAlign_multMapSelect.cpp:71-80)
 struct MultOrder { std::vector<uint64_t> offset; std::vector<uint32_t> partner; std::vector<uint32_t> quantPick; };
 
-bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const staramd_results &r, const staramd_transcript *trBest, std::string &out,
-                           std::vector<ChimPair> *bamOut = nullptr);
+// nameBatch / nameIr: where the read's name, read group and unclipped lengths come from when b holds merged mates (PEmerged_bool = 1)
+bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra, const staramd_transcript *trBest, std::string &out,
+                           std::vector<ChimPair> *bamOut = nullptr, const ReadBatch *nameBatch = nullptr, uint32_t nameIr = 0);
+// Transcript::alignScore: score and mismatches of an alignment recomputed from its blocks; Read1 = the read as mapped, Lread its length
+int chimAlignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, ChimTr &c);
 
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {
@@ -271,7 +286,8 @@ public:
                              std::string *unmappedFastx = nullptr,              // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
                              std::string *chimJunction = nullptr,               // Chimeric.out.junction lines (--chimSegmentMin > 0)
                              std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr,           // TranscriptomeSAM records
-                             const MultOrder *order = nullptr, bool dry = false) const;   // dry: no alignment records, only the side outputs asked for
+                             const MultOrder *order = nullptr, bool dry = false,
+                             const MergedBatch *merged = nullptr, const staramd_results *mergedRes = nullptr) const;   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
     // nAlignT (with --quantMode TranscriptomeSAM): per read, the number of transcriptomic alignments + 1 where the read draws its primary one
     // right after its shuffles (ReadAlign_quantTranscriptome.cpp:69), 0 where it does not
     template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr) const {

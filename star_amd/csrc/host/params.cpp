@@ -25,7 +25,7 @@ RunParams::RunParams() {
     dev.alignSJoverhangMin = 5; dev.alignSJDBoverhangMin = 3;
     dev.alignSJstitchMismatchNmax[0] = 0; dev.alignSJstitchMismatchNmax[1] = -1; dev.alignSJstitchMismatchNmax[2] = 0; dev.alignSJstitchMismatchNmax[3] = 0;
     dev.alignSplicedMateMapLmin = 0; dev.alignSplicedMateMapLminOverLmate = 0.66;
-    dev.alignEndsProtrudeNbasesMax = 0; dev.alignEndsProtrudeConcordantPair = 1;
+    dev.alignEndsProtrudeNbasesMax = 0; dev.alignEndsProtrudeConcordantPair = 0;
     dev.alignSoftClipAtReferenceEnds = 1; dev.alignInsertionFlushRight = 0;
     dev.outFilterIntronStrandsRemoveInconsistent = 1; dev.outFilterIntronMotifs = 0; dev.outSAMstrandFieldIntronMotif = 0;
     dev.chimSegmentMinPositive = 0; dev.outFilterBySJoutStage = 0;
@@ -152,6 +152,8 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMheaderCommentFile") { if (one(k, v) != "-") outSAMheaderCommentFile = one(k, v); }
         else if (k == "outSJtype") { const std::string &m = v[0]; if (m == "None") outSJnone = true; else if (m != "Standard") err = "EXITING because of FATAL input ERROR: unrecognized option in --outSJtype   " + m + "\nSOLUTION: use one of the allowed options: --outSJtype   Standard    OR    None\n"; }
         else if (k == "outQSconversionAdd") outQSconversionAdd = (int)I(k, v);
+        else if (k == "peOverlapNbasesMin") peOverlapNbasesMin = (uint32_t)U(k, v);
+        else if (k == "peOverlapMMp") peOverlapMMp = D(k, v);
         else if (k == "outMultimapperOrder") { const std::string &m = one(k, v); if (m == "Random") outMultimapperRandom = true; else if (m != "Old_2.4") err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --outMultimapperOrder: " + m + "\nSOLUTION: specify one of the allowed values: Old_2.4 or Random\n"; }
         else if (k == "outSAMorder") { const std::string &m = one(k, v); if (m != "Paired" && m != "PairedKeepInputOrder") err = "EXITING because of FATAL INPUT ERROR: unknown value for --outSAMorder: " + m; }   // batches are always written in input order here
         else if (k == "readMatesLengthsIn") { const std::string &m = one(k, v); if (m != "NotEqual" && m != "Equal") err = "EXITING: unknown value for --readMatesLengthsIn: " + m; }
@@ -286,7 +288,9 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "alignTranscriptsPerWindowNmax") dev.alignTranscriptsPerWindowNmax = (uint32_t)U(k, v);
         else if (k == "alignTranscriptsPerReadNmax") dev.alignTranscriptsPerReadNmax = (uint32_t)U(k, v);
         else if (k == "alignEndsType") alignEndsType = one(k, v);
-        else if (k == "alignEndsProtrude") { if (v.size() != 2) err = "EXITING: --alignEndsProtrude expects 2 values"; else { dev.alignEndsProtrudeNbasesMax = (int32_t)strtol(v[0].c_str(), nullptr, 10); dev.alignEndsProtrudeConcordantPair = v[1] == "ConcordantPair"; } }
+        else if (k == "alignEndsProtrude") { if (v.size() != 2) err = "EXITING: --alignEndsProtrude expects 2 values"; else {   // Parameters.cpp:1084-1097: the pair type only counts when protrusion is allowed at all
+            dev.alignEndsProtrudeNbasesMax = (int32_t)strtol(v[0].c_str(), nullptr, 10); dev.alignEndsProtrudeConcordantPair = 0;
+            if (dev.alignEndsProtrudeNbasesMax > 0) { if (v[1] == "ConcordantPair") dev.alignEndsProtrudeConcordantPair = 1; else if (v[1] != "DiscordantPair") err = "EXITING because of fatal PARAMETERS error: unrecognized option in of --alignEndsProtrude=" + v[1] + "\nSOLUTION: use allowed option: ConcordantPair or DiscordantPair"; } } }
         else if (k == "alignSoftClipAtReferenceEnds") { const std::string &s = one(k, v); dev.alignSoftClipAtReferenceEnds = (s == "Yes"); if (s != "Yes" && s != "No") err = "EXITING: unsupported --alignSoftClipAtReferenceEnds " + s; }
         else if (k == "alignInsertionFlush") { const std::string &s = one(k, v); dev.alignInsertionFlushRight = (s == "Right"); if (s != "None" && s != "Right") err = "EXITING: unsupported --alignInsertionFlush " + s; }
         else if (k == "winAnchorMultimapNmax") dev.winAnchorMultimapNmax = (uint32_t)U(k, v);
@@ -358,6 +362,7 @@ std::string RunParams::parse(int argc, char **argv) {
         if (!outSAMattrRG.empty() && !hasRG && readFilesManifest.empty()) outSAMattrOrder.push_back("RG");   // only --outSAMattrRGline adds the attribute by itself (Parameters_samAttributes.cpp:201)
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
+    if (peOverlapNbasesMin > 0 && readFilesIn.size() == 2) dev.resultSelect = 0;          // every alignment of the merged mates is cut back into a pair and re-scored (ReadAlign_peOverlapMergeMap.cpp:279-296)
     if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
     attrHasCh = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "ch") != outSAMattrOrder.end();
@@ -366,6 +371,11 @@ std::string RunParams::parse(int argc, char **argv) {
         if (std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") == outSAMattrOrder.end()) outSAMattrOrder.push_back("NM");
     }
     if (chim.segmentMin == 0) { chim.outBam = false; chim.outJunctions = false; }
+    if (peOverlapNbasesMin > 0 && chim.segmentMin > 0) {
+        if (chim.multimapNmax == 0 && chim.outJunctions) return "EXITING because of fatal PARAMETERS error: --chimMultimapNmax 0 (default old chimeric detection) and --peOverlapNbasesMin > 0 (merging ovelrapping mates) presently only works with --chimOutType WithinBAM\nSOLUTION: re-run with --chimOutType WithinBAM\n";
+        if (chim.multimapNmax == 0) return "EXITING: --peOverlapNbasesMin > 0 with the default chimeric detection (--chimMultimapNmax 0) is not implemented; use --chimMultimapNmax > 0";
+        if (chim.outBam) return "EXITING: --peOverlapNbasesMin > 0 with --chimOutType WithinBAM is not implemented; use --chimOutType Junctions";
+    }
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     outSAMattrOrderQuant = {"NH", "HI"};
     for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC") outSAMattrOrderQuant.push_back(a);

@@ -543,6 +543,91 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
     }
 }
 
+// ---- merged mates back to a pair (--peOverlapNbasesMin) ----
+//   Transcript::peOverlapSEtoPE    source/ReadAlign_peOverlapMergeMap.cpp:136-265
+//   ReadAlign::peOverlapSEtoPE     source/ReadAlign_peOverlapMergeMap.cpp:267-307
+// An alignment of the merged read is cut into the blocks of mate 1 and of mate 2 (the overlap appears in both); scores are recomputed on the pair.
+// false = more than MAX_N_EXONS blocks, the alignment is dropped
+static bool mergedAlignToPair(ChimTr &o, const uint32_t mateStart[2], const staramd_transcript &t, const staramd_exon *tex, uint64_t tLread, const uint64_t readLength[2], uint64_t Lread) {
+    uint64_t mLen[2] = {readLength[t.Str], readLength[1 - t.Str]};
+    uint64_t mSta2[2] = {0, mLen[0] + 1};
+    uint64_t mSta[2] = {mateStart[0], mateStart[1]};
+    if (t.Str == 1) { for (int ii = 0; ii < 2; ii++) mSta[ii] = tLread - readLength[ii] - mSta[ii]; std::swap(mSta[0], mSta[1]); }
+    uint64_t mEnd[2] = {mSta[0] + mLen[0], mSta[1] + mLen[1]};
+    memset(&o, 0, sizeof(o));
+    uint32_t nExons = 0;
+    for (int imate = 0; imate < 2; imate++) {
+        for (uint32_t iex = 0; iex < t.nExons; iex++) {
+            const staramd_exon &e = tex[iex];
+            if (e.R >= mEnd[imate] || (uint64_t)e.R + e.L <= mSta[imate]) continue;
+            if (nExons >= STARAMD_MAX_N_EXONS) return false;
+            staramd_exon &x = o.ex[nExons];
+            x.iFrag = (uint8_t)(imate == 0 ? t.Str : 1 - t.Str);
+            x.sjA = e.sjA;
+            if (iex + 1 < t.nExons) { x.canonSJ = e.canonSJ; x.sjAnnot = e.sjAnnot; x.sjStr = e.sjStr; x.shiftSJ[0] = e.shiftSJ[0]; x.shiftSJ[1] = e.shiftSJ[1]; }
+            if (e.R >= mSta[imate]) { x.G = e.G; x.L = e.L; x.R = (uint16_t)(e.R - mSta[imate] + mSta2[imate]); }
+            else { x.R = (uint16_t)mSta2[imate]; uint64_t delta = mSta[imate] - e.R; x.L = (uint16_t)(e.L - delta); x.G = e.G + delta; }
+            if ((uint64_t)e.R + e.L > mEnd[imate]) x.L = (uint16_t)(x.L - ((uint64_t)e.R + e.L - mEnd[imate]));
+            ++nExons;
+        }
+        if (nExons > 0) { staramd_exon &x = o.ex[nExons - 1]; x.canonSJ = -3; x.sjAnnot = 0; x.sjStr = 0; x.shiftSJ[0] = x.shiftSJ[1] = 0; }
+    }
+    if (nExons == 0) return false;
+    staramd_transcript &a = o.t;
+    a.nExons = (uint16_t)nExons;
+    for (int ii = 0; ii < 3; ii++) a.intronMotifs[ii] = t.intronMotifs[ii];
+    a.sjMotifStrand = t.sjMotifStrand; a.Chr = t.Chr; a.Str = t.Str; a.roStr = t.roStr; a.gStart = t.gStart; a.gLength = t.gLength; a.iFrag = -1;
+    uint32_t rLength = 0;
+    for (uint32_t iex = 0; iex < nExons; iex++) rLength += o.ex[iex].L;
+    a.rLength = (uint16_t)rLength; a.mappedLength = rLength; a.rStart = o.ex[0].R;
+    a.roStart = (uint16_t)(a.roStr == 0 ? a.rStart : Lread - a.rStart - rLength);
+    a.nGap = t.nGap; a.lGap = t.lGap; a.nDel = t.nDel; a.nIns = t.nIns; a.lDel = t.nDel; a.lIns = t.lIns;      // lDel = nDel, as in the reference (:257)
+    a.nUnique = t.nUnique; a.nAnchor = t.nAnchor;
+    return true;
+}
+
+// all alignments of the merged read, window by window; the best of a window moves to its front.  Returns the index of the best one, -1 if nothing converted
+static int mergedReadToPair(const RunParams &P, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, const uint64_t readLength[2], const uint32_t mateStart[2],
+                            const ReadAligns &se, uint64_t seLread, std::vector<staramd_transcript> &T, std::vector<staramd_exon> &E, uint32_t &nW) {
+    T.clear(); E.clear(); nW = 0;
+    int best = -1; int64_t bestScore = -10 * (int64_t)Lread;
+    std::vector<ChimTr> win;
+    for (uint32_t k0 = 0; k0 < se.nTr;) {
+        uint32_t k1 = k0;
+        while (k1 < se.nTr && se.T[k1].iW == se.T[k0].iW) k1++;
+        win.clear();
+        for (uint32_t k = k0; k < k1; k++) {
+            ChimTr c;
+            if (!mergedAlignToPair(c, mateStart, se.T[k], se.ex + se.T[k].exonOffset, seLread, readLength, Lread)) continue;
+            chimAlignScore(P.dev, gi, Read1, Lread, c);
+            {   // nMatch of Transcript::alignScore (mappedFilter needs it)
+                uint32_t nMatch = 0;
+                for (uint32_t iex = 0; iex < c.t.nExons; iex++) for (uint32_t ii = 0; ii < c.ex[iex].L; ii++) {
+                    uint64_t rp = (uint64_t)c.ex[iex].R + ii;
+                    uint8_t r1 = c.t.roStr == 0 ? Read1[rp] : Read1[Lread - 1 - rp];
+                    if (c.t.roStr != 0 && r1 < 4) r1 = 3 - r1;
+                    if (r1 < 4 && r1 == gi.G[c.ex[iex].G + ii]) ++nMatch;
+                }
+                c.t.nMatch = nMatch;
+            }
+            win.push_back(c);
+            if (win.back().t.maxScore > win[0].t.maxScore) std::swap(win.back(), win[0]);
+        }
+        if (!win.empty()) {
+            for (ChimTr &c : win) {
+                c.t.iW = nW; c.t.exonOffset = (uint32_t)E.size();
+                E.insert(E.end(), c.ex, c.ex + c.t.nExons);
+                T.push_back(c.t);
+            }
+            const int head = (int)(T.size() - win.size());
+            if (T[head].maxScore > bestScore) { best = head; bestScore = T[head].maxScore; }
+            ++nW;
+        }
+        k0 = k1;
+    }
+    return best;
+}
+
 std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st) {
     return processRange(b, r, 0, b.n, sam, sj, st);
 }
@@ -623,8 +708,10 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                                   OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
-                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order, bool dry) const {
+                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order, bool dry,
+                                  const MergedBatch *merged, const staramd_results *mergedRes) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
+    std::vector<staramd_transcript> pairT; std::vector<staramd_exon> pairE;
     const bool samOff = this->samOff || dry;
     std::vector<TrView> trMult;
     for (uint32_t ir = lo; ir < hi; ir++) {
@@ -642,15 +729,38 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         }
         st.readN++; st.readBases += rc.readLength[0] + rc.readLength[1];
         const staramd_transcript *T = r.tr + rr.trOffset;
+        const staramd_exon *EX = r.ex;
+        uint32_t nTrAll = rr.nTr;
         uint64_t nW = rr.nW;
         const staramd_transcript *trBest = (nW > 0 && rr.trBest >= 0) ? T + rr.trBest : nullptr;
+        // ---- peOverlapMergeMap (ReadAlign_peOverlapMergeMap.cpp:4-75): where the merged mates mapped, their alignments, cut back into the two mates, replace the pair's
+        bool peOvYes = false, chimRecord = false;
+        std::vector<ChimPair> chimPairs, *cpp = (chimJunction && P.chim.outBam) ? &chimPairs : nullptr;
+        if (merged && merged->index[ir] >= 0 && mergedRes->reads[merged->index[ir]].nW > 0) {
+            const uint32_t mi = (uint32_t)merged->index[ir];
+            const staramd_read_result &mr = mergedRes->reads[mi];
+            const ReadAligns se{mergedRes->tr + mr.trOffset, mr.nTr, mergedRes->ex};
+            const uint64_t seLread = merged->reads.readOffset[mi + 1] - merged->reads.readOffset[mi];
+            const int peScore = trBest ? trBest->maxScore : 0;
+            uint32_t nWpair = 0;
+            const int best = mergedReadToPair(P, gi, b.bases.data() + b.readOffset[ir], rc.Lread, rc.readLength, merged->mateStart[ir].data(), se, seLread, pairT, pairE, nWpair);
+            T = pairT.data(); EX = pairE.data(); nTrAll = (uint32_t)pairT.size(); nW = nWpair;
+            trBest = best >= 0 ? T + best : nullptr;
+            if (chimJunction && P.dev.outFilterBySJoutStage <= 1 && P.chim.multimapNmax > 0                       // chimericDetectionPEmerged (ReadAlign_chimericDetectionPEmerged.cpp:27-32)
+                && (trBest ? trBest->maxScore : 0) <= (int)(rc.readLength[0] + rc.readLength[1]) - (int)P.chim.nonchimScoreDropMin) {
+                const staramd_transcript *seBest = mr.trBest >= 0 ? se.T + mr.trBest : nullptr;
+                if (seBest) chimRecord = chimericDetectionMult(P, gi, merged->reads, mi, se, seBest, *chimJunction, cpp, &b, ir);
+                if (chimRecord) st.chimericAll++;
+            }
+            if (peScore <= (trBest ? trBest->maxScore : 0) || chimRecord) peOvYes = true;
+        }
         // ---- multMapSelect
         trMult.clear();
         uint64_t nTr = 0;
         if (nW > 0) {
             int maxScore = trBest->maxScore;     // == max over windows' heads (asserted in the reference :20-24)
-            for (uint32_t k = 0; k < rr.nTr; k++)
-                if (T[k].maxScore + P.dev.outFilterMultimapScoreRange >= maxScore) { TrView v; v.t = T + k; v.ex = r.ex + T[k].exonOffset; v.primary = false; trMult.push_back(v); }
+            for (uint32_t k = 0; k < nTrAll; k++)
+                if (T[k].maxScore + P.dev.outFilterMultimapScoreRange >= maxScore) { TrView v; v.t = T + k; v.ex = EX + T[k].exonOffset; v.primary = false; trMult.push_back(v); }
             nTr = trMult.size();
             if (!(nTr > P.outFilterMultimapNmax || nTr == 0)) {
                 if (nTr == 1) trMult[0].primary = true;
@@ -678,17 +788,17 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         else if ((trBest->nMM > b.mmMaxTotal[ir]) || (double(trBest->nMM) / double(trBest->rLength) > P.dev.outFilterMismatchNoverLmax)) { st.unmappedMismatch++; unmapType = 2; }
         else if (nTr > P.outFilterMultimapNmax) { st.unmappedMulti++; unmapType = 3; }
         // ---- chimericDetection (ReadAlign_oneRead.cpp:95-97; not in the 2nd stage of BySJout, ReadAlign_chimericDetection.cpp:23)
-        if (chimJunction && nW > 0 && P.dev.outFilterBySJoutStage <= 1) {
-            bool chimRecord = false;
-            std::vector<ChimPair> chimPairs, *cpp = P.chim.outBam ? &chimPairs : nullptr;
-            if (P.chim.multimapNmax == 0) chimRecord = chimericDetectionOld(P, gi, b, ir, r, trBest, nTr, nTr > 0 ? trMult[0].t : nullptr, nTr > 1 ? trMult[1].t : nullptr, *chimJunction, cpp);
+        if (chimJunction && nW > 0 && P.dev.outFilterBySJoutStage <= 1 && !peOvYes) {       // ReadAlign_oneRead.cpp:95-97
+            const ReadAligns ra{T, nTrAll, EX};
+            chimRecord = false;
+            if (P.chim.multimapNmax == 0) chimRecord = chimericDetectionOld(P, gi, b, ir, ra, trBest, nTr, nTr > 0 ? trMult[0].t : nullptr, nTr > 1 ? trMult[1].t : nullptr, *chimJunction, cpp);
             else if (trBest->maxScore <= (int)(rc.readLength[0] + rc.readLength[1]) - (int)P.chim.nonchimScoreDropMin)       // ReadAlign_chimericDetection.cpp:48
-                chimRecord = chimericDetectionMult(P, gi, b, ir, r, trBest, *chimJunction, cpp);
+                chimRecord = chimericDetectionMult(P, gi, b, ir, ra, trBest, *chimJunction, cpp);
             if (chimRecord) st.chimericAll++;
-            if (chimRecord && P.chim.outBam) {          // the chimera stands for the read in the BAM: nothing else is output or counted for it (ReadAlign_oneRead.cpp:99-101)
-                if (!samOff) for (size_t k = 0; k < chimPairs.size(); k++) chimBamOutput(sam, P, gi, rc, chimPairs[k], k, chimPairs.size(), bamKeys);
-                continue;
-            }
+        }
+        if (chimRecord && P.chim.outBam) {          // the chimera stands for the read in the BAM: nothing else is output or counted for it (ReadAlign_oneRead.cpp:99-101)
+            if (!samOff) for (size_t k = 0; k < chimPairs.size(); k++) chimBamOutput(sam, P, gi, rc, chimPairs[k], k, chimPairs.size(), bamKeys);
+            continue;
         }
         // ---- outFilterBySJout, 1st stage (ReadAlign_outputAlignments.cpp:90-124)
         if (sj1 && unmapType <= 0) {
@@ -729,7 +839,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                     }
                 }
             }
-            const staramd_exon *exB = r.ex + trBest->exonOffset;
+            const staramd_exon *exB = EX + trBest->exonOffset;
             mateMapped[exB[0].iFrag] = true; mateMapped[exB[trBest->nExons - 1].iFrag] = true;
             if (rc.nMates > 1 && !(mateMapped[0] && mateMapped[1])) unmapType = 4;
             if (unmapType == 4 && P.outSAMunmappedWithin && !samOff && (!keepPairs || P.outBAMcoord)) {     // :216-233
@@ -739,8 +849,8 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             }
         } else if (P.outSAMunmappedWithin && !samOff) {
             staramd_transcript t0; memset(&t0, 0, sizeof(t0));
-            if (bam) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped, bamKeys);
-            else samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? r.ex + trBest->exonOffset : nullptr, unmapType, mateMapped);
+            if (bam) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? EX + trBest->exonOffset : nullptr, unmapType, mateMapped, bamKeys);
+            else samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? EX + trBest->exonOffset : nullptr, unmapType, mateMapped);
         }
         if (unmapType >= 0) {
             st.unmappedAll++;

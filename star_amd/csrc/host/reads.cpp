@@ -314,3 +314,67 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
 }
 
 } // namespace staramd
+
+namespace staramd {
+namespace {
+// localSearchNisMM (SequenceFuns.cpp:317-339): best ungapped placement of y on the tail of x; N anywhere counts as a mismatch
+uint64_t localSearchNisMM(const uint8_t *x, uint64_t nx, const uint8_t *y, uint64_t ny, double pMM) {
+    uint64_t nMatchBest = 0, nMMbest = 0, ixBest = nx;
+    for (uint64_t ix = 0; ix < nx; ix++) {
+        uint64_t nMatch = 0, nMM = 0;
+        const uint64_t n = std::min(ny, nx - ix);
+        for (uint64_t iy = 0; iy < n; iy++) { if (x[ix + iy] == y[iy] && y[iy] < 4) nMatch++; else nMM++; }
+        if ((nMatch > nMatchBest || (nMatch == nMatchBest && nMM < nMMbest)) && double(nMM) / double(nMatch) <= pMM) { ixBest = ix; nMatchBest = nMatch; nMMbest = nMM; }
+    }
+    return ixBest;
+}
+}
+
+void MergedBatch::build(const ReadBatch &b, const RunParams &P) {
+    const uint32_t n = b.n;
+    index.assign(n, -1); nOv.assign(n, 0); mateStart.assign(n, std::array<uint32_t, 2>{0, 0});
+    reads.clear();
+    std::vector<uint8_t> side(n, 0);                    // 1: mate 2 continues mate 1, 2: mate 1 continues mate 2
+    const int T = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::min(std::max(P.runThreadN, 1), 64), n / 512));
+    auto search = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint8_t *R = b.bases.data() + b.readOffset[i];
+            const uint64_t Lread = b.readOffset[i + 1] - b.readOffset[i], len0 = b.mate1Length[i], len1 = Lread - len0 - 1;
+            const uint64_t s1 = localSearchNisMM(R, len0, R + len0 + 1, len1, P.peOverlapMMp);
+            const uint64_t s0 = localSearchNisMM(R + len0 + 1, len1, R, len0, P.peOverlapMMp);
+            const uint64_t o1 = std::min(len1, len0 - s1), o0 = std::min(len0, len1 - s0);
+            uint64_t ov = std::max(o0, o1);
+            if (ov < P.peOverlapNbasesMin) continue;
+            nOv[i] = (uint32_t)ov;
+            if (o1 >= o0) { mateStart[i] = {0u, (uint32_t)s1}; side[i] = 1; }
+            else { mateStart[i] = {(uint32_t)s0, 0u}; side[i] = 2; }
+        }
+    };
+    if (T == 1) search(0, n);
+    else {
+        std::vector<std::thread> th; const uint32_t per = (n + T - 1) / T;
+        for (int t = 0; t < T; t++) th.emplace_back(search, std::min(n, (uint32_t)t * per), std::min(n, (uint32_t)(t + 1) * per));
+        for (auto &x : th) x.join();
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (!side[i]) continue;
+        const uint8_t *R = b.bases.data() + b.readOffset[i];
+        const uint64_t Lread = b.readOffset[i + 1] - b.readOffset[i], len0 = b.mate1Length[i], len1 = Lread - len0 - 1;
+        index[i] = (int32_t)reads.n;
+        if (side[i] == 1) {                              // mate 1, then what is left of mate 2 after the overlap
+            const uint64_t o1 = std::min(len1, len0 - mateStart[i][1]);
+            reads.bases.insert(reads.bases.end(), R, R + len0);
+            if (o1 < len1) reads.bases.insert(reads.bases.end(), R + len0 + 1 + o1, R + len0 + 1 + len1);
+        } else {                                         // mate 2, then what is left of mate 1
+            const uint64_t o0 = std::min(len0, len1 - mateStart[i][0]);
+            reads.bases.insert(reads.bases.end(), R + len0 + 1, R + len0 + 1 + len1);
+            if (o0 < len0) reads.bases.insert(reads.bases.end(), R + o0, R + len0);
+        }
+        const uint64_t Lm = Lread - nOv[i] - 1;
+        reads.readOffset.push_back(reads.readOffset.back() + Lm);
+        reads.mate1Length.push_back((uint16_t)Lm);
+        reads.mmMaxTotal.push_back(b.mmMaxTotal[i]);     // copyRead keeps the pair's mismatch budget (ReadAlign_waspMap.cpp:120)
+        reads.n++;
+    }
+}
+} // namespace staramd

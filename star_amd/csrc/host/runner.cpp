@@ -25,6 +25,7 @@ struct Runner {
     ReadBatch batch;
     staramd_batch batchView;
     ReadBatch slots[3];                 // pipelined CLI: parse / map / post-map work on different slots
+    MergedBatch mergedMain, mergedSlots[3];   // --peOverlapNbasesMin: the merged mates of batch / slots[k], mapped as a second batch
     std::unique_ptr<PostMap> post;
     OutSJ sj;
     Stats stats;
@@ -141,6 +142,7 @@ struct Runner {
         if (!err.empty()) { error = err; return -1; }
         if (!ok) return 0;
         batchView = batch.view();
+        if (P.peOverlapNbasesMin > 0 && P.dev.readNmates == 2) mergedMain.build(batch, P);
         return (int)batch.n;
     }
     // ---- SAM text goes to the file on its own thread: formatting of batch k+1 overlaps the write of batch k.  Two sets of
@@ -170,7 +172,8 @@ struct Runner {
     }
     // post-map of one batch on --runThreadN host threads: contiguous read ranges, per-thread SAM buffer / junctions / Stats
     // (what the reference keeps per ReadAlignChunk), SAM text written in read order
-    bool emitBatch(const ReadBatch &bt, const staramd_results *r) {
+    bool emitBatch(const ReadBatch &bt, const staramd_results *r, const MergedBatch *mg = nullptr, const staramd_results *mgRes = nullptr) {
+        if (mg && (mg->reads.n == 0 || !mgRes)) { if (mg->reads.n > 0) { error = "EXITING because of FATAL ERROR: --peOverlapNbasesMin: the merged mates of the batch were not mapped (sah_merged_batch / sah_emit_merged)"; return false; } mg = nullptr; }
         uint32_t T = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
         T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per thread
         int k;
@@ -204,7 +207,7 @@ struct Runner {
                     std::string sam0, q0; OutSJ sj0, sj10; Stats st0; std::vector<uint32_t> held0; std::vector<QuantPatch> qp0;
                     const bool samOff0 = post->samOff;
                     (void)samOff0;
-                    errs[t] = post->processRange(bt, *r, lo, hi, sam0, sj0, st0, stage1 ? &sj10 : nullptr, stage1 ? &held0 : nullptr, nullptr, nullptr, nullptr, nullptr, &q0, &qp0, nullptr, true);
+                    errs[t] = post->processRange(bt, *r, lo, hi, sam0, sj0, st0, stage1 ? &sj10 : nullptr, stage1 ? &held0 : nullptr, nullptr, nullptr, nullptr, nullptr, &q0, &qp0, nullptr, true, mg, mgRes);
                     for (const QuantPatch &p : qp0) nAlignT[p.ir] = p.nAlignT + 1;
                 };
                 std::vector<std::thread> th;
@@ -222,13 +225,13 @@ struct Runner {
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                              P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes);
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                          nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes);
         };
         if (T == 1) work(0);
         else {
@@ -321,7 +324,7 @@ struct Runner {
         coordChunks.clear(); coordKeys.clear();
         return failed ? "EXITING because of fatal ERROR: could not write " + path : "";
     }
-    bool emit(const staramd_results *r) { return emitBatch(batch, r); }
+    bool emit(const staramd_results *r, const staramd_results *rMerged = nullptr) { return emitBatch(batch, r, P.peOverlapNbasesMin > 0 && P.dev.readNmates == 2 ? &mergedMain : nullptr, rMerged); }
     // end of the 1st pass (twoPassRunPass1.cpp:75-96): junctions + Log.final.out of the pass into _STARpass1/, insertion of the
     // junctions into the index, reads rewound.  The caller then re-uploads the index (staramd_update_index).
     bool endPass1() {
@@ -413,6 +416,15 @@ int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {
     return n;
 }
 int sah_emit(void *h, const staramd_results *res) { return ((Runner *)h)->emit(res) ? 0 : -1; }
+// --peOverlapNbasesMin > 0: after sah_next_batch, sah_merged_batch gives the pairs of the batch whose mates overlap, merged into single reads (0 = none);
+// map them with the same engine and hand both result sets to sah_emit_merged.  Same for the slots of the pipelined variant.
+int sah_merged_batch(void *h, staramd_batch *out) { Runner *r = (Runner *)h; if (!(r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) || r->mergedMain.reads.n == 0) return 0; if (out) *out = r->mergedMain.reads.view(); return (int)r->mergedMain.reads.n; }
+int sah_emit_merged(void *h, const staramd_results *res, const staramd_results *resMerged) { return ((Runner *)h)->emit(res, resMerged) ? 0 : -1; }
+int sah_merged_slot(void *h, int slot, staramd_batch *out) { Runner *r = (Runner *)h; if (!(r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) || r->mergedSlots[slot].reads.n == 0) return 0; if (out) *out = r->mergedSlots[slot].reads.view(); return (int)r->mergedSlots[slot].reads.n; }
+int sah_emit_slot_merged(void *h, int slot, const staramd_results *res, const staramd_results *resMerged) {
+    Runner *r = (Runner *)h;
+    return r->emitBatch(r->slots[slot], res, r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2 ? &r->mergedSlots[slot] : nullptr, resMerged) ? 0 : -1;
+}
 // pipelined variant (star_amd CLI): three batch slots so that FASTQ parsing of batch k+1, the device mapping of batch k and
 // the post-map / SAM writing of batch k-1 overlap.  parse and emit are each called from ONE thread, in batch order.
 int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
@@ -422,6 +434,7 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
     if (!err.empty()) { r->error = err; return -1; }
     if (!ok) return 0;
     if (out) *out = r->slots[slot].view();
+    if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
     return (int)r->slots[slot].n;
 }
 int sah_emit_slot(void *h, int slot, const staramd_results *res) { Runner *r = (Runner *)h; return r->emitBatch(r->slots[slot], res) ? 0 : -1; }

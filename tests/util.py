@@ -84,6 +84,17 @@ def prepare(name, workdir, need_ref=True):
     return info
 
 
+def _map(eng, b):
+    for per_read in (64, 256, 1024):          # the caller owns the result arrays: grow and call again when they are too small
+        bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * per_read)
+        try:
+            eng.map_batch(b, bufs)
+            return bufs
+        except RuntimeError as e:
+            if per_read == 1024 or not ("-3" in str(e) or "too small" in str(e)):
+                raise
+
+
 def run_with_engine(info, prefix, engine_factory, batch_reads=777):
     """alignReads through the host library; `engine_factory(genome_p, params_p)` gives an object with map_batch/close."""
     argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", prefix] + list(info.get("extra", []))
@@ -95,15 +106,10 @@ def run_with_engine(info, prefix, engine_factory, batch_reads=777):
                 b = run.next_batch(batch_reads)
                 if b is None:
                     break
-                for per_read in (64, 256, 1024):          # the caller owns the result arrays: grow and call again when they are too small
-                    bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * per_read)
-                    try:
-                        eng.map_batch(b, bufs)
-                        break
-                    except RuntimeError as e:
-                        if per_read == 1024 or not ("-3" in str(e) or "too small" in str(e)):
-                            raise
-                run.emit(bufs.res)
+                bufs = _map(eng, b)
+                mb = run.merged_batch()                   # --peOverlapNbasesMin: overlapping mates merged into single reads, a second batch
+                mbufs = _map(eng, mb) if mb is not None else None
+                run.emit(bufs.res, mbufs.res if mbufs is not None else None)
             phase = run.next_phase()
             if phase == 0:
                 break
