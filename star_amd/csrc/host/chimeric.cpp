@@ -158,18 +158,48 @@ int chimAlignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t
     return maxScore;
 }
 namespace {
+// ReadAlign::peOverlapChimericSEtoPE (ReadAlign_peOverlapMergeMap.cpp:309-368): both segments of a chimera of merged mates cut back into the two mates; the
+// shortest one-mate part of either segment (ties: the one whose junction lies deeper in its mate) is dropped, so that one mate is chimerically split, not both.
+// nb / nir: the pair; Lread: length of the merged read
+static void chimericMergedToPair(const ReadBatch &nb, uint32_t nir, const uint32_t *mateStart, uint64_t Lread, const ChimTr &se1, const ChimTr &se2, ChimTr tmp[2]) {
+    const uint64_t LreadPE = nb.readOffset[nir + 1] - nb.readOffset[nir];
+    const uint64_t readLengthPE[2] = {nb.mate1Length[nir], LreadPE - nb.mate1Length[nir] - 1};
+    const uint64_t readLengthOriginalPE[2] = {nb.seqSpan[0][nir].len, nb.seqSpan[1][nir].len};
+    mergedAlignToPair(tmp[0], mateStart, se1.t, se1.ex, Lread, readLengthPE, LreadPE);
+    mergedAlignToPair(tmp[1], mateStart, se2.t, se2.ex, Lread, readLengthPE, LreadPE);
+    uint64_t segLen[2][2] = {{0, 0}, {0, 0}}, segEx[2] = {0, 0}, i1 = 0, i2 = 0, posOfJunctionInRead = 0;
+    for (uint64_t ii = 0; ii < 2; ii++) {
+        for (uint32_t iex = 0; iex < tmp[ii].t.nExons; iex++) {
+            if (tmp[ii].ex[iex].iFrag == tmp[ii].ex[0].iFrag) { segLen[ii][0] += tmp[ii].ex[iex].L; segEx[ii] = iex; } else segLen[ii][1] += tmp[ii].ex[iex].L;
+        }
+        const uint64_t readLen0 = readLengthOriginalPE[tmp[ii].ex[0].iFrag], readLen1 = readLengthOriginalPE[1 - tmp[ii].ex[0].iFrag];
+        for (uint64_t jj = 0; jj < 2; jj++) {
+            const uint64_t R = tmp[ii].ex[jj].R;
+            const uint64_t cur = R > readLen0 ? readLen0 + readLen1 + 1 - R : R;
+            if (segLen[ii][jj] < segLen[i1][i2] || (segLen[ii][jj] == segLen[i1][i2] && cur > posOfJunctionInRead)) { posOfJunctionInRead = cur; i1 = ii; i2 = jj; }
+        }
+    }
+    ChimTr &c = tmp[i1];
+    if (i2 == 1) c.t.nExons = (uint16_t)(segEx[i1] + 1);
+    else {
+        const uint32_t shift = (uint32_t)segEx[i1] + 1, nNew = c.t.nExons - shift;
+        for (uint32_t iex = 0; iex < nNew; iex++) c.ex[iex] = c.ex[iex + shift];
+        c.t.nExons = (uint16_t)nNew;
+    }
+}
 } // namespace
 
 // returns true when a chimeric alignment was recorded (Stats::chimericAll); the junction line is appended to `out`
 bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra,
                           const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out,
-                          std::vector<ChimPair> *bamOut) {
+                          std::vector<ChimPair> *bamOut, const ReadBatch *nameBatch, uint32_t nameIr, const uint32_t *mateStart) {
     const ChimParams &C = P.chim;
+    const bool merged = nameBatch != nullptr;                 // b holds merged mates (ReadAlign_chimericDetectionPEmerged.cpp:12-25): a single-end read for the detection
     const struct { uint32_t nTr; } rr = {ra.nTr};
     const staramd_transcript *T = ra.T;
     const struct { const staramd_exon *ex; } r = {ra.ex};
     const uint64_t Lread = b.readOffset[ir + 1] - b.readOffset[ir];
-    const int nMates = (int)P.dev.readNmates;
+    const int nMates = merged ? 1 : (int)P.dev.readNmates;
     const uint64_t readLength[2] = {b.mate1Length[ir], nMates == 2 ? Lread - b.mate1Length[ir] - 1 : 0};
     const uint8_t *Read1 = b.bases.data() + b.readOffset[ir];
     const int64_t nG = (int64_t)gi.G.size();
@@ -260,9 +290,17 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
     if (trChim[0].t.Str != trChim[1].t.Str || trChim[0].t.Chr != trChim[1].t.Chr
         || (trChim[0].t.Str == 0 ? chimJ1 - chimJ0 + 1ull : chimJ0 - chimJ1 + 1ull) > (chimMotif >= 0 ? P.dev.alignIntronMax : P.dev.alignMatesGapMax)) {
         if (chimMotif >= 0 && (x0.L < C.junctionOverhangMin + chimRepeat0 || x1.L < C.junctionOverhangMin + chimRepeat1)) return false;
-        if (bamOut) {                                                // chimericDetectionOldOutput :11-16: both segments re-scored, one chimera, the best by definition
+        if (bamOut && !merged) {                                     // chimericDetectionOldOutput :11-16: both segments re-scored, one chimera, the best by definition
             chimAlignScore(P.dev, gi, Read1, Lread, trChim[0]); chimAlignScore(P.dev, gi, Read1, Lread, trChim[1]);
             bamOut->push_back(ChimPair{trChim[0], trChim[1], true});
+        }
+        if (bamOut && merged) {                                      // cut back into the pair first, then re-scored on the pair
+            ChimTr tmp[2];
+            chimericMergedToPair(*nameBatch, nameIr, mateStart, Lread, trChim[0], trChim[1], tmp);
+            const uint64_t LreadPE = nameBatch->readOffset[nameIr + 1] - nameBatch->readOffset[nameIr];
+            const uint8_t *Read1PE = nameBatch->bases.data() + nameBatch->readOffset[nameIr];
+            chimAlignScore(P.dev, gi, Read1PE, LreadPE, tmp[0]); chimAlignScore(P.dev, gi, Read1PE, LreadPE, tmp[1]);
+            bamOut->push_back(ChimPair{tmp[0], tmp[1], true});
         }
         if (!C.outJunctions) return true;
         // Chimeric.out.junction (chimericDetectionOldOutput :61-71)
@@ -299,7 +337,7 @@ struct ChimAlign { ChimTr a1, a2; uint64_t chimJ1, chimJ2, chimRepeat1, chimRepe
 } // namespace
 
 bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra, const staramd_transcript *trBest, std::string &out,
-                           std::vector<ChimPair> *bamOut, const ReadBatch *nameBatch, uint32_t nameIr) {
+                           std::vector<ChimPair> *bamOut, const ReadBatch *nameBatch, uint32_t nameIr, const uint32_t *mateStart) {
     const ChimParams &C = P.chim;
     const struct { uint32_t nTr; } rr = {ra.nTr};
     const staramd_transcript *T = ra.T;
@@ -397,7 +435,12 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
     for (size_t i = 0; i < chimAligns.size(); i++) {
         const ChimAlign &ca = chimAligns[i];
         if (ca.chimScore < minScoreToConsider) continue;
-        if (bamOut) bamOut->push_back(ChimPair{ca.a1, ca.a2, i == bestChimAlign});
+        if (bamOut && !merged) bamOut->push_back(ChimPair{ca.a1, ca.a2, i == bestChimAlign});
+        if (bamOut && merged) {
+            ChimTr tmp[2];
+            chimericMergedToPair(nb, nir, mateStart, Lread, ca.a1, ca.a2, tmp);
+            bamOut->push_back(ChimPair{tmp[0], tmp[1], i == bestChimAlign});
+        }
         if (!C.outJunctions) continue;
         const uint64_t c1 = gi.chrStart[ca.a1.t.Chr], c2 = gi.chrStart[ca.a2.t.Chr];
         out += gi.chrName[ca.a1.t.Chr]; out.push_back('\t'); appendU(out, ca.chimJ1 - c1 + 1); out.push_back('\t'); out.push_back(ca.a1.t.Str == 0 ? '+' : '-'); out.push_back('\t');

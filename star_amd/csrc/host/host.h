@@ -260,7 +260,7 @@ struct ChimPair { ChimTr a1, a2; bool best; };   // the two segments, in read or
 struct ReadAligns { const staramd_transcript *T; uint32_t nTr; const staramd_exon *ex; };
 bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra,
                           const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out,
-                          std::vector<ChimPair> *bamOut = nullptr);
+                          std::vector<ChimPair> *bamOut = nullptr, const ReadBatch *nameBatch = nullptr, uint32_t nameIr = 0, const uint32_t *mateStart = nullptr);
 
 // --outMultimapperOrder Random: the swap partners of the two Fisher-Yates shuffles of every multimapping read of a batch, drawn in read
 // order from the run's one random stream before the batch is formatted on threads (ReadAlign_multMapSelect.cpp:71-80)
@@ -268,7 +268,9 @@ struct MultOrder { std::vector<uint64_t> offset; std::vector<uint32_t> partner; 
 
 // nameBatch / nameIr: where the read's name, read group and unclipped lengths come from when b holds merged mates (PEmerged_bool = 1)
 bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra, const staramd_transcript *trBest, std::string &out,
-                           std::vector<ChimPair> *bamOut = nullptr, const ReadBatch *nameBatch = nullptr, uint32_t nameIr = 0);
+                           std::vector<ChimPair> *bamOut = nullptr, const ReadBatch *nameBatch = nullptr, uint32_t nameIr = 0, const uint32_t *mateStart = nullptr);
+// Transcript::peOverlapSEtoPE: an alignment of merged mates cut into the blocks of the two mates (scores not set); false = too many blocks
+bool mergedAlignToPair(ChimTr &o, const uint32_t mateStart[2], const staramd_transcript &t, const staramd_exon *tex, uint64_t tLread, const uint64_t readLength[2], uint64_t Lread);
 // Transcript::alignScore: score and mismatches of an alignment recomputed from its blocks; Read1 = the read as mapped, Lread its length
 int chimAlignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, ChimTr &c);
 

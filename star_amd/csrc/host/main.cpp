@@ -27,6 +27,8 @@ uint64_t sah_batch_reads(void *h);
 int sah_device(void *h);
 int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
 int sah_emit_slot(void *h, int slot, const staramd_results *res);
+int sah_merged_slot(void *h, int slot, staramd_batch *out);
+int sah_emit_slot_merged(void *h, int slot, const staramd_results *res, const staramd_results *resMerged);
 int sah_finish(void *h);
 int sah_next_phase(void *h);
 uint64_t sah_novel_junctions(void *h, const uint64_t **start, const uint64_t **end);
@@ -35,7 +37,7 @@ void sah_destroy(void *h);
 }
 
 namespace {
-struct Msg { int slot; int n; staramd_batch b; int resIdx; };
+struct Msg { int slot; int n; staramd_batch b; int resIdx; bool merged; };
 struct Queue {                                   // bounded hand-off between two pipeline stages
     std::mutex m; std::condition_variable cv; std::deque<Msg> q; bool closed = false;
     void push(const Msg &x) { { std::lock_guard<std::mutex> l(m); q.push_back(x); } cv.notify_all(); }
@@ -58,7 +60,7 @@ int main(int argc, char **argv) {
     staramd_ctx *ctx = nullptr;
     int rc = staramd_create(&ctx, sah_device(h), sah_genome(h), sah_params(h), (uint32_t)batchReads, 0);
     if (rc) { fprintf(stderr, "\nEXITING because of FATAL ERROR: cannot initialise the MI355X engine: %s\n", staramd_last_error()); sah_destroy(h); return 105; }
-    ResBuf rb[2];
+    ResBuf rb[4];                                    // [0..1] the batches in flight, [2..3] their merged mates (--peOverlapNbasesMin)
     for (auto &r : rb) {
         r.reads.resize(batchReads); r.tr.resize(batchReads * 16 + 4096); r.ex.resize(r.tr.size() * 3);
         memset(&r.res, 0, sizeof(r.res));
@@ -86,7 +88,7 @@ int main(int argc, char **argv) {
         std::thread writer([&] {
             Msg m;
             while (mapped.pop(m)) {
-                if (failure.empty() && sah_emit_slot(h, m.slot, &rb[m.resIdx].res)) fail(sah_error(h));
+                if (failure.empty() && (m.merged ? sah_emit_slot_merged(h, m.slot, &rb[m.resIdx].res, &rb[2 + m.resIdx].res) : sah_emit_slot(h, m.slot, &rb[m.resIdx].res))) fail(sah_error(h));
                 results.give(m.resIdx); slots.give(m.slot);
             }
         });
@@ -94,16 +96,25 @@ int main(int argc, char **argv) {
         while (parsed.pop(m)) {
             if (!failure.empty()) { slots.give(m.slot); continue; }
             m.resIdx = results.take();
-            staramd_results &res = rb[m.resIdx].res;
-            rc = staramd_map_batch(ctx, &m.b, &res);
-            if (rc == STARAMD_ERR_RESULT_OVERFLOW) {             // rare: more transcripts than the buffers hold -> grow and retry
-                ResBuf &r = rb[m.resIdx];
-                r.tr.resize(res.trCount + res.trCount / 4 + 4096); r.ex.resize(res.exCount + res.exCount / 4 + 4096);
-                res.tr = r.tr.data(); res.trCapacity = r.tr.size(); res.ex = r.ex.data(); res.exCapacity = r.ex.size();
-                rc = staramd_map_batch(ctx, &m.b, &res);
+            auto mapInto = [&](const staramd_batch &bt, ResBuf &r) {
+                staramd_results &res = r.res;
+                int e = staramd_map_batch(ctx, &bt, &res);
+                if (e == STARAMD_ERR_RESULT_OVERFLOW) {          // rare: more transcripts than the buffers hold -> grow and retry
+                    r.tr.resize(res.trCount + res.trCount / 4 + 4096); r.ex.resize(res.exCount + res.exCount / 4 + 4096);
+                    res.tr = r.tr.data(); res.trCapacity = r.tr.size(); res.ex = r.ex.data(); res.exCapacity = r.ex.size();
+                    e = staramd_map_batch(ctx, &bt, &res);
+                }
+                if (!e) msDevice += res.msTotalDevice;
+                return e;
+            };
+            rc = mapInto(m.b, rb[m.resIdx]);
+            m.merged = false;
+            if (!rc) {                                           // --peOverlapNbasesMin: the overlapping mates of the batch, merged into single reads, are a second batch
+                staramd_batch mb;
+                if (sah_merged_slot(h, m.slot, &mb) > 0) { m.merged = true; rc = mapInto(mb, rb[2 + m.resIdx]); }
             }
             if (rc) { fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error()); results.give(m.resIdx); slots.give(m.slot); continue; }
-            nReads += (uint64_t)m.n; msDevice += res.msTotalDevice;
+            nReads += (uint64_t)m.n;
             mapped.push(m);
         }
         mapped.close();

@@ -373,8 +373,6 @@ std::string RunParams::parse(int argc, char **argv) {
     if (chim.segmentMin == 0) { chim.outBam = false; chim.outJunctions = false; }
     if (peOverlapNbasesMin > 0 && chim.segmentMin > 0) {
         if (chim.multimapNmax == 0 && chim.outJunctions) return "EXITING because of fatal PARAMETERS error: --chimMultimapNmax 0 (default old chimeric detection) and --peOverlapNbasesMin > 0 (merging ovelrapping mates) presently only works with --chimOutType WithinBAM\nSOLUTION: re-run with --chimOutType WithinBAM\n";
-        if (chim.multimapNmax == 0) return "EXITING: --peOverlapNbasesMin > 0 with the default chimeric detection (--chimMultimapNmax 0) is not implemented; use --chimMultimapNmax > 0";
-        if (chim.outBam) return "EXITING: --peOverlapNbasesMin > 0 with --chimOutType WithinBAM is not implemented; use --chimOutType Junctions";
     }
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     outSAMattrOrderQuant = {"NH", "HI"};

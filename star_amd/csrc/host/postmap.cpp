@@ -548,7 +548,7 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
 //   ReadAlign::peOverlapSEtoPE     source/ReadAlign_peOverlapMergeMap.cpp:267-307
 // An alignment of the merged read is cut into the blocks of mate 1 and of mate 2 (the overlap appears in both); scores are recomputed on the pair.
 // false = more than MAX_N_EXONS blocks, the alignment is dropped
-static bool mergedAlignToPair(ChimTr &o, const uint32_t mateStart[2], const staramd_transcript &t, const staramd_exon *tex, uint64_t tLread, const uint64_t readLength[2], uint64_t Lread) {
+bool mergedAlignToPair(ChimTr &o, const uint32_t mateStart[2], const staramd_transcript &t, const staramd_exon *tex, uint64_t tLread, const uint64_t readLength[2], uint64_t Lread) {
     uint64_t mLen[2] = {readLength[t.Str], readLength[1 - t.Str]};
     uint64_t mSta2[2] = {0, mLen[0] + 1};
     uint64_t mSta[2] = {mateStart[0], mateStart[1]};
@@ -746,10 +746,15 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             const int best = mergedReadToPair(P, gi, b.bases.data() + b.readOffset[ir], rc.Lread, rc.readLength, merged->mateStart[ir].data(), se, seLread, pairT, pairE, nWpair);
             T = pairT.data(); EX = pairE.data(); nTrAll = (uint32_t)pairT.size(); nW = nWpair;
             trBest = best >= 0 ? T + best : nullptr;
-            if (chimJunction && P.dev.outFilterBySJoutStage <= 1 && P.chim.multimapNmax > 0                       // chimericDetectionPEmerged (ReadAlign_chimericDetectionPEmerged.cpp:27-32)
-                && (trBest ? trBest->maxScore : 0) <= (int)(rc.readLength[0] + rc.readLength[1]) - (int)P.chim.nonchimScoreDropMin) {
+            if (chimJunction) {                                  // chimericDetectionPEmerged (ReadAlign_chimericDetectionPEmerged.cpp:5-39): on the merged read's own alignments
                 const staramd_transcript *seBest = mr.trBest >= 0 ? se.T + mr.trBest : nullptr;
-                if (seBest) chimRecord = chimericDetectionMult(P, gi, merged->reads, mi, se, seBest, *chimJunction, cpp, &b, ir);
+                if (P.chim.multimapNmax == 0 && seBest) {
+                    // the merged read's multMapSelect: how many alignments are within the score range of its best, and the first two of them
+                    uint64_t nTrSE = 0; const staramd_transcript *m0 = nullptr, *m1 = nullptr;
+                    for (uint32_t k = 0; k < se.nTr; k++) if (se.T[k].maxScore + P.dev.outFilterMultimapScoreRange >= seBest->maxScore) { if (nTrSE == 0) m0 = se.T + k; else if (nTrSE == 1) m1 = se.T + k; nTrSE++; }
+                    chimRecord = chimericDetectionOld(P, gi, merged->reads, mi, se, seBest, nTrSE, m0, m1, *chimJunction, cpp, &b, ir, merged->mateStart[ir].data());
+                } else if (P.chim.multimapNmax > 0 && seBest && (trBest ? trBest->maxScore : 0) <= (int)(rc.readLength[0] + rc.readLength[1]) - (int)P.chim.nonchimScoreDropMin)
+                    chimRecord = chimericDetectionMult(P, gi, merged->reads, mi, se, seBest, *chimJunction, cpp, &b, ir, merged->mateStart[ir].data());
                 if (chimRecord) st.chimericAll++;
             }
             if (peScore <= (trBest ? trBest->maxScore : 0) || chimRecord) peOvYes = true;

@@ -92,3 +92,33 @@ def test_pe_overlap_chimeric_stress(tmp_path, built):
     print("chimeric lines %d, merged %d" % (len(a), merged))
     assert a == b
     assert merged > 100
+
+
+@pytest.mark.parametrize("clip", ["HardClip", "SoftClip", "Old"])
+def test_pe_overlap_chimeric_within_bam(clip, tmp_path, built):
+    """Arriba's way: chimeras of merged mates written into the BAM; both segments are cut back into the two mates and the shortest
+    one-mate part is dropped, so that only one mate is split"""
+    from util import bam_parts
+    info = dict(prepare("pe101", str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    info["fastq"] = _chimeric_fragments(info, d, n=1200, seed=5)
+    flags = ["--peOverlapNbasesMin", "10", "--chimSegmentMin", "10", "--chimOutType", "WithinBAM", clip, "Junctions", "--chimJunctionOverhangMin", "10", "--chimScoreMin", "1", "--chimScoreDropMax", "30",
+             "--chimScoreJunctionNonGTAG", "0", "--chimScoreSeparation", "1", "--alignSJstitchMismatchNmax", "5", "-1", "5", "5", "--chimSegmentReadGapMax", "3", "--chimMultimapNmax", "50",
+             "--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate", "--outSAMunmapped", "Within"]
+    if clip == "Old":            # the default detection algorithm on the merged reads (older Arriba recipes): BAM only
+        flags = ["--peOverlapNbasesMin", "10", "--chimSegmentMin", "10", "--chimOutType", "WithinBAM", "--chimJunctionOverhangMin", "10", "--chimScoreMin", "1", "--chimScoreDropMax", "30",
+                 "--chimScoreJunctionNonGTAG", "0", "--chimScoreSeparation", "1", "--chimSegmentReadGapMax", "3", "--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate", "--outSAMunmapped", "Within"]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refW_"), threads=1, extra=flags)
+    info["extra"] = flags
+    new = run_with_engine(info, os.path.join(d, "newW_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=500)
+    for f in ("Aligned.out.bam", "Aligned.sortedByCoord.out.bam"):
+        (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + f), bam_parts(new + f)
+        assert ra == rb and len(rr) == len(nr)
+        bad = [k for k in range(len(rr)) if rr[k] != nr[k]]
+        assert not bad, (f, len(bad), bad[:3])
+    flag = lambda rec: int.from_bytes(rec[18:20], "little")
+    print("records %d, supplementary %d" % (len(rr), sum(1 for x in rr if flag(x) & 0x800)))
+    assert sum(1 for x in rr if flag(x) & 0x800) > 100
+    if clip != "Old":
+        assert open(ref + "Chimeric.out.junction").readlines() == open(new + "Chimeric.out.junction").readlines()
+    assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(new + "Log.final.out")
