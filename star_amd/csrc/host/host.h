@@ -43,6 +43,10 @@ struct ChimParams {
     bool outJunctions = true, outBam = false, bamHardClip = true;                   // --chimOutType Junctions | WithinBAM [HardClip | SoftClip]
 };
 
+struct WigParams {                     // --outWigType / --outWigStrand / --outWigNorm / --outWigReferencesPrefix (Parameters.cpp:511-560)
+    bool yes = false; int format = 0, type = 0, norm = 1; bool strand = true; std::string referencesPrefix;
+};
+
 struct RunParams {
     staramd_params dev;                 // what reaches the device hot path
     // run
@@ -93,6 +97,7 @@ struct RunParams {
     bool sjdbInsertYes() const { return twopass || sjdbInsertPass1(); }
     bool outFilterBySJout = false;       // --outFilterType BySJout
     ChimParams chim;                     // --chim* (chimeric.cpp)
+    WigParams wig;                       // --outWig* (signal.cpp)
     std::vector<std::string> outSAMattrRG, outSAMattrRGlineSplit;   // --outSAMattrRGline (Parameters_readFilesInit.cpp:64-93)
     bool outReadsUnmappedFastx = false;  // --outReadsUnmapped Fastx
     bool outSAMreadIDnumber = false;     // --outSAMreadID Number
@@ -273,6 +278,9 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
 bool mergedAlignToPair(ChimTr &o, const uint32_t mateStart[2], const staramd_transcript &t, const staramd_exon *tex, uint64_t tLread, const uint64_t readLength[2], uint64_t Lread);
 // Transcript::alignScore: score and mismatches of an alignment recomputed from its blocks; Read1 = the read as mapped, Lread its length
 int chimAlignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, ChimTr &c);
+
+// signal.cpp: coverage tracks from BAM records in coordinate order; error text or ""
+std::string writeSignal(const RunParams &P, const GenomeIndex &gi, const std::string &sigFileName, const std::vector<const char *> &recs);
 
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {

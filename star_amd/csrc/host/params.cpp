@@ -152,6 +152,15 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMheaderCommentFile") { if (one(k, v) != "-") outSAMheaderCommentFile = one(k, v); }
         else if (k == "outSJtype") { const std::string &m = v[0]; if (m == "None") outSJnone = true; else if (m != "Standard") err = "EXITING because of FATAL input ERROR: unrecognized option in --outSJtype   " + m + "\nSOLUTION: use one of the allowed options: --outSJtype   Standard    OR    None\n"; }
         else if (k == "outQSconversionAdd") outQSconversionAdd = (int)I(k, v);
+        else if (k == "outWigType") {          // Parameters.cpp:511-552
+            if (v[0] == "None") wig.yes = false; else if (v[0] == "bedGraph") { wig.yes = true; wig.format = 0; } else if (v[0] == "wiggle") { wig.yes = true; wig.format = 1; }
+            else err = "EXITING because of FATAL INPUT ERROR: unrecognized option in --outWigType=" + v[0] + "\nSOLUTION: use one of the allowed values of --outWigType : 'None' or 'bedGraph' \n";
+            if (v.size() > 1) { if (v[1] == "read1_5p") wig.type = 1; else if (v[1] == "read2") wig.type = 2; else err = "EXITING because of FATAL INPUT ERROR: unrecognized second option in --outWigType=" + v[1] + "\nSOLUTION: use one of the allowed values of --outWigType : 'read1_5p' \n"; }
+        }
+        else if (k == "outWigStrand") { const std::string &m = v[0]; if (m == "Stranded") wig.strand = true; else if (m == "Unstranded") wig.strand = false; else err = "EXITING because of FATAL INPUT ERROR: unrecognized option in --outWigStrand=" + m + "\nSOLUTION: use one of the allowed values of --outWigStrand : 'Stranded' or 'Unstranded' \n"; }
+        else if (k == "outWigNorm") { const std::string &m = v[0]; if (m == "None") wig.norm = 0; else if (m == "RPM") wig.norm = 1; else err = "EXITING because of fatal parameter ERROR: unrecognized option in --outWigNorm=" + m + "\nSOLUTION: use one of the allowed values of --outWigNorm : 'None' or 'RPM' \n"; }
+        else if (k == "outWigReferencesPrefix") { if (one(k, v) != "-") wig.referencesPrefix = one(k, v); }
+        else if (k == "seedNoneLociPerWindow" || k == "winReadCoverageRelativeMin" || k == "winReadCoverageBasesMin" || k == "limitGenomeGenerateRAM") { (void)D(k, v); }   // long-read build / index generation only (ReadAlign_stitchPieces.cpp:202-230)
         else if (k == "peOverlapNbasesMin") peOverlapNbasesMin = (uint32_t)U(k, v);
         else if (k == "peOverlapMMp") peOverlapMMp = D(k, v);
         else if (k == "outMultimapperOrder") { const std::string &m = one(k, v); if (m == "Random") outMultimapperRandom = true; else if (m != "Old_2.4") err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --outMultimapperOrder: " + m + "\nSOLUTION: specify one of the allowed values: Old_2.4 or Random\n"; }
@@ -371,6 +380,7 @@ std::string RunParams::parse(int argc, char **argv) {
         if (std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") == outSAMattrOrder.end()) outSAMattrOrder.push_back("NM");
     }
     if (chim.segmentMin == 0) { chim.outBam = false; chim.outJunctions = false; }
+    if (wig.yes && !outBAMcoord) return "EXITING because of fatal PARAMETER error: generating signal with --outWigType requires sorted BAM\nSOLUTION: re-run STAR with with --outSAMtype BAM SortedByCoordinate, or, id you also need unsroted BAM, with --outSAMtype BAM SortedByCoordinate Unsorted\n";
     if (peOverlapNbasesMin > 0 && chim.segmentMin > 0) {
         if (chim.multimapNmax == 0 && chim.outJunctions) return "EXITING because of fatal PARAMETERS error: --chimMultimapNmax 0 (default old chimeric detection) and --peOverlapNbasesMin > 0 (merging ovelrapping mates) presently only works with --chimOutType WithinBAM\nSOLUTION: re-run with --chimOutType WithinBAM\n";
     }

@@ -321,6 +321,12 @@ struct Runner {
         }
         std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), f);
         if (toStdout) fflush(stdout); else fclose(f);
+        if (P.wig.yes && !failed) {                                 // STAR.cpp:275-283: signal tracks from the sorted alignments
+            std::vector<const char *> recs(n);
+            for (uint64_t i = 0; i < n; i++) { const BamKey &k = K[ord[i]]; recs[i] = coordChunks[k.chunk].data() + k.off; }
+            std::string werr = writeSignal(P, gi, P.outFileNamePrefix + "Signal", recs);
+            if (!werr.empty()) return werr;
+        }
         coordChunks.clear(); coordKeys.clear();
         return failed ? "EXITING because of fatal ERROR: could not write " + path : "";
     }

@@ -1,0 +1,39 @@
+"""--outWigType bedGraph | wiggle [read1_5p | read2] with --outWigStrand / --outWigNorm / --outWigReferencesPrefix: the coverage tracks the reference
+writes from its sorted BAM at the end of an alignReads run (signalFromBAM.cpp), here from the sorted records still in memory (signal.cpp)."""
+import os
+
+import pytest
+
+from util import capi, oracle_lib, prepare, refstar, run_with_engine
+
+pytestmark = pytest.mark.skipif(not refstar.have_ref(), reason="oracle/_ref/STAR not built (no /root/reference here)")
+
+CASES = [("pe101", ["--outWigType", "bedGraph"]),
+         ("pe101", ["--outWigType", "wiggle", "--outWigStrand", "Unstranded", "--outWigNorm", "None"]),
+         ("pe101_sparse3", ["--outWigType", "bedGraph", "read2", "--outWigNorm", "None", "--outFilterMultimapNmax", "30"]),
+         ("pe76_overlap", ["--outWigType", "bedGraph", "read1_5p", "--outWigReferencesPrefix", "chr2"]),
+         ("se50", ["--outWigType", "wiggle", "read1_5p", "--outSAMunmapped", "Within"])]
+
+
+@pytest.mark.parametrize("name,more", CASES)
+def test_signal_tracks(name, more, tmp_path, built):
+    info = dict(prepare(name, str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    info["extra"] = [x for x in info["extra"]] + more + ["--outSAMtype", "BAM", "SortedByCoordinate"]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refS_"), threads=1, extra=info["extra"])
+    new = run_with_engine(info, os.path.join(d, "newS_"), lambda g, p: oracle_lib.Oracle(g, p))
+    files = sorted(f[len("refS_"):] for f in os.listdir(d) if f.startswith("refS_Signal."))
+    assert len(files) == (2 if "Unstranded" in more else 4)
+    total = 0
+    for f in files:
+        a, b = open(os.path.join(d, "refS_" + f), "rb").read(), open(os.path.join(d, "newS_" + f), "rb").read()
+        assert a == b, f
+        total += len(a)
+    assert total > 10000
+
+
+def test_signal_needs_sorted_bam(tmp_path, built):
+    info = prepare("se50", str(tmp_path), need_ref=False)
+    with pytest.raises(RuntimeError) as e:
+        capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "e_"), "--outWigType", "bedGraph"])
+    assert "generating signal with --outWigType requires sorted BAM" in str(e.value)
