@@ -143,6 +143,7 @@ struct ReadBatch {
     uint64_t firstReadIndex = 0;
     std::vector<uint64_t> origIndex;      // 2nd stage of BySJout: index of the read in the original input (empty otherwise)
     uint32_t fileIndex = 0;               // which of the comma-separated input files the batch came from (a batch never spans two)
+    bool fasta = false;                   // the reads came without qualities (FASTA input, readLoad.cpp:84-88): QUAL is * in SAM, 0xFF in BAM, Fastx output is FASTA
     uint64_t readIndex(uint32_t i) const { return origIndex.empty() ? firstReadIndex + i : origIndex[i]; }
     std::string_view name(uint32_t i) const { return std::string_view(text[0].data() + nameSpan[i].off, nameSpan[i].len); }
     std::string_view seq(int m, uint32_t i) const { return std::string_view(text[m].data() + seqSpan[m][i].off, seqSpan[m][i].len); }
@@ -183,6 +184,9 @@ private:
     bool eof[2] = {false, false};
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
     std::vector<uint64_t> lineStart[2], lineEnd[2];
+    bool noQualities = false;             // held FASTA reads (2nd stage of BySJout)
+    bool fasta = false;                   // '>' records, possibly with the sequence over several lines (ReadAlignChunk_processChunks.cpp:158-190)
+    uint64_t fillFasta(int m, uint64_t want, std::vector<char> &text);
     // moves text of up to `want` records into `text`; fills lineStart/lineEnd; returns the number of complete lines
     uint64_t fill(int m, uint64_t want, std::vector<char> &text);
 };

@@ -169,12 +169,13 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         } else out += "\t*\t0\t0";
         out.push_back('\t');
         const std::string_view sq = b.seq((int)Mate, ir), ql = b.qual((int)Mate, ir);
-        if (Mate == Str) { out += sq; out.push_back('\t'); if (!P.outSAMmodeNoQS) out += ql; else out.push_back('*'); }
+        const bool noQS = P.outSAMmodeNoQS || b.fasta;           // readFileType==2 ? Qual : "*" (ReadAlign_outputTranscriptSAM.cpp:215)
+        if (Mate == Str) { out += sq; out.push_back('\t'); if (!noQS) out += ql; else out.push_back('*'); }
         else {
             size_t n = sq.size();
             for (size_t k = 0; k < n; k++) out.push_back(rcNt(sq[n - 1 - k]));
             out.push_back('\t');
-            if (!P.outSAMmodeNoQS) { for (size_t k = 0; k < n; k++) out.push_back(ql[n - 1 - k]); } else out.push_back('*');
+            if (!noQS) { for (size_t k = 0; k < n; k++) out.push_back(ql[n - 1 - k]); } else out.push_back('*');
         }
         for (const std::string &a : P.outSAMattrOrder) {
             if (a == "NH") { out += "\tNH:i:"; appendUint(out, nTrOut); }
@@ -368,7 +369,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; core[7] = 0; }
         const size_t off0 = out.size();
         if (recOffsets) recOffsets->push_back(off0);
-        bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS, attr, hardClip[imate][0], hardClip[imate][1]);
+        bamFinish(out, core, b.name(ir), packed[imate], b.seq((int)Mate, ir), b.qual((int)Mate, ir), Mate != Str, P.outSAMmodeNoQS || b.fasta, attr, hardClip[imate][0], hardClip[imate][1]);
         // BAMoutput::coordOneAlign key (ReadAlign_outputAlignments.cpp:196-199): iReadAll << 32 | iTr << 8 | mate of the first exon; chimeric segments: iReadAll << 32
         if (keys && !chim) keys->push_back(BamKey{((uint64_t)core[0] << 32) | core[1], (b.readIndex(ir) << 32) | (iTrOut << 8) | ex[0].iFrag, off0, (uint32_t)(out.size() - off0), 0});
     }
@@ -494,7 +495,7 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         if (mateChr < gi.view.nChrReal) { core[5] = mateChr; core[6] = mateStart; } else { core[5] = (uint32_t)-1; core[6] = (uint32_t)-1; }
         core[7] = 0;
         const size_t off0 = out.size();
-        bamFinish(out, core, b.name(ir), std::vector<uint32_t>(), b.seq(imate, ir), b.qual(imate, ir), false, P.outSAMmodeNoQS, attr);
+        bamFinish(out, core, b.name(ir), std::vector<uint32_t>(), b.seq(imate, ir), b.qual(imate, ir), false, P.outSAMmodeNoQS || b.fasta, attr);
         if (keys) keys->push_back(BamKey{~0ull, b.readIndex(ir) << 32, off0, (uint32_t)(out.size() - off0), 0});      // unmapped: last, in read order
     }
 }
@@ -535,7 +536,7 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         out += b.name(ir); out.push_back('\t'); appendUint(out, samFLAG); out += "\t*\t0\t0\t*";
         if (rc.nMates == 2 && mateMap[1 - imate]) { out.push_back('\t'); out += gi.chrName[trBest->Chr]; out.push_back('\t'); appendUint(out, exBest[0].G + 1 - gi.chrStart[trBest->Chr]); }
         else out += "\t*\t0";
-        out += "\t0\t"; out += b.seq(imate, ir); out.push_back('\t'); out += b.qual(imate, ir);
+        out += "\t0\t"; out += b.seq(imate, ir); out.push_back('\t'); if (b.fasta) out.push_back('*'); else out += b.qual(imate, ir);      // :44
         out += "\tNH:i:0\tHI:i:0\tAS:i:"; appendInt(out, trBest ? trBest->maxScore : 0);
         out += "\tnM:i:"; appendUint(out, trBest ? trBest->nMM : 0); out += "\tuT:A:"; appendInt(out, unmapType);
         if (!P.outSAMattrRG.empty()) { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
@@ -862,9 +863,10 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             if (unmappedFastx) {                 // outReadsUnmapped (ReadAlign_outputAlignments.cpp:259-275): both mates, also of one-mate alignments
                 for (int im = 0; im < rc.nMates; im++) {
                     std::string &u = unmappedFastx[im];
-                    u.push_back('@'); u += b.name(ir); u.push_back(' '); u.push_back((char)('0' + im)); u.push_back(':'); u.push_back(b.filter[ir]); u += ": ";
+                    u.push_back(b.fasta ? '>' : '@'); u += b.name(ir); u.push_back(' '); u.push_back((char)('0' + im)); u.push_back(':'); u.push_back(b.filter[ir]); u += ": ";
                     if (rc.nMates > 1) { u.push_back(' '); u.push_back(mateMapped[0] ? '1' : '0'); u.push_back(mateMapped[1] ? '1' : '0'); }
-                    u.push_back('\n'); u += b.seq(im, ir); u += "\n+\n"; u += b.qual(im, ir); u.push_back('\n');
+                    u.push_back('\n'); u += b.seq(im, ir); u.push_back('\n');
+                    if (!b.fasta) { u += "+\n"; u += b.qual(im, ir); u.push_back('\n'); }
                 }
             }
         }

@@ -51,6 +51,12 @@ std::string FastqReader::openCurrent() {
         setvbuf(f[i], nullptr, _IONBF, 0);          // blocks are read straight into the batch text
         carry[i].clear(); eof[i] = false;
     }
+    {   // the first character of the first mate's file decides the format (ReadAlignChunk_processChunks.cpp:111,158)
+        char c = 0;
+        size_t got = fread(&c, 1, 1, f[0]);
+        if (got == 1) carry[0].push_back(c);
+        fasta = got == 1 && c == '>';
+    }
     return "";
 }
 
@@ -69,6 +75,7 @@ std::string FastqReader::open(const std::vector<std::string> &paths, const std::
 
 void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn) {
     nMates = nMatesIn; fromMemory = true;
+    noQualities = noQualities || fasta; fasta = false;      // held reads are kept as four-line records whatever the input format was
     mem[0].swap(mate1); mem[1].swap(mate2);
     for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; }
     readsSoFar = 0;
@@ -107,7 +114,61 @@ static uint64_t scanNewlines(const char *p, uint64_t from, uint64_t to, std::vec
     return i;
 }
 
+// FASTA reads: every record is rewritten as four lines (ID, the sequence on one line, +, a quality line of 'A's as readLoad.cpp:84-88 assigns) so that the
+// rest of the batcher is the same for both formats; ReadBatch::fasta tells the writers that there are no real qualities
+uint64_t FastqReader::fillFasta(int m, uint64_t want, std::vector<char> &text) {
+    std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
+    ls.clear(); le.clear(); text.clear();
+    std::vector<char> &raw = carry[m];              // unparsed input text
+    size_t p = 0; uint64_t nRec = 0;
+    auto more = [&]() {                              // append a block; false at the end of the input
+        if (eof[m]) return false;
+        const size_t block = 1u << 22, old = raw.size();
+        raw.resize(old + block);
+        size_t got;
+        if (fromMemory) { got = std::min<size_t>(block, mem[m].size() - memPos[m]); memcpy(raw.data() + old, mem[m].data() + memPos[m], got); memPos[m] += got; }
+        else got = fread(raw.data() + old, 1, block, f[m]);
+        raw.resize(old + got);
+        if (got < block) eof[m] = true;
+        return got > 0;
+    };
+    auto line = [&](size_t from, size_t &end) {      // [from, end) up to the newline; false when the line is not complete yet
+        for (;;) {
+            const char *nl = from < raw.size() ? (const char *)memchr(raw.data() + from, '\n', raw.size() - from) : nullptr;
+            if (nl) { end = (size_t)(nl - raw.data()); return true; }
+            if (!more()) { end = raw.size(); return from < raw.size(); }
+        }
+    };
+    auto emit = [&](const char *a, size_t n) { ls.push_back(text.size()); text.insert(text.end(), a, a + n); le.push_back(text.size()); text.push_back('\n'); };
+    while (nRec < want) {
+        size_t e;
+        if (!line(p, e)) break;
+        if (e == p) { ls.push_back(text.size()); le.push_back(text.size()); text.push_back('\n'); p = raw.size(); break; }   // an empty line ends the input
+        size_t he = e; if (he > p && (unsigned char)raw[he - 1] < 33) he--;
+        ls.push_back(text.size()); text.push_back('@'); text.insert(text.end(), raw.begin() + p + 1, raw.begin() + he); le.push_back(text.size()); text.push_back('\n');
+        p = std::min(e + 1, raw.size());
+        ls.push_back(text.size());
+        for (;;) {                                   // sequence lines until the next '>' or the end
+            if (p >= raw.size() && !more()) break;
+            if (p < raw.size() && raw[p] == '>') break;
+            size_t se;
+            if (!line(p, se)) break;
+            size_t s1 = se; if (s1 > p && (unsigned char)raw[s1 - 1] < 33) s1--;
+            text.insert(text.end(), raw.begin() + p, raw.begin() + s1);
+            p = std::min(se + 1, raw.size());
+        }
+        const size_t L = text.size() - ls.back();
+        le.push_back(text.size()); text.push_back('\n');
+        emit("+", 1);
+        ls.push_back(text.size()); text.insert(text.end(), L, 'A'); le.push_back(text.size()); text.push_back('\n');
+        nRec++;
+    }
+    raw.erase(raw.begin(), raw.begin() + std::min(p, raw.size()));
+    return ls.size();
+}
+
 uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
+    if (fasta) return fillFasta(m, want, text);
     std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
     ls.clear(); le.clear();
     text.assign(carry[m].begin(), carry[m].end());      // (not swap: every buffer keeps its capacity, so no fresh pages per batch)
@@ -168,7 +229,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     uint64_t nLines[2] = {0, 0};
     for (;;) {
         for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
-        b.fileIndex = (uint32_t)curFile;
+        b.fileIndex = (uint32_t)curFile; b.fasta = fasta || noQualities;
         // a batch never spans two input files: when this one is exhausted the next batch starts with the next file
         if (!fromMemory && nLines[0] == 0 && curFile + 1 < files_[0].size()) { closeFiles(); curFile++; std::string e = openCurrent(); if (!e.empty()) { err = e; return false; } continue; }
         break;
