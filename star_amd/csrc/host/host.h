@@ -113,6 +113,8 @@ struct RunParams {
     std::string readFilesPrefix, readFilesManifest;         // --readFilesPrefix, --readFilesManifest (Parameters_readFilesInit.cpp:41-139)
     std::vector<std::string> outSAMheaderHD, outSAMheaderPG; std::string outSAMheaderCommentFile;   // samHeaders.cpp:56-96
     bool runDirPermAll = false, genomeLoadShared = false;
+    int readFilesSAMmates = 0;           // --readFilesType SAM SE | PE: 1 | 2 (0 = Fastx)
+    bool samAttrKeepAll = true, samAttrKeepNone = false; std::vector<std::string> samAttrKeep;   // --readFilesSAMattrKeep (BAM output only, Parameters_readFilesInit.cpp:13-31)
     uint32_t peOverlapNbasesMin = 0; double peOverlapMMp = 0.01;   // --peOverlapNbasesMin, --peOverlapMMp
     bool outSJnone = false;              // --outSJtype None
     int outQSconversionAdd = 0;          // --outQSconversionAdd (readLoad.cpp:71-82)
@@ -143,6 +145,8 @@ struct ReadBatch {
     uint64_t firstReadIndex = 0;
     std::vector<uint64_t> origIndex;      // 2nd stage of BySJout: index of the read in the original input (empty otherwise)
     uint32_t fileIndex = 0;               // which of the comma-separated input files the batch came from (a batch never spans two)
+    std::vector<TextSpan> extraSpan[2];   // SAM input: the attributes of the input record, tab-separated text (readNameExtra, readLoad.cpp:28-29); empty otherwise
+    std::string_view extra(int m, uint32_t i) const { return extraSpan[m].empty() ? std::string_view() : std::string_view(text[m].data() + extraSpan[m][i].off, extraSpan[m][i].len); }
     bool fasta = false;                   // the reads came without qualities (FASTA input, readLoad.cpp:84-88): QUAL is * in SAM, 0xFF in BAM, Fastx output is FASTA
     uint64_t readIndex(uint32_t i) const { return origIndex.empty() ? firstReadIndex + i : origIndex[i]; }
     std::string_view name(uint32_t i) const { return std::string_view(text[0].data() + nameSpan[i].off, nameSpan[i].len); }
@@ -164,7 +168,8 @@ class FastqReader {
 public:
     ~FastqReader();
     // readCommand: --readFilesCommand (e.g. "zcat", "gunzip -c"); the text then comes from a pipe (Parameters_openReadsFiles.cpp:23-96)
-    std::string open(const std::vector<std::string> &paths, const std::string &readCommand = "");   // paths[m] = comma-separated list for mate m
+    // paths[m] = comma-separated list for mate m; samMates > 0: the one list holds SAM text with samMates (1 or 2) consecutive records per read (--readFilesType SAM SE|PE)
+    std::string open(const std::vector<std::string> &paths, const std::string &readCommand = "", int samMates = 0);
     void openMemory(std::string mate1, std::string mate2, int nMatesIn);   // FASTQ text held in memory (2nd stage of BySJout)
     std::string reopen();                 // rewind to the first read (Parameters::closeReadsFiles/openReadsFiles between the two passes)
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
@@ -185,6 +190,10 @@ private:
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
     std::vector<uint64_t> lineStart[2], lineEnd[2];
     bool noQualities = false;             // held FASTA reads (2nd stage of BySJout)
+    int samMates_ = 0; bool extras = false;   // SAM text input (ReadAlignChunk_processChunks.cpp:28-107); ID lines may carry attributes after a \x01
+    std::vector<char> samText2; std::vector<uint64_t> samLs2, samLe2;   // mate 2 of the records fillSam parsed for mate 1
+    uint64_t fillSam(uint64_t want, std::vector<char> &text);
+    std::string samError; uint64_t firstFlag = 0; std::string lastExtra[2];
     bool fasta = false;                   // '>' records, possibly with the sequence over several lines (ReadAlignChunk_processChunks.cpp:158-190)
     uint64_t fillFasta(int m, uint64_t want, std::vector<char> &text);
     // moves text of up to `want` records into `text`; fills lineStart/lineEnd; returns the number of complete lines
@@ -331,5 +340,18 @@ private:
     const RunParams &P;
     const GenomeIndex &gi;
 };
+
+// revComplementNucleotides, SequenceFuns.cpp:16-58
+inline char rcNt(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
+        case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K'; case 'S': return 'S'; case 'W': return 'W';
+        case 'B': return 'V'; case 'D': return 'H'; case 'V': return 'B'; case 'H': return 'D';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; case 'n': return 'n';
+        case 'r': return 'y'; case 'y': return 'r'; case 'k': return 'm'; case 'm': return 'k'; case 's': return 's'; case 'w': return 'w';
+        case 'b': return 'v'; case 'd': return 'h'; case 'v': return 'b'; case 'h': return 'd';
+        default: return c;
+    }
+}
 
 } // namespace staramd

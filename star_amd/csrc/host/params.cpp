@@ -152,6 +152,18 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMheaderCommentFile") { if (one(k, v) != "-") outSAMheaderCommentFile = one(k, v); }
         else if (k == "outSJtype") { const std::string &m = v[0]; if (m == "None") outSJnone = true; else if (m != "Standard") err = "EXITING because of FATAL input ERROR: unrecognized option in --outSJtype   " + m + "\nSOLUTION: use one of the allowed options: --outSJtype   Standard    OR    None\n"; }
         else if (k == "outQSconversionAdd") outQSconversionAdd = (int)I(k, v);
+        else if (k == "readFilesType") {       // Parameters_readFilesInit.cpp:11-39,152-166
+            if (v[0] == "Fastx") readFilesSAMmates = 0;
+            else if (v[0] == "SAM") {
+                if (v.size() == 2 && v[1] == "SE") readFilesSAMmates = 1; else if (v.size() == 2 && v[1] == "PE") readFilesSAMmates = 2;
+                else err = "EXITING because of FATAL INPUT ERROR: --readFilesType SAM requires specifying SE or PE reads\nSOLUTION: specify --readFilesType SAM SE for single-end reads or --readFilesType SAM PE for paired-end reads\n";
+            } else err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --readFilesType: " + v[0] + "\nSOLUTION: specify one of the allowed values: Fastx or SAM\n";
+        }
+        else if (k == "readFilesSAMattrKeep") {
+            samAttrKeepAll = false; samAttrKeepNone = false; samAttrKeep.clear();
+            if (v[0] == "All") samAttrKeepAll = true; else if (v[0] == "None") samAttrKeepNone = true;
+            else for (auto &t : v) { if (t.size() != 2) err = "EXITING because of FATAL PARAMETER ERROR: each SAM tags in --readFilesSAMtagsKeep should contain two letters\n                                  SOLUTION: specify only two-letter tags in --readFilesSAMtagsKeep."; samAttrKeep.push_back(t); }
+        }
         else if (k == "outWigType") {          // Parameters.cpp:511-552
             if (v[0] == "None") wig.yes = false; else if (v[0] == "bedGraph") { wig.yes = true; wig.format = 0; } else if (v[0] == "wiggle") { wig.yes = true; wig.format = 1; }
             else err = "EXITING because of FATAL INPUT ERROR: unrecognized option in --outWigType=" + v[0] + "\nSOLUTION: use one of the allowed values of --outWigType : 'None' or 'bedGraph' \n";
@@ -371,7 +383,7 @@ std::string RunParams::parse(int argc, char **argv) {
         if (!outSAMattrRG.empty() && !hasRG && readFilesManifest.empty()) outSAMattrOrder.push_back("RG");   // only --outSAMattrRGline adds the attribute by itself (Parameters_samAttributes.cpp:201)
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
-    if (peOverlapNbasesMin > 0 && readFilesIn.size() == 2) dev.resultSelect = 0;          // every alignment of the merged mates is cut back into a pair and re-scored (ReadAlign_peOverlapMergeMap.cpp:279-296)
+    if (peOverlapNbasesMin > 0 && (readFilesIn.size() == 2 || readFilesSAMmates == 2)) dev.resultSelect = 0;          // every alignment of the merged mates is cut back into a pair and re-scored (ReadAlign_peOverlapMergeMap.cpp:279-296)
     if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
     attrHasCh = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "ch") != outSAMattrOrder.end();
@@ -390,6 +402,11 @@ std::string RunParams::parse(int argc, char **argv) {
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     dev.readNmates = (uint32_t)readFilesIn.size();
+    if (readFilesSAMmates > 0) {
+        if (readFilesIn.size() != 1) return "EXITING: --readFilesType SAM reads all mates from one input (one file or list in --readFilesIn)";
+        if (readFilesIn[0].find(',') != std::string::npos) return "EXITING: --readFilesType SAM with several input files is not implemented; concatenate them in --readFilesCommand";
+        dev.readNmates = (uint32_t)readFilesSAMmates;
+    }
     if (dev.readNmates != 2) outSAMunmappedKeepPairs = false;     // Parameters.cpp:1074
     {   // ParametersClip::initialize (ParametersClip_initialize.cpp:33-82): a lone 0 / "-" is repeated for all mates, anything else needs one value per mate
         const std::string nm = std::to_string(dev.readNmates);

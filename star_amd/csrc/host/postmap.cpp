@@ -21,18 +21,6 @@ inline void appendUint(std::string &s, uint64_t v) {
 }
 inline void appendInt(std::string &s, int64_t v) { if (v < 0) { s.push_back('-'); appendUint(s, (uint64_t)(-v)); } else appendUint(s, (uint64_t)v); }
 
-// revComplementNucleotides, SequenceFuns.cpp:16-58
-inline char rcNt(char c) {
-    switch (c) {
-        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
-        case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K'; case 'S': return 'S'; case 'W': return 'W';
-        case 'B': return 'V'; case 'D': return 'H'; case 'V': return 'B'; case 'H': return 'D';
-        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; case 'n': return 'n';
-        case 'r': return 'y'; case 'y': return 'r'; case 'k': return 'm'; case 'm': return 'k'; case 's': return 's'; case 'w': return 'w';
-        case 'b': return 'v'; case 'd': return 'h'; case 'v': return 'b'; case 'h': return 'd';
-        default: return c;
-    }
-}
 
 struct TrView {                 // one candidate alignment = header + exon slice of the result arrays
     const staramd_transcript *t; const staramd_exon *ex;
@@ -190,6 +178,8 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "MC") { if (nMates > 1) { out += "\tMC:Z:"; out += matesCIGAR[1 - imate]; } }
             else if (a == "RG") { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
         }
+        // SAM input: its attributes go out again; indexed by the position of the mate in the alignment, not by the mate, as the reference does (:351-353)
+        if (!b.extra((int)imate, ir).empty()) { out.push_back('\t'); out += b.extra((int)imate, ir); }
         out.push_back('\n');
     }
 }
@@ -227,6 +217,26 @@ inline uint8_t nuclToNumBAM(char c) {                    // SequenceFuns.cpp:99-
         case 'Y': case 'y': return 10; case 'H': case 'h': return 11; case 'K': case 'k': return 12; case 'D': case 'd': return 13; case 'B': case 'b': return 14;
         default: return 15;
     }
+}
+// bamAttrArrayWriteSAMtags (BAMfunctions.cpp:147-192): attributes of the input SAM record as BAM attributes; i -> int32, A, Z, f; others dropped
+void attrFromSAMtags(std::string &a, std::string_view tags, const RunParams &P) {
+    if (tags.empty() || P.samAttrKeepNone) return;
+    size_t pos1 = 0, pos2;
+    do {
+        pos2 = tags.find('\t', pos1);
+        std::string_view t = tags.substr(pos1, pos2 == std::string_view::npos ? std::string_view::npos : pos2 - pos1);
+        pos1 = pos2 + 1;
+        if (t.size() < 5) continue;
+        if (!P.samAttrKeepAll && std::find(P.samAttrKeep.begin(), P.samAttrKeep.end(), std::string(t.substr(0, 2))) == P.samAttrKeep.end()) continue;
+        const std::string val(t.substr(5));
+        switch (t[3]) {
+            case 'i': { int32_t v = (int32_t)strtol(val.c_str(), nullptr, 10); a.push_back(t[0]); a.push_back(t[1]); a.push_back('i'); a.append((const char *)&v, 4); break; }
+            case 'A': { a.push_back(t[0]); a.push_back(t[1]); a.push_back('A'); a.push_back(val.empty() ? 0 : val[0]); break; }
+            case 'Z': { a.push_back(t[0]); a.push_back(t[1]); a.push_back('Z'); a += val; a.push_back(0); break; }
+            case 'f': { float v = strtof(val.c_str(), nullptr); a.push_back(t[0]); a.push_back(t[1]); a.push_back('f'); a.append((const char *)&v, 4); break; }
+            default: break;
+        }
+    } while (pos2 != std::string_view::npos);
 }
 // tail of a record: name, CIGAR, packed sequence, qualities, attributes (:547-590); the 9 core words come first
 void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, const std::vector<uint32_t> &cigar, std::string_view seq, std::string_view qual, bool rev,
@@ -352,6 +362,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
             else if (a == "ch") { if (alignType <= -10) attrChar(attr, "ch", '1'); }
         }
+        attrFromSAMtags(attr, b.extra((int)Mate, ir), P);
         uint32_t core[8];
         core[0] = t.Chr;
         core[1] = (uint32_t)(ex[iEx1].G - chrS);
@@ -487,6 +498,7 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         attrInt(attr, "NH", 0); attrInt(attr, "HI", 0); attrInt(attr, "AS", trBest ? trBest->maxScore : 0); attrInt(attr, "nM", trBest ? trBest->nMM : 0);
         attrChar(attr, "uT", (char)('0' + unmapType));
         if (!P.outSAMattrRG.empty()) attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
+        attrFromSAMtags(attr, b.extra(imate, ir), P);
         uint32_t core[8];
         core[0] = (uint32_t)-1; core[1] = (uint32_t)-1;
         core[2] = ((uint32_t)reg2bin(-1, 0) << 16) | (uint32_t)(b.name(ir).size() + 1);
@@ -540,6 +552,7 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         out += "\tNH:i:0\tHI:i:0\tAS:i:"; appendInt(out, trBest ? trBest->maxScore : 0);
         out += "\tnM:i:"; appendUint(out, trBest ? trBest->nMM : 0); out += "\tuT:A:"; appendInt(out, unmapType);
         if (!P.outSAMattrRG.empty()) { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
+        if (!b.extra(imate, ir).empty()) { out.push_back('\t'); out += b.extra(imate, ir); }               // :47-49
         out.push_back('\n');
     }
 }
@@ -863,7 +876,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             if (unmappedFastx) {                 // outReadsUnmapped (ReadAlign_outputAlignments.cpp:259-275): both mates, also of one-mate alignments
                 for (int im = 0; im < rc.nMates; im++) {
                     std::string &u = unmappedFastx[im];
-                    u.push_back(b.fasta ? '>' : '@'); u += b.name(ir); u.push_back(' '); u.push_back((char)('0' + im)); u.push_back(':'); u.push_back(b.filter[ir]); u += ": ";
+                    u.push_back(b.fasta ? '>' : '@'); u += b.name(ir); u.push_back(' '); u.push_back((char)('0' + im)); u.push_back(':'); u.push_back(b.filter[ir]); u += ": "; u += b.extra(im, ir);
                     if (rc.nMates > 1) { u.push_back(' '); u.push_back(mateMapped[0] ? '1' : '0'); u.push_back(mateMapped[1] ? '1' : '0'); }
                     u.push_back('\n'); u += b.seq(im, ir); u.push_back('\n');
                     if (!b.fasta) { u += "+\n"; u += b.qual(im, ir); u.push_back('\n'); }

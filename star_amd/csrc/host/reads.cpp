@@ -29,7 +29,7 @@ void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
     nameSpan.clear(); filter.clear(); origIndex.clear();
     for (int m = 0; m < 2; m++) for (int q = 0; q < 2; q++) clipN[m][q].clear();
-    for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); }
+    for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); extraSpan[i].clear(); }
 }
 
 void FastqReader::closeFiles() {
@@ -38,7 +38,7 @@ void FastqReader::closeFiles() {
 FastqReader::~FastqReader() { closeFiles(); }
 
 std::string FastqReader::openCurrent() {
-    for (int i = 0; i < nMates; i++) {
+    for (int i = 0; i < (samMates_ > 0 ? 1 : nMates); i++) {
         const std::string &path = files_[i][curFile];
         if (command_.empty()) f[i] = fopen(path.c_str(), "rb");
         else {
@@ -60,9 +60,9 @@ std::string FastqReader::openCurrent() {
     return "";
 }
 
-std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand) {
+std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand, int samMates) {
     closeFiles();
-    nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false;
+    nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false; samMates_ = samMates; extras = samMates > 0;
     for (int i = 0; i < nMates; i++) {              // --readFilesIn a1,a2,... b1,b2,...: the files of a mate are read one after the other
         files_[i].clear();
         size_t p0 = 0;
@@ -70,12 +70,14 @@ std::string FastqReader::open(const std::vector<std::string> &paths, const std::
     }
     if (nMates == 2 && files_[0].size() != files_[1].size()) return "EXITING: because of fatal INPUT ERROR: number of input files for mate 1 is not equal to that for mate 2";
     curFile = 0; readsSoFar = 0;
-    return openCurrent();
+    std::string e = openCurrent();
+    if (samMates_ > 0) { nMates = samMates_; fasta = false; }      // one stream, both mates
+    return e;
 }
 
 void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn) {
     nMates = nMatesIn; fromMemory = true;
-    noQualities = noQualities || fasta; fasta = false;      // held reads are kept as four-line records whatever the input format was
+    noQualities = noQualities || fasta; fasta = false; samMates_ = 0;     // held reads are kept as four-line records whatever the input format was
     mem[0].swap(mate1); mem[1].swap(mate2);
     for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; }
     readsSoFar = 0;
@@ -83,7 +85,8 @@ void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn)
 
 std::string FastqReader::reopen() {
     if (fromMemory) { for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; } readsSoFar = 0; return ""; }
-    return open(paths_, command_);      // first file again (a pipe cannot be rewound: the command is run again)
+    lastExtra[0].clear(); lastExtra[1].clear();    // the next pass runs on fresh ReadAlign objects
+    return open(paths_, command_, samMates_);      // first file again (a pipe cannot be rewound: the command is run again)
 }
 
 // offsets of the '\n' bytes in [p+from, p+to), appended to `out` until `out` holds `maxOut` entries; returns the offset where
@@ -167,7 +170,86 @@ uint64_t FastqReader::fillFasta(int m, uint64_t want, std::vector<char> &text) {
     return ls.size();
 }
 
+// SAM text input (--readFilesType SAM SE|PE, ReadAlignChunk_processChunks.cpp:28-107): header lines skipped; one record per mate, the two of a pair on
+// consecutive lines; sequences of reverse-strand records are turned back; the attributes go onto the ID line (after a \x01 here) and come out again with
+// every alignment of the read.  Rewritten as four-line records for both mates at once; fill(1) hands out mate 2.
+uint64_t FastqReader::fillSam(uint64_t want, std::vector<char> &text) {
+    std::vector<uint64_t> *LS[2] = {&lineStart[0], &samLs2}, *LE[2] = {&lineEnd[0], &samLe2};
+    std::vector<char> *TX[2] = {&text, &samText2};
+    for (int m = 0; m < 2; m++) { LS[m]->clear(); LE[m]->clear(); TX[m]->clear(); }
+    std::vector<char> &raw = carry[0];
+    size_t p = 0; uint64_t nRec = 0;
+    auto more = [&]() {
+        if (eof[0]) return false;
+        const size_t block = 1u << 22, old = raw.size();
+        raw.resize(old + block);
+        size_t got = fread(raw.data() + old, 1, block, f[0]);
+        raw.resize(old + got);
+        if (got < block) eof[0] = true;
+        return got > 0;
+    };
+    auto line = [&](size_t from, size_t &end) {
+        for (;;) {
+            const char *nl = from < raw.size() ? (const char *)memchr(raw.data() + from, '\n', raw.size() - from) : nullptr;
+            if (nl) { end = (size_t)(nl - raw.data()); return true; }
+            if (!more()) { end = raw.size(); return from < raw.size(); }
+        }
+    };
+    auto put = [&](int m, const char *a, size_t n) { LS[m]->push_back(TX[m]->size()); TX[m]->insert(TX[m]->end(), a, a + n); LE[m]->push_back(TX[m]->size()); TX[m]->push_back('\n'); };
+    std::string name1, idLine, seq, qual; int imate1 = 0;
+    while (nRec < want) {
+        // the samMates_ records of one read
+        bool got = true; size_t pRec = p;
+        for (int imate = 0; imate < samMates_; imate++) {
+            size_t e;
+            for (;;) {                                   // skip header lines
+                if (!line(p, e)) { got = false; break; }
+                if (e > p && raw[p] == '@') { p = e + 1; if (imate == 0) pRec = p; continue; }
+                break;
+            }
+            if (!got || e == p) { got = false; break; }
+            size_t le = e; if (le > p && (unsigned char)raw[le - 1] < 33) le--;
+            // fields: QNAME FLAG (7 skipped) SEQ QUAL attributes
+            size_t fs[12], fe[12]; int nf = 0; size_t q = p;
+            while (nf < 11 && q <= le) { fs[nf] = q; while (q < le && raw[q] != '\t' && raw[q] != ' ') q++; fe[nf] = q; nf++; if (q >= le) break; q++; }
+            if (nf < 11) { p = e + 1; got = false; samError = "EXITING because of FATAL ERROR in input SAM file: a record has fewer than 11 fields"; break; }
+            std::string nm(raw.data() + fs[0], fe[0] - fs[0]);
+            const uint64_t flag = strtoull(std::string(raw.data() + fs[1], fe[1] - fs[1]).c_str(), nullptr, 10);
+            if (imate == 0) { name1 = nm; imate1 = (samMates_ == 2 && (flag & 0x80)) ? 1 : 0; firstFlag = flag; }
+            else {
+                if (nm != name1) { samError = "EXITING because of FATAL ERROR in input BAM file: the consecutive lines in paired-end BAM have different read IDs:\n" + name1 + "   vs   " + nm + "\n\n SOLUTION: fix BAM file formatting. Paired-end reads should be always consecutive lines, with exactly 2 lines per paired-end read"; got = false; break; }
+                if (!(((firstFlag & 0x40) && (flag & 0x80)) || ((flag & 0x40) && (firstFlag & 0x80)))) { samError = "EXITING because of FATAL ERROR in input BAM file: the consecutive lines in paired-end BAM have wrong mate FLAG bits"; got = false; break; }
+                imate1 = 1 - imate1;
+            }
+            seq.assign(raw.data() + fs[9], fe[9] - fs[9]); qual.assign(raw.data() + fs[10], fe[10] - fs[10]);
+            if (flag & 0x10) {
+                std::reverse(seq.begin(), seq.end());
+                for (char &c : seq) c = rcNt(c);
+                std::reverse(qual.begin(), qual.end());
+            }
+            idLine = "@" + nm + " 0:" + ((flag & 0x800) ? "Y" : "N") + ":0";
+            size_t as = fe[10]; while (as < le && (raw[as] == '\t' || raw[as] == ' ')) as++;
+            if (as < le) { idLine.push_back('\x01'); idLine.append(raw.data() + as, le - as); }
+            put(imate1, idLine.data(), idLine.size()); put(imate1, seq.data(), seq.size()); put(imate1, "+", 1); put(imate1, qual.data(), qual.size());
+            p = std::min(e + 1, raw.size());
+        }
+        if (!got) {
+            if (samError.empty() && LS[0]->size() != LS[1]->size() && samMates_ == 2) samError = "EXITING because of FATAL ERROR in input SAM file: the last paired-end read has one record only";
+            (void)pRec; p = raw.size() > p && samError.empty() && !eof[0] ? p : p;
+            break;
+        }
+        nRec++;
+    }
+    raw.erase(raw.begin(), raw.begin() + std::min(p, raw.size()));
+    return LS[0]->size();
+}
+
 uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
+    if (samMates_ > 0) {
+        if (m == 0) return fillSam(want, text);
+        text.swap(samText2); lineStart[1].swap(samLs2); lineEnd[1].swap(samLe2);
+        return lineStart[1].size();
+    }
     if (fasta) return fillFasta(m, want, text);
     std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
     ls.clear(); le.clear();
@@ -252,7 +334,8 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     b.nameSpan.assign(n, TextSpan{0, 0}); b.filter.assign(n, 'N');
     if (fromMemory) b.origIndex.assign(n, 0);
     if (P.clipYes) for (int m = 0; m < nMates; m++) for (int q = 0; q < 2; q++) b.clipN[m][q].assign(n, 0);
-    for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); }
+    for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); if (extras) b.extraSpan[m].assign(n, TextSpan{0, 0}); }
+    if (!samError.empty()) { err = samError; return false; }
     lap("alloc");
     const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(std::max(P.runThreadN, 1), 32), n / 2048));
     std::vector<uint32_t> Lread(n);
@@ -280,6 +363,11 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
                 if (len[m] > STARAMD_READ_LEN_MAX) { bad(i, "EXITING because of FATAL ERROR in reads input: Lread>DEF_readSeqLengthMax"); return; }
                 if (qe - qs != len[m]) { bad(i, "EXITING because of FATAL ERROR in reads input: quality string length is not equal to sequence length"); return; }
                 b.seqSpan[m][i] = TextSpan{ss, (uint32_t)len[m]}; b.qualSpan[m][i] = TextSpan{qs, (uint32_t)len[m]};
+                if (extras) {                           // attributes of the input SAM record, kept on the ID line after a \x01
+                    const char *tm = b.text[m].data(); const uint64_t is = lineStart[m][4 * i], ie = lineEnd[m][4 * i];
+                    const char *x = (const char *)memchr(tm + is, '\x01', ie - is);
+                    b.extraSpan[m][i] = x ? TextSpan{(uint64_t)(x + 1 - tm), (uint32_t)(tm + ie - x - 1)} : TextSpan{0, 0};
+                }
                 if (P.outQSconversionAdd != 0) {        // readLoad.cpp:71-82, in place: every output of the qualities sees the converted ones
                     char *q = &b.text[m][qs];
                     for (uint64_t k = 0; k < len[m]; k++) { int v = int(q[k]) + P.outQSconversionAdd; q[k] = (char)(v < 33 ? 33 : v > 126 ? 126 : v); }
@@ -314,8 +402,8 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
             }
             // read ID: first white-space token of mate 1's line, then trimmed at readNameSeparator chars
             uint64_t p = s0 + 1, e = p;
-            while (e < e0 && t0[e] != ' ' && t0[e] != '\t') e++;
-            if (e < e0) {
+            while (e < e0 && t0[e] != ' ' && t0[e] != '\t' && t0[e] != '\x01') e++;
+            if (e < e0 && t0[e] != '\x01') {
                 uint64_t f2 = e;
                 while (f2 < e0 && (t0[f2] == ' ' || t0[f2] == '\t')) f2++;
                 uint64_t f3 = f2;
@@ -370,6 +458,15 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
         }
     });
     lap("pass2");
+    if (extras) {
+        // a record without attributes keeps those of the read before it: readLoad's getline on the exhausted ID line leaves readNameExtra as it was
+        // (readLoad.cpp:28-29); reproduced for the one-thread order of the reference
+        for (uint64_t i = 0; i < n; i++) for (int m = 0; m < nMates; m++) {
+            TextSpan &x = b.extraSpan[m][i];
+            if (x.len > 0) lastExtra[m].assign(b.text[m].data() + x.off, x.len);
+            else if (!lastExtra[m].empty()) { x = TextSpan{(uint64_t)b.text[m].size(), (uint32_t)lastExtra[m].size()}; b.text[m].insert(b.text[m].end(), lastExtra[m].begin(), lastExtra[m].end()); }
+        }
+    }
     readsSoFar += n;
     return true;
 }

@@ -77,7 +77,7 @@ struct Runner {
             error = sjdbInsertJunctions(P, gi, sjdbLoci, false, "", insertLog);
             if (!error.empty()) return false;
         }
-        error = reader.open(P.readFilesIn, P.readFilesCommand);
+        error = reader.open(P.readFilesIn, P.readFilesCommand, P.readFilesSAMmates);
         if (!error.empty()) return false;
         post.reset(new PostMap(P, gi));
         rngMultOrder.seed((unsigned)P.runRNGseed);                  // ReadAlign.cpp:11 (iChunk 0)
@@ -277,7 +277,9 @@ struct Runner {
                 for (uint32_t ir : helds[t])                         // held reads, in input order (ReadAlign_outputAlignments.cpp:108-121)
                     for (uint32_t m = 0; m < P.dev.readNmates; m++) {
                         std::string &x = heldText[m];
-                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0 " : " 0:N:0 "; x += std::to_string(bt.readIndex(ir)); x.push_back('\n');
+                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0 " : " 0:N:0 "; x += std::to_string(bt.readIndex(ir));
+                        if (!bt.extra((int)m, ir).empty()) { x.push_back('\x01'); x += bt.extra((int)m, ir); }
+                        x.push_back('\n');
                         x += bt.seq((int)m, ir); x += "\n+\n"; x += bt.qual((int)m, ir); x.push_back('\n');
                     }
             }
