@@ -40,6 +40,7 @@ struct ChimParams {
     bool filterGenomicN = true;
     int outJunctionFormat = 0;
     uint64_t multimapNmax = 0, multimapScoreRange = 1, nonchimScoreDropMin = 20;   // --chimMultimapNmax > 0: the multimapping algorithm
+    bool outSamOld = false;                                                         // --chimOutType SeparateSAMold
     bool outJunctions = true, outBam = false, bamHardClip = true;                   // --chimOutType Junctions | WithinBAM [HardClip | SoftClip]
 };
 
@@ -310,7 +311,8 @@ public:
                              std::string *chimJunction = nullptr,               // Chimeric.out.junction lines (--chimSegmentMin > 0)
                              std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr,           // TranscriptomeSAM records
                              const MultOrder *order = nullptr, bool dry = false,
-                             const MergedBatch *merged = nullptr, const staramd_results *mergedRes = nullptr) const;   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
+                             const MergedBatch *merged = nullptr, const staramd_results *mergedRes = nullptr,
+                             std::string *chimSam = nullptr) const;               // Chimeric.out.sam records (--chimOutType SeparateSAMold)   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
     // nAlignT (with --quantMode TranscriptomeSAM): per read, the number of transcriptomic alignments + 1 where the read draws its primary one
     // right after its shuffles (ReadAlign_quantTranscriptome.cpp:69), 0 where it does not
     template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr) const {

@@ -236,7 +236,7 @@ std::string RunParams::parse(int argc, char **argv) {
             chim.outJunctions = false;
             for (auto &t : v) {
                 if (t == "Junctions") chim.outJunctions = true; else if (t == "WithinBAM") chim.outBam = true; else if (t == "HardClip") chim.bamHardClip = true; else if (t == "SoftClip") chim.bamHardClip = false;
-                else if (t == "SeparateSAMold") err = "EXITING: --chimOutType SeparateSAMold (Chimeric.out.sam) is not implemented; use Junctions and / or WithinBAM";
+                else if (t == "SeparateSAMold") chim.outSamOld = true;
                 else err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --chimOutType: " + t + "\nSOLUTION: re-run STAR with --chimOutType Junctions , SeparateSAMold  , WithinBAM , HardClip \n";
             }
         }
@@ -391,10 +391,11 @@ std::string RunParams::parse(int argc, char **argv) {
         if (!outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETERS error: --chimOutType WithinBAM requires BAM output\nSOLUTION: re-run with --outSAMtype BAM Unsorted/SortedByCoordinate\n";
         if (std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") == outSAMattrOrder.end()) outSAMattrOrder.push_back("NM");
     }
-    if (chim.segmentMin == 0) { chim.outBam = false; chim.outJunctions = false; }
+    if (chim.segmentMin == 0) { chim.outBam = false; chim.outJunctions = false; chim.outSamOld = false; }
+    if (chim.multimapNmax > 0 && chim.outSamOld) return "EXITING because of fatal PARAMETERS error: --chimMultimapNmax > 0 (new chimeric detection) presently only works with --chimOutType Junctions/WithinBAM\nSOLUTION: re-run with --chimOutType Junctions/WithinBAM\n";
     if (wig.yes && !outBAMcoord) return "EXITING because of fatal PARAMETER error: generating signal with --outWigType requires sorted BAM\nSOLUTION: re-run STAR with with --outSAMtype BAM SortedByCoordinate, or, id you also need unsroted BAM, with --outSAMtype BAM SortedByCoordinate Unsorted\n";
     if (peOverlapNbasesMin > 0 && chim.segmentMin > 0) {
-        if (chim.multimapNmax == 0 && chim.outJunctions) return "EXITING because of fatal PARAMETERS error: --chimMultimapNmax 0 (default old chimeric detection) and --peOverlapNbasesMin > 0 (merging ovelrapping mates) presently only works with --chimOutType WithinBAM\nSOLUTION: re-run with --chimOutType WithinBAM\n";
+        if (chim.multimapNmax == 0 && (chim.outJunctions || chim.outSamOld)) return "EXITING because of fatal PARAMETERS error: --chimMultimapNmax 0 (default old chimeric detection) and --peOverlapNbasesMin > 0 (merging ovelrapping mates) presently only works with --chimOutType WithinBAM\nSOLUTION: re-run with --chimOutType WithinBAM\n";
     }
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     outSAMattrOrderQuant = {"NH", "HI"};

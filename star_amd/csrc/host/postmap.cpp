@@ -37,6 +37,10 @@ struct ReadCtx {
 };
 } // namespace
 
+// a segment of a chimeric alignment (--chimOutType WithinBAM / SeparateSAMold): alignType -10 = the representative one, -11 / -12 = supplementary with the hard
+// clip on the left / right, -13 = supplementary with soft clips; mateChr (> nChrReal: none), mateStart (0-based in the chromosome), mateStrand: the other segment
+struct ChimBam { int alignType; uint32_t mateChr, mateStart; uint8_t mateStrand; };
+
 std::string PostMap::samHeader() const {                 // samHeaders.cpp:27-98
     std::string h;
     if (P.outSAMheaderHD.empty()) h = "@HD\tVN:1.4";
@@ -56,7 +60,7 @@ std::string PostMap::samHeader() const {                 // samHeaders.cpp:27-98
 }
 
 // ---- ReadAlign::outputTranscriptSAM, mapped branch (:57-356) ----
-static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut) {
+static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, const ChimBam *chim = nullptr) {
     const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
     bool flagPaired = rc.nMates == 2;
@@ -67,7 +71,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     uint64_t Lread = rc.Lread;
     if (flagPaired) {
         samFlagCommon = 0x0001;
-        if (iExMate == nEx - 1) samFlagCommon += 0x0008;      // mateChr == (uint)-1 > nChrReal (:75)
+        if (iExMate == nEx - 1) { if (!chim || chim->mateChr > gi.view.nChrReal) samFlagCommon += 0x0008; }      // no mate given: (uint)-1 > nChrReal (:75)
         else if (P.dev.alignEndsProtrudeConcordantPair ||
                  ((ex[0].G <= ex[iExMate + 1].G + ex[0].R) && (ex[iExMate].G + ex[iExMate].L <= ex[nEx - 1].G + Lread - ex[nEx - 1].R)))
             samFlagCommon += 0x0002;
@@ -105,7 +109,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         uint32_t Mate = ex[iEx1].iFrag;
         if (Mate == 0) { samFLAG |= Str * 0x10; if (nMates == 2) samFLAG |= (1 - Str) * 0x20; }
         else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
-        if (flagPaired) samFLAG |= (Mate == 0 ? 0x0040 : 0x0080);
+        if (flagPaired) { samFLAG |= (Mate == 0 ? 0x0040 : 0x0080); if (nMates == 1 && chim && chim->mateStrand == 1) samFLAG |= 0x20; }     // :120-123
         if (!tv.primary) samFLAG |= 0x100;
         const std::string &cigar = matesCIGAR[imate];
         std::string SJmotif, SJintron;
@@ -154,7 +158,8 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             out += "\t=\t"; appendUint(out, ex[imate == 0 ? iExMate + 1 : 0].G + 1 - chrS); out.push_back('\t');
             if (imate != 0) out.push_back('-');
             appendUint(out, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);        // (--outSAMtlen 2 changes BAM output only, as in the reference)
-        } else out += "\t*\t0\t0";
+        } else if (chim && chim->mateChr < gi.view.nChrReal) { out.push_back('\t'); out += gi.chrName[chim->mateChr]; out.push_back('\t'); appendUint(out, (uint64_t)chim->mateStart + 1); out += "\t0"; }
+        else out += "\t*\t0\t0";
         out.push_back('\t');
         const std::string_view sq = b.seq((int)Mate, ir), ql = b.qual((int)Mate, ir);
         const bool noQS = P.outSAMmodeNoQS || b.fasta;           // readFileType==2 ? Qual : "*" (ReadAlign_outputTranscriptSAM.cpp:215)
@@ -260,9 +265,6 @@ void bamFinish(std::string &out, const uint32_t core[8], std::string_view name, 
 
 // mapped mates of one alignment (alignType -1)
 // quant = a projection onto a transcript (ReadAlign_quantTranscriptome.cpp:71-76): coordinates start at 0, attributes NH HI (+ RG, MC)
-// chim (--chimOutType WithinBAM): a segment of a chimeric alignment; alignType -10 = the representative one, -11 / -12 = supplementary with the hard clip on
-// the left / right, -13 = supplementary with soft clips; mateChr (> nChrReal: none), mateStart (0-based in the chromosome), mateStrand describe the other segment
-struct ChimBam { int alignType; uint32_t mateChr, mateStart; uint8_t mateStrand; };
 static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, std::vector<BamKey> *keys,
                       bool quant = false, std::vector<uint64_t> *recOffsets = nullptr, const ChimBam *chim = nullptr) {
     const int alignType = chim ? chim->alignType : -1;
@@ -475,6 +477,28 @@ static void chimBamOutput(std::string &out, const RunParams &P, const GenomeInde
         const size_t off0 = out.size();
         out += recs[ii];
         if (keys) keys->push_back(BamKey{((uint64_t)rd32(recs[ii].data() + 4) << 32) | rd32(recs[ii].data() + 8), rc.b->readIndex(rc.i) << 32, off0, (uint32_t)recs[ii].size(), 0});
+    }
+}
+
+// --chimOutType SeparateSAMold (ReadAlign_chimericDetectionOldOutput.cpp:18-59): the two segments as SAM records of Chimeric.out.sam, each pointing at the other
+static void chimSamOldOutput(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const ChimPair &cp) {
+    const ChimTr *trChim[2] = {&cp.a1, &cp.a2};
+    auto frag0 = [&](int i) { return trChim[i]->ex[0].iFrag; };
+    auto fragN = [&](int i) { return trChim[i]->ex[trChim[i]->t.nExons - 1].iFrag; };
+    bool primary[2];
+    if (frag0(0) != fragN(0)) { primary[0] = true; primary[1] = false; }
+    else if (frag0(1) != fragN(1)) { primary[1] = true; primary[0] = false; }
+    else if (frag0(0) != frag0(1)) { primary[0] = primary[1] = true; }
+    else { int r = trChim[0]->t.maxScore > trChim[1]->t.maxScore ? 0 : 1; primary[r] = true; primary[1 - r] = false; }
+    for (int iTr = 0; iTr < 2; iTr++) {
+        TrView v; v.t = &trChim[iTr]->t; v.ex = trChim[iTr]->ex; v.primary = primary[iTr];
+        if (rc.nMates == 2) {
+            const ChimTr &o = *trChim[1 - iTr];
+            uint32_t iex = 0;
+            if (frag0(1 - iTr) != fragN(1 - iTr)) for (; iex < o.t.nExons; iex++) if (o.ex[iex].iFrag != frag0(iTr)) break;
+            ChimBam cb; cb.alignType = -1; cb.mateChr = o.t.Chr; cb.mateStart = (uint32_t)(o.ex[iex].G - gi.chrStart[o.t.Chr]); cb.mateStrand = (uint8_t)(o.t.Str != o.ex[iex].iFrag);
+            samMapped(out, P, gi, rc, v, 2, (uint64_t)iTr, &cb);
+        } else samMapped(out, P, gi, rc, v, 2, (uint64_t)iTr);
     }
 }
 
@@ -723,7 +747,7 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                                   OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
                                   std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order, bool dry,
-                                  const MergedBatch *merged, const staramd_results *mergedRes) const {
+                                  const MergedBatch *merged, const staramd_results *mergedRes, std::string *chimSam) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<staramd_transcript> pairT; std::vector<staramd_exon> pairE;
     const bool samOff = this->samOff || dry;
@@ -749,7 +773,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         const staramd_transcript *trBest = (nW > 0 && rr.trBest >= 0) ? T + rr.trBest : nullptr;
         // ---- peOverlapMergeMap (ReadAlign_peOverlapMergeMap.cpp:4-75): where the merged mates mapped, their alignments, cut back into the two mates, replace the pair's
         bool peOvYes = false, chimRecord = false;
-        std::vector<ChimPair> chimPairs, *cpp = (chimJunction && P.chim.outBam) ? &chimPairs : nullptr;
+        std::vector<ChimPair> chimPairs, *cpp = (chimJunction && (P.chim.outBam || P.chim.outSamOld)) ? &chimPairs : nullptr;
         if (merged && merged->index[ir] >= 0 && mergedRes->reads[merged->index[ir]].nW > 0) {
             const uint32_t mi = (uint32_t)merged->index[ir];
             const staramd_read_result &mr = mergedRes->reads[mi];
@@ -815,6 +839,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                 chimRecord = chimericDetectionMult(P, gi, b, ir, ra, trBest, *chimJunction, cpp);
             if (chimRecord) st.chimericAll++;
         }
+        if (chimRecord && P.chim.outSamOld && chimSam) for (const ChimPair &cp : chimPairs) chimSamOldOutput(*chimSam, P, gi, rc, cp);
         if (chimRecord && P.chim.outBam) {          // the chimera stands for the read in the BAM: nothing else is output or counted for it (ReadAlign_oneRead.cpp:99-101)
             if (!samOff) for (size_t k = 0; k < chimPairs.size(); k++) chimBamOutput(sam, P, gi, rc, chimPairs[k], k, chimPairs.size(), bamKeys);
             continue;

@@ -31,6 +31,7 @@ struct Runner {
     Stats stats;
     FILE *samOut = nullptr;
     FILE *chimOut = nullptr;                        // Chimeric.out.junction
+    FILE *chimSamOut = nullptr;                     // Chimeric.out.sam (--chimOutType SeparateSAMold)
     FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
     std::string error;
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
@@ -114,6 +115,12 @@ struct Runner {
                 fputs("chr_donorA\tbrkpt_donorA\tstrand_donorA\tchr_acceptorB\tbrkpt_acceptorB\tstrand_acceptorB\tjunction_type\trepeat_left_lenA\trepeat_right_lenB\tread_name\t"
                       "start_alnA\tcigar_alnA\tstart_alnB\tcigar_alnB\tnum_chim_aln\tmax_poss_aln_score\tnon_chim_aln_score\tthis_chim_aln_score\tbestall_chim_aln_score\tPEmerged_bool\treadgrp\n", chimOut);
         }
+        if (P.chim.segmentMin > 0 && P.chim.outSamOld) {            // ParametersChimeric_initialize.cpp:39-42
+            std::string cp = P.outFileNamePrefix + "Chimeric.out.sam";
+            chimSamOut = fopen(cp.c_str(), "wb");
+            if (!chimSamOut) { error = "EXITING because of fatal ERROR: could not create output file " + cp; return false; }
+            std::string h = post->samHeader(); fwrite(h.data(), 1, h.size(), chimSamOut);
+        }
         if (P.outReadsUnmappedFastx)
             for (uint32_t m = 0; m < P.dev.readNmates; m++) {
                 std::string up = P.outFileNamePrefix + "Unmapped.out.mate" + std::to_string(m + 1);
@@ -190,7 +197,7 @@ struct Runner {
         const bool trSAM = P.quantTrSAM && quantOut && !pass1;       // twoPassRunPass1.cpp:24-29
         std::vector<std::string> qraws(trSAM ? T : 0); std::vector<std::vector<QuantPatch> > qpatches(trSAM ? T : 0);
         const bool chimOn = P.chim.segmentMin > 0 && !pass1;        // twoPassRunPass1.cpp:24: no chimeric detection in the 1st pass
-        std::vector<std::string> chims(chimOn ? T : 0);
+        std::vector<std::string> chims(chimOn ? T : 0), chimSams(chimOn && chimSamOut ? T : 0);
         const bool unm = P.outReadsUnmappedFastx && !pass1;
         std::vector<std::array<std::string, 2> > unms(unm ? T : 0);
         const bool randomOrder = P.outMultimapperRandom;
@@ -225,13 +232,13 @@ struct Runner {
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                              P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t]);
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                          nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t]);
         };
         if (T == 1) work(0);
         else {
@@ -262,6 +269,7 @@ struct Runner {
             }
         }
         if (chimOn && chimOut) for (uint32_t t = 0; t < T; t++) if (!chims[t].empty()) fwrite(chims[t].data(), 1, chims[t].size(), chimOut);
+        for (const std::string &cs : chimSams) if (!cs.empty()) fwrite(cs.data(), 1, cs.size(), chimSamOut);
         if (unm) for (uint32_t t = 0; t < T; t++) for (uint32_t m = 0; m < P.dev.readNmates; m++)
             if (!unms[t][m].empty() && unmappedOut[m]) fwrite(unms[t][m].data(), 1, unms[t][m].size(), unmappedOut[m]);
         if (P.outBAMcoord && !post->samOff)                         // keep the records for the coordinate sort at the end of the run (in memory)
@@ -374,6 +382,7 @@ struct Runner {
     bool finish() {
         stopWriter();
         for (FILE *&u : unmappedOut) if (u) { fclose(u); u = nullptr; }
+        if (chimSamOut) { fclose(chimSamOut); chimSamOut = nullptr; }
         if (quantOut) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), quantOut); if (quantOut == stdout) fflush(stdout); else fclose(quantOut); quantOut = nullptr; }
         if (chimOut) {
             if (P.chim.outJunctionFormat == 1)              // Stats::writeLines (Stats.cpp:147-155, STAR.cpp:285)

@@ -109,6 +109,17 @@ def test_chimeric_within_bam_stress(tag, mult, tmp_path, built):
     assert bam_parts(d + "/refW_Aligned.sortedByCoord.out.bam")[1:] == bam_parts(d + "/newW_Aligned.sortedByCoord.out.bam")[1:]
 
 
+@pytest.mark.parametrize("tag", ["pe", "se"])
+def test_chimeric_separate_sam_old(tag, tmp_path, built):
+    """--chimOutType SeparateSAMold: Chimeric.out.sam, the two segments as SAM records that point at each other; the linear alignments stay in Aligned.out.sam"""
+    info, d = _stress(tag, tmp_path)
+    info["extra"] = list(info["extra"]) + ["--chimOutType", "SeparateSAMold", "Junctions", "--outSAMattributes", "NH", "HI", "AS", "nM", "NM", "MD"]
+    _compare(info, d, lambda g, p: oracle_lib.Oracle(g, p), min_lines=400)
+    body = lambda p: [l for l in open(p, "rb") if not l.startswith(b"@")]
+    a, b = body(d + "/refC_Chimeric.out.sam"), body(d + "/newC_Chimeric.out.sam")
+    assert a == b and len(a) > 800
+
+
 # data sets made of chimeras: mates from different loci (junction type -1) and reads whose halves come from different loci (types 0 / 1 / 2)
 STRESS = {"pe": (dict(seed=9, chr_lengths=(300000, 250000, 200000), n_tr=100, n_reads=3000, read_len=125, paired=True, sub_rate=0.005, chim_rate=0.6),
                  ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "10", "--chimScoreDropMax", "80", "--chimScoreSeparation", "1", "--chimSegmentReadGapMax", "5"]),
