@@ -114,6 +114,7 @@ struct RunParams {
     std::string readFilesPrefix, readFilesManifest;         // --readFilesPrefix, --readFilesManifest (Parameters_readFilesInit.cpp:41-139)
     std::vector<std::string> outSAMheaderHD, outSAMheaderPG; std::string outSAMheaderCommentFile;   // samHeaders.cpp:56-96
     bool runDirPermAll = false, genomeLoadShared = false;
+    bool runModeFromBAM = false; std::string inputBAMfile;   // --runMode inputAlignmentsFromBAM --inputBAMfile: signal tracks from an existing BAM, no mapping
     int readFilesSAMmates = 0;           // --readFilesType SAM SE | PE: 1 | 2 (0 = Fastx)
     bool samAttrKeepAll = true, samAttrKeepNone = false; std::vector<std::string> samAttrKeep;   // --readFilesSAMattrKeep (BAM output only, Parameters_readFilesInit.cpp:13-31)
     uint32_t peOverlapNbasesMin = 0; double peOverlapMMp = 0.01;   // --peOverlapNbasesMin, --peOverlapMMp
@@ -294,7 +295,8 @@ bool mergedAlignToPair(ChimTr &o, const uint32_t mateStart[2], const staramd_tra
 int chimAlignScore(const staramd_params &D, const GenomeIndex &gi, const uint8_t *Read1, uint64_t Lread, ChimTr &c);
 
 // signal.cpp: coverage tracks from BAM records in coordinate order; error text or ""
-std::string writeSignal(const RunParams &P, const GenomeIndex &gi, const std::string &sigFileName, const std::vector<const char *> &recs);
+std::string writeSignal(const RunParams &P, const std::vector<std::string> &chrName, const std::vector<uint64_t> &chrLength, const std::string &sigFileName, const std::vector<const char *> &recs);
+std::string signalFromBamFile(const RunParams &P, const std::string &bamPath, const std::string &sigFileName);   // --runMode inputAlignmentsFromBAM
 
 // ---- post-map: multMapSelect, mappedFilter, outputAlignments ----
 class PostMap {

@@ -25,6 +25,7 @@ const staramd_genome *sah_genome(void *h);
 const staramd_params *sah_params(void *h);
 uint64_t sah_batch_reads(void *h);
 int sah_device(void *h);
+int sah_tool_done(void *h);
 int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
 int sah_emit_slot(void *h, int slot, const staramd_results *res);
 int sah_merged_slot(void *h, int slot, staramd_batch *out);
@@ -56,6 +57,7 @@ int main(int argc, char **argv) {
     char err[4096];
     void *h = sah_create(argc, argv, err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }
+    if (sah_tool_done(h)) { sah_destroy(h); return 0; }          // --runMode inputAlignmentsFromBAM: nothing to map
     const uint64_t batchReads = sah_batch_reads(h);
     staramd_ctx *ctx = nullptr;
     int rc = staramd_create(&ctx, sah_device(h), sah_genome(h), sah_params(h), (uint32_t)batchReads, 0);

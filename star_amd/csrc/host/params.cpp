@@ -103,7 +103,8 @@ std::string RunParams::parse(int argc, char **argv) {
     std::map<std::string, std::vector<std::string> > clipArgs;
     for (auto &e : kv) {
         const std::string &k = e.first; const std::vector<std::string> &v = e.second;
-        if (k == "runMode") { if (one(k, v) != "alignReads") err = "EXITING: only --runMode alignReads is implemented by the MI355X engine (index generation: use reference STAR)"; }
+        if (k == "runMode") { const std::string &m = one(k, v); if (m == "inputAlignmentsFromBAM") runModeFromBAM = true; else if (m != "alignReads") err = "EXITING: --runMode " + m + " is not implemented: alignReads and inputAlignmentsFromBAM are (index generation: use reference STAR)"; }
+        else if (k == "inputBAMfile") { if (one(k, v) != "-") inputBAMfile = one(k, v); }
         else if (k == "genomeDir") genomeDir = one(k, v);
         else if (k == "readFilesIn") readFilesIn = v;
         else if (k == "outFileNamePrefix") outFileNamePrefix = one(k, v);
@@ -337,6 +338,11 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
+    if (runModeFromBAM) {                    // Parameters.cpp:585-605
+        if (!wig.yes) return "EXITING because of fatal INPUT error: at the moment --runMode inputFromBAM only works with --outWigType bedGraph OR --bamRemoveDuplicatesType Identical\nSOLUTION: re-run STAR with --outWigType bedGraph (duplicate removal is not implemented here)\n";
+        if (inputBAMfile.empty()) return "EXITING because of fatal INPUT error: --runMode inputAlignmentsFromBAM needs --inputBAMfile";
+        return "";
+    }
     if (!readFilesManifest.empty()) {        // Parameters_readFilesInit.cpp:100-139: Read1 <tab> Read2 (or -) <tab> read group line
         std::ifstream rfM(readFilesManifest.c_str());
         if (!rfM.good()) return "EXITING because of fatal INPUT error: could not open input file " + readFilesManifest + "\nSOLUTION: check the path and permissions for readFilesManifest = " + readFilesManifest + "\n";

@@ -30,6 +30,7 @@ struct Runner {
     OutSJ sj;
     Stats stats;
     FILE *samOut = nullptr;
+    bool toolDone = false;                          // --runMode inputAlignmentsFromBAM: everything happened in init()
     FILE *chimOut = nullptr;                        // Chimeric.out.junction
     FILE *chimSamOut = nullptr;                     // Chimeric.out.sam (--chimOutType SeparateSAMold)
     FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
@@ -56,6 +57,11 @@ struct Runner {
         time(&stats.timeStart);
         error = P.parse(argc, argv);
         if (!error.empty()) return false;
+        if (P.runModeFromBAM) {                                     // a tool mode: no index, no reads, no engine
+            error = signalFromBamFile(P, P.inputBAMfile, P.outFileNamePrefix + "Signal");
+            toolDone = true;
+            return error.empty();
+        }
         error = gi.load(P.genomeDir);
         if (!error.empty()) return false;
         if (P.sjdbInsertYes()) {
@@ -334,7 +340,7 @@ struct Runner {
         if (P.wig.yes && !failed) {                                 // STAR.cpp:275-283: signal tracks from the sorted alignments
             std::vector<const char *> recs(n);
             for (uint64_t i = 0; i < n; i++) { const BamKey &k = K[ord[i]]; recs[i] = coordChunks[k.chunk].data() + k.off; }
-            std::string werr = writeSignal(P, gi, P.outFileNamePrefix + "Signal", recs);
+            std::string werr = writeSignal(P, std::vector<std::string>(gi.chrName.begin(), gi.chrName.begin() + gi.view.nChrReal), std::vector<uint64_t>(gi.chrLength.begin(), gi.chrLength.begin() + gi.view.nChrReal), P.outFileNamePrefix + "Signal", recs);
             if (!werr.empty()) return werr;
         }
         coordChunks.clear(); coordKeys.clear();
@@ -424,6 +430,7 @@ void *sah_create(int argc, char **argv, char *errbuf, int errlen) {
 const staramd_genome *sah_genome(void *h) { return &((Runner *)h)->gi.view; }
 const staramd_params *sah_params(void *h) { return &((Runner *)h)->P.dev; }
 uint64_t sah_batch_reads(void *h) { return ((Runner *)h)->P.gpuBatchReads; }
+int sah_tool_done(void *h) { return ((Runner *)h)->toolDone ? 1 : 0; }     // 1: the run was a tool mode (--runMode inputAlignmentsFromBAM) and is finished
 int sah_device(void *h) { return ((Runner *)h)->P.gpuDevice; }
 double sah_genome_load_seconds(void *h) { return ((Runner *)h)->gi.loadSeconds; }
 int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {

@@ -4,6 +4,7 @@
 #include "host.h"
 #include <cstring>
 #include <cstdio>
+#include <zlib.h>
 
 namespace staramd {
 
@@ -39,9 +40,9 @@ bool auxInt(const char *rec, const char tag[2], int64_t &val) {
 }
 }
 
-std::string writeSignal(const RunParams &P, const GenomeIndex &gi, const std::string &sigFileName, const std::vector<const char *> &recs) {
+std::string writeSignal(const RunParams &P, const std::vector<std::string> &chrName, const std::vector<uint64_t> &chrLength, const std::string &sigFileName, const std::vector<const char *> &recs) {
     const WigParams &W = P.wig;
-    auto wanted = [&](int32_t tid) { return W.referencesPrefix.empty() || gi.chrName[tid].compare(0, W.referencesPrefix.size(), W.referencesPrefix) == 0; };
+    auto wanted = [&](int32_t tid) { return W.referencesPrefix.empty() || chrName[tid].compare(0, W.referencesPrefix.size(), W.referencesPrefix) == 0; };
     double nMult = 0, nUniq = 0;
     if (W.norm == 1) {
         for (const char *rec : recs) {
@@ -70,14 +71,14 @@ std::string writeSignal(const RunParams &P, const GenomeIndex &gi, const std::st
         if (iChr == -999) return;
         for (int is = 0; is < sigN; is++) {
             FILE *f = out[is];
-            if (W.format == 1) fprintf(f, "variableStep chrom=%s\n", gi.chrName[iChr].c_str());
+            if (W.format == 1) fprintf(f, "variableStep chrom=%s\n", chrName[iChr].c_str());
             double prevSig = 0;
             for (uint32_t ig = 0; ig < chrLen; ig++) {
                 const double newSig = sigAll[(size_t)sigN * ig + is];
                 if (W.format == 0) {
                     if (newSig != prevSig) {
                         if (prevSig != 0) { fprintf(f, "%u\t", ig); num(f, prevSig * normFactor[is]); fputc('\n', f); }
-                        if (newSig != 0) fprintf(f, "%s\t%u\t", gi.chrName[iChr].c_str(), ig);
+                        if (newSig != 0) fprintf(f, "%s\t%u\t", chrName[iChr].c_str(), ig);
                         prevSig = newSig;
                     }
                 } else if (newSig != 0) { fprintf(f, "%u\t", ig + 1); num(f, newSig * normFactor[is]); fputc('\n', f); }
@@ -92,7 +93,7 @@ std::string writeSignal(const RunParams &P, const GenomeIndex &gi, const std::st
             if (!rec) break;
             iChr = tid;
             if (iChr == -1 || !wanted(iChr)) { iChr = -999; continue; }
-            chrLen = (uint32_t)gi.chrLength[iChr] + 1;                 // one extra base at the end, always 0
+            chrLen = (uint32_t)chrLength[iChr] + 1;                 // one extra base at the end, always 0
             sigAll.assign((size_t)sigN * chrLen, 0.0);
         }
         if (iChr == -999) continue;
@@ -126,6 +127,43 @@ std::string writeSignal(const RunParams &P, const GenomeIndex &gi, const std::st
     }
     for (int is = 0; is < sigN; is++) fclose(out[is]);
     return "";
+}
+
+// --runMode inputAlignmentsFromBAM --inputBAMfile x.bam --outWigType ... (Parameters.cpp:585-592): the same tracks from a coordinate-sorted BAM file.
+// The file is inflated block by block (BGZF = concatenated gzip members) and held in memory; chromosome names and lengths come from its header.
+std::string signalFromBamFile(const RunParams &P, const std::string &bamPath, const std::string &sigFileName) {
+    gzFile in = gzopen(bamPath.c_str(), "rb");
+    if (!in) return "EXITING because of fatal INPUT error: could not open --inputBAMfile " + bamPath;
+    std::vector<char> d;
+    for (;;) {
+        const size_t old = d.size(), block = 1u << 24;
+        d.resize(old + block);
+        int got = gzread(in, d.data() + old, (unsigned)block);
+        if (got < 0) { gzclose(in); return "EXITING because of fatal INPUT error: could not decompress --inputBAMfile " + bamPath; }
+        d.resize(old + (size_t)got);
+        if ((size_t)got < block) break;
+    }
+    gzclose(in);
+    if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) return "EXITING because of fatal INPUT error: --inputBAMfile " + bamPath + " is not a BAM file";
+    size_t p = 8 + rd32(d.data() + 4);
+    if (p + 4 > d.size()) return "EXITING because of fatal INPUT error: truncated BAM header in " + bamPath;
+    const uint32_t nRef = rd32(d.data() + p); p += 4;
+    std::vector<std::string> chrName; std::vector<uint64_t> chrLength;
+    for (uint32_t i = 0; i < nRef; i++) {
+        if (p + 4 > d.size()) return "EXITING because of fatal INPUT error: truncated BAM header in " + bamPath;
+        const uint32_t ln = rd32(d.data() + p); p += 4;
+        if (p + ln + 4 > d.size()) return "EXITING because of fatal INPUT error: truncated BAM header in " + bamPath;
+        chrName.emplace_back(d.data() + p, ln ? ln - 1 : 0); p += ln;
+        chrLength.push_back(rd32(d.data() + p)); p += 4;
+    }
+    std::vector<const char *> recs;
+    while (p + 4 <= d.size()) {
+        const uint32_t bs = rd32(d.data() + p);
+        if (p + 4 + bs > d.size()) break;
+        recs.push_back(d.data() + p);
+        p += 4 + bs;
+    }
+    return writeSignal(P, chrName, chrLength, sigFileName, recs);
 }
 
 } // namespace staramd

@@ -37,3 +37,23 @@ def test_signal_needs_sorted_bam(tmp_path, built):
     with pytest.raises(RuntimeError) as e:
         capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "e_"), "--outWigType", "bedGraph"])
     assert "generating signal with --outWigType requires sorted BAM" in str(e.value)
+
+
+def test_signal_from_bam_file_with_the_cli(tmp_path, built):
+    """--runMode inputAlignmentsFromBAM --inputBAMfile x --outWigType ...: ENCODE's second step.  A tool mode of the star_amd binary: no index, no reads, no GPU."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "star_amd", "bin", "star_amd")
+    info = dict(prepare("pe101", str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "refB_"), threads=1, extra=list(info["extra"]) + ["--outSAMtype", "BAM", "SortedByCoordinate"])
+    bam = ref + "Aligned.sortedByCoord.out.bam"
+    for k, flags in enumerate((["--outWigType", "bedGraph"], ["--outWigType", "wiggle", "read1_5p", "--outWigStrand", "Unstranded", "--outWigNorm", "None", "--outWigReferencesPrefix", "chr1"])):
+        a, b = os.path.join(d, "sigref%d_" % k), os.path.join(d, "signew%d_" % k)
+        subprocess.check_call([refstar.REF_BIN, "--runMode", "inputAlignmentsFromBAM", "--inputBAMfile", bam, "--outFileNamePrefix", a] + flags, stdout=subprocess.DEVNULL)
+        subprocess.check_call([cli, "--runMode", "inputAlignmentsFromBAM", "--inputBAMfile", bam, "--outFileNamePrefix", b] + flags)
+        files = sorted(f[len("sigref%d_" % k):] for f in os.listdir(d) if f.startswith("sigref%d_Signal." % k))
+        assert len(files) in (2, 4)
+        for f in files:
+            assert open(a + f, "rb").read() == open(b + f, "rb").read(), f
+    r = subprocess.run([cli, "--runMode", "inputAlignmentsFromBAM", "--inputBAMfile", bam, "--outFileNamePrefix", os.path.join(d, "x_")], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"--runMode inputFromBAM only works with --outWigType" in r.stderr
