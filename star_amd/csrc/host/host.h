@@ -317,23 +317,23 @@ public:
                              std::string *chimSam = nullptr) const;               // Chimeric.out.sam records (--chimOutType SeparateSAMold)   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
     // nAlignT (with --quantMode TranscriptomeSAM): per read, the number of transcriptomic alignments + 1 where the read draws its primary one
     // right after its shuffles (ReadAlign_quantTranscriptome.cpp:69), 0 where it does not
-    template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr) const {
+    template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr,
+                                            const MergedBatch *merged = nullptr, const staramd_results *mergedRes = nullptr) const {
         o.offset.assign(b.n + 1, 0); o.partner.clear(); o.quantPick.assign(nAlignT ? b.n : 0, 0);
         for (uint32_t ir = 0; ir < b.n; ir++) {
-            const staramd_read_result &rr = r.reads[ir];
             o.offset[ir] = o.partner.size();
-            struct AtExit { const std::vector<uint32_t> *n; MultOrder &o; uint32_t ir; Rng &u; ~AtExit() { if (n && (*n)[ir]) o.quantPick[ir] = (uint32_t)(int)(u() * ((*n)[ir] - 1)); } } quantDraw{nAlignT, o, ir, uniform01};
-            if (rr.nW == 0 || rr.trBest < 0) continue;
-            const staramd_transcript *T = r.tr + rr.trOffset;
-            const int maxScore = T[rr.trBest].maxScore;
             uint64_t nTr = 0, nbest = 0;
-            for (uint32_t k = 0; k < rr.nTr; k++) if (T[k].maxScore + P.dev.outFilterMultimapScoreRange >= maxScore) { nTr++; if (T[k].maxScore == maxScore) nbest++; }
-            if (nTr > P.outFilterMultimapNmax || nTr < 2) continue;
-            for (int itr = (int)nbest - 1; itr >= 1; itr--) o.partner.push_back((uint32_t)int(uniform01() * itr + 0.5));
-            for (int itr = (int)(nTr - nbest) - 1; itr >= 1; itr--) o.partner.push_back((uint32_t)int(uniform01() * itr + 0.5));
+            multCounts(b, r, ir, merged, mergedRes, nTr, nbest);
+            if (!(nTr > P.outFilterMultimapNmax || nTr < 2)) {
+                for (int itr = (int)nbest - 1; itr >= 1; itr--) o.partner.push_back((uint32_t)int(uniform01() * itr + 0.5));
+                for (int itr = (int)(nTr - nbest) - 1; itr >= 1; itr--) o.partner.push_back((uint32_t)int(uniform01() * itr + 0.5));
+            }
+            if (nAlignT && (*nAlignT)[ir]) o.quantPick[ir] = (uint32_t)(int)(uniform01() * ((*nAlignT)[ir] - 1));
         }
         o.offset[b.n] = o.partner.size();
     }
+    // multMapSelect's counts for one read: alignments within the score range of the best, and how many of them tie with it (after mate merging, if any)
+    void multCounts(const ReadBatch &b, const staramd_results &r, uint32_t ir, const MergedBatch *merged, const staramd_results *mergedRes, uint64_t &nTr, uint64_t &nbest) const;
     const GeneAnnotation *genes = nullptr;           // --quantMode GeneCounts
     const TranscriptAnnotation *transcripts = nullptr;   // --quantMode TranscriptomeSAM
     std::string quantBamHeader() const;              // samHeaders.cpp:8-20

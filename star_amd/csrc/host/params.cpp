@@ -379,7 +379,6 @@ std::string RunParams::parse(int argc, char **argv) {
     if (outSJnone && outFilterBySJout) return "EXITING because of FATAL input ERROR: --outFilterType BySJout requires --outSJtype Standard\nSOLUTION: --outFilterType Normal    OR   --outFilterType BySJout --outSJtype Standard\n";
     if (outSJnone && twopass) return "EXITING because of FATAL input ERROR: --twopassMode Basic needs the junctions of the 1st pass, i.e. --outSJtype Standard\n";
     if (twopass && genomeLoadShared) return "EXITING because of fatal PARAMETERS error: 2-pass method is not compatible with genomeLoad shared memory options\nSOLUTION: re-run STAR with --genomeLoad NoSharedMemory ; this is the only option compatible with --twopassMode Basic .\n";
-    if (outSAMunmappedKeepPairs && outBAMunsorted && outBAMcoord) return "EXITING: --outSAMunmapped Within KeepPairs with both BAM Unsorted and SortedByCoordinate in one run is not implemented; run one of the two";
     {   // read groups: one for all input files or one per file; the RG attribute comes with them (Parameters_readFilesInit.cpp:84-93, Parameters_samAttributes.cpp:201-206)
         size_t nFiles = readFilesIn.empty() ? 0 : (size_t)std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') + 1;
         if (outSAMattrRG.size() > 1 && outSAMattrRG.size() != nFiles)

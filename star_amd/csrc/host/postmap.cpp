@@ -666,6 +666,26 @@ static int mergedReadToPair(const RunParams &P, const GenomeIndex &gi, const uin
     return best;
 }
 
+void PostMap::multCounts(const ReadBatch &b, const staramd_results &r, uint32_t ir, const MergedBatch *merged, const staramd_results *mergedRes, uint64_t &nTr, uint64_t &nbest) const {
+    nTr = nbest = 0;
+    const staramd_read_result &rr = r.reads[ir];
+    const staramd_transcript *T = r.tr + rr.trOffset; uint32_t nTrAll = rr.nTr; int best = (rr.nW > 0 && rr.trBest >= 0) ? rr.trBest : -1;
+    std::vector<staramd_transcript> pairT; std::vector<staramd_exon> pairE;
+    if (merged && merged->index[ir] >= 0 && mergedRes->reads[merged->index[ir]].nW > 0) {
+        const uint32_t mi = (uint32_t)merged->index[ir];
+        const staramd_read_result &mr = mergedRes->reads[mi];
+        const ReadAligns se{mergedRes->tr + mr.trOffset, mr.nTr, mergedRes->ex};
+        const uint64_t Lread = b.readOffset[ir + 1] - b.readOffset[ir];
+        const uint64_t readLength[2] = {b.mate1Length[ir], Lread - b.mate1Length[ir] - 1};
+        uint32_t nW = 0;
+        best = mergedReadToPair(P, gi, b.bases.data() + b.readOffset[ir], Lread, readLength, merged->mateStart[ir].data(), se, merged->reads.readOffset[mi + 1] - merged->reads.readOffset[mi], pairT, pairE, nW);
+        T = pairT.data(); nTrAll = (uint32_t)pairT.size();
+    }
+    if (best < 0) return;
+    const int maxScore = T[best].maxScore;
+    for (uint32_t k = 0; k < nTrAll; k++) if (T[k].maxScore + P.dev.outFilterMultimapScoreRange >= maxScore) { nTr++; if (T[k].maxScore == maxScore) nbest++; }
+}
+
 std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st) {
     return processRange(b, r, 0, b.n, sam, sj, st);
 }
@@ -874,7 +894,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             const bool keepPairs = P.outSAMunmappedKeepPairs;
             if (!samOff) for (uint64_t it = 0; it < nTrWrite; it++) {
                 if (bam) bamMapped(sam, P, gi, rc, trMult[it], nTr, it, bamKeys); else samMapped(sam, P, gi, rc, trMult[it], nTr, it);
-                if (keepPairs && !P.outBAMcoord) {   // ReadAlign_outputAlignments.cpp:178-195: the unmapped mate right after every one-mate alignment (not in the sorted BAM)
+                if (keepPairs && (!P.outBAMcoord || P.outBAMunsorted)) {   // ReadAlign_outputAlignments.cpp:178-195: the unmapped mate right after every one-mate alignment (no sort key: not in the sorted BAM)
                     const staramd_transcript &t = *trMult[it].t;
                     bool mateMapped1[2] = {false, false};
                     mateMapped1[trMult[it].ex[0].iFrag] = true; mateMapped1[trMult[it].ex[t.nExons - 1].iFrag] = true;
@@ -889,10 +909,18 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             if (unmapType == 4 && P.outSAMunmappedWithin && !samOff && (!keepPairs || P.outBAMcoord)) {     // :216-233
                 bool trBestSecondary = false;
                 if (keepPairs) { trBestSecondary = true; for (uint64_t it = 0; it < nTr; it++) if (trMult[it].t == trBest && trMult[it].primary) trBestSecondary = false; }
-                if (bam) bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped, bamKeys, trBestSecondary); else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
+                if (bam) {
+                    const size_t k0 = bamKeys ? bamKeys->size() : 0;
+                    bamUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped, bamKeys, trBestSecondary);
+                    if (keepPairs && P.outBAMunsorted && bamKeys) for (size_t k = k0; k < bamKeys->size(); k++) (*bamKeys)[k].len |= 0x80000000u;   // for the sorted BAM only: cut out of the unsorted stream
+                } else samUnmapped(sam, P, gi, rc, trBest, exB, unmapType, mateMapped);
             }
+        } else if (P.outSAMunmappedWithin && quantBam && samOff) {        // no alignment output, but the transcriptome BAM still gets the unmapped reads (:237-245)
+            staramd_transcript t0; memset(&t0, 0, sizeof(t0));
+            bamUnmapped(*quantBam, P, gi, rc, trBest ? trBest : &t0, trBest ? EX + trBest->exonOffset : nullptr, unmapType, mateMapped, nullptr);
         } else if (P.outSAMunmappedWithin && !samOff) {
             staramd_transcript t0; memset(&t0, 0, sizeof(t0));
+            if (quantBam) bamUnmapped(*quantBam, P, gi, rc, trBest ? trBest : &t0, trBest ? EX + trBest->exonOffset : nullptr, unmapType, mateMapped, nullptr);   // :243-245
             if (bam) bamUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? EX + trBest->exonOffset : nullptr, unmapType, mateMapped, bamKeys);
             else samUnmapped(sam, P, gi, rc, trBest ? trBest : &t0, trBest ? EX + trBest->exonOffset : nullptr, unmapType, mateMapped);
         }

@@ -228,7 +228,7 @@ struct Runner {
                 count(0);
                 for (auto &x : th) x.join();
             }
-            post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder, trSAM ? &nAlignT : nullptr);
+            post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder, trSAM ? &nAlignT : nullptr, mg, mgRes);
         }
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
@@ -239,6 +239,15 @@ struct Runner {
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                              P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
                                              trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t]);
+                bool cut = false;
+                if (P.outBAMcoord) for (const BamKey &k : keyss[t]) if (k.len & 0x80000000u) { cut = true; break; }
+                if (cut) {                                           // KeepPairs with both BAM files: records that belong to the sorted one only
+                    std::string only; size_t pos = 0;
+                    for (BamKey &k : keyss[t]) if (k.len & 0x80000000u) { k.len &= 0x7fffffffu; only.append(raw, pos, k.off - pos); pos = k.off + k.len; }
+                    only.append(raw, pos, std::string::npos);
+                    if (errs[t].empty() && !bgzfCompress(only, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
+                    return;
+                }
                 if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }

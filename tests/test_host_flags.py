@@ -210,7 +210,7 @@ def test_random_order_with_transcriptome_bam(paired, more, tmp_path, built):
     assert open(ref + "ReadsPerGene.out.tab", "rb").read() == open(new + "ReadsPerGene.out.tab", "rb").read()
 
 
-@pytest.mark.parametrize("mode", ["sam", "bam_unsorted", "bam_sorted", "sam_random"])
+@pytest.mark.parametrize("mode", ["sam", "bam_unsorted", "bam_sorted", "bam_both", "sam_random"])
 def test_keep_pairs(mode, tmp_path, built):
     """--outSAMunmapped Within KeepPairs: the unmapped mate follows every one-mate alignment of a multimapper (secondary where the alignment is);
     the sorted BAM keeps one unmapped record per read"""
@@ -236,11 +236,12 @@ def test_keep_pairs(mode, tmp_path, built):
         flag = lambda l: int(l.split(b"\t")[1])
         assert sum(1 for l in a if flag(l) & 0x4 and flag(l) & 0x100) > 0
     else:
-        kind = "Unsorted" if mode == "bam_unsorted" else "SortedByCoordinate"
-        ref, new = _both(info, "kpb", flags + ["--outSAMtype", "BAM", kind])
-        f = "Aligned.out.bam" if mode == "bam_unsorted" else "Aligned.sortedByCoord.out.bam"
-        (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + f), bam_parts(new + f)
-        assert ra == rb and rr == nr
+        kinds = {"bam_unsorted": ["Unsorted"], "bam_sorted": ["SortedByCoordinate"], "bam_both": ["Unsorted", "SortedByCoordinate"]}[mode]
+        ref, new = _both(info, "kpb", flags + ["--outSAMtype", "BAM"] + kinds)
+        for kind in kinds:
+            f = "Aligned.out.bam" if kind == "Unsorted" else "Aligned.sortedByCoord.out.bam"
+            (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + f), bam_parts(new + f)
+            assert ra == rb and rr == nr, f
 
 
 def test_alignments_to_stdout(tmp_path, built):

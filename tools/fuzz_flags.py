@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Random flag combinations against the reference (CPU): the host library driven by the oracle vs oracle/_ref/STAR with the same flags on the same data.
+Not part of the test suite; a bug hunt.  usage: tools/fuzz_flags.py [iterations] [seed]   -- failures are listed with the command line that reproduces them."""
+import os
+import random
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from util import bam_parts, compare_outputs, oracle_lib, prepare, refstar, run_with_engine   # noqa: E402
+
+POOL = [   # (flags, needs paired)
+    (["--outSAMunmapped", "Within"], 0), (["--outSAMunmapped", "Within", "KeepPairs"], 1), (["--outFilterType", "BySJout"], 0), (["--twopassMode", "Basic"], 0),
+    (["--outSAMattributes", "NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC"], 0), (["--outSAMstrandField", "intronMotif"], 0), (["--outSAMprimaryFlag", "AllBestScore"], 0),
+    (["--outFilterMultimapNmax", "3"], 0), (["--outFilterMultimapNmax", "40", "--winAnchorMultimapNmax", "80"], 0), (["--outFilterMultimapScoreRange", "4"], 0),
+    (["--outSAMmultNmax", "2"], 0), (["--outMultimapperOrder", "Random"], 0), (["--outMultimapperOrder", "Random", "--runRNGseed", "99"], 0),
+    (["--alignEndsType", "EndToEnd"], 0), (["--alignEndsType", "Extend5pOfRead1"], 0), (["--alignEndsType", "Extend5pOfReads12"], 1),
+    (["--alignEndsProtrude", "15", "ConcordantPair"], 1), (["--alignEndsProtrude", "8", "DiscordantPair"], 1), (["--alignInsertionFlush", "Right"], 0),
+    (["--alignSoftClipAtReferenceEnds", "No"], 0), (["--alignIntronMax", "5000", "--alignMatesGapMax", "5000"], 0), (["--alignSJoverhangMin", "3", "--alignSJDBoverhangMin", "1"], 0),
+    (["--alignSplicedMateMapLmin", "30", "--alignSplicedMateMapLminOverLmate", "0"], 0), (["--scoreGap", "-2", "--scoreGapNoncan", "-4"], 0), (["--scoreGenomicLengthLog2scale", "0"], 0),
+    (["--scoreDelOpen", "-1", "--scoreInsOpen", "-1", "--scoreDelBase", "-1", "--scoreInsBase", "-1"], 0), (["--sjdbScore", "0"], 0), (["--seedSearchStartLmax", "25"], 0),
+    (["--seedSearchStartLmaxOverLread", "0.3"], 0), (["--seedSearchLmax", "30"], 0), (["--seedMultimapNmax", "200"], 0), (["--seedPerWindowNmax", "10"], 0),
+    (["--outFilterMismatchNmax", "3"], 0), (["--outFilterMismatchNoverLmax", "0.05"], 0), (["--outFilterMismatchNoverReadLmax", "0.04"], 0),
+    (["--outFilterScoreMinOverLread", "0.3", "--outFilterMatchNminOverLread", "0.3"], 0), (["--outFilterIntronMotifs", "RemoveNoncanonical"], 0),
+    (["--outFilterIntronMotifs", "RemoveNoncanonicalUnannotated"], 0), (["--outFilterIntronStrands", "None"], 0), (["--outSJfilterReads", "Unique"], 0),
+    (["--outSJfilterOverhangMin", "20", "8", "8", "8"], 0), (["--outSJfilterCountUniqueMin", "1", "1", "1", "1", "--outSJfilterCountTotalMin", "1", "1", "1", "1"], 0),
+    (["--clip5pNbases", "3"], -1), (["--clip3pNbases", "4", "2"], 1), (["--clip3pAdapterSeq", "AGATCGGAAG"], -1), (["--clip3pAdapterSeq", "AGATCGGAAG", "CTGTCTCTTA", "--clip3pAdapterMMp", "0.1", "0.2"], 1),
+    (["--peOverlapNbasesMin", "10", "--peOverlapMMp", "0.1"], 1), (["--peOverlapNbasesMin", "5"], 1),
+    (["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "10"], 0), (["--chimSegmentMin", "15", "--chimMultimapNmax", "10", "--chimNonchimScoreDropMin", "10"], 0),
+    (["--chimSegmentMin", "12", "--chimScoreDropMax", "40", "--chimScoreSeparation", "3", "--chimSegmentReadGapMax", "3", "--chimMainSegmentMultNmax", "2"], 0),
+    (["--quantMode", "GeneCounts"], 0), (["--quantMode", "TranscriptomeSAM"], 0), (["--quantMode", "TranscriptomeSAM", "GeneCounts", "--quantTranscriptomeSAMoutput", "BanSingleEnd"], 0),
+    (["--outSAMreadID", "Number"], 0), (["--outReadsUnmapped", "Fastx"], 0), (["--outSAMtlen", "2"], 0), (["--outSAMflagOR", "1024"], 0), (["--outSAMmapqUnique", "50"], 0),
+    (["--outSAMattrIHstart", "0"], 0), (["--outQSconversionAdd", "-5"], 0), (["--outSAMmode", "NoQS"], 0), (["--winBinNbits", "14", "--winAnchorDistNbins", "5"], 0),
+    (["--alignTranscriptsPerReadNmax", "50", "--alignTranscriptsPerWindowNmax", "5"], 0),
+]   # (--alignWindowsPerReadNmax with a small value is left out: the reference itself dies with SIGSEGV on it)
+OUTTYPES = [[], [], [], ["--outSAMtype", "BAM", "Unsorted"], ["--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate"], ["--outSAMtype", "BAM", "SortedByCoordinate", "--outWigType", "bedGraph"]]
+DATA = ["pe101", "se50", "pe150_indel", "pe76_overlap", "pe150_chim", "pe101_sparse3"]
+
+
+def key(flags):
+    return flags[0] if flags[0] not in ("--outSAMunmapped",) else flags[0]
+
+
+def one(it, rng, keep):
+    name = rng.choice(DATA)
+    work = tempfile.mkdtemp(prefix="fuzz%04d_" % it)
+    info = dict(prepare(name, work, need_ref=False))
+    paired = len(info["fastq"]) == 2
+    used = set(x for x in info["extra"] if x.startswith("--"))
+    flags = []
+    for fl, need in rng.sample(POOL, rng.randrange(2, 7)):
+        if need == 1 and not paired:
+            continue
+        if need == -1 and paired:
+            fl = [fl[0]] + [v for v in fl[1:] for _ in (0, 1)] if len(fl) == 2 else fl
+        names = [x for x in fl if x.startswith("--")]
+        if any(n in used for n in names):
+            continue
+        used.update(names)
+        flags += fl
+    out = rng.choice(OUTTYPES)
+    if "--chimSegmentMin" in flags and "--peOverlapNbasesMin" in flags and "--chimMultimapNmax" not in flags:
+        flags += ["--chimMultimapNmax", "5"]
+    if "--chimSegmentMin" in flags and out and rng.random() < 0.5 and "--chimMultimapNmax" in flags:
+        flags += ["--chimOutType", "WithinBAM", "Junctions"]
+    if "--quantMode" in flags and "GeneCounts" in flags and name == "se50":
+        pass
+    info["extra"] = list(info["extra"]) + flags + out
+    if name == "se50" and "--quantMode" in flags:
+        info["extra"] += ["--sjdbGTFfile", info["gtf"]]
+    d = os.path.dirname(info["fastq"][0])
+    problems = []
+    print("run  [%d] %s %s" % (it, name, " ".join(info["extra"])), flush=True)
+    try:
+        ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=info["extra"])
+    except Exception as e:       # the reference rejects the combination: ours must too
+        try:
+            run_with_engine(info, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=rng.choice([300, 777, 5000]))
+            problems.append("reference failed (%s) but ours ran" % type(e).__name__)
+        except Exception:
+            pass
+        ref = None
+    if ref:
+        try:
+            new = run_with_engine(info, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=rng.choice([300, 777, 5000]))
+            if out and "Unsorted" in out:
+                (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + "Aligned.out.bam"), bam_parts(new + "Aligned.out.bam")
+                if ra != rb or rr != nr:
+                    problems.append("Aligned.out.bam differs (%d vs %d records)" % (len(rr), len(nr)))
+            elif not out:
+                problems += compare_outputs(ref, new)
+            for f in sorted(os.listdir(d)):
+                if not f.startswith("ref_") or os.path.isdir(os.path.join(d, f)):
+                    continue
+                g = f[4:]
+                if g in ("Aligned.out.sam", "Aligned.out.bam", "Log.out", "Log.progress.out", "Log.final.out", "Log.std.out"):
+                    continue
+                pa, pb = os.path.join(d, f), os.path.join(d, "new_" + g)
+                if not os.path.exists(pb):
+                    problems.append("missing output " + g); continue
+                if g.endswith(".bam"):
+                    if bam_parts(pa)[1:] != bam_parts(pb)[1:]:
+                        problems.append(g + " differs")
+                elif g == "Chimeric.out.junction":
+                    L = lambda p: [l for l in open(p) if not l.startswith("# 2.7.11b")]
+                    if L(pa) != L(pb):
+                        problems.append(g + " differs")
+                elif open(pa, "rb").read() != open(pb, "rb").read():
+                    problems.append(g + " differs")
+            if refstar.final_log_counters(ref + "Log.final.out") != refstar.final_log_counters(new + "Log.final.out"):
+                problems.append("Log.final.out counters differ")
+        except Exception as e:
+            problems.append("ours failed: %s" % str(e)[:300])
+    tag = "%s %s" % (name, " ".join(info["extra"]))
+    if problems:
+        print("FAIL [%d] %s\n      %s\n      kept in %s" % (it, tag, "; ".join(sorted(set(problems)))[:600], work), flush=True)
+    else:
+        print("ok   [%d] %s" % (it, tag), flush=True)
+        if not keep:
+            shutil.rmtree(work, ignore_errors=True)
+    return not problems
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    bad = sum(0 if one(i, rng, False) else 1 for i in range(n))
+    print("%d of %d combinations differ" % (bad, n))
