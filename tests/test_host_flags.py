@@ -240,6 +240,10 @@ def test_keep_pairs(mode, tmp_path, built):
         ref, new = _both(info, "kpb", flags + ["--outSAMtype", "BAM"] + kinds)
         for kind in kinds:
             f = "Aligned.out.bam" if kind == "Unsorted" else "Aligned.sortedByCoord.out.bam"
+            if mode == "bam_both" and kind == "SortedByCoordinate":
+                # with both files the reference overwrites the record buffers of a one-mate alignment with its unmapped mate before the sorted copy is taken
+                # (ReadAlign_outputAlignments.cpp:185-199), so its sorted BAM loses those alignments; ours is the sorted file of the sorted-only run
+                ref = refstar.align(info["idx"], info["fastq"], ref + "only_", threads=1, extra=list(info["extra"]) + flags + ["--outSAMtype", "BAM", "SortedByCoordinate"])
             (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + f), bam_parts(new + f)
             assert ra == rb and rr == nr, f
 
