@@ -34,6 +34,11 @@ POOL = [   # (flags, needs paired)
     (["--outSAMreadID", "Number"], 0), (["--outReadsUnmapped", "Fastx"], 0), (["--outSAMtlen", "2"], 0), (["--outSAMflagOR", "1024"], 0), (["--outSAMmapqUnique", "50"], 0),
     (["--outSAMattrIHstart", "0"], 0), (["--outQSconversionAdd", "-5"], 0), (["--outSAMmode", "NoQS"], 0), (["--winBinNbits", "14", "--winAnchorDistNbins", "5"], 0),
     (["--alignTranscriptsPerReadNmax", "50", "--alignTranscriptsPerWindowNmax", "5"], 0),
+    (["--chimSegmentMin", "12", "--chimOutType", "SeparateSAMold", "Junctions"], 0), (["--chimSegmentMin", "20", "--chimFilter", "None", "--chimScoreJunctionNonGTAG", "0", "--chimOutJunctionFormat", "1"], 0),
+    (["--outSJtype", "None"], 0), (["--quantMode", "TranscriptomeSAM", "--quantTranscriptomeSAMoutput", "BanSingleEnd_ExtendSoftclip"], 0), (["--quantMode", "TranscriptomeSAM", "--quantTranscriptomeBAMcompression", "-1"], 0),
+    (["--outSJfilterDistToOtherSJmin", "5", "0", "3", "5", "--outSJfilterIntronMaxVsReadN", "1000", "2000", "3000"], 0), (["--alignSJstitchMismatchNmax", "2", "-1", "2", "2"], 0),
+    (["--seedSplitMin", "8", "--seedMapMin", "3"], 0), (["--scoreStitchSJshift", "0"], 0), (["--outFilterScoreMin", "60"], 0), (["--outFilterMatchNmin", "70"], 0),
+    (["--readMapNumber", "700"], 0), (["--twopassMode", "Basic", "--twopass1readsN", "500"], 0), (["--winFlankNbins", "2"], 0), (["--limitOutSJcollapsed", "2000000"], 0),
 ]   # (--alignWindowsPerReadNmax with a small value is left out: the reference itself dies with SIGSEGV on it)
 OUTTYPES = [[], [], [], ["--outSAMtype", "BAM", "Unsorted"], ["--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate"], ["--outSAMtype", "BAM", "SortedByCoordinate", "--outWigType", "bedGraph"]]
 DATA = ["pe101", "se50", "pe150_indel", "pe76_overlap", "pe150_chim", "pe101_sparse3"]
@@ -63,8 +68,12 @@ def one(it, rng, keep):
     out = rng.choice(OUTTYPES)
     if "--chimSegmentMin" in flags and "--peOverlapNbasesMin" in flags and "--chimMultimapNmax" not in flags:
         flags += ["--chimMultimapNmax", "5"]
-    if "--chimSegmentMin" in flags and out and rng.random() < 0.5 and "--chimMultimapNmax" in flags:
-        flags += ["--chimOutType", "WithinBAM", "Junctions"]
+    if "--chimSegmentMin" in flags and out and rng.random() < 0.5 and "--chimOutType" not in flags and ("--chimMultimapNmax" in flags or "--peOverlapNbasesMin" not in flags):
+        flags += ["--chimOutType", "WithinBAM"] + (["Junctions"] if "--peOverlapNbasesMin" not in flags or "--chimMultimapNmax" in flags else []) + rng.choice([[], ["SoftClip"]])
+    if "SeparateSAMold" in flags and "--chimMultimapNmax" in flags:
+        k = flags.index("--chimMultimapNmax"); del flags[k:k + 2]
+    if "--outSJtype" in flags and ("--twopassMode" in flags or "--outFilterType" in flags):
+        k = flags.index("--outSJtype"); del flags[k:k + 2]
     if "--quantMode" in flags and "GeneCounts" in flags and name == "se50":
         pass
     info["extra"] = list(info["extra"]) + flags + out
@@ -84,13 +93,19 @@ def one(it, rng, keep):
         ref = None
     if ref:
         try:
-            new = run_with_engine(info, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=rng.choice([300, 777, 5000]))
+            ours = dict(info)
+            if rng.random() < 0.3 and "--outMultimapperOrder" not in flags and not ("--quantMode" in flags and "TranscriptomeSAM" in flags):
+                ours["extra"] = list(info["extra"]) + ["--runThreadN", "3"]       # threads on our side only: the outputs must not depend on them
+            new = run_with_engine(ours, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=rng.choice([300, 777, 5000]))
             if out and "Unsorted" in out:
                 (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + "Aligned.out.bam"), bam_parts(new + "Aligned.out.bam")
                 if ra != rb or rr != nr:
                     problems.append("Aligned.out.bam differs (%d vs %d records)" % (len(rr), len(nr)))
             elif not out:
-                problems += compare_outputs(ref, new)
+                if os.path.exists(ref + "SJ.out.tab"):
+                    problems += compare_outputs(ref, new)
+                elif refstar.sam_body_sorted(ref + "Aligned.out.sam") != refstar.sam_body_sorted(new + "Aligned.out.sam"):
+                    problems.append("SAM differs")
             for f in sorted(os.listdir(d)):
                 if not f.startswith("ref_") or os.path.isdir(os.path.join(d, f)):
                     continue
@@ -102,6 +117,10 @@ def one(it, rng, keep):
                     problems.append("missing output " + g); continue
                 if g.endswith(".bam"):
                     if bam_parts(pa)[1:] != bam_parts(pb)[1:]:
+                        problems.append(g + " differs")
+                elif g == "Chimeric.out.sam":
+                    L = lambda p: [l for l in open(p, "rb") if not l.startswith(b"@")]
+                    if L(pa) != L(pb):
                         problems.append(g + " differs")
                 elif g == "Chimeric.out.junction":
                     L = lambda p: [l for l in open(p) if not l.startswith("# 2.7.11b")]
