@@ -31,7 +31,7 @@ all: host engine shadow cli oracle
 host: star_amd/lib/libstaramd_host.so
 engine: star_amd/lib/libstaramd.so
 cli: star_amd/bin/star_amd
-oracle: oracle/_build/liboracle.so
+oracle: oracle/_build/liboracle.so oracle/_build/star_amd_oracle_cli
 
 star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
 	@mkdir -p star_amd/lib
@@ -53,6 +53,10 @@ star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.
 oracle/_build/liboracle.so: oracle/star_oracle.cpp include/star_amd.h
 	@mkdir -p oracle/_build
 	$(CXX) $(CXXFLAGS) -shared oracle/star_oracle.cpp -o $@
+
+# test infrastructure: the command-line front end with the oracle behind the engine's C ABI (oracle/cli_shim.cpp), for CPU tests of main.cpp
+oracle/_build/star_amd_oracle_cli: star_amd/csrc/host/main.cpp oracle/cli_shim.cpp oracle/_build/liboracle.so star_amd/lib/libstaramd_host.so
+	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
 
 ref:
 	$(MAKE) -f oracle/Makefile.ref -j8 all

@@ -1,0 +1,30 @@
+// cli_shim.cpp -- TEST INFRASTRUCTURE, never shipped, never linked by anything under star_amd/.
+// The engine's C ABI (include/star_amd.h) implemented on top of the CPU oracle, so that the command-line front end (star_amd/csrc/host/main.cpp: the
+// three-stage batch pipeline, the phases of 2-pass / BySJout, the second batch of merged mates) can be exercised by tests on a box without a GPU.
+// `make oracle` links it with main.cpp into oracle/_build/star_amd_oracle_cli; tests/test_cli_pipeline.py is the only user.
+#include "../include/star_amd.h"
+#include <string>
+
+extern "C" {
+void *oracle_create(const staramd_genome *g, const staramd_params *p);
+void oracle_destroy(void *h);
+int oracle_set_novel_junctions(void *h, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage);
+int oracle_map_batch(void *h, const staramd_batch *b, staramd_results *r);
+}
+
+struct staramd_ctx { void *o; };
+static std::string lastError;
+
+extern "C" {
+int staramd_create(staramd_ctx **out, int, const staramd_genome *g, const staramd_params *p, uint32_t, uint64_t) { *out = new staramd_ctx{oracle_create(g, p)}; return STARAMD_OK; }
+int staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p) { oracle_destroy(ctx->o); ctx->o = oracle_create(g, p); return STARAMD_OK; }
+int staramd_set_novel_junctions(staramd_ctx *ctx, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage) { return oracle_set_novel_junctions(ctx->o, start, end, n, stage); }
+int staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results *r) {
+    int rc = oracle_map_batch(ctx->o, b, r);
+    r->msSeed = r->msWindows = r->msStitch = r->msTotalDevice = 0;
+    if (rc) lastError = "result buffers too small";
+    return rc;
+}
+void staramd_destroy(staramd_ctx *ctx) { if (ctx) { oracle_destroy(ctx->o); delete ctx; } }
+const char *staramd_last_error(void) { return lastError.c_str(); }
+}

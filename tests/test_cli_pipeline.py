@@ -1,0 +1,54 @@
+"""The command-line front end (star_amd/csrc/host/main.cpp): three batch slots (parse / map / post-map on their own threads), the phases of 2-pass and
+BySJout (index re-upload, junction whitelist), the second batch of merged mates.  On a box without a GPU the same main.cpp is linked against the oracle
+behind the engine's C ABI (oracle/cli_shim.cpp -> oracle/_build/star_amd_oracle_cli, test infrastructure); the GPU twin of this file is the `cli`
+tests in test_by_sjout.py / test_config1.py, which run the shipped binary."""
+import os
+import subprocess
+
+import pytest
+
+from util import bam_parts, compare_outputs, prepare, refstar
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "oracle", "_build", "star_amd_oracle_cli")
+pytestmark = pytest.mark.skipif(not refstar.have_ref() or not os.path.exists(CLI), reason="oracle/_ref/STAR or the oracle-backed CLI not built")
+
+CASES = [("pe101", ["--twopassMode", "Basic", "--outFilterType", "BySJout", "--outSAMunmapped", "Within"], 700),
+         ("pe76_overlap", ["--peOverlapNbasesMin", "10", "--peOverlapMMp", "0.1", "--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMultimapNmax", "20",
+                           "--chimOutType", "WithinBAM", "Junctions", "--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate", "--quantMode", "GeneCounts"], 300),
+         ("se50", ["--sjdbGTFfile", "GTF", "--quantMode", "TranscriptomeSAM", "GeneCounts", "--outSAMtype", "BAM", "SortedByCoordinate", "--outWigType", "bedGraph"], 450),
+         ("pe150_chim", ["--chimSegmentMin", "15", "--outMultimapperOrder", "Random", "--outReadsUnmapped", "Fastx", "--clip3pNbases", "3", "5"], 5000)]
+
+
+@pytest.mark.parametrize("name,more,batch", CASES)
+def test_cli_pipeline(name, more, batch, tmp_path, built):
+    info = dict(prepare(name, str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    more = [info["gtf"] if x == "GTF" else x for x in more]
+    flags = list(info["extra"]) + more
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=flags)
+    new = os.path.join(d, "cli_")
+    subprocess.check_call([CLI, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] +
+                          ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + flags, stderr=subprocess.DEVNULL)
+    n = 0
+    for f in sorted(os.listdir(d)):
+        if not f.startswith("ref_") or os.path.isdir(os.path.join(d, f)):
+            continue
+        g = f[4:]
+        if g in ("Log.out", "Log.progress.out", "Log.final.out", "Log.std.out"):
+            continue
+        pa, pb = os.path.join(d, f), new + g
+        assert os.path.exists(pb), g
+        if g == "Aligned.out.sam":
+            assert refstar.sam_body_sorted(pa) == refstar.sam_body_sorted(pb)
+        elif g.endswith(".bam"):
+            (ta, ra, rr), (tb, rb, nr) = bam_parts(pa), bam_parts(pb)
+            assert ra == rb and (rr == nr if "Random" not in more else sorted(rr) == sorted(nr)), g
+        elif g == "Chimeric.out.junction":
+            L = lambda p: [l for l in open(p) if not l.startswith("# 2.7.11b")]
+            assert L(pa) == L(pb)
+        else:
+            assert open(pa, "rb").read() == open(pb, "rb").read(), g
+        n += 1
+    assert n >= 2
+    assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(new + "Log.final.out")
