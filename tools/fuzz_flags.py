@@ -96,7 +96,16 @@ def one(it, rng, keep):
             ours = dict(info)
             if rng.random() < 0.3 and "--outMultimapperOrder" not in flags and not ("--quantMode" in flags and "TranscriptomeSAM" in flags):
                 ours["extra"] = list(info["extra"]) + ["--runThreadN", "3"]       # threads on our side only: the outputs must not depend on them
-            new = run_with_engine(ours, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=rng.choice([300, 777, 5000]))
+            cli = os.path.join(ROOT, "oracle", "_build", "star_amd_oracle_cli")
+            if rng.random() < 0.35 and os.path.exists(cli):          # the command-line front end (main.cpp) with the oracle behind the engine's C ABI
+                import subprocess
+                new = os.path.join(d, "new_")
+                r = subprocess.run([cli, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", new, "--gpuBatchReads", str(rng.choice([256, 1000, 4096]))]
+                                   + [x for x in ours["extra"]] + ([] if "--runThreadN" in ours["extra"] else ["--runThreadN", "2"]), stderr=subprocess.PIPE)
+                if r.returncode != 0:
+                    raise RuntimeError("CLI: " + r.stderr.decode()[-300:])
+            else:
+                new = run_with_engine(ours, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=rng.choice([300, 777, 5000]))
             if out and "Unsorted" in out:
                 (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + "Aligned.out.bam"), bam_parts(new + "Aligned.out.bam")
                 if ra != rb or rr != nr:
