@@ -314,7 +314,7 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
         out.push_back('\t'); appendU(out, chimRepeat0); out.push_back('\t'); appendU(out, chimRepeat1); out.push_back('\t'); out += b.name(ir);
         out.push_back('\t'); appendU(out, trChim[0].ex[0].G - c0 + 1); out.push_back('\t'); out += cigarP(trChim[0], readLengthOriginal, readLengthPair, nMates);
         out.push_back('\t'); appendU(out, trChim[1].ex[0].G - c1 + 1); out.push_back('\t'); out += cigarP(trChim[1], readLengthOriginal, readLengthPair, nMates);
-        if (std::find(P.outSAMattrOrder.begin(), P.outSAMattrOrder.end(), "RG") != P.outSAMattrOrder.end()) { out.push_back('\t'); out += P.outSAMattrRG.at(b.fileIndex); }   // outSAMattrPresent.RG (:68)
+        if (std::find(P.outSAMattrOrder.begin(), P.outSAMattrOrder.end(), "RG") != P.outSAMattrOrder.end()) { out.push_back('\t'); out += P.outSAMattrRG.at(b.fileOf(ir)); }   // outSAMattrPresent.RG (:68)
         out.push_back('\n');
         return true;
     }
@@ -450,7 +450,7 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
         out.push_back('\t'); appendU(out, ca.a2.ex[0].G - c2 + 1); out.push_back('\t'); out += cigarP(ca.a2, readLengthOriginal, readLengthPair, nMates);
         out.push_back('\t'); appendU(out, chimN); out.push_back('\t'); appendI(maxPossibleAlignScore); out.push_back('\t'); appendI(maxNonChimAlignScore);
         out.push_back('\t'); appendI(ca.chimScore); out.push_back('\t'); appendI(chimScoreBest); out += merged ? "\t1" : "\t0";       // PEmerged_bool
-        if (rgColumn) { out.push_back('\t'); out += P.outSAMattrRG.at(nb.fileIndex); }
+        if (rgColumn) { out.push_back('\t'); out += P.outSAMattrRG.at(nb.fileOf(nir)); }
         out.push_back('\n');
     }
     return chimN > 0;

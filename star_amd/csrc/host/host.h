@@ -147,6 +147,8 @@ struct ReadBatch {
     uint64_t firstReadIndex = 0;
     std::vector<uint64_t> origIndex;      // 2nd stage of BySJout: index of the read in the original input (empty otherwise)
     uint32_t fileIndex = 0;               // which of the comma-separated input files the batch came from (a batch never spans two)
+    std::vector<uint32_t> heldFile;       // 2nd stage of BySJout: the file every held read came from (empty otherwise)
+    uint32_t fileOf(uint32_t i) const { return heldFile.empty() ? fileIndex : heldFile[i]; }
     std::vector<TextSpan> extraSpan[2];   // SAM input: the attributes of the input record, tab-separated text (readNameExtra, readLoad.cpp:28-29); empty otherwise
     std::string_view extra(int m, uint32_t i) const { return extraSpan[m].empty() ? std::string_view() : std::string_view(text[m].data() + extraSpan[m][i].off, extraSpan[m][i].len); }
     bool fasta = false;                   // the reads came without qualities (FASTA input, readLoad.cpp:84-88): QUAL is * in SAM, 0xFF in BAM, Fastx output is FASTA

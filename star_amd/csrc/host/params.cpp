@@ -329,10 +329,11 @@ std::string RunParams::parse(int argc, char **argv) {
     else if (alignEndsType == "Extend5pOfReads12") { dev.alignEndsTypeExt[0][0] = 1; dev.alignEndsTypeExt[1][0] = 1; }
     else if (alignEndsType == "Extend3pOfRead1") dev.alignEndsTypeExt[0][1] = 1;
     else if (alignEndsType != "Local") return "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --alignEndsType: " + alignEndsType;
+    bool addXSlater = false;
     {   // Parameters_samAttributes.cpp:172-178,213-216: XS <=> --outSAMstrandField intronMotif
         bool hasXS = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "XS") != outSAMattrOrder.end();
         if (hasXS) dev.outSAMstrandFieldIntronMotif = 1;
-        else if (dev.outSAMstrandFieldIntronMotif) outSAMattrOrder.push_back("XS");
+        else if (dev.outSAMstrandFieldIntronMotif) addXSlater = true;      // appended after the RG that --outSAMattrRGline brings (:201-216)
     }
     // Parameters.cpp:779-826
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
@@ -386,6 +387,7 @@ std::string RunParams::parse(int argc, char **argv) {
         if (outSAMattrRG.size() == 1) for (size_t i = 1; i < nFiles; i++) outSAMattrRG.push_back(outSAMattrRG[0]);
         bool hasRG = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "RG") != outSAMattrOrder.end();
         if (!outSAMattrRG.empty() && !hasRG && readFilesManifest.empty()) outSAMattrOrder.push_back("RG");   // only --outSAMattrRGline adds the attribute by itself (Parameters_samAttributes.cpp:201)
+        if (addXSlater) outSAMattrOrder.push_back("XS");
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
     if (peOverlapNbasesMin > 0 && (readFilesIn.size() == 2 || readFilesSAMmates == 2)) dev.resultSelect = 0;          // every alignment of the merged mates is cut back into a pair and re-scored (ReadAlign_peOverlapMergeMap.cpp:279-296)

@@ -181,7 +181,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "NM") { out += "\tNM:i:"; appendUint(out, tagNM); }
             else if (a == "MD") { out += "\tMD:Z:"; out += tagMD; }
             else if (a == "MC") { if (nMates > 1) { out += "\tMC:Z:"; out += matesCIGAR[1 - imate]; } }
-            else if (a == "RG") { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
+            else if (a == "RG") { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileOf(ir)); }
         }
         // SAM input: its attributes go out again; indexed by the position of the mate in the alignment, not by the mate, as the reference does (:351-353)
         if (!b.extra((int)imate, ir).empty()) { out.push_back('\t'); out += b.extra((int)imate, ir); }
@@ -361,7 +361,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "NM") attrInt(attr, "NM", (int64_t)tagNM);
             else if (a == "MD") attrStr(attr, "MD", tagMD);
             else if (a == "MC") { if (nMates > 1) attrStr(attr, "MC", matesCIGAR[1 - imate]); }
-            else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
+            else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileOf(ir)));
             else if (a == "ch") { if (alignType <= -10) attrChar(attr, "ch", '1'); }
         }
         attrFromSAMtags(attr, b.extra((int)Mate, ir), P);
@@ -521,7 +521,7 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         std::string attr;
         attrInt(attr, "NH", 0); attrInt(attr, "HI", 0); attrInt(attr, "AS", trBest ? trBest->maxScore : 0); attrInt(attr, "nM", trBest ? trBest->nMM : 0);
         attrChar(attr, "uT", (char)('0' + unmapType));
-        if (!P.outSAMattrRG.empty()) attrStr(attr, "RG", P.outSAMattrRG.at(b.fileIndex));
+        if (!P.outSAMattrRG.empty()) attrStr(attr, "RG", P.outSAMattrRG.at(b.fileOf(ir)));
         attrFromSAMtags(attr, b.extra(imate, ir), P);
         uint32_t core[8];
         core[0] = (uint32_t)-1; core[1] = (uint32_t)-1;
@@ -575,7 +575,7 @@ static void samUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         out += "\t0\t"; out += b.seq(imate, ir); out.push_back('\t'); if (b.fasta) out.push_back('*'); else out += b.qual(imate, ir);      // :44
         out += "\tNH:i:0\tHI:i:0\tAS:i:"; appendInt(out, trBest ? trBest->maxScore : 0);
         out += "\tnM:i:"; appendUint(out, trBest ? trBest->nMM : 0); out += "\tuT:A:"; appendInt(out, unmapType);
-        if (!P.outSAMattrRG.empty()) { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileIndex); }
+        if (!P.outSAMattrRG.empty()) { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileOf(ir)); }
         if (!b.extra(imate, ir).empty()) { out.push_back('\t'); out += b.extra(imate, ir); }               // :47-49
         out.push_back('\n');
     }

@@ -27,7 +27,7 @@ staramd_batch ReadBatch::view() const {
 }
 void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
-    nameSpan.clear(); filter.clear(); origIndex.clear();
+    nameSpan.clear(); filter.clear(); origIndex.clear(); heldFile.clear();
     for (int m = 0; m < 2; m++) for (int q = 0; q < 2; q++) clipN[m][q].clear();
     for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); extraSpan[i].clear(); }
 }
@@ -332,7 +332,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     b.n = (uint32_t)n;
     b.readOffset.assign(n + 1, 0); b.mate1Length.assign(n, 0); b.mmMaxTotal.assign(n, 0);
     b.nameSpan.assign(n, TextSpan{0, 0}); b.filter.assign(n, 'N');
-    if (fromMemory) b.origIndex.assign(n, 0);
+    if (fromMemory) { b.origIndex.assign(n, 0); b.heldFile.assign(n, 0); }
     if (P.clipYes) for (int m = 0; m < nMates; m++) for (int q = 0; q < 2; q++) b.clipN[m][q].assign(n, 0);
     for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); if (extras) b.extraSpan[m].assign(n, TextSpan{0, 0}); }
     if (!samError.empty()) { err = samError; return false; }
@@ -413,6 +413,9 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
                     uint64_t f4 = f3; while (f4 < e0 && (t0[f4] == ' ' || t0[f4] == '\t')) f4++;
                     uint64_t v = 0; while (f4 < e0 && t0[f4] >= '0' && t0[f4] <= '9') { v = v * 10 + (uint64_t)(t0[f4] - '0'); f4++; }
                     b.origIndex[i] = v;
+                    while (f4 < e0 && (t0[f4] == ' ' || t0[f4] == '\t')) f4++;       // 4th field: the input file of the read (ReadAlign_outputAlignments.cpp:113)
+                    uint64_t fi = 0; while (f4 < e0 && t0[f4] >= '0' && t0[f4] <= '9') { fi = fi * 10 + (uint64_t)(t0[f4] - '0'); f4++; }
+                    b.heldFile[i] = (uint32_t)fi;
                 }
             }
             uint64_t ne = e;

@@ -220,7 +220,8 @@ struct Runner {
                     std::string sam0, q0; OutSJ sj0, sj10; Stats st0; std::vector<uint32_t> held0; std::vector<QuantPatch> qp0;
                     const bool samOff0 = post->samOff;
                     (void)samOff0;
-                    errs[t] = post->processRange(bt, *r, lo, hi, sam0, sj0, st0, stage1 ? &sj10 : nullptr, stage1 ? &held0 : nullptr, nullptr, nullptr, nullptr, nullptr, &q0, &qp0, nullptr, true, mg, mgRes);
+                    std::string chim0;      // reads whose chimera goes into the BAM are not quantified: the detection has to run here too
+                    errs[t] = post->processRange(bt, *r, lo, hi, sam0, sj0, st0, stage1 ? &sj10 : nullptr, stage1 ? &held0 : nullptr, nullptr, nullptr, nullptr, chimOn ? &chim0 : nullptr, &q0, &qp0, nullptr, true, mg, mgRes);
                     for (const QuantPatch &p : qp0) nAlignT[p.ir] = p.nAlignT + 1;
                 };
                 std::vector<std::thread> th;
@@ -300,7 +301,7 @@ struct Runner {
                 for (uint32_t ir : helds[t])                         // held reads, in input order (ReadAlign_outputAlignments.cpp:108-121)
                     for (uint32_t m = 0; m < P.dev.readNmates; m++) {
                         std::string &x = heldText[m];
-                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0 " : " 0:N:0 "; x += std::to_string(bt.readIndex(ir));
+                        x.push_back('@'); x += bt.name(ir); x += bt.filter[ir] == 'Y' ? " 0:Y:0 " : " 0:N:0 "; x += std::to_string(bt.readIndex(ir)); x.push_back(' '); x += std::to_string(bt.fileOf(ir));
                         if (!bt.extra((int)m, ir).empty()) { x.push_back('\x01'); x += bt.extra((int)m, ir); }
                         x.push_back('\n');
                         x += bt.seq((int)m, ir); x += "\n+\n"; x += bt.qual((int)m, ir); x.push_back('\n');

@@ -80,6 +80,26 @@ def one(it, rng, keep):
     if name == "se50" and "--quantMode" in flags:
         info["extra"] += ["--sjdbGTFfile", info["gtf"]]
     d = os.path.dirname(info["fastq"][0])
+    fmt = rng.random()
+    if fmt < 0.12:                                   # the same reads as FASTA / as SAM text / gzipped / split into two files per mate
+        import test_fasta_reads
+        info["fastq"] = test_fasta_reads._to_fasta(info["fastq"], d, rng.choice([0, 40]))
+    elif fmt < 0.24 and "--outSAMattrRGline" not in info["extra"]:
+        import test_sam_reads
+        info["extra"] += ["--readFilesType", "SAM", "PE" if paired else "SE"] + rng.choice([[], ["--readFilesSAMattrKeep", "None"], ["--readFilesSAMattrKeep", "RG", "XN"]])
+        info["fastq"] = test_sam_reads._to_sam(info["fastq"], d)
+        if "--outMultimapperOrder" in info["extra"]:
+            pass
+    elif fmt < 0.34:
+        import subprocess as sp
+        for f in info["fastq"]:
+            sp.check_call("gzip -c '%s' > '%s.gz'" % (f, f), shell=True)
+        info["fastq"] = [f + ".gz" for f in info["fastq"]]
+        info["extra"] += ["--readFilesCommand", rng.choice(["zcat", "gunzip -c"])] if False else ["--readFilesCommand", "zcat"]
+    elif fmt < 0.44:
+        import test_output_options
+        info["fastq"] = test_output_options._split(info["fastq"], d)
+        info["extra"] += rng.choice([[], ["--outSAMattrRGline", "ID:a", "SM:x", ",", "ID:b"]])
     problems = []
     print("run  [%d] %s %s" % (it, name, " ".join(info["extra"])), flush=True)
     try:
