@@ -51,7 +51,25 @@ def key(flags):
 def one(it, rng, keep):
     name = rng.choice(DATA)
     work = tempfile.mkdtemp(prefix="fuzz%04d_" % it)
-    info = dict(prepare(name, work, need_ref=False))
+    if rng.random() < 0.3:                           # a fresh data set: random genome, annotation, read length, error / indel / chimera rates, index parameters
+        from star_amd import synth
+        rl = rng.choice([36, 50, 75, 100, 125, 151, 250])
+        pe = rng.random() < 0.6
+        kw = dict(seed=rng.randrange(1 << 30), chr_lengths=tuple(rng.randrange(60000, 300000) for _ in range(rng.randrange(1, 5))), n_tr=rng.randrange(20, 120), n_reads=rng.randrange(800, 2500),
+                  read_len=rl, paired=pe, sub_rate=rng.choice([0.0, 0.005, 0.02, 0.05]), n_rate=rng.choice([0.0, 0.002, 0.02]), indel_rate=rng.choice([0.0, 0.0, 0.002]),
+                  chim_rate=rng.choice([0.0, 0.0, 0.1]), frag=(max(rl // 2, 40), max(rl * 3, 200)))
+        name = "rand_%s%d" % ("pe" if pe else "se", rl)
+        d0 = os.path.join(work, name)
+        info = synth.make_dataset(d0, **kw)
+        info["idx"] = os.path.join(d0, "idx")
+        gtf = rng.random() < 0.7
+        refstar.genome_generate(info["fasta"], info["idx"], gtf=info["gtf"] if gtf else None, sa_index_nbases=rng.choice([6, 8, 10]), **(dict(sjdb_overhang=rng.choice([rl - 1, 30, 100])) if gtf else {}),
+                                **(dict(extra=("--genomeSAsparseD", str(rng.choice([2, 3])))) if rng.random() < 0.2 else {}))
+        info["extra"] = []
+        if not gtf:
+            global POOL_NO_GTF
+    else:
+        info = dict(prepare(name, work, need_ref=False))
     paired = len(info["fastq"]) == 2
     used = set(x for x in info["extra"] if x.startswith("--"))
     flags = []
@@ -77,7 +95,7 @@ def one(it, rng, keep):
     if "--quantMode" in flags and "GeneCounts" in flags and name == "se50":
         pass
     info["extra"] = list(info["extra"]) + flags + out
-    if name == "se50" and "--quantMode" in flags:
+    if (name == "se50" or name.startswith("rand_")) and "--quantMode" in flags and not os.path.exists(os.path.join(info["idx"], "exonGeTrInfo.tab")):
         info["extra"] += ["--sjdbGTFfile", info["gtf"]]
     d = os.path.dirname(info["fastq"][0])
     fmt = rng.random()
