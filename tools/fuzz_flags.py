@@ -38,6 +38,11 @@ POOL = [   # (flags, needs paired)
     (["--outSJtype", "None"], 0), (["--quantMode", "TranscriptomeSAM", "--quantTranscriptomeSAMoutput", "BanSingleEnd_ExtendSoftclip"], 0), (["--quantMode", "TranscriptomeSAM", "--quantTranscriptomeBAMcompression", "-1"], 0),
     (["--outSJfilterDistToOtherSJmin", "5", "0", "3", "5", "--outSJfilterIntronMaxVsReadN", "1000", "2000", "3000"], 0), (["--alignSJstitchMismatchNmax", "2", "-1", "2", "2"], 0),
     (["--seedSplitMin", "8", "--seedMapMin", "3"], 0), (["--scoreStitchSJshift", "0"], 0), (["--outFilterScoreMin", "60"], 0), (["--outFilterMatchNmin", "70"], 0),
+    (["--seedSearchStartLmax", "12"], 0), (["--seedSearchStartLmax", "80"], 0), (["--seedMultimapNmax", "50"], 0), (["--winAnchorMultimapNmax", "20"], 0), (["--winAnchorMultimapNmax", "200", "--seedMultimapNmax", "300"], 0),
+    (["--alignIntronMin", "5"], 0), (["--alignIntronMin", "60"], 0), (["--scoreGapATAC", "-2", "--scoreGapGCAG", "-1"], 0), (["--outFilterMultimapNmax", "1"], 0), (["--sjdbScore", "5"], 0),
+    (["--scoreGenomicLengthLog2scale", "-1"], 0), (["--alignSplicedMateMapLminOverLmate", "0.9"], 1), (["--alignSJstitchMismatchNmax", "0", "0", "0", "0"], 0), (["--seedSearchLmax", "15", "--seedSearchStartLmax", "30"], 0),
+    (["--alignIntronMax", "300"], 0), (["--alignMatesGapMax", "400"], 1), (["--winBinNbits", "10", "--winAnchorDistNbins", "30"], 0), (["--winBinNbits", "18"], 0), (["--seedPerReadNmax", "300"], 0),
+    (["--outFilterMismatchNoverLmax", "0.0"], 0), (["--scoreInsOpen", "-5", "--scoreDelOpen", "0"], 0), (["--alignSJoverhangMin", "20"], 0), (["--seedMapMin", "10", "--seedSplitMin", "20"], 0),
     (["--readMapNumber", "700"], 0), (["--twopassMode", "Basic", "--twopass1readsN", "500"], 0), (["--winFlankNbins", "2"], 0), (["--limitOutSJcollapsed", "2000000"], 0),
 ]   # (--alignWindowsPerReadNmax with a small value is left out: the reference itself dies with SIGSEGV on it)
 OUTTYPES = [[], [], [], ["--outSAMtype", "BAM", "Unsorted"], ["--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate"], ["--outSAMtype", "BAM", "SortedByCoordinate", "--outWigType", "bedGraph"]]
