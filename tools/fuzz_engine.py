@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""GPU side of the bug hunt (needs an MI355X): random data sets and random HOT-PATH flags, the HIP engine's result buffers against the oracle's, byte for
+byte -- every read result, transcript and exon record, in both result-selection modes, including the second batch of merged mates and clipped / 0-length mates.
+The oracle side of the same combinations is pinned against the reference by tools/fuzz_flags.py on CPU.
+usage (on the GPU box): python tools/fuzz_engine.py [iterations] [seed]         e.g.  gpurun --timeout 900 -- 'python tools/fuzz_engine.py 60 1 > gpurun_out/fuzz_engine.log 2>&1'"""
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from util import capi, oracle_lib, prepare, refstar   # noqa: E402
+from star_amd import synth                            # noqa: E402
+
+HOT = [["--alignEndsType", "EndToEnd"], ["--alignEndsType", "Extend5pOfRead1"], ["--alignEndsType", "Extend5pOfReads12"], ["--alignEndsProtrude", "15", "ConcordantPair"],
+       ["--alignInsertionFlush", "Right"], ["--alignSoftClipAtReferenceEnds", "No"], ["--alignIntronMax", "300"], ["--alignIntronMax", "5000", "--alignMatesGapMax", "5000"], ["--alignIntronMin", "5"],
+       ["--alignIntronMin", "60"], ["--alignSJoverhangMin", "3", "--alignSJDBoverhangMin", "1"], ["--alignSJoverhangMin", "20"], ["--alignSplicedMateMapLmin", "30", "--alignSplicedMateMapLminOverLmate", "0"],
+       ["--alignSplicedMateMapLminOverLmate", "0.9"], ["--alignSJstitchMismatchNmax", "0", "0", "0", "0"], ["--alignSJstitchMismatchNmax", "5", "-1", "5", "5"], ["--alignTranscriptsPerReadNmax", "50", "--alignTranscriptsPerWindowNmax", "5"],
+       ["--scoreGap", "-2", "--scoreGapNoncan", "-4"], ["--scoreGapATAC", "-2", "--scoreGapGCAG", "-1"], ["--scoreGenomicLengthLog2scale", "0"], ["--scoreGenomicLengthLog2scale", "-1"],
+       ["--scoreDelOpen", "-1", "--scoreInsOpen", "-1", "--scoreDelBase", "-1", "--scoreInsBase", "-1"], ["--scoreInsOpen", "-5", "--scoreDelOpen", "0"], ["--scoreStitchSJshift", "0"], ["--sjdbScore", "0"], ["--sjdbScore", "5"],
+       ["--seedSearchStartLmax", "12"], ["--seedSearchStartLmax", "80"], ["--seedSearchStartLmaxOverLread", "0.3"], ["--seedSearchLmax", "30"], ["--seedMultimapNmax", "50"], ["--seedMultimapNmax", "300", "--winAnchorMultimapNmax", "200"],
+       ["--seedPerWindowNmax", "10"], ["--seedPerReadNmax", "300"], ["--seedSplitMin", "8", "--seedMapMin", "3"], ["--seedMapMin", "10", "--seedSplitMin", "20"], ["--winAnchorMultimapNmax", "20"],
+       ["--winBinNbits", "10", "--winAnchorDistNbins", "30"], ["--winBinNbits", "14", "--winAnchorDistNbins", "5"], ["--winBinNbits", "18"], ["--winFlankNbins", "2"],
+       ["--outFilterMismatchNmax", "3"], ["--outFilterMismatchNoverLmax", "0.05"], ["--outFilterMismatchNoverLmax", "0.0"], ["--outFilterMismatchNoverReadLmax", "0.04"], ["--outFilterMultimapScoreRange", "4"],
+       ["--outFilterIntronMotifs", "RemoveNoncanonical"], ["--outFilterIntronMotifs", "RemoveNoncanonicalUnannotated"], ["--outFilterIntronStrands", "None"], ["--outSAMstrandField", "intronMotif"],
+       ["--chimSegmentMin", "12"], ["--peOverlapNbasesMin", "10", "--peOverlapMMp", "0.1"], ["--clip3pNbases", "CLIP"], ["--clip5pNbases", "CLIP"], ["--clip3pAdapterSeq", "ADAPT"]]
+
+
+def one(it, rng):
+    work = tempfile.mkdtemp(prefix="fzeng%04d_" % it)
+    if rng.random() < 0.5:
+        rl = rng.choice([36, 50, 75, 100, 125, 151, 250])
+        pe = rng.random() < 0.6
+        kw = dict(seed=rng.randrange(1 << 30), chr_lengths=tuple(rng.randrange(60000, 300000) for _ in range(rng.randrange(1, 5))), n_tr=rng.randrange(20, 120), n_reads=rng.randrange(800, 2500),
+                  read_len=rl, paired=pe, sub_rate=rng.choice([0.0, 0.005, 0.02, 0.05]), n_rate=rng.choice([0.0, 0.002, 0.02]), indel_rate=rng.choice([0.0, 0.0, 0.002]),
+                  chim_rate=rng.choice([0.0, 0.0, 0.1]), frag=(max(rl // 2, 40), max(rl * 3, 200)))
+        name = "rand_%s%d" % ("pe" if pe else "se", rl)
+        d = os.path.join(work, name)
+        info = synth.make_dataset(d, **kw)
+        info["idx"] = os.path.join(d, "idx")
+        gtf = rng.random() < 0.7
+        refstar.genome_generate(info["fasta"], info["idx"], gtf=info["gtf"] if gtf else None, sa_index_nbases=rng.choice([6, 8, 10]), **(dict(sjdb_overhang=rng.choice([rl - 1, 30, 100])) if gtf else {}),
+                                **(dict(extra=("--genomeSAsparseD", str(rng.choice([2, 3])))) if rng.random() < 0.2 else {}))
+        info["extra"] = []
+    else:
+        name = rng.choice(["pe101", "se50", "pe150_indel", "pe76_overlap", "pe150_chim", "pe101_sparse3"])
+        info = dict(prepare(name, work, need_ref=False))
+    paired = len(info["fastq"]) == 2
+    used, flags = set(x for x in info["extra"] if x.startswith("--")), []
+    for fl in rng.sample(HOT, rng.randrange(1, 6)):
+        names = [x for x in fl if x.startswith("--")]
+        if any(n in used for n in names) or (not paired and fl[0] in ("--peOverlapNbasesMin", "--alignEndsProtrude", "--alignSplicedMateMapLminOverLmate") ) or (not paired and "Extend5pOfReads12" in fl):
+            continue
+        used.update(names)
+        fl = [str(rng.choice([3, 20, 400])) if v == "CLIP" else ("AGATCGGAAG" if v == "ADAPT" else v) for v in fl]   # 400: everything clipped, 0-length mates
+        if fl[0].startswith("--clip") and paired:
+            fl = [fl[0], fl[1], fl[1] if rng.random() < 0.5 else "0"] if fl[1] != "AGATCGGAAG" else [fl[0], fl[1], "-", "--clip3pAdapterMMp", "0.1", "0.1"]
+        flags += fl
+    flags += ["--gpuResultSelect", rng.choice(["All", "Selected"])]
+    tag = "%s %s" % (name, " ".join(info["extra"] + flags))
+    print("run  [%d] %s" % (it, tag), flush=True)
+    run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", os.path.join(work, "x_")] + info["extra"] + flags)
+    eng = capi.Engine(run.genome, run.params, device=0, max_reads=4096)
+    orc = oracle_lib.Oracle(run.genome, run.params)
+    bad = None
+    try:
+        while bad is None:
+            b = run.next_batch(rng.choice([700, 1500, 4000]))
+            if b is None:
+                break
+            for bt in (b, run.merged_batch()):
+                if bt is None:
+                    continue
+                n = bt.nReads
+                bg, bo = capi.ResultBuffers(n, tr_cap=n * 400), capi.ResultBuffers(n, tr_cap=n * 400)
+                eng.map_batch(bt, bg); orc.map_batch(bt, bo)
+                if bg.as_bytes(n) != bo.as_bytes(n) or bg.res.trCount != bo.res.trCount:
+                    for i in range(n):
+                        a, o = bg.reads[i], bo.reads[i]
+                        fa = (a.status, a.nW, a.nTr, a.trOffset, a.trBest, a.maxScoreMate[0], a.maxScoreMate[1], a.unmappedLength)
+                        fo = (o.status, o.nW, o.nTr, o.trOffset, o.trBest, o.maxScoreMate[0], o.maxScoreMate[1], o.unmappedLength)
+                        if fa != fo:
+                            bad = "read %d: engine %r oracle %r" % (i, fa, fo); break
+                    bad = bad or "transcript / exon records differ"
+                    break
+            if bad is None:
+                bufs = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 4); bufs = None
+    except Exception as e:
+        bad = "exception: %s" % str(e)[:300]
+    finally:
+        eng.close(); orc.close(); run.close()
+    print(("FAIL [%d] %s\n      %s\n      kept in %s" % (it, tag, bad, work)) if bad else ("ok   [%d]" % it), flush=True)
+    return bad is None
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = sum(0 if one(i, rng) else 1 for i in range(n))
+    print("%d of %d combinations differ" % (bad, n))
+    sys.exit(1 if bad else 0)
