@@ -144,6 +144,8 @@ def host_lib():
         L.sah_genome_load_seconds.restype = C.c_double; L.sah_genome_load_seconds.argtypes = [C.c_void_p]
         L.sah_next_batch.restype = C.c_int; L.sah_next_batch.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Batch)]
         L.sah_emit.restype = C.c_int; L.sah_emit.argtypes = [C.c_void_p, C.POINTER(Results)]
+        L.sah_wasp_batch.restype = C.c_int; L.sah_wasp_batch.argtypes = [C.c_void_p, C.POINTER(Results), C.POINTER(Batch)]
+        L.sah_wasp_results.restype = C.c_int; L.sah_wasp_results.argtypes = [C.c_void_p, C.POINTER(Results), C.POINTER(Results)]
         L.sah_merged_batch.restype = C.c_int; L.sah_merged_batch.argtypes = [C.c_void_p, C.POINTER(Batch)]
         L.sah_emit_merged.restype = C.c_int; L.sah_emit_merged.argtypes = [C.c_void_p, C.POINTER(Results), C.POINTER(Results)]
         L.sah_finish.restype = C.c_int; L.sah_finish.argtypes = [C.c_void_p]
@@ -211,6 +213,17 @@ class HostRun:
         b = Batch()
         n = self.L.sah_merged_batch(self.h, C.byref(b))
         return b if n > 0 else None
+
+    def wasp_batch(self, results):
+        """--waspOutputMode SAMtag: the allele-swapped reads built from the results of the current batch (None when there are none); map them with the same
+        engine and hand their results to wasp_results() before emit()."""
+        b = Batch()
+        n = self.L.sah_wasp_batch(self.h, C.byref(results), C.byref(b))
+        return b if n > 0 else None
+
+    def wasp_results(self, results, wasp_results):
+        if self.L.sah_wasp_results(self.h, C.byref(results), C.byref(wasp_results) if wasp_results is not None else None) != 0:
+            raise RuntimeError(self.L.sah_error(self.h).decode())
 
     def emit(self, results, merged=None):
         rc = self.L.sah_emit(self.h, C.byref(results)) if merged is None else self.L.sah_emit_merged(self.h, C.byref(results), C.byref(merged))

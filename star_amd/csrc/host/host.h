@@ -115,6 +115,7 @@ struct RunParams {
     std::vector<std::string> outSAMheaderHD, outSAMheaderPG; std::string outSAMheaderCommentFile;   // samHeaders.cpp:56-96
     bool runDirPermAll = false, genomeLoadShared = false;
     bool runModeFromBAM = false; std::string inputBAMfile;   // --runMode inputAlignmentsFromBAM --inputBAMfile: signal tracks from an existing BAM, no mapping
+    std::string varVCFfile; bool varHeteroOnly = false, wasp = false; const struct Variation *var = nullptr;   // --varVCFfile, --waspOutputMode SAMtag (Parameters.cpp:854-890)
     int readFilesSAMmates = 0;           // --readFilesType SAM SE | PE: 1 | 2 (0 = Fastx)
     bool samAttrKeepAll = true, samAttrKeepNone = false; std::vector<std::string> samAttrKeep;   // --readFilesSAMattrKeep (BAM output only, Parameters_readFilesInit.cpp:13-31)
     uint32_t peOverlapNbasesMin = 0; double peOverlapMMp = 0.01;   // --peOverlapNbasesMin, --peOverlapMMp
@@ -160,12 +161,30 @@ struct ReadBatch {
     void clear();
 };
 
+// variation.cpp: the SNVs of --varVCFfile, sorted by genome coordinate; nt[i] = {reference, allele 1, allele 2} as 0..3
+struct VarOverlap { std::vector<uint32_t> ind, readCoord; std::vector<int32_t> genCoord; std::vector<char> allele; };   // allele: 1 / 2 = matches that allele, 3 neither, 4 = N in the read
+struct Variation {
+    std::vector<uint64_t> loci; std::vector<std::array<uint8_t, 3> > nt;
+    std::string load(const RunParams &P, const GenomeIndex &gi);
+    void overlap(const staramd_transcript &t, const staramd_exon *ex, const uint8_t *Read1, uint64_t Lread, uint64_t chrStart, VarOverlap &o) const;
+};
+struct ReadBatch;
+// --waspOutputMode SAMtag: the allele-swapped copies of the reads of a batch that WASP maps again (one more batch), and the verdict (vW) per read
+struct WaspBatch;
+
 // --peOverlapNbasesMin > 0: the pairs of a batch whose mates overlap, merged into single-end reads that are mapped as a second batch
 // (ReadAlign::peMergeMates, ReadAlign_peOverlapMergeMap.cpp:77-134).  index[i] = position of pair i in `reads`, or -1
 struct MergedBatch {
     ReadBatch reads;
     std::vector<int32_t> index; std::vector<uint32_t> nOv; std::vector<std::array<uint32_t, 2> > mateStart;
     void build(const ReadBatch &b, const RunParams &P);
+};
+
+struct WaspBatch {
+    ReadBatch reads;
+    std::vector<uint32_t> first, count; std::vector<int8_t> type;
+    void build(const RunParams &P, const GenomeIndex &gi, const Variation &var, const ReadBatch &b, const staramd_results &r);
+    void finish(const RunParams &P, const ReadBatch &b, const staramd_results &r, const staramd_results &rw);
 };
 
 class FastqReader {
@@ -316,7 +335,8 @@ public:
                              std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr,           // TranscriptomeSAM records
                              const MultOrder *order = nullptr, bool dry = false,
                              const MergedBatch *merged = nullptr, const staramd_results *mergedRes = nullptr,
-                             std::string *chimSam = nullptr) const;               // Chimeric.out.sam records (--chimOutType SeparateSAMold)   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
+                             std::string *chimSam = nullptr,                     // Chimeric.out.sam records (--chimOutType SeparateSAMold)
+                             const std::vector<int8_t> *waspType = nullptr) const;   // vW per read (--waspOutputMode SAMtag)   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
     // nAlignT (with --quantMode TranscriptomeSAM): per read, the number of transcriptomic alignments + 1 where the read draws its primary one
     // right after its shuffles (ReadAlign_quantTranscriptome.cpp:69), 0 where it does not
     template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr,

@@ -29,6 +29,8 @@ int sah_tool_done(void *h);
 int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
 int sah_emit_slot(void *h, int slot, const staramd_results *res);
 int sah_merged_slot(void *h, int slot, staramd_batch *out);
+int sah_wasp_slot(void *h, int slot, const staramd_results *res, staramd_batch *out);
+int sah_wasp_results_slot(void *h, int slot, const staramd_results *res, const staramd_results *resWasp);
 int sah_emit_slot_merged(void *h, int slot, const staramd_results *res, const staramd_results *resMerged);
 int sah_finish(void *h);
 int sah_next_phase(void *h);
@@ -62,8 +64,10 @@ int main(int argc, char **argv) {
     staramd_ctx *ctx = nullptr;
     int rc = staramd_create(&ctx, sah_device(h), sah_genome(h), sah_params(h), (uint32_t)batchReads, 0);
     if (rc) { fprintf(stderr, "\nEXITING because of FATAL ERROR: cannot initialise the MI355X engine: %s\n", staramd_last_error()); sah_destroy(h); return 105; }
-    ResBuf rb[4];                                    // [0..1] the batches in flight, [2..3] their merged mates (--peOverlapNbasesMin)
-    for (auto &r : rb) {
+    ResBuf piecePart;                                // one piece of a WASP re-mapping batch
+    ResBuf rb[6];                                    // [0..1] the batches in flight, [2..3] their merged mates (--peOverlapNbasesMin), [4..5] their WASP re-mapping
+    for (ResBuf *rp : {&rb[0], &rb[1], &rb[2], &rb[3], &rb[4], &rb[5], &piecePart}) {
+        ResBuf &r = *rp;
         r.reads.resize(batchReads); r.tr.resize(batchReads * 16 + 4096); r.ex.resize(r.tr.size() * 3);
         memset(&r.res, 0, sizeof(r.res));
         r.res.reads = r.reads.data(); r.res.tr = r.tr.data(); r.res.trCapacity = r.tr.size(); r.res.ex = r.ex.data(); r.res.exCapacity = r.ex.size();
@@ -114,6 +118,31 @@ int main(int argc, char **argv) {
             if (!rc) {                                           // --peOverlapNbasesMin: the overlapping mates of the batch, merged into single reads, are a second batch
                 staramd_batch mb;
                 if (sah_merged_slot(h, m.slot, &mb) > 0) { m.merged = true; rc = mapInto(mb, rb[2 + m.resIdx]); }
+            }
+            if (!rc) {                                           // --waspOutputMode: allele-swapped copies of some reads, one more batch (can be larger than the batch itself)
+                staramd_batch wb;
+                int nw = sah_wasp_slot(h, m.slot, &rb[m.resIdx].res, &wb);
+                if (nw > 0) {
+                    // as many pieces as it takes (a read over a dense cluster of SNVs has up to 1023 copies); the results of the pieces are appended to one set
+                    ResBuf &r = rb[4 + m.resIdx];
+                    if (r.reads.size() < (size_t)nw) { r.reads.resize((size_t)nw); r.res.reads = r.reads.data(); }
+                    uint64_t trN = 0, exN = 0;
+                    for (uint32_t done = 0; done < (uint32_t)nw && !rc; ) {
+                        staramd_batch piece = wb; piece.nReads = std::min<uint32_t>((uint32_t)batchReads, (uint32_t)nw - done);
+                        piece.readOffset = wb.readOffset + done; piece.mate1Length = wb.mate1Length + done; piece.mmMaxTotal = wb.mmMaxTotal + done;
+                        rc = mapInto(piece, piecePart);
+                        if (rc) break;
+                        const staramd_results &pr = piecePart.res;
+                        if (r.tr.size() < trN + pr.trCount) r.tr.resize((trN + pr.trCount) * 3 / 2 + 1024);
+                        if (r.ex.size() < exN + pr.exCount) r.ex.resize((exN + pr.exCount) * 3 / 2 + 1024);
+                        for (uint32_t k = 0; k < piece.nReads; k++) { r.reads[done + k] = pr.reads[k]; r.reads[done + k].trOffset += (uint32_t)trN; }
+                        for (uint64_t k = 0; k < pr.trCount; k++) { r.tr[trN + k] = pr.tr[k]; r.tr[trN + k].exonOffset += (uint32_t)exN; }
+                        if (pr.exCount) memcpy(&r.ex[exN], pr.ex, pr.exCount * sizeof(staramd_exon));
+                        trN += pr.trCount; exN += pr.exCount; done += piece.nReads;
+                    }
+                    r.res.reads = r.reads.data(); r.res.tr = r.tr.data(); r.res.trCapacity = r.tr.size(); r.res.trCount = trN; r.res.ex = r.ex.data(); r.res.exCapacity = r.ex.size(); r.res.exCount = exN;
+                }
+                if (!rc && sah_wasp_results_slot(h, m.slot, &rb[m.resIdx].res, nw > 0 ? &rb[4 + m.resIdx].res : nullptr)) { fail(sah_error(h)); results.give(m.resIdx); slots.give(m.slot); continue; }
             }
             if (rc) { fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error()); results.give(m.resIdx); slots.give(m.slot); continue; }
             nReads += (uint64_t)m.n;

@@ -153,6 +153,8 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "outSAMheaderCommentFile") { if (one(k, v) != "-") outSAMheaderCommentFile = one(k, v); }
         else if (k == "outSJtype") { const std::string &m = v[0]; if (m == "None") outSJnone = true; else if (m != "Standard") err = "EXITING because of FATAL input ERROR: unrecognized option in --outSJtype   " + m + "\nSOLUTION: use one of the allowed options: --outSJtype   Standard    OR    None\n"; }
         else if (k == "outQSconversionAdd") outQSconversionAdd = (int)I(k, v);
+        else if (k == "varVCFfile") { if (one(k, v) != "-") varVCFfile = one(k, v); }
+        else if (k == "waspOutputMode") { const std::string &m = one(k, v); if (m == "SAMtag") { wasp = true; varHeteroOnly = true; } else if (m != "None") err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented --waspOutputMode option: " + m + "\nSOLUTION: re-run STAR with allowed --waspOutputMode options: None or SAMtag\n"; }
         else if (k == "readFilesType") {       // Parameters_readFilesInit.cpp:11-39,152-166
             if (v[0] == "Fastx") readFilesSAMmates = 0;
             else if (v[0] == "SAM") {
@@ -195,7 +197,7 @@ std::string RunParams::parse(int argc, char **argv) {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
             else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC", "ch"}; }   // + ch (Parameters_samAttributes.cpp:51-52)
-            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG" || t == "ch") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG" || t == "ch" || t == "vA" || t == "vG" || t == "vW") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
@@ -329,7 +331,7 @@ std::string RunParams::parse(int argc, char **argv) {
     else if (alignEndsType == "Extend5pOfReads12") { dev.alignEndsTypeExt[0][0] = 1; dev.alignEndsTypeExt[1][0] = 1; }
     else if (alignEndsType == "Extend3pOfRead1") dev.alignEndsTypeExt[0][1] = 1;
     else if (alignEndsType != "Local") return "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --alignEndsType: " + alignEndsType;
-    bool addXSlater = false;
+    bool addXSlater = false, vWquant = false;
     {   // Parameters_samAttributes.cpp:172-178,213-216: XS <=> --outSAMstrandField intronMotif
         bool hasXS = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "XS") != outSAMattrOrder.end();
         if (hasXS) dev.outSAMstrandFieldIntronMotif = 1;
@@ -388,6 +390,15 @@ std::string RunParams::parse(int argc, char **argv) {
         bool hasRG = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "RG") != outSAMattrOrder.end();
         if (!outSAMattrRG.empty() && !hasRG && readFilesManifest.empty()) outSAMattrOrder.push_back("RG");   // only --outSAMattrRGline adds the attribute by itself (Parameters_samAttributes.cpp:201)
         if (addXSlater) outSAMattrOrder.push_back("XS");
+        {   // Parameters.cpp:876-890, Parameters_samAttributes.cpp:187-206
+            auto has = [&](const char *a) { return std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), a) != outSAMattrOrder.end(); };
+            if (wasp && varVCFfile.empty()) return "EXITING because of FATAL INPUT ERROR: --waspOutputMode option requires VCF file: SAMtag\nSOLUTION: re-run STAR with --waspOutputMode ... and --varVCFfile /path/to/file.vcf\n";
+            if (wasp && !outBAMunsorted && !outBAMcoord) return "EXITING because of FATAL INPUT ERROR: --waspOutputMode requires output to BAM file\nSOLUTION: re-run STAR with --waspOutputMode ... and --outSAMtype BAM ... \n";
+            if (varVCFfile.empty() && (has("vA") || has("vG"))) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains vA and/or vG tag(s), but --varVCFfile is not set\nSOLUTION: re-run STAR with a --varVCFfile option, or without vA/vG tags in --outSAMattributes\n";
+            if (!wasp && has("vW")) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains vW tag, but --waspOutputMode is not set\nSOLUTION: re-run STAR with a --waspOutputMode option, or without vW tags in --outSAMattributes\n";
+            if (wasp && !has("vW")) { outSAMattrOrder.push_back("vW"); vWquant = true; }      // only the vW that is added here goes into the transcriptome BAM as well (:201-206 vs :90-92)
+            if (wasp && peOverlapNbasesMin > 0) return "EXITING: --waspOutputMode together with --peOverlapNbasesMin is not implemented";
+        }
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
     if (peOverlapNbasesMin > 0 && (readFilesIn.size() == 2 || readFilesSAMmates == 2)) dev.resultSelect = 0;          // every alignment of the merged mates is cut back into a pair and re-scored (ReadAlign_peOverlapMergeMap.cpp:279-296)
@@ -406,7 +417,7 @@ std::string RunParams::parse(int argc, char **argv) {
     }
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     outSAMattrOrderQuant = {"NH", "HI"};
-    for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC") outSAMattrOrderQuant.push_back(a);
+    for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC" || (a == "vW" && vWquant)) outSAMattrOrderQuant.push_back(a);
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     dev.readNmates = (uint32_t)readFilesIn.size();

@@ -31,6 +31,7 @@ struct ReadCtx {
     const ReadBatch *b; uint32_t i;
     uint64_t Lread, readLength[2];
     uint64_t readLengthOriginal[2], clip[2][2];   // lengths before clipping; clip[mate][0 = 5', 1 = 3']
+    int waspType = -1;                            // vW (--waspOutputMode SAMtag), -1: none
     int nMates;
     // bases soft-clipped on the left of the mate's alignment because of --clip* (ReadAlign_calcCIGAR.cpp:14-23)
     uint64_t trimL(uint32_t Str, uint32_t Mate) const { return clip[Mate][Str == Mate ? 0 : 1]; }
@@ -280,6 +281,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     // CIGAR strings of both mates for MC (calcCIGAR)
     std::string matesCIGAR[2];
     std::vector<uint32_t> packed[2]; std::vector<int32_t> SJintron[2]; std::vector<char> SJmotif[2];
+    VarOverlap vo; bool varDone = false;
     uint64_t hardClip[2][2];
     for (uint32_t imate = 0; imate < nMates; imate++) {
         uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
@@ -363,6 +365,15 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "MC") { if (nMates > 1) attrStr(attr, "MC", matesCIGAR[1 - imate]); }
             else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileOf(ir)));
             else if (a == "ch") { if (alignType <= -10) attrChar(attr, "ch", '1'); }
+            else if ((a == "vA" || a == "vG") && P.var) {          // ReadAlign_alignBAM.cpp:347-360: the SNVs under the whole alignment, on every record of it
+                if (!varDone) { P.var->overlap(t, ex, b.bases.data() + b.readOffset[ir], Lread, quant ? 0 : gi.chrStart[t.Chr], vo); varDone = true; }
+                if (!vo.allele.empty()) {
+                    uint32_t nv = (uint32_t)vo.allele.size();
+                    if (a == "vA") { attr += "vABc"; attr.append((const char *)&nv, 4); attr.append(vo.allele.data(), nv); }
+                    else { attr += "vGBi"; attr.append((const char *)&nv, 4); attr.append((const char *)vo.genCoord.data(), 4 * (size_t)nv); }
+                }
+            }
+            else if (a == "vW") { if (rc.waspType != -1) { int32_t w = rc.waspType; attr += "vWi"; attr.append((const char *)&w, 4); } }
         }
         attrFromSAMtags(attr, b.extra((int)Mate, ir), P);
         uint32_t core[8];
@@ -767,7 +778,7 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
 std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
                                   OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
                                   std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order, bool dry,
-                                  const MergedBatch *merged, const staramd_results *mergedRes, std::string *chimSam) const {
+                                  const MergedBatch *merged, const staramd_results *mergedRes, std::string *chimSam, const std::vector<int8_t> *waspType) const {
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<staramd_transcript> pairT; std::vector<staramd_exon> pairE;
     const bool samOff = this->samOff || dry;
@@ -785,6 +796,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             rc.readLengthOriginal[m] = m < rc.nMates ? b.seqSpan[m][ir].len : 0;
             for (int q = 0; q < 2; q++) rc.clip[m][q] = m < rc.nMates ? b.clipped(m, q, ir) : 0;
         }
+        rc.waspType = waspType ? (*waspType)[ir] : -1;
         st.readN++; st.readBases += rc.readLength[0] + rc.readLength[1];
         const staramd_transcript *T = r.tr + rr.trOffset;
         const staramd_exon *EX = r.ex;

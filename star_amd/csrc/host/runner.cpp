@@ -25,6 +25,8 @@ struct Runner {
     ReadBatch batch;
     staramd_batch batchView;
     ReadBatch slots[3];                 // pipelined CLI: parse / map / post-map work on different slots
+    Variation variation;                      // --varVCFfile
+    WaspBatch waspMain, waspSlots[3];         // --waspOutputMode SAMtag: the allele-swapped reads of batch / slots[k], mapped as one more batch
     MergedBatch mergedMain, mergedSlots[3];   // --peOverlapNbasesMin: the merged mates of batch / slots[k], mapped as a second batch
     std::unique_ptr<PostMap> post;
     OutSJ sj;
@@ -86,6 +88,7 @@ struct Runner {
         }
         error = reader.open(P.readFilesIn, P.readFilesCommand, P.readFilesSAMmates);
         if (!error.empty()) return false;
+        if (!P.varVCFfile.empty()) { error = variation.load(P, gi); if (!error.empty()) return false; P.var = &variation; }
         post.reset(new PostMap(P, gi));
         rngMultOrder.seed((unsigned)P.runRNGseed);                  // ReadAlign.cpp:11 (iChunk 0)
         if (P.quantTrSAM) {
@@ -185,7 +188,9 @@ struct Runner {
     }
     // post-map of one batch on --runThreadN host threads: contiguous read ranges, per-thread SAM buffer / junctions / Stats
     // (what the reference keeps per ReadAlignChunk), SAM text written in read order
-    bool emitBatch(const ReadBatch &bt, const staramd_results *r, const MergedBatch *mg = nullptr, const staramd_results *mgRes = nullptr) {
+    bool emitBatch(const ReadBatch &bt, const staramd_results *r, const MergedBatch *mg = nullptr, const staramd_results *mgRes = nullptr, const WaspBatch *wasp = nullptr) {
+        if (P.wasp && !pass1 && !wasp) { error = "EXITING because of FATAL ERROR: --waspOutputMode: the allele-swapped reads of the batch were not mapped (sah_wasp_batch / sah_wasp_results)"; return false; }
+        const std::vector<int8_t> *waspType = (wasp && !pass1) ? &wasp->type : nullptr;
         if (mg && (mg->reads.n == 0 || !mgRes)) { if (mg->reads.n > 0) { error = "EXITING because of FATAL ERROR: --peOverlapNbasesMin: the merged mates of the batch were not mapped (sah_merged_batch / sah_emit_merged)"; return false; } mg = nullptr; }
         uint32_t T = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
         T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per thread
@@ -239,7 +244,7 @@ struct Runner {
                 raw.clear();
                 errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                              P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t]);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t], waspType);
                 bool cut = false;
                 if (P.outBAMcoord) for (const BamKey &k : keyss[t]) if (k.len & 0x80000000u) { cut = true; break; }
                 if (cut) {                                           // KeepPairs with both BAM files: records that belong to the sorted one only
@@ -254,7 +259,7 @@ struct Runner {
             }
             errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
                                          nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t]);
+                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t], waspType);
         };
         if (T == 1) work(0);
         else {
@@ -356,7 +361,7 @@ struct Runner {
         coordChunks.clear(); coordKeys.clear();
         return failed ? "EXITING because of fatal ERROR: could not write " + path : "";
     }
-    bool emit(const staramd_results *r, const staramd_results *rMerged = nullptr) { return emitBatch(batch, r, P.peOverlapNbasesMin > 0 && P.dev.readNmates == 2 ? &mergedMain : nullptr, rMerged); }
+    bool emit(const staramd_results *r, const staramd_results *rMerged = nullptr) { return emitBatch(batch, r, P.peOverlapNbasesMin > 0 && P.dev.readNmates == 2 ? &mergedMain : nullptr, rMerged, P.wasp ? &waspMain : nullptr); }
     // end of the 1st pass (twoPassRunPass1.cpp:75-96): junctions + Log.final.out of the pass into _STARpass1/, insertion of the
     // junctions into the index, reads rewound.  The caller then re-uploads the index (staramd_update_index).
     bool endPass1() {
@@ -454,10 +459,39 @@ int sah_emit(void *h, const staramd_results *res) { return ((Runner *)h)->emit(r
 // map them with the same engine and hand both result sets to sah_emit_merged.  Same for the slots of the pipelined variant.
 int sah_merged_batch(void *h, staramd_batch *out) { Runner *r = (Runner *)h; if (!(r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) || r->mergedMain.reads.n == 0) return 0; if (out) *out = r->mergedMain.reads.view(); return (int)r->mergedMain.reads.n; }
 int sah_emit_merged(void *h, const staramd_results *res, const staramd_results *resMerged) { return ((Runner *)h)->emit(res, resMerged) ? 0 : -1; }
+// --waspOutputMode SAMtag: after mapping a batch, sah_wasp_batch builds from its results the allele-swapped reads that WASP maps again (0 = none, still call
+// sah_wasp_results with NULL); map them with the same engine, hand the results to sah_wasp_results, then emit as usual.  *_slot: the pipelined variant.
+int sah_wasp_batch(void *h, const staramd_results *res, staramd_batch *out) {
+    Runner *r = (Runner *)h;
+    if (!r->P.wasp || r->pass1) return 0;
+    r->waspMain.build(r->P, r->gi, r->variation, r->batch, *res);
+    if (out) *out = r->waspMain.reads.view();
+    return (int)r->waspMain.reads.n;
+}
+int sah_wasp_results(void *h, const staramd_results *res, const staramd_results *resWasp) {
+    Runner *r = (Runner *)h;
+    if (!r->P.wasp || r->pass1) return 0;
+    if (r->waspMain.reads.n > 0 && !resWasp) { r->error = "EXITING because of FATAL ERROR: --waspOutputMode: results of the re-mapped reads are missing"; return -1; }
+    if (r->waspMain.reads.n > 0) r->waspMain.finish(r->P, r->batch, *res, *resWasp);
+    return 0;
+}
+int sah_wasp_slot(void *h, int slot, const staramd_results *res, staramd_batch *out) {
+    Runner *r = (Runner *)h;
+    if (!r->P.wasp || r->pass1) return 0;
+    r->waspSlots[slot].build(r->P, r->gi, r->variation, r->slots[slot], *res);
+    if (out) *out = r->waspSlots[slot].reads.view();
+    return (int)r->waspSlots[slot].reads.n;
+}
+int sah_wasp_results_slot(void *h, int slot, const staramd_results *res, const staramd_results *resWasp) {
+    Runner *r = (Runner *)h;
+    if (!r->P.wasp || r->pass1) return 0;
+    if (r->waspSlots[slot].reads.n > 0) { if (!resWasp) { r->error = "EXITING because of FATAL ERROR: --waspOutputMode: results of the re-mapped reads are missing"; return -1; } r->waspSlots[slot].finish(r->P, r->slots[slot], *res, *resWasp); }
+    return 0;
+}
 int sah_merged_slot(void *h, int slot, staramd_batch *out) { Runner *r = (Runner *)h; if (!(r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) || r->mergedSlots[slot].reads.n == 0) return 0; if (out) *out = r->mergedSlots[slot].reads.view(); return (int)r->mergedSlots[slot].reads.n; }
 int sah_emit_slot_merged(void *h, int slot, const staramd_results *res, const staramd_results *resMerged) {
     Runner *r = (Runner *)h;
-    return r->emitBatch(r->slots[slot], res, r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2 ? &r->mergedSlots[slot] : nullptr, resMerged) ? 0 : -1;
+    return r->emitBatch(r->slots[slot], res, r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2 ? &r->mergedSlots[slot] : nullptr, resMerged, r->P.wasp ? &r->waspSlots[slot] : nullptr) ? 0 : -1;
 }
 // pipelined variant (star_amd CLI): three batch slots so that FASTQ parsing of batch k+1, the device mapping of batch k and
 // the post-map / SAM writing of batch k-1 overlap.  parse and emit are each called from ONE thread, in batch order.
@@ -471,7 +505,7 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
     if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
     return (int)r->slots[slot].n;
 }
-int sah_emit_slot(void *h, int slot, const staramd_results *res) { Runner *r = (Runner *)h; return r->emitBatch(r->slots[slot], res) ? 0 : -1; }
+int sah_emit_slot(void *h, int slot, const staramd_results *res) { Runner *r = (Runner *)h; return r->emitBatch(r->slots[slot], res, nullptr, nullptr, r->P.wasp ? &r->waspSlots[slot] : nullptr) ? 0 : -1; }
 int sah_threads(void *h) { return ((Runner *)h)->P.runThreadN; }
 // 2-pass mapping: sah_in_pass1() is 1 after sah_create when --twopassMode Basic was given; map all batches, call sah_pass1_end()
 // (junction insertion on the host), re-upload sah_genome()/sah_params() with staramd_update_index(), map all batches again.

@@ -17,13 +17,17 @@ CASES = [("pe101", ["--twopassMode", "Basic", "--outFilterType", "BySJout", "--o
          ("pe76_overlap", ["--peOverlapNbasesMin", "10", "--peOverlapMMp", "0.1", "--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMultimapNmax", "20",
                            "--chimOutType", "WithinBAM", "Junctions", "--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate", "--quantMode", "GeneCounts"], 300),
          ("se50", ["--sjdbGTFfile", "GTF", "--quantMode", "TranscriptomeSAM", "GeneCounts", "--outSAMtype", "BAM", "SortedByCoordinate", "--outWigType", "bedGraph"], 450),
-         ("pe150_chim", ["--chimSegmentMin", "15", "--outMultimapperOrder", "Random", "--outReadsUnmapped", "Fastx", "--clip3pNbases", "3", "5"], 5000)]
+         ("pe150_chim", ["--chimSegmentMin", "15", "--outMultimapperOrder", "Random", "--outReadsUnmapped", "Fastx", "--clip3pNbases", "3", "5"], 5000),
+         ("pe101", ["--waspOutputMode", "SAMtag", "--varVCFfile", "VCF", "--outSAMtype", "BAM", "Unsorted", "--twopassMode", "Basic"], 1000)]
 
 
 @pytest.mark.parametrize("name,more,batch", CASES)
 def test_cli_pipeline(name, more, batch, tmp_path, built):
     info = dict(prepare(name, str(tmp_path), need_ref=False))
     d = os.path.dirname(info["fastq"][0])
+    if "VCF" in more:
+        from test_wasp import _vcf
+        more = [_vcf(info, d) if x == "VCF" else x for x in more]
     more = [info["gtf"] if x == "GTF" else x for x in more]
     flags = list(info["extra"]) + more
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=flags)

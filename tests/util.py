@@ -109,6 +109,9 @@ def run_with_engine(info, prefix, engine_factory, batch_reads=777):
                 bufs = _map(eng, b)
                 mb = run.merged_batch()                   # --peOverlapNbasesMin: overlapping mates merged into single reads, a second batch
                 mbufs = _map(eng, mb) if mb is not None else None
+                wb = run.wasp_batch(bufs.res)             # --waspOutputMode: allele-swapped copies of some reads, one more batch
+                wbufs = _map(eng, wb) if wb is not None else None
+                run.wasp_results(bufs.res, wbufs.res if wbufs is not None else None)
                 run.emit(bufs.res, mbufs.res if mbufs is not None else None)
             phase = run.next_phase()
             if phase == 0:

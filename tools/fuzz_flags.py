@@ -99,6 +99,11 @@ def one(it, rng, keep):
         k = flags.index("--outSJtype"); del flags[k:k + 2]
     if "--quantMode" in flags and "GeneCounts" in flags and name == "se50":
         pass
+    if rng.random() < 0.15 and "--peOverlapNbasesMin" not in flags and "--outSAMattributes" not in flags and "--outSAMattributes" not in info["extra"]:
+        import test_wasp                       # the sample's SNVs: vA / vG, and the WASP filter when the output is BAM
+        flags += ["--varVCFfile", test_wasp._vcf(info, os.path.dirname(info["fastq"][0]), seed=rng.randrange(1000)), "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG"]
+        if out:
+            flags += ["--waspOutputMode", "SAMtag"]
     info["extra"] = list(info["extra"]) + flags + out
     if (name == "se50" or name.startswith("rand_")) and "--quantMode" in flags and not os.path.exists(os.path.join(info["idx"], "exonGeTrInfo.tab")):
         info["extra"] += ["--sjdbGTFfile", info["gtf"]]
