@@ -267,6 +267,8 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
     if (chimScoreNext + C.scoreSeparation >= chimScoreBest) return false;
     auto roStartOf = [&](const ChimTr &c) { return c.t.roStr == 0 ? (uint64_t)c.t.rStart : Lread - c.t.rStart - c.t.rLength; };
     if (roStartOf(trChim[0]) > roStartOf(trChim[1])) std::swap(trChim[0], trChim[1]);
+    VarOverlap varOrig[2];
+    if (bamOut && P.var && !merged) for (int k = 0; k < 2; k++) P.var->overlap(trChim[k].t, trChim[k].ex, Read1, Lread, gi.chrStart[trChim[k].t.Chr], varOrig[k]);
     const uint32_t e0 = trChim[0].t.Str == 1 ? 0 : trChim[0].t.nExons - 1, e1 = trChim[1].t.Str == 0 ? 0 : trChim[1].t.nExons - 1;
     uint64_t chimRepeat0 = 0, chimRepeat1 = 0, chimJ0 = 0, chimJ1 = 0; int chimMotif = 0;
     staramd_exon &x0 = trChim[0].ex[e0], &x1 = trChim[1].ex[e1];
@@ -292,7 +294,7 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
         if (chimMotif >= 0 && (x0.L < C.junctionOverhangMin + chimRepeat0 || x1.L < C.junctionOverhangMin + chimRepeat1)) return false;
         if (bamOut && !merged) {                                     // chimericDetectionOldOutput :11-16: both segments re-scored, one chimera, the best by definition
             chimAlignScore(P.dev, gi, Read1, Lread, trChim[0]); chimAlignScore(P.dev, gi, Read1, Lread, trChim[1]);
-            bamOut->push_back(ChimPair{trChim[0], trChim[1], true});
+            bamOut->push_back(ChimPair{trChim[0], trChim[1], true, varOrig[0], varOrig[1]});
         }
         if (bamOut && merged) {                                      // cut back into the pair first, then re-scored on the pair
             ChimTr tmp[2];
@@ -300,7 +302,7 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
             const uint64_t LreadPE = nameBatch->readOffset[nameIr + 1] - nameBatch->readOffset[nameIr];
             const uint8_t *Read1PE = nameBatch->bases.data() + nameBatch->readOffset[nameIr];
             chimAlignScore(P.dev, gi, Read1PE, LreadPE, tmp[0]); chimAlignScore(P.dev, gi, Read1PE, LreadPE, tmp[1]);
-            bamOut->push_back(ChimPair{tmp[0], tmp[1], true});
+            bamOut->push_back(ChimPair{tmp[0], tmp[1], true, VarOverlap(), VarOverlap()});
         }
         if (!C.outJunctions) return true;
         // Chimeric.out.junction (chimericDetectionOldOutput :61-71)
@@ -332,7 +334,7 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
 namespace {
 struct Segment { const staramd_transcript *t; const staramd_exon *ex; uint64_t roS, roE; uint32_t str; bool good; };
 
-struct ChimAlign { ChimTr a1, a2; uint64_t chimJ1, chimJ2, chimRepeat1, chimRepeat2; int chimMotif, chimScore; };
+struct ChimAlign { ChimTr a1, a2; uint64_t chimJ1, chimJ2, chimRepeat1, chimRepeat2; int chimMotif, chimScore; VarOverlap var1, var2; };
 
 } // namespace
 
@@ -398,6 +400,7 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
             // chimericStitching
             ChimAlign ca;
             load(ca.a1, *p1->t, p1->ex); load(ca.a2, *p2->t, p2->ex);
+            if (bamOut && P.var && !merged) { P.var->overlap(ca.a1.t, ca.a1.ex, Read1, Lread, gi.chrStart[ca.a1.t.Chr], ca.var1); P.var->overlap(ca.a2.t, ca.a2.ex, Read1, Lread, gi.chrStart[ca.a2.t.Chr], ca.var2); }
             const uint32_t chimStr = std::max(s1.str, s2.str);
             ca.chimRepeat1 = ca.chimRepeat2 = ca.chimJ1 = ca.chimJ2 = 0; ca.chimMotif = 0; ca.chimScore = chimScore;
             staramd_exon &x1 = ca.a1.ex[ex1], &x2 = ca.a2.ex[ex2];
@@ -435,11 +438,11 @@ bool chimericDetectionMult(const RunParams &P, const GenomeIndex &gi, const Read
     for (size_t i = 0; i < chimAligns.size(); i++) {
         const ChimAlign &ca = chimAligns[i];
         if (ca.chimScore < minScoreToConsider) continue;
-        if (bamOut && !merged) bamOut->push_back(ChimPair{ca.a1, ca.a2, i == bestChimAlign});
+        if (bamOut && !merged) bamOut->push_back(ChimPair{ca.a1, ca.a2, i == bestChimAlign, ca.var1, ca.var2});
         if (bamOut && merged) {
             ChimTr tmp[2];
             chimericMergedToPair(nb, nir, mateStart, Lread, ca.a1, ca.a2, tmp);
-            bamOut->push_back(ChimPair{tmp[0], tmp[1], i == bestChimAlign});
+            bamOut->push_back(ChimPair{tmp[0], tmp[1], i == bestChimAlign, VarOverlap(), VarOverlap()});
         }
         if (!C.outJunctions) continue;
         const uint64_t c1 = gi.chrStart[ca.a1.t.Chr], c2 = gi.chrStart[ca.a2.t.Chr];

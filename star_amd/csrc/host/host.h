@@ -296,7 +296,7 @@ struct ReadBatch;
 // chimeric.cpp: ReadAlign::chimericDetectionOld + the Chimeric.out.junction line; true = a chimeric alignment was recorded
 // one segment of a chimeric alignment: a copy of the alignment whose block next to the chimeric junction was cut / extended to it
 struct ChimTr { staramd_transcript t; staramd_exon ex[STARAMD_MAX_N_EXONS]; };
-struct ChimPair { ChimTr a1, a2; bool best; };   // the two segments, in read order; best = the top-scoring chimera of the read (the primary one in the BAM)
+struct ChimPair { ChimTr a1, a2; bool best; VarOverlap var1, var2; };   // var1/2: the SNVs under the two alignments as they were BEFORE the junction shift (what the reference's copies carry)   // the two segments, in read order; best = the top-scoring chimera of the read (the primary one in the BAM)
 // the recorded alignments of one read, window by window, best first in each: T[k].exonOffset indexes ex
 struct ReadAligns { const staramd_transcript *T; uint32_t nTr; const staramd_exon *ex; };
 bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra,
@@ -361,6 +361,7 @@ public:
     std::string quantBamHeader() const;              // samHeaders.cpp:8-20
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     std::string bamHeader(bool sortedByCoordinate = false) const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)
+    int waspCarry = -1;                              // vW of the last read of the batch before (see processRange)
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:
     const RunParams &P;

@@ -397,6 +397,8 @@ std::string RunParams::parse(int argc, char **argv) {
             if (varVCFfile.empty() && (has("vA") || has("vG"))) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains vA and/or vG tag(s), but --varVCFfile is not set\nSOLUTION: re-run STAR with a --varVCFfile option, or without vA/vG tags in --outSAMattributes\n";
             if (!wasp && has("vW")) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains vW tag, but --waspOutputMode is not set\nSOLUTION: re-run STAR with a --waspOutputMode option, or without vW tags in --outSAMattributes\n";
             if (wasp && !has("vW")) { outSAMattrOrder.push_back("vW"); vWquant = true; }      // only the vW that is added here goes into the transcriptome BAM as well (:201-206 vs :90-92)
+            for (const char *a : {"vG", "vA", "vW"})        // samAttrRequiresBAM (:236-240, 250-260), in this order
+                if (has(a) && !outBAMunsorted && !outBAMcoord) return std::string("EXITING because of fatal PARAMETER error: --outSAMattributes contains ") + a + " tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without " + a + " tag in --outSAMattributes\n";
             if (wasp && peOverlapNbasesMin > 0) return "EXITING: --waspOutputMode together with --peOverlapNbasesMin is not implemented";
         }
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";

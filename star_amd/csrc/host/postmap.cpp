@@ -40,7 +40,7 @@ struct ReadCtx {
 
 // a segment of a chimeric alignment (--chimOutType WithinBAM / SeparateSAMold): alignType -10 = the representative one, -11 / -12 = supplementary with the hard
 // clip on the left / right, -13 = supplementary with soft clips; mateChr (> nChrReal: none), mateStart (0-based in the chromosome), mateStrand: the other segment
-struct ChimBam { int alignType; uint32_t mateChr, mateStart; uint8_t mateStrand; };
+struct ChimBam { int alignType; uint32_t mateChr, mateStart; uint8_t mateStrand; const VarOverlap *var = nullptr; };
 
 std::string PostMap::samHeader() const {                 // samHeaders.cpp:27-98
     std::string h;
@@ -366,6 +366,7 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
             else if (a == "RG") attrStr(attr, "RG", P.outSAMattrRG.at(b.fileOf(ir)));
             else if (a == "ch") { if (alignType <= -10) attrChar(attr, "ch", '1'); }
             else if ((a == "vA" || a == "vG") && P.var) {          // ReadAlign_alignBAM.cpp:347-360: the SNVs under the whole alignment, on every record of it
+                if (!varDone && chim && chim->var) { vo = *chim->var; varDone = true; }
                 if (!varDone) { P.var->overlap(t, ex, b.bases.data() + b.readOffset[ir], Lread, quant ? 0 : gi.chrStart[t.Chr], vo); varDone = true; }
                 if (!vo.allele.empty()) {
                     uint32_t nv = (uint32_t)vo.allele.size();
@@ -472,6 +473,7 @@ static void chimBamOutput(std::string &out, const RunParams &P, const GenomeInde
         cb.mateStart = (uint32_t)(mateStartG - gi.chrStart[cb.mateChr < gi.view.nChrReal ? cb.mateChr : 0]);
         if (!(cb.mateChr < gi.view.nChrReal)) cb.mateStart = (uint32_t)((uint64_t)-1 - gi.chrStart[0]);
         TrView v; v.t = &trChim[itr]->t; v.ex = trChim[itr]->ex; v.primary = cp.best;
+        cb.var = itr == 0 ? &cp.var1 : &cp.var2;
         std::string raw; std::vector<uint64_t> offs;
         bamMapped(raw, P, gi, rc, v, chimN, iTr, nullptr, false, &offs, &cb);
         for (size_t k = 0; k < offs.size(); k++) recs.push_back(raw.substr(offs[k], (k + 1 < offs.size() ? offs[k + 1] : raw.size()) - offs[k]));
@@ -783,6 +785,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
     std::vector<staramd_transcript> pairT; std::vector<staramd_exon> pairE;
     const bool samOff = this->samOff || dry;
     std::vector<TrView> trMult;
+    int waspPrev = -1;
     for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];
         if (rr.status & STARAMD_ST_FATAL_SEEDS_PER_READ)
@@ -797,6 +800,8 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             for (int q = 0; q < 2; q++) rc.clip[m][q] = m < rc.nMates ? b.clipped(m, q, ir) : 0;
         }
         rc.waspType = waspType ? (*waspType)[ir] : -1;
+        const int waspOfRead = rc.waspType;
+        if (waspType && ir == lo) waspPrev = lo > 0 ? (*waspType)[lo - 1] : waspCarry;
         st.readN++; st.readBases += rc.readLength[0] + rc.readLength[1];
         const staramd_transcript *T = r.tr + rr.trOffset;
         const staramd_exon *EX = r.ex;
@@ -872,6 +877,8 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             if (chimRecord) st.chimericAll++;
         }
         if (chimRecord && P.chim.outSamOld && chimSam) for (const ChimPair &cp : chimPairs) chimSamOldOutput(*chimSam, P, gi, rc, cp);
+        if (chimRecord && P.chim.outBam) rc.waspType = waspPrev;     // waspMap does not run for such a read: its records show the verdict of the read before it (ReadAlign_oneRead.cpp:99-103)
+        else waspPrev = waspOfRead;
         if (chimRecord && P.chim.outBam) {          // the chimera stands for the read in the BAM: nothing else is output or counted for it (ReadAlign_oneRead.cpp:99-101)
             if (!samOff) for (size_t k = 0; k < chimPairs.size(); k++) chimBamOutput(sam, P, gi, rc, chimPairs[k], k, chimPairs.size(), bamKeys);
             continue;

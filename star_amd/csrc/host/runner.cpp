@@ -314,6 +314,7 @@ struct Runner {
             }
             if (sj1.data.size() > 4000000) sj1.collapse();
         }
+        if (waspType && !waspType->empty()) post->waspCarry = waspType->back();
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
         return true;

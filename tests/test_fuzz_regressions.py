@@ -16,7 +16,9 @@ CASES = [("pe76_overlap", False, ["--clip3pNbases", "4", "2", "--outFilterMismat
          ("se50", True, ["--outSAMstrandField", "intronMotif", "--outSAMtype", "BAM", "Unsorted", "--outSAMattrRGline", "ID:a", "SM:x", ",", "ID:b"]),
          ("pe150_indel", True, ["--outFilterType", "BySJout", "--outSAMtype", "BAM", "SortedByCoordinate", "--outSAMattrRGline", "ID:a", "SM:x", ",", "ID:b"]),
          ("pe150_chim", False, ["--outMultimapperOrder", "Random", "--chimSegmentMin", "12", "--chimScoreDropMax", "40", "--chimScoreSeparation", "3", "--chimSegmentReadGapMax", "3",
-                                "--quantMode", "TranscriptomeSAM", "--chimOutType", "WithinBAM", "Junctions", "--outSAMtype", "BAM", "Unsorted"])]
+                                "--quantMode", "TranscriptomeSAM", "--chimOutType", "WithinBAM", "Junctions", "--outSAMtype", "BAM", "Unsorted"]),
+         ("pe150_chim", False, ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "10", "--chimOutType", "WithinBAM", "Junctions", "--varVCFfile", "VCF", "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG",
+                                "--waspOutputMode", "SAMtag", "--outSAMtype", "BAM", "Unsorted"])]
 
 
 @pytest.mark.parametrize("name,split,more", CASES)
@@ -25,6 +27,10 @@ def test_fuzz_regression(name, split, more, tmp_path, built):
     d = os.path.dirname(info["fastq"][0])
     if split:
         info["fastq"] = _split(info["fastq"], d)
+    if "VCF" in more:            # chimeric records carry the variants of the alignments before the junction shift, and the WASP verdict of the read before
+        from test_wasp import _vcf
+        more = [_vcf(info, d) if x == "VCF" else x for x in more]
+        info["extra"] = [x for x in info["extra"] if False]
     info["extra"] = list(info["extra"]) + more
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=info["extra"])
     new = run_with_engine(info, os.path.join(d, "new_"), lambda g, p: oracle_lib.Oracle(g, p), batch_reads=777)

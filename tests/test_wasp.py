@@ -81,6 +81,7 @@ def test_wasp_parameter_errors(tmp_path, built):
     base = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "e_")]
     for extra, text in [(["--waspOutputMode", "SAMtag"], "--waspOutputMode option requires VCF file"), (["--waspOutputMode", "SAMtag", "--varVCFfile", "x.vcf"], "--waspOutputMode requires output to BAM file"),
                         (["--outSAMattributes", "NH", "vA"], "contains vA and/or vG tag(s), but --varVCFfile is not set"), (["--outSAMattributes", "NH", "vW"], "contains vW tag, but --waspOutputMode is not set"),
+                        (["--outSAMattributes", "NH", "vA", "--varVCFfile", "x.vcf"], "contains vA tag, which requires BAM output"),
                         (["--waspOutputMode", "Yes"], "unknown/unimplemented --waspOutputMode option: Yes")]:
         with pytest.raises(RuntimeError) as e:
             capi.HostRun(base + extra)
