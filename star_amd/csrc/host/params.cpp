@@ -197,7 +197,7 @@ std::string RunParams::parse(int argc, char **argv) {
             if (v.size() == 1 && v[0] == "Standard") outSAMattrOrder = {"NH", "HI", "AS", "nM"};
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
             else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC", "ch"}; }   // + ch (Parameters_samAttributes.cpp:51-52)
-            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG" || t == "ch" || t == "vA" || t == "vG" || t == "vW") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
+            else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG" || t == "ch" || t == "vA" || t == "vG" || t == "vW" || t == "rB" || t == "cN") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }
@@ -397,7 +397,8 @@ std::string RunParams::parse(int argc, char **argv) {
             if (varVCFfile.empty() && (has("vA") || has("vG"))) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains vA and/or vG tag(s), but --varVCFfile is not set\nSOLUTION: re-run STAR with a --varVCFfile option, or without vA/vG tags in --outSAMattributes\n";
             if (!wasp && has("vW")) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains vW tag, but --waspOutputMode is not set\nSOLUTION: re-run STAR with a --waspOutputMode option, or without vW tags in --outSAMattributes\n";
             if (wasp && !has("vW")) { outSAMattrOrder.push_back("vW"); vWquant = true; }      // only the vW that is added here goes into the transcriptome BAM as well (:201-206 vs :90-92)
-            for (const char *a : {"vG", "vA", "vW"})        // samAttrRequiresBAM (:236-240, 250-260), in this order
+            if (has("cN") && !outBAMunsorted && !outBAMcoord) return "EXITING: --outSAMattributes cN is only written to BAM output";
+            for (const char *a : {"rB", "vG", "vA", "vW"})        // samAttrRequiresBAM (:236-240, 250-260), in this order
                 if (has(a) && !outBAMunsorted && !outBAMcoord) return std::string("EXITING because of fatal PARAMETER error: --outSAMattributes contains ") + a + " tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without " + a + " tag in --outSAMattributes\n";
             if (wasp && peOverlapNbasesMin > 0) return "EXITING: --waspOutputMode together with --peOverlapNbasesMin is not implemented";
         }
@@ -419,7 +420,7 @@ std::string RunParams::parse(int argc, char **argv) {
     }
     if (attrHasCh && !outBAMunsorted && !outBAMcoord) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains ch tag, which requires BAM output.\nSOLUTION: re-run STAR with --outSAMtype BAM Unsorted (and/or) SortedByCoordinate option, or without ch tag in --outSAMattributes\n";
     outSAMattrOrderQuant = {"NH", "HI"};
-    for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC" || (a == "vW" && vWquant)) outSAMattrOrderQuant.push_back(a);
+    for (const std::string &a : outSAMattrOrder) if (a == "RG" || a == "MC" || a == "rB" || a == "cN" || (a == "vW" && vWquant)) outSAMattrOrderQuant.push_back(a);
     attrNMorMD = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "NM") != outSAMattrOrder.end() || std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "MD") != outSAMattrOrder.end();
     if (genomeDir.empty()) return "EXITING: --genomeDir is required";
     dev.readNmates = (uint32_t)readFilesIn.size();

@@ -374,6 +374,15 @@ static void bamMapped(std::string &out, const RunParams &P, const GenomeIndex &g
                     else { attr += "vGBi"; attr.append((const char *)&nv, 4); attr.append((const char *)vo.genCoord.data(), 4 * (size_t)nv); }
                 }
             }
+            else if (a == "rB") {                                  // :335-346 read and genome coordinates of every block of this mate
+                std::vector<int32_t> rb;
+                for (uint32_t ii = iEx1; ii <= iEx2; ii++) { rb.push_back((int32_t)ex[ii].R + 1); rb.push_back((int32_t)ex[ii].R + ex[ii].L); rb.push_back((int32_t)(ex[ii].G - chrS + 1)); rb.push_back((int32_t)(ex[ii].G - chrS + ex[ii].L)); }
+                attr += "rBBi"; uint32_t n = (uint32_t)rb.size(); attr.append((const char *)&n, 4); attr.append((const char *)rb.data(), 4 * (size_t)n);
+            }
+            else if (a == "cN") {                                  // :318-322 clipped bases at the 5' and 3' end; indexed by the position of the mate in the alignment, as in the reference
+                int32_t v1[2] = {(int32_t)rc.clip[imate][0], (int32_t)rc.clip[imate][1]};
+                attr += "cNBi"; uint32_t n = 2; attr.append((const char *)&n, 4); attr.append((const char *)v1, 8);
+            }
             else if (a == "vW") { if (rc.waspType != -1) { int32_t w = rc.waspType; attr += "vWi"; attr.append((const char *)&w, 4); } }
         }
         attrFromSAMtags(attr, b.extra((int)Mate, ir), P);
@@ -535,6 +544,7 @@ static void bamUnmapped(std::string &out, const RunParams &P, const GenomeIndex 
         attrInt(attr, "NH", 0); attrInt(attr, "HI", 0); attrInt(attr, "AS", trBest ? trBest->maxScore : 0); attrInt(attr, "nM", trBest ? trBest->nMM : 0);
         attrChar(attr, "uT", (char)('0' + unmapType));
         if (!P.outSAMattrRG.empty()) attrStr(attr, "RG", P.outSAMattrRG.at(b.fileOf(ir)));
+        if (std::find(P.outSAMattrOrder.begin(), P.outSAMattrOrder.end(), "cN") != P.outSAMattrOrder.end()) { int32_t v1[2] = {(int32_t)rc.clip[imate][0], (int32_t)rc.clip[imate][1]}; attr += "cNBi"; uint32_t n = 2; attr.append((const char *)&n, 4); attr.append((const char *)v1, 8); }   // :181-184
         attrFromSAMtags(attr, b.extra(imate, ir), P);
         uint32_t core[8];
         core[0] = (uint32_t)-1; core[1] = (uint32_t)-1;

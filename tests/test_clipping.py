@@ -97,6 +97,15 @@ def test_clipping_in_bam_and_chimeric_output(tmp_path, built):
     assert open(ref + "SJ.out.tab", "rb").read() == open(new + "SJ.out.tab", "rb").read()
 
 
+def test_clip_and_block_attributes(tmp_path, built):
+    """cN (bases clipped at the two ends) and rB (read and genome coordinates of every block), BAM only"""
+    info = dict(prepare("pe101", str(tmp_path), need_ref=False))
+    flags = ["--outSAMattributes", "NH", "HI", "rB", "cN", "AS", "--clip3pNbases", "5", "2", "--clip5pNbases", "1", "3", "--outSAMunmapped", "Within", "--outSAMtype", "BAM", "Unsorted"]
+    ref, new = _run(info, "cn", flags, tmp_path)
+    (ta, ra, rr), (tb, rb, nr) = bam_parts(ref + "Aligned.out.bam"), bam_parts(new + "Aligned.out.bam")
+    assert ra == rb and rr == nr and sum(1 for x in rr if b"rBBi" in x) > 1000
+
+
 def test_clipping_parameter_errors(tmp_path, built):
     info = prepare("pe101", str(tmp_path), need_ref=False)
     base = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "e_")]
