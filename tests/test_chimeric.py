@@ -15,7 +15,7 @@ CASES = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", 
                          "--twopassMode", "Basic"]),
          ("pe101", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--outFilterType", "BySJout"]),
          ("se50", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--chimFilter", "None"]),
-         ("pe150_indel", ["--chimSegmentMin", "15", "--runThreadN", "3"]),
+         ("pe101_sparse3", ["--chimSegmentMin", "15", "--runThreadN", "3"]),
          ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMainSegmentMultNmax", "1"])]
 
 MULT = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--chimMultimapNmax", "10"]),

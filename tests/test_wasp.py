@@ -39,7 +39,7 @@ def _vcf(info, d, seed=4):
 
 CASES = [("pe101", ["--waspOutputMode", "SAMtag", "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG", "vW", "--outSAMtype", "BAM", "Unsorted"]),
          ("se50", ["--waspOutputMode", "SAMtag", "--outSAMtype", "BAM", "Unsorted", "SortedByCoordinate", "--outSAMunmapped", "Within", "--runThreadN", "3"]),
-         ("pe150_indel", ["--outSAMattributes", "NH", "HI", "vG", "vA", "--outSAMtype", "BAM", "Unsorted", "--twopassMode", "Basic"]),
+         ("pe76_overlap", ["--outSAMattributes", "NH", "HI", "vG", "vA", "--outSAMtype", "BAM", "Unsorted", "--twopassMode", "Basic"]),
          ("pe101_sparse3", ["--waspOutputMode", "SAMtag", "--outSAMattributes", "vA", "vW", "NH", "--outSAMtype", "BAM", "SortedByCoordinate", "--outFilterType", "BySJout", "--quantMode", "TranscriptomeSAM"]),
          ("pe76_overlap", ["--waspOutputMode", "SAMtag", "--outSAMtype", "BAM", "Unsorted", "--quantMode", "TranscriptomeSAM", "GeneCounts", "--outMultimapperOrder", "Random"])]
 
