@@ -67,17 +67,48 @@ PARAM_SWEEP = {
 }
 
 
-def prepare(name, workdir, need_ref=True):
-    """Generate data set + reference index (+ reference outputs). Returns dict of paths."""
+_PREPARED = {}
+
+
+def _build_dataset(name, d):
     ds_kw, gg_kw, extra = DATASETS[name]
-    d = os.path.join(workdir, name)
     info = synth.make_dataset(d, **ds_kw)
-    idx = os.path.join(d, "idx")
     gg = dict(gg_kw)
     use_gtf = gg.pop("use_gtf")
-    refstar.genome_generate(info["fasta"], idx, gtf=info["gtf"] if use_gtf else None, **gg)
+    refstar.genome_generate(info["fasta"], os.path.join(d, "idx"), gtf=info["gtf"] if use_gtf else None, **gg)
+    return info
+
+
+def prepare(name, workdir, need_ref=True):
+    """Data set + reference index (+ reference outputs) under workdir/name. Returns dict of paths.  The genome, the reads and the index are generated once
+    per test process (they are deterministic and read-only) and linked into every test's own directory, where its outputs go."""
+    import pickle
+    import shutil
+    import tempfile
+    ds_kw, gg_kw, extra = DATASETS[name]
+    if name not in _PREPARED:
+        root = tempfile.mkdtemp(prefix="staramd_data_%s_" % name)
+        info0 = _build_dataset(name, os.path.join(root, name))
+        _PREPARED[name] = (os.path.join(root, name), pickle.dumps(info0))
+        import atexit
+        atexit.register(shutil.rmtree, root, True)
+    src, blob = _PREPARED[name]
+    d = os.path.join(workdir, name)
+    os.makedirs(d, exist_ok=True)
+    info = pickle.loads(blob)
+    for k, v in list(info.items()):                 # fasta, gtf, fastq: links into the test's directory
+        if isinstance(v, str) and v.startswith(src):
+            dst = os.path.join(d, os.path.relpath(v, src)); os.symlink(v, dst) if not os.path.lexists(dst) else None; info[k] = dst
+        elif isinstance(v, list) and v and isinstance(v[0], str) and v[0].startswith(src):
+            out = []
+            for x in v:
+                dst = os.path.join(d, os.path.relpath(x, src)); os.symlink(x, dst) if not os.path.lexists(dst) else None; out.append(dst)
+            info[k] = out
+    idx = os.path.join(d, "idx")
+    if not os.path.lexists(idx):
+        os.symlink(os.path.join(src, "idx"), idx)
     info["idx"] = idx
-    info["extra"] = extra
+    info["extra"] = list(extra)
     if need_ref:
         refstar.align(idx, info["fastq"], os.path.join(d, "ref_"), threads=1, extra=extra)
         info["ref_prefix"] = os.path.join(d, "ref_")
