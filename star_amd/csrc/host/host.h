@@ -119,6 +119,7 @@ struct RunParams {
     int readFilesSAMmates = 0;           // --readFilesType SAM SE | PE: 1 | 2 (0 = Fastx)
     bool samAttrKeepAll = true, samAttrKeepNone = false; std::vector<std::string> samAttrKeep;   // --readFilesSAMattrKeep (BAM output only, Parameters_readFilesInit.cpp:13-31)
     uint32_t peOverlapNbasesMin = 0; double peOverlapMMp = 0.01;   // --peOverlapNbasesMin, --peOverlapMMp
+    bool outSAMorderKeep = false;        // --outSAMorder PairedKeepInputOrder
     bool outSJnone = false;              // --outSJtype None
     int outQSconversionAdd = 0;          // --outQSconversionAdd (readLoad.cpp:71-82)
     bool outMultimapperRandom = false;   // --outMultimapperOrder Random (ReadAlign_multMapSelect.cpp:62-92)

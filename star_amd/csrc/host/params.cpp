@@ -179,7 +179,7 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "peOverlapNbasesMin") peOverlapNbasesMin = (uint32_t)U(k, v);
         else if (k == "peOverlapMMp") peOverlapMMp = D(k, v);
         else if (k == "outMultimapperOrder") { const std::string &m = one(k, v); if (m == "Random") outMultimapperRandom = true; else if (m != "Old_2.4") err = "EXITING because of FATAL INPUT ERROR: unknown/unimplemented value for --outMultimapperOrder: " + m + "\nSOLUTION: specify one of the allowed values: Old_2.4 or Random\n"; }
-        else if (k == "outSAMorder") { const std::string &m = one(k, v); if (m != "Paired" && m != "PairedKeepInputOrder") err = "EXITING because of FATAL INPUT ERROR: unknown value for --outSAMorder: " + m; }   // batches are always written in input order here
+        else if (k == "outSAMorder") { const std::string &m = one(k, v); if (m == "PairedKeepInputOrder") outSAMorderKeep = true; else if (m != "Paired") err = "EXITING because of FATAL INPUT ERROR: unknown value for --outSAMorder: " + m; }   // batches are always written in input order here
         else if (k == "readMatesLengthsIn") { const std::string &m = one(k, v); if (m != "NotEqual" && m != "Equal") err = "EXITING: unknown value for --readMatesLengthsIn: " + m; }
         else if (k == "readQualityScoreBase") { (void)I(k, v); }       // only STARsolo's statistics look at it (SoloFeature_statsOutput.cpp:18)
         else if (k == "runDirPerm") { const std::string &m = one(k, v); if (m == "All_RWX") runDirPermAll = true; else if (m != "User_RWX") err = "EXITING because of FATAL INPUT ERROR: unrecognized option in --runDirPerm=" + m + "\nSOLUTION: use one of the allowed values of --runDirPerm : 'User_RWX' or 'All_RWX' \n"; }
@@ -379,6 +379,9 @@ std::string RunParams::parse(int argc, char **argv) {
     if (readFilesIn.size() == 2 && std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') != std::count(readFilesIn[1].begin(), readFilesIn[1].end(), ','))
         return "EXITING: because of fatal INPUT ERROR: number of input files for mate2=" + std::to_string(std::count(readFilesIn[1].begin(), readFilesIn[1].end(), ',') + 1) + " is not equal to that for mate0="
                + std::to_string(std::count(readFilesIn[0].begin(), readFilesIn[0].end(), ',') + 1) + "\nMake sure that the number of files in --readFilesIn is the same for both mates\n";
+    // Parameters.cpp:710-721 (nothing here depends on the option, but the combinations the reference refuses are refused)
+    if (outFilterBySJout && outSAMorderKeep) return "EXITING: fatal input ERROR: --outFilterType=BySJout is not presently compatible with --outSAMorder=PairedKeepInputOrder\nSOLUTION: re-run STAR without setting one of those parameters.\n";
+    if (outSAMorderKeep && (outBAMunsorted || outBAMcoord || outSAMnone)) return "EXITING: fatal input ERROR: --outSAMorder=PairedKeepInputOrder is presently only compatible with SAM output, i.e. default --outSMAtype SAM\nSOLUTION: re-run STAR without --outSAMorder=PairedKeepInputOrder, or with --outSAMorder=PairedKeepInputOrder --outSMAtype SAM .\n";
     if (outSJnone && outFilterBySJout) return "EXITING because of FATAL input ERROR: --outFilterType BySJout requires --outSJtype Standard\nSOLUTION: --outFilterType Normal    OR   --outFilterType BySJout --outSJtype Standard\n";
     if (outSJnone && twopass) return "EXITING because of FATAL input ERROR: --twopassMode Basic needs the junctions of the 1st pass, i.e. --outSJtype Standard\n";
     if (twopass && genomeLoadShared) return "EXITING because of fatal PARAMETERS error: 2-pass method is not compatible with genomeLoad shared memory options\nSOLUTION: re-run STAR with --genomeLoad NoSharedMemory ; this is the only option compatible with --twopassMode Basic .\n";
