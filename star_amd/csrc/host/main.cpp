@@ -56,6 +56,7 @@ struct ResBuf { std::vector<staramd_read_result> reads; std::vector<staramd_tran
 }
 
 int main(int argc, char **argv) {
+    for (int i = 1; i < argc; i++) if (std::string(argv[i]) == "--version") { printf("2.7.11b\n"); return 0; }      // the version whose behaviour is reproduced (Parameters.cpp:340-343)
     char err[4096];
     void *h = sah_create(argc, argv, err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }

@@ -148,6 +148,23 @@ struct Runner {
             else h = post->samHeader();
             fwrite(h.data(), 1, h.size(), samOut);
         }
+        {   // Log.out and Log.progress.out exist with the reference's first and last lines (pipelines look for the files and for "ALL DONE!"); what the
+            // reference logs in between (its parameter dump, timing of its own stages) has no counterpart here
+            FILE *lo = fopen((P.outFileNamePrefix + "Log.out").c_str(), "wb");
+            if (lo) {
+                fprintf(lo, "STAR version=2.7.11b\nstar_amd: MI355X seed-search-and-stitch engine behind STAR's alignReads command line\n##### Command Line:\n%s\n", P.commandLine.c_str());
+                fprintf(lo, "Finished loading and checking parameters\nNumber of real (reference) chromosomes= %u\n", gi.view.nChrReal);
+                for (uint32_t i = 0; i < gi.view.nChrReal; i++) fprintf(lo, "%u\t%s\t%llu\t%llu\n", i + 1, gi.chrName[i].c_str(), (unsigned long long)gi.chrLength[i], (unsigned long long)gi.chrStart[i]);
+                if (!insertLog.empty()) fputs(insertLog.c_str(), lo);
+                fclose(lo);
+            }
+            FILE *lp = fopen((P.outFileNamePrefix + "Log.progress.out").c_str(), "wb");
+            if (lp) {
+                fputs("           Time    Speed        Read     Read   Mapped   Mapped   Mapped   Mapped Unmapped Unmapped Unmapped Unmapped\n"
+                      "                    M/hr      number   length   unique   length   MMrate    multi   multi+       MM    short    other\n", lp);
+                fclose(lp);
+            }
+        }
         startWriter();
         time(&stats.timeStartMap);
         return true;
@@ -422,6 +439,7 @@ struct Runner {
         if (!P.outSJnone) error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129; STAR.cpp:251
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
+        for (const char *f : {"Log.out", "Log.progress.out"}) { FILE *l = fopen((P.outFileNamePrefix + f).c_str(), "ab"); if (l) { fputs("ALL DONE!\n", l); fclose(l); } }
         if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
