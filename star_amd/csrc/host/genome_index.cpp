@@ -45,6 +45,8 @@ std::string GenomeIndex::load(const std::string &genomeDir) {
             else if (k == "genomeChrBinNbits") ls >> gChrBinNbits;
             else if (k == "genomeSAsparseD") ls >> gSAsparseD;
             else if (k == "sjdbOverhang") ls >> sjdbOverhang;
+            else if (k == "genomeType") { std::string v; ls >> v; if (v != "Full") return "EXITING because of FATAL ERROR: the index in " + dir + " was generated with --genomeType " + v + "; only Full genomes are supported by the MI355X engine"; }
+            else if (k == "genomeTransformType") { std::string v; ls >> v; if (v != "None") return "EXITING because of FATAL ERROR: the index in " + dir + " is a transformed genome (--genomeTransformType " + v + "); genome transformation is not supported by the MI355X engine"; }
         }
     }
     if (versionGenome != "2.7.4a")       // parametersDefault:2 ; Genome_genomeLoad.cpp:71-83
