@@ -329,15 +329,27 @@ public:
     // bamKeys (with --outSAMtype BAM SortedByCoordinate): one entry per BAM record appended to `sam`
     // sj1 / held: 1st stage of --outFilterType BySJout (ReadAlign_outputAlignments.cpp:90-124): junctions of every read go to sj1,
     // reads with an unannotated junction are not output but listed in `held` for the 2nd stage
-    std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                             OutSJ *sj1 = nullptr, std::vector<uint32_t> *held = nullptr, GeneCounts *gc = nullptr, std::vector<BamKey> *bamKeys = nullptr,
-                             std::string *unmappedFastx = nullptr,              // unmappedFastx[2]: --outReadsUnmapped Fastx text per mate
-                             std::string *chimJunction = nullptr,               // Chimeric.out.junction lines (--chimSegmentMin > 0)
-                             std::string *quantBam = nullptr, std::vector<QuantPatch> *quantPatches = nullptr,           // TranscriptomeSAM records
-                             const MultOrder *order = nullptr, bool dry = false,
-                             const MergedBatch *merged = nullptr, const staramd_results *mergedRes = nullptr,
-                             std::string *chimSam = nullptr,                     // Chimeric.out.sam records (--chimOutType SeparateSAMold)
-                             const std::vector<int8_t> *waspType = nullptr) const;   // vW per read (--waspOutputMode SAMtag)   // --peOverlapNbasesMin: merged mates and their alignments   // dry: no alignment records, only the side outputs asked for
+    // what one range of reads adds to (per-thread buffers of the caller; null = that output is off)
+    struct RangeOut {
+        std::string *sam = nullptr;                      // SAM text or raw BAM records of the alignments
+        OutSJ *sj = nullptr; Stats *st = nullptr;
+        OutSJ *sj1 = nullptr; std::vector<uint32_t> *held = nullptr;   // 1st stage of --outFilterType BySJout (ReadAlign_outputAlignments.cpp:90-124): junctions of every read, reads held for the 2nd stage
+        GeneCounts *gc = nullptr;                        // --quantMode GeneCounts
+        std::vector<BamKey> *bamKeys = nullptr;          // --outSAMtype BAM SortedByCoordinate: one key per record in *sam
+        std::string *unmappedFastx = nullptr;            // [2]: --outReadsUnmapped Fastx text per mate
+        std::string *chimJunction = nullptr;             // Chimeric.out.junction lines (--chimSegmentMin > 0); non-null switches the detection on
+        std::string *chimSam = nullptr;                  // Chimeric.out.sam records (--chimOutType SeparateSAMold)
+        std::string *quantBam = nullptr; std::vector<QuantPatch> *quantPatches = nullptr;   // --quantMode TranscriptomeSAM records
+    };
+    // what the batch brings along besides its own alignments
+    struct RangeIn {
+        const MultOrder *order = nullptr;                // --outMultimapperOrder Random: the shuffles, drawn beforehand
+        bool dry = false;                                // no alignment records, only the side outputs asked for
+        const MergedBatch *merged = nullptr; const staramd_results *mergedRes = nullptr;   // --peOverlapNbasesMin: merged mates and their alignments
+        const std::vector<int8_t> *waspType = nullptr;   // vW per read (--waspOutputMode SAMtag)
+    };
+    std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, const RangeOut &out, const RangeIn &in) const;
+    std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, const RangeOut &out) const;
     // nAlignT (with --quantMode TranscriptomeSAM): per read, the number of transcriptomic alignments + 1 where the read draws its primary one
     // right after its shuffles (ReadAlign_quantTranscriptome.cpp:69), 0 where it does not
     template <class Rng> void drawMultOrder(const ReadBatch &b, const staramd_results &r, Rng &&uniform01, MultOrder &o, const std::vector<uint32_t> *nAlignT = nullptr,

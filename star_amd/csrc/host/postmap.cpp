@@ -710,7 +710,8 @@ void PostMap::multCounts(const ReadBatch &b, const staramd_results &r, uint32_t 
 }
 
 std::string PostMap::process(const ReadBatch &b, const staramd_results &r, std::string &sam, OutSJ &sj, Stats &st) {
-    return processRange(b, r, 0, b.n, sam, sj, st);
+    RangeOut o; o.sam = &sam; o.sj = &sj; o.st = &st;
+    return processRange(b, r, 0, b.n, o);
 }
 
 // reads [lo, hi) of the batch: the reference's per-thread ReadAlign loop body (ReadAlign_oneRead.cpp:87-111); ranges of one
@@ -787,10 +788,15 @@ static void recordSJ(const RunParams &P, const std::vector<TrView> &trMult, uint
     }
 }
 
-std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, std::string &sam, OutSJ &sj, Stats &st,
-                                  OutSJ *sj1, std::vector<uint32_t> *held, GeneCounts *gc, std::vector<BamKey> *bamKeys, std::string *unmappedFastx, std::string *chimJunction,
-                                  std::string *quantBam, std::vector<QuantPatch> *quantPatches, const MultOrder *order, bool dry,
-                                  const MergedBatch *merged, const staramd_results *mergedRes, std::string *chimSam, const std::vector<int8_t> *waspType) const {
+std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, const RangeOut &out) const { return processRange(b, r, lo, hi, out, RangeIn()); }
+
+std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, const RangeOut &out, const RangeIn &in) const {
+    std::string &sam = *out.sam; OutSJ &sj = *out.sj; Stats &st = *out.st;
+    OutSJ *const sj1 = out.sj1; std::vector<uint32_t> *const held = out.held; GeneCounts *const gc = out.gc; std::vector<BamKey> *const bamKeys = out.bamKeys;
+    std::string *const unmappedFastx = out.unmappedFastx, *const chimJunction = out.chimJunction, *const chimSam = out.chimSam, *const quantBam = out.quantBam;
+    std::vector<QuantPatch> *const quantPatches = out.quantPatches;
+    const MultOrder *const order = in.order; const bool dry = in.dry; const MergedBatch *const merged = in.merged; const staramd_results *const mergedRes = in.mergedRes;
+    const std::vector<int8_t> *const waspType = in.waspType;
     const bool bam = P.outBAMunsorted || P.outBAMcoord;
     std::vector<staramd_transcript> pairT; std::vector<staramd_exon> pairE;
     const bool samOff = this->samOff || dry;

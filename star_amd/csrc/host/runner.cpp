@@ -243,7 +243,11 @@ struct Runner {
                     const bool samOff0 = post->samOff;
                     (void)samOff0;
                     std::string chim0;      // reads whose chimera goes into the BAM are not quantified: the detection has to run here too
-                    errs[t] = post->processRange(bt, *r, lo, hi, sam0, sj0, st0, stage1 ? &sj10 : nullptr, stage1 ? &held0 : nullptr, nullptr, nullptr, nullptr, chimOn ? &chim0 : nullptr, &q0, &qp0, nullptr, true, mg, mgRes);
+                    PostMap::RangeOut ro; ro.sam = &sam0; ro.sj = &sj0; ro.st = &st0; if (stage1) { ro.sj1 = &sj10; ro.held = &held0; }
+                    if (chimOn) ro.chimJunction = &chim0;
+                    ro.quantBam = &q0; ro.quantPatches = &qp0;
+                    PostMap::RangeIn ri; ri.dry = true; ri.merged = mg; ri.mergedRes = mgRes;
+                    errs[t] = post->processRange(bt, *r, lo, hi, ro, ri);
                     for (const QuantPatch &p : qp0) nAlignT[p.ir] = p.nAlignT + 1;
                 };
                 std::vector<std::thread> th;
@@ -256,27 +260,32 @@ struct Runner {
         auto work = [&](uint32_t t) {
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
             o.sams[t].clear();
-            if ((P.outBAMunsorted || P.outBAMcoord) && !post->samOff) {     // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
-                std::string &raw = o.raws[t];
-                raw.clear();
-                errs[t] = post->processRange(bt, *r, lo, hi, raw, sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                             P.outBAMcoord ? &keyss[t] : nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t], waspType);
-                bool cut = false;
-                if (P.outBAMcoord) for (const BamKey &k : keyss[t]) if (k.len & 0x80000000u) { cut = true; break; }
-                if (cut) {                                           // KeepPairs with both BAM files: records that belong to the sorted one only
-                    std::string only; size_t pos = 0;
-                    for (BamKey &k : keyss[t]) if (k.len & 0x80000000u) { k.len &= 0x7fffffffu; only.append(raw, pos, k.off - pos); pos = k.off + k.len; }
-                    only.append(raw, pos, std::string::npos);
-                    if (errs[t].empty() && !bgzfCompress(only, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
-                    return;
-                }
-                if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
+            const bool bamOut = (P.outBAMunsorted || P.outBAMcoord) && !post->samOff;   // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
+            std::string &raw = o.raws[t];
+            if (bamOut) raw.clear();
+            PostMap::RangeOut ro;
+            ro.sam = bamOut ? &raw : &o.sams[t]; ro.sj = &sjs[t]; ro.st = &sts[t];
+            if (stage1) { ro.sj1 = &sj1s[t]; ro.held = &helds[t]; }
+            if (quant) ro.gc = &gcs[t];
+            if (bamOut && P.outBAMcoord) ro.bamKeys = &keyss[t];
+            if (unm) ro.unmappedFastx = unms[t].data();
+            if (chimOn) ro.chimJunction = &chims[t];
+            if (!chimSams.empty()) ro.chimSam = &chimSams[t];
+            if (trSAM) { ro.quantBam = &qraws[t]; ro.quantPatches = &qpatches[t]; }
+            PostMap::RangeIn ri;
+            ri.order = randomOrder ? &multOrder : nullptr; ri.merged = mg; ri.mergedRes = mgRes; ri.waspType = waspType;
+            errs[t] = post->processRange(bt, *r, lo, hi, ro, ri);
+            if (!bamOut) return;
+            bool cut = false;
+            if (P.outBAMcoord) for (const BamKey &k : keyss[t]) if (k.len & 0x80000000u) { cut = true; break; }
+            if (cut) {                                           // KeepPairs with both BAM files: records that belong to the sorted one only
+                std::string only; size_t pos = 0;
+                for (BamKey &k : keyss[t]) if (k.len & 0x80000000u) { k.len &= 0x7fffffffu; only.append(raw, pos, k.off - pos); pos = k.off + k.len; }
+                only.append(raw, pos, std::string::npos);
+                if (errs[t].empty() && !bgzfCompress(only, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
-            errs[t] = post->processRange(bt, *r, lo, hi, o.sams[t], sjs[t], sts[t], stage1 ? &sj1s[t] : nullptr, stage1 ? &helds[t] : nullptr, quant ? &gcs[t] : nullptr,
-                                         nullptr, unm ? unms[t].data() : nullptr, chimOn ? &chims[t] : nullptr,
-                                             trSAM ? &qraws[t] : nullptr, trSAM ? &qpatches[t] : nullptr, randomOrder ? &multOrder : nullptr, false, mg, mgRes, chimSams.empty() ? nullptr : &chimSams[t], waspType);
+            if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
         };
         if (T == 1) work(0);
         else {
