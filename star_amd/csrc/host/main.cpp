@@ -17,27 +17,7 @@
 #include <condition_variable>
 #include <deque>
 #include <string>
-#include "../../../include/star_amd.h"
-
-extern "C" {
-void *sah_create(int argc, char **argv, char *errbuf, int errlen);
-const staramd_genome *sah_genome(void *h);
-const staramd_params *sah_params(void *h);
-uint64_t sah_batch_reads(void *h);
-int sah_device(void *h);
-int sah_tool_done(void *h);
-int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
-int sah_emit_slot(void *h, int slot, const staramd_results *res);
-int sah_merged_slot(void *h, int slot, staramd_batch *out);
-int sah_wasp_slot(void *h, int slot, const staramd_results *res, staramd_batch *out);
-int sah_wasp_results_slot(void *h, int slot, const staramd_results *res, const staramd_results *resWasp);
-int sah_emit_slot_merged(void *h, int slot, const staramd_results *res, const staramd_results *resMerged);
-int sah_finish(void *h);
-int sah_next_phase(void *h);
-uint64_t sah_novel_junctions(void *h, const uint64_t **start, const uint64_t **end);
-const char *sah_error(void *h);
-void sah_destroy(void *h);
-}
+#include "../../../include/star_amd_host.h"
 
 namespace {
 struct Msg { int slot; int n; staramd_batch b; int resIdx; bool merged; };

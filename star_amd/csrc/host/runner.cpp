@@ -4,6 +4,7 @@
 // so the same post-map code is exercised with results produced by the HIP engine (product) or,
 // in tests only, by the CPU oracle.
 #include "host.h"
+#include "../../../include/star_amd_host.h"
 #include <cstring>
 #include <algorithm>
 #include <ctime>

@@ -47,3 +47,13 @@ def test_no_cpu_fallback_without_gpu(built):
     rc = L.staramd_create(C.byref(ctx), 0, C.byref(g), C.byref(p), 16, 0)
     assert rc == -2, rc                      # STARAMD_ERR_DEVICE
     assert b"no HIP device" in L.staramd_last_error() or b"hip" in L.staramd_last_error().lower()
+
+
+def test_host_library_exports_every_declared_symbol(built):
+    """include/star_amd_host.h (the job-level interface around the engine) against libstaramd_host.so"""
+    txt = open(os.path.join(ROOT, "include", "star_amd_host.h")).read()
+    names = sorted(set(re.findall(r"^\s*[a-z_A-Z0-9 \*]*?\b(sah_[a-z_0-9]+)\s*\(", txt, re.M)))
+    assert len(names) >= 35, names
+    L = capi.host_lib()
+    for n in names:
+        assert hasattr(L, n), "libstaramd_host.so does not export " + n
