@@ -121,6 +121,31 @@ class ResultBuffers:
                 bytes(memoryview(self.ex))[:r.exCount * C.sizeof(Exon)])
 
 
+def map_in_pieces(map_one, batch, bufs, max_reads):
+    """A batch larger than an engine context takes (e.g. the re-mapping batch of --waspOutputMode, where a read over a dense SNV cluster has hundreds of
+    copies): mapped in pieces of at most max_reads reads through map_one(piece, piece_bufs); the results are appended into bufs as if it had been one call."""
+    n, done, tr_n, ex_n = batch.nReads, 0, 0, 0
+    ro = C.cast(batch.readOffset, C.c_void_p).value; m1 = C.cast(batch.mate1Length, C.c_void_p).value; mm = C.cast(batch.mmMaxTotal, C.c_void_p).value
+    while done < n:
+        k = min(max_reads, n - done)
+        piece = Batch()
+        piece.nReads = k; piece.bases = batch.bases
+        piece.readOffset = C.cast(ro + 8 * done, type(batch.readOffset)); piece.mate1Length = C.cast(m1 + 2 * done, type(batch.mate1Length)); piece.mmMaxTotal = C.cast(mm + 2 * done, type(batch.mmMaxTotal))
+        pb = ResultBuffers(k, tr_cap=max(1024, bufs.res.trCapacity // 2))
+        map_one(piece, pb)
+        if tr_n + pb.res.trCount > bufs.res.trCapacity or ex_n + pb.res.exCount > bufs.res.exCapacity:
+            raise RuntimeError("map_in_pieces: result buffers too small (-3)")
+        for i in range(k):
+            bufs.reads[done + i] = pb.reads[i]
+            bufs.reads[done + i].trOffset += tr_n
+        C.memmove(C.byref(bufs.tr, tr_n * C.sizeof(Transcript)), pb.tr, pb.res.trCount * C.sizeof(Transcript))
+        for i in range(pb.res.trCount):
+            bufs.tr[tr_n + i].exonOffset += ex_n
+        C.memmove(C.byref(bufs.ex, ex_n * C.sizeof(Exon)), pb.ex, pb.res.exCount * C.sizeof(Exon))
+        tr_n += pb.res.trCount; ex_n += pb.res.exCount; done += k
+    bufs.res.trCount = tr_n; bufs.res.exCount = ex_n
+
+
 def _need(path):
     if not os.path.isfile(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or `make`) first; "
@@ -271,6 +296,7 @@ class Engine:
         L = engine_lib()
         self.L = L
         self.ctx = C.c_void_p()
+        self.max_reads = max_reads
         max_bases = max_bases or max_reads * 660
         rc = L.staramd_create(C.byref(self.ctx), device, genome_p, params_p, max_reads, max_bases)
         if rc != 0:
@@ -287,6 +313,8 @@ class Engine:
             raise RuntimeError("staramd_set_novel_junctions failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))
 
     def map_batch(self, batch, bufs):
+        if batch.nReads > self.max_reads:        # more reads than the context was created for: in pieces
+            return map_in_pieces(self.map_batch, batch, bufs, self.max_reads)
         rc = self.L.staramd_map_batch(self.ctx, C.byref(batch), C.byref(bufs.res))
         if rc != 0:
             raise RuntimeError("staramd_map_batch failed (%d): %s" % (rc, self.L.staramd_last_error().decode()))

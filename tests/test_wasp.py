@@ -86,3 +86,18 @@ def test_wasp_parameter_errors(tmp_path, built):
         with pytest.raises(RuntimeError) as e:
             capi.HostRun(base + extra)
         assert text in str(e.value)
+
+
+def test_large_batches_are_mapped_in_pieces(tmp_path, built):
+    """capi.map_in_pieces (what Engine.map_batch does with a batch larger than its context, e.g. a WASP re-mapping batch): same result bytes as one call"""
+    info = prepare("pe101", str(tmp_path), need_ref=False)
+    run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "p_")])
+    orc = oracle_lib.Oracle(run.genome, run.params)
+    try:
+        b = run.next_batch(2500)
+        whole, parts = capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64), capi.ResultBuffers(b.nReads, tr_cap=b.nReads * 64)
+        orc.map_batch(b, whole)
+        capi.map_in_pieces(orc.map_batch, b, parts, 700)
+        assert whole.res.trCount == parts.res.trCount and whole.as_bytes(b.nReads) == parts.as_bytes(b.nReads)
+    finally:
+        orc.close(); run.close()
