@@ -1,4 +1,4 @@
-"""Flag combinations that tools/fuzz_flags.py found to differ from the reference, kept as regression tests: unmapped reads in the transcriptome BAM,
+"""Flag combinations that tests/tools/fuzz_flags.py found to differ from the reference, kept as regression tests: unmapped reads in the transcriptome BAM,
 random multimapper order with merged mates, order of auto-added RG / XS attributes, read groups of reads held for the 2nd BySJout stage with several input
 files, random order + chimeric alignments in the BAM + transcriptome BAM."""
 import os

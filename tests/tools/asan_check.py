@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Memory / undefined-behaviour check of the host side (CPU): main.cpp + the host library + the oracle behind the engine's C ABI (oracle/cli_shim.cpp), built into
 one binary with -fsanitize=address,undefined and run over feature-rich flag sets and odd inputs (SAM text, multi-line FASTA, several files, edge reads).
-usage: tools/asan_check.py      (exit code 1 when a sanitizer reports anything)"""
+usage: tests/tools/asan_check.py      (exit code 1 when a sanitizer reports anything)"""
 import glob
 import os
 import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 from util import make_edge_reads, prepare            # noqa: E402
 import test_fasta_reads, test_output_options, test_sam_reads, test_wasp   # noqa: E402

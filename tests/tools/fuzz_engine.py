@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """GPU side of the bug hunt (needs an MI355X): random data sets and random HOT-PATH flags, the HIP engine's result buffers against the oracle's, byte for
 byte -- every read result, transcript and exon record, in both result-selection modes, including the second batch of merged mates and clipped / 0-length mates.
-The oracle side of the same combinations is pinned against the reference by tools/fuzz_flags.py on CPU.
-usage (on the GPU box): python tools/fuzz_engine.py [iterations] [seed]         e.g.  gpurun --timeout 900 -- 'python tools/fuzz_engine.py 60 1 > gpurun_out/fuzz_engine.log 2>&1'"""
+The oracle side of the same combinations is pinned against the reference by tests/tools/fuzz_flags.py on CPU.
+usage (on the GPU box): python tests/tools/fuzz_engine.py [iterations] [seed]         e.g.  gpurun --timeout 900 -- 'python tests/tools/fuzz_engine.py 60 1 > gpurun_out/fuzz_engine.log 2>&1'"""
 import os
 import random
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 from util import capi, oracle_lib, prepare, refstar   # noqa: E402
 from star_amd import synth                            # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Random flag combinations against the reference (CPU): the host library driven by the oracle vs oracle/_ref/STAR with the same flags on the same data.
-Not part of the test suite; a bug hunt.  usage: tools/fuzz_flags.py [iterations] [seed]   -- failures are listed with the command line that reproduces them."""
+Not part of the test suite; a bug hunt.  usage: tests/tools/fuzz_flags.py [iterations] [seed]   -- failures are listed with the command line that reproduces them."""
 import os
 import random
 import shutil
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 from util import bam_parts, compare_outputs, oracle_lib, prepare, refstar, run_with_engine   # noqa: E402
 
