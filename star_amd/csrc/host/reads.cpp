@@ -439,6 +439,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     if (P.outSAMreadIDnumber && !fromMemory)           // --outSAMreadID Number: the read's 1-based index in the input (ReadAlignChunk_processChunks.cpp:117-119)
         for (uint64_t i = 0; i < n; i++) {
             std::string nm = std::to_string(readsSoFar + i + 1);
+            for (char c : P.readNameSeparator) { size_t q = nm.find(c); if (q != std::string::npos) nm.resize(q); }   // readLoad trims the number like any other name (readLoad.cpp:95-98)
             b.nameSpan[i] = TextSpan{(uint64_t)b.text[0].size(), (uint32_t)nm.size()};
             b.text[0].insert(b.text[0].end(), nm.begin(), nm.end());
         }

@@ -79,6 +79,12 @@ def one(it, rng, keep):
         info["extra"] = []
         if not gtf:
             global POOL_NO_GTF
+    elif rng.random() < 0.2:                         # a genome with two diverged copies of every chromosome: most reads are multimappers with ties and near-ties
+        import pathlib
+        import test_host_flags
+        pe = rng.random() < 0.6
+        info = test_host_flags._multicopy(pathlib.Path(work), pe, seed=rng.randrange(1, 1000))
+        name = "multicopy_%s" % ("pe" if pe else "se")
     else:
         info = dict(prepare(name, work, need_ref=False))
     paired = len(info["fastq"]) == 2
