@@ -135,12 +135,11 @@ RANDOM = {
 }
 
 
-def _multicopy(tmp_path, paired=True, seed=21):
+def _multicopy_build(d, paired, seed):
     """a genome where every chromosome has two diverged copies (0.7 % and 1.5 % substitutions): most reads are multimappers whose
     alignments tie or differ by a few points"""
     import numpy as np
     from star_amd import synth
-    d = str(tmp_path / "multicopy")
     info = synth.make_dataset(d, seed=seed, chr_lengths=(120000, 90000), n_tr=60, n_reads=2000, read_len=101 if paired else 75, paired=paired, sub_rate=0.004)
     rng = np.random.default_rng(seed)
     names, seqs, cur = [], [], None
@@ -162,6 +161,30 @@ def _multicopy(tmp_path, paired=True, seed=21):
                     o.write(t[i:i + 70] + "\n")
     info["idx"] = os.path.join(d, "idx")
     refstar.genome_generate(info["fasta"], info["idx"], gtf=info["gtf"], sa_index_nbases=8, sjdb_overhang=100)
+    info["extra"] = []
+    return info
+
+
+_MULTICOPY = {}
+
+
+def _multicopy(tmp_path, paired=True, seed=21):
+    """built once per (paired, seed) and test process, linked into the test's own directory"""
+    import atexit
+    import shutil
+    import tempfile
+    key = (paired, seed)
+    if key not in _MULTICOPY:
+        root = tempfile.mkdtemp(prefix="staramd_multicopy_")
+        atexit.register(shutil.rmtree, root, True)
+        _MULTICOPY[key] = _multicopy_build(os.path.join(root, "multicopy"), paired, seed)
+    src = _MULTICOPY[key]
+    d = str(tmp_path / "multicopy")
+    os.makedirs(d, exist_ok=True)
+    info = dict(src)
+    link = lambda p: (os.path.lexists(os.path.join(d, os.path.basename(p))) or os.symlink(p, os.path.join(d, os.path.basename(p)))) and None or os.path.join(d, os.path.basename(p))
+    info["fasta"], info["gtf"], info["idx"] = link(src["fasta"]), link(src["gtf"]), link(src["idx"])
+    info["fastq"] = [link(f) for f in src["fastq"]]
     info["extra"] = []
     return info
 
