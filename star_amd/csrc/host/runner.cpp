@@ -4,6 +4,8 @@
 // so the same post-map code is exercised with results produced by the HIP engine (product) or,
 // in tests only, by the CPU oracle.
 #include "host.h"
+#include <sys/stat.h>
+#include <cerrno>
 #include "../../../include/star_amd_host.h"
 #include <cstring>
 #include <algorithm>
@@ -60,6 +62,18 @@ struct Runner {
         time(&stats.timeStart);
         error = P.parse(argc, argv);
         if (!error.empty()) return false;
+        {   // createDirectory (streamFuns.cpp:10-35): the directory part of --outFileNamePrefix is made, with its parents, mode S_IRWXU
+            const std::string dirPath = P.outFileNamePrefix.substr(0, P.outFileNamePrefix.find_last_of('/') + 1);
+            if (!dirPath.empty() && mkdir(dirPath.c_str(), S_IRWXU) == -1 && errno != EEXIST) {
+                for (size_t i1 = dirPath.find_first_of('/', 1); i1 < dirPath.size(); i1 = dirPath.find_first_of('/', i1 + 1)) {
+                    const std::string d1 = dirPath.substr(0, i1);
+                    if (mkdir(d1.c_str(), S_IRWXU) == -1 && errno != EEXIST) {
+                        error = "EXITING because of fatal OUTPUT FILE error: could not create output directory: " + d1 + " for --outFileNamePrefix " + P.outFileNamePrefix + "\n ERROR: " + strerror(errno) + "\nSOLUTION: check the path and permissions.\n";
+                        return false;
+                    }
+                }
+            }
+        }
         if (P.runModeFromBAM) {                                     // a tool mode: no index, no reads, no engine
             error = signalFromBamFile(P, P.inputBAMfile, P.outFileNamePrefix + "Signal");
             toolDone = true;

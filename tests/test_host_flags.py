@@ -319,3 +319,12 @@ def test_accepted_knobs_and_directory_permissions(tmp_path, built):
         with pytest.raises(RuntimeError) as e:
             capi.HostRun(base + extra)
         assert text in str(e.value), (extra, str(e.value))
+
+
+def test_output_directory_is_created(tmp_path, built):
+    """the directory part of --outFileNamePrefix is created with its parents (streamFuns.cpp createDirectory)"""
+    info = prepare("se50", str(tmp_path), need_ref=False)
+    prefix = str(tmp_path / "a" / "b" / "run_")
+    run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", prefix])
+    run.close()
+    assert os.path.isdir(str(tmp_path / "a" / "b")) and os.path.exists(prefix + "Log.out")
