@@ -28,7 +28,8 @@ def _header(path, keep_cl=False):
 
 
 def _both(info, tag, flags, **kw):
-    d = os.path.dirname(info["fastq"][0].split(",")[0])
+    d = os.path.dirname(info["fastq"][0].split(",")[0]) or info.get("outdir", "")
+    assert d, "outputs must not land in the current directory"
     info = dict(info)
     info["extra"] = list(info["extra"]) + flags
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_%s_" % tag), threads=1, extra=info["extra"])
@@ -90,6 +91,7 @@ def test_manifest_and_prefix(name, tmp_path, built):
     assert _header(ref + "Aligned.out.sam") == _header(new + "Aligned.out.sam")
     # the same through --readFilesIn with a trailing comma
     info["fastq"] = [",".join(os.path.basename(x) for x in p) + "," for p in parts]
+    info["outdir"] = d
     ref, new = _both(info, "pre", ["--readFilesPrefix", d + "/", "--outSAMattrRGline", "ID:first", "SM:a b", ",", "ID:second"])
     assert not compare_outputs(ref, new)
 
