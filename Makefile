@@ -18,20 +18,20 @@ define build_engine
 	@set -e; for f in $(HIP_SRC); do b=$$(basename $$f .hip); extra=""; if [ $$b = k_stitch ]; then extra="$(STITCH_FLAGS)"; fi; \
 	  $(HIPCC) $(HIPFLAGS) $(2) $$extra -c $$f -o star_amd/lib/obj/$(1)/$$b.o & done; wait; \
 	  for f in $(HIP_SRC); do test -s star_amd/lib/obj/$(1)/$$(basename $$f .hip).o; done
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(patsubst star_amd/csrc/engine/%.hip,star_amd/lib/obj/$(1)/%.o,$(HIP_SRC)) -o $@
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(foreach f,$(HIP_SRC),star_amd/lib/obj/$(1)/$(basename $(notdir $(f))).o) -o $@
 endef
 
 HOST_SRC := $(wildcard star_amd/csrc/host/*.cpp)
 HOST_LIB_SRC := $(filter-out star_amd/csrc/host/main.cpp,$(HOST_SRC))
-HIP_SRC  := $(wildcard star_amd/csrc/engine/*.hip)
-HIP_HDR  := $(wildcard star_amd/csrc/engine/*.h) include/star_amd.h
+HIP_SRC  := $(wildcard star_amd/csrc/engine/*.hip) $(wildcard star_amd/csrc/index/*.hip)
+HIP_HDR  := $(wildcard star_amd/csrc/engine/*.h) $(wildcard star_amd/csrc/index/*.h) include/star_amd.h include/star_amd_index.h
 
 all: host engine shadow cli oracle
 
 host: star_amd/lib/libstaramd_host.so
 engine: star_amd/lib/libstaramd.so
 cli: star_amd/bin/star_amd
-oracle: oracle/_build/liboracle.so oracle/_build/star_amd_oracle_cli
+oracle: oracle/_build/liboracle.so oracle/_build/libindex_emul.so oracle/_build/star_amd_oracle_cli
 
 star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
 	@mkdir -p star_amd/lib
@@ -46,7 +46,7 @@ shadow: star_amd/lib/libstaramd_shadow.so
 star_amd/lib/libstaramd_shadow.so: $(HIP_SRC) $(HIP_HDR)
 	$(call build_engine,shadow,-DSTARAMD_SHADOW)
 
-star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so
+star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so include/star_amd_host.h include/star_amd_index.h
 	@mkdir -p star_amd/bin
 	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp -o $@ -Lstar_amd/lib -lstaramd_host -lstaramd -Wl,-rpath,'$$ORIGIN/../lib'
 
@@ -54,9 +54,14 @@ oracle/_build/liboracle.so: oracle/star_oracle.cpp include/star_amd.h
 	@mkdir -p oracle/_build
 	$(CXX) $(CXXFLAGS) -shared oracle/star_oracle.cpp -o $@
 
+# test infrastructure: the index-building algorithm (star_amd/csrc/index/index_core.h) on a plain-loop backend, to check its logic without a GPU
+oracle/_build/libindex_emul.so: oracle/index_emul.cpp $(wildcard star_amd/csrc/index/*.h)
+	@mkdir -p oracle/_build
+	$(CXX) $(CXXFLAGS) -fopenmp -shared oracle/index_emul.cpp -o $@
+
 # test infrastructure: the command-line front end with the oracle behind the engine's C ABI (oracle/cli_shim.cpp), for CPU tests of main.cpp
-oracle/_build/star_amd_oracle_cli: star_amd/csrc/host/main.cpp oracle/cli_shim.cpp oracle/_build/liboracle.so star_amd/lib/libstaramd_host.so
-	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
+oracle/_build/star_amd_oracle_cli: star_amd/csrc/host/main.cpp oracle/cli_shim.cpp oracle/_build/liboracle.so oracle/_build/libindex_emul.so star_amd/lib/libstaramd_host.so include/star_amd_host.h include/star_amd_index.h
+	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -lindex_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
 
 ref:
 	$(MAKE) -f oracle/Makefile.ref -j8 all

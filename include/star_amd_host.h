@@ -27,6 +27,12 @@ void *sah_create(int argc, char **argv, char *errbuf, int errlen);      /* NULL 
 void  sah_destroy(void *h);
 const char *sah_error(void *h);
 int   sah_tool_done(void *h);                                           /* 1: --runMode inputAlignmentsFromBAM, everything happened in sah_create */
+/* --runMode genomeGenerate: sah_create scanned the FASTA files; build SA + SAindex into these buffers with staramd_index_build
+ * (star_amd_index.h), then sah_generate_finish inserts the annotated junctions and writes the genomeDir files */
+int   sah_generate_mode(void *h);
+int   sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases,
+                           uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap);
+int   sah_generate_finish(void *h, uint64_t nSA, uint64_t nSAbyte, uint64_t nSAibyte);
 const staramd_genome *sah_genome(void *h);                              /* what staramd_create / staramd_update_index take */
 const staramd_params *sah_params(void *h);
 uint64_t sah_batch_reads(void *h);                                      /* --gpuBatchReads */

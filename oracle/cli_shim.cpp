@@ -3,6 +3,7 @@
 // three-stage batch pipeline, the phases of 2-pass / BySJout, the second batch of merged mates) can be exercised by tests on a box without a GPU.
 // `make oracle` links it with main.cpp into oracle/_build/star_amd_oracle_cli; tests/test_cli_pipeline.py is the only user.
 #include "../include/star_amd.h"
+#include "../include/star_amd_index.h"
 #include <string>
 
 extern "C" {
@@ -10,6 +11,7 @@ void *oracle_create(const staramd_genome *g, const staramd_params *p);
 void oracle_destroy(void *h);
 int oracle_set_novel_junctions(void *h, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage);
 int oracle_map_batch(void *h, const staramd_batch *b, staramd_results *r);
+int index_emul_build(const uint8_t *G, uint64_t nGenome, uint32_t GstrandBit, uint32_t saIndexNbases, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, uint64_t *out);
 }
 
 struct staramd_ctx { void *o; };
@@ -27,4 +29,15 @@ int staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results 
 }
 void staramd_destroy(staramd_ctx *ctx) { if (ctx) { oracle_destroy(ctx->o); delete ctx; } }
 const char *staramd_last_error(void) { return lastError.c_str(); }
+// index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp
+int staramd_index_build(int, const uint8_t *G, const staramd_index_params *p, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, staramd_index_result *res) {
+    uint64_t out[32];
+    int rc = index_emul_build(G, p->nGenome, p->GstrandBit, p->gSAindexNbases, SA, saCap, SAi, saiCap, out);
+    *res = staramd_index_result();
+    res->nSA = out[0]; res->nSAbyte = out[1]; res->nSAi = out[2]; res->nSAibyte = out[3]; res->doublingRounds = (uint32_t)out[4];
+    for (int i = 0; i < 17; i++) res->genomeSAindexStart[i] = out[5 + i];
+    if (rc) lastError = "index_emul_build failed";
+    return rc;
+}
+const char *staramd_index_last_error(void) { return lastError.c_str(); }
 }

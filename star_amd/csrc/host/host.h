@@ -114,6 +114,8 @@ struct RunParams {
     std::string readFilesPrefix, readFilesManifest;         // --readFilesPrefix, --readFilesManifest (Parameters_readFilesInit.cpp:41-139)
     std::vector<std::string> outSAMheaderHD, outSAMheaderPG; std::string outSAMheaderCommentFile;   // samHeaders.cpp:56-96
     bool runDirPermAll = false, genomeLoadShared = false;
+    // --runMode genomeGenerate (genome_generate.cpp): FASTA -> genomeDir, suffix array + SAindex built on the device
+    bool runModeGenerate = false; std::vector<std::string> genomeFastaFiles; uint32_t genomeSAindexNbases = 14, genomeChrBinNbits = 18, genomeSAsparseD = 1;
     bool runModeFromBAM = false; std::string inputBAMfile;   // --runMode inputAlignmentsFromBAM --inputBAMfile: signal tracks from an existing BAM, no mapping
     std::string varVCFfile; bool varHeteroOnly = false, wasp = false; const struct Variation *var = nullptr;   // --varVCFfile, --waspOutputMode SAMtag (Parameters.cpp:854-890)
     int readFilesSAMmates = 0;           // --readFilesType SAM SE | PE: 1 | 2 (0 = Fastx)
@@ -232,6 +234,13 @@ std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, b
 std::string makeRunDir(const std::string &d, bool allRWX = false);
 // --sjdbGTFfile at the mapping stage (gtf.cpp): junctions of the annotation appended to `loci` with priority 20
 std::string loadGTFjunctions(const RunParams &P, const GenomeIndex &gi, SjdbLoci &loci, const std::string &dirOut, std::string &log);
+
+// ---- --runMode genomeGenerate (genome_generate.cpp; Genome::genomeGenerate, source/Genome_genomeGenerate.cpp:96-416) ----
+// scan: FASTA -> gi.G / chromosome tables (genomeScanFastaFiles.cpp:5-92), chr*.txt written, index geometry decided; SA / SAi of `gi`
+// are sized for the device build (staramd_index_build, include/star_amd_index.h), which the caller runs between the two calls.
+struct GenerateJob { uint32_t GstrandBit = 0; uint64_t nSA = 0, saBytes = 0, saiBytes = 0; uint64_t saiStart[17] = {0}; };
+std::string genomeGenerateScan(RunParams &P, GenomeIndex &gi, GenerateJob &job);
+std::string genomeGenerateFinish(RunParams &P, GenomeIndex &gi, GenerateJob &job, SjdbLoci &loci, std::string &log);
 
 // ---- Stats (source/Stats.{h,cpp}) ----
 struct Stats {

@@ -18,6 +18,7 @@
 #include <deque>
 #include <string>
 #include "../../../include/star_amd_host.h"
+#include "../../../include/star_amd_index.h"
 
 namespace {
 struct Msg { int slot; int n; staramd_batch b; int resIdx; bool merged; };
@@ -41,6 +42,23 @@ int main(int argc, char **argv) {
     void *h = sah_create(argc, argv, err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }
     if (sah_tool_done(h)) { sah_destroy(h); return 0; }          // --runMode inputAlignmentsFromBAM: nothing to map
+    if (sah_generate_mode(h)) {                                  // --runMode genomeGenerate: suffix array + SAindex on the device
+        const uint8_t *G; uint64_t nGenome, saCap, saiCap; uint32_t gsb, nb; uint8_t *SA, *SAi;
+        if (sah_generate_buffers(h, &G, &nGenome, &gsb, &nb, &SA, &saCap, &SAi, &saiCap)) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
+        staramd_index_params ip; memset(&ip, 0, sizeof(ip));
+        ip.nGenome = nGenome; ip.GstrandBit = gsb; ip.gSAindexNbases = nb; ip.gSAsparseD = 1;
+        staramd_index_result ir;
+        auto tg = std::chrono::steady_clock::now();
+        int grc = staramd_index_build(sah_device(h), G, &ip, SA, saCap, SAi, saiCap, &ir);
+        if (grc) { fprintf(stderr, "\nEXITING because of FATAL ERROR: index build on the MI355X failed: %s\n", staramd_index_last_error()); sah_destroy(h); return 105; }
+        double sBuild = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+        if (sah_generate_finish(h, ir.nSA, ir.nSAbyte, ir.nSAibyte)) { fprintf(stderr, "\n%s\n", sah_error(h)); sah_destroy(h); return 104; }
+        double sAll = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+        fprintf(stderr, "star_amd: genomeGenerate: %llu suffixes, %u doubling rounds, device build %.3f s (%.1f ms on the stream), junction insertion + files %.3f s\n",
+                (unsigned long long)ir.nSA, ir.doublingRounds, sBuild, ir.msTotal, sAll - sBuild);
+        sah_destroy(h);
+        return 0;
+    }
     const uint64_t batchReads = sah_batch_reads(h);
     staramd_ctx *ctx = nullptr;
     int rc = staramd_create(&ctx, sah_device(h), sah_genome(h), sah_params(h), (uint32_t)batchReads, 0);

@@ -103,7 +103,12 @@ std::string RunParams::parse(int argc, char **argv) {
     std::map<std::string, std::vector<std::string> > clipArgs;
     for (auto &e : kv) {
         const std::string &k = e.first; const std::vector<std::string> &v = e.second;
-        if (k == "runMode") { const std::string &m = one(k, v); if (m == "inputAlignmentsFromBAM") runModeFromBAM = true; else if (m != "alignReads") err = "EXITING: --runMode " + m + " is not implemented: alignReads and inputAlignmentsFromBAM are (index generation: use reference STAR)"; }
+        if (k == "runMode") { const std::string &m = one(k, v); if (m == "inputAlignmentsFromBAM") runModeFromBAM = true; else if (m == "genomeGenerate") runModeGenerate = true; else if (m != "alignReads") err = "EXITING: --runMode " + m + " is not implemented: alignReads, genomeGenerate and inputAlignmentsFromBAM are"; }
+        else if (k == "genomeFastaFiles") { if (!(v.size() == 1 && v[0] == "-")) genomeFastaFiles = v; }
+        else if (k == "genomeSAindexNbases") genomeSAindexNbases = (uint32_t)U(k, v);
+        else if (k == "genomeChrBinNbits") genomeChrBinNbits = (uint32_t)U(k, v);
+        else if (k == "genomeSAsparseD") genomeSAsparseD = (uint32_t)U(k, v);
+        else if (k == "limitGenomeGenerateRAM") { (void)U(k, v); }      // the sort runs in HBM: nothing to size on the host
         else if (k == "inputBAMfile") { if (one(k, v) != "-") inputBAMfile = one(k, v); }
         else if (k == "genomeDir") genomeDir = one(k, v);
         else if (k == "readFilesIn") readFilesIn = v;
@@ -341,6 +346,18 @@ std::string RunParams::parse(int argc, char **argv) {
     if (twopass1Set && !twopass) return "EXITING because of fatal PARAMETERS error: --twopass1readsN is defined, but --twoPassMode is not defined\nSOLUTION: to activate the 2-pass mode, use --twopassMode Basic";
     if (twopass && twopass1readsN == 0) return "EXITING because of fatal PARAMETERS error: --twopass1readsN = 0 in the 2-pass mode\nSOLUTION: for the 2-pass mode, specify --twopass1readsN > 0. Use a very large number or -1 to map all reads in the 1st pass.\n";
     if (sjdbInsertYes() && sjdbOverhangSet && sjdbOverhang == 0) return "EXITING because of fatal PARAMETERS error: pGe.sjdbOverhang <=0 while junctions are inserted on the fly with --sjdbFileChrStartEnd or/and --sjdbGTFfile\nSOLUTION: specify pGe.sjdbOverhang>0, ideally readmateLength-1";
+    if (runModeGenerate) {                   // Genome_genomeGenerate.cpp:100-129
+        if (genomeDir.empty()) return "EXITING because of fatal INPUT error: --runMode genomeGenerate needs --genomeDir";
+        if (genomeFastaFiles.empty()) return "EXITING because of fatal INPUT error: --runMode genomeGenerate needs --genomeFastaFiles";
+        if (genomeSAindexNbases < 1 || genomeSAindexNbases > 16) return "EXITING because of fatal PARAMETERS error: --genomeSAindexNbases must be in 1..16";
+        if (genomeChrBinNbits < 1 || genomeChrBinNbits > 40) return "EXITING because of fatal PARAMETERS error: bad --genomeChrBinNbits";
+        if (!sjdbOverhangSet) sjdbOverhang = 100;
+        if (sjdbOverhang == 0 && sjdbInsertPass1())
+            return "EXITING because of FATAL INPUT PARAMETER ERROR: for generating genome with annotations (--sjdbFileChrStartEnd or --sjdbGTFfile options)\nyou need to specify >0 --sjdbOverhang\nSOLUTION: re-run genome generation specifying non-zero --sjdbOverhang, which ideally should be equal to OneMateLength-1, or could be chosen generically as ~100\n";
+        if (!sjdbInsertPass1() && sjdbOverhangSet && sjdbOverhang > 0)
+            return "EXITING because of FATAL INPUT PARAMETER ERROR: when generating genome without annotations (--sjdbFileChrStartEnd or --sjdbGTFfile options)\ndo not specify >0 --sjdbOverhang\nSOLUTION: re-run genome generation without --sjdbOverhang option\n";
+        return "";
+    }
     if (runModeFromBAM) {                    // Parameters.cpp:585-605
         if (!wig.yes) return "EXITING because of fatal INPUT error: at the moment --runMode inputFromBAM only works with --outWigType bedGraph OR --bamRemoveDuplicatesType Identical\nSOLUTION: re-run STAR with --outWigType bedGraph (duplicate removal is not implemented here)\n";
         if (inputBAMfile.empty()) return "EXITING because of fatal INPUT error: --runMode inputAlignmentsFromBAM needs --inputBAMfile";

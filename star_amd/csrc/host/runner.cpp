@@ -36,6 +36,7 @@ struct Runner {
     Stats stats;
     FILE *samOut = nullptr;
     bool toolDone = false;                          // --runMode inputAlignmentsFromBAM: everything happened in init()
+    bool generateMode = false; GenerateJob genJob;  // --runMode genomeGenerate: FASTA scanned in init(), SA / SAindex built by the caller on the device
     FILE *chimOut = nullptr;                        // Chimeric.out.junction
     FILE *chimSamOut = nullptr;                     // Chimeric.out.sam (--chimOutType SeparateSAMold)
     FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
@@ -73,6 +74,11 @@ struct Runner {
                     }
                 }
             }
+        }
+        if (P.runModeGenerate) {                                    // index generation: no reads; the device stages are run by the caller
+            error = genomeGenerateScan(P, gi, genJob);
+            generateMode = true;
+            return error.empty();
         }
         if (P.runModeFromBAM) {                                     // a tool mode: no index, no reads, no engine
             error = signalFromBamFile(P, P.inputBAMfile, P.outFileNamePrefix + "Signal");
@@ -488,6 +494,23 @@ void *sah_create(int argc, char **argv, char *errbuf, int errlen) {
 const staramd_genome *sah_genome(void *h) { return &((Runner *)h)->gi.view; }
 const staramd_params *sah_params(void *h) { return &((Runner *)h)->P.dev; }
 uint64_t sah_batch_reads(void *h) { return ((Runner *)h)->P.gpuBatchReads; }
+// --runMode genomeGenerate: sah_create has scanned the FASTA files; the caller builds SA + SAindex with staramd_index_build
+// (include/star_amd_index.h) into the buffers handed out here, then sah_generate_finish inserts the annotated junctions and writes genomeDir.
+int sah_generate_mode(void *h) { return ((Runner *)h)->generateMode ? 1 : 0; }
+int sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases, uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap) {
+    Runner *r = (Runner *)h;
+    if (!r->generateMode) { r->error = "sah_generate_buffers: not in --runMode genomeGenerate"; return -1; }
+    *G = r->gi.G.data(); *nGenome = r->gi.view.nGenome; *GstrandBit = r->genJob.GstrandBit; *saIndexNbases = r->gi.view.gSAindexNbases;
+    *SA = r->gi.SA.data(); *saCap = r->gi.SA.size(); *SAi = r->gi.SAi.data(); *saiCap = r->gi.SAi.size();
+    return 0;
+}
+int sah_generate_finish(void *h, uint64_t nSA, uint64_t nSAbyte, uint64_t nSAibyte) {
+    Runner *r = (Runner *)h;
+    if (!r->generateMode) { r->error = "sah_generate_finish: not in --runMode genomeGenerate"; return -1; }
+    if (nSA != r->genJob.nSA || nSAbyte != r->genJob.saBytes || nSAibyte != r->genJob.saiBytes) { r->error = "EXITING because of FATAL problem while generating the suffix array: the device build returned " + std::to_string(nSA) + " indices, expected nSA=" + std::to_string(r->genJob.nSA); return -1; }
+    r->error = genomeGenerateFinish(r->P, r->gi, r->genJob, r->sjdbLoci, r->insertLog);
+    return r->error.empty() ? 0 : -1;
+}
 int sah_tool_done(void *h) { return ((Runner *)h)->toolDone ? 1 : 0; }     // 1: the run was a tool mode (--runMode inputAlignmentsFromBAM) and is finished
 int sah_device(void *h) { return ((Runner *)h)->P.gpuDevice; }
 double sah_genome_load_seconds(void *h) { return ((Runner *)h)->gi.loadSeconds; }

@@ -279,3 +279,89 @@ def make_dataset(outdir, seed=1, chr_lengths=(300000, 200000, 150000), n_tr=120,
     fq = write_fastq(os.path.join(outdir, "reads"), m1, m2)
     return {"fasta": fa, "gtf": gtf, "fastq": fq, "n_reads": n_reads, "read_len": read_len,
             "paired": paired, "genome_bases": int(sum(chr_lengths)), "n_transcripts": len(trs)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench-size genomes: vectorised end to end, seconds per gigabase
+
+HUMAN_LIKE_FAMILIES = (
+    # (consensus length, copies per Mb, divergence range, minimum fraction of the consensus kept (5' truncation))
+    (300, 350, (0.08, 0.16), 0.8),        # Alu-like: ~10 % of the genome
+    (6000, 130, (0.02, 0.20), 0.05),      # L1-like, mostly truncated: ~17 %
+    (250, 300, (0.20, 0.30), 0.5),        # MIR-like, old: ~5 %
+    (2500, 18, (0.05, 0.20), 0.3), (1800, 22, (0.05, 0.25), 0.3), (900, 40, (0.04, 0.18), 0.4), (3500, 10, (0.03, 0.15), 0.3),
+    (1200, 30, (0.06, 0.22), 0.4), (5000, 6, (0.01, 0.10), 0.2), (700, 45, (0.10, 0.25), 0.5),   # DNA / LTR-like families: ~12 %
+    (60, 50, (0.0, 0.0), 1.0),            # short exact repeats
+)
+
+
+def make_genome_large(seed, total_mb, n_chr, families=HUMAN_LIKE_FAMILIES, segdup_per_mb=0.02, n_runs_per_mb=2, microsat_per_mb=30, device=None):
+    """Random ACGT genome of total_mb megabases in n_chr equal chromosomes with interspersed repeat families (about half of
+    the bases), a few recent segmental duplications (10-40 kb, ~1 % divergence), microsatellites and short N runs.
+    Generated with torch on `device` (the GPU when there is one: a 3.1 Gb genome takes seconds; the random stream depends on the
+    device type).  Returns (list of per-chromosome uint8 ASCII numpy arrays (views into one buffer), bases written by repeats / n)."""
+    import torch
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
+    n = int(total_mb) * 1000000
+    ri = lambda lo, hi, size, dt=torch.int64: torch.randint(lo, hi, (int(size),), generator=gen, device=dev, dtype=dt)
+    ru = lambda size: torch.rand(int(size), generator=gen, device=dev)
+    g = torch.empty(n, dtype=torch.uint8, device=dev)
+    for lo in range(0, n, 1 << 30):
+        hi = min(n, lo + (1 << 30)); g[lo:hi] = ri(0, 4, hi - lo, torch.uint8)
+    covered = 0
+
+    def flat(length):                        # per-element copy id and offset inside the copy
+        tot = int(length.sum()); start = torch.cumsum(length, 0) - length
+        cid = torch.repeat_interleave(torch.arange(length.numel(), device=dev), length)
+        return tot, cid, torch.arange(tot, device=dev) - start[cid]
+
+    for unit_len, per_mb, (d0, d1), min_frac in families:
+        copies = int(per_mb * total_mb)
+        if copies == 0:
+            continue
+        unit = ri(0, 4, unit_len, torch.uint8)
+        step = max(1, min(copies, (1 << 27) // unit_len))
+        for lo in range(0, copies, step):
+            k = min(step, copies - lo)
+            length = (unit_len * (min_frac + (1 - min_frac) * ru(k) ** 2)).to(torch.int64).clamp(20, unit_len)   # 3' end kept, 5' truncated
+            pos = ri(0, n - unit_len - 1, k)
+            div = d0 + (d1 - d0) * ru(k)
+            rev = ru(k) < 0.5
+            tot, cid, off = flat(length)
+            base = unit[unit_len - length[cid] + off]
+            mut = ru(tot) < div[cid]
+            base = torch.where(mut, (base + ri(1, 4, tot, torch.uint8)) & 3, base)
+            r = rev[cid]
+            base = torch.where(r, 3 - base, base)
+            dst = torch.where(r, pos[cid] + (length[cid] - 1 - off), pos[cid] + off)
+            g[dst] = base
+            covered += tot
+    for _ in range(int(segdup_per_mb * total_mb) + 1):         # recent segmental duplications
+        ln = int(ri(10000, 40000, 1).item())
+        if n <= 3 * ln:
+            break
+        a, b = int(ri(0, n - ln, 1).item()), int(ri(0, n - ln, 1).item())
+        cp = g[a:a + ln].clone()
+        m = ru(ln) < 0.01
+        cp = torch.where(m, (cp + ri(1, 4, ln, torch.uint8)) & 3, cp)
+        g[b:b + ln] = cp
+        covered += ln
+    k = int(microsat_per_mb * total_mb)
+    if k:
+        for motif_len in (1, 2, 3, 4):
+            kk = max(1, k // 4)
+            pos = ri(0, n - 200, kk); ln = ri(15, 60, kk)
+            motif = ri(0, 4, kk * motif_len, torch.uint8).reshape(kk, motif_len)
+            tot, cid, off = flat(ln)
+            g[pos[cid] + off] = motif[cid, off % motif_len]
+    g = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[g.long()] if n < (1 << 28) else torch.cat([torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[g[lo:lo + (1 << 28)].long()] for lo in range(0, n, 1 << 28)])
+    kn = int(n_runs_per_mb * total_mb)
+    if kn:
+        pos = ri(0, n - 40, kn); ln = ri(1, 30, kn)
+        tot, cid, off = flat(ln)
+        g[pos[cid] + off] = ord("N")
+    g = g.cpu().numpy()
+    clen = n // n_chr
+    seqs = [g[i * clen:(i + 1) * clen if i < n_chr - 1 else n] for i in range(n_chr)]
+    return seqs, min(1.0, covered / n)
