@@ -22,7 +22,9 @@ define build_engine
 endef
 
 HOST_SRC := $(wildcard star_amd/csrc/host/*.cpp)
-HOST_LIB_SRC := $(filter-out star_amd/csrc/host/main.cpp,$(HOST_SRC))
+HOST_LIB_SRC := $(filter-out star_amd/csrc/host/main.cpp star_amd/csrc/host/cli_run.cpp,$(HOST_SRC))
+CLI_SRC := star_amd/csrc/host/main.cpp star_amd/csrc/host/cli_run.cpp
+CLI_HDR := include/star_amd_host.h include/star_amd_index.h include/star_amd_cli.h include/star_amd.h
 HIP_SRC  := $(wildcard star_amd/csrc/engine/*.hip) $(wildcard star_amd/csrc/index/*.hip)
 HIP_HDR  := $(wildcard star_amd/csrc/engine/*.h) $(wildcard star_amd/csrc/index/*.h) include/star_amd.h include/star_amd_index.h
 
@@ -30,7 +32,7 @@ all: host engine shadow cli oracle
 
 host: star_amd/lib/libstaramd_host.so
 engine: star_amd/lib/libstaramd.so
-cli: star_amd/bin/star_amd
+cli: star_amd/bin/star_amd star_amd/lib/libstaramd_cli.so
 oracle: oracle/_build/liboracle.so oracle/_build/libindex_emul.so oracle/_build/star_amd_oracle_cli
 
 star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
@@ -46,9 +48,13 @@ shadow: star_amd/lib/libstaramd_shadow.so
 star_amd/lib/libstaramd_shadow.so: $(HIP_SRC) $(HIP_HDR)
 	$(call build_engine,shadow,-DSTARAMD_SHADOW)
 
-star_amd/bin/star_amd: star_amd/csrc/host/main.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so include/star_amd_host.h include/star_amd_index.h
+star_amd/bin/star_amd: $(CLI_SRC) star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so $(CLI_HDR)
 	@mkdir -p star_amd/bin
-	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp -o $@ -Lstar_amd/lib -lstaramd_host -lstaramd -Wl,-rpath,'$$ORIGIN/../lib'
+	$(CXX) $(CXXFLAGS) -fPIE $(CLI_SRC) -o $@ -Lstar_amd/lib -lstaramd_host -lstaramd -Wl,-rpath,'$$ORIGIN/../lib'
+
+# the same front end as a library (bench.py and tests run the pipeline in-process through ctypes)
+star_amd/lib/libstaramd_cli.so: star_amd/csrc/host/cli_run.cpp star_amd/lib/libstaramd_host.so star_amd/lib/libstaramd.so $(CLI_HDR)
+	$(CXX) $(CXXFLAGS) -shared star_amd/csrc/host/cli_run.cpp -o $@ -Lstar_amd/lib -lstaramd_host -lstaramd -Wl,-rpath,'$$ORIGIN'
 
 oracle/_build/liboracle.so: oracle/star_oracle.cpp include/star_amd.h
 	@mkdir -p oracle/_build
@@ -60,8 +66,8 @@ oracle/_build/libindex_emul.so: oracle/index_emul.cpp $(wildcard star_amd/csrc/i
 	$(CXX) $(CXXFLAGS) -fopenmp -shared oracle/index_emul.cpp -o $@
 
 # test infrastructure: the command-line front end with the oracle behind the engine's C ABI (oracle/cli_shim.cpp), for CPU tests of main.cpp
-oracle/_build/star_amd_oracle_cli: star_amd/csrc/host/main.cpp oracle/cli_shim.cpp oracle/_build/liboracle.so oracle/_build/libindex_emul.so star_amd/lib/libstaramd_host.so include/star_amd_host.h include/star_amd_index.h
-	$(CXX) $(CXXFLAGS) -fPIE star_amd/csrc/host/main.cpp oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -lindex_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
+oracle/_build/star_amd_oracle_cli: $(CLI_SRC) oracle/cli_shim.cpp oracle/_build/liboracle.so oracle/_build/libindex_emul.so star_amd/lib/libstaramd_host.so $(CLI_HDR)
+	$(CXX) $(CXXFLAGS) -fPIE $(CLI_SRC) oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -lindex_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
 
 ref:
 	$(MAKE) -f oracle/Makefile.ref -j8 all

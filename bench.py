@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the seed-search-and-stitch hot path on MI355X.
+"""bench.py -- throughput of the seed-search-and-stitch hot path on MI355X, measured END TO END:
+FASTQ text in -> Aligned.out.sam + SJ.out.tab out, index load excluded, on a human-scale index.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-  step      = one pass of the whole device hot path (seed search -> windows -> stitch -> gather, results copied back to
-              the host) over one batch of synthetic read pairs that is ALREADY RESIDENT in HBM when the timed region starts
+  step      = one batch of `--reads` DISTINCT read pairs streamed through the product pipeline (star_amd's front end run in-process:
+              FASTQ parse -> staramd_map_batch on the GPU -> multMapSelect ... SAM text -> file), batches overlapping as they do in the CLI
+  timing    = W warm-up batches are mapped AND written, the pipeline is drained, all ranks meet at a barrier, then the clock runs from
+              the submission of the first of the K timed batches to the last SAM byte of the last one (barrier again, max over ranks)
   metric    = BASELINE.json's: million reads (pairs) aligned per second, whole job
-  workload  = synthetic 2x101 bp PE reads on a synthetic genome with repeats + annotated/novel junctions (there is no
-              GRCh38 in the image and no network; the size is what an index build inside the run allows -- config.workload)
-  roofline  = dominant kernel (by HIP-event time inside the engine, on the engine's stream): algorithmic bytes / duration
+  workload  = BASELINE config 2 stand-in: synthetic genome of `--genome-mb` megabases (default 3100 = human size, ~half of it repeat
+              families) + ~350 k annotated junctions (sjdbOverhang 100, 14-base SAindex), 2x101 bp pairs, 85 % spliced, 1 % substitutions;
+              the index is generated INSIDE the run on the GPU (star_amd --runMode genomeGenerate: the reference needs ~20 min for it)
+  roofline  = dominant kernel by HIP-event time on the engine's stream, summed over the timed batches: algorithmic bytes / duration
               vs the 8 TB/s HBM peak
-  cpu_baseline = the reference itself (oracle/_ref/STAR, all host cores) timed on a bounded sample of the same reads
-Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier, the max-over-ranks reduction and the final
-junction-table gather); reads are sharded, every rank holds a full index replica; no data-path collective (weak scaling).
+  cpu_baseline = the reference itself (oracle/_ref/STAR) on the same FASTQ and the same index, --runThreadN = all host cores, with an
+              input chunk small enough that every thread has work (>= 8 chunks per thread)
+Multi-GPU: one process per GPU (torch.distributed / RCCL for the barriers, the max-over-ranks reduction and the junction-table
+all_gather at the end of the run); reads are sharded, every rank holds a full index replica; no data-path collective (weak scaling).
 """
 import argparse
+import ctypes as C
 import hashlib
 import json
+import math
 import os
+import pickle
 import subprocess
 import sys
 import time
@@ -25,191 +33,263 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+T_START = time.time()
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mb", type=int, default=int(os.environ.get("STARAMD_BENCH_GENOME_MB", "100")))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("STARAMD_BENCH_READS", "400000")), help="read pairs per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--genome-mb", type=int, default=int(os.environ.get("STARAMD_BENCH_GENOME_MB", "3100")))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("STARAMD_BENCH_READS", "400000")), help="read pairs per GPU per step (= --gpuBatchReads)")
     ap.add_argument("--read-len", type=int, default=101)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("STARAMD_BENCH_CPU_SAMPLE", "400000")))
-    ap.add_argument("--cpu-repeat", type=int, default=int(os.environ.get("STARAMD_BENCH_CPU_REPEAT", "4")), help="the CPU baseline maps the sample this many times over (longer run: STAR's threads reach steady state)")
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("STARAMD_BENCH_HOST_THREADS", "0")), help="post-map threads per rank (0: min(64, cores/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cli-e2e", action="store_true")
-    ap.add_argument("--no-two-pass-e2e", action="store_true")
-    ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/tmp/star_amd_bench"))
+    ap.add_argument("--no-sweep", action="store_true", help="skip the index-size sweep (100 / 400 / 1000 Mb)")
+    ap.add_argument("--no-two-pass", action="store_true")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("STARAMD_BENCH_BUDGET_S", "1500")), help="optional legs are skipped once this much wall time is used")
+    ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/dev/shm/star_amd_bench" if os.path.isdir("/dev/shm") else "/tmp/star_amd_bench"))
     return ap.parse_args()
 
 
-def prepare_data(args, world):
-    """Synthetic genome + index (reference genomeGenerate: index building is out of scope)
-    + one FASTQ shard per rank.  Cached by parameter hash."""
-    from star_amd import synth
-    from oracle import refstar
+# ---------------------------------------------------------------------------------------------------------------------
+# data
+
+def genome_dir(args, mb):
+    key = hashlib.md5(("v5g|%d|%d" % (mb, args.read_len)).encode()).hexdigest()[:10]
+    return os.path.join(args.workdir, "genome_%dmb_%s" % (mb, key))
+
+
+def build_genome(args, mb, log):
+    """Synthetic genome + annotation + index (rank 0).  The index is built by the product itself on the GPU
+    (star_amd --runMode genomeGenerate, byte-identical to the reference's genomeGenerate: tests/test_index_build.py)."""
     import numpy as np
-    key = hashlib.md5(("v3|%d|%d|%d|%d" % (args.genome_mb, args.reads, args.read_len, world)).encode()).hexdigest()[:12]
-    d = os.path.join(args.workdir, key)
-    done = os.path.join(d, "DONE")
-    if os.path.isfile(done):
-        return d
-    if not refstar.have_ref():
-        raise RuntimeError("oracle/_ref/STAR is missing: it is needed to build the benchmark index (python -c 'import __graft_entry__ as g; g.build()')")
-    os.makedirs(d, exist_ok=True)
-    # genome + annotation + index depend on (genome_mb, read_len) only: shared by the runs with 1, 2, 4, 8 GPUs
-    gkey = hashlib.md5(("v3g|%d|%d" % (args.genome_mb, args.read_len)).encode()).hexdigest()[:12]
-    gdir = os.path.join(args.workdir, "genome_" + gkey)
-    gdone = os.path.join(gdir, "DONE")
-    os.makedirs(gdir, exist_ok=True)
-    rng = np.random.default_rng(20260922)
-    nchr = max(1, args.genome_mb // 10)
-    chr_len = [args.genome_mb * 1000000 // nchr] * nchr
-    names = ["chr%d" % (i + 1) for i in range(nchr)]
-    mb = args.genome_mb
-    seqs = synth.make_genome(rng, chr_len, repeat_families=((300, 300 * mb, 0.08), (6000, 15 * mb, 0.05), (60, 50 * mb, 0.0)), n_runs=2 * mb)
-    trs = synth.make_transcripts(rng, seqs, 200 * mb)
+    from star_amd import synth
+    g = genome_dir(args, mb)
+    if os.path.isfile(os.path.join(g, "DONE")):
+        return g, json.load(open(os.path.join(g, "build.json")))
+    os.makedirs(g, exist_ok=True)
+    info = {"genome_mb": mb}
+    nchr = max(1, min(24, mb // 40))
+    t = time.time()
+    seqs, frac = synth.make_genome_large(20260922, mb, nchr)
+    info["genome_synth_s"] = time.time() - t; info["repeat_bases_fraction"] = frac
+    rng = np.random.default_rng(20260923)
+    t = time.time()
+    trs = synth.make_transcripts(rng, seqs, 65 * mb)
     annotated = rng.random(len(trs)) < 0.7
-    if not os.path.isfile(gdone):
-        synth._write_fasta(os.path.join(gdir, "genome.fa"), names, seqs)
-        synth.write_gtf(os.path.join(gdir, "annot.gtf"), names, trs, annotated)
-    m1, m2 = synth.make_reads(rng, seqs, trs, args.reads * world, args.read_len, True, frac_spliced=0.85, sub_rate=0.01, n_rate=0.001)
-    for r in range(world):
-        lo, hi = r * args.reads, (r + 1) * args.reads
-        synth.write_fastq(os.path.join(d, "reads_r%d" % r), m1[lo:hi], m2[lo:hi])
-    if not os.path.isfile(gdone):
-        import math
-        nb = max(4, min(14, int(math.log2(args.genome_mb * 1e6) / 2 - 1)))
-        refstar.genome_generate(os.path.join(gdir, "genome.fa"), os.path.join(gdir, "idx"), gtf=os.path.join(gdir, "annot.gtf"),
-                                sjdb_overhang=args.read_len - 1, sa_index_nbases=nb, threads=os.cpu_count() or 8)
-        open(gdone, "w").write("ok\n")
-    for f in ("idx", "genome.fa", "annot.gtf"):
-        link = os.path.join(d, f)
-        if not os.path.lexists(link):
-            os.symlink(os.path.join(gdir, f), link)
-    open(done, "w").write("ok\n")
-    return d
+    info["transcripts"] = len(trs); info["transcripts_s"] = time.time() - t
+    names = ["chr%d" % (i + 1) for i in range(nchr)]
+    t = time.time()
+    synth._write_fasta(os.path.join(g, "genome.fa"), names, seqs)
+    synth.write_gtf(os.path.join(g, "annot.gtf"), names, trs, annotated)
+    np.save(os.path.join(g, "genome.npy"), seqs[0].base if seqs[0].base is not None else np.concatenate(seqs))
+    pickle.dump({"trs": trs, "chr_len": [len(s) for s in seqs]}, open(os.path.join(g, "transcripts.pkl"), "wb"))
+    info["write_fasta_gtf_s"] = time.time() - t
+    del seqs
+    nb = max(4, min(14, int(math.log2(mb * 1e6) / 2 - 1)))
+    exe = os.path.join(ROOT, "star_amd", "bin", "star_amd")
+    idx = os.path.join(g, "idx")
+    os.makedirs(idx, exist_ok=True)
+    cmd = [exe, "--runMode", "genomeGenerate", "--genomeDir", idx, "--genomeFastaFiles", os.path.join(g, "genome.fa"), "--genomeSAindexNbases", str(nb),
+           "--sjdbGTFfile", os.path.join(g, "annot.gtf"), "--sjdbOverhang", str(args.read_len - 1), "--runThreadN", str(os.cpu_count() or 8),
+           "--outFileNamePrefix", idx + "/_log_"]
+    t = time.time()
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, STARAMD_HOST_TIMING="1"))
+    info["index_generate_s"] = time.time() - t
+    if p.returncode != 0:
+        raise RuntimeError("star_amd --runMode genomeGenerate failed: " + p.stderr[-2000:])
+    info["index_generate_log"] = p.stderr.strip().splitlines()[-8:]
+    info["SAindexNbases"] = nb
+    info["junctions_in_index"] = int(open(os.path.join(idx, "sjdbInfo.txt")).readline().split()[0])
+    info["index_bytes"] = sum(os.path.getsize(os.path.join(idx, f)) for f in ("Genome", "SA", "SAindex"))
+    json.dump(info, open(os.path.join(g, "build.json"), "w"))
+    open(os.path.join(g, "DONE"), "w").write("ok\n")
+    log("genome %d Mb: synth %.1f s, transcripts %.1f s, files %.1f s, index %.1f s" % (mb, info["genome_synth_s"], info["transcripts_s"], info["write_fasta_gtf_s"], info["index_generate_s"]))
+    return g, info
 
 
-def cpu_baseline(d, args, n_sample):
-    """Reference STAR itself (oracle/_ref/STAR, built from /root/reference by oracle/Makefile.ref) on the first n_sample
-    pairs of rank 0's shard, same index, default parameters.  Mapping time only: wall(run) - wall(index-load-only run).
-    STAR's read loop does not scale to every core count (chunked input under one mutex, per-thread buffers), so a few
-    thread counts up to all host cores are timed and the BEST one is reported; `cores` = threads of that run."""
+_SAMPLER = None
+
+
+def _chunk_job(job):
+    seed, n, prefix, first_id = job
+    from star_amd import synth
+    m1, m2 = _SAMPLER.sample(seed, n)
+    synth.write_fastq_ids(prefix, m1, m2, first_id)
+    return prefix
+
+
+def make_reads(args, g, out_dir, tag, n_pairs, seed_base):
+    """n_pairs pairs as chunk files <out_dir>/<tag>_cNNN_{1,2}.fq (comma-separated lists go to --readFilesIn); chunks are sampled by a
+    pool of forked workers from the shared genome / transcriptome arrays."""
+    global _SAMPLER
+    import numpy as np
+    from star_amd import synth
+    os.makedirs(out_dir, exist_ok=True)
+    chunk = 500000
+    jobs = []
+    for c, lo in enumerate(range(0, n_pairs, chunk)):
+        jobs.append((seed_base * 100003 + c, min(chunk, n_pairs - lo), os.path.join(out_dir, "%s_c%03d" % (tag, c)), lo))
+    done = os.path.join(out_dir, tag + ".DONE")
+    if not os.path.isfile(done):
+        gseq = np.load(os.path.join(g, "genome.npy"), mmap_mode="r")
+        meta = pickle.load(open(os.path.join(g, "transcripts.pkl"), "rb"))
+        seqs, o = [], 0
+        for ln in meta["chr_len"]:
+            seqs.append(gseq[o:o + ln]); o += ln
+        _SAMPLER = synth.ReadSampler(seqs, meta["trs"], args.read_len)
+        _SAMPLER.gseq = np.asarray(gseq)
+        import multiprocessing as mp
+        nproc = max(1, min(len(jobs), (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 32))
+        if nproc > 1:
+            with mp.get_context("fork").Pool(nproc) as pool:
+                pool.map(_chunk_job, jobs)
+        else:
+            for j in jobs:
+                _chunk_job(j)
+        _SAMPLER = None
+        open(done, "w").write("ok\n")
+    return [",".join(j[2] + "_%d.fq" % m for j in jobs) for m in (1, 2)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the product pipeline in-process (libstaramd_cli.so, include/star_amd_cli.h)
+
+class CliHooks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("warmup_done", C.CFUNCTYPE(None, C.c_void_p)), ("exchange", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int))]
+
+
+class CliReport(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("wallMapping", C.c_double), ("timedReads", C.c_uint64), ("timedWall", C.c_double),
+                ("genomeLoadSeconds", C.c_double), ("indexUploadSeconds", C.c_double), ("nDevices", C.c_int),
+                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 24),
+                ("parseBusy", C.c_double), ("emitBusy", C.c_double), ("batches", C.c_uint64), ("pass1Seconds", C.c_double)]
+
+
+COUNTER_NAMES = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut",
+                 "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
+STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitch_verify+replay+finish", "k_scan+k_gather", "device_total"]
+
+
+def run_cli(argv, warmup_done=None, exchange=None):
+    lib = C.CDLL(os.path.join(ROOT, "star_amd", "lib", "libstaramd_cli.so"))
+    lib.staramd_cli_main.restype = C.c_int
+    lib.staramd_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(CliHooks), C.POINTER(CliReport)]
+    args = [b"star_amd"] + [a.encode() for a in argv]
+    arr = (C.c_char_p * len(args))(*args)
+    hooks = CliHooks()
+    WD, EX = CliHooks._fields_[1][1], CliHooks._fields_[2][1]
+    wd = WD(lambda u: warmup_done() if warmup_done else None)
+    ex = EX(lambda u, h, last: int(exchange(h, last) or 0) if exchange else 0)
+    hooks.user = None; hooks.warmup_done = wd; hooks.exchange = ex
+    rep = CliReport()
+    rc = lib.staramd_cli_main(len(args), arr, C.byref(hooks), C.byref(rep))
+    return rc, rep
+
+
+def report_dict(rep, lread):
+    n = max(int(rep.timedReads), 1); nb = max(int(rep.batches), 1)
+    c = dict(zip(COUNTER_NAMES, [int(x) for x in rep.counters]))
+    for k in ("nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"):      # kept by the profile / shadow builds only
+        c.pop(k, None)
+    ms = dict(zip(STAGE_NAMES, [float(x) / nb for x in rep.stageMs]))       # per launch = per batch
+    # Algorithmic bytes (DESIGN.md section 6): what the algorithm must fetch / write, from the engine's own counters
+    bytes_seed = 8 * c["nSAi"] + 8 * c["nSAprobe"] + c["nGcmp"] + n * lread + 24 * c["nSeeds"]
+    bytes_win = 8 * c["nSAenum"] + 24 * c["nSeeds"] + 24 * c["nWA"]
+    bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + (lread // 2) * (c["nWindows"] if c["nWindows"] else n) + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
+    kern = {"k_seed_search": (ms["k_seed_search"], bytes_seed / nb), "k_windows": (ms["k_windows"], bytes_win / nb), "k_stitch_win": (ms["k_stitch_win"], bytes_stitch / nb)}
+    return c, ms, kern, (bytes_seed + bytes_win + bytes_stitch) / n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline + parity
+
+def cpu_baseline(idx, fq, out_prefix, n_pairs):
+    """The reference itself (oracle/_ref/STAR, built from /root/reference by oracle/Makefile.ref), same index, same FASTQ, default parameters.
+    STAR deals input to its threads in chunks of limitIObufferSize[0]/nMates bytes (ReadAlignChunk_processChunks.cpp:14-30, Parameters.cpp:1160);
+    the default (30 MB -> ~67 k pairs) would leave most of 256 threads without a chunk on a 10 M-pair sample, so the input buffer is set to
+    2 MB (~4.4 k pairs per chunk: >= 8 chunks per thread).  Mapping time = wall(full run) - wall(run that only loads the index)."""
     from oracle import refstar
     ncpu = os.cpu_count() or 1
-    env = os.environ.get("STARAMD_BENCH_CPU_THREADS")
-    counts = [int(x) for x in env.split(",")] if env else sorted(set(max(1, ncpu // k) for k in (1, 2, 4, 8)), reverse=True)
-    fq = [os.path.join(d, "reads_r0_1.fq"), os.path.join(d, "reads_r0_2.fq")]
-    rep = max(1, args.cpu_repeat)
-    if rep > 1:                             # a longer input lets STAR's chunked multi-threading reach its speed
-        cat = [os.path.join(d, "cpu_in_%d_%d.fq" % (rep, i + 1)) for i in range(2)]
-        for src, dst in zip(fq, cat):
-            if not os.path.isfile(dst):
-                with open(dst, "wb") as fo:
-                    data = open(src, "rb").read()
-                    for _ in range(rep):
-                        fo.write(data)
-        fq = cat
-        n_sample *= rep
-    out = os.path.join(d, "cpu_")
+    small = ["--limitIObufferSize", "2000000", "50000000"]
+    chunks = n_pairs * 225 // 1000000
 
-    def run(nmap, threads):
+    def run(nmap, threads, extra=()):
         t = time.perf_counter()
-        refstar.align(os.path.join(d, "idx"), fq, out, threads=threads, extra=["--readMapNumber", str(nmap)])
+        refstar.align(idx, fq, out_prefix, threads=threads, extra=["--readMapNumber", str(nmap)] + small + list(extra))
         return time.perf_counter() - t
-    run(1, counts[0])                      # warm the page cache
-    tried = []
-    for th in counts:
-        t_load = run(1, th)
-        t_full = run(n_sample, th)
-        t_map = max(t_full - t_load, 1e-3)
-        tried.append((n_sample / t_map / 1e6, th, t_map))
-    best = max(tried)
-    return {"value": best[0], "unit": "Mreads/s", "cores": best[1], "kind": "reference",
-            "sample": "%d pairs (the first pairs of the same workload, repeated to fill the run), STAR 2.7.11b; mapping time = wall(full) - wall(index load only); "
-                      "threads tried (Mreads/s): %s; host has %d cores" % (n_sample, ", ".join("%d: %.4f" % (th, v) for v, th, _ in tried), ncpu)}
+    run(1, ncpu)                                    # page cache
+    t_load = min(run(1, ncpu), run(1, ncpu))
+    tried = {}
+    for th in sorted(set([max(1, ncpu // 4), max(1, ncpu // 2), ncpu])):
+        t_full = run(n_pairs, th)
+        tried[th] = n_pairs / max(t_full - t_load, 1e-3) / 1e6
+    # the all-core run is last: its outputs stay for the parity check
+    n1 = min(n_pairs, 60000)
+    t1 = run(n1, 1, ["--outSAMmode", "None"]) if False else None
+    one = None
+    try:
+        p1 = out_prefix + "t1_"
+        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", str(n1)]); t_one = time.perf_counter() - t
+        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", "1"]); t_one_load = time.perf_counter() - t
+        one = n1 / max(t_one - t_one_load, 1e-3) / 1e6
+    except Exception:
+        one = None
+    return {"value": tried[ncpu], "unit": "Mreads/s", "cores": ncpu, "kind": "reference",
+            "sample": "%d pairs (the same FASTQ the GPU run maps), STAR 2.7.11b --runThreadN %d, --limitIObufferSize 2000000 (~%d input chunks = %.1f per thread); "
+                      "mapping time = wall(full) - wall(index load only, %.1f s); by thread count (Mreads/s): %s; one thread on %d pairs: %s Mreads/s"
+                      % (n_pairs, ncpu, chunks, chunks / ncpu, t_load, ", ".join("%d: %.4f" % (k, v) for k, v in sorted(tried.items())), n1,
+                         ("%.5f" % one) if one else "n/a"),
+            "by_threads": {str(k): v for k, v in sorted(tried.items())}, "one_thread": one, "index_load_s": t_load}
 
 
-def cli_end_to_end(d, args):
-    """The drop-in itself: star_amd/bin/star_amd (FASTQ parsing, engine, post-map, SAM/SJ/Log writing; pipelined, post-map on
-    host threads) on the same input the CPU baseline maps.  Wall time of its mapping loop, index load excluded -- the same
-    interval the reference reports between "Started mapping" and "Finished"."""
-    import re
-    rep = max(1, args.cpu_repeat)
-    src = [os.path.join(d, "reads_r0_%d.fq" % (i + 1)) for i in range(2)]
-    fq = [os.path.join(d, "cpu_in_%d_%d.fq" % (rep, i + 1)) if rep > 1 else src[i] for i in range(2)]
-    for s_, dst in zip(src, fq):
-        if not os.path.isfile(dst):             # same repeated input as the CPU baseline leg
-            data = open(s_, "rb").read()
-            with open(dst, "wb") as fo:
-                for _ in range(rep):
-                    fo.write(data)
-    exe = os.path.join(ROOT, "star_amd", "bin", "star_amd")
-    if not os.path.isfile(exe):
-        return None
-    threads = min(os.cpu_count() or 1, 64)
-    cmd = [exe, "--runMode", "alignReads", "--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + \
-          ["--outFileNamePrefix", os.path.join(d, "cli_"), "--runThreadN", str(threads), "--gpuBatchReads", str(min(args.reads, 200000)),
-           "--readMapNumber", str(min(args.cpu_sample, args.reads) * rep)]           # the same reads the CPU baseline leg maps
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    m = re.search(r"star_amd: (\d+) reads, ([0-9.]+) s wall in the mapping loop \(([0-9.]+) s on the device\)", p.stderr)
-    if p.returncode != 0 or not m:
-        return {"error": (p.stderr or "")[-400:]}
-    n, wall, dev = int(m.group(1)), float(m.group(2)), float(m.group(3))
-    return {"value": n / wall / 1e6, "unit": "Mreads/s", "reads": n, "wall_s": wall, "device_s": dev, "host_threads": threads,
-            "what": "star_amd CLI end to end: FASTQ in -> Aligned.out.sam + SJ.out.tab out (index load excluded)"}
+def _digest_range(job):
+    path, lo, hi = job
+    n, acc = 0, 0
+    with open(path, "rb") as f:
+        if lo:
+            f.seek(lo - 1)
+            if f.read(1) != b"\n":
+                f.readline()
+        while f.tell() < hi:
+            l = f.readline()
+            if not l:
+                break
+            if l[:1] == b"@":
+                continue
+            acc = (acc + int.from_bytes(hashlib.blake2b(l, digest_size=8).digest(), "little")) & 0xFFFFFFFFFFFFFFFF
+            n += 1
+    return n, acc
 
 
-def full_size_parity(d):
-    """Parity at the size of the bench run (size-independent properties): the reference's outputs of the cpu_baseline leg and the
-    CLI's outputs of the cli_end_to_end leg come from the same FASTQ -- SJ.out.tab and the Log.final.out counters must be identical,
-    and the SAM bodies must be the same multiset of records (thread interleaving reorders them): record count + order-independent
-    sum of 64-bit record hashes."""
-    import hashlib
+def sam_digest(path):
+    """(record count, order-independent sum of 64-bit record hashes) of a SAM file, hashed by a pool over byte ranges."""
+    import multiprocessing as mp
+    size = os.path.getsize(path)
+    nproc = max(1, min(64, (os.cpu_count() or 8) // 2, size // (1 << 24) + 1))
+    step = size // nproc + 1
+    jobs = [(path, i * step, min(size, (i + 1) * step)) for i in range(nproc)]
+    with mp.get_context("fork").Pool(nproc) as pool:
+        parts = pool.map(_digest_range, jobs)
+    return sum(p[0] for p in parts), sum(p[1] for p in parts) & 0xFFFFFFFFFFFFFFFF
+
+
+def full_size_parity(ref, new):
+    """Parity at the size of the bench run (size-independent properties): SJ.out.tab and the Log.final.out counters identical, the SAM
+    bodies the same multiset of records (thread interleaving reorders them): record count + order-independent sum of record hashes."""
     from oracle import refstar
-    ref, new = os.path.join(d, "cpu_"), os.path.join(d, "cli_")
     if not all(os.path.isfile(p + f) for p in (ref, new) for f in ("Aligned.out.sam", "SJ.out.tab", "Log.final.out")):
         return None
-
-    def digest(path):
-        n, acc = 0, 0
-        with open(path, "rb") as f:
-            for l in f:
-                if l[:1] == b"@":
-                    continue
-                acc = (acc + int.from_bytes(hashlib.blake2b(l, digest_size=8).digest(), "little")) & 0xFFFFFFFFFFFFFFFF
-                n += 1
-        return n, acc
-    (na, ha), (nb, hb) = digest(ref + "Aligned.out.sam"), digest(new + "Aligned.out.sam")
+    (na, ha), (nb, hb) = sam_digest(ref + "Aligned.out.sam"), sam_digest(new + "Aligned.out.sam")
     return {"sam_records_reference": na, "sam_records_star_amd": nb, "sam_multiset_identical": na == nb and ha == hb,
             "sj_out_tab_identical": open(ref + "SJ.out.tab", "rb").read() == open(new + "SJ.out.tab", "rb").read(),
+            "sj_out_tab_lines": sum(1 for _ in open(new + "SJ.out.tab")),
             "log_final_counters_identical": refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(new + "Log.final.out")}
 
 
-def two_pass_end_to_end(d, args):
-    """the CLI with --twopassMode Basic on one batch-worth of the workload (reads_r0): 1st pass on the GPU
-    without SAM, junction insertion on the host (sjdb_insert.cpp), index re-upload (staramd_update_index), 2nd pass."""
-    import re
-    fq = [os.path.join(d, "reads_r0_%d.fq" % (i + 1)) for i in range(2)]
-    exe = os.path.join(ROOT, "star_amd", "bin", "star_amd")
-    if not os.path.isfile(exe) or not all(os.path.isfile(f) for f in fq):
-        return None
-    threads = min(os.cpu_count() or 1, 64)
-    cmd = [exe, "--runMode", "alignReads", "--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + \
-          ["--outFileNamePrefix", os.path.join(d, "cli2p_"), "--runThreadN", str(threads), "--gpuBatchReads", str(min(args.reads, 200000)), "--twopassMode", "Basic"]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    m1 = re.search(r"1st pass \+ junction insertion \+ index re-upload: ([0-9.]+) s \((\d+) reads\)", p.stderr)
-    m2 = re.search(r"star_amd: (\d+) reads, ([0-9.]+) s wall in the mapping loop \(([0-9.]+) s on the device\)", p.stderr)
-    if p.returncode != 0 or not m1 or not m2:
-        return {"error": (p.stderr or "")[-400:]}
-    n1 = int(m1.group(2)); wall = float(m2.group(2))
-    sjdb = sum(1 for _ in open(os.path.join(d, "cli2p__STARgenome", "sjdbList.out.tab")))
-    return {"value": n1 / wall / 1e6, "unit": "Mreads/s (each read counted once, both passes + insertion in the wall time)", "reads": n1, "wall_s": wall,
-            "pass1_plus_insertion_plus_reupload_s": float(m1.group(1)), "device_s_both_passes": float(m2.group(3)), "junctions_in_index_after_pass1": sjdb,
-            "host_threads": threads, "what": "star_amd CLI --twopassMode Basic end to end (index load excluded)"}
-
+# ---------------------------------------------------------------------------------------------------------------------
 
 def main():
     args = parse()
@@ -226,136 +306,179 @@ def main():
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
+    notes = []
+
+    def log(s):
+        notes.append("[%.0f s] %s" % (time.time() - T_START, s))
+        if os.environ.get("STARAMD_BENCH_VERBOSE"):
+            print("bench: " + notes[-1], file=sys.stderr, flush=True)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    from star_amd import capi
+    if not os.path.isfile(os.path.join(ROOT, "star_amd", "lib", "libstaramd_cli.so")):
+        raise RuntimeError("star_amd/lib/libstaramd_cli.so is missing (python -c 'import __graft_entry__ as g; g.build()')")
+    mb = args.genome_mb
+    n_total = (args.steps + args.warmup) * args.reads
     if rank == 0:
-        d = prepare_data(args, world)
+        g, ginfo = build_genome(args, mb, log)
     barrier()
     if rank != 0:
-        d = prepare_data(args, world)     # cached by rank 0
-    fq = [os.path.join(d, "reads_r%d_1.fq" % rank), os.path.join(d, "reads_r%d_2.fq" % rank)]
-    outp = os.path.join(d, "gpu_r%d_" % rank)
-    run = capi.HostRun(["--genomeDir", os.path.join(d, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", outp])
-    t0 = time.perf_counter()
-    eng = capi.Engine(run.genome, run.params, device=local_rank, max_reads=args.reads)
-    t_upload = time.perf_counter() - t0
-    batch = run.next_batch(args.reads)
-    n = batch.nReads
-    bufs = capi.ResultBuffers(n, tr_cap=n * 64)
-    # first call uploads the batch (host -> HBM); afterwards it is resident
-    t0 = time.perf_counter()
-    eng.map_batch(batch, bufs)
-    t_first = time.perf_counter() - t0
-    for _ in range(args.warmup):
-        eng.map_resident(bufs)
-    stage_names = ["seed", "windows", "order", "stitch_walk", "stitch_redecide", "gather", "total"]
-    ms = dict((k, 0.0) for k in stage_names)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.map_resident(bufs)
-        tm = eng.timings()
-        for k in stage_names:
-            ms[k] += tm[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # post-map on the host for this rank's shard (SAM + junction table), then the end-of-run junction/stats merge
-    run.emit(bufs.res)
-    sj_merge_ms = None
-    if dist is not None:
-        from star_amd import multi_gpu
+        g, ginfo = build_genome(args, mb, log)          # cached by rank 0
+    idx = os.path.join(g, "idx")
+    run_dir = os.path.join(g, "run_w%d_n%d" % (world, n_total))
+    t = time.time()
+    fq = make_reads(args, g, run_dir, "reads_r%d" % rank, n_total, 7000 + rank)
+    log("rank %d: %d pairs of reads in %.1f s" % (rank, n_total, time.time() - t))
+    outp = os.path.join(run_dir, "gpu_r%d_" % rank)
+    threads = args.host_threads or max(4, min(64, (os.cpu_count() or 8) // world))
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", outp, "--runThreadN", str(threads),
+            "--gpuBatchReads", str(args.reads), "--gpuDevice", str(local_rank), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
+    t_clock = {}
+
+    def warmup_done():
+        barrier()
+        t_clock["t0"] = time.perf_counter()
+
+    sj_ms = {}
+
+    def exchange(h, last):
+        if dist is None or not last:
+            return 0
+        from star_amd import multi_gpu, capi
         t1 = time.perf_counter()
-        multi_gpu.merge_run_outputs(run, dist, dev, rank, world)
-        sj_merge_ms = (time.perf_counter() - t1) * 1e3
-    if rank == 0:
-        run.finish()
-    cnt = eng.counters()
-    names = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut",
-             "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
-    c = dict(zip(names, cnt))
-    if os.environ.get("STARAMD_ENGINE_LIB") not in ("profile", "shadow"):
-        for k in ("nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"):      # diagnostics kept by the profile / shadow builds only
-            c.pop(k, None)
-    prof = None
-    if os.environ.get("STARAMD_ENGINE_LIB") == "profile" and len(cnt) >= 37:
-        pn = ["walk", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime",
-              "windows:passA", "windows:flanks", "windows:passB_enumerate+owner", "windows:passB_assign", "windows:emission",
-              "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
-        prof = dict(zip(pn, cnt[21:37]))
-    eng.close(); run.close()
+        multi_gpu.merge_handle_outputs(capi.host_lib(), h, dist, dev, rank, world)
+        sj_ms["ms"] = (time.perf_counter() - t1) * 1e3
+        return 0
+
+    barrier()
+    rc, rep = run_cli(argv, warmup_done, exchange)
+    if rc != 0:
+        raise RuntimeError("the star_amd pipeline failed with exit code %d" % rc)
+    elapsed = float(rep.timedWall)
+    barrier()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([int(rep.timedReads)], dtype=torch.int64, device=dev)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        timed_reads_all = int(nn.item())
+    else:
+        timed_reads_all = int(rep.timedReads)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     steps = max(args.steps, 1)
-    for k in ms:
-        ms[k] /= steps
     lread = 2 * args.read_len + 1
-    # Algorithmic bytes per launch: bytes the algorithm must fetch / write, from the engine's own
-    # counters of the batch -- not what the cache hierarchy moved.  One launch = one batch of n pairs.
-    #   seed search : SAindex entries (8 B each), packed-SA probes (8 B), genome bases compared (1 B), the read, 24 B per stored seed
-    #   windows     : SA entries enumerated (8 B), seeds in, 24 B per window seed out
-    #   stitch walk : genome bases inspected by the stitcher (1 B each, re-reads across recursion nodes included, as the
-    #                 oracle counts them), 24 B per window seed in, the 4-bit read per window, 96 B + 32 B/exon per transcript out
-    bytes_seed = 8 * c["nSAi"] + 8 * c["nSAprobe"] + c["nGcmp"] + n * lread + 24 * c["nSeeds"]
-    bytes_win = 8 * c["nSAenum"] + 24 * c["nSeeds"] + 24 * c["nWA"]
-    bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + (lread // 2) * (c["nWindows"] if c["nWindows"] else n) + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
-    kernels = {"k_seed_search": (ms["seed"], bytes_seed), "k_windows": (ms["windows"], bytes_win), "k_stitch_win": (ms["stitch_walk"], bytes_stitch)}
-    dom = max(kernels, key=lambda k: kernels[k][0])
-    dms, dbytes = kernels[dom]
+    c, ms, kern, bytes_per_pair = report_dict(rep, lread)
+    n = max(int(rep.timedReads), 1)
+    dom = max(kern, key=lambda k: kern[k][0])
+    dms, dbytes = kern[dom]
     achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-    value = world * n * steps / elapsed / 1e6
+    value = timed_reads_all / elapsed / 1e6
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")      # measured separately with rocprofv3 --pmc (see profiles/README.md)
-    if os.path.isfile(tfile):
-        try:
-            traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    try:        # HBM traffic of the dominant kernel from rocprofv3 --pmc passes (profiles/README.md); only when taken on THIS engine build and workload size
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads:
+            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
+    device_s = float(rep.deviceMs[0]) / 1e3
     out = {
-        "metric": "million reads aligned/sec (whole node), 2x101 bp PE, seed-search-and-stitch hot path",
+        "metric": "million reads aligned/sec (whole node), 2x101 bp PE human-scale index, FASTQ in -> SAM out",
         "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/u64 integer", "data": "synthetic",
-        "config": {"workload": "synthetic %d Mb genome (18%% repeats, sjdb from GTF), %d pairs 2x%d bp per GPU per step (85%% spliced, 1%% subs); "
-                               "stand-in for BASELINE config 2 (GRCh38 index cannot be built inside the run)" % (args.genome_mb, n, args.read_len),
-                   "reads_per_gpu_per_step": n, "genome_mb": args.genome_mb, "parallelism": "reads sharded over %d GPU(s), full index replica each" % world},
+        "config": {"workload": "BASELINE config 2 stand-in: synthetic %d Mb genome (%d chromosomes, %.0f %% of the bases written by repeat families), %d junctions in the index "
+                               "(sjdbOverhang %d, SAindex %d bases, index %.1f GB in HBM), %d DISTINCT pairs 2x%d bp per GPU streamed as %d + %d batches of %d "
+                               "(85%% spliced, 1%% substitutions, 0.1%% N); FASTQ text in -> Aligned.out.sam + SJ.out.tab out, index load excluded"
+                               % (mb, max(1, min(24, mb // 40)), 100 * ginfo.get("repeat_bases_fraction", 0), ginfo.get("junctions_in_index", 0), args.read_len - 1,
+                                  ginfo.get("SAindexNbases", 0), ginfo.get("index_bytes", 0) / 1e9, n_total, args.read_len, args.warmup, args.steps, args.reads),
+                   "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads,
+                   "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms,
-                     "per_kernel_ms": {"k_seed_search": ms["seed"], "k_windows": ms["windows"], "k_order": ms["order"], "k_stitch_win": ms["stitch_walk"],
-                                       "k_stitch_verify+replay+finish": ms["stitch_redecide"], "k_scan+k_gather": ms["gather"], "device_total": ms["total"]},
-                     "algorithmic_bytes_per_pair_whole_path": (bytes_seed + bytes_win + bytes_stitch) / n,
-                     "note": "the dominant kernel is instruction-issue bound (branchy integer walk, state in LDS), not HBM bound: see DESIGN.md section 6"},
+                     "traffic": traffic, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
+                     "algorithmic_bytes_per_pair_whole_path": bytes_per_pair,
+                     "note": "per launch = per batch of %d pairs, averaged over the %d timed batches of rank 0 (HIP events on the engine's stream)" % (args.reads, int(rep.batches))},
         "counters_per_pair": {k: v / n for k, v in c.items()},
-        "stitch_section_cycles": prof,
-        "index_upload_s": t_upload, "first_batch_incl_h2d_s": t_first, "sj_merge_ms": sj_merge_ms,
+        "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s": device_s, "device_resident_Mreads_s": n / device_s / 1e6 if device_s > 0 else None,
+                     "cli_over_device": device_s / float(rep.timedWall) if rep.timedWall > 0 else None,
+                     "map_batch_call_s": float(rep.deviceBusy[0]), "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
+                     "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
+                     "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
+                     "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds)},
+        "index_build": ginfo, "sj_merge_ms": sj_ms.get("ms"),
     }
-    if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
-        out["cpu_baseline"] = cpu_baseline(d, args, min(args.cpu_sample, n))
-    if not args.no_cli_e2e and world == 1:
-        out["cli_end_to_end"] = cli_end_to_end(d, args)
-    if world == 1 and isinstance(out.get("cpu_baseline"), dict) and isinstance(out.get("cli_end_to_end"), dict) and "error" not in out["cli_end_to_end"]:
-        try:
-            out["full_size_parity"] = full_size_parity(d)
-        except Exception as e:
-            out["full_size_parity"] = {"error": repr(e)[:300]}
-    if not args.no_two_pass_e2e and world == 1:
-        try:
-            out["two_pass_end_to_end"] = two_pass_end_to_end(d, args)
-        except Exception as e:                      # an informational leg must not take the bench line down
-            out["two_pass_end_to_end"] = {"error": repr(e)[:300]}
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    ref_prefix = os.path.join(run_dir, "cpu_")
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(idx, fq, ref_prefix, n_total)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)[:400]}
+        try:
+            out["full_size_parity"] = full_size_parity(ref_prefix, outp)
+        except Exception as e:
+            out["full_size_parity"] = {"error": repr(e)[:300]}
+    if not args.no_sweep and world == 1:
+        out["index_size_sweep"] = sweep(args, mb, out, log)
+    if not args.no_two_pass and world == 1 and time.time() - T_START < args.budget_s:
+        try:
+            out["two_pass_end_to_end"] = two_pass(args, idx, fq, run_dir, threads)
+        except Exception as e:
+            out["two_pass_end_to_end"] = {"error": repr(e)[:300]}
+    out["bench_wall_s"] = time.time() - T_START
+    out["notes"] = notes
+    print(json.dumps(out))
+
+
+def sweep(args, main_mb, main_out, log):
+    """The same pipeline on smaller indices (100 / 400 / 1000 Mb): how the kernels behave as the index outgrows the 256 MB Infinity Cache."""
+    rows = []
+    lread = 2 * args.read_len + 1
+    for mb in (100, 400, 1000):
+        if mb >= main_mb or time.time() - T_START > args.budget_s:
+            continue
+        try:
+            g, ginfo = build_genome(args, mb, log)
+            nb, w = 5, 1
+            n_total = (nb + w) * args.reads
+            rd = os.path.join(g, "sweep_n%d" % n_total)
+            fq = make_reads(args, g, rd, "reads", n_total, 9000 + mb)
+            argv = ["--runMode", "alignReads", "--genomeDir", os.path.join(g, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"),
+                    "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))), "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)]
+            rc, rep = run_cli(argv)
+            if rc:
+                rows.append({"genome_mb": mb, "error": "exit code %d" % rc}); continue
+            c, ms, kern, bpp = report_dict(rep, lread)
+            rows.append({"genome_mb": mb, "Mreads_s": int(rep.timedReads) / float(rep.timedWall) / 1e6, "per_kernel_ms": ms, "index_generate_s": ginfo.get("index_generate_s"),
+                         "junctions_in_index": ginfo.get("junctions_in_index"), "algorithmic_bytes_per_pair": bpp})
+        except Exception as e:
+            rows.append({"genome_mb": mb, "error": repr(e)[:300]})
+    rows.append({"genome_mb": main_mb, "Mreads_s": main_out["value"], "per_kernel_ms": main_out["roofline"]["per_kernel_ms"],
+                 "index_generate_s": main_out["index_build"].get("index_generate_s"), "junctions_in_index": main_out["index_build"].get("junctions_in_index"),
+                 "algorithmic_bytes_per_pair": main_out["roofline"]["algorithmic_bytes_per_pair_whole_path"]})
+    return rows
+
+
+def two_pass(args, idx, fq, run_dir, threads):
+    """--twopassMode Basic on two batches of the workload: 1st pass on the GPU without SAM, junction insertion, index
+    replaced in HBM, 2nd pass."""
+    n = 2 * args.reads
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "cli2p_"), "--runThreadN", str(threads),
+            "--gpuBatchReads", str(args.reads), "--twopassMode", "Basic", "--readMapNumber", str(n)]
+    rc, rep = run_cli(argv)
+    if rc:
+        return {"error": "exit code %d" % rc}
+    sjdb = sum(1 for _ in open(os.path.join(run_dir, "cli2p__STARgenome", "sjdbList.out.tab")))
+    return {"value": n / float(rep.wallMapping) / 1e6, "unit": "Mreads/s (each read counted once, both passes + insertion in the wall time)", "reads": n,
+            "wall_s": float(rep.wallMapping), "pass1_plus_insertion_plus_reupload_s": float(rep.pass1Seconds), "junctions_in_index_after_pass1": sjdb,
+            "host_threads": threads, "what": "star_amd --twopassMode Basic end to end (index load excluded)"}
 
 
 if __name__ == "__main__":

@@ -29,6 +29,8 @@ int staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results 
 }
 void staramd_destroy(staramd_ctx *ctx) { if (ctx) { oracle_destroy(ctx->o); delete ctx; } }
 const char *staramd_last_error(void) { return lastError.c_str(); }
+int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
+int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 // index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp
 int staramd_index_build(int, const uint8_t *G, const staramd_index_params *p, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, staramd_index_result *res) {
     uint64_t out[32];

@@ -1,0 +1,294 @@
+// cli_run.cpp -- `star_amd`: command-line drop-in for `STAR --runMode alignReads` as a function
+// (include/star_amd_cli.h).  Same flags (the subset that reaches the hot path or its outputs; anything else is rejected),
+// same genomeDir, same Aligned.out.sam / SJ.out.tab / Log.final.out.  The per-read hot path runs on the MI355X(s) through
+// the C ABI of include/star_amd.h; there is no CPU path.
+//
+// Pipeline (the reference interleaves these per thread, ReadAlignChunk_processChunks.cpp / _mapChunk.cpp):
+//   reader thread    FASTQ text -> numeric batch            (sah_parse_slot)            one, batches numbered in input order
+//   mapper threads   one per GPU (--gpuDevices a,b,...): a batch through that GPU's engine context (staramd_map_batch),
+//                    plus its merged-mates / WASP re-mapping batches on the same context
+//   writer thread    post-map + SAM text on --runThreadN host threads (sah_emit_slot), batches taken in INPUT order whatever
+//                    order the GPUs finish in (the order-dependent host state: random multimapper order, vW carry, KeepInputOrder)
+// Junction table, Stats and gene counts live in the one host object: nothing to merge inside a process (the reference's
+// per-thread tables, outputSJ.cpp:39-83, collapse to one).  Between phases (2-pass, BySJout) every context gets the new
+// index / whitelist.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <map>
+#include <chrono>
+#include <thread>
+#include <mutex>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <string>
+#include <memory>
+#include "../../../include/star_amd_host.h"
+#include "../../../include/star_amd_index.h"
+#include "../../../include/star_amd_cli.h"
+
+namespace {
+typedef std::chrono::steady_clock Clock;
+inline double since(Clock::time_point t) { return std::chrono::duration<double>(Clock::now() - t).count(); }
+
+struct Msg { int slot = -1; int n = 0; uint64_t seq = 0; staramd_batch b; bool merged = false; };
+struct Queue {                                   // hand-off between two pipeline stages
+    std::mutex m; std::condition_variable cv; std::deque<Msg> q; bool closed = false;
+    void push(const Msg &x) { { std::lock_guard<std::mutex> l(m); q.push_back(x); } cv.notify_all(); }
+    void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+    bool pop(Msg &x) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; x = q.front(); q.pop_front(); return true; }
+};
+struct Tokens {                                  // counting semaphore over a small set of buffer indices
+    std::mutex m; std::condition_variable cv; std::deque<int> free;
+    int take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free.empty(); }); int v = free.front(); free.pop_front(); return v; }
+    void give(int v) { { std::lock_guard<std::mutex> l(m); free.push_back(v); } cv.notify_all(); }
+};
+struct ResBuf {
+    std::vector<staramd_read_result> reads; std::vector<staramd_transcript> tr; std::vector<staramd_exon> ex; staramd_results res;
+    void size(uint64_t nReads) {
+        if (reads.size() < nReads) reads.resize(nReads);
+        if (tr.size() < nReads * 4 + 4096) { tr.resize(nReads * 4 + 4096); ex.resize(tr.size() * 3); }
+        memset(&res, 0, sizeof(res));
+        point();
+    }
+    void point() { res.reads = reads.data(); res.tr = tr.data(); res.trCapacity = tr.size(); res.ex = ex.data(); res.exCapacity = ex.size(); }
+};
+
+// CLI-level flags that never reach the host library: --gpuDevices a,b,c   --benchWarmupReads N
+struct CliFlags { std::vector<int> devices; uint64_t warmupReads = 0; std::vector<char *> rest; };
+CliFlags splitFlags(int argc, char **argv) {
+    CliFlags f;
+    for (int i = 0; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "--gpuDevices" && i + 1 < argc) {
+            std::string v = argv[++i]; size_t p = 0;
+            while (p <= v.size()) { size_t q = v.find(',', p); if (q == std::string::npos) q = v.size(); if (q > p) f.devices.push_back(atoi(v.substr(p, q - p).c_str())); p = q + 1; }
+        } else if (a == "--benchWarmupReads" && i + 1 < argc) f.warmupReads = strtoull(argv[++i], nullptr, 10);
+        else f.rest.push_back(argv[i]);
+    }
+    return f;
+}
+} // namespace
+
+extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, staramd_cli_report *report) {
+    staramd_cli_report rep; memset(&rep, 0, sizeof(rep));
+    auto publish = [&]() { if (report) *report = rep; };
+    for (int i = 1; i < argc; i++) if (std::string(argv[i]) == "--version") { printf("2.7.11b\n"); return 0; }      // the version whose behaviour is reproduced (Parameters.cpp:340-343)
+    CliFlags flags = splitFlags(argc, argv);
+    char err[4096];
+    void *h = sah_create((int)flags.rest.size(), flags.rest.data(), err, sizeof(err));
+    if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }
+    if (sah_tool_done(h)) { sah_destroy(h); return 0; }          // --runMode inputAlignmentsFromBAM: nothing to map
+    if (sah_generate_mode(h)) {                                  // --runMode genomeGenerate: suffix array + SAindex on the device
+        const uint8_t *G; uint64_t nGenome, saCap, saiCap; uint32_t gsb, nb; uint8_t *SA, *SAi;
+        if (sah_generate_buffers(h, &G, &nGenome, &gsb, &nb, &SA, &saCap, &SAi, &saiCap)) { fprintf(stderr, "\n%s\n", sah_error(h)); return 104; }
+        staramd_index_params ip; memset(&ip, 0, sizeof(ip));
+        ip.nGenome = nGenome; ip.GstrandBit = gsb; ip.gSAindexNbases = nb; ip.gSAsparseD = 1;
+        staramd_index_result ir;
+        auto tg = Clock::now();
+        int grc = staramd_index_build(flags.devices.empty() ? sah_device(h) : flags.devices[0], G, &ip, SA, saCap, SAi, saiCap, &ir);
+        if (grc) { fprintf(stderr, "\nEXITING because of FATAL ERROR: index build on the MI355X failed: %s\n", staramd_index_last_error()); sah_destroy(h); return 105; }
+        double sBuild = since(tg);
+        if (sah_generate_finish(h, ir.nSA, ir.nSAbyte, ir.nSAibyte)) { fprintf(stderr, "\n%s\n", sah_error(h)); sah_destroy(h); return 104; }
+        fprintf(stderr, "star_amd: genomeGenerate: %llu suffixes, %u doubling rounds, device build %.3f s (%.1f ms on the stream), junction insertion + files %.3f s\n",
+                (unsigned long long)ir.nSA, ir.doublingRounds, sBuild, ir.msTotal, since(tg) - sBuild);
+        sah_destroy(h);
+        return 0;
+    }
+    const uint64_t batchReads = sah_batch_reads(h);
+    std::vector<int> devices = flags.devices;
+    if (devices.empty()) devices.push_back(sah_device(h));
+    if (devices.size() > STARAMD_CLI_MAX_DEV) { fprintf(stderr, "\nEXITING because of fatal PARAMETERS error: --gpuDevices lists more than %d devices\n", STARAMD_CLI_MAX_DEV); sah_destroy(h); return 104; }
+    const int nDev = (int)devices.size();
+    rep.nDevices = nDev; rep.genomeLoadSeconds = sah_genome_load_seconds(h);
+    // ---- one engine context per GPU, index replicas uploaded concurrently
+    std::vector<staramd_ctx *> ctx(nDev, nullptr);
+    {
+        auto tu = Clock::now();
+        std::vector<int> rcs(nDev, 0); std::vector<std::string> es(nDev);
+        std::vector<std::thread> th;
+        for (int d = 0; d < nDev; d++) th.emplace_back([&, d] { rcs[d] = staramd_create(&ctx[d], devices[d], sah_genome(h), sah_params(h), (uint32_t)batchReads, 0); if (rcs[d]) es[d] = staramd_last_error(); });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < nDev; d++) if (rcs[d]) {
+            fprintf(stderr, "\nEXITING because of FATAL ERROR: cannot initialise the MI355X engine on device %d: %s\n", devices[d], es[d].c_str());
+            for (auto c : ctx) if (c) staramd_destroy(c);
+            sah_destroy(h); return 105;
+        }
+        rep.indexUploadSeconds = since(tu);
+    }
+    const int nSlots = std::min(24, 2 * nDev + 2);
+    std::vector<ResBuf> rb(nSlots), rbMerged(nSlots), rbWasp(nSlots);
+    std::vector<ResBuf> piecePart(nDev);
+    for (auto &r : rb) r.size(batchReads);
+    std::string failure; std::mutex failM; std::atomic<bool> failed(false);
+    auto fail = [&](const std::string &s) { std::lock_guard<std::mutex> l(failM); if (failure.empty()) failure = s; failed = true; };
+    // ---- timing state
+    std::mutex statM;
+    uint64_t nReads = 0; double msDeviceAll = 0;
+    bool timedOn = flags.warmupReads == 0; bool warmupPending = flags.warmupReads > 0;
+    Clock::time_point tTimed = Clock::now();
+    const auto t0 = Clock::now();
+    // warm-up pause: the reader stops after >= warmupReads reads, waits until every batch handed out so far is written
+    std::mutex drainM; std::condition_variable drainCv; uint64_t seqParsed = 0, seqEmitted = 0;
+
+    auto mapAllBatches = [&]() {
+        Queue parsed; Tokens slots;
+        std::mutex doneM; std::condition_variable doneCv; std::map<uint64_t, Msg> done; bool mappersClosed = false;
+        for (int i = 0; i < nSlots; i++) slots.give(i);
+        { std::lock_guard<std::mutex> l(drainM); seqParsed = seqEmitted = 0; }
+        std::thread reader([&] {
+            uint64_t seq = 0, readsOut = 0;
+            for (;;) {
+                if (warmupPending && readsOut >= flags.warmupReads) {            // drain, barrier, start the clock
+                    { std::unique_lock<std::mutex> l(drainM); drainCv.wait(l, [&] { return seqEmitted == seqParsed || failed.load(); }); }
+                    if (hooks && hooks->warmup_done) hooks->warmup_done(hooks->user);
+                    std::lock_guard<std::mutex> l(statM);
+                    warmupPending = false; timedOn = true; tTimed = Clock::now();
+                }
+                Msg m; m.slot = slots.take();
+                if (failed.load()) { slots.give(m.slot); break; }
+                auto tp = Clock::now();
+                m.n = sah_parse_slot(h, m.slot, batchReads, &m.b);
+                if (m.n < 0) { fail(sah_error(h)); slots.give(m.slot); break; }
+                if (m.n == 0) { slots.give(m.slot); break; }
+                { std::lock_guard<std::mutex> l(statM); if (timedOn) rep.parseBusy += since(tp); }
+                m.seq = seq++; readsOut += (uint64_t)m.n;
+                { std::lock_guard<std::mutex> l(drainM); seqParsed = seq; }
+                parsed.push(m);
+            }
+            parsed.close();
+        });
+        std::thread writer([&] {
+            uint64_t next = 0;
+            for (;;) {
+                Msg m;
+                {
+                    std::unique_lock<std::mutex> l(doneM);
+                    doneCv.wait(l, [&] { return done.count(next) || mappersClosed; });
+                    auto it = done.find(next);
+                    if (it == done.end()) { if (mappersClosed) break; continue; }
+                    m = it->second; done.erase(it);
+                }
+                next++;
+                auto te = Clock::now();
+                if (!failed.load() && m.n > 0 && (m.merged ? sah_emit_slot_merged(h, m.slot, &rb[m.slot].res, &rbMerged[m.slot].res) : sah_emit_slot(h, m.slot, &rb[m.slot].res))) fail(sah_error(h));
+                { std::lock_guard<std::mutex> l(statM); if (timedOn && m.n > 0) { rep.emitBusy += since(te); rep.timedReads += (uint64_t)m.n; rep.batches++; } if (m.n > 0) nReads += (uint64_t)m.n; }
+                slots.give(m.slot);
+                { std::lock_guard<std::mutex> l(drainM); seqEmitted = next; }
+                drainCv.notify_all();
+            }
+        });
+        std::vector<std::thread> mappers;
+        for (int d = 0; d < nDev; d++) mappers.emplace_back([&, d] {
+            Msg m;
+            while (parsed.pop(m)) {
+                int rc = 0;
+                if (!failed.load()) {
+                    auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[24] = {0};
+                    auto mapInto = [&](const staramd_batch &bt, ResBuf &r, bool main) {
+                        if (r.reads.size() < bt.nReads || r.tr.empty()) r.size(std::max<uint64_t>(bt.nReads, 1024));
+                        staramd_results &res = r.res;
+                        int e = staramd_map_batch(ctx[d], &bt, &res);
+                        if (e == STARAMD_ERR_RESULT_OVERFLOW) {          // more transcripts than the buffers hold -> grow and retry
+                            r.tr.resize(res.trCount + res.trCount / 4 + 4096); r.ex.resize(res.exCount + res.exCount / 4 + 4096); r.point();
+                            e = staramd_map_batch(ctx[d], &bt, &res);
+                        }
+                        if (!e) {
+                            msDev += res.msTotalDevice;
+                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 7); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[24] = {0}; int kc = staramd_get_counters(ctx[d], c, 24); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
+                        }
+                        return e;
+                    };
+                    rc = mapInto(m.b, rb[m.slot], true);
+                    m.merged = false;
+                    if (!rc) {                                           // --peOverlapNbasesMin: the overlapping mates of the batch, merged into single reads, are a second batch
+                        staramd_batch mb;
+                        if (sah_merged_slot(h, m.slot, &mb) > 0) { m.merged = true; rc = mapInto(mb, rbMerged[m.slot], false); }
+                    }
+                    if (!rc) {                                           // --waspOutputMode: allele-swapped copies of some reads, one more batch (can be larger than the batch itself)
+                        staramd_batch wb;
+                        int nw = sah_wasp_slot(h, m.slot, &rb[m.slot].res, &wb);
+                        if (nw > 0) {
+                            // as many pieces as it takes (a read over a dense cluster of SNVs has up to 1023 copies); every piece is rebased to offset 0
+                            // (the engine sizes and uploads a batch by readOffset[nReads]); the results of the pieces are appended to one set
+                            ResBuf &r = rbWasp[m.slot]; ResBuf &part = piecePart[d];
+                            if (r.reads.size() < (size_t)nw) { r.reads.resize((size_t)nw); }
+                            uint64_t trN = 0, exN = 0; std::vector<uint64_t> off;
+                            for (uint32_t doneN = 0; doneN < (uint32_t)nw && !rc; ) {
+                                staramd_batch piece = wb; piece.nReads = std::min<uint32_t>((uint32_t)batchReads, (uint32_t)nw - doneN);
+                                const uint64_t base = wb.readOffset[doneN];
+                                off.resize(piece.nReads + 1);
+                                for (uint32_t k = 0; k <= piece.nReads; k++) off[k] = wb.readOffset[doneN + k] - base;
+                                piece.bases = wb.bases + base; piece.readOffset = off.data(); piece.mate1Length = wb.mate1Length + doneN; piece.mmMaxTotal = wb.mmMaxTotal + doneN;
+                                rc = mapInto(piece, part, false);
+                                if (rc) break;
+                                const staramd_results &pr = part.res;
+                                if (r.tr.size() < trN + pr.trCount) r.tr.resize((trN + pr.trCount) * 3 / 2 + 1024);
+                                if (r.ex.size() < exN + pr.exCount) r.ex.resize((exN + pr.exCount) * 3 / 2 + 1024);
+                                for (uint32_t k = 0; k < piece.nReads; k++) { r.reads[doneN + k] = pr.reads[k]; r.reads[doneN + k].trOffset += (uint32_t)trN; }
+                                for (uint64_t k = 0; k < pr.trCount; k++) { r.tr[trN + k] = pr.tr[k]; r.tr[trN + k].exonOffset += (uint32_t)exN; }
+                                if (pr.exCount) memcpy(&r.ex[exN], pr.ex, pr.exCount * sizeof(staramd_exon));
+                                trN += pr.trCount; exN += pr.exCount; doneN += piece.nReads;
+                            }
+                            r.point(); r.res.trCount = trN; r.res.exCount = exN;
+                        }
+                        if (!rc && sah_wasp_results_slot(h, m.slot, &rb[m.slot].res, nw > 0 ? &rbWasp[m.slot].res : nullptr)) { fail(sah_error(h)); rc = 0; }
+                    }
+                    if (rc) fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error());
+                    std::lock_guard<std::mutex> l(statM);
+                    msDeviceAll += msDev;
+                    if (timedOn && !rc) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += msDev; for (int i = 0; i < 8; i++) rep.stageMs[i] += stage[i]; for (int i = 0; i < 24; i++) rep.counters[i] += cnt[i]; }
+                }
+                if (failed.load()) m.n = 0;                              // still goes through the writer so that the slot and the sequence number are released
+                { std::lock_guard<std::mutex> l(doneM); done[m.seq] = m; }
+                doneCv.notify_all();
+            }
+        });
+        for (auto &t : mappers) t.join();
+        { std::lock_guard<std::mutex> l(doneM); mappersClosed = true; }
+        doneCv.notify_all();
+        drainCv.notify_all();
+        reader.join(); writer.join();
+    };
+    // phases (sah_next_phase): plain run = one; --twopassMode Basic adds a 1st pass without SAM, after which the junctions it found
+    // are inserted into the index (sjdb_insert.cpp) and every HBM copy is replaced (twoPassRunPass1.cpp:9-96);
+    // --outFilterType BySJout adds a 2nd stage over the held reads with the filtered novel junctions as a whitelist (STAR.cpp:203-220)
+    for (;;) {
+        mapAllBatches();
+        if (failed.load()) break;
+        // the phase that follows is known only after sah_next_phase; ranks exchange their tables before it
+        if (hooks && hooks->exchange && hooks->exchange(hooks->user, h, 0)) { fail("cross-rank exchange failed"); break; }
+        int phase = sah_next_phase(h);
+        if (phase < 0) { fail(sah_error(h)); break; }
+        if (phase == 0) break;
+        std::vector<int> rcs(nDev, 0); std::vector<std::string> es(nDev);
+        std::vector<std::thread> th;
+        if (phase == 1) {
+            for (int d = 0; d < nDev; d++) th.emplace_back([&, d] { rcs[d] = staramd_update_index(ctx[d], sah_genome(h), sah_params(h)); if (rcs[d]) es[d] = staramd_last_error(); });
+            for (auto &t : th) t.join();
+            for (int d = 0; d < nDev; d++) if (rcs[d]) fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + es[d]);
+            if (failed.load()) break;
+            rep.pass1Seconds = since(t0);
+            fprintf(stderr, "star_amd: 1st pass + junction insertion + index re-upload: %.3f s (%llu reads)\n", rep.pass1Seconds, (unsigned long long)nReads);
+        } else {
+            const uint64_t *ns, *ne; uint64_t nn = sah_novel_junctions(h, &ns, &ne);
+            for (int d = 0; d < nDev; d++) if (staramd_set_novel_junctions(ctx[d], ns, ne, nn, 2)) fail(std::string("EXITING because of FATAL ERROR: ") + staramd_last_error());
+            if (failed.load()) break;
+            fprintf(stderr, "star_amd: BySJout stage 1 done (%llu reads so far), %llu novel junctions passed filtering\n", (unsigned long long)nReads, (unsigned long long)nn);
+        }
+    }
+    int exitCode = 0;
+    if (failed.load()) { fprintf(stderr, "\n%s\n", failure.c_str()); exitCode = 104; }
+    else if (hooks && hooks->exchange && hooks->exchange(hooks->user, h, 1)) { fprintf(stderr, "\ncross-rank exchange failed\n"); exitCode = 104; }
+    else if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); exitCode = 104; }
+    double sec = since(t0);
+    rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
+    if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",
+                           (unsigned long long)nReads, sec, msDeviceAll / 1e3 / nDev, sec > 0 ? (double)nReads / sec / 1e6 : 0.0, nDev);
+    for (auto c : ctx) staramd_destroy(c);
+    sah_destroy(h);
+    publish();
+    return exitCode;
+}

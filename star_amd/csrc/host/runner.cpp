@@ -27,10 +27,11 @@ struct Runner {
     FastqReader reader;
     ReadBatch batch;
     staramd_batch batchView;
-    ReadBatch slots[3];                 // pipelined CLI: parse / map / post-map work on different slots
+    static const int NSLOT = 24;        // batch slots of the pipelined CLI (3 + 2 per GPU are in use: cli_run.cpp)
+    ReadBatch slots[NSLOT];             // pipelined CLI: parse / map / post-map work on different slots
     Variation variation;                      // --varVCFfile
-    WaspBatch waspMain, waspSlots[3];         // --waspOutputMode SAMtag: the allele-swapped reads of batch / slots[k], mapped as one more batch
-    MergedBatch mergedMain, mergedSlots[3];   // --peOverlapNbasesMin: the merged mates of batch / slots[k], mapped as a second batch
+    WaspBatch waspMain, waspSlots[NSLOT];         // --waspOutputMode SAMtag: the allele-swapped reads of batch / slots[k], mapped as one more batch
+    MergedBatch mergedMain, mergedSlots[NSLOT];   // --peOverlapNbasesMin: the merged mates of batch / slots[k], mapped as a second batch
     std::unique_ptr<PostMap> post;
     OutSJ sj;
     Stats stats;

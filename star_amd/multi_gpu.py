@@ -120,3 +120,36 @@ def merge_run_outputs(run, dist, dev, rank, world):
     run.L.sah_sj_select(run.h, 0)
     _merge_gene_counts(run, dist, dev, rank, world)
     return _gather_tables(run, dist, dev, rank, world, everyone=False)
+
+
+# ---- the same exchanges for the in-process front end (include/star_amd_cli.h: staramd_cli_hooks.exchange hands out the sah_* handle) ----
+
+class HandleRun:
+    """Adapter: a raw sah_* handle + the host library, in the shape the functions above expect."""
+
+    def __init__(self, L, h):
+        self.L = L
+        self.h = C.c_void_p(h) if not isinstance(h, C.c_void_p) else h
+
+    def in_pass1(self):
+        self.L.sah_in_pass1.restype = C.c_int; self.L.sah_in_pass1.argtypes = [C.c_void_p]
+        return bool(self.L.sah_in_pass1(self.h))
+
+
+def exchange_before_phase(L, h, dist, dev, rank, world):
+    """Hook body for a phase that is NOT the last one (1st pass of --twopassMode Basic, stage 1 of --outFilterType BySJout): every rank
+    imports every other rank's junction table, so that all ranks insert the same junctions / build the same whitelist."""
+    run = HandleRun(L, h)
+    _bind(L)
+    if run.in_pass1():
+        L.sah_sj_select(run.h, 0)
+        _gather_tables(run, dist, dev, rank, world, everyone=True)
+    elif L.sah_in_stage1(run.h):
+        L.sah_sj_select(run.h, 1)
+        _gather_tables(run, dist, dev, rank, world, everyone=True, with_stats=False)
+        L.sah_sj_select(run.h, 0)
+
+
+def merge_handle_outputs(L, h, dist, dev, rank, world):
+    """Hook body for the end of the run: rank 0 ends up with the union of the junction tables, the summed counters and gene counts."""
+    return merge_run_outputs(HandleRun(L, h), dist, dev, rank, world)

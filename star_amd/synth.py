@@ -365,3 +365,84 @@ def make_genome_large(seed, total_mb, n_chr, families=HUMAN_LIKE_FAMILIES, segdu
     clen = n // n_chr
     seqs = [g[i * clen:(i + 1) * clen if i < n_chr - 1 else n] for i in range(n_chr)]
     return seqs, min(1.0, covered / n)
+
+
+class ReadSampler:
+    """Bench-size read sampling: the transcriptome / genome concatenations are built once, then any number of chunks of pairs is
+    drawn from them (each chunk from its own seed, so chunks can be made by different processes and always come out the same).
+    Same model as make_reads: a fraction of the fragments comes from spliced transcripts, the rest from the chromosomes; FR pairs;
+    substitutions and Ns per base."""
+
+    def __init__(self, seqs, trs, read_len, frag=(200, 500)):
+        self.L = read_len; self.frag = frag
+        self.glen = np.asarray([len(s) for s in seqs], dtype=np.int64)
+        base = seqs[0].base if seqs[0].base is not None else None
+        contiguous = base is not None and all(s.base is base for s in seqs) and base.size == int(self.glen.sum())
+        self.gseq = base if contiguous else np.concatenate(seqs)
+        self.gstart = np.concatenate([[0], np.cumsum(self.glen)[:-1]])
+        fmin = max(frag[0], read_len)
+        # transcriptome as an index map into gseq (no copy of the sequence): per transcript the exon pieces
+        ex_g, ex_len, tlen = [], [], []
+        for t in trs:
+            n = 0
+            for a, b in t["exons"]:
+                ex_g.append(self.gstart[t["chr"]] + a); ex_len.append(b - a + 1); n += b - a + 1
+            tlen.append(n)
+        ex_g = np.asarray(ex_g, dtype=np.int64); ex_len = np.asarray(ex_len, dtype=np.int64)
+        tot = int(ex_len.sum())
+        if tot:
+            start = np.cumsum(ex_len) - ex_len
+            eid = np.repeat(np.arange(len(ex_len)), ex_len)
+            self.tr_seq = self.gseq[ex_g[eid] + (np.arange(tot) - start[eid])]
+        else:
+            self.tr_seq = np.zeros(0, dtype=np.uint8)
+        self.tlen = np.asarray(tlen, dtype=np.int64)
+        self.tstart = np.cumsum(self.tlen) - self.tlen if len(tlen) else np.zeros(0, dtype=np.int64)
+        self.usable = np.flatnonzero(self.tlen >= fmin)
+        w = self.tlen[self.usable].astype(np.float64)
+        self.tcum = np.cumsum(w / w.sum()) if len(w) else None
+        ok = np.flatnonzero(self.glen > frag[1] + 2)
+        self.gok = ok; self.gcum = np.cumsum(self.glen[ok] / self.glen[ok].sum())
+
+    def sample(self, seed, n, frac_spliced=0.85, sub_rate=0.01, n_rate=0.001):
+        rng = np.random.default_rng(seed)
+        L = self.L
+        n_spl = int(n * frac_spliced) if len(self.usable) else 0
+        idx = np.arange(L)
+        m1 = np.empty((n, L), dtype=np.uint8); m2 = np.empty((n, L), dtype=np.uint8)
+
+        def put(src, starts, flens, lo):
+            k = len(starts)
+            a = src[starts[:, None] + idx]
+            b = _COMP[src[(starts + flens - L)[:, None] + idx][:, ::-1]]
+            flip = rng.random(k) < 0.5
+            m1[lo:lo + k] = np.where(flip[:, None], b, a)
+            m2[lo:lo + k] = np.where(flip[:, None], a, b)
+        if n_spl:
+            pick = self.usable[np.minimum(np.searchsorted(self.tcum, rng.random(n_spl)), len(self.usable) - 1)]
+            fl = np.minimum(np.maximum(rng.integers(self.frag[0], self.frag[1] + 1, size=n_spl), L), self.tlen[pick])
+            off = (rng.random(n_spl) * (self.tlen[pick] - fl + 1)).astype(np.int64)
+            put(self.tr_seq, self.tstart[pick] + off, fl, 0)
+        n_gen = n - n_spl
+        if n_gen:
+            c = self.gok[np.minimum(np.searchsorted(self.gcum, rng.random(n_gen)), len(self.gok) - 1)]
+            fl = rng.integers(max(self.frag[0], L), self.frag[1] + 1, size=n_gen)
+            off = (rng.random(n_gen) * (self.glen[c] - fl)).astype(np.int64)
+            put(self.gseq, self.gstart[c] + off, fl, n_spl)
+        for m in (m1, m2):
+            if sub_rate > 0:
+                mask = rng.random(m.shape, dtype=np.float32) < sub_rate
+                cur = m[mask]
+                code = np.searchsorted(_ACGT, cur) % 4
+                m[mask] = _ACGT[(code + rng.integers(1, 4, size=cur.shape[0])) % 4]
+            if n_rate > 0:
+                m[rng.random(m.shape, dtype=np.float32) < n_rate] = ord("N")
+        perm = rng.permutation(n)
+        return m1[perm], m2[perm]
+
+
+def write_fastq_ids(prefix, m1, m2, first_id):
+    """FASTQ pair files with read names r<first_id + i> (fixed width)."""
+    ids = np.arange(first_id, first_id + m1.shape[0])
+    _fastq_block("r", ids, m1).tofile(prefix + "_1.fq")
+    _fastq_block("r", ids, m2).tofile(prefix + "_2.fq")

@@ -21,6 +21,16 @@ CASES = [("pe101", ["--twopassMode", "Basic", "--outFilterType", "BySJout", "--o
          ("pe101", ["--waspOutputMode", "SAMtag", "--varVCFfile", "VCF", "--outSAMtype", "BAM", "Unsorted", "--twopassMode", "Basic"], 1000)]
 
 
+# the same runs with one mapper thread per "GPU" (--gpuDevices: two / three oracle-backed contexts fed from the one reader, emitted in input
+# order by the one writer, index / whitelist updates fanned out between the phases): still equal to ONE reference run
+MULTI = [(CASES[0][0], CASES[0][1], 150, "0,1"), (CASES[1][0], CASES[1][1], 120, "0,1,2"), (CASES[3][0], CASES[3][1], 400, "0,1"), (CASES[4][0], CASES[4][1], 200, "0,1")]
+
+
+@pytest.mark.parametrize("name,more,batch,devices", MULTI)
+def test_cli_pipeline_multi_device(name, more, batch, devices, tmp_path, built):
+    test_cli_pipeline(name, more + ["--gpuDevices", devices], batch, tmp_path, built)
+
+
 @pytest.mark.parametrize("name,more,batch", CASES)
 def test_cli_pipeline(name, more, batch, tmp_path, built):
     info = dict(prepare(name, str(tmp_path), need_ref=False))
@@ -29,11 +39,14 @@ def test_cli_pipeline(name, more, batch, tmp_path, built):
         from test_wasp import _vcf
         more = [_vcf(info, d) if x == "VCF" else x for x in more]
     more = [info["gtf"] if x == "GTF" else x for x in more]
+    cli_only = []
+    if "--gpuDevices" in more:
+        i = more.index("--gpuDevices"); cli_only = more[i:i + 2]; more = more[:i] + more[i + 2:]
     flags = list(info["extra"]) + more
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=flags)
     new = os.path.join(d, "cli_")
     subprocess.check_call([CLI, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] +
-                          ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + flags, stderr=subprocess.DEVNULL)
+                          ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + flags + cli_only, stderr=subprocess.DEVNULL)
     n = 0
     for f in sorted(os.listdir(d)):
         if not f.startswith("ref_") or os.path.isdir(os.path.join(d, f)):
