@@ -122,8 +122,18 @@ def _chunk_job(job):
 
 
 def make_reads(args, g, out_dir, tag, n_pairs, seed_base):
-    """n_pairs pairs as chunk files <out_dir>/<tag>_cNNN_{1,2}.fq (comma-separated lists go to --readFilesIn); chunks are sampled by a
-    pool of forked workers from the shared genome / transcriptome arrays."""
+    """n_pairs pairs as <out_dir>/<tag>_{1,2}.fq.  Runs in a child interpreter (`bench.py --make-reads ...`): the sampler forks a pool of
+    workers, which must not happen in a process that has initialised the HIP runtime."""
+    out = [os.path.join(out_dir, "%s_%d.fq" % (tag, m)) for m in (1, 2)]
+    if not os.path.isfile(os.path.join(out_dir, tag + ".DONE")):
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--make-reads", json.dumps([args.read_len, g, out_dir, tag, n_pairs, seed_base, int(os.environ.get("WORLD_SIZE", "1"))])],
+                       check=True, timeout=1200, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    return out
+
+
+def _make_reads_child(read_len, g, out_dir, tag, n_pairs, seed_base, world):
+    """chunks are sampled by a pool of forked workers from the shared genome / transcriptome arrays, then joined into one file per mate
+    (a comma-separated list would send the reference through a fifo + an executable script in its temp directory: /dev/shm is noexec)"""
     global _SAMPLER
     import numpy as np
     from star_amd import synth
@@ -139,10 +149,10 @@ def make_reads(args, g, out_dir, tag, n_pairs, seed_base):
         seqs, o = [], 0
         for ln in meta["chr_len"]:
             seqs.append(gseq[o:o + ln]); o += ln
-        _SAMPLER = synth.ReadSampler(seqs, meta["trs"], args.read_len)
+        _SAMPLER = synth.ReadSampler(seqs, meta["trs"], read_len)
         _SAMPLER.gseq = np.asarray(gseq)
         import multiprocessing as mp
-        nproc = max(1, min(len(jobs), (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 32))
+        nproc = max(1, min(len(jobs), (os.cpu_count() or 8) // max(1, world), 32))
         if nproc > 1:
             with mp.get_context("fork").Pool(nproc) as pool:
                 pool.map(_chunk_job, jobs)
@@ -150,8 +160,18 @@ def make_reads(args, g, out_dir, tag, n_pairs, seed_base):
             for j in jobs:
                 _chunk_job(j)
         _SAMPLER = None
+        for m in (1, 2):
+            with open(os.path.join(out_dir, "%s_%d.fq" % (tag, m)), "wb") as fo:
+                for j in jobs:
+                    part = j[2] + "_%d.fq" % m
+                    with open(part, "rb") as fi:
+                        while True:
+                            b = fi.read(1 << 26)
+                            if not b:
+                                break
+                            fo.write(b)
+                    os.remove(part)
         open(done, "w").write("ok\n")
-    return [",".join(j[2] + "_%d.fq" % m for j in jobs) for m in (1, 2)]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -206,7 +226,7 @@ def report_dict(rep, lread):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline + parity
 
-def cpu_baseline(idx, fq, out_prefix, n_pairs):
+def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
     """The reference itself (oracle/_ref/STAR, built from /root/reference by oracle/Makefile.ref), same index, same FASTQ, default parameters.
     STAR deals input to its threads in chunks of limitIObufferSize[0]/nMates bytes (ReadAlignChunk_processChunks.cpp:14-30, Parameters.cpp:1160);
     the default (30 MB -> ~67 k pairs) would leave most of 256 threads without a chunk on a 10 M-pair sample, so the input buffer is set to
@@ -218,7 +238,8 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs):
 
     def run(nmap, threads, extra=()):
         t = time.perf_counter()
-        refstar.align(idx, fq, out_prefix, threads=threads, extra=["--readMapNumber", str(nmap)] + small + list(extra))
+        refstar.align(idx, fq, out_prefix, threads=threads, extra=["--readMapNumber", str(nmap)] + small + list(extra), timeout=900)
+        log("reference STAR: %d reads, %d threads: %.1f s" % (nmap, threads, time.perf_counter() - t))
         return time.perf_counter() - t
     run(1, ncpu)                                    # page cache
     t_load = min(run(1, ncpu), run(1, ncpu))
@@ -228,12 +249,11 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs):
         tried[th] = n_pairs / max(t_full - t_load, 1e-3) / 1e6
     # the all-core run is last: its outputs stay for the parity check
     n1 = min(n_pairs, 60000)
-    t1 = run(n1, 1, ["--outSAMmode", "None"]) if False else None
     one = None
     try:
         p1 = out_prefix + "t1_"
-        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", str(n1)]); t_one = time.perf_counter() - t
-        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", "1"]); t_one_load = time.perf_counter() - t
+        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", str(n1)], timeout=600); t_one = time.perf_counter() - t
+        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", "1"], timeout=600); t_one_load = time.perf_counter() - t
         one = n1 / max(t_one - t_one_load, 1e-3) / 1e6
     except Exception:
         one = None
@@ -265,7 +285,14 @@ def _digest_range(job):
 
 
 def sam_digest(path):
-    """(record count, order-independent sum of 64-bit record hashes) of a SAM file, hashed by a pool over byte ranges."""
+    """(record count, order-independent sum of 64-bit record hashes) of a SAM file; in a child interpreter (it forks a pool)."""
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--sam-digest", path], check=True, timeout=1200, stdout=subprocess.PIPE, text=True,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    n, acc = p.stdout.split()
+    return int(n), int(acc)
+
+
+def _sam_digest_child(path):
     import multiprocessing as mp
     size = os.path.getsize(path)
     nproc = max(1, min(64, (os.cpu_count() or 8) // 2, size // (1 << 24) + 1))
@@ -310,8 +337,7 @@ def main():
 
     def log(s):
         notes.append("[%.0f s] %s" % (time.time() - T_START, s))
-        if os.environ.get("STARAMD_BENCH_VERBOSE"):
-            print("bench: " + notes[-1], file=sys.stderr, flush=True)
+        print("bench: " + notes[-1], file=sys.stderr, flush=True)
 
     def barrier():
         if dist is not None:
@@ -418,11 +444,13 @@ def main():
     ref_prefix = os.path.join(run_dir, "cpu_")
     if not args.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(idx, fq, ref_prefix, n_total)
+            out["cpu_baseline"] = cpu_baseline(idx, fq, ref_prefix, n_total, log)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)[:400]}
+        log("cpu_baseline done")
         try:
             out["full_size_parity"] = full_size_parity(ref_prefix, outp)
+            log("full_size_parity done")
         except Exception as e:
             out["full_size_parity"] = {"error": repr(e)[:300]}
     if not args.no_sweep and world == 1:
@@ -482,4 +510,9 @@ def two_pass(args, idx, fq, run_dir, threads):
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:2] == ["--make-reads"]:
+        _make_reads_child(*json.loads(sys.argv[2]))
+    elif sys.argv[1:2] == ["--sam-digest"]:
+        print("%d %d" % _sam_digest_child(sys.argv[2]))
+    else:
+        main()

@@ -42,7 +42,7 @@ def genome_generate(fasta, outdir, gtf=None, sjdb_overhang=100, sa_index_nbases=
     return outdir
 
 
-def align(genome_dir, fastqs, outprefix, threads=1, extra=(), binary=None):
+def align(genome_dir, fastqs, outprefix, threads=1, extra=(), binary=None, timeout=None):
     """reference `--runMode alignReads`; returns the output prefix."""
     os.makedirs(os.path.dirname(outprefix) or ".", exist_ok=True)
     tmp = outprefix + "_STARtmp"
@@ -50,7 +50,7 @@ def align(genome_dir, fastqs, outprefix, threads=1, extra=(), binary=None):
         shutil.rmtree(tmp)
     cmd = [binary or REF_BIN, "--runMode", "alignReads", "--genomeDir", genome_dir, "--readFilesIn"] + list(fastqs) + \
           ["--runThreadN", str(threads), "--outFileNamePrefix", outprefix] + list(extra)
-    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    subprocess.run(cmd, stdout=subprocess.DEVNULL, check=True, timeout=timeout)
     return outprefix
 
 
