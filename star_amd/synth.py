@@ -299,16 +299,19 @@ def make_genome_large(seed, total_mb, n_chr, families=HUMAN_LIKE_FAMILIES, segdu
     """Random ACGT genome of total_mb megabases in n_chr equal chromosomes with interspersed repeat families (about half of
     the bases), a few recent segmental duplications (10-40 kb, ~1 % divergence), microsatellites and short N runs.
     Generated with torch on `device` (the GPU when there is one: a 3.1 Gb genome takes seconds; the random stream depends on the
-    device type).  Returns (list of per-chromosome uint8 ASCII numpy arrays (views into one buffer), bases written by repeats / n)."""
+    device type), one chromosome at a time (tensors stay far below 2^31 elements); the family consensus sequences are shared by all
+    chromosomes.  Returns (list of per-chromosome uint8 ASCII numpy arrays (views into one buffer), bases written by repeats / n)."""
     import torch
     dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
     gen = torch.Generator(device=dev); gen.manual_seed(int(seed))
     n = int(total_mb) * 1000000
     ri = lambda lo, hi, size, dt=torch.int64: torch.randint(lo, hi, (int(size),), generator=gen, device=dev, dtype=dt)
     ru = lambda size: torch.rand(int(size), generator=gen, device=dev)
-    g = torch.empty(n, dtype=torch.uint8, device=dev)
-    for lo in range(0, n, 1 << 30):
-        hi = min(n, lo + (1 << 30)); g[lo:hi] = ri(0, 4, hi - lo, torch.uint8)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    units = [ri(0, 4, f[0], torch.uint8) for f in families]
+    out = np.empty(n, dtype=np.uint8)
+    clen = n // n_chr
+    bounds = [(i * clen, (i + 1) * clen if i < n_chr - 1 else n) for i in range(n_chr)]
     covered = 0
 
     def flat(length):                        # per-element copy id and offset inside the copy
@@ -316,54 +319,55 @@ def make_genome_large(seed, total_mb, n_chr, families=HUMAN_LIKE_FAMILIES, segdu
         cid = torch.repeat_interleave(torch.arange(length.numel(), device=dev), length)
         return tot, cid, torch.arange(tot, device=dev) - start[cid]
 
-    for unit_len, per_mb, (d0, d1), min_frac in families:
-        copies = int(per_mb * total_mb)
-        if copies == 0:
-            continue
-        unit = ri(0, 4, unit_len, torch.uint8)
-        step = max(1, min(copies, (1 << 27) // unit_len))
-        for lo in range(0, copies, step):
-            k = min(step, copies - lo)
-            length = (unit_len * (min_frac + (1 - min_frac) * ru(k) ** 2)).to(torch.int64).clamp(20, unit_len)   # 3' end kept, 5' truncated
-            pos = ri(0, n - unit_len - 1, k)
-            div = d0 + (d1 - d0) * ru(k)
-            rev = ru(k) < 0.5
-            tot, cid, off = flat(length)
-            base = unit[unit_len - length[cid] + off]
-            mut = ru(tot) < div[cid]
-            base = torch.where(mut, (base + ri(1, 4, tot, torch.uint8)) & 3, base)
-            r = rev[cid]
-            base = torch.where(r, 3 - base, base)
-            dst = torch.where(r, pos[cid] + (length[cid] - 1 - off), pos[cid] + off)
-            g[dst] = base
-            covered += tot
-    for _ in range(int(segdup_per_mb * total_mb) + 1):         # recent segmental duplications
-        ln = int(ri(10000, 40000, 1).item())
-        if n <= 3 * ln:
-            break
-        a, b = int(ri(0, n - ln, 1).item()), int(ri(0, n - ln, 1).item())
-        cp = g[a:a + ln].clone()
-        m = ru(ln) < 0.01
-        cp = torch.where(m, (cp + ri(1, 4, ln, torch.uint8)) & 3, cp)
-        g[b:b + ln] = cp
-        covered += ln
-    k = int(microsat_per_mb * total_mb)
-    if k:
-        for motif_len in (1, 2, 3, 4):
-            kk = max(1, k // 4)
-            pos = ri(0, n - 200, kk); ln = ri(15, 60, kk)
-            motif = ri(0, 4, kk * motif_len, torch.uint8).reshape(kk, motif_len)
+    for c0, c1 in bounds:
+        m = c1 - c0; mbc = m / 1e6
+        g = ri(0, 4, m, torch.uint8)
+        for (unit_len, per_mb, (d0, d1), min_frac), unit in zip(families, units):
+            copies = int(per_mb * mbc)
+            if copies == 0 or m <= unit_len + 2:
+                continue
+            step = max(1, min(copies, (1 << 27) // unit_len))
+            for lo in range(0, copies, step):
+                k = min(step, copies - lo)
+                length = (unit_len * (min_frac + (1 - min_frac) * ru(k) ** 2)).to(torch.int64).clamp(20, unit_len)   # 3' end kept, 5' truncated
+                pos = ri(0, m - unit_len - 1, k)
+                div = d0 + (d1 - d0) * ru(k)
+                rev = ru(k) < 0.5
+                tot, cid, off = flat(length)
+                base = unit[unit_len - length[cid] + off]
+                mut = ru(tot) < div[cid]
+                base = torch.where(mut, (base + ri(1, 4, tot, torch.uint8)) & 3, base)
+                r = rev[cid]
+                base = torch.where(r, 3 - base, base)
+                dst = torch.where(r, pos[cid] + (length[cid] - 1 - off), pos[cid] + off)
+                g[dst] = base
+                covered += tot
+        for _ in range(int(segdup_per_mb * mbc) + 1):         # recent segmental duplications (inside the chromosome)
+            ln = int(ri(10000, 40000, 1).item())
+            if m <= 3 * ln:
+                break
+            a, b = int(ri(0, m - ln, 1).item()), int(ri(0, m - ln, 1).item())
+            cp = g[a:a + ln].clone()
+            mm = ru(ln) < 0.01
+            g[b:b + ln] = torch.where(mm, (cp + ri(1, 4, ln, torch.uint8)) & 3, cp)
+            covered += ln
+        k = int(microsat_per_mb * mbc)
+        if k and m > 400:
+            for motif_len in (1, 2, 3, 4):
+                kk = max(1, k // 4)
+                pos = ri(0, m - 200, kk); ln = ri(15, 60, kk)
+                motif = ri(0, 4, kk * motif_len, torch.uint8).reshape(kk, motif_len)
+                tot, cid, off = flat(ln)
+                g[pos[cid] + off] = motif[cid, off % motif_len]
+        g = acgt[g.long()]
+        kn = int(n_runs_per_mb * mbc)
+        if kn and m > 100:
+            pos = ri(0, m - 40, kn); ln = ri(1, 30, kn)
             tot, cid, off = flat(ln)
-            g[pos[cid] + off] = motif[cid, off % motif_len]
-    g = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[g.long()] if n < (1 << 28) else torch.cat([torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[g[lo:lo + (1 << 28)].long()] for lo in range(0, n, 1 << 28)])
-    kn = int(n_runs_per_mb * total_mb)
-    if kn:
-        pos = ri(0, n - 40, kn); ln = ri(1, 30, kn)
-        tot, cid, off = flat(ln)
-        g[pos[cid] + off] = ord("N")
-    g = g.cpu().numpy()
-    clen = n // n_chr
-    seqs = [g[i * clen:(i + 1) * clen if i < n_chr - 1 else n] for i in range(n_chr)]
+            g[pos[cid] + off] = ord("N")
+        out[c0:c1] = g.cpu().numpy()
+        del g
+    seqs = [out[a:b] for a, b in bounds]
     return seqs, min(1.0, covered / n)
 
 
