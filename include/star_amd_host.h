@@ -19,6 +19,7 @@
 #ifndef STAR_AMD_HOST_H
 #define STAR_AMD_HOST_H
 #include "star_amd.h"
+#include "star_amd_index.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -29,6 +30,8 @@ const char *sah_error(void *h);
 int   sah_tool_done(void *h);                                           /* 1: --runMode inputAlignmentsFromBAM, everything happened in sah_create */
 /* --runMode genomeGenerate: sah_create scanned the FASTA files; build SA + SAindex into these buffers with staramd_index_build
  * (star_amd_index.h), then sah_generate_finish inserts the annotated junctions and writes the genomeDir files */
+/* call BEFORE sah_create: junction insertion runs on the device through fn (= staramd_sjdb_insert); NULL = host restatement (sjdb_insert.cpp) */
+void  sah_set_sjdb_device_fn(int (*fn)(int device, const staramd_sjdb_args *, staramd_sjdb_result *), int device);
 int   sah_generate_mode(void *h);
 int   sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases,
                            uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap);

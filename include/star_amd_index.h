@@ -41,6 +41,23 @@ typedef struct staramd_index_result {
 int staramd_index_build(int device, const uint8_t *G, const staramd_index_params *p,
                         uint8_t *SA, uint64_t saCapacity, uint8_t *SAi, uint64_t saiCapacity, staramd_index_result *res);
 
+/* Junction insertion (sjdbBuildIndex, source/sjdbBuildIndex.cpp:15-333) on the device, host buffers in and out: the search of every new
+ * junction suffix in the old suffix array, the sort of the new suffixes, the merge into the new packed array and the SAindex of the result.
+ * What sjdbPrepare decides (which junctions, their sequences, motifs, shifts) is the caller's: it hands in
+ *   Gsj       sjdbN blocks of sjdbLength codes (donor flank, acceptor flank, spacer 5): the forward half of the reference's Gsj
+ *   isOld     per junction of the NEW table: 1 = already in the old index (binarySearch2 hit, :47-55): no new suffixes
+ *   oldSJind  per junction of the OLD table: its number in the new table (:54)
+ * SAout / SAiOut are sized by the caller: nSAnew = nSAold + (number of offsets in Gsj+revcomp(Gsj) that start with ACGT inside new junctions). */
+typedef struct staramd_sjdb_args {
+    const uint8_t *G; uint64_t nGenomeOld, nGenomeReal;      /* old genome text; nGenomeReal = chrStart[nChrReal] = start of the junction block */
+    const uint8_t *SA; uint64_t nSAold, nSAbyteOld; uint32_t GstrandBit, gSAindexNbases;
+    const uint8_t *Gsj; uint32_t sjdbN, sjdbLength;
+    const uint8_t *isOld; const uint32_t *oldSJind; uint32_t oldSjdbN; uint32_t reserved; uint64_t sjNew;
+    uint8_t *SAout; uint64_t saOutCapacity; uint8_t *SAiOut; uint64_t saiOutCapacity;
+} staramd_sjdb_args;
+typedef struct staramd_sjdb_result { uint64_t nInd, nSAnew, nSAbyteNew, nSAibyte; float msTotal; uint32_t reserved; } staramd_sjdb_result;
+int staramd_sjdb_insert(int device, const staramd_sjdb_args *a, staramd_sjdb_result *res);
+
 const char *staramd_index_last_error(void);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@ void *oracle_create(const staramd_genome *g, const staramd_params *p);
 void oracle_destroy(void *h);
 int oracle_set_novel_junctions(void *h, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage);
 int oracle_map_batch(void *h, const staramd_batch *b, staramd_results *r);
+int sjdb_emul_insert(int, const staramd_sjdb_args *a, staramd_sjdb_result *res);
 int index_emul_build(const uint8_t *G, uint64_t nGenome, uint32_t GstrandBit, uint32_t saIndexNbases, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, uint64_t *out);
 }
 
@@ -41,5 +42,6 @@ int staramd_index_build(int, const uint8_t *G, const staramd_index_params *p, ui
     if (rc) lastError = "index_emul_build failed";
     return rc;
 }
+int staramd_sjdb_insert(int d, const staramd_sjdb_args *a, staramd_sjdb_result *res) { return sjdb_emul_insert(d, a, res); }
 const char *staramd_index_last_error(void) { return lastError.c_str(); }
 }

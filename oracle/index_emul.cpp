@@ -3,6 +3,8 @@
 // machine without a GPU (tests/test_index_build.py, -m "not gpu").  The product is the HIP instantiation in
 // star_amd/csrc/index/index_gpu.hip; nothing under star_amd/ links this file.
 #include "../star_amd/csrc/index/index_core.h"
+#include "../star_amd/csrc/index/sjdb_core.h"
+#include "../include/star_amd_index.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -42,5 +44,18 @@ extern "C" int index_emul_build(const uint8_t *G, uint64_t nGenome, uint32_t Gst
     int rc = buildAll(be, G, P, SA, saCap, SAi, saiCap, R);
     out[0] = R.nSA; out[1] = R.nSAbyte; out[2] = R.nSAi; out[3] = R.nSAibyte; out[4] = R.rounds;
     for (int i = 0; i < 17; i++) out[5 + i] = R.saiStart[i];
+    return rc;
+}
+
+// junction insertion: the device algorithm (star_amd/csrc/index/sjdb_core.h) on the plain-loop backend; same signature as staramd_sjdb_insert
+extern "C" int sjdb_emul_insert(int, const staramd_sjdb_args *a, staramd_sjdb_result *res) {
+    LoopBackend be;
+    SjdbParams P; P.nGenomeOld = a->nGenomeOld; P.nGenomeReal = a->nGenomeReal; P.nSAold = a->nSAold; P.GstrandBit = a->GstrandBit;
+    P.sjdbN = a->sjdbN; P.sjdbLength = a->sjdbLength; P.oldSjdbN = a->oldSjdbN; P.sjNew = a->sjNew; P.saIndexNbases = a->gSAindexNbases;
+    SjdbHostArgs A{a->G, a->SA, a->nSAbyteOld, a->Gsj, a->isOld, a->oldSJind, a->SAout, a->saOutCapacity, a->SAiOut, a->saiOutCapacity};
+    u64 nInd = 0, nb = 0, nbi = 0;
+    int rc = sjdbInsertHost(be, P, A, nInd, nb, nbi);
+    memset(res, 0, sizeof(*res));
+    res->nInd = nInd; res->nSAnew = a->nSAold + nInd; res->nSAbyteNew = nb; res->nSAibyte = nbi;
     return rc;
 }

@@ -338,3 +338,24 @@ class Engine:
         if self.ctx:
             self.L.staramd_destroy(self.ctx)
             self.ctx = C.c_void_p()
+
+
+class device_sjdb_insertion:
+    """Context manager: junction insertion (2-pass, --sjdbFileChrStartEnd / --sjdbGTFfile at the mapping stage) of every HostRun created inside
+    runs through `fn_lib.fn_name` -- staramd_sjdb_insert of the engine library on a GPU box, or its plain-loop twin in the CPU tests
+    (oracle/_build/libindex_emul.so: sjdb_emul_insert) -- instead of the host restatement.  Process-wide switch of the host library."""
+
+    def __init__(self, lib_path=None, fn_name="staramd_sjdb_insert", device=0):
+        self.lib = C.CDLL(lib_path or _need(ENGINE_PATH))
+        self.fn = C.cast(getattr(self.lib, fn_name), C.c_void_p)
+        self.device = device
+
+    def __enter__(self):
+        L = host_lib()
+        L.sah_set_sjdb_device_fn.restype = None; L.sah_set_sjdb_device_fn.argtypes = [C.c_void_p, C.c_int]
+        L.sah_set_sjdb_device_fn(self.fn, self.device)
+        return self
+
+    def __exit__(self, *a):
+        host_lib().sah_set_sjdb_device_fn(None, 0)
+        return False

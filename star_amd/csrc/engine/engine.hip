@@ -67,6 +67,7 @@ struct staramd_ctx {
     u64 counters[DC_N];
     u32 residentReads = 0; u32 residentMaxLread = 0;
     u32 *hostScratch = nullptr;         // pinned: totals + cursors read-back
+    std::vector<u64> rebased;           // read offsets of a batch that does not start at base 0
 };
 
 template <class T> static int devAlloc(std::vector<void *> &reg, T **p, u64 n) {
@@ -434,19 +435,23 @@ static int runDevice(staramd_ctx *c, staramd_results *r) {
 extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd_results *r) {
     if (!c || !b || !r || !r->reads) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
     if (b->nReads == 0) { r->trCount = r->exCount = 0; return STARAMD_OK; }
-    if (b->nReads > c->maxReads || b->readOffset[b->nReads] > c->maxBases) { g_err = "batch larger than the context's work space"; return STARAMD_ERR_ARG; }
+    // a batch may be a slice of a larger one (readOffset[0] > 0: the pieces of a WASP re-mapping batch): sized and uploaded from its own first base
+    const u64 base0 = b->readOffset[0], nBases = b->readOffset[b->nReads] - base0;
+    if (b->nReads > c->maxReads || nBases > c->maxBases) { g_err = "batch larger than the context's work space"; return STARAMD_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream; u32 n = b->nReads;
     u32 maxL = 0;
     for (u32 i = 0; i < n; i++) { u64 L = b->readOffset[i + 1] - b->readOffset[i]; if (L > maxL) maxL = (u32)L; }
+    const u64 *offs = b->readOffset;
+    if (base0) { c->rebased.resize((size_t)n + 1); for (u32 i = 0; i <= n; i++) c->rebased[i] = b->readOffset[i] - base0; offs = c->rebased.data(); }
     if (maxL > 2 * STARAMD_READ_LEN_MAX + 1) { g_err = "read longer than DEF_readSeqLengthMax"; return STARAMD_ERR_ARG; }
     u32 packWords = (maxL + 7) / 8;
     if ((u64)packWords * n > c->packWordsCap) {
         int rc = devRealloc(c->workAllocs, &c->dPacked, (u64)packWords * c->maxReads); if (rc) return rc;
         c->packWordsCap = (u32)std::min<u64>((u64)packWords * c->maxReads, 0xFFFFFFFFull);
     }
-    HIPCHK(hipMemcpyAsync(c->dBases, b->bases, b->readOffset[n], hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->dReadOffset, b->readOffset, (u64)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->dBases, b->bases + base0, nBases, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->dReadOffset, offs, (u64)(n + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->dMate1, b->mate1Length, (u64)n * 2, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->dMM, b->mmMaxTotal, (u64)n * 2, hipMemcpyHostToDevice, s));
     c->B.nReads = n; c->residentReads = n; c->residentMaxLread = maxL;

@@ -77,6 +77,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     auto publish = [&]() { if (report) *report = rep; };
     for (int i = 1; i < argc; i++) if (std::string(argv[i]) == "--version") { printf("2.7.11b\n"); return 0; }      // the version whose behaviour is reproduced (Parameters.cpp:340-343)
     CliFlags flags = splitFlags(argc, argv);
+    if (!getenv("STARAMD_SJDB_HOST")) sah_set_sjdb_device_fn(staramd_sjdb_insert, flags.devices.empty() ? 0 : flags.devices[0]);   // junction insertion on the device
     char err[4096];
     void *h = sah_create((int)flags.rest.size(), flags.rest.data(), err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }

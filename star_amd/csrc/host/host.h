@@ -13,6 +13,7 @@
 #include <istream>
 #include <string_view>
 #include "../../../include/star_amd.h"
+#include "../../../include/star_amd_index.h"
 
 namespace staramd {
 
@@ -232,6 +233,9 @@ void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci);            // sjdbLoa
 // sjdbInsertJunctions.cpp:11-102: rewrites gi (G, SA, SAi, junction table) and P.dev.winBinN; returns error text or ""
 std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, bool pass2, const std::string &pass1sjFile, std::string &log);
 std::string makeRunDir(const std::string &d, bool allRWX = false);
+// junction insertion on the device: the front end hands in staramd_sjdb_insert (include/star_amd_index.h); null = host restatement
+typedef int (*SjdbDeviceFn)(int device, const staramd_sjdb_args *a, staramd_sjdb_result *res);
+void setSjdbDeviceFn(SjdbDeviceFn fn, int device);
 // --sjdbGTFfile at the mapping stage (gtf.cpp): junctions of the annotation appended to `loci` with priority 20
 std::string loadGTFjunctions(const RunParams &P, const GenomeIndex &gi, SjdbLoci &loci, const std::string &dirOut, std::string &log);
 

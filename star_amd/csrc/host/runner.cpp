@@ -497,6 +497,9 @@ const staramd_params *sah_params(void *h) { return &((Runner *)h)->P.dev; }
 uint64_t sah_batch_reads(void *h) { return ((Runner *)h)->P.gpuBatchReads; }
 // --runMode genomeGenerate: sah_create has scanned the FASTA files; the caller builds SA + SAindex with staramd_index_build
 // (include/star_amd_index.h) into the buffers handed out here, then sah_generate_finish inserts the annotated junctions and writes genomeDir.
+// junction insertion (2-pass, --sjdbGTFfile / --sjdbFileChrStartEnd at the mapping stage, genomeGenerate with annotations) on the device:
+// fn = staramd_sjdb_insert of the engine library (include/star_amd_index.h); process-wide; NULL restores the host restatement
+void sah_set_sjdb_device_fn(int (*fn)(int, const staramd_sjdb_args *, staramd_sjdb_result *), int device) { staramd::setSjdbDeviceFn(fn, device); }
 int sah_generate_mode(void *h) { return ((Runner *)h)->generateMode ? 1 : 0; }
 int sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases, uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap) {
     Runner *r = (Runner *)h;

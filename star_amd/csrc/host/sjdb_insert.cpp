@@ -132,6 +132,11 @@ void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci) {
     }
 }
 
+// device junction insertion (include/star_amd_index.h staramd_sjdb_insert), handed in by the front end that links the engine: the host
+// library itself links no GPU code.  Null: the threaded host restatement below does the work.
+static SjdbDeviceFn g_sjdbDeviceFn = nullptr; static int g_sjdbDevice = 0;
+void setSjdbDeviceFn(SjdbDeviceFn fn, int device) { g_sjdbDeviceFn = fn; g_sjdbDevice = device; }
+
 void GenomeIndex::refreshView() {
     view.G = G.data(); view.nGenome = G.size();
     view.SA = SA.data(); view.SAi = SAi.data();
@@ -280,6 +285,43 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
         if (sjdbInd[isj] < 0) sjNew2++; else oldSJind[sjdbInd[isj]] = (uint32_t)isj1;
     }
     const uint64_t sjNew = sjNew2 / 2;
+    const uint64_t nGenomeNew = nGenomeReal + nGsj;
+    {
+        uint32_t bit1 = (uint32_t)std::floor(std::log((double)nGenomeNew) / std::log(2.0)) + 1;
+        if (bit1 < 32) bit1 = 32;
+        if (bit1 > V.GstrandBit)
+            return "EXITING because of FATAL ERROR: cannot insert junctions on the fly because of strand GstrandBit problem\nSOLUTION: please contact STAR author at https://groups.google.com/forum/#!forum/rna-star\n";
+    }
+    const uint32_t wSA = V.GstrandBit + 1;
+    std::vector<uint8_t> SA2v; uint64_t nSAnew = 0;
+    if (g_sjdbDeviceFn) {
+        // ---- on the device: search, sort, merge and SAindex (star_amd/csrc/index/sjdb_core.h)
+        std::vector<uint8_t> isOld(sjdbN);
+        for (uint64_t isj = 0; isj < sjdbN; isj++) isOld[isj] = sjdbInd[isj] >= 0;
+        uint64_t nInd = 0;
+        for (uint64_t isj = 0; isj < 2 * sjdbN; isj++) {
+            if (sjdbInd[isj] >= 0) continue;
+            const uint8_t *q = Gsj.data() + isj * sjdbLength;
+            for (uint64_t k = 0; k < sjdbLength; k++) nInd += q[k] < 4;
+        }
+        nSAnew = oldNSA + nInd;
+        SA2v.assign(Packed::lengthByte(nSAnew + 1, wSA) + 16, 0);
+        std::vector<uint8_t> SAiNew(gi.SAi.size() + 16, 0);
+        staramd_sjdb_args a; memset(&a, 0, sizeof(a));
+        a.G = gi.G.data(); a.nGenomeOld = oldNGenome; a.nGenomeReal = nGenomeReal;
+        a.SA = gi.SA.data(); a.nSAold = oldNSA; a.nSAbyteOld = V.nSAbyte; a.GstrandBit = V.GstrandBit; a.gSAindexNbases = V.gSAindexNbases;
+        a.Gsj = Gsj.data(); a.sjdbN = (uint32_t)sjdbN; a.sjdbLength = (uint32_t)sjdbLength;
+        a.isOld = isOld.data(); a.oldSJind = oldSJind.data(); a.oldSjdbN = (uint32_t)oldSjdbN; a.sjNew = sjNew;
+        a.SAout = SA2v.data(); a.saOutCapacity = SA2v.size(); a.SAiOut = SAiNew.data(); a.saiOutCapacity = SAiNew.size();
+        staramd_sjdb_result r;
+        int rc = g_sjdbDeviceFn(g_sjdbDevice, &a, &r);
+        if (rc) return "EXITING because of FATAL ERROR: junction insertion on the MI355X failed (code " + std::to_string(rc) + ")";
+        if (r.nInd != nInd || r.nSAibyte != V.nSAibyte) return "EXITING because of FATAL ERROR: junction insertion on the MI355X returned an index of unexpected size";
+        SAiNew.resize(gi.SAi.size());
+        gi.SAi.swap(SAiNew);
+        lap("device insert");
+        log += "   Finished SA search: number of new junctions=" + std::to_string(sjNew) + ", old junctions=" + std::to_string(sjdbN - sjNew) + "\n";
+    } else {
     typedef std::array<uint64_t, 2> T2;                                   // (insertion point in the old SA, offset in Gsj)
     std::vector<T2> ind;
     {
@@ -322,15 +364,8 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     lap("sort");
     const uint64_t nInd = ind.size();
     ind.push_back({(uint64_t)-999ll, (uint64_t)-999ll});                  // sentinel (:103-104)
-    const uint64_t nGenomeNew = nGenomeReal + nGsj, nSAnew = oldNSA + nInd;
-    {
-        uint32_t bit1 = (uint32_t)std::floor(std::log((double)nGenomeNew) / std::log(2.0)) + 1;
-        if (bit1 < 32) bit1 = 32;
-        if (bit1 > V.GstrandBit)
-            return "EXITING because of FATAL ERROR: cannot insert junctions on the fly because of strand GstrandBit problem\nSOLUTION: please contact STAR author at https://groups.google.com/forum/#!forum/rna-star\n";
-    }
-    const uint32_t wSA = V.GstrandBit + 1;
-    std::vector<uint8_t> SA2v(Packed::lengthByte(nSAnew + 1, wSA) + 8, 0);
+    nSAnew = oldNSA + nInd;
+    SA2v.assign(Packed::lengthByte(nSAnew + 1, wSA) + 8, 0);
     Packed SA2(SA2v.data(), wSA);
     const uint64_t nGsjNew = sjNew * sjdbLength, N2bit = 1ull << V.GstrandBit, strandMask = ~N2bit;
     {
@@ -436,11 +471,12 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
         }
     }
     lap("SAi");
+    }
     // ---------------- the index is now the new one
     gi.G.assign(nGenomeNew, 0);
     memcpy(gi.G.data(), G, nGenomeReal);
     memcpy(gi.G.data() + nGenomeReal, Gsj.data(), nGsj);
-    SA2.put(nSAnew, 0);                                                    // sjdbInsertJunctions.cpp:66-68
+    { Packed SA2f(SA2v.data(), wSA); SA2f.put(nSAnew, 0); }                // sjdbInsertJunctions.cpp:66-68
     SA2v.resize(Packed::lengthByte(nSAnew, wSA) + 8);
     gi.SA.swap(SA2v);
     gi.sjdbStart.swap(nStart); gi.sjdbEnd.swap(nEnd); gi.sjdbMotif.swap(nMotif); gi.sjdbShiftLeft.swap(nShL); gi.sjdbShiftRight.swap(nShR); gi.sjdbStrand.swap(nStrand);

@@ -28,13 +28,15 @@ MULTI = [(CASES[0][0], CASES[0][1], 150, "0,1"), (CASES[1][0], CASES[1][1], 120,
 
 @pytest.mark.parametrize("name,more,batch,devices", MULTI)
 def test_cli_pipeline_multi_device(name, more, batch, devices, tmp_path, built):
-    test_cli_pipeline(name, more + ["--gpuDevices", devices], batch, tmp_path, built)
+    run_cli_case(CLI, name, more + ["--gpuDevices", devices], batch, tmp_path)
 
 
-@pytest.mark.parametrize("name,more,batch", CASES)
-def test_cli_pipeline(name, more, batch, tmp_path, built):
+def run_cli_case(cli, name, more, batch, tmp_path, fastq_hook=None):
+    """one run of a command-line front end (`cli`) against one run of the reference with the same flags: every output file"""
     info = dict(prepare(name, str(tmp_path), need_ref=False))
     d = os.path.dirname(info["fastq"][0])
+    if fastq_hook:
+        info["fastq"] = fastq_hook(info, d)
     if "VCF" in more:
         from test_wasp import _vcf
         more = [_vcf(info, d) if x == "VCF" else x for x in more]
@@ -43,10 +45,14 @@ def test_cli_pipeline(name, more, batch, tmp_path, built):
     if "--gpuDevices" in more:
         i = more.index("--gpuDevices"); cli_only = more[i:i + 2]; more = more[:i] + more[i + 2:]
     flags = list(info["extra"]) + more
-    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=flags)
+    rf = list(flags)
+    if "--runThreadN" in rf:
+        k = rf.index("--runThreadN"); del rf[k:k + 2]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=rf)
     new = os.path.join(d, "cli_")
-    subprocess.check_call([CLI, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] +
-                          ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + flags + cli_only, stderr=subprocess.DEVNULL)
+    p = subprocess.run([cli, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] +
+                       ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + rf + cli_only, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-1500:]
     n = 0
     for f in sorted(os.listdir(d)):
         if not f.startswith("ref_") or os.path.isdir(os.path.join(d, f)):
@@ -69,3 +75,8 @@ def test_cli_pipeline(name, more, batch, tmp_path, built):
         n += 1
     assert n >= 2
     assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(new + "Log.final.out")
+
+
+@pytest.mark.parametrize("name,more,batch", CASES)
+def test_cli_pipeline(name, more, batch, tmp_path, built):
+    run_cli_case(CLI, name, more, batch, tmp_path)

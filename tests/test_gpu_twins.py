@@ -1,0 +1,58 @@
+"""GPU twins of the host-side features that feed EXTRA batches or unusual reads through the hot path: every case runs the shipped
+binary (star_amd/bin/star_amd, HIP engine) against one run of the reference with the same flags and compares every output file.
+
+  merged mates      --peOverlapNbasesMin: the overlapping pairs of a batch, merged into single-end reads, are a second engine batch under
+                    PE parameters (ReadAlign_peOverlapMergeMap.cpp:31 re-enters mapOneRead)
+  clipped reads     --clip*: the device maps the shorter reads, among them 0-length mates and mates shorter than a seed
+  WASP              --waspOutputMode: allele-swapped copies re-mapped as one more batch (ReadAlign_waspMap.cpp:78), here with a batch
+                    size small enough that the re-mapping batch goes through the engine in pieces
+  phases            2-pass (index replaced in HBM), BySJout (whitelist), chimeric detection (every window returned)
+  two contexts      --gpuDevices 0,0: two mapper threads with their own engine contexts on the one GPU of the test box
+"""
+import os
+
+import pytest
+
+import test_cli_pipeline as tcp
+import test_pe_overlap as tpo
+import test_clipping as tcl
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not tcp.refstar.have_ref(), reason="oracle/_ref/STAR not built")]
+GPU_CLI = os.path.join(tcp.ROOT, "star_amd", "bin", "star_amd")
+
+
+@pytest.mark.parametrize("name,more,batch", tcp.CASES)
+def test_cli_cases_on_gpu(name, more, batch, tmp_path, built):
+    tcp.run_cli_case(GPU_CLI, name, more, batch, tmp_path)
+
+
+@pytest.mark.parametrize("name,more,batch,devices", [(c[0], c[1], c[2], "0,0") for c in tcp.MULTI[:3]])
+def test_two_contexts_on_one_gpu(name, more, batch, devices, tmp_path, built):
+    tcp.run_cli_case(GPU_CLI, name, more + ["--gpuDevices", devices], batch, tmp_path)
+
+
+@pytest.mark.parametrize("name,more", tpo.CASES + tpo.CHIM)
+def test_merged_mates_on_gpu(name, more, tmp_path, built):
+    tcp.run_cli_case(GPU_CLI, name, more, 600, tmp_path)
+
+
+def test_merged_chimeric_fragments_on_gpu(tmp_path, built):
+    flags = ["--peOverlapNbasesMin", "10", "--peOverlapMMp", "0.1", "--chimSegmentMin", "12", "--chimJunctionOverhangMin", "10", "--chimMultimapNmax", "10", "--chimMultimapScoreRange", "3",
+             "--chimNonchimScoreDropMin", "15", "--chimScoreDropMax", "80", "--chimSegmentReadGapMax", "5", "--outSAMunmapped", "Within"]
+    tcp.run_cli_case(GPU_CLI, "pe101", flags, 700, tmp_path, fastq_hook=lambda info, d: tpo._chimeric_fragments(info, d))
+
+
+@pytest.mark.parametrize("tag", sorted(tcl.PE))
+def test_clipped_pairs_on_gpu(tag, tmp_path, built):
+    """adapters at every position incl. position 0: 0-length mates and mates shorter than seedSplitMin reach the device"""
+    tcp.run_cli_case(GPU_CLI, "pe101", tcl.PE[tag], 500, tmp_path, fastq_hook=lambda info, d: tcl._with_adapters(info["fastq"], d, (tcl.AD1, tcl.AD2), zero_len=True))
+
+
+@pytest.mark.parametrize("tag", sorted(tcl.SE))
+def test_clipped_single_on_gpu(tag, tmp_path, built):
+    tcp.run_cli_case(GPU_CLI, "se50", tcl.SE[tag], 500, tmp_path, fastq_hook=lambda info, d: tcl._with_adapters(info["fastq"], d, (tcl.AD1,), zero_len=True))
+
+
+def test_wasp_in_pieces_on_gpu(tmp_path, built):
+    """batch of 150 reads: the WASP re-mapping batch (several copies per read) is larger than the context and goes through in rebased pieces"""
+    tcp.run_cli_case(GPU_CLI, "pe101", ["--waspOutputMode", "SAMtag", "--varVCFfile", "VCF", "--outSAMtype", "BAM", "Unsorted", "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG", "vW"], 150, tmp_path)
