@@ -10,7 +10,8 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -pthread
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
 # k_stitch_win is 168 VGPRs at 3 waves/SIMD with spills: without loop unrolling it spills 9 registers instead of 26 and is 3 % faster
 # (measured, same box: 163.7 -> 158.4 ms); the other kernels keep the default
-STITCH_FLAGS := -fno-unroll-loops
+STITCH_WAVES ?= 3
+STITCH_FLAGS := -fno-unroll-loops -DSTITCH_WAVES=$(STITCH_WAVES)
 
 # $(call build_engine,<variant>,<extra defines>): every .hip file to its own object (in parallel), then one shared library
 define build_engine

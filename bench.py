@@ -184,7 +184,7 @@ class CliHooks(C.Structure):
 class CliReport(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("wallMapping", C.c_double), ("timedReads", C.c_uint64), ("timedWall", C.c_double),
                 ("genomeLoadSeconds", C.c_double), ("indexUploadSeconds", C.c_double), ("nDevices", C.c_int),
-                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 24),
+                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 40),
                 ("parseBusy", C.c_double), ("emitBusy", C.c_double), ("batches", C.c_uint64), ("pass1Seconds", C.c_double)]
 
 
@@ -220,6 +220,12 @@ def report_dict(rep, lread):
     bytes_win = 8 * c["nSAenum"] + 24 * c["nSeeds"] + 24 * c["nWA"]
     bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + (lread // 2) * (c["nWindows"] if c["nWindows"] else n) + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
     kern = {"k_seed_search": (ms["k_seed_search"], bytes_seed / nb), "k_windows": (ms["k_windows"], bytes_win / nb), "k_stitch_win": (ms["k_stitch_win"], bytes_stitch / nb)}
+    if os.environ.get("STARAMD_PROFILE_BUILD"):          # libstaramd.so built with -DSTARAMD_PROFILE: shader-clock cycles per section, summed over waves
+        pn = ["walk(all)", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime", "windows:passA", "windows:flanks", "windows:passB_enumerate+owner",
+              "windows:passB_assign", "windows:emission", "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
+        raw = [int(x) for x in rep.counters]
+        c["profile_cycles_per_pair"] = dict(zip(pn, [v / n for v in raw[21:37]]))
+        c["profile_counts_per_pair"] = dict(zip(["nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"], [v / n for v in raw[8:12]]))
     return c, ms, kern, (bytes_seed + bytes_win + bytes_stitch) / n
 
 
@@ -430,7 +436,7 @@ def main():
                      "traffic": traffic, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
                      "algorithmic_bytes_per_pair_whole_path": bytes_per_pair,
                      "note": "per launch = per batch of %d pairs, averaged over the %d timed batches of rank 0 (HIP events on the engine's stream)" % (args.reads, int(rep.batches))},
-        "counters_per_pair": {k: v / n for k, v in c.items()},
+        "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
         "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s": device_s, "device_resident_Mreads_s": n / device_s / 1e6 if device_s > 0 else None,
                      "cli_over_device": device_s / float(rep.timedWall) if rep.timedWall > 0 else None,
                      "map_batch_call_s": float(rep.deviceBusy[0]), "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),

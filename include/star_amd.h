@@ -149,7 +149,8 @@ typedef struct staramd_read_result {
     uint32_t nTr;             /* total transcripts over those windows                                    */
     uint32_t trOffset;        /* first transcript of this read in staramd_results.tr                     */
     int32_t  trBest;          /* index (relative to trOffset) of trBest, -1 if none                      */
-    int32_t  maxScoreMate[2];
+    int32_t  maxScoreMate[2]; /* resultSelect 0: exactly ReadAlign::maxScoreMate[]; resultSelect 1: over the windows that were walked (a lower
+                               * bound: windows that cannot hold a selectable transcript are skipped).  Nothing outside the hot path reads it. */
     uint32_t unmappedLength;  /* trBest->rLength of the unmapped classifications (mapOneRead.cpp:100-111) */
 } staramd_read_result;
 

@@ -50,16 +50,18 @@ struct DSeed { u64 saStart; u32 nrep; u16 rStart, L; u8 dir, iFrag; u8 pad[6]; }
 // one row of the reference's WA table (IncludeDefine.h:197-204)
 struct DWA { u64 gStart; u32 nrep; u16 L, rStart; i32 sjA; u8 anchor, iFrag; u8 pad[2]; };
 // window with seeds, output of the window kernel
-struct DWin { u32 read; u32 chr; u32 waOffset; u16 nWA; u8 str; u8 pad; };
+struct DWin { u32 read; u32 chr; u32 waOffset; u16 nWA; u8 str; u8 mates; };   // mates: bit f set = the window holds seeds of mate f
 
 // per-read bookkeeping carried between kernels
 struct DRead {
     u32 status; u32 seedOffset; u32 nSeeds; u32 unmappedLength;
     u32 winOffset; u32 nWin;            // windows with seeds (window pool)
-    u32 wtOffset; u32 nWt;              // nWt: windows that recorded transcripts (wtOffset unused)
+    u32 wtOffset; u32 nWt;              // wtOffset: largest seed count among the read's windows (k_windows); nWt: windows that recorded transcripts
     i32 maxScoreMate[2];
     i32 bestW;                          // ordinal of trBest's window among recorded windows, -1
     u32 nTr, nEx;                       // totals for the gather step
+    i32 pruneBest;                      // best window score seen so far among the read's window items (k_stitch_win window pruning; atomicMax)
+    u32 pad0;
 };
 
 // result of stitching one window (slot = index of the window in winPool)
@@ -77,6 +79,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_shadowBad, DC_shadowN, DC_shadowExtBad, DC_shadowExtN,   // shadow-validation build only (see stitch_scalar.h)
        DC_prof0, DC_prof1, DC_prof2, DC_prof3, DC_prof4, DC_prof5, DC_prof6, DC_prof7,   // -DSTARAMD_PROFILE build: shader-clock cycles per section of k_stitch_win
        DC_prof8, DC_prof9, DC_prof10, DC_prof11, DC_prof12, DC_prof13, DC_prof14, DC_prof15,
+       DC_nPrunedWin,                                                  // windows not walked because no transcript of theirs could be selected (k_stitch_win)
        DC_N };
 
 // cursors[] slots
@@ -86,6 +89,7 @@ enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS 
        CUR_ST_TICKET0 = 16, CUR_ITEM = 25,                               // pass 0: all work items (reads or windows)
        CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
        CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
+       CUR_ST_HEAVY = 23, CUR_ST_TICKETH = 24,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
        CUR_N = 32 };
 // CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
 enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };
@@ -106,7 +110,9 @@ struct DevBatch {
     u32 *items; u8 *itemClass;   // winCap entries; itemClass ~ log2(estimated walk size)
     u32 *ovfWin;       // reads deferred to the big-work-space pass of k_windows
     u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
+    u32 *heavyList;                    // pass-0 items whose windows hold more seeds than the lean launch has LDS for
     u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win
+    u32 *candTops;                     // bytes of its region a wavefront of the first pass-0 launch used (the second one goes on behind them)
     u32 *cursors;      // CUR_*
     u64 *counters;     // DC_N
 };

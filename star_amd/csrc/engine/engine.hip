@@ -15,7 +15,7 @@ extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch,
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
-extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords, u32 mode);
+extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords, u32 mode, u32 pruneEnable);
 extern "C" __global__ void k_stitch_replay(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords);
 extern "C" __global__ void k_stitch_verify(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_stitch_finish(const DevIndex *X, DevBatch B);
@@ -25,8 +25,9 @@ extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *ex
                                     staramd_transcript *outTr, u32 outTrCap, staramd_exon *outEx, u32 outExCap);
 
 // per-lane / per-wave work-space sizes (same formulas as the kernels)
+static inline u32 waRowsH(u32 capDepth) { return capDepth == 0 ? (u32)WA_MAX : std::min<u32>(capDepth - 1u, (u32)WA_MAX); }
 static inline u32 stitchStateBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_MAX * 24u + WA_MAX * 8u + arenaBytes;
+    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + waRowsH(capDepth) * 32u + arenaBytes;
     return (b + 127u) & ~127u;
 }
 static inline u64 winWaveBytesH(u32 capW, u32 capBlocks, u32 big) {
@@ -60,6 +61,9 @@ struct staramd_ctx {
     u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
     u32 stBlocks = 0, stBlocksBig = 0, replayBlocks = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
     u32 capDepth = 0, capRank = 0, arenaFast = 0, arenaBig = 0, ldsWordsCap = 0;
+    // lean pass-0 launch: windows of at most leanDepth-1 seeds (almost all) walked with a small LDS slice per wavefront, so that more
+    // wavefronts are resident per CU; the others are handed to a second launch with the full-size slice (0 = one full-size launch)
+    u32 leanDepth = 0, leanArena = 0, stBlocksLean = 0;
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
@@ -196,6 +200,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.order, (u64)B.winCap + 64))) return rc;
     if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.replayList, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.heavyList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.trPool, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
     if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
@@ -250,11 +255,24 @@ static int allocWork(staramd_ctx *c) {
         c->replayBlocks = (u32)c->nCU * envU32("STARAMD_REPLAY_BLOCKS_PER_CU", (u32)std::min(rpPerCU, 8));
         if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_replay %d blocks/CU (LDS %zu B/block)\n", rpPerCU, ldsReplay);
     }
-    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)std::max(c->stBlocks, c->replayBlocks) * 4 * c->arenaBig))) return rc;
+    // lean launch geometry
+    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 9); c->leanArena = envU32("STARAMD_LEAN_ARENA", 2048) & ~31u;
+    if (c->leanDepth >= c->capDepth) c->leanDepth = 0;
+    c->stBlocksLean = 0;
+    if (c->leanDepth) {
+        int lpCU = stPerCU;
+        size_t ldsLean = 4 * (size_t)(stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena) + 27 * 4 + 16);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lpCU, k_stitch_win, 256, ldsLean) != hipSuccess || lpCU < 1) lpCU = stPerCU;
+        c->stBlocksLean = (u32)c->nCU * envU32("STARAMD_LEAN_BLOCKS_PER_CU", (u32)lpCU);
+        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win lean launch: depth %u, arena %u B, %d blocks/CU (LDS %zu B/block)\n", c->leanDepth, c->leanArena, lpCU, ldsLean);
+    }
+    const u32 maxStBlocks = std::max(std::max(c->stBlocks, c->stBlocksLean), c->replayBlocks);
+    if ((rc = devAlloc(R, &c->scrStitchBig, (u64)maxStBlocks * 4 * c->arenaBig))) return rc;
     // candidate logs: one private region per wavefront; sized so that a wavefront's share of a full batch fits
     B.candWaveBytes = ((u64)envU32("STARAMD_CAND_KB_PER_WAVE", 0) * 1024) & ~31ull;
     if (B.candWaveBytes == 0) { u64 per = (u64)N * 6144 / ((u64)c->stBlocks * 4) + 262144; B.candWaveBytes = std::min<u64>(per, 0xFFFF0000ull) & ~31ull; }
-    if ((rc = devAlloc(R, &B.candPool, (u64)c->stBlocks * 4 * B.candWaveBytes))) return rc;
+    if ((rc = devAlloc(R, &B.candPool, (u64)std::max(c->stBlocks, c->stBlocksLean) * 4 * B.candWaveBytes))) return rc;
+    if ((rc = devAlloc(R, &B.candTops, (u64)maxStBlocks * 4 + 64))) return rc;
     return 0;
 }
 
@@ -328,6 +346,7 @@ static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
         if ((rc = devRealloc(R, &B.order, (u64)B.winCap + 64))) return rc;
         if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.heavyList, (u64)B.winCap))) return rc;
     }
     if (flags & OVF_TRPOOL) {
         B.trCap = grow(B.trCap, cur[CUR_TR]); B.exCap = grow(B.exCap, cur[CUR_EX]);
@@ -345,6 +364,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipMemsetAsync(B.cursors, 0, CUR_N * sizeof(u32), s));
     HIPCHK(hipMemsetAsync(B.counters, 0, DC_N * sizeof(u64), s));
     HIPCHK(hipMemsetAsync(B.costHist, 0, 64 * sizeof(u32), s));
+    HIPCHK(hipMemsetAsync(B.candTops, 0, ((size_t)std::max(std::max(c->stBlocks, c->stBlocksLean), c->replayBlocks) * 4 + 64) * sizeof(u32), s));
     dim3 block(256);
     u32 ldsWords = ((c->residentMaxLread + 7) / 8) | 1u;              // odd stride: conflict-free LDS staging
     HIPCHK(hipEventRecord(c->ev[0], s));
@@ -366,8 +386,14 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     {
         size_t readBytes = (ldsWords * 4u + 15u) & ~15u;
         size_t ldsFast = 4 * (readBytes + stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast));
+        const u32 prune = envU32("STARAMD_PRUNE", 1);
+        size_t ldsLean = c->leanDepth ? 4 * (readBytes + stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena)) : 0;
         for (u32 mode = 0; mode < 2; mode++) {
-            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, mode);
+            if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest
+                hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksLean), block, ldsLean, s, c->dX, B, c->scrStitchBig, c->leanDepth, c->capRank, c->leanArena, c->arenaBig, ldsWords, 0u, prune);
+                hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
+            } else
+            hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, mode, prune);
             if (mode == 0) HIPCHK(hipEventRecord(c->ev[6], s));
             if (mode == 0) {
                 hipLaunchKernelGGL(k_stitch_verify, dim3((n + 255) / 256), block, 0, s, c->dX, B);

@@ -249,7 +249,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search(const DevInde
         }
         // classification, ReadAlign_mapOneRead.cpp:100-115
         DRead rd;
-        rd.status = 0; rd.seedOffset = 0; rd.nSeeds = 0; rd.unmappedLength = 0; rd.winOffset = 0; rd.nWin = 0; rd.wtOffset = 0; rd.nWt = 0;
+        rd.status = 0; rd.seedOffset = 0; rd.nSeeds = 0; rd.unmappedLength = 0; rd.winOffset = 0; rd.nWin = 0; rd.wtOffset = 0; rd.nWt = 0; rd.pruneBest = 0; rd.pad0 = 0;
         rd.maxScoreMate[0] = rd.maxScoreMate[1] = 0; rd.bestW = -1; rd.nTr = 0; rd.nEx = 0;
         nSeedsTot += st.nP;
         if (st.fatal) rd.status |= STARAMD_ST_FATAL_SEEDS_PER_READ;

@@ -724,10 +724,10 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
 }
 
 // per-window LDS work space, in bytes: undo stack, exon rows, leaf copy, rank list, seed list (+ arena in the fast path)
-#define WA_LDS_BYTES (WA_MAX * 24u)
-#define COMPAT_LDS_BYTES (WA_MAX * 8u)              // u64 compat[WA_MAX]: which later seeds can follow seed A at all
+// seed list rows (24 B) and compat masks (8 B): as many as the launch walks at most (capDepth - 1 seeds per window), never more than WA_MAX
+__host__ __device__ inline u32 waRows(u32 capDepth) { return capDepth == 0 ? (u32)WA_MAX : (capDepth - 1u < (u32)WA_MAX ? capDepth - 1u : (u32)WA_MAX); }
 __host__ __device__ inline u32 stitchStateBytes(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + WA_LDS_BYTES + COMPAT_LDS_BYTES + arenaBytes;
+    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + waRows(capDepth) * 32u + arenaBytes;
     return (b + 127u) & ~127u;
 }
 
@@ -881,8 +881,8 @@ __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRan
     m.LEAF = m.EX + STARAMD_MAX_N_EXONS;
     m.rank = (LDS u16 *)(m.LEAF + STARAMD_MAX_N_EXONS);
     m.WA = (LDS DWA *)((LDS u8 *)m.rank + ((capRank * 2u + 31u) & ~31u));
-    m.compat = (LDS u64 *)((LDS u8 *)m.WA + WA_LDS_BYTES);
-    m.arena = (LDS u8 *)m.compat + COMPAT_LDS_BYTES;
+    m.compat = (LDS u64 *)((LDS u8 *)m.WA + waRows(capDepth) * 24u);
+    m.arena = (LDS u8 *)m.compat + waRows(capDepth) * 8u;
 }
 
 __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
@@ -905,8 +905,11 @@ __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBat
 // the windows whose decisions could differ.  mode: 0 = pass 0, 1 = pass 1.
 // A window whose recorded transcripts outgrow the LDS arena is walked again at once by the same wavefront with its
 // arena in global memory (bigArena: one worst-case arena per wavefront).
-extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
-                                                             u32 bigArenaBytes, u32 ldsWords, u32 mode) {
+#ifndef STITCH_WAVES
+#define STITCH_WAVES 3      // minimum waves per SIMD the register allocation of the walk kernel is held to (Makefile: STITCH_WAVES)
+#endif
+extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
+                                                             u32 bigArenaBytes, u32 ldsWords, u32 mode, u32 pruneEnable) {
     if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
@@ -924,13 +927,31 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
     const u32 waveId = blockIdx.x * wavesPerBlock + waveInBlock;
     WinRec wr; wr.rank = m.rank; wr.arenaL = m.arena; wr.arenaBytesL = arenaBytes; wr.arenaG = bigArena + (u64)waveId * bigArenaBytes; wr.arenaBytesG = bigArenaBytes;
     gcInit(c.ca); gcInit(c.cb);
-    c.candBase = B.candPool + (u64)waveId * B.candWaveBytes; c.candTop = 0; c.candCap = (u32)B.candWaveBytes; c.nCand = 0; c.logOn = mode == 0; c.logOvf = false;
+    // mode 0: pass 0 over every item; mode 2: pass 0 over the items the lean-LDS launch (mode 0 with a small capDepth) handed on;
+    // mode 1: pass 1, full re-walk of the windows on the redo list
+    const bool pass0 = mode != 1;
+    c.candBase = B.candPool + (u64)waveId * B.candWaveBytes; c.candTop = 0; c.candCap = (u32)B.candWaveBytes; c.nCand = 0; c.logOn = pass0; c.logOvf = false;
+    if (mode == 2) {               // the log region of a wavefront is shared by the two pass-0 launches: go on behind what the lean launch wrote
+        c.candTop = (u32)B.candTops[waveId];
+    }
     // break points of the genomic-length score term: lane k keeps points k and k+64 in registers for the whole kernel
     const u64 glb0 = lane < X.nBreak ? X.glBreak[lane] : ~0ull, glb1 = lane + 64u < X.nBreak ? X.glBreak[lane + 64u] : ~0ull;
     const u32 *list; u32 nItems, ticketSlot;
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_ITEM] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
+    else if (mode == 2) { list = B.heavyList; nItems = B.cursors[CUR_ST_HEAVY]; ticketSlot = CUR_ST_TICKETH; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
-    u32 nOvf = 0, lastRead = 0xFFFFFFFFu;
+    u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0;
+    // ---- window pruning (ours; exact for what is returned under resultSelect == 1).  multMapSelect only ever picks transcripts with
+    // maxScore >= trBest->maxScore - outFilterMultimapScoreRange (ReadAlign_multMapSelect.cpp:26-44).  The score of a transcript is bounded by
+    // the lengths of the mates whose seeds its window holds plus perJ per junction (perJ = the positive part of the junction scores), so once
+    // some window of the read has recorded a score `best`, a window with  bound + range + perJ * (MAX_N_EXONS - 1) < best  cannot contribute
+    // a selected transcript and is not walked.  What the skipped windows would have done to maxScoreMate[] (stitchWindowAligns.cpp:232-247)
+    // only moves record decisions of single-mate transcripts, all of which are below the selection threshold by the extra perJ term and cannot
+    // cover (and so remove, :267-285) a two-mate transcript.  Off when every transcript is wanted (resultSelect == 0: chimeric detection,
+    // merged mates), with a positive genomic-length term or positive indel scores, and for reads that could reach alignTranscriptsPerReadNmax.
+    const i32 perJ = max(0, P.sjdbScore) + max(0, max(max(P.scoreGap, P.scoreGapNoncan), max(P.scoreGapGCAG, P.scoreGapATAC)));
+    const bool pruneOn = pass0 && P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && pruneEnable != 0
+                         && P.scoreDelOpen <= 0 && P.scoreDelBase <= 0 && P.scoreInsOpen <= 0 && P.scoreInsBase <= 0;
 #ifdef STARAMD_PROFILE
     for (int k = 0; k < 16; k++) c.prof[k] = 0;
     const u64 profKernelStart = __builtin_readcyclecounter();
@@ -946,12 +967,32 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
         const bool wholeRead = (item & 0x80000000u) != 0;
         u32 w0 = item, nWin = 1;
         i32 carry[2] = {0, 0};
-        if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; }
+        u32 maxSeeds; i32 bestSoFar = 0; u32 nWinRead = 0;
+        if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; maxSeeds = rd.wtOffset; nWinRead = rd.nWin; }
+        else maxSeeds = first32(B.winPool[item].nWA);
+        if (mode == 0 && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {       // more seeds than this (lean) launch has LDS rows for: the full-size launch takes the item
+            if (lane == 0) { u32 k = atomicAdd(&B.cursors[CUR_ST_HEAVY], 1u); B.heavyList[k] = item; }
+            continue;
+        }
         for (u32 iw = 0; iw < nWin; iw++) {
             const u32 w = w0 + iw;
             const DWin win = uni(B.winPool[w]);
             if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
             if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+            if (pruneOn && win.mates != 0) {
+                if (!wholeRead) { nWinRead = first32(B.reads[win.read].nWin); bestSoFar = firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+                const i32 bound = (i32)((win.mates & 1u) ? c.readLength[0] : 0u) + (i32)((win.mates & 2u) ? c.readLength[1] : 0u) + perJ * ((i32)win.nWA - 1);
+                if ((u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax
+                    && bound + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1) < bestSoFar) {
+                    if (lane == 0) {
+                        DWinOut z; z.trOffset = z.nTr = z.exOffset = z.nEx = 0; z.mm[0] = z.mm[1] = 0; z.sens[0] = z.sens[1] = 0x7FFFFFFF; z.minIn[0] = z.minIn[1] = 0;
+                        z.headScore = 0; z.candOff32 = 0; z.headGlen = 0; z.nCand = 0; z.pad = 0;
+                        B.wout[w] = z;
+                    }
+                    nPruned++;
+                    continue;
+                }
+            }
             {   // stage the window's seed list in LDS (6 dwords per row)
                 const u32 *src = (const u32 *)(B.waPool + win.waOffset); LDS u32 *dst = (LDS u32 *)m.WA;
                 for (u32 k = lane; k < win.nWA * 6u; k += NLANE) dst[k] = src[k];
@@ -959,8 +1000,8 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
             }
             DWinOut o;
             if (wholeRead) { o.minIn[0] = carry[0]; o.minIn[1] = carry[1]; }
-            else { o = uni(B.wout[w]); if (mode == 0) { o.minIn[0] = o.minIn[1] = 0; } }
-            c.logOn = mode == 0 && !wholeRead;
+            else { o = uni(B.wout[w]); if (pass0) { o.minIn[0] = o.minIn[1] = 0; } }
+            c.logOn = pass0 && !wholeRead;
             const u32 candStart = c.candTop;
             bool ok = false;
             for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {         // 2nd attempt: same walk, record arena in HBM
@@ -975,6 +1016,10 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
             if (!flushWindow(B, lane, wr, o)) continue;
             o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
             carry[0] = c.maxScoreMate[0]; carry[1] = c.maxScoreMate[1];
+            if (pruneOn && o.headScore > 0) {              // the window recorded a transcript of this score: later windows are measured against it
+                if (wholeRead) bestSoFar = max(bestSoFar, o.headScore);
+                else if (lane == 0) atomicMax(&B.reads[win.read].pruneBest, o.headScore);
+            }
             // the incoming maxScoreMate of a whole-read item is exact: its result is final
             o.sens[0] = wholeRead ? 0x7FFFFFFF : c.sens[0]; o.sens[1] = wholeRead ? 0x7FFFFFFF : c.sens[1];
             // keep the candidate log only if some decision of this window depends on the incoming maxScoreMate
@@ -988,12 +1033,14 @@ extern "C" __global__ void __launch_bounds__(256, 3) k_stitch_win(const DevIndex
         }
     }
     if (lane == 0) {
+        if (mode == 0) B.candTops[waveId] = c.candTop;
         atomicAdd((unsigned long long *)&B.counters[DC_nGstitch], (unsigned long long)c.nGstitch);
         atomicAdd((unsigned long long *)&B.counters[DC_nStitchCalls], (unsigned long long)c.nStitchCalls);
         atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);
         atomicAdd((unsigned long long *)&B.counters[DC_nNodes], (unsigned long long)c.nNodes);
         atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
+        if (nPruned) atomicAdd((unsigned long long *)&B.counters[DC_nPrunedWin], (unsigned long long)nPruned);
 #ifdef STARAMD_PROFILE
         c.prof[7] = __builtin_readcyclecounter() - profKernelStart;      // whole wave life time
         for (int k = 0; k < 16; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);

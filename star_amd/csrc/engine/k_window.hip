@@ -357,9 +357,10 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
         }
         if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
         // ---- emit windows that hold seeds, in window order
-        u32 nOut = 0, nWA = 0; u32 est = 0;
-        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 20u); } }
-        for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); est += (u32)__shfl_xor((int)est, o, 64); }
+        u32 nOut = 0, nWA = 0; u32 est = 0, nMax = 0;
+        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 20u); nMax = max(nMax, n); } }
+        for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); est += (u32)__shfl_xor((int)est, o, 64); nMax = max(nMax, (u32)__shfl_xor((int)nMax, o, 64)); }
+        rd.wtOffset = nMax;
         if (nOut > 0) {
             // stitch work items: a light read (its walks are bounded by est = sum over windows of 2^seeds) is ONE item -- its
             // windows are walked in order by one wavefront, so maxScoreMate is carried exactly and nothing has to be
@@ -376,12 +377,14 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                 u32 n = s.t.nwa[j];
                 if (n == 0) continue;
                 u32 m = s.t.meta[j];
+                const DWA *A = s.arena + (u64)s.t.blk[j] * WA_MAX;
+                u8 fr = 0;
+                if (lane < n) { const DWA row = A[lane]; fr = row.iFrag; B.waPool[ao + lane] = row; }
+                const u8 mates = (u8)((__ballot(lane < n && fr == 0) ? 1u : 0u) | (__ballot(lane < n && fr != 0) ? 2u : 0u));
                 if (lane == 0) {
-                    DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.pad = 0; B.winPool[wo] = d;
+                    DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.mates = mates; B.winPool[wo] = d;
                     if (!light) { B.items[io] = wo; B.itemClass[io] = (u8)min(n + 1u, 31u); io++; }
                 }
-                const DWA *A = s.arena + (u64)s.t.blk[j] * WA_MAX;
-                if (lane < n) B.waPool[ao + lane] = A[lane];
                 wo++; ao += n;
             }
             nWAtot += nWA;

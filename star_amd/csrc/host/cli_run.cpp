@@ -187,7 +187,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
             while (parsed.pop(m)) {
                 int rc = 0;
                 if (!failed.load()) {
-                    auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[24] = {0};
+                    auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[40] = {0};
                     auto mapInto = [&](const staramd_batch &bt, ResBuf &r, bool main) {
                         if (r.reads.size() < bt.nReads || r.tr.empty()) r.size(std::max<uint64_t>(bt.nReads, 1024));
                         staramd_results &res = r.res;
@@ -198,7 +198,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                         }
                         if (!e) {
                             msDev += res.msTotalDevice;
-                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 7); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[24] = {0}; int kc = staramd_get_counters(ctx[d], c, 24); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
+                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 7); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[40] = {0}; int kc = staramd_get_counters(ctx[d], c, 40); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
                         }
                         return e;
                     };
@@ -240,7 +240,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                     if (rc) fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error());
                     std::lock_guard<std::mutex> l(statM);
                     msDeviceAll += msDev;
-                    if (timedOn && !rc) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += msDev; for (int i = 0; i < 8; i++) rep.stageMs[i] += stage[i]; for (int i = 0; i < 24; i++) rep.counters[i] += cnt[i]; }
+                    if (timedOn && !rc) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += msDev; for (int i = 0; i < 8; i++) rep.stageMs[i] += stage[i]; for (int i = 0; i < 40; i++) rep.counters[i] += cnt[i]; }
                 }
                 if (failed.load()) m.n = 0;                              // still goes through the writer so that the slot and the sequence number are released
                 { std::lock_guard<std::mutex> l(doneM); done[m.seq] = m; }
