@@ -734,14 +734,18 @@ static void quantTranscriptome(const RunParams &P, const GenomeIndex &gi, const 
             uint64_t nMM1 = 0;
             const uint8_t *rd = b.bases.data() + b.readOffset[ir];
             auto R = [&](uint64_t p) -> uint8_t { uint8_t c = t.roStr == 0 ? rd[p] : rd[Lread - 1 - p]; return (t.roStr != 0 && c < 4) ? (uint8_t)(3 - c) : c; };
+            // the reference's G sits inside G1 with spacer padding either side (Genome_genomeLoad.cpp:27,320-323): a soft clip that hangs over
+            // an end of the genome array compares against the padding code there
+            const uint64_t nG = gi.view.nGenome;
+            auto GG = [&](uint64_t p) -> uint8_t { return p < nG ? gi.G[p] : (uint8_t)5; };      // p - k below base 0 wraps to a huge value: padding
             for (uint32_t iab = 0; iab < g.nExons; iab++) {
                 uint64_t left1 = 0, right1 = 0;
                 if (iab == 0) left1 = g.ex[iab].R;
                 else if (g.ex[iab - 1].canonSJ == -3) left1 = g.ex[iab].R - rc.readLength[g.ex[iab - 1].iFrag] - 1;
                 if (iab == g.nExons - 1) right1 = Lread - g.ex[iab].R - g.ex[iab].L;
                 else if (g.ex[iab].canonSJ == -3) right1 = rc.readLength[g.ex[iab].iFrag] - g.ex[iab].R - g.ex[iab].L;
-                for (uint64_t k = 1; k <= left1; k++) { uint8_t r1 = R(g.ex[iab].R - k), g1 = gi.G[g.ex[iab].G - k]; if (r1 != g1 && r1 < 4 && g1 < 4) ++nMM1; }
-                for (uint64_t k = 0; k < right1; k++) { uint8_t r1 = R((uint64_t)g.ex[iab].R + g.ex[iab].L + k), g1 = gi.G[g.ex[iab].G + g.ex[iab].L + k]; if (r1 != g1 && r1 < 4 && g1 < 4) ++nMM1; }
+                for (uint64_t k = 1; k <= left1; k++) { uint8_t r1 = R(g.ex[iab].R - k), g1 = GG(g.ex[iab].G - k); if (r1 != g1 && r1 < 4 && g1 < 4) ++nMM1; }
+                for (uint64_t k = 0; k < right1; k++) { uint8_t r1 = R((uint64_t)g.ex[iab].R + g.ex[iab].L + k), g1 = GG(g.ex[iab].G + g.ex[iab].L + k); if (r1 != g1 && r1 < 4 && g1 < 4) ++nMM1; }
                 g.ex[iab].R = (uint16_t)(g.ex[iab].R - left1); g.ex[iab].G -= left1; g.ex[iab].L = (uint16_t)(g.ex[iab].L + left1 + right1);
             }
             if (t.nMM + nMM1 > std::min<uint64_t>(mmMaxTotal, (uint64_t)(P.dev.outFilterMismatchNoverLmax * (double)(Lread - 1)))) continue;

@@ -310,7 +310,12 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     uint64_t nLines[2] = {0, 0};
     for (;;) {
-        for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
+        if (nMates == 2 && samMates_ == 0 && !fasta) {       // the two mate files are read and scanned for line ends side by side
+            std::thread second([&] { nLines[1] = fill(1, want, b.text[1]); });
+            nLines[0] = fill(0, want, b.text[0]);
+            second.join();
+        } else
+            for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
         b.fileIndex = (uint32_t)curFile; b.fasta = fasta || noQualities;
         // a batch never spans two input files: when this one is exhausted the next batch starts with the next file
         if (!fromMemory && nLines[0] == 0 && curFile + 1 < files_[0].size()) { closeFiles(); curFile++; std::string e = openCurrent(); if (!e.empty()) { err = e; return false; } continue; }

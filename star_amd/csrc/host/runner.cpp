@@ -4,6 +4,8 @@
 // so the same post-map code is exercised with results produced by the HIP engine (product) or,
 // in tests only, by the CPU oracle.
 #include "host.h"
+#include <unistd.h>
+#include <atomic>
 #include <sys/stat.h>
 #include <cerrno>
 #include "../../../include/star_amd_host.h"
@@ -42,6 +44,7 @@ struct Runner {
     FILE *chimSamOut = nullptr;                     // Chimeric.out.sam (--chimOutType SeparateSAMold)
     FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
     std::string error;
+    std::string parseError;             // set by the reader thread of the pipelined front end only (sah_parse_slot); `error` belongs to the emit / control side
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
     std::string insertLog;
     bool pass1 = false;
@@ -207,11 +210,35 @@ struct Runner {
     std::mutex wm; std::condition_variable wcv;
     std::deque<int> freeSets, fullSets; bool writerStop = false, writerFailed = false;
     std::thread writerThread;
+    int samFd = -1; uint64_t samPos = 0;     // positional writes of the SAM / unsorted BAM text (regular file)
     void writerLoop() {
         for (;;) {
             int k;
             { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !fullSets.empty() || writerStop; }); if (fullSets.empty()) return; k = fullSets.front(); fullSets.pop_front(); }
             OutSet &o = outSets[k];
+            if (samOut && samOut != stdout && (o.used > 1 || samFd >= 0)) {
+                // a regular file: the per-thread text buffers go out side by side, each at its own offset (one fwrite stream tops out near
+                // 2 GB/s on tmpfs, the SAM text of one GPU runs at about that)
+                if (samFd < 0) { fflush(samOut); samFd = fileno(samOut); samPos = (uint64_t)ftello(samOut); }
+                std::vector<uint64_t> at(o.used + 1, samPos);
+                for (uint32_t t = 0; t < o.used; t++) at[t + 1] = at[t] + o.sams[t].size();
+                const uint32_t W = std::min<uint32_t>(8, o.used);
+                std::atomic<uint32_t> next(0); std::atomic<bool> bad(false);
+                auto put = [&] {
+                    for (;;) {
+                        uint32_t t = next.fetch_add(1);
+                        if (t >= o.used) break;
+                        const char *p = o.sams[t].data(); uint64_t left = o.sams[t].size(), off = at[t];
+                        while (left) { ssize_t w = pwrite(samFd, p, left, (off_t)off); if (w <= 0) { bad = true; return; } p += w; left -= (uint64_t)w; off += (uint64_t)w; }
+                    }
+                };
+                std::vector<std::thread> th;
+                for (uint32_t i = 1; i < W; i++) th.emplace_back(put);
+                put();
+                for (auto &x : th) x.join();
+                samPos = at[o.used];
+                if (bad) writerFailed = true;
+            } else
             for (uint32_t t = 0; t < o.used; t++)
                 if (!o.sams[t].empty() && samOut && fwrite(o.sams[t].data(), 1, o.sams[t].size(), samOut) != o.sams[t].size()) writerFailed = true;
             { std::lock_guard<std::mutex> l(wm); freeSets.push_back(k); }
@@ -462,6 +489,7 @@ struct Runner {
         }
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (samOut) {
+            if (samFd >= 0) { fflush(samOut); fseeko(samOut, (off_t)samPos, SEEK_SET); }      // the batches went out through positional writes: the stream goes on behind them
             if (P.outBAMunsorted) { std::string e; bgzfEof(e); fwrite(e.data(), 1, e.size(), samOut); }
             if (samOut == stdout) fflush(stdout); else fclose(samOut);
             samOut = nullptr;
@@ -569,7 +597,7 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
     Runner *r = (Runner *)h;
     std::string err;
     bool ok = r->reader.nextBatch(r->slots[slot], r->P, maxReads, err);
-    if (!err.empty()) { r->error = err; return -1; }
+    if (!err.empty()) { r->parseError = err; return -1; }
     if (!ok) return 0;
     if (out) *out = r->slots[slot].view();
     if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
@@ -672,7 +700,7 @@ int sah_stats_import_add(void *h, const uint64_t *in) {
     s.add(a);
     return 0;
 }
-const char *sah_error(void *h) { return ((Runner *)h)->error.c_str(); }
+const char *sah_error(void *h) { Runner *r = (Runner *)h; return !r->parseError.empty() ? r->parseError.c_str() : r->error.c_str(); }
 void sah_destroy(void *h) { delete (Runner *)h; }
 
 }
