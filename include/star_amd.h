@@ -200,6 +200,16 @@ int  staramd_create(staramd_ctx **out, int device, const staramd_genome *g, cons
                     uint32_t maxBatchReads, uint64_t maxBatchBases);
 /* Replace the index after sjdbInsertJunctions (two-pass); same semantics as create's upload. */
 int  staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p);
+/* Junction insertion into the index RESIDENT in HBM (sjdbBuildIndex, source/sjdbBuildIndex.cpp:15-333): the suffix search of
+ * the new junction sequences, the merge into a new packed suffix array and the SAindex of the result all happen on the device; SA / SAindex never
+ * cross PCIe (staramd_update_index re-uploads ~30 GB for a human index).  `a` is what sjdbPrepare produced (struct in star_amd_index.h; its G / SA
+ * / SAout / SAiOut members are ignored).  When SAout / SAiOut are not NULL the new packed arrays are also copied out (--sjdbInsertSave All).
+ * Follow with staramd_update_tables, which brings the junction tables and the parameters of the new index. */
+struct staramd_sjdb_args; struct staramd_sjdb_result;
+int  staramd_insert_junctions(staramd_ctx *ctx, const struct staramd_sjdb_args *a, uint8_t *SAout, uint64_t saOutCapacity, uint8_t *SAiOut, uint64_t saiOutCapacity,
+                              struct staramd_sjdb_result *res);
+/* New chromosome / junction tables and parameters for an index whose big arrays (G, SA, SAindex) are already in place in HBM; g->G / SA / SAi are not read. */
+int  staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p);
 /* 2nd stage of --outFilterType BySJout.  Replaces the mutation of P.sjNovelStart / P.sjNovelEnd / P.sjNovelN and
  * P.outFilterBySJoutStage between the two mapping stages (source/STAR.cpp:203-220, source/outputSJ.cpp:139-161): with
  * stage == 2 a transcript is recorded only if each of its unannotated junctions (start = first intron base, end = last

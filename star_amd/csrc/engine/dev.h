@@ -80,6 +80,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_prof0, DC_prof1, DC_prof2, DC_prof3, DC_prof4, DC_prof5, DC_prof6, DC_prof7,   // -DSTARAMD_PROFILE build: shader-clock cycles per section of k_stitch_win
        DC_prof8, DC_prof9, DC_prof10, DC_prof11, DC_prof12, DC_prof13, DC_prof14, DC_prof15,
        DC_nPrunedWin,                                                  // windows not walked because no transcript of theirs could be selected (k_stitch_win)
+       DC_nRewalkRead,                                                 // light reads whose two-mate windows did not clear the bar: walked again in window order
        DC_N };
 
 // cursors[] slots

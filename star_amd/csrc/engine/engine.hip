@@ -2,6 +2,9 @@
 // The hot path has no CPU fallback: every entry point fails with an error code when the GPU or the
 // kernels are not usable.
 #include "dev.h"
+#include "../index/hip_backend.h"
+#include "../index/sjdb_core.h"
+#include "../../../include/star_amd_index.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,30 +114,9 @@ static void buildGlBreaks(DevIndex &X, double scale) {
     }
 }
 
-static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
+// chromosome / junction tables, index geometry, parameters and the DevIndex block (everything but G, SA, SAindex)
+static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
-    memset(&X, 0, sizeof(X));
-    if (g->gSAsparseD < 1 || g->gSAsparseD > 8) { g_err = "genomeSAsparseD must be in 1..8"; return STARAMD_ERR_ARG; }
-    if (g->gSAindexNbases > 16 || g->GstrandBit + 3 > 63) { g_err = "unsupported index geometry"; return STARAMD_ERR_ARG; }
-    if (p->seedPerWindowNmax > WA_MAX || p->seedPerWindowNmax < 1) { g_err = "seedPerWindowNmax must be in 1..64 on the device (one lane per window seed)"; return STARAMD_ERR_ARG; }
-    if (p->alignTranscriptsPerWindowNmax > 2000 || p->alignTranscriptsPerWindowNmax < 1) { g_err = "alignTranscriptsPerWindowNmax must be in 1..2000 on the device"; return STARAMD_ERR_ARG; }
-    if (p->winAnchorMultimapNmax > 64) { /* anchors are enumerated in chunks of 64 loci: any value works */ }
-    // genome with padding
-    {
-        u8 *dG = nullptr;
-        int rc = devAlloc(c->indexAllocs, &dG, g->nGenome + 2 * GPAD); if (rc) return rc;
-        HIPCHK(hipMemset(dG, 5, g->nGenome + 2 * GPAD));
-        HIPCHK(hipMemcpy(dG + GPAD, g->G, g->nGenome, hipMemcpyHostToDevice));
-        X.G = dG + GPAD;
-    }
-    {
-        u64 nW = (g->nSAbyte + 7) / 8 + 2; u64 *d = nullptr;
-        int rc = devAlloc(c->indexAllocs, &d, nW); if (rc) return rc;
-        HIPCHK(hipMemset(d, 0, nW * 8)); HIPCHK(hipMemcpy(d, g->SA, g->nSAbyte, hipMemcpyHostToDevice)); X.SA = d;
-        nW = (g->nSAibyte + 7) / 8 + 2;
-        rc = devAlloc(c->indexAllocs, &d, nW); if (rc) return rc;
-        HIPCHK(hipMemset(d, 0, nW * 8)); HIPCHK(hipMemcpy(d, g->SAi, g->nSAibyte, hipMemcpyHostToDevice)); X.SAi = d;
-    }
     int rc;
     if ((rc = devUpload(c->indexAllocs, &X.chrBin, g->chrBin, g->chrBinN, 4))) return rc;
     if ((rc = devUpload(c->indexAllocs, &X.chrStart, g->chrStart, (u64)g->nChrReal + 1))) return rc;
@@ -161,6 +143,33 @@ static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_pa
     { int rc2 = devAlloc(c->indexAllocs, &c->dX, (u64)1); if (rc2) return rc2; }
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
     return 0;
+}
+
+static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
+    DevIndex &X = c->X;
+    memset(&X, 0, sizeof(X));
+    if (g->gSAsparseD < 1 || g->gSAsparseD > 8) { g_err = "genomeSAsparseD must be in 1..8"; return STARAMD_ERR_ARG; }
+    if (g->gSAindexNbases > 16 || g->GstrandBit + 3 > 63) { g_err = "unsupported index geometry"; return STARAMD_ERR_ARG; }
+    if (p->seedPerWindowNmax > WA_MAX || p->seedPerWindowNmax < 1) { g_err = "seedPerWindowNmax must be in 1..64 on the device (one lane per window seed)"; return STARAMD_ERR_ARG; }
+    if (p->alignTranscriptsPerWindowNmax > 2000 || p->alignTranscriptsPerWindowNmax < 1) { g_err = "alignTranscriptsPerWindowNmax must be in 1..2000 on the device"; return STARAMD_ERR_ARG; }
+    if (p->winAnchorMultimapNmax > 64) { /* anchors are enumerated in chunks of 64 loci: any value works */ }
+    // genome with padding
+    {
+        u8 *dG = nullptr;
+        int rc = devAlloc(c->indexAllocs, &dG, g->nGenome + 2 * GPAD); if (rc) return rc;
+        HIPCHK(hipMemset(dG, 5, g->nGenome + 2 * GPAD));
+        HIPCHK(hipMemcpy(dG + GPAD, g->G, g->nGenome, hipMemcpyHostToDevice));
+        X.G = dG + GPAD;
+    }
+    {
+        u64 nW = (g->nSAbyte + 7) / 8 + 2; u64 *d = nullptr;
+        int rc = devAlloc(c->indexAllocs, &d, nW); if (rc) return rc;
+        HIPCHK(hipMemset(d, 0, nW * 8)); HIPCHK(hipMemcpy(d, g->SA, g->nSAbyte, hipMemcpyHostToDevice)); X.SA = d;
+        nW = (g->nSAibyte + 7) / 8 + 2;
+        rc = devAlloc(c->indexAllocs, &d, nW); if (rc) return rc;
+        HIPCHK(hipMemset(d, 0, nW * 8)); HIPCHK(hipMemcpy(d, g->SAi, g->nSAibyte, hipMemcpyHostToDevice)); X.SAi = d;
+    }
+    return uploadTables(c, g, p);
 }
 
 static u32 envU32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)strtoul(s, nullptr, 10) : dflt; }
@@ -386,7 +395,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     {
         size_t readBytes = (ldsWords * 4u + 15u) & ~15u;
         size_t ldsFast = 4 * (readBytes + stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast));
-        const u32 prune = envU32("STARAMD_PRUNE", 1);
+        const u32 prune = envU32("STARAMD_PRUNE", 3);       // bit 0: window pruning, bit 1: two-mate windows of a light read first
         size_t ldsLean = c->leanDepth ? 4 * (readBytes + stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena)) : 0;
         for (u32 mode = 0; mode < 2; mode++) {
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest

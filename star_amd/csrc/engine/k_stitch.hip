@@ -940,7 +940,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_ITEM] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
     else if (mode == 2) { list = B.heavyList; nItems = B.cursors[CUR_ST_HEAVY]; ticketSlot = CUR_ST_TICKETH; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
-    u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0;
+    u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0, nRewalk = 0;
+    const bool sweepEnable = (pruneEnable & 2u) != 0;
     // ---- window pruning (ours; exact for what is returned under resultSelect == 1).  multMapSelect only ever picks transcripts with
     // maxScore >= trBest->maxScore - outFilterMultimapScoreRange (ReadAlign_multMapSelect.cpp:26-44).  The score of a transcript is bounded by
     // the lengths of the mates whose seeds its window holds plus perJ per junction (perJ = the positive part of the junction scores), so once
@@ -974,12 +975,43 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             if (lane == 0) { u32 k = atomicAdd(&B.cursors[CUR_ST_HEAVY], 1u); B.heavyList[k] = item; }
             continue;
         }
+        // A light read is walked in up to two sweeps.  Sweep 0 (only when some of its windows hold seeds of both mates and some do not): the
+        // two-mate windows alone, in window order.  If the best score they record clears the pruning bar of EVERY other window of the read,
+        // those are all skipped unwalked (sweep 1) -- the reasoning of the pruning note above holds for any order of the walked windows, because
+        // all that order changes are maxScoreMate-dependent decisions about single-mate transcripts, none of which can be selected then.  If it
+        // does not, nothing is kept: the read is walked again from scratch, every window in the reference's order (sweep 2).
+        u32 sweep = 2; i32 barAll = 0;
+        if (wholeRead && pruneOn && sweepEnable && nWin > 1 && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax) {
+            bool anyPair = false, anySingle = false;
+            for (u32 base = 0; base < nWin; base += NLANE) {
+                const u32 k = base + lane; u32 mt = 0, na = 0;
+                if (k < nWin) { const DWin wk = B.winPool[w0 + k]; mt = wk.mates; na = wk.nWA; }
+                anyPair |= __ballot(k < nWin && mt == 3u) != 0; anySingle |= __ballot(k < nWin && mt != 3u) != 0;
+                // bound of a single-mate window needs the mate lengths: taken from the read below (same for all its windows)
+                const i32 extra = (k < nWin && mt != 3u) ? perJ * ((i32)na - 1) + (i32)(mt & 1u) * 0 : -0x40000000;
+                barAll = max(barAll, (i32)waveMaxU32((u32)(extra + 0x40000000)) - 0x40000000);
+            }
+            if (anyPair && anySingle) sweep = 0;
+        }
+        for (;;) {
+        if (sweep == 2) { carry[0] = carry[1] = 0; bestSoFar = 0; }
         for (u32 iw = 0; iw < nWin; iw++) {
             const u32 w = w0 + iw;
             const DWin win = uni(B.winPool[w]);
             if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
             if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-            if (pruneOn && win.mates != 0) {
+            if (sweep == 0 && win.mates != 3u) continue;
+            if (sweep == 1) {
+                if (win.mates == 3u) continue;                         // walked in sweep 0
+                if (lane == 0) {
+                    DWinOut z; z.trOffset = z.nTr = z.exOffset = z.nEx = 0; z.mm[0] = z.mm[1] = 0; z.sens[0] = z.sens[1] = 0x7FFFFFFF; z.minIn[0] = z.minIn[1] = 0;
+                    z.headScore = 0; z.candOff32 = 0; z.headGlen = 0; z.nCand = 0; z.pad = 0;
+                    B.wout[w] = z;
+                }
+                nPruned++;
+                continue;
+            }
+            if (pruneOn && win.mates != 0 && sweep == 2) {
                 if (!wholeRead) { nWinRead = first32(B.reads[win.read].nWin); bestSoFar = firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
                 const i32 bound = (i32)((win.mates & 1u) ? c.readLength[0] : 0u) + (i32)((win.mates & 2u) ? c.readLength[1] : 0u) + perJ * ((i32)win.nWA - 1);
                 if ((u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax
@@ -1031,6 +1063,15 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             }
             if (lane == 0) B.wout[w] = o;
         }
+        if (sweep == 0) {
+            // the bar every single-mate window must stay under: longest mate + junction bonuses of the window with most seeds + the margins
+            const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + barAll + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1);
+            if (bar < bestSoFar) { sweep = 1; continue; }
+            sweep = 2; nRewalk++;
+            continue;
+        }
+        break;
+        }
     }
     if (lane == 0) {
         if (mode == 0) B.candTops[waveId] = c.candTop;
@@ -1041,6 +1082,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
         if (nPruned) atomicAdd((unsigned long long *)&B.counters[DC_nPrunedWin], (unsigned long long)nPruned);
+        if (nRewalk) atomicAdd((unsigned long long *)&B.counters[DC_nRewalkRead], (unsigned long long)nRewalk);
 #ifdef STARAMD_PROFILE
         c.prof[7] = __builtin_readcyclecounter() - profKernelStart;      // whole wave life time
         for (int k = 0; k < 16; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);

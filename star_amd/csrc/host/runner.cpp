@@ -211,18 +211,21 @@ struct Runner {
     std::deque<int> freeSets, fullSets; bool writerStop = false, writerFailed = false;
     std::thread writerThread;
     int samFd = -1; uint64_t samPos = 0;     // positional writes of the SAM / unsorted BAM text (regular file)
+    double tWriter = 0, tEmitWaitSet = 0, tEmitFormat = 0, tEmitTail = 0;      // seconds, whole run (STARAMD_HOST_TIMING prints them at the end)
     void writerLoop() {
         for (;;) {
             int k;
             { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !fullSets.empty() || writerStop; }); if (fullSets.empty()) return; k = fullSets.front(); fullSets.pop_front(); }
             OutSet &o = outSets[k];
+            const auto tw0 = std::chrono::steady_clock::now();
+            struct AddTime { double &acc; std::chrono::steady_clock::time_point t0; ~AddTime() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } addTime{tWriter, tw0};
             if (samOut && samOut != stdout && (o.used > 1 || samFd >= 0)) {
                 // a regular file: the per-thread text buffers go out side by side, each at its own offset (one fwrite stream tops out near
                 // 2 GB/s on tmpfs, the SAM text of one GPU runs at about that)
                 if (samFd < 0) { fflush(samOut); samFd = fileno(samOut); samPos = (uint64_t)ftello(samOut); }
                 std::vector<uint64_t> at(o.used + 1, samPos);
                 for (uint32_t t = 0; t < o.used; t++) at[t + 1] = at[t] + o.sams[t].size();
-                const uint32_t W = std::min<uint32_t>(8, o.used);
+                const uint32_t W = std::min<uint32_t>(2, o.used);      // tmpfs does not scale past one or two writers; a positional write skips stdio's copy
                 std::atomic<uint32_t> next(0); std::atomic<bool> bad(false);
                 auto put = [&] {
                     for (;;) {
@@ -261,7 +264,9 @@ struct Runner {
         uint32_t T = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
         T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per thread
         int k;
+        auto te0 = std::chrono::steady_clock::now();
         { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !freeSets.empty(); }); k = freeSets.front(); freeSets.pop_front(); }
+        auto te1 = std::chrono::steady_clock::now(); tEmitWaitSet += std::chrono::duration<double>(te1 - te0).count();
         OutSet &o = outSets[k];
         if (o.sams.size() < T) { o.sams.resize(T); o.raws.resize(T); }
         o.used = T;
@@ -306,14 +311,22 @@ struct Runner {
             }
             post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder, trSAM ? &nAlignT : nullptr, mg, mgRes);
         }
+        static const bool hostTiming = getenv("STARAMD_HOST_TIMING") != nullptr;
+        std::vector<double> tThread(hostTiming ? T : 0);
         auto work = [&](uint32_t t) {
+            struct Tm { std::vector<double> &v; uint32_t t; std::chrono::steady_clock::time_point t0; ~Tm() { if (!v.empty()) v[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } tm{tThread, t, std::chrono::steady_clock::now()};
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
-            o.sams[t].clear();
+            // the thread appends to objects of its own for the length of the range: neighbouring elements of the per-thread vectors share
+            // cache lines, and a std::string / std::vector rewrites its size word on every append (measured: 4x per record with 8 threads)
+            std::string samL, rawL; OutSJ sjL; Stats stL;
+            samL.swap(o.sams[t]); rawL.swap(o.raws[t]);
+            struct Back { std::string &a, &al, &b, &bl; OutSJ &s, &sl; Stats &st, &stl; ~Back() { a.swap(al); b.swap(bl); s = std::move(sl); st = stl; } } back{o.sams[t], samL, o.raws[t], rawL, sjs[t], sjL, sts[t], stL};
+            samL.clear();
             const bool bamOut = (P.outBAMunsorted || P.outBAMcoord) && !post->samOff;   // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
-            std::string &raw = o.raws[t];
+            std::string &raw = rawL;
             if (bamOut) raw.clear();
             PostMap::RangeOut ro;
-            ro.sam = bamOut ? &raw : &o.sams[t]; ro.sj = &sjs[t]; ro.st = &sts[t];
+            ro.sam = bamOut ? &raw : &samL; ro.sj = &sjL; ro.st = &stL;
             if (stage1) { ro.sj1 = &sj1s[t]; ro.held = &helds[t]; }
             if (quant) ro.gc = &gcs[t];
             if (bamOut && P.outBAMcoord) ro.bamKeys = &keyss[t];
@@ -331,10 +344,10 @@ struct Runner {
                 std::string only; size_t pos = 0;
                 for (BamKey &k : keyss[t]) if (k.len & 0x80000000u) { k.len &= 0x7fffffffu; only.append(raw, pos, k.off - pos); pos = k.off + k.len; }
                 only.append(raw, pos, std::string::npos);
-                if (errs[t].empty() && !bgzfCompress(only, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
+                if (errs[t].empty() && !bgzfCompress(only, P.outBAMcompression, samL)) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
                 return;
             }
-            if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, o.sams[t])) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
+            if (errs[t].empty() && P.outBAMunsorted && !bgzfCompress(raw, P.outBAMcompression, samL)) errs[t] = "EXITING because of fatal ERROR: BGZF compression failed";
         };
         if (T == 1) work(0);
         else {
@@ -343,6 +356,10 @@ struct Runner {
             work(0);
             for (auto &x : th) x.join();
         }
+        auto te2 = std::chrono::steady_clock::now(); tEmitFormat += std::chrono::duration<double>(te2 - te1).count();
+        if (hostTiming && T > 0) { double mn = 1e9, mx = 0, sm = 0; for (double x : tThread) { mn = std::min(mn, x); mx = std::max(mx, x); sm += x; }
+            fprintf(stderr, "  emit: %u threads, section %.2f ms, per-thread min %.2f / mean %.2f / max %.2f ms\n", T, std::chrono::duration<double, std::milli>(te2 - te1).count(), mn, sm / T, mx); }
+        struct AddTail { double &acc; std::chrono::steady_clock::time_point t0; ~AddTail() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } addTail{tEmitTail, te2};
         for (uint32_t t = 0; t < T; t++) if (!errs[t].empty() && error.empty()) error = errs[t];
         if (!error.empty()) o.used = 0;
         { std::lock_guard<std::mutex> l(wm); fullSets.push_back(k); }
@@ -502,7 +519,7 @@ struct Runner {
         if (P.quantGeneCounts) { error = geneCounts.write(P.outFileNamePrefix + "ReadsPerGene.out.tab", genes, stats); if (!error.empty()) return false; }
         return true;
     }
-    ~Runner() { stopWriter(); if (samOut && samOut != stdout) fclose(samOut); if (quantOut == stdout) quantOut = nullptr; for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); if (quantOut) fclose(quantOut); }
+    ~Runner() { stopWriter(); if (getenv("STARAMD_HOST_TIMING")) fprintf(stderr, "  host stages, whole run: writer %.3f s, emit: wait for a text buffer set %.3f s, format on threads %.3f s, serial tail %.3f s\n", tWriter, tEmitWaitSet, tEmitFormat, tEmitTail); if (samOut && samOut != stdout) fclose(samOut); if (quantOut == stdout) quantOut = nullptr; for (FILE *u : unmappedOut) if (u) fclose(u); if (chimOut) fclose(chimOut); if (quantOut) fclose(quantOut); }
 };
 
 } // namespace staramd

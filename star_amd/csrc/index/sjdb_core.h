@@ -69,7 +69,7 @@ template <class SAget> IDX_HD u64 sjdbSearchOne(const u8 *G, u64 nGenomeOld, u32
 struct SjdbDeviceResult {
     u64 nInd, nSAnew, nGenomeNew;
     u64 *dSApacked; u64 saWords;      // new packed suffix array (device), caller frees with be.free
-    u8 *dGnew;                        // new genome text with SJ_GPAD spacer bytes either side (device): dGnew + SJ_GPAD = base 0
+    u8 *dGnew;                        // new genome text with padOut spacer bytes either side (device): dGnew + padOut = base 0
     u64 *dSAiPacked; u64 saiWords;    // new packed SAindex (device)
     int badFirstSuffix;
 };
@@ -78,7 +78,7 @@ struct SjdbDeviceResult {
 // hGsj: junction sequences of the NEW table, forward half only: sjdbN blocks of sjdbLength codes, the last code of a block = spacer.
 // hIsOld[sjdbN]: 1 = the junction is already in the old index (no new suffixes).  hOldSJind[oldSjdbN]: new number of every old junction.
 template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *dGold, const u64 *dSAold, const u8 *hGsj, const u8 *hIsOld,
-                                         const u32 *hOldSJind, const u64 *saiStart, SjdbDeviceResult &R) {
+                                         const u32 *hOldSJind, const u64 *saiStart, SjdbDeviceResult &R, u64 padOut = SJ_GPAD) {
     const u64 nGsj = (u64)P.sjdbN * P.sjdbLength, nQ = 2 * nGsj + 1;
     const u32 Lsj = P.sjdbLength, GstrandBit = P.GstrandBit, saBits = P.GstrandBit + 1;
     const u64 nGenomeOld = P.nGenomeOld, nSAold = P.nSAold, nGenomeReal = P.nGenomeReal;
@@ -181,12 +181,12 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
     }
     be.free(pos); be.free(off); be.free(dOldSJind); be.free(dIsOld);
     // ---- new genome text: chromosomes + forward junction block, spacers either side
-    R.dGnew = be.template alloc<u8>(R.nGenomeNew + 2 * SJ_GPAD);
+    R.dGnew = be.template alloc<u8>(R.nGenomeNew + 2 * padOut);
     {
         u8 *gn = R.dGnew; const u64 nGn = R.nGenomeNew;
-        be.forEach(nGn + 2 * SJ_GPAD, [=] IDX_L (u64 i) {
+        be.forEach(nGn + 2 * padOut, [=] IDX_L (u64 i) {
             u8 c = 5;
-            if (i >= SJ_GPAD && i < SJ_GPAD + nGn) { u64 p = i - SJ_GPAD; c = p < nGenomeReal ? dGold[p] : dQ[p - nGenomeReal]; }
+            if (i >= padOut && i < padOut + nGn) { u64 p = i - padOut; c = p < nGenomeReal ? dGold[p] : dQ[p - nGenomeReal]; }
             gn[i] = c;
         });
     }
@@ -197,7 +197,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
     {
         const u64 N = R.nGenomeNew;
         u8 *dTraw = be.template alloc<u8>(2 * N + 2 * TPAD);
-        u8 *T = buildText(be, R.dGnew + SJ_GPAD, N, dTraw);
+        u8 *T = buildText(be, R.dGnew + padOut, N, dTraw);
         u64 *dSApos = be.template alloc<u64>(nSAnew);
         { const u64 *sp = R.dSApacked; const u64 N2bit = 1ull << GstrandBit;
           be.forEach(nSAnew, [=] IDX_L (u64 i) { u64 v = packedGetW(sp, i, saBits); dSApos[i] = (v & N2bit) ? N + (v & ~N2bit) : v; }); }
