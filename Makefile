@@ -68,7 +68,7 @@ oracle/_build/libindex_emul.so: oracle/index_emul.cpp $(wildcard star_amd/csrc/i
 
 # test infrastructure: the command-line front end with the oracle behind the engine's C ABI (oracle/cli_shim.cpp), for CPU tests of main.cpp
 oracle/_build/star_amd_oracle_cli: $(CLI_SRC) oracle/cli_shim.cpp oracle/_build/liboracle.so oracle/_build/libindex_emul.so star_amd/lib/libstaramd_host.so $(CLI_HDR)
-	$(CXX) $(CXXFLAGS) -fPIE $(CLI_SRC) oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -lindex_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -DSTARAMD_NO_RESIDENT_SJDB -fPIE $(CLI_SRC) oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -lindex_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
 
 ref:
 	$(MAKE) -f oracle/Makefile.ref -j8 all

@@ -32,6 +32,12 @@ int   sah_tool_done(void *h);                                           /* 1: --
  * (star_amd_index.h), then sah_generate_finish inserts the annotated junctions and writes the genomeDir files */
 /* call BEFORE sah_create: junction insertion runs on the device through fn (= staramd_sjdb_insert); NULL = host restatement (sjdb_insert.cpp) */
 void  sah_set_sjdb_device_fn(int (*fn)(int device, const staramd_sjdb_args *, staramd_sjdb_result *), int device);
+/* junction insertion on the arrays RESIDENT in the engine contexts: fn runs staramd_insert_junctions on every context (include/star_amd.h);
+ * used once sah_engines_ready was called; sah_index_in_engine: 1 = the last phase change left the new index in the engines already
+ * (follow with staramd_update_tables instead of staramd_update_index); reading it clears it */
+void  sah_set_sjdb_resident_fn(int (*fn)(void *user, const staramd_sjdb_args *, staramd_sjdb_result *), void *user);
+void  sah_engines_ready(void *h);
+int   sah_index_in_engine(void *h);
 int   sah_generate_mode(void *h);
 int   sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases,
                            uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap);

@@ -30,6 +30,7 @@ int staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results 
 }
 void staramd_destroy(staramd_ctx *ctx) { if (ctx) { oracle_destroy(ctx->o); delete ctx; } }
 const char *staramd_last_error(void) { return lastError.c_str(); }
+int staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p) { return staramd_update_index(ctx, g, p); }
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 // index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp

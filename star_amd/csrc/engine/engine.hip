@@ -310,6 +310,65 @@ extern "C" int staramd_update_index(staramd_ctx *c, const staramd_genome *g, con
     return uploadIndex(c, g, p);
 }
 
+
+// ---- junction insertion into the resident index (include/star_amd.h) ---------------------------------------------------------------
+static void dropAlloc(std::vector<void *> &reg, const void *p) {
+    for (size_t i = 0; i < reg.size(); i++) if (reg[i] == p) { (void)hipFree(reg[i]); reg.erase(reg.begin() + i); return; }
+}
+
+extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args *a, uint8_t *SAout, uint64_t saOutCapacity, uint8_t *SAiOut, uint64_t saiOutCapacity,
+                                        staramd_sjdb_result *res) {
+    if (!c || !a || !res || !a->Gsj || !a->isOld || (a->oldSjdbN && !a->oldSJind)) { g_err = "staramd_insert_junctions: null argument"; return STARAMD_ERR_ARG; }
+    if (a->sjdbN == 0 || a->sjdbLength < 3) { g_err = "staramd_insert_junctions: no junctions"; return STARAMD_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    using namespace staridx;
+    DevIndex &X = c->X;
+    HipBackend be; be.s = c->stream;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, be.s);
+    SjdbParams P; P.nGenomeOld = X.nGenome; P.nGenomeReal = a->nGenomeReal; P.nSAold = X.nSA; P.GstrandBit = X.strandBit;
+    P.sjdbN = a->sjdbN; P.sjdbLength = a->sjdbLength; P.oldSjdbN = a->oldSjdbN; P.sjNew = a->sjNew; P.saIndexNbases = X.saiNbases;
+    SjdbDeviceResult R; memset(&R, 0, sizeof(R));
+    sjdbInsertDevice(be, P, X.G, X.SA, a->Gsj, a->isOld, a->oldSJind, X.saiStart, R, (u64)GPAD);
+    memset(res, 0, sizeof(*res));
+    res->nInd = R.nInd; res->nSAnew = R.nSAnew;
+    res->nSAbyteNew = packedBytes(R.nSAnew, X.saBits); res->nSAibyte = packedBytes(X.saiStart[X.saiNbases], X.saiBits);
+    int rc = STARAMD_OK;
+    if (be.err != hipSuccess) { g_err = std::string("staramd_insert_junctions: ") + be.where + ": " + hipGetErrorString(be.err); rc = STARAMD_ERR_DEVICE; }
+    else if (R.badFirstSuffix) { g_err = "staramd_insert_junctions: the first suffix has a non-ACGT base inside the SAindex prefix"; rc = STARAMD_ERR_ARG; }
+    else if ((SAout && saOutCapacity < res->nSAbyteNew) || (SAiOut && saiOutCapacity < res->nSAibyte)) { g_err = "staramd_insert_junctions: output buffers too small"; rc = STARAMD_ERR_RESULT_OVERFLOW; }
+    if (!rc) {
+        if (SAout) be.copyToHost(SAout, (const u8 *)R.dSApacked, res->nSAbyteNew);
+        if (SAiOut) be.copyToHost(SAiOut, (const u8 *)R.dSAiPacked, res->nSAibyte);
+        if (be.err != hipSuccess) { g_err = std::string("staramd_insert_junctions: ") + be.where + ": " + hipGetErrorString(be.err); rc = STARAMD_ERR_DEVICE; }
+    }
+    (void)hipEventRecord(e1, be.s); (void)hipStreamSynchronize(be.s);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); res->msTotal = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (be.tmp) (void)hipFree(be.tmp);
+    if (rc) { if (R.dSApacked) (void)hipFree(R.dSApacked); if (R.dGnew) (void)hipFree(R.dGnew); if (R.dSAiPacked) (void)hipFree(R.dSAiPacked); return rc; }
+    // the new arrays take the place of the old ones
+    dropAlloc(c->indexAllocs, X.G - GPAD); dropAlloc(c->indexAllocs, X.SA); dropAlloc(c->indexAllocs, X.SAi);
+    c->indexAllocs.push_back(R.dGnew); c->indexAllocs.push_back(R.dSApacked); c->indexAllocs.push_back(R.dSAiPacked);
+    X.G = R.dGnew + GPAD; X.SA = R.dSApacked; X.SAi = R.dSAiPacked;
+    X.nGenome = R.nGenomeNew; X.nSA = R.nSAnew;
+    HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    return STARAMD_OK;
+}
+
+extern "C" int staramd_update_tables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
+    if (!c || !g || !p) { g_err = "staramd_update_tables: null argument"; return STARAMD_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    DevIndex &X = c->X;
+    if (g->nGenome != X.nGenome || g->nSA != X.nSA) { g_err = "staramd_update_tables: the resident arrays belong to another index (nGenome / nSA differ)"; return STARAMD_ERR_ARG; }
+    const void *keep[3] = {X.G - GPAD, X.SA, X.SAi};
+    std::vector<void *> kept;
+    for (void *q : c->indexAllocs) { if (q == keep[0] || q == keep[1] || q == keep[2]) kept.push_back(q); else (void)hipFree(q); }
+    c->indexAllocs.swap(kept);
+    return uploadTables(c, g, p);
+}
+
 extern "C" int staramd_set_novel_junctions(staramd_ctx *c, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage) {
     if (!c || (n && (!start || !end))) { g_err = "staramd_set_novel_junctions: null argument"; return STARAMD_ERR_ARG; }
     if (n > 0xFFFFFFF0ull) { g_err = "staramd_set_novel_junctions: too many junctions"; return STARAMD_ERR_ARG; }

@@ -119,6 +119,23 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
         }
         rep.indexUploadSeconds = since(tu);
     }
+#ifndef STARAMD_NO_RESIDENT_SJDB
+    // junction insertion between the passes runs on the arrays resident in HBM, on every context (no host copy of the new SA unless it is to be saved)
+    struct ResidentUser { std::vector<staramd_ctx *> *ctx; } residentUser{&ctx};
+    if (!getenv("STARAMD_SJDB_HOST") && !getenv("STARAMD_SJDB_NO_RESIDENT")) {
+        sah_set_sjdb_resident_fn([](void *user, const staramd_sjdb_args *a, staramd_sjdb_result *res) -> int {
+            std::vector<staramd_ctx *> &cx = *((ResidentUser *)user)->ctx;
+            std::vector<int> rcs(cx.size(), 0); std::vector<staramd_sjdb_result> rs(cx.size());
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < cx.size(); d++) th.emplace_back([&, d] { rcs[d] = staramd_insert_junctions(cx[d], a, d == 0 ? a->SAout : nullptr, a->saOutCapacity, d == 0 ? a->SAiOut : nullptr, a->saiOutCapacity, &rs[d]); });
+            for (auto &t : th) t.join();
+            for (size_t d = 0; d < cx.size(); d++) if (rcs[d]) { fprintf(stderr, "star_amd: junction insertion on device context %zu failed: %s\n", d, staramd_last_error()); return rcs[d]; }
+            *res = rs[0];
+            return 0;
+        }, &residentUser);
+        sah_engines_ready(h);
+    }
+#endif
     const int nSlots = std::min(24, 2 * nDev + 2);
     std::vector<ResBuf> rb(nSlots), rbMerged(nSlots), rbWasp(nSlots);
     std::vector<ResBuf> piecePart(nDev);
@@ -267,7 +284,10 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
         std::vector<int> rcs(nDev, 0); std::vector<std::string> es(nDev);
         std::vector<std::thread> th;
         if (phase == 1) {
-            for (int d = 0; d < nDev; d++) th.emplace_back([&, d] { rcs[d] = staramd_update_index(ctx[d], sah_genome(h), sah_params(h)); if (rcs[d]) es[d] = staramd_last_error(); });
+            const bool inEngine = sah_index_in_engine(h) != 0;       // the insertion ran on the resident arrays: only tables and parameters are new
+            for (int d = 0; d < nDev; d++) th.emplace_back([&, d] {
+                rcs[d] = inEngine ? staramd_update_tables(ctx[d], sah_genome(h), sah_params(h)) : staramd_update_index(ctx[d], sah_genome(h), sah_params(h));
+                if (rcs[d]) es[d] = staramd_last_error(); });
             for (auto &t : th) t.join();
             for (int d = 0; d < nDev; d++) if (rcs[d]) fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + es[d]);
             if (failed.load()) break;
@@ -288,6 +308,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",
                            (unsigned long long)nReads, sec, msDeviceAll / 1e3 / nDev, sec > 0 ? (double)nReads / sec / 1e6 : 0.0, nDev);
+    sah_set_sjdb_resident_fn(nullptr, nullptr);
     for (auto c : ctx) staramd_destroy(c);
     sah_destroy(h);
     publish();

@@ -28,6 +28,8 @@ struct GenomeIndex {
     staramd_genome view;      // pointers into the vectors above
     double loadSeconds = 0;
     bool sjdbInfoExists = false;
+    bool engineHoldsIndex = false;   // set by the front end once every engine context holds this index (staramd_create): insertion may then run on the resident arrays
+    bool indexInEngine = false;      // the last junction insertion ran on the resident arrays: the engines need staramd_update_tables, not a re-upload
     // returns empty string on success, else the error text
     std::string load(const std::string &genomeDir);
     void refreshView();       // re-point `view` at the vectors after they were rewritten (sjdb insertion)
@@ -236,6 +238,8 @@ std::string makeRunDir(const std::string &d, bool allRWX = false);
 // junction insertion on the device: the front end hands in staramd_sjdb_insert (include/star_amd_index.h); null = host restatement
 typedef int (*SjdbDeviceFn)(int device, const staramd_sjdb_args *a, staramd_sjdb_result *res);
 void setSjdbDeviceFn(SjdbDeviceFn fn, int device);
+typedef int (*SjdbResidentFn)(void *user, const staramd_sjdb_args *a, staramd_sjdb_result *res);
+void setSjdbResidentFn(SjdbResidentFn fn, void *user);
 // --sjdbGTFfile at the mapping stage (gtf.cpp): junctions of the annotation appended to `loci` with priority 20
 std::string loadGTFjunctions(const RunParams &P, const GenomeIndex &gi, SjdbLoci &loci, const std::string &dirOut, std::string &log);
 

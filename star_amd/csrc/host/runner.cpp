@@ -545,6 +545,11 @@ uint64_t sah_batch_reads(void *h) { return ((Runner *)h)->P.gpuBatchReads; }
 // junction insertion (2-pass, --sjdbGTFfile / --sjdbFileChrStartEnd at the mapping stage, genomeGenerate with annotations) on the device:
 // fn = staramd_sjdb_insert of the engine library (include/star_amd_index.h); process-wide; NULL restores the host restatement
 void sah_set_sjdb_device_fn(int (*fn)(int, const staramd_sjdb_args *, staramd_sjdb_result *), int device) { staramd::setSjdbDeviceFn(fn, device); }
+// the same on the arrays resident in the engine contexts (staramd_insert_junctions for every context): fn(user, args, result); the front end calls
+// sah_engines_ready once its contexts hold the index, and asks sah_index_in_engine after a phase change whether a re-upload is needed at all
+void sah_set_sjdb_resident_fn(int (*fn)(void *, const staramd_sjdb_args *, staramd_sjdb_result *), void *user) { staramd::setSjdbResidentFn(fn, user); }
+void sah_engines_ready(void *h) { ((Runner *)h)->gi.engineHoldsIndex = true; }
+int sah_index_in_engine(void *h) { Runner *r = (Runner *)h; int v = r->gi.indexInEngine ? 1 : 0; r->gi.indexInEngine = false; return v; }
 int sah_generate_mode(void *h) { return ((Runner *)h)->generateMode ? 1 : 0; }
 int sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases, uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap) {
     Runner *r = (Runner *)h;

@@ -136,6 +136,9 @@ void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci) {
 // library itself links no GPU code.  Null: the threaded host restatement below does the work.
 static SjdbDeviceFn g_sjdbDeviceFn = nullptr; static int g_sjdbDevice = 0;
 void setSjdbDeviceFn(SjdbDeviceFn fn, int device) { g_sjdbDeviceFn = fn; g_sjdbDevice = device; }
+// the same on the index RESIDENT in the engine contexts (staramd_insert_junctions): SA / SAindex stay in HBM, the host copies are dropped
+static SjdbResidentFn g_sjdbResidentFn = nullptr; static void *g_sjdbResidentUser = nullptr;
+void setSjdbResidentFn(SjdbResidentFn fn, void *user) { g_sjdbResidentFn = fn; g_sjdbResidentUser = user; }
 
 void GenomeIndex::refreshView() {
     view.G = G.data(); view.nGenome = G.size();
@@ -294,7 +297,9 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     }
     const uint32_t wSA = V.GstrandBit + 1;
     std::vector<uint8_t> SA2v; uint64_t nSAnew = 0;
-    if (g_sjdbDeviceFn) {
+    const bool resident = g_sjdbResidentFn != nullptr && gi.engineHoldsIndex;
+    const bool hostArrays = !resident || P.sjdbInsertSaveAll || P.runModeGenerate;      // does the host need the new SA / SAindex at all?
+    if (g_sjdbDeviceFn || resident) {
         // ---- on the device: search, sort, merge and SAindex (star_amd/csrc/index/sjdb_core.h)
         std::vector<uint8_t> isOld(sjdbN);
         for (uint64_t isj = 0; isj < sjdbN; isj++) isOld[isj] = sjdbInd[isj] >= 0;
@@ -305,20 +310,20 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
             for (uint64_t k = 0; k < sjdbLength; k++) nInd += q[k] < 4;
         }
         nSAnew = oldNSA + nInd;
-        SA2v.assign(Packed::lengthByte(nSAnew + 1, wSA) + 16, 0);
-        std::vector<uint8_t> SAiNew(gi.SAi.size() + 16, 0);
+        if (hostArrays) SA2v.assign(Packed::lengthByte(nSAnew + 1, wSA) + 16, 0);
+        std::vector<uint8_t> SAiNew(hostArrays ? V.nSAibyte + 24 : 0, 0);
         staramd_sjdb_args a; memset(&a, 0, sizeof(a));
         a.G = gi.G.data(); a.nGenomeOld = oldNGenome; a.nGenomeReal = nGenomeReal;
         a.SA = gi.SA.data(); a.nSAold = oldNSA; a.nSAbyteOld = V.nSAbyte; a.GstrandBit = V.GstrandBit; a.gSAindexNbases = V.gSAindexNbases;
         a.Gsj = Gsj.data(); a.sjdbN = (uint32_t)sjdbN; a.sjdbLength = (uint32_t)sjdbLength;
         a.isOld = isOld.data(); a.oldSJind = oldSJind.data(); a.oldSjdbN = (uint32_t)oldSjdbN; a.sjNew = sjNew;
-        a.SAout = SA2v.data(); a.saOutCapacity = SA2v.size(); a.SAiOut = SAiNew.data(); a.saiOutCapacity = SAiNew.size();
+        a.SAout = hostArrays ? SA2v.data() : nullptr; a.saOutCapacity = SA2v.size(); a.SAiOut = hostArrays ? SAiNew.data() : nullptr; a.saiOutCapacity = SAiNew.size();
         staramd_sjdb_result r;
-        int rc = g_sjdbDeviceFn(g_sjdbDevice, &a, &r);
+        int rc = resident ? g_sjdbResidentFn(g_sjdbResidentUser, &a, &r) : g_sjdbDeviceFn(g_sjdbDevice, &a, &r);
         if (rc) return "EXITING because of FATAL ERROR: junction insertion on the MI355X failed (code " + std::to_string(rc) + ")";
         if (r.nInd != nInd || r.nSAibyte != V.nSAibyte) return "EXITING because of FATAL ERROR: junction insertion on the MI355X returned an index of unexpected size";
-        SAiNew.resize(gi.SAi.size());
-        gi.SAi.swap(SAiNew);
+        if (hostArrays) { SAiNew.resize(V.nSAibyte + 8); gi.SAi.swap(SAiNew); }
+        gi.indexInEngine = resident;
         lap("device insert");
         log += "   Finished SA search: number of new junctions=" + std::to_string(sjNew) + ", old junctions=" + std::to_string(sjdbN - sjNew) + "\n";
     } else {
@@ -476,9 +481,11 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     gi.G.assign(nGenomeNew, 0);
     memcpy(gi.G.data(), G, nGenomeReal);
     memcpy(gi.G.data() + nGenomeReal, Gsj.data(), nGsj);
-    { Packed SA2f(SA2v.data(), wSA); SA2f.put(nSAnew, 0); }                // sjdbInsertJunctions.cpp:66-68
-    SA2v.resize(Packed::lengthByte(nSAnew, wSA) + 8);
-    gi.SA.swap(SA2v);
+    if (!SA2v.empty()) {
+        { Packed SA2f(SA2v.data(), wSA); SA2f.put(nSAnew, 0); }            // sjdbInsertJunctions.cpp:66-68
+        SA2v.resize(Packed::lengthByte(nSAnew, wSA) + 8);
+        gi.SA.swap(SA2v);
+    } else { std::vector<uint8_t>().swap(gi.SA); std::vector<uint8_t>().swap(gi.SAi); }      // the arrays live in HBM only (staramd_insert_junctions)
     gi.sjdbStart.swap(nStart); gi.sjdbEnd.swap(nEnd); gi.sjdbMotif.swap(nMotif); gi.sjdbShiftLeft.swap(nShL); gi.sjdbShiftRight.swap(nShR); gi.sjdbStrand.swap(nStrand);
     gi.sjDstart.swap(nD); gi.sjAstart.swap(nA);
     V.sjdbN = (uint32_t)sjdbN; V.sjGstart = nGenomeReal;

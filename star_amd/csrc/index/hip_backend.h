@@ -9,9 +9,10 @@
 
 namespace staridx {
 
-template <class F> __global__ void __launch_bounds__(256) k_forEach(u64 n, F f) {
+// one thread per element of [base, base + n); a launch carries at most 2^31 work-items (the dispatch packet counts them in 32 bits)
+template <class F> __global__ void __launch_bounds__(256) k_forEach(u64 base, u64 n, F f) {
     u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
-    if (i < n) f(i);
+    if (i < n) f(base + i);
 }
 
 struct HipBackend {
@@ -30,8 +31,11 @@ struct HipBackend {
     void free(void *p) { if (p) chk(hipFree(p), "hipFree"); }
     template <class F> void forEach(u64 n, F f) {
         if (n == 0 || err != hipSuccess) return;
-        u64 blocks = (n + 255) / 256;
-        hipLaunchKernelGGL(k_forEach<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
+        const u64 SLICE = 1ull << 31;
+        for (u64 base = 0; base < n; base += SLICE) {
+            const u64 m = n - base < SLICE ? n - base : SLICE;
+            hipLaunchKernelGGL(k_forEach<F>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, base, m, f);
+        }
         chk(hipGetLastError(), "k_forEach launch");
     }
     void needTmp(size_t b) {
