@@ -177,36 +177,12 @@ def _make_reads_child(read_len, g, out_dir, tag, n_pairs, seed_base, world):
 # ---------------------------------------------------------------------------------------------------------------------
 # the product pipeline in-process (libstaramd_cli.so, include/star_amd_cli.h)
 
-class CliHooks(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("warmup_done", C.CFUNCTYPE(None, C.c_void_p)), ("exchange", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int))]
-
-
-class CliReport(C.Structure):
-    _fields_ = [("reads", C.c_uint64), ("wallMapping", C.c_double), ("timedReads", C.c_uint64), ("timedWall", C.c_double),
-                ("genomeLoadSeconds", C.c_double), ("indexUploadSeconds", C.c_double), ("nDevices", C.c_int),
-                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 40),
-                ("parseBusy", C.c_double), ("emitBusy", C.c_double), ("batches", C.c_uint64), ("pass1Seconds", C.c_double)]
+from star_amd.capi import CliHooks, CliReport, run_cli      # the product pipeline in-process (libstaramd_cli.so, include/star_amd_cli.h)
 
 
 COUNTER_NAMES = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut",
                  "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
 STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitch_verify+replay+finish", "k_scan+k_gather", "device_total"]
-
-
-def run_cli(argv, warmup_done=None, exchange=None):
-    lib = C.CDLL(os.path.join(ROOT, "star_amd", "lib", "libstaramd_cli.so"))
-    lib.staramd_cli_main.restype = C.c_int
-    lib.staramd_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(CliHooks), C.POINTER(CliReport)]
-    args = [b"star_amd"] + [a.encode() for a in argv]
-    arr = (C.c_char_p * len(args))(*args)
-    hooks = CliHooks()
-    WD, EX = CliHooks._fields_[1][1], CliHooks._fields_[2][1]
-    wd = WD(lambda u: warmup_done() if warmup_done else None)
-    ex = EX(lambda u, h, last: int(exchange(h, last) or 0) if exchange else 0)
-    hooks.user = None; hooks.warmup_done = wd; hooks.exchange = ex
-    rep = CliReport()
-    rc = lib.staramd_cli_main(len(args), arr, C.byref(hooks), C.byref(rep))
-    return rc, rep
 
 
 def report_dict(rep, lread):
@@ -377,12 +353,15 @@ def main():
     sj_ms = {}
 
     def exchange(h, last):
-        if dist is None or not last:
+        if dist is None:
             return 0
         from star_amd import multi_gpu, capi
         t1 = time.perf_counter()
-        multi_gpu.merge_handle_outputs(capi.host_lib(), h, dist, dev, rank, world)
-        sj_ms["ms"] = (time.perf_counter() - t1) * 1e3
+        if last:
+            multi_gpu.merge_handle_outputs(capi.host_lib(), h, dist, dev, rank, world)
+            sj_ms["ms"] = (time.perf_counter() - t1) * 1e3
+        else:
+            multi_gpu.exchange_before_phase(capi.host_lib(), h, dist, dev, rank, world)
         return 0
 
     barrier()

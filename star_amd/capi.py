@@ -359,3 +359,37 @@ class device_sjdb_insertion:
     def __exit__(self, *a):
         host_lib().sah_set_sjdb_device_fn(None, 0)
         return False
+
+
+# ---- the command-line front end as a function (include/star_amd_cli.h) ----
+
+class CliHooks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("warmup_done", C.CFUNCTYPE(None, C.c_void_p)), ("exchange", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int))]
+
+
+class CliReport(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("wallMapping", C.c_double), ("timedReads", C.c_uint64), ("timedWall", C.c_double),
+                ("genomeLoadSeconds", C.c_double), ("indexUploadSeconds", C.c_double), ("nDevices", C.c_int),
+                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 40),
+                ("parseBusy", C.c_double), ("emitBusy", C.c_double), ("batches", C.c_uint64), ("pass1Seconds", C.c_double)]
+
+
+def run_cli(argv, warmup_done=None, exchange=None, lib_path=None):
+    """The whole front end (star_amd/csrc/host/cli_run.cpp) in this process: argv as on the command line; warmup_done() is called when the
+    --benchWarmupReads reads are written and the pipeline is empty; exchange(handle, last) at the end of every mapping phase (cross-rank tables).
+    Returns (exit code, CliReport)."""
+    lib = C.CDLL(lib_path or _need(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstaramd_cli.so")))
+    lib.staramd_cli_main.restype = C.c_int
+    lib.staramd_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(CliHooks), C.POINTER(CliReport)]
+    args = [b"star_amd"] + [a.encode() for a in argv]
+    arr = (C.c_char_p * len(args))(*args)
+    hooks = CliHooks()
+    WD, EX = CliHooks._fields_[1][1], CliHooks._fields_[2][1]
+    wd = WD(lambda u: warmup_done() if warmup_done else None)
+    ex = EX(lambda u, h, last: int(exchange(h, last) or 0) if exchange else 0)
+    hooks.user = None; hooks.warmup_done = wd; hooks.exchange = ex
+    rep = CliReport()
+    rc = lib.staramd_cli_main(len(args), arr, C.byref(hooks), C.byref(rep))
+    return rc, rep
+
+

@@ -101,3 +101,55 @@ def test_two_ranks_two_pass_by_sjout_gene_counts(tmp_path, built):
     for r in range(world):
         union += refstar.sam_body_sorted(os.path.join(str(tmp_path), "r%d_Aligned.out.sam" % r))
     assert sorted(union) == refstar.sam_body_sorted(ref + "Aligned.out.sam")
+
+
+# ---- the same through the in-process front end (include/star_amd_cli.h), as bench.py drives it: the whole pipeline of a rank is ONE call, the
+# cross-rank exchanges happen inside its `exchange` hook (star_amd/multi_gpu.py exchange_before_phase / merge_handle_outputs) ----
+
+CLI_ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libstaramd_cli_oracle.so")
+
+
+def _cli_worker(rank, world, port, idx, shards, extra, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from star_amd import multi_gpu
+    dev = torch.device("cpu")
+    prefix = os.path.join(outdir, "c%d_" % rank)
+    marks = []
+
+    def exchange(h, last):
+        if last:
+            multi_gpu.merge_handle_outputs(capi.host_lib(), h, dist, dev, rank, world)
+        else:
+            multi_gpu.exchange_before_phase(capi.host_lib(), h, dist, dev, rank, world)
+        marks.append(last)
+        return 0
+
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + shards[rank] + ["--outFileNamePrefix", prefix, "--runThreadN", "2", "--gpuBatchReads", "400",
+            "--benchWarmupReads", "400"] + list(extra)
+    rc, rep = capi.run_cli(argv, warmup_done=lambda: dist.barrier(), exchange=exchange, lib_path=CLI_ORACLE_LIB)
+    assert rc == 0 and marks and marks[-1] == 1 and rep.timedReads > 0 and rep.reads >= rep.timedReads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.isfile(CLI_ORACLE_LIB), reason="oracle-backed front-end library not built")
+@pytest.mark.parametrize("flags", [[], ["--twopassMode", "Basic", "--outFilterType", "BySJout", "--quantMode", "GeneCounts"]])
+def test_two_ranks_through_the_front_end_hooks(flags, tmp_path, built):
+    info = prepare("pe101", str(tmp_path), need_ref=False)
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(str(tmp_path), "ref_"), threads=1, extra=flags)
+    world = 2
+    shards = _split_fastq(info["fastq"], world, str(tmp_path))
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_cli_worker, args=(world, port, info["idx"], shards, flags, str(tmp_path)), nprocs=world, join=True)
+    c0 = os.path.join(str(tmp_path), "c0_")
+    assert open(ref + "SJ.out.tab", "rb").read() == open(c0 + "SJ.out.tab", "rb").read()
+    assert refstar.final_log_counters(ref + "Log.final.out") == refstar.final_log_counters(c0 + "Log.final.out")
+    if flags:
+        assert open(ref + "ReadsPerGene.out.tab", "rb").read() == open(c0 + "ReadsPerGene.out.tab", "rb").read()
+    union = []
+    for r in range(world):
+        union += refstar.sam_body_sorted(os.path.join(str(tmp_path), "c%d_Aligned.out.sam" % r))
+    assert sorted(union) == refstar.sam_body_sorted(ref + "Aligned.out.sam")
