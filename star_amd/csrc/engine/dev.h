@@ -85,7 +85,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
 
 // cursors[] slots
 enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS = 6,
-       CUR_TICKET_SEED = 8, CUR_TICKET_WIN = 9, CUR_OVF_WIN = 11, CUR_TICKET_WIN2 = 13,
+       CUR_TICKET_SEED = 8, CUR_TICKET_WIN = 9, CUR_OVF_WIN = 11, CUR_TICKET_WIN2 = 13, CUR_OVF_WIN2 = 12, CUR_TICKET_WIN3 = 14,
        // stitch stage: work lists of window ids and their tickets
        CUR_ST_TICKET0 = 16, CUR_ITEM = 25,                               // pass 0: all work items (reads or windows)
        CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
@@ -109,7 +109,8 @@ struct DevBatch {
     u32 *costHist;     // 32 cost classes + 32 offsets
     // stitch work items: bit 31 set = a whole (light) read, its windows walked in order by one wavefront; else a window id
     u32 *items; u8 *itemClass;   // winCap entries; itemClass ~ log2(estimated walk size)
-    u32 *ovfWin;       // reads deferred to the big-work-space pass of k_windows
+    u32 *ovfWin;       // reads deferred by the first pass of k_windows (table rows in LDS exhausted)
+    u32 *ovfWin2;      // reads deferred by the middle pass (larger LDS table) to the pass with the table in global memory
     u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
     u32 *heavyList;                    // pass-0 items whose windows hold more seeds than the lean launch has LDS for
     u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win

@@ -14,7 +14,7 @@
 
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
-extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big, u32 lightEst);
+extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid);
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
@@ -30,7 +30,7 @@ extern "C" __global__ void k_gather(DevBatch B, const u32 *trBase, const u32 *ex
 // per-lane / per-wave work-space sizes (same formulas as the kernels)
 static inline u32 waRowsH(u32 capDepth) { return capDepth == 0 ? (u32)WA_MAX : std::min<u32>(capDepth - 1u, (u32)WA_MAX); }
 static inline u32 stitchStateBytesH(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + waRowsH(capDepth) * 32u + arenaBytes;
+    u32 b = capDepth * 112u + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + waRowsH(capDepth) * 32u + 96u + arenaBytes;
     return (b + 127u) & ~127u;
 }
 static inline u64 winWaveBytesH(u32 capW, u32 capBlocks, u32 big) {
@@ -60,6 +60,8 @@ struct staramd_ctx {
     u32 seedLanes = 0; DSeed *scrSeed = nullptr; u32 seedPerLane = 0;
     // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
+    // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
+    u32 winBlocksMid = 0, capWMid = 0, capBlocksMid = 0; u8 *scrWinMid = nullptr;
     // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
     u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
     u32 stBlocks = 0, stBlocksBig = 0, replayBlocks = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
@@ -214,6 +216,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
     if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
     if ((rc = devAlloc(R, &B.ovfWin, (u64)N))) return rc;
+    if ((rc = devAlloc(R, &B.ovfWin2, (u64)N))) return rc;
     if ((rc = devAlloc(R, &B.cursors, (u64)CUR_N))) return rc;
     if ((rc = devAlloc(R, &B.counters, (u64)DC_N))) return rc;
     if ((rc = devAlloc(R, &c->dTrBase, (u64)N))) return rc;
@@ -241,6 +244,12 @@ static int allocWork(staramd_ctx *c) {
     c->winBlocks = (u32)c->nCU * envU32("STARAMD_WIN_BLOCKS_PER_CU", (u32)winPerCU);
     c->winBlocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (N + 3) / 4));
     if ((rc = devAlloc(R, &c->scrWin, (u64)c->winBlocks * 4 * winWaveBytesH(c->capW, c->capBlocks, 0)))) return rc;
+    c->capWMid = envU32("STARAMD_CAP_WINDOWS_MID", 1024); c->capBlocksMid = envU32("STARAMD_CAP_WA_BLOCKS_MID", 1024);
+    if (c->capWMid <= c->capW || c->capWMid >= P.alignWindowsPerReadNmax) c->capWMid = 0;
+    if (c->capWMid) {
+        c->winBlocksMid = envU32("STARAMD_WIN_BLOCKS_MID", (u32)c->nCU * 4u);
+        if ((rc = devAlloc(R, &c->scrWinMid, (u64)c->winBlocksMid * winWaveBytesH(c->capWMid, c->capBlocksMid, 0)))) return rc;
+    }
     c->capWBig = P.alignWindowsPerReadNmax; c->capBlocksBig = P.alignWindowsPerReadNmax;
     c->winBlocksBig = envU32("STARAMD_WIN_BLOCKS_BIG", 64);
     if ((rc = devAlloc(R, &c->scrWinBig, (u64)c->winBlocksBig * 4 * winWaveBytesH(c->capWBig, c->capBlocksBig, 1)))) return rc;
@@ -443,8 +452,10 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[1], s));
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
-        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst);
-        hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u, c->lightEst);
+        const u32 useMid = c->capWMid ? 1u : 0u;
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid);
+        if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid);
+        hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u, c->lightEst, useMid);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
         hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1), 0, s, B);

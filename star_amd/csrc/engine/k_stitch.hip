@@ -470,8 +470,9 @@ template <bool BIG> __device__ static u32 compactArena(WinRec &w) {
 
 // record decision is taken: de-duplicate candidate (o, exon rows ex / x) against the recorded transcripts and insert it
 // by rank (stitchWindowAligns.cpp:267-303).  Used by the walk (pass 0 / full re-walk) and by the replay of a candidate log.
-template <bool BIG, class EXP> __device__ static void recordCandidateImpl(const staramd_params &P, u32 lane, const staramd_transcript &o, const staramd_exon &x, EXP ex, WinRec &wr) {
-    const int Score = o.maxScore; const u64 gLength = o.gLength; const u32 mappedLength = o.mappedLength; const u32 ne = o.nExons;
+// hdr: the 12 words of the candidate's output record header (LDS staging slot in the walk, registers in the replay)
+template <bool BIG, class EXP, class HP> __device__ static void recordCandidateImpl(const staramd_params &P, u32 lane, const int Score, const u64 gLength, const u32 mappedLength, const u32 ne, HP hdr,
+                                                                                   const staramd_exon &x, EXP ex, WinRec &wr) {
     // ---- de-duplication against the recorded transcripts (:267-285): lane k classifies record k
     //   BLOCK  new one adds nothing to record k and scores lower  -> the walk over the list stops, new one is dropped
     //   REMOVE record k adds nothing to the new one                -> record k is removed (if met before a BLOCK)
@@ -537,9 +538,9 @@ template <bool BIG, class EXP> __device__ static void recordCandidateImpl(const 
     if (lane == 0) wr.rank[iTr] = (u16)(off / 32u);
     wr.nWinTr = newN;
     if (lane == 0) {                                  // record = output transcript header + exon rows, 8-byte words
-        typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(wr) + off); const u64 *sw = (const u64 *)&o;
+        typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(wr) + off);
 #pragma unroll
-        for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i];
+        for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = hdr[i];
     }
     if (lane < ne) {
         typename AS<BIG>::u64p d = (typename AS<BIG>::u64p)(ArenaSel<BIG>::get(wr) + off + REC_HDR + 32u * lane); const u64 *sw = (const u64 *)&x;
@@ -548,13 +549,14 @@ template <bool BIG, class EXP> __device__ static void recordCandidateImpl(const 
     if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
-template <class EXP> __device__ static void recordCandidate(const staramd_params &P, u32 lane, const staramd_transcript &o, const staramd_exon &x, EXP ex, WinRec &wr) {
-    if (wr.big) { recordCandidateImpl<true>(P, lane, o, x, ex, wr); wr.bestScore = wr.nWinTr > 0 ? recT<true>(wr, 0)->maxScore : 0; }
-    else { recordCandidateImpl<false>(P, lane, o, x, ex, wr); wr.bestScore = wr.nWinTr > 0 ? recT<false>(wr, 0)->maxScore : 0; }
+template <class EXP, class HP> __device__ static void recordCandidate(const staramd_params &P, u32 lane, const int Score, const u64 gLength, const u32 mappedLength, const u32 ne, HP hdr,
+                                                                      const staramd_exon &x, EXP ex, WinRec &wr) {
+    if (wr.big) { recordCandidateImpl<true>(P, lane, Score, gLength, mappedLength, ne, hdr, x, ex, wr); wr.bestScore = wr.nWinTr > 0 ? recT<true>(wr, 0)->maxScore : 0; }
+    else { recordCandidateImpl<false>(P, lane, Score, gLength, mappedLength, ne, hdr, x, ex, wr); wr.bestScore = wr.nWinTr > 0 ? recT<false>(wr, 0)->maxScore : 0; }
 }
 
 // leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
-__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr, const u64 glb0, const u64 glb1) {
+__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr, const u64 glb0, const u64 glb1, LDS u64 *recSlot) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
     DIAG(c.nLeaves++);
     u32 Lread = c.Lread; u32 Str = c.str;
@@ -689,17 +691,20 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
         // decided by the maxScoreMate clause alone: the decision holds for any incoming maxScoreMate <= Score + range
         if (!c1) { if (iFragT == 0) c.sens[0] = min(c.sens[0], Score + P.outFilterMultimapScoreRange); else c.sens[1] = min(c.sens[1], Score + P.outFilterMultimapScoreRange); }
     }
-    // ---- the candidate as an output record: header (wave-uniform) + this lane's exon row
-    staramd_transcript o;
-    { u64 *z = (u64 *)&o; for (u32 i = 0; i < REC_HDR / 8; i++) z[i] = 0; }          // padding included: records are compared byte for byte
-    o.iW = 0; o.exonOffset = 0;
-    o.nExons = (u16)ne; o.rStart = (u16)h.rStart; o.rLength = (u16)rLength;
-    o.roStart = (u16)((Str == 0) ? h.rStart : Lread - h.rStart - rLength);
-    o.Str = (u8)Str; o.roStr = (u8)Str; o.iFrag = (i8)iFragT; o.sjMotifStrand = sjMotifStrand; o.Chr = chr;
-    o.gStart = h.gStart; o.gLength = gLength; o.maxScore = Score; o.nMatch = h.nMatch; o.nMM = h.nMM; o.mappedLength = rLength;
-    o.nGap = h.nGap; o.lGap = h.lGap; o.nDel = h.nDel; o.lDel = h.lDel; o.nIns = h.nIns; o.lIns = h.lIns;
-    o.nUnique = (u16)h.nUnique; o.nAnchor = (u16)h.nAnchor;
-    o.intronMotifs[0] = intronMotifs[0]; o.intronMotifs[1] = intronMotifs[1]; o.intronMotifs[2] = intronMotifs[2]; o.pad0 = 0; o.pad1 = 0;
+    // ---- the candidate as an output record: header (wave-uniform) + this lane's exon row.  The header is assembled by lane 0 in a 96-byte
+    // staging slot of the wavefront's LDS slice (as a local struct it sat in scratch memory: 96 B x 64 lanes = 6 KB of HBM writes per candidate)
+    if (lane == 0) {
+        LDS staramd_transcript *o = (LDS staramd_transcript *)recSlot;
+        o->iW = 0; o->exonOffset = 0;
+        o->nExons = (u16)ne; o->rStart = (u16)h.rStart; o->rLength = (u16)rLength;
+        o->roStart = (u16)((Str == 0) ? h.rStart : Lread - h.rStart - rLength);
+        o->Str = (u8)Str; o->roStr = (u8)Str; o->iFrag = (i8)iFragT; o->sjMotifStrand = sjMotifStrand; o->Chr = chr;
+        o->gStart = h.gStart; o->gLength = gLength; o->maxScore = Score; o->nMatch = h.nMatch; o->nMM = h.nMM; o->mappedLength = rLength;
+        o->nGap = h.nGap; o->lGap = h.lGap; o->nDel = h.nDel; o->lDel = h.lDel; o->nIns = h.nIns; o->lIns = h.lIns;
+        o->nUnique = (u16)h.nUnique; o->nAnchor = (u16)h.nAnchor;
+        o->intronMotifs[0] = intronMotifs[0]; o->intronMotifs[1] = intronMotifs[1]; o->intronMotifs[2] = intronMotifs[2]; o->pad0 = 0; o->pad1 = 0;   // padding included: records are compared byte for byte
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     staramd_exon x = xe;
     if (lane < ne) {
         if (lane + 1 == ne) { x.canonSJ = 0; x.sjAnnot = 0; x.sjStr = 0; x.shiftSJ[0] = x.shiftSJ[1] = 0; }
@@ -712,26 +717,27 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
         if (c.candTop + need > c.candCap) c.logOvf = true;
         else {
             u64 *d = (u64 *)(c.candBase + c.candTop);
-            if (lane == 0) { const u64 *sw = (const u64 *)&o;
+            if (lane == 0) {
 #pragma unroll
-                for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = sw[i]; }
+                for (u32 i = 0; i < REC_HDR / 8; i++) d[i] = recSlot[i]; }
             if (lane < ne) { const u64 *sw = (const u64 *)&x; u64 *de = d + REC_HDR / 8 + 4u * lane; de[0] = sw[0]; de[1] = sw[1]; de[2] = sw[2]; de[3] = sw[3]; }
             c.candTop += need; c.nCand++;
         }
     }
     PROF_MARK(c, 15);
-    { PROF_T0(); recordCandidate(P, lane, o, x, ex, wr); PROF_ADD(c, 4); }
+    { PROF_T0(); recordCandidate(P, lane, Score, gLength, rLength, ne, recSlot, x, ex, wr); PROF_ADD(c, 4); }
 }
 
 // per-window LDS work space, in bytes: undo stack, exon rows, leaf copy, rank list, seed list (+ arena in the fast path)
+#define REC_HDR_BYTES 96u
 // seed list rows (24 B) and compat masks (8 B): as many as the launch walks at most (capDepth - 1 seeds per window), never more than WA_MAX
 __host__ __device__ inline u32 waRows(u32 capDepth) { return capDepth == 0 ? (u32)WA_MAX : (capDepth - 1u < (u32)WA_MAX ? capDepth - 1u : (u32)WA_MAX); }
 __host__ __device__ inline u32 stitchStateBytes(u32 capDepth, u32 capRank, u32 arenaBytes) {
-    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + waRows(capDepth) * 32u + arenaBytes;
+    u32 b = capDepth * (u32)sizeof(SFrame) + 2u * STARAMD_MAX_N_EXONS * 32u + ((capRank * 2u + 31u) & ~31u) + waRows(capDepth) * 32u + REC_HDR_BYTES + arenaBytes;
     return (b + 127u) & ~127u;
 }
 
-struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LDS u64 *compat; LDS u16 *rank; LDS u8 *arena; };
+struct LaneMem { LDS SFrame *stack; LDS staramd_exon *EX, *LEAF; LDS DWA *WA; LDS u64 *compat; LDS u64 *rec; LDS u16 *rank; LDS u8 *arena; };
 
 // next seed index > i whose bit is set in mask, nA if none
 __device__ __forceinline__ u32 nextSeed(u64 mask, u32 i, u32 nA) {
@@ -775,7 +781,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             if (h.tR2 != 0) {
                 if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr, glb0, glb1); PROF_ADD(c, 3); }
+                { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr, glb0, glb1, m.rec); PROF_ADD(c, 3); }
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
@@ -882,7 +888,8 @@ __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRan
     m.rank = (LDS u16 *)(m.LEAF + STARAMD_MAX_N_EXONS);
     m.WA = (LDS DWA *)((LDS u8 *)m.rank + ((capRank * 2u + 31u) & ~31u));
     m.compat = (LDS u64 *)((LDS u8 *)m.WA + waRows(capDepth) * 24u);
-    m.arena = (LDS u8 *)m.compat + waRows(capDepth) * 8u;
+    m.rec = (LDS u64 *)((LDS u8 *)m.compat + waRows(capDepth) * 8u);      // staging slot for one output record header
+    m.arena = (LDS u8 *)m.rec + REC_HDR_BYTES;
 }
 
 __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
@@ -1118,7 +1125,7 @@ __device__ static bool replayWindow(const staramd_params &P, u32 lane, const DWi
         bool c1 = Score + P.outFilterMultimapScoreRange >= winBest || P.chimSegmentMinPositive;
         bool c2 = f >= 0 && Score + P.outFilterMultimapScoreRange >= Mf;
         if (!(c1 || c2)) continue;
-        recordCandidate(P, lane, t, x, ex, wr);
+        recordCandidate(P, lane, Score, (u64)t.gLength, (u32)t.mappedLength, ne, (const u64 *)&t, x, ex, wr);
         if (wr.overflow) return false;
     }
     return true;

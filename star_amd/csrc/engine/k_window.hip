@@ -208,7 +208,11 @@ __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
 
 extern __shared__ u32 ldsTab[];     // fast pass: wavesPerBlock * capW * 8 words
 
-extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 big, u32 lightEst) {
+// mode 0: every read, table in LDS (capW rows); reads that outgrow it go to list ovfWin
+// mode 2: the reads of ovfWin, table still in LDS but with more rows (blocks of one wavefront); reads that outgrow that go to list ovfWin2
+// mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits
+extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid) {
+    const u32 big = mode == 1u ? 1u : 0u;
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
@@ -225,14 +229,15 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
 #ifdef STARAMD_PROFILE
     u64 wprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    const u32 nItems = big ? B.cursors[CUR_OVF_WIN] : B.nReads;
-    const u32 ticketSlot = big ? CUR_TICKET_WIN2 : CUR_TICKET_WIN;
+    const u32 *inList = mode == 0u ? nullptr : (mode == 2u || !useMid) ? B.ovfWin : B.ovfWin2;
+    const u32 nItems = mode == 0u ? B.nReads : (mode == 2u || !useMid) ? B.cursors[CUR_OVF_WIN] : B.cursors[CUR_OVF_WIN2];
+    const u32 ticketSlot = mode == 0u ? CUR_TICKET_WIN : mode == 2u ? CUR_TICKET_WIN2 : CUR_TICKET_WIN3;
     for (;;) {
         u32 it = 0;
         if (lane == 0) it = atomicAdd(&B.cursors[ticketSlot], 1u);
         it = first32(it);
         if (it >= nItems) break;
-        u32 ir = big ? B.ovfWin[it] : it;
+        u32 ir = inList ? inList[it] : it;
         DRead rd = B.reads[ir];
         if (rd.nSeeds == 0) continue;
         const DSeed *PC = B.seedPool + rd.seedOffset;
@@ -351,6 +356,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
         if (s.overflow) {
             if (lane == 0) {
                 if (big) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); B.reads[ir] = rd; }
+                else if (mode == 2u) { u32 k = atomicAdd(&B.cursors[CUR_OVF_WIN2], 1u); B.ovfWin2[k] = ir; }
                 else { u32 k = atomicAdd(&B.cursors[CUR_OVF_WIN], 1u); B.ovfWin[k] = ir; nOvf++; }
             }
             continue;
@@ -394,7 +400,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
     }
     if (lane == 0) {
 #ifdef STARAMD_PROFILE
-        if (!big) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof8 + k], (unsigned long long)wprof[k]);
+        if (mode == 0u) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof8 + k], (unsigned long long)wprof[k]);
 #endif
         atomicAdd((unsigned long long *)&B.counters[DC_nSAenum], (unsigned long long)nSAenum);
         atomicAdd((unsigned long long *)&B.counters[DC_nWindows], (unsigned long long)nWindows);

@@ -104,13 +104,17 @@ def test_shadow_validation(name, tmp_path, built):
 
 # Rarely taken paths of the engine, forced by shrinking its work space through the STARAMD_* knobs:
 #   tiny pools            -> bump allocators overflow, the host doubles the pool and re-runs the batch
-#   2 windows / 2 blocks  -> every read with more windows goes through the second k_windows launch (table in global memory)
+#   2 windows / 2 blocks  -> every read with more windows goes through the middle k_windows launch (larger table in LDS);
+#                            with a 3-window middle table, on to the last launch (table in global memory); with the
+#                            middle launch off, straight to the last launch
 #   256-byte record arena -> windows re-walked with the record arena in HBM
 #   tiny candidate logs   -> maxScoreMate-sensitive windows re-walked (k_stitch_win mode 1) instead of replayed
 #   every read heavy / every read light -> both kinds of stitch work items
 FORCED = {
     "tiny_pools": {"STARAMD_POOL_SLACK": "64", "STARAMD_SEEDS_PER_READ": "1", "STARAMD_WINDOWS_PER_READ": "1", "STARAMD_WA_PER_READ": "1", "STARAMD_TR_PER_READ": "1"},
     "window_overflow": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2"},
+    "window_overflow_twice": {"STARAMD_CAP_WINDOWS": "1", "STARAMD_CAP_WA_BLOCKS": "1", "STARAMD_CAP_WINDOWS_MID": "3", "STARAMD_CAP_WA_BLOCKS_MID": "3"},
+    "window_overflow_no_middle": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2", "STARAMD_CAP_WINDOWS_MID": "0"},
     "arena_overflow": {"STARAMD_STITCH_ARENA": "256"},
     "log_overflow": {"STARAMD_CAND_KB_PER_WAVE": "1"},
     "all_heavy": {"STARAMD_LIGHT_EST": "0"},
