@@ -421,6 +421,8 @@ def main():
                      "map_batch_call_s": float(rep.deviceBusy[0]), "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
                      "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                      "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
+                     "finish_s": float(rep.finishSeconds),
+                     "finish_what": "inside timed_wall_s, after the last batch: last SAM writes, junction collapse + filter + SJ.out.tab, Log.final.out",
                      "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds)},
         "index_build": ginfo, "sj_merge_ms": sj_ms.get("ms"),
     }

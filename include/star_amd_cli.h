@@ -40,6 +40,7 @@ typedef struct staramd_cli_report {
     double   parseBusy, emitBusy;  /* seconds the reader / the post-map+writer stage were busy, timed region          */
     uint64_t batches;              /* timed batches                                                                   */
     double   pass1Seconds;         /* --twopassMode Basic: 1st pass + junction insertion + index re-upload            */
+    double   finishSeconds;        /* after the last batch is handed to the writer: last writes, SJ.out.tab, Log.final.out (inside timedWall) */
 } staramd_cli_report;
 
 /* Runs the whole job; returns the process exit code (0 ok).  hooks / report may be NULL. */

@@ -119,8 +119,14 @@ struct DevBatch {
     u64 *counters;     // DC_N
 };
 
+// Index arrays and batch buffers are global memory, but their pointers are read from structures (or rebuilt from integers),
+// so the compiler knows no address space and emits flat_load; a flat access also counts against lgkmcnt and holds up
+// the waits for scalar loads and LDS.  GLOBAL(T, p) states the address space: global_load.
+#define GLOBAL(T, p) ((const __attribute__((address_space(1))) T *)(p))
+
 // ---- packed array access: PackedArray::operator[] (source/PackedArray.h:24-32) with aligned loads ----
-__device__ __forceinline__ u64 packedGet(const u64 *a, u64 i, u32 bits, u64 mask) {
+__device__ __forceinline__ u64 packedGet(const u64 *a0, u64 i, u32 bits, u64 mask) {
+    const __attribute__((address_space(1))) u64 *a = GLOBAL(u64, a0);
     u64 b = i * bits; u64 w = b >> 6; u32 s = (u32)(b & 63);
     u64 lo = a[w];
     u64 v = lo >> s;
@@ -135,7 +141,7 @@ struct GCache { i64 base; u64 word; };
 __device__ __forceinline__ void gcInit(GCache &c) { c.base = (i64)0x7fffffffffffff00ll; c.word = 0; }
 __device__ __forceinline__ u8 gcGet(const u8 *G, GCache &c, i64 pos) {
     i64 b = pos & ~7ll;
-    if (b != c.base) { c.word = *(const u64 *)(G + b); c.base = b; }
+    if (b != c.base) { c.word = *GLOBAL(u64, G + b); c.base = b; }
     return (u8)(c.word >> ((u32)(pos & 7) * 8));
 }
 

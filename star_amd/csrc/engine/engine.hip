@@ -15,6 +15,7 @@
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
 extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid);
+extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid);
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
@@ -455,7 +456,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         const u32 useMid = c->capWMid ? 1u : 0u;
         hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid);
         if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid);
-        hipLaunchKernelGGL(k_windows, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, 1u, c->lightEst, useMid);
+        hipLaunchKernelGGL(k_windows_big, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, c->lightEst, useMid);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
         hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1), 0, s, B);

@@ -17,7 +17,7 @@ struct SeedCnt { u64 nSAi, nSAprobe, nGcmp; };
 
 // 8 bytes starting at an arbitrary address, little endian, through aligned 8-byte loads (the arrays are padded)
 __device__ __forceinline__ u64 load8(const u8 *p) {
-    const u64 a = (u64)p; const u64 *q = (const u64 *)(a & ~7ull); const u32 sh = (u32)(a & 7ull) * 8u;
+    const u64 a = (u64)p; const __attribute__((address_space(1))) u64 *q = GLOBAL(u64, a & ~7ull); const u32 sh = (u32)(a & 7ull) * 8u;
     const u64 w0 = q[0];
     if (sh == 0) return w0;
     return (w0 >> sh) | (q[1] << (64u - sh));

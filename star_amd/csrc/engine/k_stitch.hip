@@ -167,11 +167,11 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
     int Score = 0;
     if (sjAB != -1 && eA.sjA == sjAB && eA.iFrag == iFragB && rBstart == rAend + 1 && gAend + 1 < gBstart) {
         // both seeds come from the same inserted sjdb sequence: the junction is the annotated one (:18-34)
-        const u32 sMotif = first32(X.sjdbMotif[sjAB]), sShL = first32(X.sjdbShiftLeft[sjAB]), sShR = first32(X.sjdbShiftRight[sjAB]);
+        const u32 sMotif = first32(GLOBAL(u8, X.sjdbMotif)[sjAB]), sShL = first32(GLOBAL(u8, X.sjdbShiftLeft)[sjAB]), sShR = first32(GLOBAL(u8, X.sjdbShiftRight)[sjAB]);
         if (sMotif == 0 && (L <= sShR || eA.L <= sShL)) return -1000006;
         eN.L = (u16)L; eN.R = (u16)rBstart; eN.G = gBstart;
         eA.canonSJ = (i8)sMotif; eA.shiftSJ[0] = (u16)sShL; eA.shiftSJ[1] = (u16)sShR;
-        eA.sjAnnot = 1; eA.sjStr = (u8)first32(X.sjdbStrand[sjAB]);
+        eA.sjAnnot = 1; eA.sjStr = (u8)first32(GLOBAL(u8, X.sjdbStrand)[sjAB]);
         added = true; h.nMatch += L;
         Score += (int)L; Score += P.sjdbScore;
     } else {
@@ -321,15 +321,15 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }
                 } else {
-                    jCan = (int)first32(X.sjdbMotif[sjdbInd]);
+                    jCan = (int)first32(GLOBAL(u8, X.sjdbMotif)[sjdbInd]);
                     if (jCan == 0) {
-                        const u32 sShL = first32(X.sjdbShiftLeft[sjdbInd]);
+                        const u32 sShL = first32(GLOBAL(u8, X.sjdbShiftLeft)[sjdbInd]);
                         if (L <= sShL || eA.L <= sShL) return -1000006;
                         jR += (int)sShL;
                         if ((u64)rAend + (i64)jR >= rBend) return -1000006;
-                        jjL = sShL; jjR = first32(X.sjdbShiftRight[sjdbInd]);
+                        jjL = sShL; jjR = first32(GLOBAL(u8, X.sjdbShiftRight)[sjdbInd]);
                     }
-                    eA.sjAnnot = 1; eA.sjStr = (u8)first32(X.sjdbStrand[sjdbInd]);
+                    eA.sjAnnot = 1; eA.sjStr = (u8)first32(GLOBAL(u8, X.sjdbStrand)[sjdbInd]);
                     Score += P.sjdbScore;
                 }
                 eA.shiftSJ[0] = (u16)jjL; eA.shiftSJ[1] = (u16)jjR; eA.canonSJ = (i8)jCan;
@@ -606,7 +606,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
     const u32 ex0R = laneGet32(xe.R, 0), exLR = laneGet32(xe.R, last), exLL = laneGet32(exL, last);
     const u32 ex0Frag = laneGet32(xe.iFrag, 0), exLFrag = laneGet32(xe.iFrag, last);
     if (!P.alignSoftClipAtReferenceEnds &&
-        ((exLG + Lread - exLR) > (X.chrStart[chr] + X.chrLength[chr]) || ex0G < (X.chrStart[chr] + ex0R))) return;
+        ((exLG + Lread - exLR) > (GLOBAL(u64, X.chrStart)[chr] + GLOBAL(u64, X.chrLength)[chr]) || ex0G < (GLOBAL(u64, X.chrStart)[chr] + ex0R))) return;
     const u32 rLength = waveSumU32(exL);
     u64 gLength = tG2 + 1 - h.gStart;
     {   // junction overhangs (:97-108)

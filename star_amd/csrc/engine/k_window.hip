@@ -35,18 +35,29 @@
 #define WPROF_MARK(k)
 #endif
 
-struct WTab {                       // per-wave window table (structure of arrays; LDS or global)
-    u32 *coreS, *coreE, *extS, *extE, *meta, *blk, *lrec, *nwa;
+// The window table is a structure of arrays that lives in LDS (first and middle launch) or in global memory (last launch).
+// The pointer type carries the address space: with plain pointers every table access compiled to a flat_load / flat_store
+// (no ds_ instruction in the whole kernel, rocprofv3 SQ_INSTS_LDS ~ 0 against 1650 flat instructions per pair).
+template <bool BIG> struct WPtr;
+template <> struct WPtr<true> { typedef u32 *P; };
+template <> struct WPtr<false> { typedef __attribute__((address_space(3))) u32 *P; };
+template <bool BIG> struct WTab {   // per-wave window table
+    typename WPtr<BIG>::P coreS, coreE, extS, extE, meta, blk, lrec, nwa;
 };
 // meta = chr << 2 | str << 1 | alive
 #define WBITS 4096u                 // per-read hash bitmap of the bins covered by windows (quick reject of loci outside every window)
-struct WS {
-    WTab t; DWA *arena; u32 *bitmap;
+template <bool BIG> struct WS {
+    WTab<BIG> t; DWA *arena; typename WPtr<BIG>::P bitmap;
     u32 nW, capW, nBlocks, capBlocks, Lread;
     bool overflow, tooMany, winLimit;
 };
 
+// after writes to the seed lists (global memory, rows exchanged between lanes): wait for them
 __device__ __forceinline__ void tabFence() { __threadfence_block(); }
+// after writes to the table only: in LDS the DS instructions of one wavefront execute in order, nothing to wait for
+template <bool BIG> __device__ __forceinline__ void rowFence() { if (BIG) __threadfence_block(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+__device__ __forceinline__ void bitOr(u32 *w, u32 v) { atomicOr(w, v); }
+__device__ __forceinline__ void bitOr(__attribute__((address_space(3))) u32 *w, u32 v) { __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // max of (key << 32 | payload) over the wave, keys distinct where non-zero: DPP max of the keys, then the payload of the
 // lane that holds the maximum
@@ -60,7 +71,7 @@ __device__ __forceinline__ u64 waveMax64(u64 v) {
 __device__ __forceinline__ u32 waveMin32(u32 v) { return ~waveMaxU32(~v); }
 
 // ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; all arguments wave-uniform; returns 1 on TOO_MANY_WINDOWS / overflow
-__device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS &s, u64 a1, u32 aStr, u32 lane) {
+template <bool BIG> __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS<BIG> &s, u64 a1, u32 aStr, u32 lane) {
     const staramd_params &P = X.P;
     u32 aBin = (u32)(a1 >> P.winBinNbits);
     u32 lo = aBin > P.winAnchorDistNbins ? aBin - P.winAnchorDistNbins : 0;
@@ -78,10 +89,10 @@ __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS &s, u64
     }
     if (__any(own)) return 0;
     candL = waveMax64(candL); candR = waveMax64(candR);
-    u32 aChr = X.chrBin[aBin >> P.winBinChrNbits];
+    u32 aChr = GLOBAL(u32, X.chrBin)[aBin >> P.winBinChrNbits];
     u32 iWinL = NOWIN, iWinR = NOWIN;
-    if (candL) { u32 ce = (u32)(candL >> 32) - 1; if (X.chrBin[ce >> P.winBinChrNbits] == aChr) iWinL = (u32)candL; }
-    if (candR) { u32 cs = ~(u32)(candR >> 32); if (X.chrBin[cs >> P.winBinChrNbits] == aChr) iWinR = (u32)candR; }
+    if (candL) { u32 ce = (u32)(candL >> 32) - 1; if (GLOBAL(u32, X.chrBin)[ce >> P.winBinChrNbits] == aChr) iWinL = (u32)candL; }
+    if (candR) { u32 cs = ~(u32)(candR >> 32); if (GLOBAL(u32, X.chrBin)[cs >> P.winBinChrNbits] == aChr) iWinR = (u32)candR; }
     if (iWinL == NOWIN && iWinR == NOWIN) {
         u32 iWin = s.nW;
         if (iWin >= s.capW) { s.overflow = true; return 1; }
@@ -91,7 +102,7 @@ __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS &s, u64
             s.t.blk[iWin] = NOWIN; s.t.lrec[iWin] = 0; s.t.nwa[iWin] = 0;
         }
         s.nW++;
-        tabFence();
+        rowFence<BIG>();
         if (s.nW >= P.alignWindowsPerReadNmax) { s.nW = P.alignWindowsPerReadNmax - 1; s.winLimit = true; return 1; }
     } else {
         u32 iWin = iWinL != NOWIN ? iWinL : iWinR;                            // left window overwrites right (:57)
@@ -101,13 +112,13 @@ __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS &s, u64
             if (iWinL != NOWIN && iWinR != NOWIN) s.t.meta[iWinR] &= ~1u;        // kill right window (:77-80)
             s.t.coreS[iWin] = binLeft; s.t.coreE[iWin] = binRight;
         }
-        tabFence();
+        rowFence<BIG>();
     }
     return 0;
 }
 
 // ReadAlign_assignAlignToWindow.cpp:6-130 ; all arguments wave-uniform; lane j holds row j of the window's list
-__device__ static void assignAlignToWindow(const DevIndex &X, WS &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
+template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X, WS<BIG> &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
     const staramd_params &P = X.P;
     u32 n = s.t.nwa[iW]; u32 lrec = s.t.lrec[iW];
     if (!aAnchor && aLength < lrec) return;
@@ -174,7 +185,7 @@ __device__ __forceinline__ bool sjAlignSplit(const DevIndex &X, u64 a1, u32 aLen
     if (sj1 < X.sjdbOverhang && sj1 + aLength > X.sjdbOverhang) {
         isj = (u32)q;
         aLengthD = (u32)(X.sjdbOverhang - sj1); aLengthA = aLength - aLengthD;
-        a1D = X.sjDstart[isj] + sj1; a1A = X.sjAstart[isj];
+        a1D = GLOBAL(u64, X.sjDstart)[isj] + sj1; a1A = GLOBAL(u64, X.sjAstart)[isj];
         return true;
     }
     return false;
@@ -184,7 +195,7 @@ __device__ __forceinline__ u32 binHash(u32 str, u32 bin) { return (bin * 2u + st
 
 // pass-B owner of a bin, wave-parallel (lane j tests window j): last flank writer wins, else the core owner
 // (ReadAlign_stitchPieces.cpp:96-118 write order)
-__device__ static u32 ownerWave(const WS &s, u32 str, u32 bin, u32 lane) {
+template <bool BIG> __device__ static u32 ownerWave(const WS<BIG> &s, u32 str, u32 bin, u32 lane) {
     u32 core = NOWIN, flank = NOWIN;
     for (u32 j0 = 0; j0 < s.nW; j0 += 64) {
         u32 j = j0 + lane; bool inExt = false, inCore = false;
@@ -206,21 +217,23 @@ __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
     return (b + 255) & ~255ull;
 }
 
-extern __shared__ u32 ldsTab[];     // fast pass: wavesPerBlock * capW * 8 words
+extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 + WBITS / 32) words
 
 // mode 0: every read, table in LDS (capW rows); reads that outgrow it go to list ovfWin
 // mode 2: the reads of ovfWin, table still in LDS but with more rows (blocks of one wavefront); reads that outgrow that go to list ovfWin2
-// mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits
-extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid) {
-    const u32 big = mode == 1u ? 1u : 0u;
+// mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits (BIG)
+template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid) {
+    const u32 big = BIG ? 1u : 0u;
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
     u32 wavesPerBlock = blockDim.x >> 6;
     u32 wave = blockIdx.x * wavesPerBlock + waveInBlock;
-    WS s;
+    WS<BIG> s;
     u8 *mine = scratch + (u64)wave * winWaveBytes(capW, capBlocks, big);
-    u32 *tab = big ? (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA)) : (ldsTab + (u64)waveInBlock * (capW * 8 + WBITS / 32));
+    typename WPtr<BIG>::P tab;
+    if constexpr (BIG) tab = (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA));
+    else tab = (typename WPtr<false>::P)ldsTab + waveInBlock * (capW * 8 + WBITS / 32);
     s.bitmap = tab + capW * 8;
     s.t.coreS = tab; s.t.coreE = tab + capW; s.t.extS = tab + 2 * capW; s.t.extE = tab + 3 * capW;
     s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + 6 * capW; s.t.nwa = tab + 7 * capW;
@@ -285,20 +298,20 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
                 if (!(m & 1u)) continue;
                 u32 chr = m >> 2;
                 u32 wb = s.t.coreS[j];
-                for (u32 ii = 0; ii < P.winFlankNbins && wb > 0 && X.chrBin[(wb - 1) >> P.winBinChrNbits] == chr; ii++) wb--;
+                for (u32 ii = 0; ii < P.winFlankNbins && wb > 0 && GLOBAL(u32, X.chrBin)[(wb - 1) >> P.winBinChrNbits] == chr; ii++) wb--;
                 s.t.extS[j] = wb;
                 wb = s.t.coreE[j];
-                for (u32 ii = 0; ii < P.winFlankNbins && (u64)wb + 1 < P.winBinN && X.chrBin[(wb + 1) >> P.winBinChrNbits] == chr; ii++) wb++;
+                for (u32 ii = 0; ii < P.winFlankNbins && (u64)wb + 1 < P.winBinN && GLOBAL(u32, X.chrBin)[(wb + 1) >> P.winBinChrNbits] == chr; ii++) wb++;
                 s.t.extE[j] = wb;
             }
             for (u32 k = lane; k < WBITS / 32; k += 64) s.bitmap[k] = 0;
-            tabFence();
+            rowFence<BIG>();
             for (u32 j = lane; j < s.nW; j += 64) {
                 u32 m = s.t.meta[j];
                 if (!(m & 1u)) continue;
-                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) { u32 hsh = binHash((m >> 1) & 1u, b); atomicOr(&s.bitmap[hsh >> 5], 1u << (hsh & 31u)); }
+                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) { u32 hsh = binHash((m >> 1) & 1u, b); bitOr(&s.bitmap[hsh >> 5], 1u << (hsh & 31u)); }
             }
-            tabFence();
+            rowFence<BIG>();
         }
         nWindows += s.nW;
         WPROF_MARK(1);
@@ -407,6 +420,16 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_windows(const DevIndex *_
         atomicAdd((unsigned long long *)&B.counters[DC_nWA], (unsigned long long)nWAtot);
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfWin], (unsigned long long)nOvf);
     }
+}
+
+#ifndef WIN_WAVES
+#define WIN_WAVES 4         // minimum waves per SIMD the register allocation of the LDS launches is held to
+#endif
+extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid) {
+    windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid);
+}
+extern "C" __global__ void __launch_bounds__(256, 4) k_windows_big(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid) {
+    windowsBody<true>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid);
 }
 
 // ---- stitch order: work items sorted by class ~ log2(estimated walk size), largest first (counting sort

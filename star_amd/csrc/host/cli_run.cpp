@@ -303,7 +303,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     int exitCode = 0;
     if (failed.load()) { fprintf(stderr, "\n%s\n", failure.c_str()); exitCode = 104; }
     else if (hooks && hooks->exchange && hooks->exchange(hooks->user, h, 1)) { fprintf(stderr, "\ncross-rank exchange failed\n"); exitCode = 104; }
-    else if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); exitCode = 104; }
+    else { const auto tf = Clock::now(); if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); exitCode = 104; } rep.finishSeconds = since(tf); }
     double sec = since(t0);
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",

@@ -7,21 +7,57 @@
 #include <fstream>
 #include <iomanip>
 #include <ctime>
+#include <cstdio>
+#include <functional>
+#include <thread>
 
 namespace staramd {
 
-void OutSJ::collapse() {
-    if (data.empty()) return;
-    std::stable_sort(data.begin(), data.end(), [](const Junction &a, const Junction &b) { return a.start != b.start ? a.start < b.start : a.gap < b.gap; });
+static inline bool sjLess(const Junction &a, const Junction &b) { return a.start != b.start ? a.start < b.start : a.gap < b.gap; }
+
+// records of one (start, gap) folded into the first: counts add up, overhangs take the maximum (Junction::collapseOneSJ, OutSJ.cpp:74-98);
+// strand / motif / annot are functions of the locus, so the order among equal keys does not matter
+static size_t foldSorted(Junction *d, size_t n) {
+    if (n == 0) return 0;
     size_t k = 0;
-    for (size_t i = 1; i < data.size(); i++) {
-        if (data[i].start == data[k].start && data[i].gap == data[k].gap) {
-            data[k].countUnique += data[i].countUnique; data[k].countMultiple += data[i].countMultiple;
-            if (data[k].overhangLeft < data[i].overhangLeft) data[k].overhangLeft = data[i].overhangLeft;
-            if (data[k].overhangRight < data[i].overhangRight) data[k].overhangRight = data[i].overhangRight;
-        } else { ++k; if (k != i) data[k] = data[i]; }
+    for (size_t i = 1; i < n; i++) {
+        if (d[i].start == d[k].start && d[i].gap == d[k].gap) {
+            d[k].countUnique += d[i].countUnique; d[k].countMultiple += d[i].countMultiple;
+            if (d[k].overhangLeft < d[i].overhangLeft) d[k].overhangLeft = d[i].overhangLeft;
+            if (d[k].overhangRight < d[i].overhangRight) d[k].overhangRight = d[i].overhangRight;
+        } else { ++k; if (k != i) d[k] = d[i]; }
     }
-    data.resize(k + 1);
+    return k + 1;
+}
+
+// OutSJ::collapseSJ (OutSJ.cpp:42-72).  A run keeps millions of records between two collapses (one per junction per read); they are
+// split into key ranges by sampled splitters, every range is sorted and folded by its own thread, the folded ranges are concatenated.
+void OutSJ::collapse() {
+    const size_t n = data.size();
+    if (n == 0) return;
+    unsigned T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 200000 || T < 2) { std::sort(data.begin(), data.end(), sjLess); data.resize(foldSorted(data.data(), n)); return; }
+    std::vector<Junction> sample;
+    const size_t nSample = 64 * T, step = n / nSample;
+    for (size_t i = 0; i < nSample; i++) sample.push_back(data[i * step]);
+    std::sort(sample.begin(), sample.end(), sjLess);
+    std::vector<Junction> split;                                  // T-1 splitters; equal keys never straddle two ranges
+    for (unsigned t = 1; t < T; t++) split.push_back(sample[t * 64]);
+    auto rangeOf = [&](const Junction &j) { return (unsigned)(std::upper_bound(split.begin(), split.end(), j, sjLess) - split.begin()); };
+    // counting scatter, the input cut into T slices
+    std::vector<std::vector<size_t>> cnt(T, std::vector<size_t>(T + 1, 0));
+    std::vector<uint8_t> rng(n);
+    auto each = [&](const std::function<void(unsigned)> &f) { std::vector<std::thread> th; for (unsigned t = 1; t < T; t++) th.emplace_back(f, t); f(0); for (auto &x : th) x.join(); };
+    each([&](unsigned t) { std::vector<size_t> c(T + 1, 0); for (size_t i = n * t / T; i < n * (t + 1) / T; i++) { unsigned r = rangeOf(data[i]); rng[i] = (uint8_t)r; c[r]++; } cnt[t] = c; });
+    std::vector<size_t> rangeStart(T + 1, 0);
+    for (unsigned r = 0; r < T; r++) { size_t tot = 0; for (unsigned t = 0; t < T; t++) { size_t c = cnt[t][r]; cnt[t][r] = rangeStart[r] + tot; tot += c; } rangeStart[r + 1] = rangeStart[r] + tot; }
+    std::vector<Junction> tmp(n);
+    each([&](unsigned t) { std::vector<size_t> pos = cnt[t]; for (size_t i = n * t / T; i < n * (t + 1) / T; i++) tmp[pos[rng[i]]++] = data[i]; });
+    std::vector<size_t> folded(T, 0);
+    each([&](unsigned r) { Junction *d = tmp.data() + rangeStart[r]; size_t m = rangeStart[r + 1] - rangeStart[r]; std::sort(d, d + m, sjLess); folded[r] = foldSorted(d, m); });
+    size_t k = 0;
+    for (unsigned r = 0; r < T; r++) { std::copy(tmp.begin() + rangeStart[r], tmp.begin() + rangeStart[r] + folded[r], data.begin() + k); k += folded[r]; }
+    data.resize(k);
 }
 
 // outputSJ.cpp:56-120: collapse, per-junction filter, then (unless `skipDistanceFilter`, 2nd stage of BySJout :84) the distance
@@ -56,7 +92,7 @@ std::vector<Junction> OutSJ::filtered(const RunParams &P, bool skipDistanceFilte
     }
     // the reference qsorts triples by the acceptor only (compareUint): ties keep an unspecified order, which cannot
     // change the outcome because equal acceptors give minDist 0 for both members of the tie
-    std::stable_sort(sjA.begin(), sjA.end(), [](const Acc &x, const Acc &y) { return x.a < y.a; });
+    std::sort(sjA.begin(), sjA.end(), [](const Acc &x, const Acc &y) { return x.a != y.a ? x.a < y.a : x.idx < y.idx; });
     for (size_t ii = 0; ii < N; ii++) {
         if (sjA[ii].motif == 8) keep[sjA[ii].idx] = 1;
         else {
@@ -82,16 +118,23 @@ std::string OutSJ::filterAndWrite(const RunParams &P, const GenomeIndex &gi, con
     std::vector<Junction> all = filtered(P, skipDistanceFilter);
     size_t N = all.size();
     std::vector<char> keep(N, 1);
-    std::ofstream out(path.c_str());
-    if (!out.good()) return "EXITING because of fatal ERROR: could not create output file " + path;
+    FILE *out = fopen(path.c_str(), "wb");
+    if (!out) return "EXITING because of fatal ERROR: could not create output file " + path;
+    // Junction::outputStream (OutSJ.cpp:100-123): decimal fields separated by tabs; formatted by hand into one buffer (half a million lines)
+    std::string buf; buf.reserve(N * 48 + 64);
+    char num[24];
+    auto dec = [&](uint64_t v) { int k = 24; do { num[--k] = (char)('0' + v % 10); v /= 10; } while (v); buf.append(num + k, 24 - k); };
+    auto sdec = [&](int v) { if (v < 0) { buf.push_back('-'); dec((uint64_t)(-(int64_t)v)); } else dec((uint64_t)v); };
     for (size_t ii = 0; ii < N; ii++) {
         if (!keep[ii]) continue;
         const Junction &j = all[ii];
         uint32_t c = gi.chrBin[j.start >> gi.view.gChrBinNbits];
-        out << gi.chrName.at(c) << "\t" << j.start + 1 - gi.chrStart[c] << "\t" << j.start + j.gap - gi.chrStart[c]
-            << "\t" << int(j.strand) << "\t" << int(j.motif) << "\t" << int(j.annot) << "\t" << j.countUnique << "\t" << j.countMultiple
-            << "\t" << j.overhangLeft << "\n";
+        buf += gi.chrName.at(c); buf.push_back('\t'); dec(j.start + 1 - gi.chrStart[c]); buf.push_back('\t'); dec(j.start + j.gap - gi.chrStart[c]);
+        buf.push_back('\t'); sdec(j.strand); buf.push_back('\t'); sdec(j.motif); buf.push_back('\t'); sdec(j.annot); buf.push_back('\t'); dec(j.countUnique);
+        buf.push_back('\t'); dec(j.countMultiple); buf.push_back('\t'); dec(j.overhangLeft); buf.push_back('\n');
     }
+    const bool ok = fwrite(buf.data(), 1, buf.size(), out) == buf.size();
+    if (fclose(out) != 0 || !ok) return "EXITING because of fatal ERROR: could not write output file " + path;
     return "";
 }
 
