@@ -391,11 +391,12 @@ def main():
     dms, dbytes = kern[dom]
     achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
     value = timed_reads_all / elapsed / 1e6
-    traffic = None
+    traffic = None; traffic_all = None
     try:        # HBM traffic of the dominant kernel from rocprofv3 --pmc passes (profiles/README.md); only when taken on THIS engine build and workload size
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
         if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads:
             traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
     except Exception:
         traffic = None
     device_s = float(rep.deviceMs[0]) / 1e3
@@ -412,7 +413,7 @@ def main():
                    "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads,
                    "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
+                     "traffic": traffic, "traffic_per_kernel": traffic_all, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
                      "algorithmic_bytes_per_pair_whole_path": bytes_per_pair,
                      "note": "per launch = per batch of %d pairs, averaged over the %d timed batches of rank 0 (HIP events on the engine's stream)" % (args.reads, int(rep.batches))},
         "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},

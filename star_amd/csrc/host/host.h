@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <atomic>
 #include <array>
 #include <cstdio>
 #include <istream>
@@ -208,6 +209,7 @@ public:
     uint64_t readsSoFar = 0;
 private:
     FILE *f[2] = {nullptr, nullptr};
+    std::atomic<uint64_t> slicedBlocks{0};           // blocks of a regular file read in slices on threads (reads.cpp fill)
     int nMates = 0;
     std::vector<std::string> paths_; std::string command_;
     std::vector<std::string> files_[2]; size_t curFile = 0;

@@ -8,6 +8,8 @@
 // found with memchr, and the records of a batch are converted on --runThreadN threads.  The batch keeps the text itself;
 // names, sequences and qualities are spans into it (nothing is copied per read until the SAM line is formatted).
 #include "host.h"
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstring>
 #include <algorithm>
 #include <thread>
@@ -88,6 +90,8 @@ std::string FastqReader::reopen() {
     lastExtra[0].clear(); lastExtra[1].clear();    // the next pass runs on fresh ReadAlign objects
     return open(paths_, command_, samMates_);      // first file again (a pipe cannot be rewound: the command is run again)
 }
+
+static bool isRegularFile(FILE *f) { struct stat st; return f && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode); }
 
 // offsets of the '\n' bytes in [p+from, p+to), appended to `out` until `out` holds `maxOut` entries; returns the offset where
 // the scan stopped.  32 bytes per step when the CPU has AVX2 (lines are ~100 bytes: one memchr call per line is mostly call overhead).
@@ -257,6 +261,7 @@ uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
     carry[m].clear();
     uint64_t scanned = 0;
     const uint64_t wantLines = want * 4;
+    static const uint64_t sliceMin = getenv("STARAMD_READ_SLICE_MIN") ? strtoull(getenv("STARAMD_READ_SLICE_MIN"), nullptr, 10) : (8u << 20);   // (tests lower it)
     for (;;) {
         scanned = scanNewlines(text.data(), scanned, text.size(), le, wantLines);
         if (le.size() >= wantLines || eof[m]) break;
@@ -267,6 +272,36 @@ uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
         text.resize(old + block);
         size_t got;
         if (fromMemory) { got = std::min<size_t>(block, mem[m].size() - memPos[m]); memcpy(text.data() + old, mem[m].data() + memPos[m], got); memPos[m] += got; }
+        else if (block >= sliceMin && isRegularFile(f[m])) {
+            // a regular file (not a pipe of --readFilesCommand): the block is cut into slices that threads read at their own positions
+            // and scan for line ends; one thread copies ~100 MB per batch and mate at memcpy speed, which is most of the parse time
+            const unsigned K = 4;
+            const off_t pos0 = ftello(f[m]);
+            const int fd = fileno(f[m]);
+            std::vector<std::vector<uint64_t>> nl(K);
+            std::vector<size_t> gotK(K, 0);
+            std::vector<std::thread> th;
+            const size_t per = (block + K - 1) / K;
+            auto slice = [&](unsigned k) {
+                const size_t lo = std::min<size_t>(block, k * per), hi = std::min<size_t>(block, lo + per);
+                size_t done = 0;
+                while (lo + done < hi) { ssize_t r = pread(fd, text.data() + old + lo + done, hi - lo - done, pos0 + (off_t)(lo + done)); if (r <= 0) break; done += (size_t)r; }
+                gotK[k] = done;
+                nl[k].reserve((size_t)((double)done / bytesPerRecord[m] * 4.2) + 16);
+                scanNewlines(text.data(), old + lo, old + lo + done, nl[k], UINT64_MAX);
+            };
+            for (unsigned k = 1; k < K; k++) th.emplace_back(slice, k);
+            slice(0);
+            for (auto &x : th) x.join();
+            got = 0;
+            for (unsigned k = 0; k < K; k++) { got += gotK[k]; if (gotK[k] < std::min<size_t>(block, (k + 1) * per) - std::min<size_t>(block, k * per)) break; }   // a short slice ends the input
+            fseeko(f[m], pos0 + (off_t)got, SEEK_SET);
+            // everything before `old` has been scanned; the line ends of the slices follow in order
+            for (unsigned k = 0; k < K && le.size() < wantLines; k++)
+                for (uint64_t e : nl[k]) { if (e >= old + got || le.size() >= wantLines) break; le.push_back(e); }
+            scanned = le.size() >= wantLines ? le.back() + 1 : old + got;
+            slicedBlocks++;
+        }
         else got = fread(text.data() + old, 1, block, f[m]);      // (fread itself loops over short pipe reads until EOF)
         text.resize(old + got);
         if (got < block) eof[m] = true;
@@ -322,6 +357,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
         break;
     }
     lap("fill");
+    if (timing) fprintf(stderr, "  parse blocks read in slices so far: %llu\n", (unsigned long long)slicedBlocks.load());
     // records of mate 1 decide the batch; an empty ID line ends the input
     uint64_t n = nLines[0] / 4;
     bool partial = nLines[0] % 4 != 0;

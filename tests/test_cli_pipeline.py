@@ -31,7 +31,7 @@ def test_cli_pipeline_multi_device(name, more, batch, devices, tmp_path, built):
     run_cli_case(CLI, name, more + ["--gpuDevices", devices], batch, tmp_path)
 
 
-def run_cli_case(cli, name, more, batch, tmp_path, fastq_hook=None):
+def run_cli_case(cli, name, more, batch, tmp_path, fastq_hook=None, env=None):
     """one run of a command-line front end (`cli`) against one run of the reference with the same flags: every output file"""
     info = dict(prepare(name, str(tmp_path), need_ref=False))
     d = os.path.dirname(info["fastq"][0])
@@ -51,7 +51,8 @@ def run_cli_case(cli, name, more, batch, tmp_path, fastq_hook=None):
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=rf)
     new = os.path.join(d, "cli_")
     p = subprocess.run([cli, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] +
-                       ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + rf + cli_only, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                       ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", str(batch)] + rf + cli_only, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, **env) if env else None)
     assert p.returncode == 0, p.stderr[-1500:]
     n = 0
     for f in sorted(os.listdir(d)):
@@ -80,3 +81,10 @@ def run_cli_case(cli, name, more, batch, tmp_path, fastq_hook=None):
 @pytest.mark.parametrize("name,more,batch", CASES)
 def test_cli_pipeline(name, more, batch, tmp_path, built):
     run_cli_case(CLI, name, more, batch, tmp_path)
+
+
+@pytest.mark.parametrize("batch", [700, 333, 5000])
+def test_cli_pipeline_sliced_input(batch, tmp_path, built):
+    """FastqReader::fill reads a block of a regular file in four slices on threads (positional reads, line ends found per slice); the threshold
+    is lowered so that every block of these small inputs takes that path: batches that end inside a slice, a carry, a short last block"""
+    run_cli_case(CLI, "pe101", ["--outSAMunmapped", "Within"], batch, tmp_path, env={"STARAMD_READ_SLICE_MIN": "1"})
