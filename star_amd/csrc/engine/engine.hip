@@ -14,7 +14,7 @@
 
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
-extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid);
+extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);
 extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid);
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
@@ -62,7 +62,7 @@ struct staramd_ctx {
     // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
-    u32 winBlocksMid = 0, capWMid = 0, capBlocksMid = 0; u8 *scrWinMid = nullptr;
+    u32 winBlocksMid = 0, capWMid = 0, capBlocksMid = 0, hashBitsMid = 65536; u8 *scrWinMid = nullptr;
     // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
     u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
     u32 stBlocks = 0, stBlocksBig = 0, replayBlocks = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
@@ -248,6 +248,10 @@ static int allocWork(staramd_ctx *c) {
     c->capWMid = envU32("STARAMD_CAP_WINDOWS_MID", 1024); c->capBlocksMid = envU32("STARAMD_CAP_WA_BLOCKS_MID", 1024);
     if (c->capWMid <= c->capW || c->capWMid >= P.alignWindowsPerReadNmax) c->capWMid = 0;
     if (c->capWMid) {
+        u32 hb = envU32("STARAMD_WIN_HASH_BITS_MID", 65536);
+        c->hashBitsMid = 4096; while (c->hashBitsMid < hb && c->hashBitsMid < (1u << 18)) c->hashBitsMid <<= 1;       // a power of two
+        while (c->hashBitsMid > 4096 && ((u64)c->capWMid * 8 + c->hashBitsMid / 32) * 4 > 65536) c->hashBitsMid >>= 1;   // table + map within 64 KB of dynamic LDS
+        if (((u64)c->capWMid * 8 + c->hashBitsMid / 32) * 4 > 65536) c->capWMid = (65536 / 4 - c->hashBitsMid / 32) / 8;
         c->winBlocksMid = envU32("STARAMD_WIN_BLOCKS_MID", (u32)c->nCU * 4u);
         if ((rc = devAlloc(R, &c->scrWinMid, (u64)c->winBlocksMid * winWaveBytesH(c->capWMid, c->capBlocksMid, 0)))) return rc;
     }
@@ -454,8 +458,8 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
         const u32 useMid = c->capWMid ? 1u : 0u;
-        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid);
-        if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid);
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, 4096u);
+        if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + c->hashBitsMid / 32) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid, c->hashBitsMid);
         hipLaunchKernelGGL(k_windows_big, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, c->lightEst, useMid);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);

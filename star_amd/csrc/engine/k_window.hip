@@ -45,10 +45,12 @@ template <bool BIG> struct WTab {   // per-wave window table
     typename WPtr<BIG>::P coreS, coreE, extS, extE, meta, blk, lrec, nwa;
 };
 // meta = chr << 2 | str << 1 | alive
-#define WBITS 4096u                 // per-read hash bitmap of the bins covered by windows (quick reject of loci outside every window)
+#define WBITS 4096u                 // per-read hash bitmap of the bins covered by windows (quick reject of loci outside every window): bits in the first and last launch
 template <bool BIG> struct WS {
     WTab<BIG> t; DWA *arena; typename WPtr<BIG>::P bitmap;
     u32 nW, capW, nBlocks, capBlocks, Lread;
+    u32 hashMask;                   // bits of the bitmap - 1 (a power of two; the middle launch has 16x the bits: its reads cover thousands of bins,
+                                    // a 4096-bit map is saturated and every locus of a 10000-fold seed would go through the serial owner lookup)
     bool overflow, tooMany, winLimit;
 };
 
@@ -191,7 +193,7 @@ __device__ __forceinline__ bool sjAlignSplit(const DevIndex &X, u64 a1, u32 aLen
     return false;
 }
 
-__device__ __forceinline__ u32 binHash(u32 str, u32 bin) { return (bin * 2u + str) & (WBITS - 1u); }
+__device__ __forceinline__ u32 binHash(u32 str, u32 bin, u32 mask) { return (bin * 2u + str) & mask; }
 
 // pass-B owner of a bin, wave-parallel (lane j tests window j): last flank writer wins, else the core owner
 // (ReadAlign_stitchPieces.cpp:96-118 write order)
@@ -217,12 +219,12 @@ __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
     return (b + 255) & ~255ull;
 }
 
-extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 + WBITS / 32) words
+extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 + hashBits / 32) words
 
 // mode 0: every read, table in LDS (capW rows); reads that outgrow it go to list ovfWin
 // mode 2: the reads of ovfWin, table still in LDS but with more rows (blocks of one wavefront); reads that outgrow that go to list ovfWin2
 // mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits (BIG)
-template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid) {
+template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
     const u32 big = BIG ? 1u : 0u;
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
@@ -233,7 +235,8 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
     u8 *mine = scratch + (u64)wave * winWaveBytes(capW, capBlocks, big);
     typename WPtr<BIG>::P tab;
     if constexpr (BIG) tab = (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA));
-    else tab = (typename WPtr<false>::P)ldsTab + waveInBlock * (capW * 8 + WBITS / 32);
+    else tab = (typename WPtr<false>::P)ldsTab + waveInBlock * (capW * 8 + hashBits / 32);
+    s.hashMask = hashBits - 1u;
     s.bitmap = tab + capW * 8;
     s.t.coreS = tab; s.t.coreE = tab + capW; s.t.extS = tab + 2 * capW; s.t.extE = tab + 3 * capW;
     s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + 6 * capW; s.t.nwa = tab + 7 * capW;
@@ -304,12 +307,12 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 for (u32 ii = 0; ii < P.winFlankNbins && (u64)wb + 1 < P.winBinN && GLOBAL(u32, X.chrBin)[(wb + 1) >> P.winBinChrNbits] == chr; ii++) wb++;
                 s.t.extE[j] = wb;
             }
-            for (u32 k = lane; k < WBITS / 32; k += 64) s.bitmap[k] = 0;
+            for (u32 k = lane; k < hashBits / 32; k += 64) s.bitmap[k] = 0;
             rowFence<BIG>();
             for (u32 j = lane; j < s.nW; j += 64) {
                 u32 m = s.t.meta[j];
                 if (!(m & 1u)) continue;
-                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) { u32 hsh = binHash((m >> 1) & 1u, b); bitOr(&s.bitmap[hsh >> 5], 1u << (hsh & 31u)); }
+                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) { u32 hsh = binHash((m >> 1) & 1u, b, s.hashMask); bitOr(&s.bitmap[hsh >> 5], 1u << (hsh & 31u)); }
             }
             rowFence<BIG>();
         }
@@ -336,13 +339,13 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                         if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
                             split = true; a1 = a1D;
                             binD = (u32)(a1D >> P.winBinNbits); binA = (u32)(a1A >> P.winBinNbits); lStr = aStr;
-                            u32 hD = binHash(aStr, binD), hA = binHash(aStr, binA);
+                            u32 hD = binHash(aStr, binD, s.hashMask), hA = binHash(aStr, binA, s.hashMask);
                             candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u; candA = (s.bitmap[hA >> 5] >> (hA & 31u)) & 1u;
                         }
                     } else {
                         lD = aLength;
                         binD = (u32)(a1 >> P.winBinNbits); lStr = aStr;
-                        u32 hD = binHash(aStr, binD);
+                        u32 hD = binHash(aStr, binD, s.hashMask);
                         candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u;
                     }
                 }
@@ -425,11 +428,11 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
 #ifndef WIN_WAVES
 #define WIN_WAVES 4         // minimum waves per SIMD the register allocation of the LDS launches is held to
 #endif
-extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid) {
-    windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid);
+extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
+    windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits);
 }
 extern "C" __global__ void __launch_bounds__(256, 4) k_windows_big(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid) {
-    windowsBody<true>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid);
+    windowsBody<true>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid, WBITS);
 }
 
 // ---- stitch order: work items sorted by class ~ log2(estimated walk size), largest first (counting sort
