@@ -239,7 +239,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->capW = envU32("STARAMD_CAP_WINDOWS", 192); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
+    c->capW = envU32("STARAMD_CAP_WINDOWS", 256); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
     int winPerCU = 3;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * (c->capW * 8 + 128) * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
     c->winBlocks = (u32)c->nCU * envU32("STARAMD_WIN_BLOCKS_PER_CU", (u32)winPerCU);
