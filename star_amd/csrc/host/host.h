@@ -359,6 +359,7 @@ public:
         std::string *chimJunction = nullptr;             // Chimeric.out.junction lines (--chimSegmentMin > 0); non-null switches the detection on
         std::string *chimSam = nullptr;                  // Chimeric.out.sam records (--chimOutType SeparateSAMold)
         std::string *quantBam = nullptr; std::vector<QuantPatch> *quantPatches = nullptr;   // --quantMode TranscriptomeSAM records
+        int *waspEnd = nullptr;                          // vW the read after this range would inherit if it were a chimera in the BAM
     };
     // what the batch brings along besides its own alignments
     struct RangeIn {
@@ -366,6 +367,7 @@ public:
         bool dry = false;                                // no alignment records, only the side outputs asked for
         const MergedBatch *merged = nullptr; const staramd_results *mergedRes = nullptr;   // --peOverlapNbasesMin: merged mates and their alignments
         const std::vector<int8_t> *waspType = nullptr;   // vW per read (--waspOutputMode SAMtag)
+        bool *probeChimBam = nullptr;                    // internal: only decide whether the (one) read of the range is a chimera that goes to the BAM
     };
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, const RangeOut &out, const RangeIn &in) const;
     std::string processRange(const ReadBatch &b, const staramd_results &r, uint32_t lo, uint32_t hi, const RangeOut &out) const;
@@ -393,7 +395,7 @@ public:
     std::string quantBamHeader() const;              // samHeaders.cpp:8-20
     std::string samHeader() const;                   // samHeaders.cpp:27-106
     std::string bamHeader(bool sortedByCoordinate = false) const;                   // outBAMwriteHeader, BAMfunctions.cpp:83-98 (uncompressed bytes)
-    int waspCarry = -1;                              // vW of the last read of the batch before (see processRange)
+    int waspCarry = -1;                              // vW a chimeric first read of the batch inherits from the batch before (see processRange)
     bool samOff = false;                             // 1st pass of 2-pass mapping: no SAM text (twoPassRunPass1.cpp:18-22)
 private:
     const RunParams &P;

@@ -92,12 +92,15 @@ std::string RunParams::parse(int argc, char **argv) {
         if (v.size() != 1) { err = "EXITING: fatal input ERROR: --" + k + " expects exactly one value"; return empty; }
         return v[0];
     };
-    auto U = [&](const std::string &k, const std::vector<std::string> &v) { return (uint64_t)strtoull(one(k, v).c_str(), nullptr, 10); };
-    auto I = [&](const std::string &k, const std::vector<std::string> &v) { return (int64_t)strtoll(one(k, v).c_str(), nullptr, 10); };
-    auto D = [&](const std::string &k, const std::vector<std::string> &v) { return strtod(one(k, v).c_str(), nullptr); };
+    // numbers: the reference reads them with operator>> and carries on with 0 after a failed conversion; a value that is not a number is
+    // reported here instead (negative values of unsigned parameters wrap around exactly as they do there)
+    auto notNumber = [&](const std::string &k, const std::string &t) { if (err.empty()) err = "EXITING: fatal input ERROR: --" + k + " expects a number, not \"" + t + "\"\nSOLUTION: check the value of --" + k + "\n"; };
+    auto U = [&](const std::string &k, const std::vector<std::string> &v) { const std::string &t = one(k, v); char *e = nullptr; uint64_t x = strtoull(t.c_str(), &e, 10); if (!err.empty()) return (uint64_t)0; if (t.empty() || *e) notNumber(k, t); return x; };
+    auto I = [&](const std::string &k, const std::vector<std::string> &v) { const std::string &t = one(k, v); char *e = nullptr; int64_t x = strtoll(t.c_str(), &e, 10); if (!err.empty()) return (int64_t)0; if (t.empty() || *e) notNumber(k, t); return x; };
+    auto D = [&](const std::string &k, const std::vector<std::string> &v) { const std::string &t = one(k, v); char *e = nullptr; double x = strtod(t.c_str(), &e); if (!err.empty()) return 0.0; if (t.empty() || *e) notNumber(k, t); return x; };
     auto I4 = [&](const std::string &k, const std::vector<std::string> &v, int32_t *out) {
         if (v.size() != 4) { err = "EXITING: fatal input ERROR: --" + k + " expects 4 values"; return; }
-        for (int j = 0; j < 4; j++) out[j] = (int32_t)strtol(v[j].c_str(), nullptr, 10);
+        for (int j = 0; j < 4; j++) { char *e = nullptr; out[j] = (int32_t)strtol(v[j].c_str(), &e, 10); if (v[j].empty() || *e) notNumber(k, v[j]); }
     };
     std::string alignEndsType = "Local";
     std::map<std::string, std::vector<std::string> > clipArgs;
@@ -279,7 +282,6 @@ std::string RunParams::parse(int argc, char **argv) {
         else if (k == "gpuResultSelect") { const std::string &s = one(k, v); if (s == "All") dev.resultSelect = 0; else if (s == "Selected") dev.resultSelect = 1; else err = "EXITING: --gpuResultSelect takes All or Selected"; }
         else if (k == "outFilterIntronMotifs") { const std::string &s = one(k, v); if (s == "None") dev.outFilterIntronMotifs = 0; else if (s == "RemoveNoncanonical") dev.outFilterIntronMotifs = 1; else if (s == "RemoveNoncanonicalUnannotated") dev.outFilterIntronMotifs = 2; else err = "EXITING because of FATAL INPUT error: unrecognized value of --outFilterIntronMotifs=" + s; }
         else if (k == "outFilterIntronStrands") { const std::string &s = one(k, v); if (s == "RemoveInconsistentStrands") dev.outFilterIntronStrandsRemoveInconsistent = 1; else if (s == "None") dev.outFilterIntronStrandsRemoveInconsistent = 0; else err = "EXITING: unsupported --outFilterIntronStrands " + s; }
-        else if (k == "outSJtype") { if (one(k, v) != "Standard") err = "EXITING: only --outSJtype Standard is implemented"; }
         else if (k == "outSJfilterReads") { const std::string &s = one(k, v); if (s == "Unique") outSJfilterReadsUnique = true; else if (s != "All") err = "EXITING: unsupported --outSJfilterReads " + s; }
         else if (k == "outSJfilterOverhangMin") I4(k, v, outSJfilterOverhangMin);
         else if (k == "outSJfilterCountUniqueMin") I4(k, v, outSJfilterCountUniqueMin);
@@ -384,7 +386,7 @@ std::string RunParams::parse(int argc, char **argv) {
             outSAMattrRG.push_back(rg.substr(3, t == std::string::npos ? std::string::npos : t - 3));
         }
         if (names[0].empty()) return "EXITING because of FATAL INPUT FILE error: readFileManifest file " + readFilesManifest + " has no lines";
-        const int nEnds = names[1][0].back() == '-' ? 1 : 2;
+        const int nEnds = (!names[1][0].empty() && names[1][0].back() == '-') ? 1 : 2;      // (an empty 2nd column is a missing file name, reported when it is opened)
         readFilesIn.assign(nEnds, "");
         for (int im = 0; im < nEnds; im++) for (size_t i = 0; i < names[im].size(); i++) readFilesIn[im] += (i ? "," : "") + names[im][i];
     }

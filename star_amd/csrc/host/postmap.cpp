@@ -806,6 +806,22 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
     const bool samOff = this->samOff || dry;
     std::vector<TrView> trMult;
     int waspPrev = -1;
+    if (waspType && !in.probeChimBam) {
+        // The BAM records of a chimeric read (--chimOutType WithinBAM) show the verdict of the read BEFORE it (ReadAlign_oneRead.cpp:99-103:
+        // waspMap does not run for such a read) -- i.e. of the nearest earlier read that was not such a read itself.  Ranges of a batch run
+        // on threads: the reads in front of this range are probed (chimeric detection only, no output) until one of the ordinary kind is found.
+        int64_t j = (int64_t)lo - 1;
+        if (P.chim.outBam && chimJunction)
+            for (; j >= 0; j--) {
+                bool chimBam = false;
+                std::string sam0, cj0; OutSJ sj0; Stats st0;
+                RangeOut po; po.sam = &sam0; po.sj = &sj0; po.st = &st0; po.chimJunction = &cj0;
+                RangeIn pi = in; pi.dry = true; pi.probeChimBam = &chimBam;
+                processRange(b, r, (uint32_t)j, (uint32_t)j + 1, po, pi);
+                if (!chimBam) break;
+            }
+        waspPrev = j >= 0 ? (*waspType)[j] : waspCarry;
+    }
     for (uint32_t ir = lo; ir < hi; ir++) {
         const staramd_read_result &rr = r.reads[ir];
         if (rr.status & STARAMD_ST_FATAL_SEEDS_PER_READ)
@@ -821,7 +837,6 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         }
         rc.waspType = waspType ? (*waspType)[ir] : -1;
         const int waspOfRead = rc.waspType;
-        if (waspType && ir == lo) waspPrev = lo > 0 ? (*waspType)[lo - 1] : waspCarry;
         st.readN++; st.readBases += rc.readLength[0] + rc.readLength[1];
         const staramd_transcript *T = r.tr + rr.trOffset;
         const staramd_exon *EX = r.ex;
@@ -896,6 +911,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
                 chimRecord = chimericDetectionMult(P, gi, b, ir, ra, trBest, *chimJunction, cpp);
             if (chimRecord) st.chimericAll++;
         }
+        if (in.probeChimBam) { *in.probeChimBam = chimRecord && P.chim.outBam; return ""; }
         if (chimRecord && P.chim.outSamOld && chimSam) for (const ChimPair &cp : chimPairs) chimSamOldOutput(*chimSam, P, gi, rc, cp);
         if (chimRecord && P.chim.outBam) rc.waspType = waspPrev;     // waspMap does not run for such a read: its records show the verdict of the read before it (ReadAlign_oneRead.cpp:99-103)
         else waspPrev = waspOfRead;
@@ -976,6 +992,7 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
             }
         }
     }
+    if (out.waspEnd) *out.waspEnd = waspPrev;
     return "";
 }
 

@@ -313,6 +313,7 @@ struct Runner {
         }
         static const bool hostTiming = getenv("STARAMD_HOST_TIMING") != nullptr;
         std::vector<double> tThread(hostTiming ? T : 0);
+        int waspEndOfBatch = post->waspCarry;
         auto work = [&](uint32_t t) {
             struct Tm { std::vector<double> &v; uint32_t t; std::chrono::steady_clock::time_point t0; ~Tm() { if (!v.empty()) v[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } tm{tThread, t, std::chrono::steady_clock::now()};
             uint32_t lo = std::min(bt.n, t * per), hi = std::min(bt.n, lo + per);
@@ -336,6 +337,7 @@ struct Runner {
             if (trSAM) { ro.quantBam = &qraws[t]; ro.quantPatches = &qpatches[t]; }
             PostMap::RangeIn ri;
             ri.order = randomOrder ? &multOrder : nullptr; ri.merged = mg; ri.mergedRes = mgRes; ri.waspType = waspType;
+            if (waspType && hi == bt.n && lo < hi) ro.waspEnd = &waspEndOfBatch;     // (one range ends the batch)
             errs[t] = post->processRange(bt, *r, lo, hi, ro, ri);
             if (!bamOut) return;
             bool cut = false;
@@ -406,7 +408,7 @@ struct Runner {
             }
             if (sj1.data.size() > 4000000) sj1.collapse();
         }
-        if (waspType && !waspType->empty()) post->waspCarry = waspType->back();
+        if (waspType && !waspType->empty()) post->waspCarry = waspEndOfBatch;
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
         return true;

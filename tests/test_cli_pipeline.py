@@ -88,3 +88,34 @@ def test_cli_pipeline_sliced_input(batch, tmp_path, built):
     """FastqReader::fill reads a block of a regular file in four slices on threads (positional reads, line ends found per slice); the threshold
     is lowered so that every block of these small inputs takes that path: batches that end inside a slice, a carry, a short last block"""
     run_cli_case(CLI, "pe101", ["--outSAMunmapped", "Within"], batch, tmp_path, env={"STARAMD_READ_SLICE_MIN": "1"})
+
+
+CHIM_WASP = ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--chimOutType", "WithinBAM", "--outSAMtype", "BAM", "Unsorted",
+             "--waspOutputMode", "SAMtag", "--varVCFfile", "VCF", "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG", "vW"]
+
+
+def _chimeras_in_runs(info, d):
+    """the input re-ordered so that its (few) chimeric reads follow one another in two runs: a chimera in the BAM then inherits its vW from
+    a read several places back, across range and batch boundaries"""
+    pre = refstar.align(info["idx"], info["fastq"], os.path.join(d, "pre_"), threads=1, extra=list(info["extra"]) + ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"])
+    chim = {l.split("\t")[9] for l in open(pre + "Chimeric.out.junction") if not l.startswith("#") and not l.startswith("chr_donorA")}
+    assert len(chim) >= 6
+    out = []
+    for m, f in enumerate(info["fastq"]):
+        L = open(f).read().split("\n")
+        recs = ["\n".join(L[i:i + 4]) for i in range(0, len(L) - 3, 4)]
+        is_chim = [r.split()[0][1:].split("/")[0] in chim for r in recs]
+        c = [r for r, x in zip(recs, is_chim) if x]; o = [r for r, x in zip(recs, is_chim) if not x]
+        assert len(c) >= 6
+        order = o[:21] + c[:len(c) // 2] + o[21:24] + c[len(c) // 2:] + o[24:]
+        g = os.path.join(d, "runs_%d.fq" % (m + 1))
+        open(g, "w").write("\n".join(order) + "\n")
+        out.append(g)
+    return out
+
+
+@pytest.mark.parametrize("batch", [8, 97, 2000])
+def test_cli_pipeline_wasp_verdict_on_chimeric_bam_records(batch, tmp_path, built):
+    """vW on the BAM records of a chimeric read is the verdict of the nearest earlier read that was not itself a chimera in the BAM
+    (ReadAlign_oneRead.cpp:99-103), whatever the batch and thread boundaries in between (the carried value)"""
+    run_cli_case(CLI, "pe150_chim", CHIM_WASP, batch, tmp_path, fastq_hook=_chimeras_in_runs)

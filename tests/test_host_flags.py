@@ -330,3 +330,16 @@ def test_output_directory_is_created(tmp_path, built):
     run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", prefix])
     run.close()
     assert os.path.isdir(str(tmp_path / "a" / "b")) and os.path.exists(prefix + "Log.out")
+
+
+def test_numeric_flags_are_validated(tmp_path, built):
+    """a value that is not a number is an input error (the reference's operator>> would carry on with 0); ADVICE round 1"""
+    info = prepare("se50", str(tmp_path), need_ref=False)
+    base = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "v_")]
+    for flags, word in [(["--runThreadN", "abc"], "runThreadN"), (["--outFilterMismatchNoverLmax", "0.3x"], "outFilterMismatchNoverLmax"),
+                        (["--outFilterMultimapNmax", "ten"], "outFilterMultimapNmax"), (["--outSJfilterOverhangMin", "30", "12", "12", "x"], "outSJfilterOverhangMin")]:
+        with pytest.raises(RuntimeError) as e:
+            capi.HostRun(base + flags)
+        assert "expects a number" in str(e.value) and word in str(e.value), str(e.value)
+    run = capi.HostRun(base + ["--outFilterMismatchNoverLmax", "3e-1", "--readMapNumber", "-1"])     # still numbers
+    run.close()
