@@ -44,7 +44,10 @@ struct Runner {
     FILE *chimSamOut = nullptr;                     // Chimeric.out.sam (--chimOutType SeparateSAMold)
     FILE *unmappedOut[2] = {nullptr, nullptr};      // --outReadsUnmapped Fastx: Unmapped.out.mate1 / mate2
     std::string error;
-    std::string parseError;             // set by the reader thread of the pipelined front end only (sah_parse_slot); `error` belongs to the emit / control side
+    // three stages of the pipelined front end run on their own threads; each reports through a string of its own (guarded by errM), and
+    // sah_error hands the calling thread a private copy: parseError -- reader (sah_parse_slot), mapError -- mapper threads (sah_wasp_results_slot),
+    // `error` -- the emit / control side (one thread at a time)
+    std::string parseError, mapError; std::mutex errM;
     SjdbLoci sjdbLoci;                  // junctions known so far (generated genome, --sjdbFileChrStartEnd, 1st pass)
     std::string insertLog;
     bool pass1 = false;
@@ -607,7 +610,7 @@ int sah_wasp_slot(void *h, int slot, const staramd_results *res, staramd_batch *
 int sah_wasp_results_slot(void *h, int slot, const staramd_results *res, const staramd_results *resWasp) {
     Runner *r = (Runner *)h;
     if (!r->P.wasp || r->pass1) return 0;
-    if (r->waspSlots[slot].reads.n > 0) { if (!resWasp) { r->error = "EXITING because of FATAL ERROR: --waspOutputMode: results of the re-mapped reads are missing"; return -1; } r->waspSlots[slot].finish(r->P, r->slots[slot], *res, *resWasp); }
+    if (r->waspSlots[slot].reads.n > 0) { if (!resWasp) { std::lock_guard<std::mutex> l(r->errM); r->mapError = "EXITING because of FATAL ERROR: --waspOutputMode: results of the re-mapped reads are missing"; return -1; } r->waspSlots[slot].finish(r->P, r->slots[slot], *res, *resWasp); }
     return 0;
 }
 int sah_merged_slot(void *h, int slot, staramd_batch *out) { Runner *r = (Runner *)h; if (!(r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) || r->mergedSlots[slot].reads.n == 0) return 0; if (out) *out = r->mergedSlots[slot].reads.view(); return (int)r->mergedSlots[slot].reads.n; }
@@ -621,7 +624,7 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
     Runner *r = (Runner *)h;
     std::string err;
     bool ok = r->reader.nextBatch(r->slots[slot], r->P, maxReads, err);
-    if (!err.empty()) { r->parseError = err; return -1; }
+    if (!err.empty()) { std::lock_guard<std::mutex> l(r->errM); r->parseError = err; return -1; }
     if (!ok) return 0;
     if (out) *out = r->slots[slot].view();
     if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
@@ -724,7 +727,13 @@ int sah_stats_import_add(void *h, const uint64_t *in) {
     s.add(a);
     return 0;
 }
-const char *sah_error(void *h) { Runner *r = (Runner *)h; return !r->parseError.empty() ? r->parseError.c_str() : r->error.c_str(); }
+const char *sah_error(void *h) {
+    Runner *r = (Runner *)h;
+    static thread_local std::string mine;
+    std::lock_guard<std::mutex> l(r->errM);
+    if (!r->parseError.empty()) mine = r->parseError; else if (!r->mapError.empty()) mine = r->mapError; else return r->error.c_str();
+    return mine.c_str();
+}
 void sah_destroy(void *h) { delete (Runner *)h; }
 
 }
