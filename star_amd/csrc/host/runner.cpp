@@ -499,6 +499,12 @@ struct Runner {
         return 0;
     }
     bool finish() {
+        // SJ.out.tab (collapse of the junction table, filters, half a million lines) does not depend on the last writes of the alignments:
+        // it is produced on a thread of its own while the writer drains (outputSJ.cpp:84,129; STAR.cpp:251)
+        std::string sjError;
+        std::thread sjThread;
+        if (!P.outSJnone) sjThread = std::thread([&] { sjError = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2); });
+        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } joinSj{sjThread};
         stopWriter();
         for (FILE *&u : unmappedOut) if (u) { fclose(u); u = nullptr; }
         if (chimSamOut) { fclose(chimSamOut); chimSamOut = nullptr; }
@@ -517,7 +523,8 @@ struct Runner {
             samOut = nullptr;
         }
         if (P.outBAMcoord && !P.outSAMnone) { error = writeSortedBam(); if (!error.empty()) return false; }
-        if (!P.outSJnone) error = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2);     // outputSJ.cpp:84,129; STAR.cpp:251
+        if (sjThread.joinable()) sjThread.join();
+        error = sjError;
         if (!error.empty()) return false;
         stats.reportFinal(P.outFileNamePrefix + "Log.final.out");
         for (const char *f : {"Log.out", "Log.progress.out"}) { FILE *l = fopen((P.outFileNamePrefix + f).c_str(), "ab"); if (l) { fputs("ALL DONE!\n", l); fclose(l); } }
