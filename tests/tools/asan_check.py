@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Memory / undefined-behaviour check of the host side (CPU): main.cpp + the host library + the oracle behind the engine's C ABI (oracle/cli_shim.cpp), built into
 one binary with -fsanitize=address,undefined and run over feature-rich flag sets and odd inputs (SAM text, multi-line FASTA, several files, edge reads).
-usage: tests/tools/asan_check.py      (exit code 1 when a sanitizer reports anything)"""
+usage: tests/tools/asan_check.py [thread]     (exit code 1 when a sanitizer reports anything; `thread` builds with -fsanitize=thread instead:
+the reader / mapper / post-map / writer threads of the front end, the sliced input reads, the threaded junction collapse)"""
 import glob
 import os
 import subprocess
@@ -15,8 +16,11 @@ import test_fasta_reads, test_output_options, test_sam_reads, test_wasp   # noqa
 
 work = tempfile.mkdtemp(prefix="asan_")
 cli = os.path.join(work, "cli")
-subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread", "-mavx2"] + sorted(glob.glob(os.path.join(ROOT, "star_amd/csrc/host/*.cpp")))
-                      + [os.path.join(ROOT, "oracle/cli_shim.cpp"), os.path.join(ROOT, "oracle/star_oracle.cpp"), "-o", cli, "-lz"])
+TSAN = len(sys.argv) > 1 and sys.argv[1] == "thread"
+subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread" if TSAN else "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread", "-mavx2", "-DSTARAMD_NO_RESIDENT_SJDB",
+                       "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "star_amd/csrc")]
+                      + sorted(glob.glob(os.path.join(ROOT, "star_amd/csrc/host/*.cpp")))
+                      + [os.path.join(ROOT, "oracle/cli_shim.cpp"), os.path.join(ROOT, "oracle/star_oracle.cpp"), os.path.join(ROOT, "oracle/index_emul.cpp"), "-o", cli, "-lz"])
 reports = 0
 
 
@@ -24,8 +28,10 @@ def run(tag, info, fq, flags):
     global reports
     d = os.path.dirname(info["fastq"][0])
     r = subprocess.run([cli, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(d, "asan_%s_" % tag), "--runThreadN", "3", "--gpuBatchReads", "600"] + flags,
-                       stderr=subprocess.PIPE, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
-    bad = [l for l in r.stderr.decode().split("\n") if "ERROR: AddressSanitizer" in l or "runtime error" in l]
+                       stderr=subprocess.PIPE, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1"))
+    bad = [l for l in r.stderr.decode().split("\n") if "ERROR: AddressSanitizer" in l or "runtime error" in l or "WARNING: ThreadSanitizer" in l]
+    if bad and TSAN:
+        open(os.path.join(work, "tsan_%s.log" % tag), "wb").write(r.stderr)
     print("%-10s rc %d, sanitizer reports: %d" % (tag, r.returncode, len(bad)))
     for l in bad[:8]:
         print("    " + l[:240])
@@ -45,5 +51,5 @@ run("edge_reads", b, list(make_edge_reads(b, db, paired=True)), ["--outSAMunmapp
 c = dict(prepare("pe150_chim", os.path.join(work, "c"), need_ref=False)); dc = os.path.dirname(c["fastq"][0])
 run("wasp_chim", c, c["fastq"], ["--chimSegmentMin", "12", "--chimOutType", "WithinBAM", "SeparateSAMold", "Junctions", "--waspOutputMode", "SAMtag", "--varVCFfile", test_wasp._vcf(c, dc),
                                  "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG", "rB", "cN", "MC", "NM", "MD", "--outSAMtype", "BAM", "SortedByCoordinate", "--outWigType", "bedGraph"])
-print("%d problem(s)" % reports)
+print("%d problem(s); work directory %s" % (reports, work))
 sys.exit(1 if reports else 0)
