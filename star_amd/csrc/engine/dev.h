@@ -145,6 +145,15 @@ __device__ __forceinline__ u8 gcGet(const u8 *G, GCache &c, i64 pos) {
     return (u8)(c.word >> ((u32)(pos & 7) * 8));
 }
 
+// LOCKSTEP(): marks a place where the lanes of a wavefront exchange data through memory and rely on executing in lock step (all lanes
+// have done what precedes before any lane does what follows; LDS and L1 serve one wavefront in order).  Nothing on the device.  The
+// wavefront emulator of the CPU tests (oracle/wave_emul/emu.h) runs the lanes one after the other and makes it a rendezvous.
+#ifdef STARAMD_WAVE_EMUL
+#define LOCKSTEP() emu_wave_sync()
+#else
+#define LOCKSTEP() ((void)0)
+#endif
+
 // ---- wave helpers (wave = 64 lanes on gfx950) ----
 __device__ __forceinline__ u32 laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u32 bcast32(u32 v, u32 srcLane) { return (u32)__shfl((int)v, (int)srcLane, 64); }

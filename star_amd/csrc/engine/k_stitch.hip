@@ -533,6 +533,7 @@ template <bool BIG, class EXP, class HP> __device__ static void recordCandidateI
         int k = top - (int)lane;
         u16 v = 0; bool mv = k > (int)iTr;
         if (mv) v = wr.rank[k - 1];
+        LOCKSTEP();                               // every lane has read its entry before its neighbour overwrites it
         if (mv) wr.rank[k] = v;
     }
     if (lane == 0) wr.rank[iTr] = (u16)(off / 32u);

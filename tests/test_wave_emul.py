@@ -1,0 +1,66 @@
+"""The kernel SOURCES of the engine (star_amd/csrc/engine/*.hip) executed on the CPU by the wavefront emulator (oracle/wave_emul/emu.h: one fiber per
+work-item, cross-lane operations as rendezvous of the 64 lanes) and compared with the oracle, result buffer by result buffer, byte for byte.
+This is the `-m "not gpu"` twin of tests/test_gpu_parity.py: seed search, window building, the wave-cooperative stitcher, verify / replay / finish and the
+result gather run exactly as written, including the rarely taken paths forced through the STARAMD_* knobs.  What it cannot show is what only hardware
+shows (memory ordering, address spaces, occupancy, speed) -- that is the `-m gpu` suite.
+
+Every case runs with the lanes of a wavefront scheduled in ascending and in descending order between two rendezvous: the results must not depend on
+it.  A dependence means that lanes hand data to one another through memory and rely on running in lock step; the place gets a LOCKSTEP() (dev.h),
+which is nothing on the device and a rendezvous here."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from util import refstar
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(ROOT, "oracle", "_build", "libstaramd_emul.so")
+SELFTEST = os.path.join(ROOT, "oracle", "_build", "wave_emul_selftest")
+pytestmark = pytest.mark.skipif(not refstar.have_ref() or not os.path.exists(LIB), reason="oracle/_ref/STAR (index generation) or oracle/_build/libstaramd_emul.so not built")
+
+
+def _run(dataset, n, more, tmp_path, env=None, order="asc"):
+    e = dict(os.environ, **(env or {}))
+    e["STARAMD_EMUL_ORDER"] = order
+    p = subprocess.run([sys.executable, os.path.join(HERE, "emul_run.py"), dataset, str(tmp_path), str(n)] + more, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    last = (p.stdout.strip().splitlines() or [""])[-1]
+    assert p.returncode == 0 and last.startswith("OK"), (last, p.stderr[-1500:])
+
+
+def test_primitives(built):
+    p = subprocess.run([SELFTEST], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0 and "primitives OK" in p.stdout, p.stdout + p.stderr
+
+
+# (data set, reads, flags): the read counts stop short of the few reads of each set whose walks take minutes in the emulator
+CASES = [("se50", 150, []), ("pe101", 40, []), ("pe101", 25, ["--gpuResultSelect", "All"]), ("pe150_indel", 12, []), ("pe76_overlap", 40, []),
+         ("pe150_chim", 20, ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"])]
+
+
+@pytest.mark.parametrize("order", ["asc", "desc"])
+@pytest.mark.parametrize("dataset,n,more", CASES)
+def test_kernels_match_oracle(dataset, n, more, order, tmp_path, built):
+    _run(dataset, n, more, tmp_path, order=order)
+
+
+# the rarely taken paths of tests/test_gpu_parity.py::test_forced_rare_paths (same knobs)
+FORCED = {
+    "tiny_pools": {"STARAMD_POOL_SLACK": "64", "STARAMD_SEEDS_PER_READ": "1", "STARAMD_WINDOWS_PER_READ": "1", "STARAMD_WA_PER_READ": "1", "STARAMD_TR_PER_READ": "1"},
+    "window_overflow": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2"},
+    "window_overflow_twice": {"STARAMD_CAP_WINDOWS": "1", "STARAMD_CAP_WA_BLOCKS": "1", "STARAMD_CAP_WINDOWS_MID": "3", "STARAMD_CAP_WA_BLOCKS_MID": "3"},
+    "window_overflow_no_middle": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2", "STARAMD_CAP_WINDOWS_MID": "0"},
+    "arena_overflow": {"STARAMD_STITCH_ARENA": "256"},
+    "log_overflow": {"STARAMD_CAND_KB_PER_WAVE": "1"},
+    "all_heavy": {"STARAMD_LIGHT_EST": "0"},
+    "all_light": {"STARAMD_LIGHT_EST": "4000000000"},
+    "no_pruning": {"STARAMD_PRUNE": "0"},
+}
+
+
+@pytest.mark.parametrize("case", sorted(FORCED))
+def test_forced_rare_paths(case, tmp_path, built):
+    _run("pe101", 25, ["--gpuResultSelect", "All"], tmp_path / "a", env=FORCED[case], order="asc")
+    _run("pe101", 30, [], tmp_path / "b", env=FORCED[case], order="desc")
