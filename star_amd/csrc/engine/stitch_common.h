@@ -37,6 +37,11 @@ struct StitchCtx {
 };
 
 __device__ __forceinline__ u8 rdNib(const StitchCtx &c, u32 j) {
+#ifdef STARAMD_WAVE_EMUL
+    // coopExtend evaluates 64 positions at once; the lanes behind the position that ends the scan (mate spacer, end of the piece) may index past the
+    // read -- their values are masked out.  The LDS of the device answers an out-of-range read with 0; host memory does not.
+    if (j >= c.Lread + 1u) return 0;
+#endif
     u8 b = ((const __attribute__((address_space(3))) u8 *)ldsReads)[c.ldsByte + (j >> 1)];
     return (j & 1) ? (u8)(b >> 4) : (u8)(b & 15);
 }

@@ -2,11 +2,20 @@
 """GPU side of the bug hunt (needs an MI355X): random data sets and random HOT-PATH flags, the HIP engine's result buffers against the oracle's, byte for
 byte -- every read result, transcript and exon record, in both result-selection modes, including the second batch of merged mates and clipped / 0-length mates.
 The oracle side of the same combinations is pinned against the reference by tests/tools/fuzz_flags.py on CPU.
-usage (on the GPU box): python tests/tools/fuzz_engine.py [iterations] [seed]         e.g.  gpurun --timeout 900 -- 'python tests/tools/fuzz_engine.py 60 1 > gpurun_out/fuzz_engine.log 2>&1'"""
+usage (on the GPU box): python tests/tools/fuzz_engine.py [iterations] [seed]         e.g.  gpurun --timeout 900 -- 'python tests/tools/fuzz_engine.py 60 1 > gpurun_out/fuzz_engine.log 2>&1'
+On a machine WITHOUT a GPU:  FUZZ_EMUL=1 python tests/tools/fuzz_engine.py [iterations] [seed]  runs the same combinations through the wavefront emulator
+(oracle/_build/libstaramd_emul.so: the kernel sources compiled for the host) on the first FUZZ_EMUL_READS (40) reads of every data set, one process per
+combination with a time limit (a few reads take minutes in the emulator: such a combination is reported as skipped)."""
 import os
 import random
+import subprocess
 import sys
 import tempfile
+
+EMUL = os.environ.get("FUZZ_EMUL") == "1"
+EMUL_READS = int(os.environ.get("FUZZ_EMUL_READS", "40"))
+if EMUL:
+    os.environ["STARAMD_ENGINE_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_build", "libstaramd_emul.so")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -58,6 +67,8 @@ def one(it, rng):
             fl = [fl[0], fl[1], fl[1] if rng.random() < 0.5 else "0"] if fl[1] != "AGATCGGAAG" else [fl[0], fl[1], "-", "--clip3pAdapterMMp", "0.1", "0.1"]
         flags += fl
     flags += ["--gpuResultSelect", rng.choice(["All", "Selected"])]
+    if EMUL:
+        flags = ["--readMapNumber", str(EMUL_READS)] + flags
     tag = "%s %s" % (name, " ".join(info["extra"] + flags))
     print("run  [%d] %s" % (it, tag), flush=True)
     run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", os.path.join(work, "x_")] + info["extra"] + flags)
@@ -97,6 +108,28 @@ def one(it, rng):
     print(("FAIL [%d] %s\n      %s\n      kept in %s" % (it, tag, bad, work)) if bad else ("ok   [%d]" % it), flush=True)
     return bad is None
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--one":          # one combination of the emulator mode, in a process of its own
+    it, seed = int(sys.argv[2]), int(sys.argv[3])
+    sys.exit(0 if one(it, random.Random(seed * 100003 + it)) else 1)
+
+if __name__ == "__main__" and EMUL:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = slow = 0
+    for i in range(n):
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(i), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=int(os.environ.get("FUZZ_EMUL_TIMEOUT", "240")))
+            out = p.stdout.strip().splitlines()
+            print("\n".join(l for l in out if l.startswith(("run ", "ok ", "FAIL", "      "))), flush=True)
+            if p.returncode != 0:
+                bad += 1
+                if not any(l.startswith("FAIL") for l in out):
+                    print("FAIL [%d] exit code %d\n%s" % (i, p.returncode, "\n".join(out[-8:])), flush=True)
+        except subprocess.TimeoutExpired:
+            slow += 1; print("skip [%d] over the time limit in the emulator" % i, flush=True)
+    print("%d of %d combinations differ (%d skipped as too slow for the emulator)" % (bad, n, slow))
+    sys.exit(1 if bad else 0)
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
