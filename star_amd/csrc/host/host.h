@@ -139,14 +139,25 @@ struct RunParams {
     void finalize(const GenomeIndex &gi);
 };
 
+// Text of a batch: a vector whose resize() does not write zeros into the ~100 MB that a read from the input file overwrites at once
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }                                  // default-initialised: left as it is
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<char, NoInitAlloc<char>> TextBuf;
+
+
 // ---- one batch of reads in the layout of staramd_batch + the text needed for SAM ----
 struct TextSpan { uint64_t off; uint32_t len; };
 struct ReadBatch {
     uint32_t n = 0;
-    std::vector<uint8_t> bases;           // combined numeric reads
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> bases;   // combined numeric reads (every byte is written by the parser: no zero fill on resize)
     std::vector<uint64_t> readOffset;     // n+1
     std::vector<uint16_t> mate1Length, mmMaxTotal;
-    std::vector<char> text[2];            // the FASTQ text of the batch as read from each mate file; the spans below point into it
+    TextBuf text[2];                      // the FASTQ text of the batch as read from each mate file; the spans below point into it
     std::vector<TextSpan> nameSpan;       // read ID without '@', trimmed at readNameSeparator (from mate 1's ID line)
     std::vector<TextSpan> seqSpan[2], qualSpan[2];
     std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
@@ -222,13 +233,13 @@ private:
     std::vector<uint64_t> lineStart[2], lineEnd[2];
     bool noQualities = false;             // held FASTA reads (2nd stage of BySJout)
     int samMates_ = 0; bool extras = false;   // SAM text input (ReadAlignChunk_processChunks.cpp:28-107); ID lines may carry attributes after a \x01
-    std::vector<char> samText2; std::vector<uint64_t> samLs2, samLe2;   // mate 2 of the records fillSam parsed for mate 1
-    uint64_t fillSam(uint64_t want, std::vector<char> &text);
+    TextBuf samText2; std::vector<uint64_t> samLs2, samLe2;   // mate 2 of the records fillSam parsed for mate 1
+    uint64_t fillSam(uint64_t want, TextBuf &text);
     std::string samError; uint64_t firstFlag = 0; std::string lastExtra[2];
     bool fasta = false;                   // '>' records, possibly with the sequence over several lines (ReadAlignChunk_processChunks.cpp:158-190)
-    uint64_t fillFasta(int m, uint64_t want, std::vector<char> &text);
+    uint64_t fillFasta(int m, uint64_t want, TextBuf &text);
     // moves text of up to `want` records into `text`; fills lineStart/lineEnd; returns the number of complete lines
-    uint64_t fill(int m, uint64_t want, std::vector<char> &text);
+    uint64_t fill(int m, uint64_t want, TextBuf &text);
 };
 
 // ---- junction insertion into the loaded index (sjdb_insert.cpp) ----

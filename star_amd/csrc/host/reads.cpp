@@ -123,7 +123,7 @@ static uint64_t scanNewlines(const char *p, uint64_t from, uint64_t to, std::vec
 
 // FASTA reads: every record is rewritten as four lines (ID, the sequence on one line, +, a quality line of 'A's as readLoad.cpp:84-88 assigns) so that the
 // rest of the batcher is the same for both formats; ReadBatch::fasta tells the writers that there are no real qualities
-uint64_t FastqReader::fillFasta(int m, uint64_t want, std::vector<char> &text) {
+uint64_t FastqReader::fillFasta(int m, uint64_t want, TextBuf &text) {
     std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
     ls.clear(); le.clear(); text.clear();
     std::vector<char> &raw = carry[m];              // unparsed input text
@@ -177,9 +177,9 @@ uint64_t FastqReader::fillFasta(int m, uint64_t want, std::vector<char> &text) {
 // SAM text input (--readFilesType SAM SE|PE, ReadAlignChunk_processChunks.cpp:28-107): header lines skipped; one record per mate, the two of a pair on
 // consecutive lines; sequences of reverse-strand records are turned back; the attributes go onto the ID line (after a \x01 here) and come out again with
 // every alignment of the read.  Rewritten as four-line records for both mates at once; fill(1) hands out mate 2.
-uint64_t FastqReader::fillSam(uint64_t want, std::vector<char> &text) {
+uint64_t FastqReader::fillSam(uint64_t want, TextBuf &text) {
     std::vector<uint64_t> *LS[2] = {&lineStart[0], &samLs2}, *LE[2] = {&lineEnd[0], &samLe2};
-    std::vector<char> *TX[2] = {&text, &samText2};
+    TextBuf *TX[2] = {&text, &samText2};
     for (int m = 0; m < 2; m++) { LS[m]->clear(); LE[m]->clear(); TX[m]->clear(); }
     std::vector<char> &raw = carry[0];
     size_t p = 0; uint64_t nRec = 0;
@@ -248,7 +248,7 @@ uint64_t FastqReader::fillSam(uint64_t want, std::vector<char> &text) {
     return LS[0]->size();
 }
 
-uint64_t FastqReader::fill(int m, uint64_t want, std::vector<char> &text) {
+uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
     if (samMates_ > 0) {
         if (m == 0) return fillSam(want, text);
         text.swap(samText2); lineStart[1].swap(samLs2); lineEnd[1].swap(samLe2);
