@@ -39,6 +39,16 @@ emu_switch:
 
 extern thread_local uint32_t ldsTab[], ldsReads[];       // emu_lds.cpp
 
+// AddressSanitizer build (oracle/wave_emul/build.sh asan): the sanitizer has to be told about every change of stack
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void **fakeStackSave, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fakeStackSave, const void **bottomOld, size_t *sizeOld);
+extern "C" void __asan_unpoison_memory_region(void const volatile *addr, size_t size);
+#endif
+#endif
+
 namespace emu {
 
 thread_local Fiber *cur = nullptr;
@@ -70,6 +80,19 @@ static Sched &sched() { if (!S) S = new Sched(); return *S; }
 
 // A lane that has to wait hands over to the next live lane of its wavefront directly; the last one of the pass returns to the scheduler
 // (which looks for progress, other wavefronts, the end of the block).
+#ifdef EMU_ASAN
+static thread_local const void *mainStackBottom = nullptr; static thread_local size_t mainStackSize = 0;
+static void switchStacks(void **saveSp, void *loadSp, Fiber *to) {           // to == nullptr: back to the scheduler's (the OS thread's) stack
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, to ? (const char *)to->stack : (const char *)mainStackBottom, to ? STACK_BYTES : mainStackSize);
+    emu_switch(saveSp, loadSp);
+    const void *b; size_t n; __sanitizer_finish_switch_fiber(fake, &b, &n);
+    if (!mainStackBottom && b) { mainStackBottom = b; mainStackSize = n; }
+}
+#else
+static inline void switchStacks(void **saveSp, void *loadSp, Fiber *) { emu_switch(saveSp, loadSp); }
+#endif
+
 static void yield() {
     Sched &s = *S; Fiber *f = cur;
     const unsigned t = f->tIdx.x, lo = t & ~63u, hi = std::min<unsigned>((unsigned)s.fibers.size(), lo + 64);
@@ -77,11 +100,14 @@ static void yield() {
     if (!s.descending) { for (unsigned k = t + 1; k < hi; k++) if (!s.fibers[k].done) { nxt = &s.fibers[k]; break; } }
     else { for (unsigned k = t; k-- > lo;) if (!s.fibers[k].done) { nxt = &s.fibers[k]; break; } }
     s.switches++;
-    if (nxt) { cur = nxt; emu_switch(&f->sp, nxt->sp); }
-    else { cur = nullptr; emu_switch(&f->sp, s.mainSp); }
+    if (nxt) { cur = nxt; switchStacks(&f->sp, nxt->sp, nxt); }
+    else { cur = nullptr; switchStacks(&f->sp, s.mainSp, nullptr); }
 }
 
 static void fiberEntry() {
+#ifdef EMU_ASAN
+    { const void *b; size_t n; __sanitizer_finish_switch_fiber(nullptr, &b, &n); if (!mainStackBottom && b) { mainStackBottom = b; mainStackSize = n; } }   // first time on this stack
+#endif
     Sched &s = *S; Fiber *f = cur;
     (*s.body)();
     f->done = true;
@@ -89,7 +115,7 @@ static void fiberEntry() {
     f->block->alive--; s.left--;
     s.progress++;
     cur = nullptr;
-    emu_switch(&f->sp, s.mainSp);
+    switchStacks(&f->sp, s.mainSp, nullptr);
     abort();                                   // a finished fiber is never resumed
 }
 
@@ -192,6 +218,9 @@ void launch(const char *name, Dim3 grid, Dim3 block, size_t shmemBytes, const st
             f.lane = t & 63; f.wave = &s.waves[t >> 6]; f.block = &s.block;
             f.wave->nLanes++; f.wave->active |= 1ull << f.lane;
             f.stack = s.stacks[t];
+#ifdef EMU_ASAN
+            __asan_unpoison_memory_region((char *)f.stack + 4096, STACK_BYTES - 4096);      // a work-item that left its kernel never unwound its frames: their red zones are stale
+#endif
             // initial frame: six callee-saved registers, then the address `ret` jumps to; at fiberEntry the stack is 8 mod 16 as after a call
             uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
             uint64_t *slot = (uint64_t *)(top - 16);
@@ -215,7 +244,7 @@ void launch(const char *name, Dim3 grid, Dim3 block, size_t shmemBytes, const st
                     else { for (unsigned k = hi; k-- > lo;) if (!s.fibers[k].done) { first = &s.fibers[k]; break; } }
                     if (!first) break;
                     cur = first; s.switches++;
-                    emu_switch(&s.mainSp, first->sp);
+                    switchStacks(&s.mainSp, first->sp, first);
                     cur = nullptr;
                     if (s.limit && s.switches - switches0 > s.limit) die("STARAMD_EMUL_MAX_SWITCHES exceeded in one launch");
                     if (s.progress == b2) break;

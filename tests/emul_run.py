@@ -7,7 +7,7 @@ import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-os.environ["STARAMD_ENGINE_LIB"] = os.path.join(os.path.dirname(HERE), "oracle", "_build", "libstaramd_emul.so")
+os.environ["STARAMD_ENGINE_LIB"] = os.environ.get("STARAMD_EMUL_LIB") or os.path.join(os.path.dirname(HERE), "oracle", "_build", "libstaramd_emul.so")     # STARAMD_EMUL_LIB: the AddressSanitizer build
 sys.path.insert(0, HERE)
 from util import capi, oracle_lib, prepare  # noqa: E402
 
