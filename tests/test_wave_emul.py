@@ -19,7 +19,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(ROOT, "oracle", "_build", "libstaramd_emul.so")
 SELFTEST = os.path.join(ROOT, "oracle", "_build", "wave_emul_selftest")
-pytestmark = pytest.mark.skipif(not refstar.have_ref() or not os.path.exists(LIB), reason="oracle/_ref/STAR (index generation) or oracle/_build/libstaramd_emul.so not built")
+CLANG = os.environ.get("EMUL_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+pytestmark = pytest.mark.skipif(not refstar.have_ref() or not os.path.exists(CLANG), reason="oracle/_ref/STAR (index generation) or the host clang++ of ROCm missing")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emul_lib(built):
+    """the emulated engine is (re)built from the kernel sources as they are now"""
+    import fcntl
+    os.makedirs(os.path.join(ROOT, "oracle", "_build"), exist_ok=True)
+    with open(os.path.join(ROOT, "oracle", "_build", ".emul.lock"), "w") as lock:          # (pytest-xdist workers would build side by side)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "oracle/_build/libstaramd_emul.so"], cwd=ROOT)
+    assert os.path.exists(LIB) and os.path.exists(SELFTEST)
 
 
 def _run(dataset, n, more, tmp_path, env=None, order="asc"):
