@@ -119,7 +119,8 @@ if __name__ == "__main__" and EMUL:
     bad = slow = 0
     for i in range(n):
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(i), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=int(os.environ.get("FUZZ_EMUL_TIMEOUT", "240")))
+            env = dict(os.environ, STARAMD_EMUL_ORDER="desc" if i % 2 else "asc")       # the lanes of a wavefront scheduled in either order: the results must not depend on it
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(i), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=int(os.environ.get("FUZZ_EMUL_TIMEOUT", "240")))
             out = p.stdout.strip().splitlines()
             print("\n".join(l for l in out if l.startswith(("run ", "ok ", "FAIL", "      "))), flush=True)
             if p.returncode != 0:
