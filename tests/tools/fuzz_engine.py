@@ -15,7 +15,7 @@ import tempfile
 EMUL = os.environ.get("FUZZ_EMUL") == "1"
 EMUL_READS = int(os.environ.get("FUZZ_EMUL_READS", "40"))
 if EMUL:
-    os.environ["STARAMD_ENGINE_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_build", "libstaramd_emul.so")
+    os.environ["STARAMD_ENGINE_LIB"] = os.environ.get("STARAMD_EMUL_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_build", "libstaramd_emul.so")    # STARAMD_EMUL_LIB: a variant build (oracle/wave_emul/build.sh variant ...)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
