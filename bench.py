@@ -343,7 +343,11 @@ def main():
     outp = os.path.join(run_dir, "gpu_r%d_" % rank)
     threads = args.host_threads or max(4, min(64, (os.cpu_count() or 8) // world))
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", outp, "--runThreadN", str(threads),
-            "--gpuBatchReads", str(args.reads), "--gpuDevice", str(local_rank), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
+    # experiment knob (default 1 = the measured configuration): STARAMD_BENCH_CONTEXTS=2 runs two engine contexts on the rank's GPU (two mapper
+    # threads, two index replicas): the copies and the low-occupancy tails of one batch overlap with the kernels of the other
+    n_ctx = max(1, int(os.environ.get("STARAMD_BENCH_CONTEXTS", "1")))
+    argv += ["--gpuDevice", str(local_rank)] if n_ctx == 1 else ["--gpuDevices", ",".join([str(local_rank)] * n_ctx)]
     t_clock = {}
 
     def warmup_done():
@@ -399,7 +403,7 @@ def main():
             traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
     except Exception:
         traffic = None
-    device_s = float(rep.deviceMs[0]) / 1e3
+    device_s = sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nDevices)))) / 1e3
     out = {
         "metric": "million reads aligned/sec (whole node), 2x101 bp PE human-scale index, FASTQ in -> SAM out",
         "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -419,7 +423,7 @@ def main():
         "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
         "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s": device_s, "device_resident_Mreads_s": n / device_s / 1e6 if device_s > 0 else None,
                      "cli_over_device": device_s / float(rep.timedWall) if rep.timedWall > 0 else None,
-                     "map_batch_call_s": float(rep.deviceBusy[0]), "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
+                     "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(max(1, int(rep.nDevices)))), "engine_contexts_per_gpu": n_ctx, "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
                      "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                      "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                      "finish_s": float(rep.finishSeconds),
