@@ -121,6 +121,7 @@ static void fiberEntry() {
 
 static void die(const char *what) {
     Sched &s = *S;
+    if (s.hashLog) fflush(s.hashLog);
     fprintf(stderr, "wave emulator: %s\n", what);
     for (size_t i = 0; i < s.fibers.size() && i < 256; i++) { const Fiber &f = s.fibers[i]; if (!f.done) fprintf(stderr, "  thread %3zu (block %u): seq %llu waiting for %s\n", i, f.bIdx.x, (unsigned long long)f.seq, f.waitingFor ? f.waitingFor : "-"); }
     abort();
@@ -146,7 +147,12 @@ __attribute__((noinline)) Exchange exchange(uint32_t v, int kind) {
                 kindName(kind), (unsigned long)((uintptr_t)site - (uintptr_t)b.dli_fbase), kindName(r.kind), (unsigned long)((uintptr_t)r.site - (uintptr_t)a.dli_fbase));
         f->waitingFor = kindName(kind); die("lanes of one wavefront reached different cross-lane operations (divergent control flow around a wave operation)");
     }
-    else if (r.kind != kind) { f->waitingFor = kindName(kind); die("lanes of one wavefront reached different cross-lane operations (divergent control flow around a wave operation)"); }
+    else if (r.kind != kind) {
+        Dl_info a, b; memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b)); dladdr(r.site, &a); dladdr(site, &b);
+        fprintf(stderr, "wave emulator: %s, operation %llu of wavefront %u: lane %u is at a %s (lib+0x%lx), an earlier lane at a %s (lib+0x%lx)\n", s.kernel, (unsigned long long)q, f->tIdx.x >> 6, f->lane,
+                kindName(kind), (unsigned long)((uintptr_t)site - (uintptr_t)b.dli_fbase), kindName(r.kind), (unsigned long)((uintptr_t)r.site - (uintptr_t)a.dli_fbase));
+        f->waitingFor = kindName(kind); die("lanes of one wavefront reached different cross-lane operations (divergent control flow around a wave operation)");
+    }
     r.val[f->lane] = v; r.arrived++; s.progress++;
     f->waitingFor = kindName(kind);
     while (r.arrived < (unsigned)__builtin_popcountll(w.active)) yield();

@@ -128,6 +128,7 @@ template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X
     if (b == NOWIN) {
         if (s.nBlocks >= s.capBlocks) { s.overflow = true; return; }
         b = s.nBlocks++;
+        LOCKSTEP();                               // every lane has read blk[iW] (and counted the block) before lane 0 fills it in
         if (lane == 0) s.t.blk[iW] = b;
     }
     DWA *A = s.arena + (u64)b * WA_MAX;
