@@ -64,6 +64,7 @@ FORCED = {
     "window_overflow": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2"},
     "window_overflow_twice": {"STARAMD_CAP_WINDOWS": "1", "STARAMD_CAP_WA_BLOCKS": "1", "STARAMD_CAP_WINDOWS_MID": "3", "STARAMD_CAP_WA_BLOCKS_MID": "3"},
     "window_overflow_no_middle": {"STARAMD_CAP_WINDOWS": "2", "STARAMD_CAP_WA_BLOCKS": "2", "STARAMD_CAP_WINDOWS_MID": "0"},
+    "block_overflow": {"STARAMD_CAP_WA_BLOCKS": "2", "STARAMD_CAP_WA_BLOCKS_MID": "3"},      # seed-list blocks run out before table rows do (first and middle launch)
     "arena_overflow": {"STARAMD_STITCH_ARENA": "256"},
     "log_overflow": {"STARAMD_CAND_KB_PER_WAVE": "1"},
     "all_heavy": {"STARAMD_LIGHT_EST": "0"},
