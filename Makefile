@@ -34,7 +34,7 @@ all: host engine shadow cli oracle
 host: star_amd/lib/libstaramd_host.so
 engine: star_amd/lib/libstaramd.so
 cli: star_amd/bin/star_amd star_amd/lib/libstaramd_cli.so
-oracle: oracle/_build/liboracle.so oracle/_build/libindex_emul.so oracle/_build/star_amd_oracle_cli oracle/_build/libstaramd_cli_oracle.so oracle/_build/libstaramd_emul.so
+oracle: oracle/_build/liboracle.so oracle/_build/libindex_emul.so oracle/_build/star_amd_oracle_cli oracle/_build/libstaramd_cli_oracle.so oracle/_build/libstaramd_emul.so oracle/_build/star_amd_emul_cli
 
 star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
 	@mkdir -p star_amd/lib
@@ -89,5 +89,10 @@ star_amd/lib/libstaramd_profile.so: $(HIP_SRC) $(HIP_HDR)
 # the engine's kernel sources compiled for the host by the wavefront emulator (oracle/wave_emul/emu.h): CPU tests of the kernel logic
 oracle/_build/libstaramd_emul.so: $(HIP_SRC) $(HIP_HDR) $(wildcard oracle/wave_emul/*.cpp oracle/wave_emul/*.h oracle/wave_emul/hip/*.h oracle/wave_emul/rocprim/*.hpp) oracle/wave_emul/build.sh
 	bash oracle/wave_emul/build.sh
+
+# the shipped front end (main.cpp + cli_run.cpp, resident junction insertion and all) linked against the EMULATED engine: CPU tests of the whole
+# binary, device index build and device junction insertion included (tests/test_wave_emul.py)
+oracle/_build/star_amd_emul_cli: $(CLI_SRC) oracle/_build/libstaramd_emul.so star_amd/lib/libstaramd_host.so $(CLI_HDR)
+	$(CXX) $(CXXFLAGS) -fPIE $(CLI_SRC) -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -lstaramd_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
 
 .PHONY: all host engine shadow cli oracle ref clean

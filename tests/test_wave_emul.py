@@ -77,3 +77,29 @@ FORCED = {
 def test_forced_rare_paths(case, tmp_path, built):
     _run("pe101", 25, ["--gpuResultSelect", "All"], tmp_path / "a", env=FORCED[case], order="asc")
     _run("pe101", 30, [], tmp_path / "b", env=FORCED[case], order="desc")
+
+
+# ---- the shipped front end (main.cpp + cli_run.cpp) linked against the emulated engine: oracle/_build/star_amd_emul_cli -------------------------
+EMUL_CLI = os.path.join(ROOT, "oracle", "_build", "star_amd_emul_cli")
+
+
+@pytest.fixture(scope="module")
+def emul_cli(emul_lib):
+    subprocess.check_call(["make", "-s", "oracle/_build/star_amd_emul_cli"], cwd=ROOT)
+    return EMUL_CLI
+
+
+@pytest.mark.parametrize("name", ["annot", "small_bins"])
+def test_front_end_generates_the_index_on_the_emulated_device(name, tmp_path, emul_cli):
+    """`--runMode genomeGenerate` through the product's own device path -- HipBackend (hip_backend.h: sliced k_forEach launches, the sort / scan calls),
+    index_gpu.hip, junction insertion of the annotation on the device -- with the kernels emulated: every genomeDir file equals the reference's"""
+    import test_index_build
+    test_index_build._run_case(emul_cli, str(tmp_path), name)
+
+
+@pytest.mark.parametrize("more,n", [(["--twopassMode", "Basic"], 60), (["--twopassMode", "Basic", "--outFilterType", "BySJout", "--sjdbGTFfile", "GTF"], 40)])
+def test_front_end_two_pass_with_resident_junction_insertion(more, n, tmp_path, emul_cli):
+    """the whole binary on the emulated engine: 1st pass, junction insertion ON THE ARRAYS RESIDENT IN THE ENGINE CONTEXT (staramd_insert_junctions +
+    staramd_update_tables behind cli_run.cpp's hook), 2nd pass -- every output file against one reference run with the same flags"""
+    from test_cli_pipeline import run_cli_case
+    run_cli_case(emul_cli, "pe101", more + ["--readMapNumber", str(n)], 40, tmp_path)
