@@ -103,3 +103,10 @@ def test_front_end_two_pass_with_resident_junction_insertion(more, n, tmp_path, 
     staramd_update_tables behind cli_run.cpp's hook), 2nd pass -- every output file against one reference run with the same flags"""
     from test_cli_pipeline import run_cli_case
     run_cli_case(emul_cli, "pe101", more + ["--readMapNumber", str(n)], 40, tmp_path)
+
+
+def test_front_end_two_contexts_on_one_device(tmp_path, emul_cli):
+    """`--gpuDevices 0,0`: two engine contexts, two mapper threads (each OS thread runs its own emulated launches), batches emitted in input order;
+    with the 1st-pass junctions inserted into BOTH contexts' resident arrays"""
+    from test_cli_pipeline import run_cli_case
+    run_cli_case(emul_cli, "pe101", ["--twopassMode", "Basic", "--readMapNumber", "60", "--gpuDevices", "0,0"], 12, tmp_path)
