@@ -70,6 +70,7 @@ FORCED = {
     "all_heavy": {"STARAMD_LIGHT_EST": "0"},
     "all_light": {"STARAMD_LIGHT_EST": "4000000000"},
     "no_pruning": {"STARAMD_PRUNE": "0"},
+    "deep_seed_table": {"STARAMD_SEED_SAI_NBASES": "10"},     # the seed search on an L-mer table of its own, two bases deeper than the genomeDir's (engine.hip buildDeepSAindex)
 }
 
 
@@ -110,3 +111,10 @@ def test_front_end_two_contexts_on_one_device(tmp_path, emul_cli):
     with the 1st-pass junctions inserted into BOTH contexts' resident arrays"""
     from test_cli_pipeline import run_cli_case
     run_cli_case(emul_cli, "pe101", ["--twopassMode", "Basic", "--readMapNumber", "60", "--gpuDevices", "0,0"], 12, tmp_path)
+
+
+def test_front_end_two_pass_with_deep_seed_table(tmp_path, emul_cli):
+    """STARAMD_SEED_SAI_NBASES: the seed search's own, deeper L-mer table is built on the device at start-up and again after the 1st-pass junctions
+    went into the resident suffix array; the outputs do not depend on it"""
+    from test_cli_pipeline import run_cli_case
+    run_cli_case(emul_cli, "pe101", ["--twopassMode", "Basic", "--readMapNumber", "50"], 25, tmp_path, env={"STARAMD_SEED_SAI_NBASES": "11"})
