@@ -71,7 +71,13 @@ def one(it, rng):
         flags = ["--readMapNumber", str(EMUL_READS)] + flags
     tag = "%s %s" % (name, " ".join(info["extra"] + flags))
     print("run  [%d] %s" % (it, tag), flush=True)
-    run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", os.path.join(work, "x_")] + info["extra"] + flags)
+    try:
+        run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", os.path.join(work, "x_")] + info["extra"] + flags)
+    except RuntimeError as e:
+        if "PARAMETERS error" in str(e) or "INPUT ERROR" in str(e):           # a combination the parameter checks refuse (as the reference does): nothing to compare
+            print("ok   [%d] (refused: %s)" % (it, str(e).splitlines()[0][:120]), flush=True)
+            return True
+        raise
     eng = capi.Engine(run.genome, run.params, device=0, max_reads=4096)
     orc = oracle_lib.Oracle(run.genome, run.params)
     bad = None
