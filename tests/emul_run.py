@@ -1,20 +1,25 @@
 """Run the first N reads of a data set through the WAVE-EMULATED engine (oracle/_build/libstaramd_emul.so: the kernel sources of
 star_amd/csrc/engine compiled for the host, oracle/wave_emul/emu.h) and through the oracle, and compare the result buffers byte for
 byte.  Test infrastructure; a fresh process so that STARAMD_ENGINE_LIB and the STARAMD_* knobs take effect.
-Usage: python tests/emul_run.py <dataset> <workdir> <nReads> [--gpuResultSelect All|Selected] [host flags...]      prints OK or the first difference"""
+Usage: python tests/emul_run.py <dataset | prepared info.pkl> <workdir> <nReads> [--gpuResultSelect All|Selected] [host flags...]      prints OK or the first difference"""
 import os
 import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 os.environ["STARAMD_ENGINE_LIB"] = os.environ.get("STARAMD_EMUL_LIB") or os.path.join(os.path.dirname(HERE), "oracle", "_build", "libstaramd_emul.so")     # STARAMD_EMUL_LIB: the AddressSanitizer build
+os.environ.setdefault("STARAMD_WIN_BLOCKS_BIG", "2")      # 64 blocks of the last k_windows launch = 3.9 GB of work space that the emulated hipMalloc would fill with its pattern
 sys.path.insert(0, HERE)
 from util import capi, oracle_lib, prepare  # noqa: E402
 
 
 def main():
     name, wd, n_reads, more = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4:]
-    info = prepare(name, wd, need_ref=False)
+    if name.endswith(".pkl"):                      # a data set the caller has prepared already (tests/test_wave_emul.py: once per session, not once per process)
+        import pickle
+        info = pickle.load(open(name, "rb"))
+    else:
+        info = prepare(name, wd, need_ref=False)
     argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", os.path.join(wd, "e_"), "--readMapNumber", str(n_reads)] + list(info["extra"]) + more
     run = capi.HostRun(argv)
     eng = capi.Engine(run.genome, run.params, device=0, max_reads=max(64, n_reads))
