@@ -137,17 +137,28 @@ __device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u3
     // the bases of a piece are all 0..3, so 8 of them are packed from one 8-byte word with shifts and masks
     if (dirR) pieceStart = pieceStartIn + iDist; else pieceStart = pieceStartIn - iDist;
     for (u32 ii = 0; ii < Lmax; ii += 8) {
-        u64 x = dirR ? load8(R + pieceStart + ii) : (load8rev(R + pieceStart - ii) ^ 0x0303030303030303ull);   // 3 - base == 3 ^ base
-        u64 z = __builtin_bswap64(x & 0x0303030303030303ull); // first base in the top byte (bytes behind the prefix may hold N / spacer codes)
-        z = (z | (z >> 6)) & 0x000F000F000F000Full;
-        z = (z | (z >> 12)) & 0x000000FF000000FFull;
-        z = (z | (z >> 24)) & 0xFFFFull;                    // 8 bases -> 16 bits, first base most significant
-        u32 nb = min(8u, Lmax - ii);
-        ind1 = (ind1 << (2 * nb)) | (z >> (2 * (8 - nb)));
+        const u64 raw = dirR ? load8(R + pieceStart + ii) : load8rev(R + pieceStart - ii);     // byte k = code of the (ii+k)-th base of the scan
+        const u32 nb = min(8u, Lmax - ii);
+        const u64 used = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+        if ((raw & used & 0xFCFCFCFCFCFCFCFCull) == 0) {
+            u64 x = dirR ? raw : (raw ^ 0x0303030303030303ull);                                   // 3 - base == 3 ^ base
+            u64 z = __builtin_bswap64(x & 0x0303030303030303ull); // first base in the top byte (bytes behind the prefix may hold N / spacer codes)
+            z = (z | (z >> 6)) & 0x000F000F000F000Full;
+            z = (z | (z >> 12)) & 0x000000FF000000FFull;
+            z = (z | (z >> 24)) & 0xFFFFull;                    // 8 bases -> 16 bits, first base most significant
+            ind1 = (ind1 << (2 * nb)) | (z >> (2 * (8 - nb)));
+        } else {
+            // a code above 3 inside the prefix: only with --seedSearchLmax, whose backward search is given Shift + 1 bases (:from ReadAlign_mapOneRead.cpp:81-86)
+            // and so runs over the start of its piece into an N, the mate spacer or the other mate.  The reference adds the code as it is
+            // (index*4 + code, index*4 + (3 - code) in unsigned 64-bit arithmetic): the carries and borrows are part of its result
+            for (u32 k = 0; k < nb; k++) { const u64 cde = (raw >> (8 * k)) & 0xFFull; ind1 = (ind1 << 2) + (dirR ? cde : 3ull - cde); }
+        }
     }
     u32 Lind = Lmax; u64 iSA1 = 0, iSA2;
     while (Lind > 0) {
-        iSA1 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1, X.saiBits, X.saiMask); cn.nSAi++;
+        const u64 flat = X.saiStart[Lind - 1] + ind1;                                    // (wraps like the reference's flat packed-array index)
+        if (flat >= X.saiStart[X.saiNbases]) { --Lind; ind1 >>= 2; continue; }          // outside the table: the reference reads whatever lies there; treated as absent
+        iSA1 = packedGet(X.SAi, flat, X.saiBits, X.saiMask); cn.nSAi++;
         if ((iSA1 & X.saiAbsentBit) == 0) break;
         --Lind; ind1 >>= 2;
     }

@@ -35,6 +35,17 @@ def test_engine_matches_oracle_buffers(name, select, tmp_path, built):
     _compare_buffers(info, ["--gpuResultSelect", select], str(tmp_path / "x_"))
 
 
+@pytest.mark.parametrize("name", ["pe101", "pe101_sparse3"])
+def test_seed_search_lmax_prefix_codes(name, tmp_path, built):
+    """--seedSearchLmax: the backward search is given Shift + 1 bases (ReadAlign_mapOneRead.cpp:81-86) and runs over the start of its piece into an N, the
+    mate spacer or the other mate; the reference adds those codes into the L-mer prefix as they are, carries and borrows included
+    (ReadAlign_maxMappableLength2strands.cpp:23-37).  Found by the emulated fuzzer (tests/tools/fuzz_engine.py, FUZZ_EMUL=1)."""
+    if not refstar.have_ref():
+        pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
+    info = prepare(name, str(tmp_path), need_ref=False)
+    _compare_buffers(info, ["--gpuResultSelect", "All", "--seedSearchLmax", "30", "--seedSearchStartLmax", "12", "--readMapNumber", "300"], str(tmp_path / "x_"))    # (the reads the emulator was run on)
+
+
 def _compare_buffers(info, more, prefix):
     argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", prefix] + info["extra"] + more
     run = capi.HostRun(argv)

@@ -55,7 +55,10 @@ def test_primitives(built):
 
 # (data set, reads, flags): the read counts stop short of the few reads of each set whose walks take minutes in the emulator
 CASES = [("se50", 150, []), ("pe101", 40, []), ("pe101", 25, ["--gpuResultSelect", "All"]), ("pe150_indel", 12, []), ("pe76_overlap", 40, []),
-         ("pe150_chim", 20, ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"])]
+         ("pe150_chim", 20, ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"]),
+         # --seedSearchLmax: the backward search is given Shift + 1 bases and runs over the start of its piece into an N / the mate spacer; the reference adds
+         # those codes into the L-mer prefix as they are (carries and borrows included) -- found by the emulated fuzzer, k_seed.hip searchOneDist
+         ("pe101", 30, ["--gpuResultSelect", "All", "--seedSearchLmax", "30", "--seedSearchStartLmax", "12"])]
 
 
 # every data set with one lane order, the paired-end set of the forced cases with both (tests/tools/fuzz_engine.py alternates the order over hundreds of
