@@ -188,6 +188,7 @@ STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitc
 def report_dict(rep, lread):
     n = max(int(rep.timedReads), 1); nb = max(int(rep.batches), 1)
     c = dict(zip(COUNTER_NAMES, [int(x) for x in rep.counters]))
+    c["nPrunedWin"], c["nRewalkRead"], c["nLaneItems"] = int(rep.counters[37]), int(rep.counters[38]), int(rep.counters[39])     # dev.h: DC_nPrunedWin, DC_nRewalkRead, DC_nLaneItems
     for k in ("nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"):      # kept by the profile / shadow builds only
         c.pop(k, None)
     ms = dict(zip(STAGE_NAMES, [float(x) / nb for x in rep.stageMs]))       # per launch = per batch

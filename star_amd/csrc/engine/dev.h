@@ -81,6 +81,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_prof8, DC_prof9, DC_prof10, DC_prof11, DC_prof12, DC_prof13, DC_prof14, DC_prof15,
        DC_nPrunedWin,                                                  // windows not walked because no transcript of theirs could be selected (k_stitch_win)
        DC_nRewalkRead,                                                 // light reads whose two-mate windows did not clear the bar: walked again in window order
+       DC_nLaneItems,                                                  // reads stitched by the lane-per-read kernel (k_stitch_lane); the others went to the cooperative one
        DC_N };
 
 // cursors[] slots

@@ -20,6 +20,7 @@ extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
 extern "C" __global__ void k_stitch_win(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords, u32 mode, u32 pruneEnable);
+extern "C" __global__ void k_stitch_lane(const DevIndex *X, DevBatch B, u8 *laneArena, u32 laneArenaBytes, u32 ldsWords, u32 pruneEnable, u32 maxClass);
 extern "C" __global__ void k_stitch_replay(const DevIndex *X, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes, u32 bigArenaBytes, u32 ldsWords);
 extern "C" __global__ void k_stitch_verify(const DevIndex *X, DevBatch B);
 extern "C" __global__ void k_stitch_finish(const DevIndex *X, DevBatch B);
@@ -76,6 +77,8 @@ struct staramd_ctx {
     // lean pass-0 launch: windows of at most leanDepth-1 seeds (almost all) walked with a small LDS slice per wavefront, so that more
     // wavefronts are resident per CU; the others are handed to a second launch with the full-size slice (0 = one full-size launch)
     u32 leanDepth = 0, leanArena = 0, stBlocksLean = 0;
+    // lane-per-read stitcher (k_stitch_lane.hip): takes the light reads whose windows hold few seeds; the cooperative kernel gets the rest
+    u32 laneBlocks = 0, laneArenaBytes = 0; u8 *scrLane = nullptr;
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
@@ -351,6 +354,18 @@ static int allocWork(staramd_ctx *c) {
         c->stBlocksLean = (u32)c->nCU * envU32("STARAMD_LEAN_BLOCKS_PER_CU", (u32)lpCU);
         if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win lean launch: depth %u, arena %u B, %d blocks/CU (LDS %zu B/block)\n", c->leanDepth, c->leanArena, lpCU, ldsLean);
     }
+    // lane-per-read launch: 256 lanes per block, each with an LDS slot for its packed read and a record arena in HBM
+    c->laneBlocks = 0;
+    if (envU32("STARAMD_LANE", 1)) {
+        int lnPerCU = 4;
+        const size_t ldsLane = 256 * (size_t)(27 * 4);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lnPerCU, k_stitch_lane, 256, ldsLane) != hipSuccess || lnPerCU < 1) lnPerCU = 2;
+        c->laneBlocks = (u32)c->nCU * envU32("STARAMD_LANE_BLOCKS_PER_CU", (u32)lnPerCU);
+        c->laneBlocks = std::max<u32>(1, std::min<u32>(c->laneBlocks, (N + 255) / 256));
+        c->laneArenaBytes = envU32("STARAMD_LANE_ARENA", 2048) & ~31u;
+        if ((rc = devAlloc(R, &c->scrLane, (u64)c->laneBlocks * 256 * c->laneArenaBytes))) return rc;
+        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_lane %d blocks/CU (LDS %zu B/block), %u blocks, %u B of record arena per lane\n", lnPerCU, ldsLane, c->laneBlocks, c->laneArenaBytes);
+    }
     const u32 maxStBlocks = std::max(std::max(c->stBlocks, c->stBlocksLean), c->replayBlocks);
     if ((rc = devAlloc(R, &c->scrStitchBig, (u64)maxStBlocks * 4 * c->arenaBig))) return rc;
     // candidate logs: one private region per wavefront; sized so that a wavefront's share of a full batch fits
@@ -539,6 +554,10 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         const u32 prune = envU32("STARAMD_PRUNE", 3);       // bit 0: window pruning, bit 1: two-mate windows of a light read first
         size_t ldsLean = c->leanDepth ? 4 * (readBytes + stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena)) : 0;
         for (u32 mode = 0; mode < 2; mode++) {
+            if (mode == 0 && c->laneBlocks) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
+                hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, envU32("STARAMD_LANE_CLASS", 5));
+                hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
+            } else
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksLean), block, ldsLean, s, c->dX, B, c->scrStitchBig, c->leanDepth, c->capRank, c->leanArena, c->arenaBig, ldsWords, 0u, prune);
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);

@@ -1,8 +1,9 @@
 // stitch_scalar.h -- one-lane (scalar) versions of extendAlign / binarySearch2 / stitchAlignToTranscript.
-// They are the first device implementation of this path (parity-proven against the oracle) and are kept ONLY for
-// the shadow-validation build (-DSTARAMD_SHADOW): there lane 0 re-runs every cooperative call through these and
-// counts disagreements (DC_shadow*), so one GPU run cross-checks every call of the wave-cooperative code.
-// The production library never calls them, except for the rarely used branches noted in k_stitch.hip.
+// Two users:
+//   * k_stitch_lane.hip (product): the lane-per-read stitcher runs these for every window of few seeds -- one lane walks one read,
+//     64 independent walks per wavefront;
+//   * the shadow-validation build of the wave-cooperative stitcher (-DSTARAMD_SHADOW, k_stitch.hip): every cooperative call is re-run
+//     through these and disagreements are counted (DC_shadow*), so one GPU run cross-checks every call of the cooperative code.
 #pragma once
 #include "stitch_common.h"
 
@@ -51,7 +52,8 @@ __device__ static bool extendAlign(StitchCtx &c, u32 rStart, u64 gStart, int dR,
 }
 
 // binarySearch2.cpp:3-43
-__device__ static int binarySearch2(u64 x, u64 y, const u64 *Xs, const u64 *Ys, int N) {
+__device__ static int binarySearch2(u64 x, u64 y, const u64 *Xs_, const u64 *Ys_, int N) {
+    const __attribute__((address_space(1))) u64 *Xs = GLOBAL(u64, Xs_), *Ys = GLOBAL(u64, Ys_);
     if (N == 0 || x > Xs[N - 1] || x < Xs[0]) return -1;
     int i1 = 0, i2 = N - 1, i3 = N / 2;
     while (i2 > i1 + 1) { i3 = (i1 + i2) / 2; if (Xs[i3] > x) i2 = i3; else i1 = i3; }
@@ -72,10 +74,10 @@ __device__ static int stitchAlignToTranscript(StitchCtx &c, u32 rAend, u64 gAend
     if (h.nExons >= STARAMD_MAX_N_EXONS) return -1000010;
     int Score = 0;
     if (sjAB != -1 && eA.sjA == sjAB && eA.iFrag == iFragB && rBstart == rAend + 1 && gAend + 1 < gBstart) {
-        if (X.sjdbMotif[sjAB] == 0 && (L <= X.sjdbShiftRight[sjAB] || eA.L <= X.sjdbShiftLeft[sjAB])) return -1000006;
+        if (GLOBAL(u8, X.sjdbMotif)[sjAB] == 0 && (L <= GLOBAL(u8, X.sjdbShiftRight)[sjAB] || eA.L <= GLOBAL(u8, X.sjdbShiftLeft)[sjAB])) return -1000006;
         eN.L = (u16)L; eN.R = (u16)rBstart; eN.G = gBstart;
-        eA.canonSJ = (i8)X.sjdbMotif[sjAB]; eA.shiftSJ[0] = X.sjdbShiftLeft[sjAB]; eA.shiftSJ[1] = X.sjdbShiftRight[sjAB];
-        eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjAB];
+        eA.canonSJ = (i8)GLOBAL(u8, X.sjdbMotif)[sjAB]; eA.shiftSJ[0] = GLOBAL(u8, X.sjdbShiftLeft)[sjAB]; eA.shiftSJ[1] = GLOBAL(u8, X.sjdbShiftRight)[sjAB];
+        eA.sjAnnot = 1; eA.sjStr = GLOBAL(u8, X.sjdbStrand)[sjAB];
         added = true; h.nMatch += L;
         Score += (int)L; Score += P.sjdbScore;
     } else {
@@ -159,14 +161,14 @@ __device__ static int stitchAlignToTranscript(StitchCtx &c, u32 rAend, u64 gAend
                     if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }
                 } else {
-                    jCan = X.sjdbMotif[sjdbInd];
-                    if (X.sjdbMotif[sjdbInd] == 0) {
-                        if (L <= X.sjdbShiftLeft[sjdbInd] || eA.L <= X.sjdbShiftLeft[sjdbInd]) return -1000006;
-                        jR += (int)X.sjdbShiftLeft[sjdbInd];
+                    jCan = GLOBAL(u8, X.sjdbMotif)[sjdbInd];
+                    if (GLOBAL(u8, X.sjdbMotif)[sjdbInd] == 0) {
+                        if (L <= GLOBAL(u8, X.sjdbShiftLeft)[sjdbInd] || eA.L <= GLOBAL(u8, X.sjdbShiftLeft)[sjdbInd]) return -1000006;
+                        jR += (int)GLOBAL(u8, X.sjdbShiftLeft)[sjdbInd];
                         if ((u64)rAend + (i64)jR >= rBend) return -1000006;
-                        jjL = X.sjdbShiftLeft[sjdbInd]; jjR = X.sjdbShiftRight[sjdbInd];
+                        jjL = GLOBAL(u8, X.sjdbShiftLeft)[sjdbInd]; jjR = GLOBAL(u8, X.sjdbShiftRight)[sjdbInd];
                     }
-                    eA.sjAnnot = 1; eA.sjStr = X.sjdbStrand[sjdbInd];
+                    eA.sjAnnot = 1; eA.sjStr = GLOBAL(u8, X.sjdbStrand)[sjdbInd];
                     Score += P.sjdbScore;
                 }
                 eA.shiftSJ[0] = (u16)jjL; eA.shiftSJ[1] = (u16)jjR; eA.canonSJ = (i8)jCan;

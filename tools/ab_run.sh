@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of engine variants / environment knobs on the GPU box (same cached 400 Mb workload for all):
+# A/B of engine variants / environment knobs on the GPU box (same cached workload for all):
 #   tools/ab_run.sh <outdir> "<tag>|<variant or ->|<ENV=VAL ...>" ...
 R=$PWD; O=$1; shift; mkdir -p $O
 export STARAMD_BENCH_GENOME_MB=${AB_GENOME_MB:-400}
@@ -11,8 +11,8 @@ for spec in "$@"; do
   python - <<PY
 import json
 try:
-    d = json.load(open("$O/$tag.json")); k = d["roofline"]["per_kernel_ms"]
-    print("%-28s value %.3f  stitch %.1f  windows %.1f  seed %.1f  redecide %.1f  total %.1f" % ("$tag", d["value"], k["k_stitch_win"], k["k_windows"], k["k_seed_search"], k["k_stitch_verify+replay+finish"], k["device_total"]))
+    d = json.load(open("$O/$tag.json")); k = d["roofline"]["per_kernel_ms"]; c = d.get("counters_per_pair", {})
+    print("%-24s value %.3f  stitch %.1f  windows %.1f  seed %.1f  redecide %.1f  total %.1f  lane %.3f pruned %.2f" % ("$tag", d["value"], k["k_stitch_win"], k["k_windows"], k["k_seed_search"], k["k_stitch_verify+replay+finish"], k["device_total"], c.get("nLaneItems", 0), c.get("nPrunedWin", 0)))
 except Exception as e:
     print("$tag FAILED", e); print(open("$O/$tag.err").read()[-600:])
 PY
