@@ -8,7 +8,7 @@ CL=${EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 FL="-x c++ -std=c++17 -O1 -g -fPIC -ffp-contract=off -Wno-unused-result -Wno-unknown-attributes -I oracle/wave_emul"
 O=oracle/_build/emul; OUT=oracle/_build/libstaramd_emul.so; SAN=""
 if [ "$1" = asan ]; then SAN="-fsanitize=address -fno-omit-frame-pointer"; FL="$FL $SAN"; O=oracle/_build/emul_asan; OUT=oracle/_build/libstaramd_emul_asan.so; fi
-#   build.sh variant <tag> <defines>   e.g. build.sh variant flat -DWIN_FLAT  ->  oracle/_build/libstaramd_emul_flat.so  (kernel variants behind compile-time switches)
+#   build.sh variant <tag> <defines>   e.g. build.sh variant w5 -DWIN_WAVES=5  ->  oracle/_build/libstaramd_emul_w5.so  (kernel variants behind compile-time switches)
 if [ "$1" = variant ]; then FL="$FL $3"; O=oracle/_build/emul_$2; OUT=oracle/_build/libstaramd_emul_$2.so; SAN=" "; fi
 mkdir -p $O
 for f in k_window k_seed k_gather k_stitch_lane engine; do $CL $FL -c star_amd/csrc/engine/$f.hip -o $O/$f.o & done

@@ -52,12 +52,6 @@ struct staramd_ctx {
     hipStream_t stream = nullptr;
     DevIndex X;                 // host copy
     DevIndex *dX = nullptr;     // device copy read by the kernels through scalar loads
-    // STARAMD_SEED_SAI_NBASES=<D> (experimental, off by default): the seed search gets an L-mer table of its own that is DEEPER than the one of the
-    // genomeDir, built on the device from the resident suffix array (HBM has room for it: 25 GB at D = 16 for a human genome).  Two more bases of
-    // prefix are two binary-search steps less per search, i.e. four dependent random gathers; the result of a search does not depend on the depth.
-    // Only k_seed_search sees it, through a second DevIndex block that differs in SAi / saiStart / saiNbases.
-    DevIndex *dXseedOwn = nullptr; u64 *deepSAi = nullptr; u32 deepNbases = 0; u64 deepStart[17] = {0}; float deepBuildMs = 0;
-    const DevIndex *seedX() const { return dXseedOwn ? dXseedOwn : dX; }
     std::vector<void *> indexAllocs, workAllocs;
     u32 maxReads = 0; u64 maxBases = 0;
     DevBatch B;
@@ -127,7 +121,6 @@ static void buildGlBreaks(DevIndex &X, double scale) {
 }
 
 static u32 envU32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)strtoul(s, nullptr, 10) : dflt; }
-static int syncSeedIndex(staramd_ctx *c);
 // chromosome / junction tables, index geometry, parameters and the DevIndex block (everything but G, SA, SAindex)
 static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
@@ -156,63 +149,9 @@ static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_p
     buildGlBreaks(X, p->scoreGenomicLengthLog2scale);
     { int rc2 = devAlloc(c->indexAllocs, &c->dX, (u64)1); if (rc2) return rc2; }
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
-    return syncSeedIndex(c);
-}
-
-// the DevIndex block of the seed search: the common one (seedX() falls back to dX), or a block of its own with the deep L-mer table in place of the genomeDir's
-static int syncSeedIndex(staramd_ctx *c) {
-    if (!c->deepSAi) { if (c->dXseedOwn) { (void)hipFree(c->dXseedOwn); c->dXseedOwn = nullptr; } return 0; }
-    DevIndex Xs = c->X;
-    Xs.SAi = c->deepSAi; Xs.saiNbases = c->deepNbases;
-    for (int i = 0; i < 17; i++) Xs.saiStart[i] = c->deepStart[i];
-    if (!c->dXseedOwn) { void *q = nullptr; HIPCHK(hipMalloc(&q, sizeof(DevIndex))); c->dXseedOwn = (DevIndex *)q; }
-    HIPCHK(hipMemcpy(c->dXseedOwn, &Xs, sizeof(DevIndex), hipMemcpyHostToDevice));
     return 0;
 }
-static void dropDeepSAindex(staramd_ctx *c) {
-    if (c->deepSAi) { (void)hipFree(c->deepSAi); c->deepSAi = nullptr; }
-    c->deepNbases = 0;
-    if (c->dXseedOwn) { (void)hipFree(c->dXseedOwn); c->dXseedOwn = nullptr; }
-}
-// (re)build after the resident G / SA changed; the genomeDir's own table stays what every other user of the index sees
-static int buildDeepSAindex(staramd_ctx *c) {
-    using namespace staridx;
-    dropDeepSAindex(c);
-    const u32 D = envU32("STARAMD_SEED_SAI_NBASES", 0);
-    DevIndex &X = c->X;
-    if (D <= X.saiNbases || D > 16 || X.sparseD != 1 || !c->stream) return syncSeedIndex(c);          // off (the default), or nothing to gain
-    HipBackend be; be.s = c->stream;
-    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, be.s);
-    const u64 N = X.nGenome, nSA = X.nSA; const u32 sb = X.strandBit, saBits = X.saBits;
-    u64 start[17]; start[0] = 0;
-    for (u32 i = 1; i <= D; i++) start[i] = start[i - 1] + (1ull << (2 * i));
-    for (u32 i = D + 1; i < 17; i++) start[i] = 0;
-    const u64 nSAi = start[D], words = packedWords(nSAi, sb + 3);
-    u8 *dTraw = be.template alloc<u8>(2 * N + 2 * TPAD);
-    u64 *dSApos = be.template alloc<u64>(nSA), *dSAiU = be.template alloc<u64>(nSAi), *dPacked = be.template alloc<u64>(words);
-    int bad = 1;
-    if (be.err == hipSuccess) {
-        u8 *T = buildText(be, X.G, N, dTraw);
-        { const u64 *sp = X.SA; const u64 N2bit = 1ull << sb;
-          be.forEach(nSA, [=] IDX_L (u64 i) { u64 v = packedGetW(sp, i, saBits); dSApos[i] = (v & N2bit) ? N + (v & ~N2bit) : v; }); }
-        bad = buildSAindex(be, T, dSApos, nSA, D, sb, start, dSAiU);
-        const u64 *su = dSAiU;
-        packArray(be, nSAi, sb + 3, dPacked, [=] IDX_L (u64 i) { return su[i]; });
-    }
-    (void)hipEventRecord(e1, be.s); (void)hipStreamSynchronize(be.s);
-    (void)hipEventElapsedTime(&c->deepBuildMs, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    be.free(dSAiU); be.free(dSApos); be.free(dTraw);
-    if (be.tmp) (void)hipFree(be.tmp);
-    if (be.err != hipSuccess || bad) {            // no room, or an index this builder does not take: the search keeps the genomeDir's table
-        if (dPacked) (void)hipFree(dPacked);
-        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "star_amd engine: deep L-mer table (%u bases) not built: %s\n", D, be.err != hipSuccess ? hipGetErrorString(be.err) : "first suffix inside the prefix");
-        return syncSeedIndex(c);
-    }
-    c->deepSAi = dPacked; c->deepNbases = D;
-    for (int i = 0; i < 17; i++) c->deepStart[i] = start[i];
-    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "star_amd engine: deep L-mer table for the seed search: %u bases, %.2f GB, built in %.1f ms\n", D, (double)words * 8 / 1e9, c->deepBuildMs);
-    return syncSeedIndex(c);
-}
+
 
 static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
@@ -387,8 +326,7 @@ extern "C" int staramd_create(staramd_ctx **out, int device, const staramd_genom
     if (!rc) rc = allocWork(c);
     if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
-    if (!rc) rc = buildDeepSAindex(c);
-    if (rc) { dropDeepSAindex(c); freeAll(c->indexAllocs); freeAll(c->workAllocs); delete c; return rc; }
+    if (rc) { freeAll(c->indexAllocs); freeAll(c->workAllocs); delete c; return rc; }
     memset(c->counters, 0, sizeof(c->counters));
     *out = c;
     return STARAMD_OK;
@@ -398,10 +336,9 @@ extern "C" int staramd_update_index(staramd_ctx *c, const staramd_genome *g, con
     if (!c) { g_err = "null context"; return STARAMD_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    dropDeepSAindex(c);
     freeAll(c->indexAllocs);
     int rc = uploadIndex(c, g, p);
-    return rc ? rc : buildDeepSAindex(c);
+    return rc;
 }
 
 
@@ -447,7 +384,7 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
     X.G = R.dGnew + GPAD; X.SA = R.dSApacked; X.SAi = R.dSAiPacked;
     X.nGenome = R.nGenomeNew; X.nSA = R.nSAnew;
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
-    return buildDeepSAindex(c);                       // (the suffix array changed: the seed search's own table, if any, is built anew)
+    return STARAMD_OK;
 }
 
 extern "C" int staramd_update_tables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
@@ -477,14 +414,13 @@ extern "C" int staramd_set_novel_junctions(staramd_ctx *c, const uint64_t *start
     X.sjNovelN = n;
     X.P.outFilterBySJoutStage = (uint8_t)stage;
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
-    return syncSeedIndex(c);
+    return 0;
 }
 
 extern "C" void staramd_destroy(staramd_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    dropDeepSAindex(c);
     freeAll(c->indexAllocs); freeAll(c->workAllocs);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->hostScratch) (void)hipHostFree(c->hostScratch);
@@ -533,7 +469,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[0], s));
     {
         u32 lanes = std::min<u32>(c->seedLanes, ((n + 255) / 256) * 256);
-        hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->seedX(), B, c->scrSeed, c->seedPerLane);
+        hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane);
     }
     HIPCHK(hipEventRecord(c->ev[1], s));
     {

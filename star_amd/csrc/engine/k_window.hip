@@ -221,36 +221,6 @@ __host__ __device__ inline u64 winWaveBytes(u32 capW, u32 capBlocks, u32 big) {
 }
 
 
-#ifdef WIN_FLAT
-// ---- WIN_FLAT (experimental, off by default): the loci of CONSECUTIVE seeds share one 64-lane enumeration step.
-// Most seeds of a read have a handful of loci, so the per-seed loop spends one exposed SA round trip per seed with a few lanes busy.
-// Here the lanes of a step are dealt out over (seed, locus) pairs in order -- seeds in their order, loci ascending, a seed with more
-// loci than lanes are left simply continues in the next step -- which is the order the reference replays them in.  Per step: one
-// gather of the seed records (each lane its own seed), one gather of the packed SA.
-struct SeedIter { u32 iP, base, winBase; u32 nrepLane; };      // next seed, next locus of it; nrepLane: nrep of seed winBase + lane
-__device__ __forceinline__ DSeed loadSeed(const DSeed *PC, u32 i) {                 // a lane's own seed record, field by field through global loads
-    const __attribute__((address_space(1))) DSeed *q = GLOBAL(DSeed, PC) + i;
-    DSeed d; d.saStart = q->saStart; d.nrep = q->nrep; d.rStart = q->rStart; d.L = q->L; d.dir = q->dir; d.iFrag = q->iFrag;
-    return d;
-}
-__device__ __forceinline__ u32 seedNrep(SeedIter &it, const DSeed *PC, u32 nSeeds, u32 lane) {   // nrep of seed it.iP (wave-uniform)
-    if (it.iP - it.winBase >= 64u) { it.winBase = it.iP; it.nrepLane = (it.winBase + lane < nSeeds) ? GLOBAL(DSeed, PC)[it.winBase + lane].nrep : 0u; }
-    return laneGet32(it.nrepLane, it.iP - it.winBase);
-}
-// deals the lanes of one step; returns the number of lanes in use (0: no seeds left); maxNrep: seeds with more loci are passed over (pass A: anchors only)
-__device__ __forceinline__ u32 nextSeedGroup(SeedIter &it, const DSeed *PC, u32 nSeeds, u32 maxNrep, u32 lane, u32 &mySeed, u32 &myK) {
-    u32 fill = 0; mySeed = NOWIN; myK = 0;
-    while (it.iP < nSeeds && fill < 64u) {
-        const u32 nrep = seedNrep(it, PC, nSeeds, lane);
-        if (nrep > maxNrep || nrep == 0) { it.iP++; it.base = 0; continue; }
-        const u32 n = min(nrep - it.base, 64u - fill);
-        if (lane >= fill && lane < fill + n) { mySeed = it.iP; myK = it.base + (lane - fill); }
-        fill += n; it.base += n;
-        if (it.base >= nrep) { it.iP++; it.base = 0; }
-    }
-    return fill;
-}
-#endif
 
 extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 + hashBits / 32) words
 
@@ -294,42 +264,6 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         s.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         WPROF_T0();
         // ---- pass A: anchors (ReadAlign_stitchPieces.cpp:41-93)
-#ifdef WIN_FLAT
-        {
-            SeedIter it; it.iP = 0; it.base = 0; it.winBase = 0; it.nrepLane = lane < rd.nSeeds ? GLOBAL(DSeed, PC)[lane].nrep : 0u;
-            u32 skipSeed = NOWIN;                                     // the seed whose remaining loci are passed over after TOO_MANY_WINDOWS (:76-80 breaks its loop only)
-            while (!s.overflow) {
-                u32 mySeed, myK;
-                const u32 fill = nextSeedGroup(it, PC, rd.nSeeds, P.winAnchorMultimapNmax, lane, mySeed, myK);
-                if (fill == 0) break;
-                u64 a1 = 0, a1A = 0; u32 aStr = 0; u32 kind = 0;       // kind: 0 skip, 1 plain, 2 split (D then A)
-                if (mySeed != NOWIN) {
-                    const DSeed sd = loadSeed(PC, mySeed);
-                    const u32 aDir = sd.dir, aLength = sd.L;
-                    a1 = packedGet(X.SA, sd.saStart + myK, X.saBits, X.saMask);
-                    aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-                    if (aDir == 1 && aStr == 0) aStr = 1;
-                    else if (aDir == 0 && aStr == 1) a1 = X.nGenome - (aLength + a1);
-                    else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
-                    kind = 1;
-                    if (a1 >= X.sjGstart) {
-                        u64 a1D; u32 lD, lA, isj;
-                        if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) { a1 = a1D; kind = 2; } else kind = 0;
-                    }
-                }
-                nSAenum += fill;
-                for (u32 l = 0; l < fill && !s.overflow; l++) {
-                    const u32 sdl = laneGet32(mySeed, l);
-                    if (sdl == skipSeed) continue;
-                    u32 k = laneGet32(kind, l);
-                    if (k == 0) continue;
-                    u64 x1 = laneGet64(a1, l); u32 xs = laneGet32(aStr, l);
-                    if (createExtendWindowsWithAlign(X, s, x1, xs, lane)) { skipSeed = sdl; continue; }
-                    if (k == 2) { u64 x2 = laneGet64(a1A, l); if (createExtendWindowsWithAlign(X, s, x2, xs, lane)) { skipSeed = sdl; continue; } }
-                }
-            }
-        }
-#else
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow; iP++) {
             const DSeed sd = PC[iP];
             if (sd.nrep > P.winAnchorMultimapNmax) continue;
@@ -361,7 +295,6 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 }
             }
         }
-#endif
         WPROF_MARK(0);
         // ---- flanks (:96-118): one lane per window
         if (!s.overflow) {
@@ -389,62 +322,6 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         nWindows += s.nW;
         WPROF_MARK(1);
         // ---- pass B: all seeds (:129-185)
-#ifdef WIN_FLAT
-        {
-            SeedIter it; it.iP = 0; it.base = 0; it.winBase = 0; it.nrepLane = lane < rd.nSeeds ? GLOBAL(DSeed, PC)[lane].nrep : 0u;
-            while (!s.overflow && !s.tooMany) {
-                u32 mySeed, myK;
-                const u32 fill = nextSeedGroup(it, PC, rd.nSeeds, 0xFFFFFFFFu, lane, mySeed, myK);
-                if (fill == 0) break;
-                u64 a1 = 0, a1A = 0; u32 aRstart = 0, lD = 0, lA = 0, isj = 0; u32 wD = NOWIN, wA = NOWIN; bool split = false;
-                u32 binD = 0, binA = 0, lStr = 0; bool candD = false, candA = false;
-                u32 myNrep = 0, myFrag = 0;
-                if (mySeed != NOWIN) {
-                    const DSeed sd = loadSeed(PC, mySeed);
-                    const u32 aDir = sd.dir, aLength = sd.L;
-                    myNrep = sd.nrep; myFrag = sd.iFrag;
-                    a1 = packedGet(X.SA, sd.saStart + myK, X.saBits, X.saMask);
-                    u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-                    aRstart = sd.rStart;
-                    if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
-                    else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
-                    else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
-                    if (a1 >= X.sjGstart) {
-                        u64 a1D;
-                        if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
-                            split = true; a1 = a1D;
-                            binD = (u32)(a1D >> P.winBinNbits); binA = (u32)(a1A >> P.winBinNbits); lStr = aStr;
-                            u32 hD = binHash(aStr, binD, s.hashMask), hA = binHash(aStr, binA, s.hashMask);
-                            candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u; candA = (s.bitmap[hA >> 5] >> (hA & 31u)) & 1u;
-                        }
-                    } else {
-                        lD = aLength;
-                        binD = (u32)(a1 >> P.winBinNbits); lStr = aStr;
-                        u32 hD = binHash(aStr, binD, s.hashMask);
-                        candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u;
-                    }
-                }
-                for (u64 cm = __ballot(candD); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binD, l), lane); if (lane == l) wD = w; }
-                for (u64 cm = __ballot(candA); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binA, l), lane); if (lane == l) wA = w; }
-                nSAenum += fill;
-                WPROF_MARK(2);
-                u64 hm = __ballot(wD != NOWIN || wA != NOWIN);
-                while (hm) {
-                    u32 l = (u32)__ffsll((long long)hm) - 1; hm &= hm - 1;
-                    u32 xwD = laneGet32(wD, l), xwA = laneGet32(wA, l);
-                    u32 xsplit = laneGet32(split ? 1u : 0u, l);
-                    u32 xr = laneGet32(aRstart, l), xlD = laneGet32(lD, l);
-                    i32 xsj = xsplit ? (i32)laneGet32(isj, l) : -1;
-                    const u32 aNrep = laneGet32(myNrep, l), aFrag = laneGet32(myFrag, l);
-                    const bool aAnchor = aNrep <= P.winAnchorMultimapNmax;
-                    if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
-                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
-                    if (s.tooMany || s.overflow) break;
-                }
-                WPROF_MARK(3);
-            }
-        }
-#else
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooMany; iP++) {
             const DSeed sd = PC[iP];
             u32 aNrep = sd.nrep, aFrag = sd.iFrag, aLength = sd.L, aDir = sd.dir;
@@ -494,7 +371,6 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 WPROF_MARK(3);
             }
         }
-#endif
         if (s.winLimit) rd.status |= STARAMD_ST_WINDOWS_LIMIT;
         if (s.overflow) {
             if (lane == 0) {

@@ -130,6 +130,11 @@ FORCED = {
     "log_overflow": {"STARAMD_CAND_KB_PER_WAVE": "1"},
     "all_heavy": {"STARAMD_LIGHT_EST": "0"},
     "all_light": {"STARAMD_LIGHT_EST": "4000000000"},
+    "block_overflow": {"STARAMD_CAP_WA_BLOCKS": "2", "STARAMD_CAP_WA_BLOCKS_MID": "3"},      # seed-list blocks run out before table rows do (first and middle launch)
+    "no_pruning": {"STARAMD_PRUNE": "0"},
+    "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
+    "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
+    "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
 }
 
 

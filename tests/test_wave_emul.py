@@ -80,7 +80,9 @@ FORCED = {
     "all_heavy": {"STARAMD_LIGHT_EST": "0"},
     "all_light": {"STARAMD_LIGHT_EST": "4000000000"},
     "no_pruning": {"STARAMD_PRUNE": "0"},
-    "deep_seed_table": {"STARAMD_SEED_SAI_NBASES": "10"},     # the seed search on an L-mer table of its own, two bases deeper than the genomeDir's (engine.hip buildDeepSAindex)
+    "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
+    "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
+    "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
 }
 
 
@@ -125,10 +127,3 @@ def test_front_end_two_contexts_on_one_device(tmp_path, emul_cli):
     with the 1st-pass junctions inserted into BOTH contexts' resident arrays"""
     from test_cli_pipeline import run_cli_case
     run_cli_case(emul_cli, "pe101", ["--twopassMode", "Basic", "--readMapNumber", "60", "--gpuDevices", "0,0"], 12, tmp_path, env=SMALL)
-
-
-def test_front_end_two_pass_with_deep_seed_table(tmp_path, emul_cli):
-    """STARAMD_SEED_SAI_NBASES: the seed search's own, deeper L-mer table is built on the device at start-up and again after the 1st-pass junctions
-    went into the resident suffix array; the outputs do not depend on it"""
-    from test_cli_pipeline import run_cli_case
-    run_cli_case(emul_cli, "pe101", ["--twopassMode", "Basic", "--readMapNumber", "50"], 25, tmp_path, env=dict(SMALL, STARAMD_SEED_SAI_NBASES="11"))
