@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the index-size sweep (100 / 400 / 1000 Mb)")
     ap.add_argument("--no-two-pass", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip kernel_ms_exclusive / host_budget / all_transcripts / config1")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("STARAMD_BENCH_BUDGET_S", "1500")), help="optional legs are skipped once this much wall time is used")
     ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/dev/shm/star_amd_bench" if os.path.isdir("/dev/shm") else "/tmp/star_amd_bench"))
     return ap.parse_args()
@@ -113,30 +114,34 @@ def build_genome(args, mb, log):
 _SAMPLER = None
 
 
+_CHIM = 0.0
+
+
 def _chunk_job(job):
     seed, n, prefix, first_id = job
     from star_amd import synth
-    m1, m2 = _SAMPLER.sample(seed, n)
+    m1, m2 = _SAMPLER.sample(seed, n, chim_rate=_CHIM)
     synth.write_fastq_ids(prefix, m1, m2, first_id)
     return prefix
 
 
-def make_reads(args, g, out_dir, tag, n_pairs, seed_base):
+def make_reads(args, g, out_dir, tag, n_pairs, seed_base, read_len=None, chim_rate=0.0):
     """n_pairs pairs as <out_dir>/<tag>_{1,2}.fq.  Runs in a child interpreter (`bench.py --make-reads ...`): the sampler forks a pool of
     workers, which must not happen in a process that has initialised the HIP runtime."""
     out = [os.path.join(out_dir, "%s_%d.fq" % (tag, m)) for m in (1, 2)]
     if not os.path.isfile(os.path.join(out_dir, tag + ".DONE")):
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--make-reads", json.dumps([args.read_len, g, out_dir, tag, n_pairs, seed_base, int(os.environ.get("WORLD_SIZE", "1"))])],
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--make-reads", json.dumps([read_len or args.read_len, g, out_dir, tag, n_pairs, seed_base, int(os.environ.get("WORLD_SIZE", "1")), chim_rate])],
                        check=True, timeout=1200, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
     return out
 
 
-def _make_reads_child(read_len, g, out_dir, tag, n_pairs, seed_base, world):
+def _make_reads_child(read_len, g, out_dir, tag, n_pairs, seed_base, world, chim_rate=0.0):
     """chunks are sampled by a pool of forked workers from the shared genome / transcriptome arrays, then joined into one file per mate
     (a comma-separated list would send the reference through a fifo + an executable script in its temp directory: /dev/shm is noexec)"""
-    global _SAMPLER
+    global _SAMPLER, _CHIM
     import numpy as np
     from star_amd import synth
+    _CHIM = float(chim_rate)
     os.makedirs(out_dir, exist_ok=True)
     chunk = 500000
     jobs = []
@@ -185,6 +190,16 @@ COUNTER_NAMES = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "
 STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitch_verify+replay+finish", "k_scan+k_gather", "device_total"]
 
 
+def engine_src_sha():
+    """sha256 over the kernel sources of the engine: what a PMC-derived figure (profiles/*_pmc_hbm_traffic.json) must have been measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "star_amd", "csrc", "engine")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def report_dict(rep, lread):
     n = max(int(rep.timedReads), 1); nb = max(int(rep.batches), 1)
     c = dict(zip(COUNTER_NAMES, [int(x) for x in rep.counters]))
@@ -227,7 +242,20 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
     run(1, ncpu)                                    # page cache
     t_load = min(run(1, ncpu), run(1, ncpu))
     tried = {}
-    for th in sorted(set([max(1, ncpu // 4), max(1, ncpu // 2), ncpu])):
+    extras = {}
+    best_th = max(1, ncpu // 4)
+    try:        # what a user would run on this box instead of one 256-thread process
+        t = time.perf_counter()
+        refstar.align(idx, fq, out_prefix + "dflt_", threads=best_th, extra=["--readMapNumber", str(n_pairs)], timeout=900)       # default --limitIObufferSize
+        extras["default_io_buffer"] = {"threads": best_th, "Mreads_s": n_pairs / max(time.perf_counter() - t - t_load, 1e-3) / 1e6}
+        log("reference STAR, default input buffer, %d threads: %.1f s" % (best_th, time.perf_counter() - t))
+    except Exception as e:
+        extras["default_io_buffer"] = {"error": repr(e)[:200]}
+    try:
+        extras["multi_process"] = multi_process_baseline(idx, fq, out_prefix, n_pairs, ncpu, small, log)
+    except Exception as e:
+        extras["multi_process"] = {"error": repr(e)[:300]}
+    for th in sorted(set([best_th, ncpu])):
         t_full = run(n_pairs, th)
         tried[th] = n_pairs / max(t_full - t_load, 1e-3) / 1e6
     # the all-core run is last: its outputs stay for the parity check
@@ -245,7 +273,50 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
                       "mapping time = wall(full) - wall(index load only, %.1f s); by thread count (Mreads/s): %s; one thread on %d pairs: %s Mreads/s"
                       % (n_pairs, ncpu, chunks, chunks / ncpu, t_load, ", ".join("%d: %.4f" % (k, v) for k, v in sorted(tried.items())), n1,
                          ("%.5f" % one) if one else "n/a"),
-            "by_threads": {str(k): v for k, v in sorted(tried.items())}, "one_thread": one, "index_load_s": t_load}
+            "by_threads": {str(k): v for k, v in sorted(tried.items())}, "one_thread": one, "index_load_s": t_load,
+            "default_io_buffer": extras.get("default_io_buffer"), "multi_process": extras.get("multi_process")}
+
+
+def multi_process_baseline(idx, fq, out_prefix, n_pairs, ncpu, small, log):
+    """8 reference processes side by side, cores/8 threads each, every one on its own eighth of the FASTQ (each holds its own copy of the index, as
+    8 independent STAR runs do): what the box can do when the one input mutex of a single process is taken out of the picture."""
+    from oracle import refstar
+    nproc = 8
+    mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9
+    idx_gb = sum(os.path.getsize(os.path.join(idx, f)) for f in ("Genome", "SA", "SAindex")) / 1e9
+    if mem_gb < nproc * idx_gb * 1.3 + 64:
+        return {"skipped": "%.0f GB of RAM for %d index copies of %.0f GB" % (mem_gb, nproc, idx_gb)}
+    per = n_pairs // nproc
+    # the FASTQ records have a fixed size (synth.write_fastq_ids): slices by byte offset
+    slices = []
+    for k in range(nproc):
+        fs = []
+        for m, f in enumerate(fq):
+            rec = os.path.getsize(f) // n_pairs
+            o = "%smp%d_%d.fq" % (out_prefix, k, m + 1)
+            with open(f, "rb") as fi, open(o, "wb") as fo:
+                fi.seek(k * per * rec); left = per * rec
+                while left > 0:
+                    b = fi.read(min(left, 1 << 26)); fo.write(b); left -= len(b)
+            fs.append(o)
+        slices.append(fs)
+    th = max(1, ncpu // nproc)
+
+    def wave(nmap):
+        t = time.perf_counter()
+        ps = [subprocess.Popen([refstar.REF_BIN, "--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + slices[k] + ["--runThreadN", str(th), "--outFileNamePrefix", "%smp%d_" % (out_prefix, k),
+                                "--readMapNumber", str(nmap)] + small, stdout=subprocess.DEVNULL) for k in range(nproc)]
+        rcs = [p.wait(timeout=1200) for p in ps]
+        if any(rcs):
+            raise RuntimeError("exit codes %r" % rcs)
+        return time.perf_counter() - t
+    t_load = wave(1)
+    t_full = wave(per)
+    for fs in slices:
+        for f in fs:
+            os.remove(f)
+    log("reference STAR x %d processes x %d threads: load %.1f s, full %.1f s" % (nproc, th, t_load, t_full))
+    return {"processes": nproc, "threads_each": th, "Mreads_s": nproc * per / max(t_full - t_load, 1e-3) / 1e6, "load_only_s": t_load, "full_s": t_full, "pairs": nproc * per}
 
 
 def _digest_range(job):
@@ -345,10 +416,9 @@ def main():
     threads = args.host_threads or max(4, min(64, (os.cpu_count() or 8) // world))
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", outp, "--runThreadN", str(threads),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
-    # experiment knob (default 1 = the measured configuration): STARAMD_BENCH_CONTEXTS=2 runs two engine contexts on the rank's GPU (two mapper
-    # threads, two index replicas): the copies and the low-occupancy tails of one batch overlap with the kernels of the other
-    n_ctx = max(1, int(os.environ.get("STARAMD_BENCH_CONTEXTS", "1")))
-    argv += ["--gpuDevice", str(local_rank)] if n_ctx == 1 else ["--gpuDevices", ",".join([str(local_rank)] * n_ctx)]
+    # (the front end runs STARAMD_CONTEXTS_PER_GPU engine contexts per GPU, default 2: two mapper threads over ONE resident index, so that the copies
+    # and the low-occupancy tails of one batch overlap with the kernels of the next; rep.nContexts says how many ran)
+    argv += ["--gpuDevice", str(local_rank)]
     t_clock = {}
 
     def warmup_done():
@@ -397,14 +467,17 @@ def main():
     achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
     value = timed_reads_all / elapsed / 1e6
     traffic = None; traffic_all = None
-    try:        # HBM traffic of the dominant kernel from rocprofv3 --pmc passes (profiles/README.md); only when taken on THIS engine build and workload size
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
-        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads:
+    issue = None
+    try:        # HBM traffic / issue utilisation from rocprofv3 --pmc passes (profiles/README.md): only when taken on THIS engine source and workload size
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
+        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads and tj.get("engine_src_sha") == engine_src_sha():
             traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
             traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+            issue = {k: v["valu_busy_frac"] for k, v in tj.items() if isinstance(v, dict) and "valu_busy_frac" in v} or None
     except Exception:
         traffic = None
-    device_s = sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nDevices)))) / 1e3
+    n_ctx = max(1, int(rep.nContexts))
+    device_s = sum(float(rep.deviceMs[k]) for k in range(n_ctx)) / 1e3
     out = {
         "metric": "million reads aligned/sec (whole node), 2x101 bp PE human-scale index, FASTQ in -> SAM out",
         "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -418,13 +491,13 @@ def main():
                    "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads,
                    "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_per_kernel": traffic_all, "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
+                     "traffic": traffic, "traffic_per_kernel": traffic_all, "issue": issue, "engine_src_sha": engine_src_sha(), "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
                      "algorithmic_bytes_per_pair_whole_path": bytes_per_pair,
                      "note": "per launch = per batch of %d pairs, averaged over the %d timed batches of rank 0 (HIP events on the engine's stream)" % (args.reads, int(rep.batches))},
         "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
         "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s": device_s, "device_resident_Mreads_s": n / device_s / 1e6 if device_s > 0 else None,
                      "cli_over_device": device_s / float(rep.timedWall) if rep.timedWall > 0 else None,
-                     "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(max(1, int(rep.nDevices)))), "engine_contexts_per_gpu": n_ctx, "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
+                     "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(n_ctx)), "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)), "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
                      "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                      "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                      "finish_s": float(rep.finishSeconds),
@@ -446,6 +519,20 @@ def main():
             log("full_size_parity done")
         except Exception as e:
             out["full_size_parity"] = {"error": repr(e)[:300]}
+    if world == 1 and not args.no_extra_legs:
+        for name, fn in (("kernel_ms_exclusive", lambda: exclusive_leg(args, idx, fq, run_dir, threads)),
+                         ("host_budget", lambda: host_budget_leg(args, idx, fq, run_dir)),
+                         ("all_transcripts", lambda: all_transcripts_leg(args, g, idx, log)),
+                         ("config1", lambda: config1_leg(args, log))):
+            if time.time() - T_START > args.budget_s:
+                out[name] = {"skipped": "time budget"}; continue
+            try:
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": repr(e)[:400]}
+            log(name + " done")
+        if isinstance(out.get("kernel_ms_exclusive"), dict) and "per_kernel_ms" in out["kernel_ms_exclusive"]:
+            out["roofline"]["per_kernel_ms_exclusive"] = out["kernel_ms_exclusive"]["per_kernel_ms"]
     if not args.no_sweep and world == 1:
         out["index_size_sweep"] = sweep(args, mb, out, log)
     if not args.no_two_pass and world == 1 and time.time() - T_START < args.budget_s:
@@ -456,6 +543,109 @@ def main():
     out["bench_wall_s"] = time.time() - T_START
     out["notes"] = notes
     print(json.dumps(out))
+
+
+def _cli_leg(argv, lread, env=None):
+    """one run of the product pipeline with extra environment; returns (rep, summary dict)"""
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k); os.environ[k] = v
+    try:
+        rc, rep = run_cli(argv)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if rc:
+        raise RuntimeError("exit code %d" % rc)
+    c, ms, kern, bpp = report_dict(rep, lread)
+    n = max(int(rep.timedReads), 1)
+    return rep, {"Mreads_s": n / float(rep.timedWall) / 1e6, "per_kernel_ms": ms, "timed_reads": n,
+                 "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
+                 "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
+                 "device_Mreads_s": n / (sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nContexts)))) / 1e3) / 1e6,
+                 "engine_contexts": int(rep.nContexts), "counters_per_pair": {k: v / n for k, v in c.items() if not isinstance(v, dict)}}
+
+
+def exclusive_leg(args, idx, fq, run_dir, threads):
+    """Per-kernel times with ONE engine context (no second batch sharing the GPU): what a launch costs when it has the device to itself.  The bench
+    line's own per_kernel_ms are taken in the timed region, where the launches of two contexts overlap."""
+    nb, w = 4, 1
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "excl_"), "--runThreadN", str(threads),
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
+    rep, d = _cli_leg(argv, 2 * args.read_len + 1, {"STARAMD_CONTEXTS_PER_GPU": "1"})
+    return d
+
+
+def host_budget_leg(args, idx, fq, run_dir):
+    """The host at the budget of an 8-GPU node: the same pipeline with cores/8 host threads for this GPU."""
+    th = max(4, (os.cpu_count() or 8) // 8)
+    nb, w = 8, 2
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "hb_"), "--runThreadN", str(th),
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
+    rep, d = _cli_leg(argv, 2 * args.read_len + 1)
+    d["host_threads"] = th
+    d["what"] = "one GPU, --runThreadN = cores / 8: the host share of one rank on an 8-GPU node"
+    return d
+
+
+def all_transcripts_leg(args, g, idx, log):
+    """2x150, 1 % errors, 5 % chimeric pairs, --chimSegmentMin 12: chimeric detection wants EVERY transcript of every window
+    (resultSelect 0, no window pruning: stitchWindowAligns.cpp:245-247).  Same index (sjdbOverhang 100).  Parity against the reference on a bounded
+    sample: SAM multiset, SJ.out.tab, Chimeric.out.junction."""
+    from oracle import refstar
+    L = 150; nb, w = 4, 1
+    n_total = (nb + w) * args.reads
+    rd = os.path.join(g, "chim_n%d" % n_total)
+    fq = make_reads(args, g, rd, "chim", n_total, 8100, read_len=L, chim_rate=0.05)
+    flags = ["--chimSegmentMin", "12", "--chimOutType", "Junctions"]
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"), "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))),
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)] + flags
+    rep, d = _cli_leg(argv, 2 * L + 1)
+    d["workload"] = "%d pairs 2x%d, 1%% substitutions, 5%% chimeric pairs, --chimSegmentMin 12 (every transcript of every window returned, no window pruning)" % (n_total, L)
+    # parity on a sample both can do quickly: the first 200 k pairs
+    ns = min(200000, n_total)
+    p_new, p_ref = os.path.join(rd, "gpuS_"), os.path.join(rd, "ref_")
+    rc, _ = run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "32", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)] + flags)
+    if rc:
+        raise RuntimeError("sample run: exit code %d" % rc)
+    t = time.perf_counter()
+    refstar.align(idx, fq, p_ref, threads=min(64, os.cpu_count() or 8), extra=["--readMapNumber", str(ns)] + flags, timeout=900)
+    d["reference_sample_s"] = time.perf_counter() - t
+    par = full_size_parity(p_ref, p_new) or {}
+    cj = [sorted(l for l in open(p + "Chimeric.out.junction", "rb") if not l.startswith(b"#")) for p in (p_ref, p_new)]
+    par["chimeric_junctions"] = len(cj[1]); par["chimeric_junction_identical"] = cj[0] == cj[1]
+    d["parity_vs_reference"] = par; d["parity_sample_pairs"] = ns
+    return d
+
+
+def config1_leg(args, log):
+    """BASELINE config 1 stand-in: yeast-size genome (12 Mb), single-end 1x50 reads; the reference with --runThreadN 1 on 100 k of them beside it."""
+    from oracle import refstar
+    mb = 12
+    sub = argparse.Namespace(**vars(args)); sub.read_len = 50
+    g, ginfo = build_genome(sub, mb, log)
+    nb, w = 4, 1
+    n_total = (nb + w) * args.reads
+    rd = os.path.join(g, "se_n%d" % n_total)
+    fq = make_reads(sub, g, rd, "se", n_total, 8200, read_len=50)[:1]
+    idx = os.path.join(g, "idx")
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"), "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))),
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)]
+    rep, d = _cli_leg(argv, 50)
+    d["workload"] = "%d single-end reads 1x50, synthetic %d Mb genome (yeast size), SAindex %d bases" % (n_total, mb, ginfo.get("SAindexNbases", 0))
+    ns = 100000
+    p_new, p_ref = os.path.join(rd, "gpuS_"), os.path.join(rd, "ref_")
+    rc, _ = run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "16", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)])
+    if rc:
+        raise RuntimeError("sample run: exit code %d" % rc)
+    t = time.perf_counter(); refstar.align(idx, fq, p_ref, threads=1, extra=["--readMapNumber", str(ns)], timeout=900); t_full = time.perf_counter() - t
+    t = time.perf_counter(); refstar.align(idx, fq, p_ref + "l_", threads=1, extra=["--readMapNumber", "1"], timeout=900); t_load = time.perf_counter() - t
+    d["reference_1_thread_Mreads_s"] = ns / max(t_full - t_load, 1e-3) / 1e6
+    d["parity_vs_reference"] = full_size_parity(p_ref, p_new); d["parity_sample_reads"] = ns
+    return d
 
 
 def sweep(args, main_mb, main_out, log):

@@ -198,6 +198,17 @@ typedef struct staramd_ctx staramd_ctx;
 /* Upload the index to HBM (once per GPU). maxBatchReads/maxBatchBases size the device work space. */
 int  staramd_create(staramd_ctx **out, int device, const staramd_genome *g, const staramd_params *p,
                     uint32_t maxBatchReads, uint64_t maxBatchBases);
+/* One more context on the device of `owner` that maps against the OWNER's resident index: work space, stream and events are its own, the
+ * 30 GB of index are not uploaded a second time.  Two (or more) contexts of one GPU fed by two host threads keep the device busy while the
+ * results of a batch are copied out and the next batch is copied in, and fill the low-occupancy tails of each other's launches (the
+ * reference's counterpart: several ReadAlignChunk workers over one shared Genome, source/STAR.cpp:194-201).  Calls that change the index
+ * (staramd_update_index / insert_junctions / update_tables / set_novel_junctions) go to the owner while no sharer is mapping; the sharers
+ * follow.  Destroy the sharers before the owner. */
+int  staramd_create_shared(staramd_ctx **out, staramd_ctx *owner, uint32_t maxBatchReads, uint64_t maxBatchBases);
+/* Page-locked host memory for the caller-owned batch / result arrays ("caller-owned pinned buffers"): staramd_map_batch copies
+ * from / into them by DMA; with pageable memory the runtime stages every copy through a bounce buffer of its own.  Plain memory still works. */
+void *staramd_pinned_alloc(uint64_t bytes);
+void  staramd_pinned_free(void *p);
 /* Replace the index after sjdbInsertJunctions (two-pass); same semantics as create's upload. */
 int  staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p);
 /* Junction insertion into the index RESIDENT in HBM (sjdbBuildIndex, source/sjdbBuildIndex.cpp:15-333): the suffix search of

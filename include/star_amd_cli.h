@@ -33,7 +33,7 @@ typedef struct staramd_cli_report {
     double   timedWall;
     double   genomeLoadSeconds, indexUploadSeconds;
     int      nDevices;
-    double   deviceBusy[STARAMD_CLI_MAX_DEV];     /* seconds inside staramd_map_batch per device, timed region        */
+    double   deviceBusy[STARAMD_CLI_MAX_DEV];     /* seconds inside staramd_map_batch per engine context, timed region */
     double   deviceMs[STARAMD_CLI_MAX_DEV];       /* HIP-event device time per device, timed region                   */
     double   stageMs[8];           /* engine stages summed over the timed batches (staramd_get_timings order)         */
     uint64_t counters[40];         /* engine counters summed over the timed batches (staramd_get_counters order)      */
@@ -41,6 +41,7 @@ typedef struct staramd_cli_report {
     uint64_t batches;              /* timed batches                                                                   */
     double   pass1Seconds;         /* --twopassMode Basic: 1st pass + junction insertion + index re-upload            */
     double   finishSeconds;        /* after the last batch is handed to the writer: last writes, SJ.out.tab, Log.final.out (inside timedWall) */
+    int      nContexts;            /* engine contexts (= mapper threads): nDevices x STARAMD_CONTEXTS_PER_GPU; deviceBusy / deviceMs are per context */
 } staramd_cli_report;
 
 /* Runs the whole job; returns the process exit code (0 ok).  hooks / report may be NULL. */

@@ -5,6 +5,8 @@
 #include "../include/star_amd.h"
 #include "../include/star_amd_index.h"
 #include <string>
+#include <cstdlib>
+#include <mutex>
 
 extern "C" {
 void *oracle_create(const staramd_genome *g, const staramd_params *p);
@@ -15,20 +17,25 @@ int sjdb_emul_insert(int, const staramd_sjdb_args *a, staramd_sjdb_result *res);
 int index_emul_build(const uint8_t *G, uint64_t nGenome, uint32_t GstrandBit, uint32_t saIndexNbases, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, uint64_t *out);
 }
 
-struct staramd_ctx { void *o; };
+struct staramd_ctx { void *o; staramd_ctx *owner; std::mutex m; };     // a "shared" context forwards to its owner's oracle (one batch at a time)
 static std::string lastError;
 
 extern "C" {
-int staramd_create(staramd_ctx **out, int, const staramd_genome *g, const staramd_params *p, uint32_t, uint64_t) { *out = new staramd_ctx{oracle_create(g, p)}; return STARAMD_OK; }
+int staramd_create(staramd_ctx **out, int, const staramd_genome *g, const staramd_params *p, uint32_t, uint64_t) { *out = new staramd_ctx(); (*out)->o = oracle_create(g, p); (*out)->owner = nullptr; return STARAMD_OK; }
+int staramd_create_shared(staramd_ctx **out, staramd_ctx *owner, uint32_t, uint64_t) { *out = new staramd_ctx(); (*out)->o = nullptr; (*out)->owner = owner->owner ? owner->owner : owner; return STARAMD_OK; }
 int staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p) { oracle_destroy(ctx->o); ctx->o = oracle_create(g, p); return STARAMD_OK; }
 int staramd_set_novel_junctions(staramd_ctx *ctx, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage) { return oracle_set_novel_junctions(ctx->o, start, end, n, stage); }
 int staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results *r) {
-    int rc = oracle_map_batch(ctx->o, b, r);
+    staramd_ctx *own = ctx->owner ? ctx->owner : ctx;
+    std::lock_guard<std::mutex> lock(own->m);
+    int rc = oracle_map_batch(own->o, b, r);
     r->msSeed = r->msWindows = r->msStitch = r->msTotalDevice = 0;
     if (rc) lastError = "result buffers too small";
     return rc;
 }
-void staramd_destroy(staramd_ctx *ctx) { if (ctx) { oracle_destroy(ctx->o); delete ctx; } }
+void staramd_destroy(staramd_ctx *ctx) { if (ctx) { if (ctx->o) oracle_destroy(ctx->o); delete ctx; } }
+void *staramd_pinned_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
+void staramd_pinned_free(void *p) { free(p); }
 const char *staramd_last_error(void) { return lastError.c_str(); }
 int staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p) { return staramd_update_index(ctx, g, p); }
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }

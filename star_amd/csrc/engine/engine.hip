@@ -81,7 +81,12 @@ struct staramd_ctx {
     u32 residentReads = 0; u32 residentMaxLread = 0;
     u32 *hostScratch = nullptr;         // pinned: totals + cursors read-back
     std::vector<u64> rebased;           // read offsets of a batch that does not start at base 0
+    // a context created with staramd_create_shared maps against the resident index of its OWNER (same device): work space, stream and
+    // events are its own, X / dX are copies of the owner's, refreshed whenever the owner's index changes
+    staramd_ctx *owner = nullptr; std::vector<staramd_ctx *> sharers;
 };
+static void refreshSharers(staramd_ctx *c) { for (staramd_ctx *s : c->sharers) { s->X = c->X; s->dX = c->dX; } }
+#define OWNER_ONLY(c) do { if ((c)->owner) { g_err = "this context shares the index of another one (staramd_create_shared): change the index through its owner"; return STARAMD_ERR_ARG; } } while (0)
 
 template <class T> static int devAlloc(std::vector<void *> &reg, T **p, u64 n) {
     void *q = nullptr;
@@ -332,12 +337,36 @@ extern "C" int staramd_create(staramd_ctx **out, int device, const staramd_genom
     return STARAMD_OK;
 }
 
+extern "C" int staramd_create_shared(staramd_ctx **out, staramd_ctx *owner, uint32_t maxBatchReads, uint64_t maxBatchBases) {
+    if (!out || !owner || maxBatchReads == 0) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    if (owner->owner) owner = owner->owner;
+    HIPCHK(hipSetDevice(owner->device));
+    staramd_ctx *c = new staramd_ctx();
+    c->device = owner->device; c->maxReads = maxBatchReads; c->maxBases = maxBatchBases ? maxBatchBases : (u64)maxBatchReads * (STARAMD_READ_LEN_MAX + 1);
+    c->owner = owner; c->X = owner->X; c->dX = owner->dX;
+    int rc = allocWork(c);
+    if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
+    if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
+    if (rc) { freeAll(c->workAllocs); delete c; return rc; }
+    memset(c->counters, 0, sizeof(c->counters));
+    owner->sharers.push_back(c);
+    *out = c;
+    return STARAMD_OK;
+}
+
+// page-locked host memory for the caller's batch / result arrays (include/star_amd.h: the copies of staramd_map_batch then run as DMA
+// transfers straight from / into them instead of being staged through the runtime's own pinned buffer)
+extern "C" void *staramd_pinned_alloc(uint64_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; } return p; }
+extern "C" void staramd_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int staramd_update_index(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     if (!c) { g_err = "null context"; return STARAMD_ERR_ARG; }
+    OWNER_ONLY(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     freeAll(c->indexAllocs);
     int rc = uploadIndex(c, g, p);
+    refreshSharers(c);
     return rc;
 }
 
@@ -351,6 +380,7 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
                                         staramd_sjdb_result *res) {
     if (!c || !a || !res || !a->Gsj || !a->isOld || (a->oldSjdbN && !a->oldSJind)) { g_err = "staramd_insert_junctions: null argument"; return STARAMD_ERR_ARG; }
     if (a->sjdbN == 0 || a->sjdbLength < 3) { g_err = "staramd_insert_junctions: no junctions"; return STARAMD_ERR_ARG; }
+    OWNER_ONLY(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     using namespace staridx;
@@ -384,11 +414,13 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
     X.G = R.dGnew + GPAD; X.SA = R.dSApacked; X.SAi = R.dSAiPacked;
     X.nGenome = R.nGenomeNew; X.nSA = R.nSAnew;
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    refreshSharers(c);
     return STARAMD_OK;
 }
 
 extern "C" int staramd_update_tables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     if (!c || !g || !p) { g_err = "staramd_update_tables: null argument"; return STARAMD_ERR_ARG; }
+    OWNER_ONLY(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     DevIndex &X = c->X;
@@ -397,12 +429,15 @@ extern "C" int staramd_update_tables(staramd_ctx *c, const staramd_genome *g, co
     std::vector<void *> kept;
     for (void *q : c->indexAllocs) { if (q == keep[0] || q == keep[1] || q == keep[2]) kept.push_back(q); else (void)hipFree(q); }
     c->indexAllocs.swap(kept);
-    return uploadTables(c, g, p);
+    const int rc = uploadTables(c, g, p);
+    refreshSharers(c);
+    return rc;
 }
 
 extern "C" int staramd_set_novel_junctions(staramd_ctx *c, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage) {
     if (!c || (n && (!start || !end))) { g_err = "staramd_set_novel_junctions: null argument"; return STARAMD_ERR_ARG; }
     if (n > 0xFFFFFFF0ull) { g_err = "staramd_set_novel_junctions: too many junctions"; return STARAMD_ERR_ARG; }
+    OWNER_ONLY(c);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     DevIndex &X = c->X; int rc;
@@ -414,6 +449,7 @@ extern "C" int staramd_set_novel_junctions(staramd_ctx *c, const uint64_t *start
     X.sjNovelN = n;
     X.P.outFilterBySJoutStage = (uint8_t)stage;
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    refreshSharers(c);
     return 0;
 }
 
@@ -421,7 +457,10 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    freeAll(c->indexAllocs); freeAll(c->workAllocs);
+    if (c->owner) { auto &v = c->owner->sharers; for (size_t i = 0; i < v.size(); i++) if (v[i] == c) { v.erase(v.begin() + i); break; } }
+    for (staramd_ctx *s : c->sharers) s->owner = nullptr;         // (their index is gone with this context: destroy the sharers first)
+    if (!c->owner) freeAll(c->indexAllocs);
+    freeAll(c->workAllocs);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->hostScratch) (void)hipHostFree(c->hostScratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);

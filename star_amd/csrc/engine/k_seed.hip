@@ -13,7 +13,7 @@
 // (first (rStart,Length) in schedule order wins).
 #include "dev.h"
 
-struct SeedCnt { u64 nSAi, nSAprobe, nGcmp; };
+struct SeedCnt { u32 nSAi, nSAprobe, nGcmp; };     // per lane and kernel: a lane compares < 2^32 bases
 
 // 8 bytes starting at an arbitrary address, little endian, through aligned 8-byte loads (the arrays are padded)
 __device__ __forceinline__ u64 load8(const u8 *p) {
@@ -62,53 +62,61 @@ __device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, 
 
 __device__ __forceinline__ u64 medianUint2(u64 a, u64 b) { return a / 2 + b / 2 + (a % 2 + b % 2) / 2; }
 
-// SuffixArrayFuns.cpp:106-131
-__device__ static u64 findMultRange(const DevIndex &X, const u8 *R, u64 i3, u32 L3, u64 i1, u32 L1, u64 i1a, u32 L1a, u64 i1b, u32 L1b, bool dirR, u32 S, SeedCnt &cn) {
+// SuffixArrayFuns.cpp:106-131.  IDX: suffix-array indices inside one search are offsets from `base` (the lower end of the interval the SAindex
+// look-up returned).  An interval is almost always shorter than 2^32 entries; then the seven indices of a search are 32-bit values (IDX = u32),
+// which halves the registers they take in a kernel that is held to 64.  The same code with IDX = u64 serves the rest (a look-up whose upper
+// neighbour is absent searches up to the end of a suffix array of 6.3 * 10^9 entries).
+template <class IDX> __device__ static IDX findMultRange(const DevIndex &X, const u8 *R, u64 base, IDX i3, u32 L3, IDX i1, u32 L1, IDX i1a, u32 L1a, IDX i1b, u32 L1b, bool dirR, u32 S, SeedCnt &cn) {
     bool compRes;
     if (L1 < L3) { L1b = L1; i1b = i1; i1a = i3; }
     else if (L1a < L1) { L1b = L1a; i1b = i1a; i1a = i1; }
-    while ((i1b + 1 < i1a) | (i1b > i1a + 1)) {
-        u64 i1c = medianUint2(i1a, i1b);
-        u32 L1c = compareSeqToGenome(X, R, S, L3, L1b, i1c, dirR, compRes, cn);
+    while (((u64)i1b + 1 < (u64)i1a) | ((u64)i1b > (u64)i1a + 1)) {
+        IDX i1c = (IDX)medianUint2(i1a, i1b);
+        u32 L1c = compareSeqToGenome(X, R, S, L3, L1b, base + i1c, dirR, compRes, cn);
         if (L1c == L3) i1a = i1c; else { i1b = i1c; L1b = L1c; }
     }
     return i1a;
 }
 
 // SuffixArrayFuns.cpp:133-207
-__device__ static u64 maxMappableLength(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
+template <class IDX> __device__ static u64 maxMappableLengthT(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1in, u64 i2in, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
     bool compRes;
-    u32 L1, L2, L3, L1a, L1b, L2a, L2b; u64 i3, i1a, i1b, i2a, i2b;
-    L1 = compareSeqToGenome(X, R, S, N, L, i1, dirR, compRes, cn);
-    L2 = compareSeqToGenome(X, R, S, N, L, i2, dirR, compRes, cn);
+    const u64 base = i1in;
+    u32 L1, L2, L3, L1a, L1b, L2a, L2b; IDX i1 = 0, i2 = (IDX)(i2in - i1in), i3, i1a, i1b, i2a, i2b;
+    L1 = compareSeqToGenome(X, R, S, N, L, base + i1, dirR, compRes, cn);
+    L2 = compareSeqToGenome(X, R, S, N, L, base + i2, dirR, compRes, cn);
     L = min(L1, L2);
     L1a = L1; L1b = L1; i1a = i1; i1b = i1; L2a = L2; L2b = L2; i2a = i2; i2b = i2;
     i3 = i1; L3 = L1;
-    while (i1 + 1 < i2) {
-        i3 = medianUint2(i1, i2);
-        L3 = compareSeqToGenome(X, R, S, N, L, i3, dirR, compRes, cn);
+    while ((u64)i1 + 1 < (u64)i2) {
+        i3 = (IDX)medianUint2(i1, i2);
+        L3 = compareSeqToGenome(X, R, S, N, L, base + i3, dirR, compRes, cn);
         if (L3 == N) break;
         if (compRes) { if (L3 > L1) { L1b = L1a; L1a = L1; i1b = i1a; i1a = i1; } i1 = i3; L1 = L3; }
         else { if (L3 > L2) { L2b = L2a; L2a = L2; i2b = i2a; i2a = i2; } i2 = i3; L2 = L3; }
         L = min(L1, L2);
     }
     if (L3 < N) { if (L1 > L2) { i3 = i1; L3 = L1; } else { i3 = i2; L3 = L2; } }
-    i1 = findMultRange(X, R, i3, L3, i1, L1, i1a, L1a, i1b, L1b, dirR, S, cn);
-    i2 = findMultRange(X, R, i3, L3, i2, L2, i2a, L2a, i2b, L2b, dirR, S, cn);
-    L = L3; ind0 = i1; ind1 = i2;
-    return i2 - i1 + 1;
+    i1 = findMultRange<IDX>(X, R, base, i3, L3, i1, L1, i1a, L1a, i1b, L1b, dirR, S, cn);
+    i2 = findMultRange<IDX>(X, R, base, i3, L3, i2, L2, i2a, L2a, i2b, L2b, dirR, S, cn);
+    L = L3; ind0 = base + i1; ind1 = base + i2;
+    return (u64)i2 - (u64)i1 + 1;
+}
+__device__ __forceinline__ u64 maxMappableLength(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
+    if (i2 - i1 < 0xFFFFFFFFull) return maxMappableLengthT<u32>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
+    return maxMappableLengthT<u64>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
 }
 
 struct SeedState {
     DSeed *PC; u32 nP; u32 cap;
-    u64 nA; u32 multNmin, multNminL;
+    u32 nA; u32 multNmin, multNminL;        // nA: only ever compared with 0 (ReadAlign_mapOneRead.cpp:106), saturating
     bool fatal;
 };
 
 // ReadAlign_storeAligns.cpp:10-160 (OPTIM_STOREaligns_SIMPLE branch)
 __device__ static void storeAligns(const DevIndex &X, SeedState &st, u32 iDir, u32 Shift, u64 Nrep, u32 L, u64 ind0, u32 iFrag) {
     if (Nrep > X.P.seedMultimapNmax) { if (Nrep < st.multNmin || st.multNmin == 0) { st.multNmin = (u32)min(Nrep, (u64)0xFFFFFFFFu); st.multNminL = L; } return; }
-    st.nA += Nrep;
+    st.nA |= 1u;
     u32 rStart = iDir == 0 ? Shift : Shift + 1 - L;
     int iP;
     for (iP = (int)st.nP - 1; iP >= 0; iP--) {
@@ -218,45 +226,50 @@ extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_search(cons
         const u8 *R = B.bases + B.readOffset[ir];
         u32 Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         st.nP = 0; st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
-        // qualitySplit, SequenceFuns.cpp:411-444
-        u16 spStart[16], spLen[16]; u8 spFrag[16];
+        // qualitySplit (SequenceFuns.cpp:411-444) and the loop over its pieces (ReadAlign_mapOneRead.cpp:40-93) fused: a piece is searched as soon as its
+        // end is found -- the pieces are processed in the order the reference stores them, and a table of pieces indexed at run time would live in
+        // scratch memory (it did: 80 bytes per lane, re-read for every seed)
         u32 Nsplit = 0, LgoodMin = 0;
+        const u32 seedSearchStartLmax = min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1)));
         {
             u32 iR = 0, iFrag = 0;
             while ((iR < Lread) & (Nsplit < P.maxNsplit)) {
                 while (iR < Lread && R[iR] > 3) { if (R[iR] == STARAMD_SPACER_BASE) iFrag++; iR++; }
                 if (iR == Lread) break;
-                u32 iR1 = iR;
-                while (iR < Lread && R[iR] <= 3) iR++;
-                if ((iR - iR1) > LgoodMin) LgoodMin = iR - iR1;
-                if ((iR - iR1) < P.seedSplitMin) continue;
-                spStart[Nsplit] = (u16)iR1; spLen[Nsplit] = (u16)(iR - iR1); spFrag[Nsplit] = (u8)iFrag; Nsplit++;
-            }
-        }
-        u32 seedSearchStartLmax = min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1)));
-        for (u32 ip = 0; ip < Nsplit; ip++) {
-            u32 pS = spStart[ip], pL = spLen[ip];
-            u32 Nstart = (P.seedSearchStartLmax > 0 && seedSearchStartLmax < pL) ? pL / seedSearchStartLmax + 1 : 1;
-            u32 Lstart = pL / Nstart;
-            bool flagDirMap = true;
-            for (u32 iDir = 0; iDir < 2; iDir++) {
-                for (u32 istart = 0; istart < Nstart; istart++) {
-                    u32 Lm;
-                    if (flagDirMap || istart > 0) {
-                        u32 Lmapped = 0;
-                        while (istart * Lstart + Lmapped + P.seedMapMin < pL) {
-                            u32 Shift = iDir == 0 ? (pS + istart * Lstart + Lmapped) : (pS + pL - istart * Lstart - 1 - Lmapped);
-                            u32 seedLength = pL - Lmapped - istart * Lstart;
-                            maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, spFrag[ip], cn);
-                            if (iDir == 0 && istart == 0 && Lmapped == 0 && Shift + Lm == pL) flagDirMap = false;
-                            Lmapped += Lm;
-                            if (Lm == 0) break;
+                const u32 pS = iR;
+                for (;;) {                                                  // end of the run of good bases, 8 bases per step
+                    const u64 bad = load8(R + iR) & 0xFCFCFCFCFCFCFCFCull;
+                    const u32 k = bad ? ((u32)__builtin_ctzll(bad) >> 3) : 8u;
+                    iR += k;
+                    if (iR >= Lread) { iR = Lread; break; }
+                    if (k < 8u) break;
+                }
+                const u32 pL = iR - pS;
+                if (pL > LgoodMin) LgoodMin = pL;
+                if (pL < P.seedSplitMin) continue;
+                Nsplit++;
+                const u32 Nstart = (P.seedSearchStartLmax > 0 && seedSearchStartLmax < pL) ? pL / seedSearchStartLmax + 1 : 1;
+                const u32 Lstart = pL / Nstart;
+                bool flagDirMap = true;
+                for (u32 iDir = 0; iDir < 2; iDir++) {
+                    for (u32 istart = 0; istart < Nstart; istart++) {
+                        u32 Lm;
+                        if (flagDirMap || istart > 0) {
+                            u32 Lmapped = 0;
+                            while (istart * Lstart + Lmapped + P.seedMapMin < pL) {
+                                u32 Shift = iDir == 0 ? (pS + istart * Lstart + Lmapped) : (pS + pL - istart * Lstart - 1 - Lmapped);
+                                u32 seedLength = pL - Lmapped - istart * Lstart;
+                                maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, iFrag, cn);
+                                if (iDir == 0 && istart == 0 && Lmapped == 0 && Shift + Lm == pL) flagDirMap = false;
+                                Lmapped += Lm;
+                                if (Lm == 0) break;
+                            }
                         }
-                    }
-                    if (P.seedSearchLmax > 0) {
-                        u32 Shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1);
-                        u32 seedLength = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - Shift) : (Shift + 1));
-                        maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, spFrag[ip], cn);
+                        if (P.seedSearchLmax > 0) {
+                            u32 Shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1);
+                            u32 seedLength = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - Shift) : (Shift + 1));
+                            maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, iFrag, cn);
+                        }
                     }
                 }
             }

@@ -45,8 +45,21 @@ struct Tokens {                                  // counting semaphore over a sm
     int take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free.empty(); }); int v = free.front(); free.pop_front(); return v; }
     void give(int v) { { std::lock_guard<std::mutex> l(m); free.push_back(v); } cv.notify_all(); }
 };
+// result arrays of a batch: page-locked (staramd_pinned_alloc), so that the engine's device-to-host copies are DMA transfers straight into them;
+// resize() leaves new elements as they are (the engine overwrites what it reports)
+template <class T> struct PinnedAlloc {
+    typedef T value_type;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) { void *p = staramd_pinned_alloc((uint64_t)n * sizeof(T)); if (!p) throw std::bad_alloc(); return (T *)p; }
+    void deallocate(T *p, size_t) { staramd_pinned_free(p); }
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
 struct ResBuf {
-    std::vector<staramd_read_result> reads; std::vector<staramd_transcript> tr; std::vector<staramd_exon> ex; staramd_results res;
+    std::vector<staramd_read_result, PinnedAlloc<staramd_read_result>> reads; std::vector<staramd_transcript, PinnedAlloc<staramd_transcript>> tr; std::vector<staramd_exon, PinnedAlloc<staramd_exon>> ex; staramd_results res;
     void size(uint64_t nReads) {
         if (reads.size() < nReads) reads.resize(nReads);
         if (tr.size() < nReads * 4 + 4096) { tr.resize(nReads * 4 + 4096); ex.resize(tr.size() * 3); }
@@ -102,26 +115,35 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     std::vector<int> devices = flags.devices;
     if (devices.empty()) devices.push_back(sah_device(h));
     if (devices.size() > STARAMD_CLI_MAX_DEV) { fprintf(stderr, "\nEXITING because of fatal PARAMETERS error: --gpuDevices lists more than %d devices\n", STARAMD_CLI_MAX_DEV); sah_destroy(h); return 104; }
-    const int nDev = (int)devices.size();
-    rep.nDevices = nDev; rep.genomeLoadSeconds = sah_genome_load_seconds(h);
-    // ---- one engine context per GPU, index replicas uploaded concurrently
+    // ---- engine contexts.  Every entry of --gpuDevices is an OWNER: a context with an index replica of its own, uploaded concurrently.  Every owner
+    // gets STARAMD_CONTEXTS_PER_GPU - 1 (default: 1) further contexts that share its resident index (staramd_create_shared: work space and stream of
+    // their own, no second replica); each context has a mapper thread, so a GPU always has a second batch in flight while the results of one are
+    // copied out and handed on (the reference: runThreadN workers over one shared genome, STAR.cpp:194-201)
+    const int nOwners = (int)devices.size();
+    int perGpu = 2; if (const char *e = getenv("STARAMD_CONTEXTS_PER_GPU")) perGpu = std::max(1, atoi(e));
+    while (nOwners * perGpu > STARAMD_CLI_MAX_DEV) perGpu--;
+    const int nDev = nOwners * perGpu;                       // contexts = mapper threads; context d belongs to owner d % nOwners
+    rep.nDevices = nOwners; rep.nContexts = nDev; rep.genomeLoadSeconds = sah_genome_load_seconds(h);
     std::vector<staramd_ctx *> ctx(nDev, nullptr);
+    auto destroyAll = [&]() { for (int d = nDev - 1; d >= 0; d--) if (ctx[d]) { staramd_destroy(ctx[d]); ctx[d] = nullptr; } };      // sharers before their owners
     {
         auto tu = Clock::now();
         std::vector<int> rcs(nDev, 0); std::vector<std::string> es(nDev);
         std::vector<std::thread> th;
-        for (int d = 0; d < nDev; d++) th.emplace_back([&, d] { rcs[d] = staramd_create(&ctx[d], devices[d], sah_genome(h), sah_params(h), (uint32_t)batchReads, 0); if (rcs[d]) es[d] = staramd_last_error(); });
+        for (int d = 0; d < nOwners; d++) th.emplace_back([&, d] { rcs[d] = staramd_create(&ctx[d], devices[d], sah_genome(h), sah_params(h), (uint32_t)batchReads, 0); if (rcs[d]) es[d] = staramd_last_error(); });
         for (auto &t : th) t.join();
+        for (int d = nOwners; d < nDev; d++) if (!rcs[d % nOwners]) { rcs[d] = staramd_create_shared(&ctx[d], ctx[d % nOwners], (uint32_t)batchReads, 0); if (rcs[d]) es[d] = staramd_last_error(); }
         for (int d = 0; d < nDev; d++) if (rcs[d]) {
-            fprintf(stderr, "\nEXITING because of FATAL ERROR: cannot initialise the MI355X engine on device %d: %s\n", devices[d], es[d].c_str());
-            for (auto c : ctx) if (c) staramd_destroy(c);
+            fprintf(stderr, "\nEXITING because of FATAL ERROR: cannot initialise the MI355X engine on device %d: %s\n", devices[d % nOwners], es[d].c_str());
+            destroyAll();
             sah_destroy(h); return 105;
         }
         rep.indexUploadSeconds = since(tu);
     }
 #ifndef STARAMD_NO_RESIDENT_SJDB
     // junction insertion between the passes runs on the arrays resident in HBM, on every context (no host copy of the new SA unless it is to be saved)
-    struct ResidentUser { std::vector<staramd_ctx *> *ctx; } residentUser{&ctx};
+    std::vector<staramd_ctx *> owners(ctx.begin(), ctx.begin() + nOwners);      // index changes go to the owners; the contexts that share an index follow
+    struct ResidentUser { std::vector<staramd_ctx *> *ctx; } residentUser{&owners};
     if (!getenv("STARAMD_SJDB_HOST") && !getenv("STARAMD_SJDB_NO_RESIDENT")) {
         sah_set_sjdb_resident_fn([](void *user, const staramd_sjdb_args *a, staramd_sjdb_result *res) -> int {
             std::vector<staramd_ctx *> &cx = *((ResidentUser *)user)->ctx;
@@ -285,17 +307,17 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
         std::vector<std::thread> th;
         if (phase == 1) {
             const bool inEngine = sah_index_in_engine(h) != 0;       // the insertion ran on the resident arrays: only tables and parameters are new
-            for (int d = 0; d < nDev; d++) th.emplace_back([&, d] {
+            for (int d = 0; d < nOwners; d++) th.emplace_back([&, d] {
                 rcs[d] = inEngine ? staramd_update_tables(ctx[d], sah_genome(h), sah_params(h)) : staramd_update_index(ctx[d], sah_genome(h), sah_params(h));
                 if (rcs[d]) es[d] = staramd_last_error(); });
             for (auto &t : th) t.join();
-            for (int d = 0; d < nDev; d++) if (rcs[d]) fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + es[d]);
+            for (int d = 0; d < nOwners; d++) if (rcs[d]) fail(std::string("EXITING because of FATAL ERROR: index re-upload failed: ") + es[d]);
             if (failed.load()) break;
             rep.pass1Seconds = since(t0);
             fprintf(stderr, "star_amd: 1st pass + junction insertion + index re-upload: %.3f s (%llu reads)\n", rep.pass1Seconds, (unsigned long long)nReads);
         } else {
             const uint64_t *ns, *ne; uint64_t nn = sah_novel_junctions(h, &ns, &ne);
-            for (int d = 0; d < nDev; d++) if (staramd_set_novel_junctions(ctx[d], ns, ne, nn, 2)) fail(std::string("EXITING because of FATAL ERROR: ") + staramd_last_error());
+            for (int d = 0; d < nOwners; d++) if (staramd_set_novel_junctions(ctx[d], ns, ne, nn, 2)) fail(std::string("EXITING because of FATAL ERROR: ") + staramd_last_error());
             if (failed.load()) break;
             fprintf(stderr, "star_amd: BySJout stage 1 done (%llu reads so far), %llu novel junctions passed filtering\n", (unsigned long long)nReads, (unsigned long long)nn);
         }
@@ -307,9 +329,9 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     double sec = since(t0);
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",
-                           (unsigned long long)nReads, sec, msDeviceAll / 1e3 / nDev, sec > 0 ? (double)nReads / sec / 1e6 : 0.0, nDev);
+                           (unsigned long long)nReads, sec, msDeviceAll / 1e3 / nDev, sec > 0 ? (double)nReads / sec / 1e6 : 0.0, nOwners);
     sah_set_sjdb_resident_fn(nullptr, nullptr);
-    for (auto c : ctx) staramd_destroy(c);
+    destroyAll();
     sah_destroy(h);
     publish();
     return exitCode;

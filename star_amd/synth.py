@@ -408,7 +408,7 @@ class ReadSampler:
         ok = np.flatnonzero(self.glen > frag[1] + 2)
         self.gok = ok; self.gcum = np.cumsum(self.glen[ok] / self.glen[ok].sum())
 
-    def sample(self, seed, n, frac_spliced=0.85, sub_rate=0.01, n_rate=0.001):
+    def sample(self, seed, n, frac_spliced=0.85, sub_rate=0.01, n_rate=0.001, chim_rate=0.0):
         rng = np.random.default_rng(seed)
         L = self.L
         n_spl = int(n * frac_spliced) if len(self.usable) else 0
@@ -433,6 +433,13 @@ class ReadSampler:
             fl = rng.integers(max(self.frag[0], L), self.frag[1] + 1, size=n_gen)
             off = (rng.random(n_gen) * (self.glen[c] - fl)).astype(np.int64)
             put(self.gseq, self.gstart[c] + off, fl, n_spl)
+        if chim_rate > 0 and n > 4:
+            # chimeric pairs: half of them get the second mate of another pair (mates from two loci), the other half a
+            # first mate whose second half comes from another read (a chimeric junction inside the mate)
+            k = int(n * chim_rate); who = rng.choice(n, size=k, replace=False); other = rng.integers(0, n, size=k)
+            h = k // 2
+            m2[who[:h]] = m2[other[:h]].copy()
+            m1[who[h:], L // 2:] = m1[other[h:], L // 2:].copy()
         for m in (m1, m2):
             if sub_rate > 0:
                 mask = rng.random(m.shape, dtype=np.float32) < sub_rate
