@@ -214,6 +214,7 @@ struct Runner {
     std::deque<int> freeSets, fullSets; bool writerStop = false, writerFailed = false;
     std::thread writerThread;
     int samFd = -1; uint64_t samPos = 0;     // positional writes of the SAM / unsorted BAM text (regular file)
+    int samSeekable = -1;                    // -1 not looked at yet, 0 pipe / FIFO / character device (sequential fwrite), 1 regular file
     double tWriter = 0, tEmitWaitSet = 0, tEmitFormat = 0, tEmitTail = 0;      // seconds, whole run (STARAMD_HOST_TIMING prints them at the end)
     void writerLoop() {
         for (;;) {
@@ -222,7 +223,10 @@ struct Runner {
             OutSet &o = outSets[k];
             const auto tw0 = std::chrono::steady_clock::now();
             struct AddTime { double &acc; std::chrono::steady_clock::time_point t0; ~AddTime() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } addTime{tWriter, tw0};
-            if (samOut && samOut != stdout && (o.used > 1 || samFd >= 0)) {
+            if (samSeekable < 0 && samOut) {            // a named pipe (mkfifo Aligned.out.sam | samtools ...) or a device has no offsets: pwrite fails with ESPIPE there
+                struct stat st; samSeekable = (samOut != stdout && fstat(fileno(samOut), &st) == 0 && S_ISREG(st.st_mode) && ftello(samOut) >= 0) ? 1 : 0;
+            }
+            if (samOut && samSeekable == 1 && (o.used > 1 || samFd >= 0)) {
                 // a regular file: the per-thread text buffers go out side by side, each at its own offset (one fwrite stream tops out near
                 // 2 GB/s on tmpfs, the SAM text of one GPU runs at about that)
                 if (samFd < 0) { fflush(samOut); samFd = fileno(samOut); samPos = (uint64_t)ftello(samOut); }

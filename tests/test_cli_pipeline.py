@@ -119,3 +119,24 @@ def test_cli_pipeline_wasp_verdict_on_chimeric_bam_records(batch, tmp_path, buil
     """vW on the BAM records of a chimeric read is the verdict of the nearest earlier read that was not itself a chimera in the BAM
     (ReadAlign_oneRead.cpp:99-103), whatever the batch and thread boundaries in between (the carried value)"""
     run_cli_case(CLI, "pe150_chim", CHIM_WASP, batch, tmp_path, fastq_hook=_chimeras_in_runs)
+
+
+def test_sam_into_a_named_pipe(tmp_path, built):
+    """Aligned.out.sam as a FIFO (mkfifo + a consumer, the way it is piped into samtools): the writer thread must fall back to sequential writes -- a
+    positional write on a pipe fails with ESPIPE (runner.cpp writerLoop)"""
+    import threading
+    info = dict(prepare("pe101", str(tmp_path), need_ref=False))
+    d = os.path.dirname(info["fastq"][0])
+    flags = list(info["extra"]) + ["--readMapNumber", "400"]
+    ref = refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=flags)
+    new = os.path.join(d, "fifo_")
+    os.mkfifo(new + "Aligned.out.sam")
+    got = []
+    t = threading.Thread(target=lambda: got.append(open(new + "Aligned.out.sam", "rb").read()))
+    t.start()
+    p = subprocess.run([CLI, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] +
+                       ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", "100"] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    t.join(timeout=60)
+    assert p.returncode == 0, p.stderr[-1500:]
+    body = sorted(l for l in got[0].splitlines(keepends=True) if not l.startswith(b"@"))
+    assert body == refstar.sam_body_sorted(ref + "Aligned.out.sam")
