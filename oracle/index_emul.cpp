@@ -16,6 +16,7 @@ using namespace staridx;
 struct LoopBackend {
     template <class T> T *alloc(u64 n) { return (T *)malloc(std::max<u64>(n * sizeof(T), 16)); }
     void free(void *p) { ::free(p); }
+    void stage(const char *) {}
     template <class F> void forEach(u64 n, F f) {
 #pragma omp parallel for schedule(static)
         for (u64 i = 0; i < n; i++) f(i);

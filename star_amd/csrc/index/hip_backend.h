@@ -3,6 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include "index_core.h"
@@ -23,6 +26,16 @@ struct HipBackend {
     u64 liveBytes = 0, peakBytes = 0;
 
     void chk(hipError_t e, const char *w) { if (e != hipSuccess && err == hipSuccess) { err = e; where = w; } }
+    // STARAMD_VERBOSE: wall time of every stage of an index operation (a stage ends with a stream synchronisation then)
+    bool verbose = getenv("STARAMD_VERBOSE") != nullptr; double tStage = 0;
+    static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+    void stage(const char *name) {
+        if (!verbose) return;
+        chk(hipStreamSynchronize(s), "stage sync");
+        const double t = now();
+        if (name && tStage > 0) fprintf(stderr, "staramd index stage %-28s %9.1f ms\n", name, (t - tStage) * 1e3);
+        tStage = t;
+    }
     template <class T> T *alloc(u64 n) {
         void *p = nullptr; size_t b = std::max<u64>(n * sizeof(T), 256);
         chk(hipMalloc(&p, b), "hipMalloc");

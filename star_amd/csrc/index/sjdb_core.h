@@ -82,6 +82,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
     const u64 nGsj = (u64)P.sjdbN * P.sjdbLength, nQ = 2 * nGsj + 1;
     const u32 Lsj = P.sjdbLength, GstrandBit = P.GstrandBit, saBits = P.GstrandBit + 1;
     const u64 nGenomeOld = P.nGenomeOld, nSAold = P.nSAold, nGenomeReal = P.nGenomeReal;
+    be.stage(nullptr);
     // ---- query text: forward blocks, their reverse complement, one closing spacer (sjdbBuildIndex.cpp:30-39)
     u8 *dQ = be.template alloc<u8>(nQ + 64);
     be.copyToDevice(dQ, hGsj, nGsj);
@@ -101,6 +102,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
     R.nInd = nInd; R.nSAnew = nSAold + nInd; R.nGenomeNew = nGenomeReal + nGsj;
     u64 *off = be.template alloc<u64>(nInd + 1), *pos = be.template alloc<u64>(nInd + 1);
     compactIf(be, 2 * nGsj, isCand, [=] IDX_L (u64 o, u64 j) { off[j] = o; });
+    be.stage("sjdb: candidates");
     // ---- search
     {
         const u64 saMask = saBits >= 64 ? ~0ull : ((1ull << saBits) - 1);
@@ -109,6 +111,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
             pos[j] = sjdbSearchOne(dGold, nGenomeOld, GstrandBit, nSAold, sa, dQ + off[j]);
         });
     }
+    be.stage("sjdb: search");
     // ---- sort by (insertion point, text up to the spacer, offset): LSD radix passes over 21-code chunks of the text (stable, so the
     //      offset order of the input breaks the remaining ties), then one stable pass on the insertion point
     if (nInd > 1) {
@@ -134,6 +137,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
         { const u64 *k = key, *k2 = keyAlt; be.forEach(nInd, [=] IDX_L (u64 j) { pos[j] = k[j]; off[j] = k2[j]; }); }
         be.free(key); be.free(keyAlt); be.free(perm); be.free(permAlt); be.free(endp);
     }
+    be.stage("sjdb: sort");
     // ---- merge (:141-207): new entry j lands at output index pos[j] + j; old entries fill the rest in order
     u32 *dOldSJind = be.template alloc<u32>((u64)P.oldSjdbN + 1);
     if (P.oldSjdbN) be.copyToDevice(dOldSJind, hOldSJind, P.oldSjdbN);
@@ -180,6 +184,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
         });
     }
     be.free(pos); be.free(off); be.free(dOldSJind); be.free(dIsOld);
+    be.stage("sjdb: merge");
     // ---- new genome text: chromosomes + forward junction block, spacers either side
     R.dGnew = be.template alloc<u8>(R.nGenomeNew + 2 * padOut);
     {
@@ -191,6 +196,7 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
         });
     }
     be.free(dQ);
+    be.stage("sjdb: new genome text");
     // ---- SAindex of the merged array
     R.saiWords = packedWords(saiStart[P.saIndexNbases], GstrandBit + 3);
     R.dSAiPacked = be.template alloc<u64>(R.saiWords);
@@ -203,11 +209,13 @@ template <class BE> int sjdbInsertDevice(BE &be, const SjdbParams &P, const u8 *
           be.forEach(nSAnew, [=] IDX_L (u64 i) { u64 v = packedGetW(sp, i, saBits); dSApos[i] = (v & N2bit) ? N + (v & ~N2bit) : v; }); }
         const u64 nSAi = saiStart[P.saIndexNbases];
         u64 *dSAiU = be.template alloc<u64>(nSAi);
+        be.stage("sjdb: SAindex text + unpack");
         R.badFirstSuffix = buildSAindex(be, T, dSApos, nSAnew, P.saIndexNbases, GstrandBit, saiStart, dSAiU);
         const u64 *su = dSAiU;
         packArray(be, nSAi, GstrandBit + 3, R.dSAiPacked, [=] IDX_L (u64 i) { return su[i]; });
         be.free(dSAiU); be.free(dSApos); be.free(dTraw);
     }
+    be.stage("sjdb: SAindex build + pack");
     return 0;
 }
 
