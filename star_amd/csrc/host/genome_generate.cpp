@@ -61,7 +61,7 @@ std::string genomeGenerateScan(RunParams &P, GenomeIndex &gi, GenerateJob &job) 
                 if (c == '\n') { lineStart = true; continue; }
                 if (lineStart && c == '>') { inHeader = true; header.assign(1, '>'); lineStart = false; continue; }
                 lineStart = false;
-                if (c < 32) continue;                                  // control characters are skipped
+                if ((signed char)c < 32) continue;                     // control characters -- and, as in the reference, which tests a signed char (genomeScanFastaFiles.cpp), bytes >= 0x80 -- are skipped
                 G.push_back(ntCode(c)); N++;
             }
         }

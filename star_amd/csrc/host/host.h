@@ -229,6 +229,7 @@ private:
     std::string mem[2]; size_t memPos[2] = {0, 0}; bool fromMemory = false;
     std::vector<char> carry[2];           // text read from the file but not yet part of a batch
     bool eof[2] = {false, false};
+    std::atomic<int> ioError{0};          // errno of a failed read of an input file (sliced pread path): reported by nextBatch, never taken for the end of the input
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
     std::vector<uint64_t> lineStart[2], lineEnd[2];
     bool noQualities = false;             // held FASTA reads (2nd stage of BySJout)

@@ -285,7 +285,13 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
             auto slice = [&](unsigned k) {
                 const size_t lo = std::min<size_t>(block, k * per), hi = std::min<size_t>(block, lo + per);
                 size_t done = 0;
-                while (lo + done < hi) { ssize_t r = pread(fd, text.data() + old + lo + done, hi - lo - done, pos0 + (off_t)(lo + done)); if (r <= 0) break; done += (size_t)r; }
+                while (lo + done < hi) {
+                    ssize_t r = pread(fd, text.data() + old + lo + done, hi - lo - done, pos0 + (off_t)(lo + done));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r < 0) { ioError = errno; break; }                 // a read error is not the end of the input
+                    if (r == 0) break;
+                    done += (size_t)r;
+                }
                 gotK[k] = done;
                 nl[k].reserve((size_t)((double)done / bytesPerRecord[m] * 4.2) + 16);
                 scanNewlines(text.data(), old + lo, old + lo + done, nl[k], UINT64_MAX);
@@ -356,6 +362,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
         if (!fromMemory && nLines[0] == 0 && curFile + 1 < files_[0].size()) { closeFiles(); curFile++; std::string e = openCurrent(); if (!e.empty()) { err = e; return false; } continue; }
         break;
     }
+    if (ioError.load()) { err = std::string("EXITING because of INPUT ERROR: read error in --readFilesIn: ") + strerror(ioError.load()) + "\n"; return false; }
     lap("fill");
     if (timing) fprintf(stderr, "  parse blocks read in slices so far: %llu\n", (unsigned long long)slicedBlocks.load());
     // records of mate 1 decide the batch; an empty ID line ends the input

@@ -564,7 +564,13 @@ void sah_set_sjdb_device_fn(int (*fn)(int, const staramd_sjdb_args *, staramd_sj
 // the same on the arrays resident in the engine contexts (staramd_insert_junctions for every context): fn(user, args, result); the front end calls
 // sah_engines_ready once its contexts hold the index, and asks sah_index_in_engine after a phase change whether a re-upload is needed at all
 void sah_set_sjdb_resident_fn(int (*fn)(void *, const staramd_sjdb_args *, staramd_sjdb_result *), void *user) { staramd::setSjdbResidentFn(fn, user); }
-void sah_engines_ready(void *h) { ((Runner *)h)->gi.engineHoldsIndex = true; }
+void sah_engines_ready(void *h) {
+    // every engine context holds the index now, and junction insertion runs on the resident arrays: the host copy of the suffix array (26 GB of a human
+    // index, per process -- one process per GPU on a node) is not needed any more.  SAindex and genome stay (small; the SAM writer reads the genome)
+    Runner *r = (Runner *)h;
+    r->gi.engineHoldsIndex = true;
+    if (!r->generateMode && !getenv("STARAMD_KEEP_HOST_SA")) { std::vector<uint8_t>().swap(r->gi.SA); r->gi.view.SA = nullptr; }
+}
 int sah_index_in_engine(void *h) { Runner *r = (Runner *)h; int v = r->gi.indexInEngine ? 1 : 0; r->gi.indexInEngine = false; return v; }
 int sah_generate_mode(void *h) { return ((Runner *)h)->generateMode ? 1 : 0; }
 int sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases, uint8_t **SA, uint64_t *saCap, uint8_t **SAi, uint64_t *saiCap) {

@@ -1,0 +1,34 @@
+"""Large-coordinate parity inside the GPU suite: a 400 Mb synthetic genome with annotation (nSA = 8 * 10^8, 13-base SAindex,
+strand bit 32, ~45 k junctions; index generated on the device by the product, byte-identical to the reference's genomeGenerate:
+tests/test_index_build.py), 200 k pairs 2x101 through the shipped pipeline and through oracle/_ref/STAR with the same flags:
+SAM bodies as a multiset, SJ.out.tab and the Log.final.out counters.  Until now this size class was only covered by bench.py:full_size_parity."""
+import argparse
+import os
+import sys
+
+import pytest
+
+from util import refstar
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not refstar.have_ref(), reason="oracle/_ref/STAR not built")]
+
+
+def test_400mb_index_200k_pairs_against_the_reference(tmp_path, built):
+    sys.path.insert(0, ROOT)
+    import bench
+    from star_amd.capi import run_cli
+    args = argparse.Namespace(read_len=101, reads=100000, workdir=str(tmp_path))
+    notes = []
+    g, ginfo = bench.build_genome(args, 400, notes.append)
+    assert ginfo["index_bytes"] > 4e9 and ginfo["junctions_in_index"] > 10000
+    n = 200000
+    fq = bench.make_reads(args, g, os.path.join(g, "t"), "reads", n, 4242)
+    idx = os.path.join(g, "idx")
+    new, ref = os.path.join(g, "t", "gpu_"), os.path.join(g, "t", "ref_")
+    rc, rep = run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", new, "--runThreadN", "16", "--gpuBatchReads", "100000"])
+    assert rc == 0 and int(rep.reads) == n
+    refstar.align(idx, fq, ref, threads=min(32, os.cpu_count() or 8), timeout=900)
+    par = bench.full_size_parity(ref, new)
+    assert par and par["sam_multiset_identical"] and par["sj_out_tab_identical"] and par["log_final_counters_identical"], par
+    assert par["sam_records_star_amd"] > 1.5 * n          # (mapped pairs write two records)
