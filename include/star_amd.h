@@ -117,7 +117,10 @@ typedef struct staramd_params {
      *   0  every transcript recorded in every window (the whole trAll[][] of the reference)
      *   1  only the transcripts ReadAlign::multMapSelect can pick: maxScore + outFilterMultimapScoreRange >= trBest->maxScore
      *      (ReadAlign_multMapSelect.cpp:26-44).  That is all the default post-map path reads; it cuts the result copy ~10x.
-     *      Must be 0 when chimeric detection (chimSegmentMin > 0) wants the other windows. */
+     *      Must be 0 when chimeric detection (chimSegmentMin > 0) wants the other windows.
+     * Contract of 1: trBest, status, unmappedLength and every field of the RETURNED transcripts / exons are the reference's exactly; nW / nTr
+     * count what is returned; maxScoreMate[] is a lower bound and the windows that cannot reach the selection threshold are not stitched at all
+     * (INTEGRATION.md "Which outputs are the reference's exactly").  A caller that needs trAll[][] or maxScoreMate[] themselves passes 0. */
     uint32_t resultSelect;
 } staramd_params;
 

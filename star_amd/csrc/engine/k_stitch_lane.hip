@@ -324,7 +324,7 @@ __device__ __forceinline__ void emptyWout(DWinOut &z) {
 }
 
 #ifndef LANE_WAVES
-#define LANE_WAVES 2        // minimum waves per SIMD the register allocation is held to
+#define LANE_WAVES 3        // minimum waves per SIMD the register allocation is held to (same box, 1000 Mb, stitch stage: 2 -> 43.6 ms (three runs 41.6-45.6), 3 -> 37.8, 4 -> 46.3)
 #endif
 extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(const DevIndex *__restrict__ Xp, DevBatch B, u8 *laneArena, u32 laneArenaBytes, u32 ldsWords, u32 pruneEnable, u32 maxClass) {
     if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch

@@ -7,7 +7,7 @@ cp star_amd/lib/libstaramd.so /tmp/libstaramd_prod.so
 for spec in "$@"; do
   IFS='|' read -r tag var envs <<< "$spec"
   if [ "$var" = "-" ] || [ -z "$var" ]; then cp /tmp/libstaramd_prod.so star_amd/lib/libstaramd.so; else cp star_amd/lib/variants/libstaramd_$var.so star_amd/lib/libstaramd.so; fi
-  env $envs timeout 300 python bench.py --steps ${AB_STEPS:-3} --warmup 1 --no-cpu-baseline --no-sweep --no-two-pass > $O/$tag.json 2> $O/$tag.err
+  env $envs timeout 300 python bench.py --steps ${AB_STEPS:-3} --warmup 1 --no-cpu-baseline --no-sweep --no-two-pass --no-extra-legs > $O/$tag.json 2> $O/$tag.err
   python - <<PY
 import json
 try:

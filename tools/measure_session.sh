@@ -4,7 +4,7 @@
 R=$PWD; TAG=${1:-r02}; MB=${2:-3100}; STEPS=${3:-3}; PASSES=${4:-"stats sq1 sq2 fetch write"}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export STARAMD_BENCH_GENOME_MB=$MB
-B="python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-sweep --no-two-pass"
+B="python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-sweep --no-two-pass --no-extra-legs"
 # data + an unprofiled line first (the profiled runs reuse the cached genome / reads in /dev/shm)
 timeout 1200 $B > $O/bench_plain.json 2> $O/bench_plain.err || { tail -5 $O/bench_plain.err; exit 1; }
 python -c "import json;d=json.load(open('$O/bench_plain.json'));print('plain', d['value'], d['roofline']['per_kernel_ms'])"
