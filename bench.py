@@ -532,8 +532,24 @@ def main():
             except Exception as e:
                 out[name] = {"error": repr(e)[:400]}
             log(name + " done")
-        if isinstance(out.get("kernel_ms_exclusive"), dict) and "per_kernel_ms" in out["kernel_ms_exclusive"]:
-            out["roofline"]["per_kernel_ms_exclusive"] = out["kernel_ms_exclusive"]["per_kernel_ms"]
+        ex = out.get("kernel_ms_exclusive")
+        if isinstance(ex, dict) and "per_kernel_ms" in ex and n_ctx > max(1, int(rep.nDevices)):
+            # The timed region runs two engine contexts per GPU: the HIP events around a launch then also cover the time slices the other context's
+            # launches get, i.e. they no longer measure the kernel.  The roofline figures are therefore taken from the one-context leg (same index,
+            # same reads, same process, minutes later: every launch has the GPU to itself, which is also what the committed rocprofv3 summary
+            # shows); the overlapped figures stay beside them.
+            r = out["roofline"]
+            r["per_kernel_ms_timed_region_two_contexts"] = r["per_kernel_ms"]; r["kernel_ms_timed_region_two_contexts"] = r["kernel_ms"]
+            r["per_kernel_ms"] = ex["per_kernel_ms"]
+            ems = ex["per_kernel_ms"]
+            kd = max(("k_seed_search", "k_windows", "k_stitch_win"), key=lambda k: ems[k])
+            r["kernel"] = kd; r["kernel_ms"] = ems[kd]
+            r["algorithmic_bytes_per_launch"] = kern[kd][1]
+            r["achieved"] = kern[kd][1] / (ems[kd] * 1e-3) / 1e9; r["frac"] = r["achieved"] / HBM_PEAK_GBS
+            if traffic_all:
+                r["traffic"] = traffic_all.get(kd)
+            r["note"] = ("per launch = per batch of %d pairs; kernel times by HIP events on the engine's stream in the ONE-context leg (kernel_ms_exclusive: %d batches, a launch has "
+                         "the GPU to itself); the timed region runs two contexts per GPU whose launches overlap (per_kernel_ms_timed_region_two_contexts)" % (args.reads, 4))
     if not args.no_sweep and world == 1:
         out["index_size_sweep"] = sweep(args, mb, out, log)
     if not args.no_two_pass and world == 1 and time.time() - T_START < args.budget_s:
