@@ -277,15 +277,36 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
             "default_io_buffer": extras.get("default_io_buffer"), "multi_process": extras.get("multi_process")}
 
 
+def memory_headroom_gb():
+    """what this container may still allocate: MemAvailable, capped by the cgroup limit minus its current usage (tmpfs pages included)"""
+    avail = None
+    for l in open("/proc/meminfo"):
+        if l.startswith("MemAvailable:"):
+            avail = int(l.split()[1]) * 1024 / 1e9
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"), ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            a, b = open(lim).read().strip(), open(cur).read().strip()
+            if a != "max" and int(a) < (1 << 60):
+                head = (int(a) - int(b)) / 1e9
+                avail = head if avail is None else min(avail, head)
+        except Exception:
+            pass
+    return avail if avail is not None else 0.0
+
+
 def multi_process_baseline(idx, fq, out_prefix, n_pairs, ncpu, small, log):
     """8 reference processes side by side, cores/8 threads each, every one on its own eighth of the FASTQ (each holds its own copy of the index, as
     8 independent STAR runs do): what the box can do when the one input mutex of a single process is taken out of the picture."""
     from oracle import refstar
     nproc = 8
-    mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9
     idx_gb = sum(os.path.getsize(os.path.join(idx, f)) for f in ("Genome", "SA", "SAindex")) / 1e9
-    if mem_gb < nproc * idx_gb * 1.3 + 64:
-        return {"skipped": "%.0f GB of RAM for %d index copies of %.0f GB" % (mem_gb, nproc, idx_gb)}
+    free_gb = memory_headroom_gb()
+    # every process holds its own copy of the index (+ ~0.1 GB per thread); the copies must fit into what the CONTAINER may still use (its cgroup limit
+    # counts the tmpfs the workload lives in), with a wide margin: a box that runs out of memory is lost, not slowed down
+    while nproc > 1 and nproc * (idx_gb * 1.1 + 2 + 0.1 * (ncpu // nproc)) > 0.7 * free_gb:
+        nproc //= 2
+    if nproc < 2:
+        return {"skipped": "%.0f GB of memory headroom for index copies of %.0f GB" % (free_gb, idx_gb)}
     per = n_pairs // nproc
     # the FASTQ records have a fixed size (synth.write_fastq_ids): slices by byte offset
     slices = []
@@ -316,7 +337,9 @@ def multi_process_baseline(idx, fq, out_prefix, n_pairs, ncpu, small, log):
         for f in fs:
             os.remove(f)
     log("reference STAR x %d processes x %d threads: load %.1f s, full %.1f s" % (nproc, th, t_load, t_full))
-    return {"processes": nproc, "threads_each": th, "Mreads_s": nproc * per / max(t_full - t_load, 1e-3) / 1e6, "load_only_s": t_load, "full_s": t_full, "pairs": nproc * per}
+    return {"processes": nproc, "threads_each": th, "Mreads_s": nproc * per / max(t_full - t_load, 1e-3) / 1e6, "load_only_s": t_load, "full_s": t_full, "pairs": nproc * per,
+            "memory_headroom_gb": free_gb, "what": "independent reference processes side by side, each on its own slice of the FASTQ with its own index copy; as many (8, 4 or 2) as fit "
+                                                   "into the container's memory limit with a wide margin"}
 
 
 def _digest_range(job):
