@@ -69,6 +69,10 @@ __device__ static bool coopExtendBody(StitchCtx &c, u32 lane, u32 rStart, u64 gS
         if (iExt > 0) { e.extendL = (u32)iExt; e.maxScore = Score; e.nMatch = (u32)nMatch; e.nMM = (u32)nMM; return true; }
         return false;
     }
+    // The reference's loop runs `for (int i = 0; i < (int) L; i++)` (extendAlign.cpp:59) over an unsigned 64-bit L: a length that went "negative"
+    // -- the second mate starting before the first exon (stitchAlignToTranscript.cpp:390: gBstart - exons[0][EX_G] + exons[0][EX_R] with
+    // --alignEndsProtrude) -- means no extension at all, not four billion bases (found by the hardware fuzzer in round 3)
+    if ((int)L <= 0) return false;
     const double thrBreak = fmin(pMMmax * (double)(u64)(Lprev + L), (double)nMMmax);
     int scoreBase = 0; u32 nMatchBase = 0, nMMBase = 0; int best = 0;
     for (u32 base = 0; base < L; base += NLANE) {

@@ -46,6 +46,17 @@ def test_seed_search_lmax_prefix_codes(name, tmp_path, built):
     _compare_buffers(info, ["--gpuResultSelect", "All", "--seedSearchLmax", "30", "--seedSearchStartLmax", "12", "--readMapNumber", "300"], str(tmp_path / "x_"))    # (the reads the emulator was run on)
 
 
+@pytest.mark.parametrize("mode", ["All", "Selected"])
+def test_negative_mate_extension_length(mode, tmp_path, built):
+    """--alignEndsProtrude + --clip5pNbases: the second mate starts before the first exon of the transcript, the extension length of the mate-gap stitch
+    (stitchAlignToTranscript.cpp:390) wraps around and the reference's `(int) L` loop bound (extendAlign.cpp:59) makes it no extension at all.
+    Found by tests/tools/fuzz_engine.py on hardware in round 3 (1 of 150 combinations)."""
+    if not refstar.have_ref():
+        pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
+    info = prepare("pe125_protrude", str(tmp_path), need_ref=False)
+    _compare_buffers(info, ["--gpuResultSelect", mode, "--sjdbScore", "0", "--outFilterMismatchNmax", "3", "--alignEndsProtrude", "15", "ConcordantPair", "--clip5pNbases", "20", "20"], str(tmp_path / "x_"))
+
+
 def _compare_buffers(info, more, prefix):
     argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", prefix] + info["extra"] + more
     run = capi.HostRun(argv)

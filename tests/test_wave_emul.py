@@ -58,7 +58,10 @@ CASES = [("se50", 150, []), ("pe101", 40, []), ("pe101", 25, ["--gpuResultSelect
          ("pe150_chim", 20, ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"]),
          # --seedSearchLmax: the backward search is given Shift + 1 bases and runs over the start of its piece into an N / the mate spacer; the reference adds
          # those codes into the L-mer prefix as they are (carries and borrows included) -- found by the emulated fuzzer, k_seed.hip searchOneDist
-         ("pe101", 30, ["--gpuResultSelect", "All", "--seedSearchLmax", "30", "--seedSearchStartLmax", "12"])]
+         ("pe101", 30, ["--gpuResultSelect", "All", "--seedSearchLmax", "30", "--seedSearchStartLmax", "12"]),
+         # --alignEndsProtrude + 5' clipping: the second mate starts before the first exon, the extension length of the mate-gap stitch is "negative"
+         # (no extension in the reference: `(int) L` loop bound, extendAlign.cpp:59) -- found by the hardware fuzzer, k_stitch.hip coopExtendBody
+         ("pe125_protrude", 160, ["--gpuResultSelect", "All", "--alignEndsProtrude", "15", "ConcordantPair", "--clip5pNbases", "20", "20"])]
 
 
 # every data set with one lane order, the paired-end set of the forced cases with both (tests/tools/fuzz_engine.py alternates the order over hundreds of

@@ -33,6 +33,11 @@ DATASETS = {
                       dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=100, extra=("--genomeSAsparseD", "3")), []),
     # 2x150, 1 % errors, 5 % chimeric pairs (mates or read halves from different loci); chimeric detection stays
     # off by default, so these exercise multi-window stitching, soft clips and the "too short" path
+    # found by the hardware fuzzer (round 3): with --alignEndsProtrude and 5' clipping the second mate can start before the first exon of the transcript;
+    # the extension length of stitchAlignToTranscript.cpp:390 then goes "negative" and the reference's `(int) L` loop bound means no extension
+    "pe125_protrude": (dict(seed=936057973, chr_lengths=(132791, 208918, 165515, 93736), n_tr=98, n_reads=2092, read_len=125, paired=True, sub_rate=0.02, n_rate=0.0, indel_rate=0.002,
+                            frag=(62, 375)),
+                       dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=100), []),
     "pe150_chim": (dict(seed=5, chr_lengths=(350000, 250000, 200000), n_tr=110, n_reads=3000, read_len=150, paired=True, sub_rate=0.01, chim_rate=0.05),
                    dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=149), []),
 }
