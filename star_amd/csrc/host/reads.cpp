@@ -275,7 +275,7 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
         else if (block >= sliceMin && isRegularFile(f[m])) {
             // a regular file (not a pipe of --readFilesCommand): the block is cut into slices that threads read at their own positions
             // and scan for line ends; one thread copies ~100 MB per batch and mate at memcpy speed, which is most of the parse time
-            const unsigned K = 4;
+            const unsigned K = readSlices;
             const off_t pos0 = ftello(f[m]);
             const int fd = fileno(f[m]);
             std::vector<std::vector<uint64_t>> nl(K);
@@ -347,6 +347,10 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     }
     if (want == 0) return false;
     static const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    {   // a block of ~100 MB per mate and batch is copied out of the page cache and scanned for line ends by this many threads per mate
+        static const unsigned fixed = getenv("STARAMD_READ_SLICES") ? (unsigned)atoi(getenv("STARAMD_READ_SLICES")) : 0u;
+        readSlices = fixed ? std::max(1u, std::min(fixed, 64u)) : (unsigned)std::max(4, std::min(16, P.runThreadN / 8));
+    }
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     uint64_t nLines[2] = {0, 0};
