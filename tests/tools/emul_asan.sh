@@ -30,5 +30,7 @@ run "STARAMD_CAND_KB_PER_WAVE=1" pe101 30
 run "STARAMD_LIGHT_EST=0" pe101 30
 run "STARAMD_LIGHT_EST=4000000000" pe101 25 --gpuResultSelect All
 run "STARAMD_PRUNE=0" pe101 30
+run "STARAMD_LANE_CLASS=31" pe101 60 --gpuResultSelect All
+run "STARAMD_LANE_CLASS=31 STARAMD_LANE_ARENA=256" pe125_protrude 160
 echo "$bad case(s) with a report"
 exit $bad
