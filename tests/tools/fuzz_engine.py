@@ -90,8 +90,16 @@ def one(it, rng):
                 if bt is None:
                     continue
                 n = bt.nReads
-                bg, bo = capi.ResultBuffers(n, tr_cap=n * 400), capi.ResultBuffers(n, tr_cap=n * 400)
-                eng.map_batch(bt, bg); orc.map_batch(bt, bo)
+                cap = n * 400
+                while True:            # (EndToEnd + every transcript of 2x250 reads: > 600 transcripts per read; the engine reports the overflow, the caller grows)
+                    bg, bo = capi.ResultBuffers(n, tr_cap=cap), capi.ResultBuffers(n, tr_cap=cap)
+                    try:
+                        eng.map_batch(bt, bg); orc.map_batch(bt, bo)
+                        break
+                    except RuntimeError as e:
+                        if "result arrays too small" not in str(e) or cap > n * 20000:
+                            raise
+                        cap *= 4
                 selected = flags[-1] == "Selected"      # resultSelect 1: maxScoreMate[] covers the walked windows only (window pruning): a lower bound
                 rg, tg, eg = bg.as_bytes(n); ro, to, eo = bo.as_bytes(n)
                 if rg != ro or tg != to or eg != eo or bg.res.trCount != bo.res.trCount:
