@@ -154,7 +154,8 @@ typedef struct staramd_read_result {
     int32_t  trBest;          /* index (relative to trOffset) of trBest, -1 if none                      */
     int32_t  maxScoreMate[2]; /* resultSelect 0: exactly ReadAlign::maxScoreMate[]; resultSelect 1: over the windows that were walked (a lower
                                * bound: windows that cannot hold a selectable transcript are skipped).  Nothing outside the hot path reads it. */
-    uint32_t unmappedLength;  /* trBest->rLength of the unmapped classifications (mapOneRead.cpp:100-111) */
+    uint32_t unmappedLength;  /* trBest->rLength of the unmapped classifications (mapOneRead.cpp:100-111); 0 for a read of length 0, where the
+                               * reference reports what the previous read of the same thread left in splitR[1][0] */
 } staramd_read_result;
 
 /* compact Transcript (source/Transcript.h:10-81): every field the post-map code reads */

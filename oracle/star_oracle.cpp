@@ -846,6 +846,10 @@ struct Oracle {
         tooManyAnchors = false; windowsLimit = false; maxScoreMate[0] = maxScoreMate[1] = 0;
         trAll.clear();
         memset(&rr, 0, sizeof(rr)); rr.trBest = -1; rr.trOffset = (uint32_t)otr.size();
+        // ReadAlign_mapOneRead.cpp:17-21: a read of length 0 (everything clipped) is not split at all, and splitR[1][0] -- which :105 then reports as
+        // trBest->rLength of MARKER_NO_GOOD_PIECES -- keeps whatever the LAST read handled by this thread left there: a value that depends on the
+        // thread's history (and on the thread count).  Nothing reads it; the boundary (include/star_amd.h: unmappedLength) defines it as 0 here.
+        if (Lread == 0) splitR[1][0] = 0;
         Nsplit = Lread > 0 ? qualitySplit(Read1[0], Lread, P.maxNsplit, P.seedSplitMin) : 0;
         u64 seedSearchStartLmax = std::min<u64>(P.seedSearchStartLmax, (u64)(P.seedSearchStartLmaxOverLread * (Lread - 1)));
         for (u64 ip = 0; ip < Nsplit; ip++) {
