@@ -16,9 +16,19 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not refstar.have_ref(), reason
 
 def test_400mb_index_200k_pairs_against_the_reference(tmp_path, built):
     sys.path.insert(0, ROOT)
+    import shutil
+    import tempfile
+    work = tempfile.mkdtemp(prefix="staramd_t400_", dir="/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path))      # ~9 GB of genome, index, reads and SAM
+    try:
+        _run(work)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def _run(work):
     import bench
     from star_amd.capi import run_cli
-    args = argparse.Namespace(read_len=101, reads=100000, workdir=str(tmp_path))
+    args = argparse.Namespace(read_len=101, reads=100000, workdir=work)
     notes = []
     g, ginfo = bench.build_genome(args, 400, notes.append)
     assert ginfo["index_bytes"] > 4e9 and ginfo["junctions_in_index"] > 10000
