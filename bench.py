@@ -571,6 +571,8 @@ def main():
             r["achieved"] = kern[kd][1] / (ems[kd] * 1e-3) / 1e9; r["frac"] = r["achieved"] / HBM_PEAK_GBS
             if traffic_all:
                 r["traffic"] = traffic_all.get(kd)
+            r["kernel_launches"] = {"k_stitch_win": "the stitch stage of pass 0 = one k_stitch_lane launch (lane per read, cheapest cost classes) + one k_stitch_win launch (wavefront per window, the rest)",
+                                    "k_windows": "k_windows x 2 + k_windows_big"}
             r["note"] = ("per launch = per batch of %d pairs; kernel times by HIP events on the engine's stream in the ONE-context leg (kernel_ms_exclusive: %d batches, a launch has "
                          "the GPU to itself); the timed region runs two contexts per GPU whose launches overlap (per_kernel_ms_timed_region_two_contexts)" % (args.reads, 4))
     if not args.no_sweep and world == 1:
