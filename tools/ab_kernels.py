@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Same-process A/B of engine builds / knobs on the GPU box, cheap in GPU-minutes: the index is generated (or taken from the bench cache) and
+loaded ONCE, a few batches are parsed ONCE, and every variant -- an engine library + environment knobs -- gets a fresh engine context over
+them (index upload ~1 s at 3.1 Gb), maps every batch `--repeat` times and reports the per-kernel HIP-event times of staramd_get_timings.
+A configuration costs ~2 s instead of the ~25 s of a bench.py run at 3100 Mb, and the variants see byte-identical input.
+
+  tools/ab_kernels.py [--genome-mb 3100] [--reads 400000] [--batches 3] [--repeat 2] [--rounds 2] "tag|lib or -|ENV=V ENV2=V" ...
+
+`lib`: path of a libstaramd*.so (tools/build_variants.sh), `-` = star_amd/lib/libstaramd.so.  The variants run in the given order, `--rounds`
+times (ABAB...: drift of the box shows up as a difference between the rounds of one variant).  The result buffers of the first variant
+are the reference: every other variant must return the same bytes (a variant that changes results is reported, not timed).
+One engine context, so per-kernel times are exclusive (bench.py's timed region overlaps two contexts)."""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+STAGES = ["k_seed_search", "k_windows", "k_order", "k_stitch(lane+win)", "verify+replay+finish", "scan+gather", "device_total"]
+
+
+def load_engine(path):
+    """a private handle of an engine library: a copy under a unique name (dlopen returns the cached handle for a path it has seen)"""
+    from star_amd import capi
+    tmp = tempfile.mkdtemp(prefix="abk_")
+    dst = os.path.join(tmp, os.path.basename(path))
+    shutil.copy(path, dst)
+    L = C.CDLL(dst)
+    L.staramd_create.restype = C.c_int
+    L.staramd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(capi.Genome), C.POINTER(capi.Params), C.c_uint32, C.c_uint64]
+    L.staramd_map_batch.restype = C.c_int
+    L.staramd_map_batch.argtypes = [C.c_void_p, C.POINTER(capi.Batch), C.POINTER(capi.Results)]
+    L.staramd_destroy.restype = None; L.staramd_destroy.argtypes = [C.c_void_p]
+    L.staramd_last_error.restype = C.c_char_p
+    L.staramd_get_timings.restype = C.c_int; L.staramd_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    L.staramd_get_counters.restype = C.c_int; L.staramd_get_counters.argtypes = [C.c_void_p, capi.u64p, C.c_int]
+    return L, tmp
+
+
+class OwnedBatch:
+    """a copy of a parsed batch (the host library reuses its buffers for the next one)"""
+
+    def __init__(self, b):
+        from star_amd import capi
+        n = b.nReads
+        nb = b.readOffset[n]
+        self.bases = (C.c_uint8 * nb).from_buffer_copy(C.string_at(b.bases, nb))
+        self.off = (C.c_uint64 * (n + 1)).from_buffer_copy(C.string_at(b.readOffset, 8 * (n + 1)))
+        self.m1 = (C.c_uint16 * n).from_buffer_copy(C.string_at(b.mate1Length, 2 * n))
+        self.mm = (C.c_uint16 * n).from_buffer_copy(C.string_at(b.mmMaxTotal, 2 * n))
+        self.b = capi.Batch()
+        self.b.nReads = n
+        self.b.bases = C.cast(self.bases, capi.u8p); self.b.readOffset = C.cast(self.off, capi.u64p)
+        self.b.mate1Length = C.cast(self.m1, capi.u16p); self.b.mmMaxTotal = C.cast(self.mm, capi.u16p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome-mb", type=int, default=3100)
+    ap.add_argument("--reads", type=int, default=400000)
+    ap.add_argument("--read-len", type=int, default=101)
+    ap.add_argument("--batches", type=int, default=3)
+    ap.add_argument("--repeat", type=int, default=2, help="times every batch is mapped per variant and round (the first pass of the first batch is a warm-up and not counted)")
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--workdir", default="/dev/shm/star_amd_bench" if os.path.isdir("/dev/shm") else "/tmp/star_amd_bench")
+    ap.add_argument("--genome-dir", default=None, help="an existing genomeDir + --fastq instead of the bench workload (tests)")
+    ap.add_argument("--fastq", nargs="*", default=None)
+    ap.add_argument("--flags", default="", help="extra alignReads flags, space separated")
+    ap.add_argument("--out", default=None, help="JSON file for the table")
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    from star_amd import capi
+    if a.genome_dir:
+        idx, fq = a.genome_dir, a.fastq
+    else:
+        import bench
+        args = argparse.Namespace(read_len=a.read_len, reads=a.reads, workdir=a.workdir)
+        g, _ = bench.build_genome(args, a.genome_mb, lambda s: print("ab_kernels:", s, file=sys.stderr))
+        idx = os.path.join(g, "idx")
+        fq = bench.make_reads(args, g, os.path.join(g, "abk_n%d" % (a.batches * a.reads)), "reads", a.batches * a.reads, 7700)
+    t0 = time.time()
+    run = capi.HostRun(["--genomeDir", idx, "--readFilesIn"] + list(fq) + ["--outFileNamePrefix", os.path.join(tempfile.mkdtemp(prefix="abk_out_"), "x_"), "--runThreadN", str(min(64, os.cpu_count() or 8))]
+                       + (a.flags.split() if a.flags else []))
+    batches = []
+    while len(batches) < a.batches:
+        b = run.next_batch(a.reads)
+        if b is None:
+            break
+        batches.append(OwnedBatch(b))
+    print("ab_kernels: index + %d batches on the host in %.1f s" % (len(batches), time.time() - t0), file=sys.stderr)
+    nmax = max(x.b.nReads for x in batches)
+    table, ref_digest = {}, None
+    saved_env = dict(os.environ)
+    for rnd in range(a.rounds):
+        for spec in a.variants:
+            tag, lib, envs = (spec.split("|") + ["", ""])[:3]
+            lib = os.path.join(ROOT, "star_amd", "lib", "libstaramd.so") if lib in ("", "-") else lib
+            os.environ.clear(); os.environ.update(saved_env)
+            for kv in envs.split():
+                k, v = kv.split("=", 1); os.environ[k] = v
+            L, tmp = load_engine(lib)
+            ctx = C.c_void_p()
+            rc = L.staramd_create(C.byref(ctx), 0, run.genome, run.params, nmax, 0)
+            if rc:
+                print("%-20s create failed: %s" % (tag, L.staramd_last_error().decode())); continue
+            bufs = capi.ResultBuffers(nmax, tr_cap=nmax * 24)
+            acc = [0.0] * 7; cnt = 0; dig = hashlib.sha256(); ok = True
+            for rep in range(a.repeat):
+                for ib, ob in enumerate(batches):
+                    rc = L.staramd_map_batch(ctx, C.byref(ob.b), C.byref(bufs.res))
+                    if rc == -3:                                     # result arrays too small: grow once
+                        bufs = capi.ResultBuffers(nmax, tr_cap=int(bufs.res.trCount * 1.3) + 4096, ex_cap=int(bufs.res.exCount * 1.3) + 4096)
+                        rc = L.staramd_map_batch(ctx, C.byref(ob.b), C.byref(bufs.res))
+                    if rc:
+                        print("%-20s map_batch failed: %s" % (tag, L.staramd_last_error().decode())); ok = False; break
+                    if rep == 0:
+                        for part in bufs.as_bytes(ob.b.nReads):
+                            dig.update(part)
+                    if rep == 0 and ib == 0:
+                        continue                                    # warm-up
+                    ms = (C.c_float * 7)(); L.staramd_get_timings(ctx, ms, 7)
+                    for i in range(7):
+                        acc[i] += ms[i]
+                    cnt += 1
+                if not ok:
+                    break
+            counters = (C.c_uint64 * 40)(); L.staramd_get_counters(ctx, counters, 40)
+            L.staramd_destroy(ctx)
+            shutil.rmtree(tmp, ignore_errors=True)
+            if not ok or cnt == 0:
+                continue
+            d = dig.hexdigest()
+            if ref_digest is None:
+                ref_digest = d
+            row = {"round": rnd, "ms": {STAGES[i]: acc[i] / cnt for i in range(7)}, "launches_timed": cnt, "results_equal_first_variant": d == ref_digest,
+                   "lane_fraction": counters[39] / max(1, batches[-1].b.nReads)}
+            table.setdefault(tag, []).append(row)
+            m = row["ms"]
+            print("%-20s r%d  seed %6.2f  windows %6.2f  stitch %6.2f  redecide %5.2f  total %7.2f  lane %.3f  %s" %
+                  (tag, rnd, m[STAGES[0]], m[STAGES[1]], m[STAGES[3]], m[STAGES[4]], m[STAGES[6]], row["lane_fraction"], "" if row["results_equal_first_variant"] else "RESULTS DIFFER FROM THE FIRST VARIANT"), flush=True)
+    os.environ.clear(); os.environ.update(saved_env)
+    run.close()
+    if a.out:
+        json.dump(table, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
