@@ -442,6 +442,8 @@ def main():
     # (the front end runs STARAMD_CONTEXTS_PER_GPU engine contexts per GPU, default 2: two mapper threads over ONE resident index, so that the copies
     # and the low-occupancy tails of one batch overlap with the kernels of the next; rep.nContexts says how many ran)
     argv += ["--gpuDevice", str(local_rank)]
+    if world > 1:          # the ranks load the 31 GB index into host memory one after the other (each keeps ~5 GB of it after the upload)
+        os.environ["STARAMD_INDEX_LOAD_LOCK"] = os.path.join(args.workdir, "index_load.lock")
     t_clock = {}
 
     def warmup_done():

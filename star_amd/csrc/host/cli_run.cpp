@@ -12,6 +12,9 @@
 // Junction table, Stats and gene counts live in the one host object: nothing to merge inside a process (the reference's
 // per-thread tables, outputSJ.cpp:39-83, collapse to one).  Between phases (2-pass, BySJout) every context gets the new
 // index / whitelist.
+#include <sys/file.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,6 +95,12 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     CliFlags flags = splitFlags(argc, argv);
     if (!getenv("STARAMD_SJDB_HOST")) sah_set_sjdb_device_fn(staramd_sjdb_insert, flags.devices.empty() ? 0 : flags.devices[0]);   // junction insertion on the device
     char err[4096];
+    // One process per GPU on a node: every rank reads the ~30 GB index into host memory before it uploads it, and keeps only ~5 GB of it afterwards
+    // (sah_engines_ready).  STARAMD_INDEX_LOAD_LOCK=<file> makes the ranks take turns (an advisory file lock from here until the engine contexts hold
+    // the index), so that the peak is one index + a few GB per rank instead of one index per rank -- which a container limit does not survive.
+    struct LoadLock { int fd = -1; void take() { if (const char *p = getenv("STARAMD_INDEX_LOAD_LOCK")) { fd = open(p, O_CREAT | O_RDWR, 0666); if (fd >= 0 && flock(fd, LOCK_EX) != 0) { close(fd); fd = -1; } } }
+                      void drop() { if (fd >= 0) { flock(fd, LOCK_UN); close(fd); fd = -1; } } ~LoadLock() { drop(); } } loadLock;
+    loadLock.take();
     void *h = sah_create((int)flags.rest.size(), flags.rest.data(), err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }
     if (sah_tool_done(h)) { sah_destroy(h); return 0; }          // --runMode inputAlignmentsFromBAM: nothing to map
@@ -158,6 +167,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
         sah_engines_ready(h);
     }
 #endif
+    loadLock.drop();
     const int nSlots = std::min(24, 2 * nDev + 2);
     std::vector<ResBuf> rb(nSlots), rbMerged(nSlots), rbWasp(nSlots);
     std::vector<ResBuf> piecePart(nDev);
