@@ -34,7 +34,7 @@ all: host engine shadow cli oracle
 host: star_amd/lib/libstaramd_host.so
 engine: star_amd/lib/libstaramd.so
 cli: star_amd/bin/star_amd star_amd/lib/libstaramd_cli.so
-oracle: oracle/_build/liboracle.so oracle/_build/libindex_emul.so oracle/_build/star_amd_oracle_cli oracle/_build/libstaramd_cli_oracle.so oracle/_build/libstaramd_emul.so oracle/_build/star_amd_emul_cli
+oracle: oracle/_build/liboracle.so oracle/_build/libindex_emul.so oracle/_build/star_amd_oracle_cli oracle/_build/libstaramd_cli_oracle.so oracle/_build/libstaramd_cli_replay.so oracle/_build/libstaramd_emul.so oracle/_build/star_amd_emul_cli
 
 star_amd/lib/libstaramd_host.so: $(HOST_LIB_SRC) star_amd/csrc/host/host.h include/star_amd.h
 	@mkdir -p star_amd/lib
@@ -74,6 +74,11 @@ oracle/_build/star_amd_oracle_cli: $(CLI_SRC) oracle/cli_shim.cpp oracle/_build/
 # the multi-rank hooks (tests/test_multi_rank_cpu.py)
 oracle/_build/libstaramd_cli_oracle.so: star_amd/csrc/host/cli_run.cpp oracle/cli_shim.cpp oracle/_build/liboracle.so oracle/_build/libindex_emul.so star_amd/lib/libstaramd_host.so $(CLI_HDR)
 	$(CXX) $(CXXFLAGS) -DSTARAMD_NO_RESIDENT_SJDB -shared star_amd/csrc/host/cli_run.cpp oracle/cli_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -lindex_emul -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
+
+# measurement infrastructure for the HOST stages on a box without a GPU: the front end over an engine stand-in that records a batch's results through the
+# oracle once and plays them back afterwards (oracle/replay_shim.cpp, tools/host_bench.py)
+oracle/_build/libstaramd_cli_replay.so: star_amd/csrc/host/cli_run.cpp oracle/replay_shim.cpp oracle/_build/liboracle.so star_amd/lib/libstaramd_host.so $(CLI_HDR)
+	$(CXX) $(CXXFLAGS) -DSTARAMD_NO_RESIDENT_SJDB -shared star_amd/csrc/host/cli_run.cpp oracle/replay_shim.cpp -o $@ -Lstar_amd/lib -lstaramd_host -Loracle/_build -loracle -Wl,-rpath,'$$ORIGIN/../../star_amd/lib' -Wl,-rpath,'$$ORIGIN'
 
 ref:
 	$(MAKE) -f oracle/Makefile.ref -j8 all

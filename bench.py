@@ -191,12 +191,30 @@ STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitc
 
 
 def engine_src_sha():
-    """sha256 over the kernel sources of the engine: what a PMC-derived figure (profiles/*_pmc_hbm_traffic.json) must have been measured on"""
+    """sha256 over the kernel sources of the engine (every .hip / .h file of star_amd/csrc/engine)"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "star_amd", "csrc", "engine")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# what a PMC-derived figure of a kernel (profiles/*_pmc_hbm_traffic.json) must have been measured on: the file(s) the kernel is written in and the
+# headers they share.  engine.hip (launch code of all kernels) is not part of it: a change there that moves a kernel's launch parameters needs a new
+# PMC pass all the same (tools/measure_session.sh), the hash cannot know.
+KERNEL_SOURCES = {
+    "k_seed_search": ["k_seed.hip"], "k_windows": ["k_window.hip"], "k_gather": ["k_gather.hip"],
+    "k_stitch_win": ["k_stitch.hip", "k_stitch_lane.hip", "stitch_common.h", "stitch_scalar.h"],
+    "k_stitch_replay": ["k_stitch.hip", "stitch_common.h"], "k_stitch_finish": ["k_stitch.hip", "stitch_common.h"],
+}
+
+
+def kernel_src_sha(kernel):
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "star_amd", "csrc", "engine")
+    for f in KERNEL_SOURCES[kernel] + ["dev.h", os.path.join("..", "..", "..", "include", "star_amd.h")]:
+        h.update(os.path.basename(f).encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -495,10 +513,12 @@ def main():
     issue = None
     try:        # HBM traffic / issue utilisation from rocprofv3 --pmc passes (profiles/README.md): only when taken on THIS engine source and workload size
         tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
-        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads and tj.get("engine_src_sha") == engine_src_sha():
-            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-            traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
-            issue = {k: v["valu_busy_frac"] for k, v in tj.items() if isinstance(v, dict) and "valu_busy_frac" in v} or None
+        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads:
+            # a kernel's figures are reported only while the sources it is written in hash to what they were when the counters were taken
+            ok = {k for k, v in tj.items() if isinstance(v, dict) and k in KERNEL_SOURCES and v.get("kernel_src_sha") == kernel_src_sha(k)}
+            traffic = tj[dom].get("hbm_bytes_per_launch") if dom in ok else None
+            traffic_all = {k: (tj[k]["hbm_bytes_per_launch"] if k in ok else None) for k in KERNEL_SOURCES if k in tj} or None
+            issue = {k: (tj[k].get("valu_busy_frac") if k in ok else None) for k in KERNEL_SOURCES if k in tj} or None
     except Exception:
         traffic = None
     n_ctx = max(1, int(rep.nContexts))

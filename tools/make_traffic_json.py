@@ -6,8 +6,8 @@ is one launch of the hot path (k_seed_search runs once per batch, k_windows thre
 FETCH_SIZE is NOT doubled: MI355X_MICROARCH.md's gfx950 x2 correction is calibrated for wide coalesced 16 B/lane streams only; these kernels
 issue 1- to 8-byte gathers, for which the guide calls the counter uncalibrated, so the figure is a lower bound of the bytes read.
 valu_busy_frac (the `roofline.issue` of the bench line): SQ_INSTS_VALU x 4 cycles (a wave64 VALU instruction occupies its SIMD16 for four
-cycles) / (kernel time from the --stats pass x 2.4 GHz x 1024 SIMDs).  engine_src_sha: sha256 of star_amd/csrc/engine/* at measurement time;
-bench.py reports these figures only when its own engine sources hash to the same value."""
+cycles) / (kernel time from the --stats pass x 2.4 GHz x 1024 SIMDs).  kernel_src_sha: sha256 of the files the kernel is written in (bench.KERNEL_SOURCES) at measurement time; bench.py reports a kernel's
+figures only while those files hash to the same value (engine_src_sha: all of star_amd/csrc/engine, kept for reference)."""
 import csv
 import json
 import os
@@ -35,7 +35,7 @@ def main():
     for k, parts in names.items():
         f = sum(fe[p]["counters"]["FETCH_SIZE"] for p in parts if p in fe)
         w = sum(wr[p]["counters"]["WRITE_SIZE"] for p in parts if p in wr)
-        res[k] = {"FETCH_SIZE_KB_per_launch": f / nb, "WRITE_SIZE_KB_per_launch": w / nb, "hbm_bytes_per_launch": (f + w) / nb * 1024.0}
+        res[k] = {"kernel_src_sha": bench.kernel_src_sha(k), "FETCH_SIZE_KB_per_launch": f / nb, "WRITE_SIZE_KB_per_launch": w / nb, "hbm_bytes_per_launch": (f + w) / nb * 1024.0}
         valu = sum(sq[p]["counters"].get("SQ_INSTS_VALU", 0) for p in parts if p in sq)
         salu = sum(sq[p]["counters"].get("SQ_INSTS_SALU", 0) for p in parts if p in sq)
         t_ns = sum(dur.get(p, 0.0) for p in parts)
