@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the index-size sweep (100 / 400 / 1000 Mb)")
     ap.add_argument("--no-two-pass", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip kernel_ms_exclusive / host_budget / all_transcripts / config1")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip kernel_ms_exclusive / variants / host_budget / all_transcripts / config1")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("STARAMD_BENCH_BUDGET_S", "1500")), help="optional legs are skipped once this much wall time is used")
     ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/dev/shm/star_amd_bench" if os.path.isdir("/dev/shm") else "/tmp/star_amd_bench"))
     return ap.parse_args()
@@ -567,6 +567,7 @@ def main():
             out["full_size_parity"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_extra_legs:
         for name, fn in (("kernel_ms_exclusive", lambda: exclusive_leg(args, idx, fq, run_dir, threads)),
+                         ("variants", lambda: variants_leg(args, idx, fq, run_dir, threads, out.get("kernel_ms_exclusive") or {}, log)),
                          ("host_budget", lambda: host_budget_leg(args, idx, fq, run_dir)),
                          ("all_transcripts", lambda: all_transcripts_leg(args, g, idx, log)),
                          ("config1", lambda: config1_leg(args, log))):
@@ -641,6 +642,46 @@ def exclusive_leg(args, idx, fq, run_dir, threads):
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
     rep, d = _cli_leg(argv, 2 * args.read_len + 1, {"STARAMD_CONTEXTS_PER_GPU": "1"})
     return d
+
+
+# kernels / knobs that are OFF by default because they have no hardware number yet (written when no GPU minutes were left): the leg below times each of them
+# exactly like kernel_ms_exclusive (one context, same index, same reads) and checks its output against that leg's, so that the bench run at the end of a round is
+# also their A/B.  A variant that wins becomes the default (and leaves this list) in the next round; one that loses is deleted.
+VARIANTS = [
+    ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
+    ("seed_flat_6waves", {"STARAMD_SEED_FLAT": "2"}),
+    ("seed_flat_4waves", {"STARAMD_SEED_FLAT": "3"}),
+    ("lane_class_post_1", {"STARAMD_LANE_CLASS_POST": "1"}),
+    ("lane_class_post_2", {"STARAMD_LANE_CLASS_POST": "2"}),
+    ("lane_class_post_2_cap6", {"STARAMD_LANE_CLASS_POST": "2", "STARAMD_LANE_CLASS": "6"}),
+]
+
+
+def variants_leg(args, idx, fq, run_dir, threads, base, log):
+    """A/B of the experimental kernels against the defaults of the kernel_ms_exclusive leg (`base` = its summary; its output files are the reference here)."""
+    nb, w = 4, 1
+    res = {"what": "experimental kernels / knobs, OFF by default, timed like kernel_ms_exclusive (ONE engine context, %d batches of %d pairs) and compared with its output "
+                   "(SAM multiset, SJ.out.tab); base = the default kernels in the same process" % (nb, args.reads),
+           "base_per_kernel_ms": base.get("per_kernel_ms")}
+    base_prefix = os.path.join(run_dir, "excl_")
+    base_dig = sam_digest(base_prefix + "Aligned.out.sam")
+    base_sj = open(base_prefix + "SJ.out.tab", "rb").read()
+    for name, env in VARIANTS:
+        if time.time() - T_START > args.budget_s:
+            res[name] = {"skipped": "time budget"}; continue
+        pre = os.path.join(run_dir, "var_")
+        argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", pre, "--runThreadN", str(threads),
+                "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
+        try:
+            e = dict(env); e["STARAMD_CONTEXTS_PER_GPU"] = "1"
+            rep, d = _cli_leg(argv, 2 * args.read_len + 1, e)
+            dig = sam_digest(pre + "Aligned.out.sam")
+            res[name] = {"env": env, "per_kernel_ms": d["per_kernel_ms"], "Mreads_s": d["Mreads_s"], "lane_items_per_pair": d["counters_per_pair"].get("nLaneItems"),
+                         "sam_multiset_identical_to_base": dig == base_dig, "sj_out_tab_identical_to_base": open(pre + "SJ.out.tab", "rb").read() == base_sj}
+        except Exception as ex:
+            res[name] = {"env": env, "error": repr(ex)[:300]}
+        log("variant %s done" % name)
+    return res
 
 
 def host_budget_leg(args, idx, fq, run_dir):

@@ -146,6 +146,11 @@ FORCED = {
     "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
     "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
     "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
+    # experimental kernels / knobs that are OFF by default until they have a hardware number (bench.py leg `variants` times them at the end of a round):
+    "seed_flat": {"STARAMD_SEED_FLAT": "1"},                  # the seed search as a state machine around one load site (k_seed_flat.hip), 8 waves per SIMD
+    "seed_flat_4waves": {"STARAMD_SEED_FLAT": "3"},           # ... with 128 VGPRs
+    "lane_class_post": {"STARAMD_LANE_CLASS_POST": "2"},      # light reads classed by their two-mate windows (k_window.hip): more of them go through the lane-per-read stitcher
+    "lane_class_post_wide": {"STARAMD_LANE_CLASS_POST": "8", "STARAMD_LANE_CLASS": "7"},
 }
 
 
