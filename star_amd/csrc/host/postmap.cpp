@@ -61,6 +61,33 @@ std::string PostMap::samHeader() const {                 // samHeaders.cpp:27-98
 }
 
 // ---- ReadAlign::outputTranscriptSAM, mapped branch (:57-356) ----
+// The text of a record is written through a raw pointer into space the output string is grown by once per alignment (an upper bound of both mates'
+// lines), numbers two digits at a time, the reverse complement through a byte table: with std::string appends character by character this function
+// was 97 % of the post-map stage (1.9 us per pair and thread; tools/host_bench.py).
+namespace {
+struct Digits2 { char d[200]; Digits2() { for (int i = 0; i < 100; i++) { d[2 * i] = (char)('0' + i / 10); d[2 * i + 1] = (char)('0' + i % 10); } } };
+const Digits2 DIG2;
+struct RcTable { char t[256]; RcTable() { for (int c = 0; c < 256; c++) t[c] = rcNt((char)c); } };
+const RcTable RCT;
+inline char *putUint(char *p, uint64_t v) {
+    char buf[24]; int n = 24;
+    while (v >= 100) { const uint64_t q = v / 100; const unsigned r = (unsigned)(v - q * 100); v = q; n -= 2; buf[n] = DIG2.d[2 * r]; buf[n + 1] = DIG2.d[2 * r + 1]; }
+    if (v >= 10) { n -= 2; buf[n] = DIG2.d[2 * v]; buf[n + 1] = DIG2.d[2 * v + 1]; } else buf[--n] = (char)('0' + v);
+    memcpy(p, buf + n, (size_t)(24 - n));
+    return p + (24 - n);
+}
+inline char *putInt(char *p, int64_t v) { if (v < 0) { *p++ = '-'; return putUint(p, (uint64_t)(-v)); } return putUint(p, (uint64_t)v); }
+inline char *putStr(char *p, const char *s, size_t n) { memcpy(p, s, n); return p + n; }
+inline char *putSv(char *p, std::string_view s) { memcpy(p, s.data(), s.size()); return p + s.size(); }
+template <size_t N> inline char *putLit(char *p, const char (&s)[N]) { memcpy(p, s, N - 1); return p + (N - 1); }
+enum SamAttr : uint8_t { A_NH, A_HI, A_AS, A_nM, A_jM, A_jI, A_XS, A_NM, A_MD, A_MC, A_RG, A_OTHER };
+inline SamAttr samAttrCode(const std::string &a) {
+    static const char *names[] = {"NH", "HI", "AS", "nM", "jM", "jI", "XS", "NM", "MD", "MC", "RG"};
+    for (int k = 0; k < 11; k++) if (a == names[k]) return (SamAttr)k;
+    return A_OTHER;
+}
+} // namespace
+
 static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &gi, const ReadCtx &rc, const TrView &tv, uint64_t nTrOut, uint64_t iTrOut, const ChimBam *chim = nullptr) {
     const staramd_transcript &t = *tv.t; const staramd_exon *ex = tv.ex;
     const ReadBatch &b = *rc.b; uint32_t ir = rc.i;
@@ -81,28 +108,33 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     uint32_t Str = t.Str;
     uint32_t leftMate = flagPaired ? Str : 0;
     uint64_t chrS = gi.chrStart[t.Chr];
-    // ReadAlign::calcCIGAR (ReadAlign_calcCIGAR.cpp:3-58): the CIGAR of both mates first, the MC tag needs the other mate's
-    std::string matesCIGAR[2];
+    // the attributes of the run as codes (the list is a parameter: the same for every record)
+    SamAttr attr[32]; uint32_t nAttr = 0; bool wantJ = false;
+    for (const std::string &a : P.outSAMattrOrder) { if (nAttr < 32) { attr[nAttr] = samAttrCode(a); wantJ = wantJ || attr[nAttr] == A_jM || attr[nAttr] == A_jI; nAttr++; } }
+    // ReadAlign::calcCIGAR (ReadAlign_calcCIGAR.cpp:3-58): the CIGAR of both mates first, the MC tag needs the other mate's.  At most 3 operations per exon + 2 clips,
+    // 21 characters each at the very most
+    char cig[2][(3 * STARAMD_MAX_N_EXONS + 2) * 21]; size_t cigLen[2] = {0, 0};
     for (uint32_t imate = 0; imate < nMates; imate++) {
         uint32_t iEx1 = imate == 0 ? 0 : iExMate + 1, iEx2 = imate == 0 ? iExMate : nEx - 1;
         uint32_t Mate = ex[iEx1].iFrag;
-        std::string &cigar = matesCIGAR[imate];
+        char *c = cig[imate];
         const uint64_t trimL = rc.trimL(Str, Mate);
         uint64_t trimL1 = trimL + ex[iEx1].R - (ex[iEx1].R < rc.readLength[leftMate] ? 0 : rc.readLength[leftMate] + 1);
-        if (trimL1 > 0) { appendUint(cigar, trimL1); cigar.push_back('S'); }
+        if (trimL1 > 0) { c = putUint(c, trimL1); *c++ = 'S'; }
         for (uint32_t ii = iEx1; ii <= iEx2; ii++) {
             if (ii > iEx1) {
                 uint64_t gapG = ex[ii].G - (ex[ii - 1].G + ex[ii - 1].L);
                 uint64_t gapR = (uint64_t)ex[ii].R - ex[ii - 1].R - ex[ii - 1].L;
-                if (gapR > 0) { appendUint(cigar, gapR); cigar.push_back('I'); }
-                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) { appendUint(cigar, gapG); cigar.push_back('N'); }
-                else if (gapG > 0) { appendUint(cigar, gapG); cigar.push_back('D'); }
+                if (gapR > 0) { c = putUint(c, gapR); *c++ = 'I'; }
+                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) { c = putUint(c, gapG); *c++ = 'N'; }
+                else if (gapG > 0) { c = putUint(c, gapG); *c++ = 'D'; }
             }
-            appendUint(cigar, ex[ii].L); cigar.push_back('M');
+            c = putUint(c, ex[ii].L); *c++ = 'M';
         }
         uint64_t trimR1 = (ex[iEx1].R < rc.readLength[leftMate] ? rc.readLengthOriginal[leftMate] : rc.readLength[leftMate] + 1 + rc.readLengthOriginal[Mate])
                           - ex[iEx2].R - ex[iEx2].L - trimL;
-        if (trimR1 > 0) { appendUint(cigar, trimR1); cigar.push_back('S'); }
+        if (trimR1 > 0) { c = putUint(c, trimR1); *c++ = 'S'; }
+        cigLen[imate] = (size_t)(c - cig[imate]);
     }
     for (uint32_t imate = 0; imate < nMates; imate++) {
         uint32_t samFLAG = samFlagCommon;
@@ -112,16 +144,20 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         else { samFLAG |= (1 - Str) * 0x10; if (nMates == 2) samFLAG |= Str * 0x20; }
         if (flagPaired) { samFLAG |= (Mate == 0 ? 0x0040 : 0x0080); if (nMates == 1 && chim && chim->mateStrand == 1) samFLAG |= 0x20; }     // :120-123
         if (!tv.primary) samFLAG |= 0x100;
-        const std::string &cigar = matesCIGAR[imate];
-        std::string SJmotif, SJintron;
-        for (uint32_t ii = iEx1 + 1; ii <= iEx2; ii++) {
-            if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) {
-                SJmotif.push_back(','); appendInt(SJmotif, ex[ii - 1].canonSJ + (ex[ii - 1].sjAnnot == 0 ? 0 : 20));   // SJ_SAM_AnnotatedMotifShift
-                SJintron.push_back(','); appendUint(SJintron, ex[ii - 1].G + ex[ii - 1].L + 1 - chrS);
-                SJintron.push_back(','); appendUint(SJintron, ex[ii].G - chrS);
+        // jM / jI (only when asked for): at most one junction per exon, 4 + 2 x 21 characters each
+        char jm[STARAMD_MAX_N_EXONS * 5 + 8], ji[STARAMD_MAX_N_EXONS * 44 + 8]; size_t jmLen = 0, jiLen = 0;
+        if (wantJ) {
+            char *m = jm, *q = ji;
+            for (uint32_t ii = iEx1 + 1; ii <= iEx2; ii++) {
+                if (ex[ii - 1].canonSJ >= 0 || ex[ii - 1].sjAnnot == 1) {
+                    *m++ = ','; m = putInt(m, ex[ii - 1].canonSJ + (ex[ii - 1].sjAnnot == 0 ? 0 : 20));   // SJ_SAM_AnnotatedMotifShift
+                    *q++ = ','; q = putUint(q, ex[ii - 1].G + ex[ii - 1].L + 1 - chrS);
+                    *q++ = ','; q = putUint(q, ex[ii].G - chrS);
+                }
             }
+            if (m == jm) { m = putLit(m, ",-1"); q = putLit(q, ",-1"); }
+            jmLen = (size_t)(m - jm); jiLen = (size_t)(q - ji);
         }
-        if (SJmotif.empty()) { SJmotif = ",-1"; SJintron = ",-1"; }
         // NM / MD (ReadAlign_outputTranscriptSAM.cpp:242-276): read in the orientation of the alignment against the genome text
         uint64_t tagNM = 0; std::string tagMD;
         if (P.attrNMorMD) {
@@ -149,44 +185,58 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         }
         int MAPQ = P.outSAMmapqUnique;
         if (nTrOut >= 5) MAPQ = 0; else if (nTrOut >= 3) MAPQ = 1; else if (nTrOut == 2) MAPQ = 3;
-        out += b.name(ir); out.push_back('\t');
-        appendUint(out, (samFLAG & P.outSAMflagAND) | P.outSAMflagOR); out.push_back('\t');
-        out += gi.chrName[t.Chr]; out.push_back('\t');
-        appendUint(out, ex[iEx1].G + 1 - chrS); out.push_back('\t');
-        appendInt(out, MAPQ); out.push_back('\t');
-        out += cigar;
+        const std::string_view nm = b.name(ir), sq = b.seq((int)Mate, ir), ql = b.qual((int)Mate, ir), xt = b.extra((int)imate, ir);
+        const std::string &chrN = gi.chrName[t.Chr];
+        const std::string *mateChrN = (nMates == 1 && chim && chim->mateChr < gi.view.nChrReal) ? &gi.chrName[chim->mateChr] : nullptr;
+        const std::string *rg = nullptr;
+        for (uint32_t k = 0; k < nAttr; k++) if (attr[k] == A_RG) rg = &P.outSAMattrRG.at(b.fileOf(ir));
+        // upper bound of the line: the variable-length parts + 16 numbers of at most 21 characters + tags and separators
+        const size_t bound = nm.size() + chrN.size() + (mateChrN ? mateChrN->size() : 0) + cigLen[0] + cigLen[1] + 2 * sq.size() + jmLen + jiLen + tagMD.size() + (rg ? rg->size() : 0) + xt.size()
+                             + 16 * 21 + 16 * nAttr + 64;
+        const size_t base = out.size();
+        out.resize(base + bound);
+        char *p = &out[base];
+        p = putSv(p, nm); *p++ = '\t';
+        p = putUint(p, (samFLAG & P.outSAMflagAND) | P.outSAMflagOR); *p++ = '\t';
+        p = putStr(p, chrN.data(), chrN.size()); *p++ = '\t';
+        p = putUint(p, ex[iEx1].G + 1 - chrS); *p++ = '\t';
+        p = putInt(p, MAPQ); *p++ = '\t';
+        p = putStr(p, cig[imate], cigLen[imate]);
         if (nMates > 1) {
-            out += "\t=\t"; appendUint(out, ex[imate == 0 ? iExMate + 1 : 0].G + 1 - chrS); out.push_back('\t');
-            if (imate != 0) out.push_back('-');
-            appendUint(out, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);        // (--outSAMtlen 2 changes BAM output only, as in the reference)
-        } else if (chim && chim->mateChr < gi.view.nChrReal) { out.push_back('\t'); out += gi.chrName[chim->mateChr]; out.push_back('\t'); appendUint(out, (uint64_t)chim->mateStart + 1); out += "\t0"; }
-        else out += "\t*\t0\t0";
-        out.push_back('\t');
-        const std::string_view sq = b.seq((int)Mate, ir), ql = b.qual((int)Mate, ir);
+            p = putLit(p, "\t=\t"); p = putUint(p, ex[imate == 0 ? iExMate + 1 : 0].G + 1 - chrS); *p++ = '\t';
+            if (imate != 0) *p++ = '-';
+            p = putUint(p, ex[nEx - 1].G + ex[nEx - 1].L - ex[0].G);        // (--outSAMtlen 2 changes BAM output only, as in the reference)
+        } else if (mateChrN) { *p++ = '\t'; p = putStr(p, mateChrN->data(), mateChrN->size()); *p++ = '\t'; p = putUint(p, (uint64_t)chim->mateStart + 1); p = putLit(p, "\t0"); }
+        else p = putLit(p, "\t*\t0\t0");
+        *p++ = '\t';
         const bool noQS = P.outSAMmodeNoQS || b.fasta;           // readFileType==2 ? Qual : "*" (ReadAlign_outputTranscriptSAM.cpp:215)
-        if (Mate == Str) { out += sq; out.push_back('\t'); if (!noQS) out += ql; else out.push_back('*'); }
+        if (Mate == Str) { p = putSv(p, sq); *p++ = '\t'; if (!noQS) p = putSv(p, ql); else *p++ = '*'; }
         else {
-            size_t n = sq.size();
-            for (size_t k = 0; k < n; k++) out.push_back(rcNt(sq[n - 1 - k]));
-            out.push_back('\t');
-            if (!noQS) { for (size_t k = 0; k < n; k++) out.push_back(ql[n - 1 - k]); } else out.push_back('*');
+            const size_t n = sq.size(); const char *sp = sq.data() + n, *qp = ql.data() + n;
+            for (size_t k = 0; k < n; k++) p[k] = RCT.t[(uint8_t)*--sp];
+            p += n; *p++ = '\t';
+            if (!noQS) { for (size_t k = 0; k < n; k++) p[k] = *--qp; p += n; } else *p++ = '*';
         }
-        for (const std::string &a : P.outSAMattrOrder) {
-            if (a == "NH") { out += "\tNH:i:"; appendUint(out, nTrOut); }
-            else if (a == "HI") { out += "\tHI:i:"; appendInt(out, (int64_t)iTrOut + P.outSAMattrIHstart); }
-            else if (a == "AS") { out += "\tAS:i:"; appendInt(out, t.maxScore); }
-            else if (a == "nM") { out += "\tnM:i:"; appendUint(out, t.nMM); }
-            else if (a == "jM") { out += "\tjM:B:c"; out += SJmotif; }
-            else if (a == "jI") { out += "\tjI:B:i"; out += SJintron; }
-            else if (a == "XS") { if (t.sjMotifStrand == 1) out += "\tXS:A:+"; else if (t.sjMotifStrand == 2) out += "\tXS:A:-"; }
-            else if (a == "NM") { out += "\tNM:i:"; appendUint(out, tagNM); }
-            else if (a == "MD") { out += "\tMD:Z:"; out += tagMD; }
-            else if (a == "MC") { if (nMates > 1) { out += "\tMC:Z:"; out += matesCIGAR[1 - imate]; } }
-            else if (a == "RG") { out += "\tRG:Z:"; out += P.outSAMattrRG.at(b.fileOf(ir)); }
+        for (uint32_t k = 0; k < nAttr; k++) {
+            switch (attr[k]) {
+                case A_NH: p = putLit(p, "\tNH:i:"); p = putUint(p, nTrOut); break;
+                case A_HI: p = putLit(p, "\tHI:i:"); p = putInt(p, (int64_t)iTrOut + P.outSAMattrIHstart); break;
+                case A_AS: p = putLit(p, "\tAS:i:"); p = putInt(p, t.maxScore); break;
+                case A_nM: p = putLit(p, "\tnM:i:"); p = putUint(p, t.nMM); break;
+                case A_jM: p = putLit(p, "\tjM:B:c"); p = putStr(p, jm, jmLen); break;
+                case A_jI: p = putLit(p, "\tjI:B:i"); p = putStr(p, ji, jiLen); break;
+                case A_XS: if (t.sjMotifStrand == 1) p = putLit(p, "\tXS:A:+"); else if (t.sjMotifStrand == 2) p = putLit(p, "\tXS:A:-"); break;
+                case A_NM: p = putLit(p, "\tNM:i:"); p = putUint(p, tagNM); break;
+                case A_MD: p = putLit(p, "\tMD:Z:"); p = putStr(p, tagMD.data(), tagMD.size()); break;
+                case A_MC: if (nMates > 1) { p = putLit(p, "\tMC:Z:"); p = putStr(p, cig[1 - imate], cigLen[1 - imate]); } break;
+                case A_RG: p = putLit(p, "\tRG:Z:"); p = putStr(p, rg->data(), rg->size()); break;
+                default: break;
+            }
         }
         // SAM input: its attributes go out again; indexed by the position of the mate in the alignment, not by the mate, as the reference does (:351-353)
-        if (!b.extra((int)imate, ir).empty()) { out.push_back('\t'); out += b.extra((int)imate, ir); }
-        out.push_back('\n');
+        if (!xt.empty()) { *p++ = '\t'; p = putSv(p, xt); }
+        *p++ = '\n';
+        out.resize((size_t)(p - out.data()));
     }
 }
 

@@ -261,6 +261,9 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
     carry[m].clear();
     uint64_t scanned = 0;
     const uint64_t wantLines = want * 4;
+    static const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    auto Tf = std::chrono::steady_clock::now(); double msRead = 0, msMerge = 0;
+    auto lapf = [&](double &acc) { if (timing) { auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(t - Tf).count(); Tf = t; } };
     static const uint64_t sliceMin = getenv("STARAMD_READ_SLICE_MIN") ? strtoull(getenv("STARAMD_READ_SLICE_MIN"), nullptr, 10) : (8u << 20);   // (tests lower it)
     for (;;) {
         scanned = scanNewlines(text.data(), scanned, text.size(), le, wantLines);
@@ -296,9 +299,11 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
                 nl[k].reserve((size_t)((double)done / bytesPerRecord[m] * 4.2) + 16);
                 scanNewlines(text.data(), old + lo, old + lo + done, nl[k], UINT64_MAX);
             };
+            lapf(msMerge);
             for (unsigned k = 1; k < K; k++) th.emplace_back(slice, k);
             slice(0);
             for (auto &x : th) x.join();
+            lapf(msRead);
             got = 0;
             for (unsigned k = 0; k < K; k++) { got += gotK[k]; if (gotK[k] < std::min<size_t>(block, (k + 1) * per) - std::min<size_t>(block, k * per)) break; }   // a short slice ends the input
             fseeko(f[m], pos0 + (off_t)got, SEEK_SET);
@@ -324,6 +329,8 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
     }
     // fastqReadOneLine strips one trailing control character (\r) from every line
     for (size_t k = 0; k < ls.size(); k++) if (le[k] > ls[k] && (unsigned char)text[le[k] - 1] < 33) le[k]--;
+    lapf(msMerge);
+    if (timing) fprintf(stderr, "  fill mate %d: read + scan on %u threads %.2f ms, serial (line table, carry) %.2f ms\n", m, readSlices, msRead, msMerge);
     return ls.size();
 }
 

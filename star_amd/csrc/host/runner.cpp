@@ -375,6 +375,7 @@ struct Runner {
         wcv.notify_all();
         if (!error.empty()) return false;
         for (uint32_t t = 0; t < T; t++) { sj.mergeFrom(sjs[t]); stats.add(sts[t]); if (quant) geneCounts.add(gcs[t]); }
+        if (hostTiming) fprintf(stderr, "  emit tail: junction records merged %.2f ms (%zu in the table)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te2).count(), sj.data.size());
         if (trSAM) {
             // one random number per mapped read, in read order, picks the primary transcriptomic alignment (ReadAlign_quantTranscriptome.cpp:69);
             // the flag is patched into the records (FLAG is the high half of the 5th word), then the text is compressed and written
