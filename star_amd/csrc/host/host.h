@@ -233,6 +233,7 @@ private:
     std::atomic<int> ioError{0};          // errno of a failed read of an input file (sliced pread path): reported by nextBatch, never taken for the end of the input
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
     std::vector<uint64_t> lineStart[2], lineEnd[2];
+    std::vector<uint64_t> lineRaw[2];     // positions of the newline bytes of the batch text (fill): the line table is built from them on threads
     bool noQualities = false;             // held FASTA reads (2nd stage of BySJout)
     int samMates_ = 0; bool extras = false;   // SAM text input (ReadAlignChunk_processChunks.cpp:28-107); ID lines may carry attributes after a \x01
     TextBuf samText2; std::vector<uint64_t> samLs2, samLe2;   // mate 2 of the records fillSam parsed for mate 1

@@ -255,8 +255,8 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
         return lineStart[1].size();
     }
     if (fasta) return fillFasta(m, want, text);
-    std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
-    ls.clear(); le.clear();
+    std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m], &nlp = lineRaw[m];
+    ls.clear(); le.clear(); nlp.clear();
     text.assign(carry[m].begin(), carry[m].end());      // (not swap: every buffer keeps its capacity, so no fresh pages per batch)
     carry[m].clear();
     uint64_t scanned = 0;
@@ -265,11 +265,17 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
     auto Tf = std::chrono::steady_clock::now(); double msRead = 0, msMerge = 0;
     auto lapf = [&](double &acc) { if (timing) { auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(t - Tf).count(); Tf = t; } };
     static const uint64_t sliceMin = getenv("STARAMD_READ_SLICE_MIN") ? strtoull(getenv("STARAMD_READ_SLICE_MIN"), nullptr, 10) : (8u << 20);   // (tests lower it)
+    auto onThreads = [&](unsigned K, const std::function<void(unsigned)> &fn) {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < K; k++) th.emplace_back(fn, k);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
     for (;;) {
-        scanned = scanNewlines(text.data(), scanned, text.size(), le, wantLines);
-        if (le.size() >= wantLines || eof[m]) break;
+        scanned = scanNewlines(text.data(), scanned, text.size(), nlp, wantLines);
+        if (nlp.size() >= wantLines || eof[m]) break;
         // read about as much as the missing records need (little is left over to carry into the next batch)
-        uint64_t missing = (wantLines - le.size() + 3) / 4;
+        uint64_t missing = (wantLines - nlp.size() + 3) / 4;
         uint64_t block = std::max<uint64_t>(1u << 16, std::min<uint64_t>(64u << 20, (uint64_t)((double)missing * bytesPerRecord[m] * 1.01) + 4096));
         size_t old = text.size();
         text.resize(old + block);
@@ -283,9 +289,9 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
             const int fd = fileno(f[m]);
             std::vector<std::vector<uint64_t>> nl(K);
             std::vector<size_t> gotK(K, 0);
-            std::vector<std::thread> th;
             const size_t per = (block + K - 1) / K;
-            auto slice = [&](unsigned k) {
+            lapf(msMerge);
+            onThreads(K, [&](unsigned k) {
                 const size_t lo = std::min<size_t>(block, k * per), hi = std::min<size_t>(block, lo + per);
                 size_t done = 0;
                 while (lo + done < hi) {
@@ -298,37 +304,52 @@ uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
                 gotK[k] = done;
                 nl[k].reserve((size_t)((double)done / bytesPerRecord[m] * 4.2) + 16);
                 scanNewlines(text.data(), old + lo, old + lo + done, nl[k], UINT64_MAX);
-            };
-            lapf(msMerge);
-            for (unsigned k = 1; k < K; k++) th.emplace_back(slice, k);
-            slice(0);
-            for (auto &x : th) x.join();
+            });
             lapf(msRead);
-            got = 0;
-            for (unsigned k = 0; k < K; k++) { got += gotK[k]; if (gotK[k] < std::min<size_t>(block, (k + 1) * per) - std::min<size_t>(block, k * per)) break; }   // a short slice ends the input
+            got = 0; unsigned Kgood = 0;
+            for (unsigned k = 0; k < K; k++) { got += gotK[k]; Kgood = k + 1; if (gotK[k] < std::min<size_t>(block, (k + 1) * per) - std::min<size_t>(block, k * per)) break; }   // a short slice ends the input
             fseeko(f[m], pos0 + (off_t)got, SEEK_SET);
-            // everything before `old` has been scanned; the line ends of the slices follow in order
-            for (unsigned k = 0; k < K && le.size() < wantLines; k++)
-                for (uint64_t e : nl[k]) { if (e >= old + got || le.size() >= wantLines) break; le.push_back(e); }
-            scanned = le.size() >= wantLines ? le.back() + 1 : old + got;
+            // everything before `old` has been scanned; the line ends of the slices follow in order: each slice is copied to its place on its thread
+            std::vector<size_t> off(Kgood + 1, nlp.size());
+            for (unsigned k = 0; k < Kgood; k++) off[k + 1] = off[k] + nl[k].size();
+            const size_t total = std::min<size_t>(off[Kgood], wantLines);
+            nlp.resize(total);
+            onThreads(Kgood, [&](unsigned k) { if (off[k] < total) memcpy(nlp.data() + off[k], nl[k].data(), (std::min(off[k + 1], total) - off[k]) * sizeof(uint64_t)); });
+            scanned = nlp.size() >= wantLines ? nlp.back() + 1 : old + got;
             slicedBlocks++;
         }
         else got = fread(text.data() + old, 1, block, f[m]);      // (fread itself loops over short pipe reads until EOF)
         text.resize(old + got);
         if (got < block) eof[m] = true;
     }
-    if (le.size() >= 4) bytesPerRecord[m] = (double)(le.back() + 1) / (double)(le.size() / 4);
-    ls.resize(le.size());
-    for (size_t k = 0; k < le.size(); k++) ls[k] = k ? le[k - 1] + 1 : 0;
-    uint64_t lineBeg = le.empty() ? 0 : le.back() + 1;
-    if (le.size() >= wantLines) {                       // the rest belongs to the next batches
+    lapf(msMerge);
+    if (nlp.size() >= 4) bytesPerRecord[m] = (double)(nlp.back() + 1) / (double)(nlp.size() / 4);
+    // the line table: starts (behind the previous newline) and ends; fastqReadOneLine strips one trailing control character (\r) from every line
+    const size_t nNl = nlp.size();
+    uint64_t lineBeg = nNl == 0 ? 0 : nlp.back() + 1;
+    const bool tailLine = nNl < wantLines && lineBeg < text.size();      // end of file without a final newline: the tail is a line
+    ls.resize(nNl + (tailLine ? 1 : 0)); le.resize(ls.size());
+    {
+        const char *tx = text.data();
+        const unsigned K = nNl >= (1u << 16) ? std::max(1u, readSlices) : 1u;
+        const size_t per = (nNl + K - 1) / K;
+        onThreads(K, [&](unsigned k) {
+            const size_t lo = std::min(nNl, k * per), hi = std::min(nNl, lo + per);
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t s0 = i ? nlp[i - 1] + 1 : 0; uint64_t e0 = nlp[i];
+                if (e0 > s0 && (unsigned char)tx[e0 - 1] < 33) e0--;
+                ls[i] = s0; le[i] = e0;
+            }
+        });
+    }
+    if (nNl >= wantLines) {                             // the rest belongs to the next batches
         carry[m].assign(text.begin() + lineBeg, text.end());
         text.resize(lineBeg);
-    } else if (lineBeg < text.size()) {                 // end of file without a final newline: the tail is a line
-        ls.push_back(lineBeg); le.push_back(text.size());
+    } else if (tailLine) {
+        uint64_t e0 = text.size();
+        if (e0 > lineBeg && (unsigned char)text[e0 - 1] < 33) e0--;
+        ls[nNl] = lineBeg; le[nNl] = e0;
     }
-    // fastqReadOneLine strips one trailing control character (\r) from every line
-    for (size_t k = 0; k < ls.size(); k++) if (le[k] > ls[k] && (unsigned char)text[le[k] - 1] < 33) le[k]--;
     lapf(msMerge);
     if (timing) fprintf(stderr, "  fill mate %d: read + scan on %u threads %.2f ms, serial (line table, carry) %.2f ms\n", m, readSlices, msRead, msMerge);
     return ls.size();

@@ -209,6 +209,7 @@ struct Runner {
     // ---- SAM text goes to the file on its own thread: formatting of batch k+1 overlaps the write of batch k.  Two sets of
     // per-thread text buffers alternate and keep their capacity (no fresh pages per batch).
     struct OutSet { std::vector<std::string> sams, raws; uint32_t used = 0; };
+    std::vector<OutSJ> sjScratch;            // emitBatch: junction records per thread (one batch at a time)
     OutSet outSets[2];
     std::mutex wm; std::condition_variable wcv;
     std::deque<int> freeSets, fullSets; bool writerStop = false, writerFailed = false;
@@ -277,7 +278,12 @@ struct Runner {
         OutSet &o = outSets[k];
         if (o.sams.size() < T) { o.sams.resize(T); o.raws.resize(T); }
         o.used = T;
-        std::vector<std::string> errs(T); std::vector<OutSJ> sjs(T); std::vector<Stats> sts(T);
+        std::vector<std::string> errs(T); std::vector<Stats> sts(T);
+        // per-thread junction records of the batch: the vectors are kept between batches (a fresh vector grows by reallocation up to a few hundred KB per thread and
+        // batch, which glibc serves with mmap / munmap: page faults on every batch)
+        std::vector<OutSJ> &sjs = sjScratch;
+        if (sjs.size() < T) sjs.resize(T);
+        for (uint32_t t = 0; t < T; t++) sjs[t].data.clear();
         const bool stage1 = bySJoutStage == 1;
         std::vector<OutSJ> sj1s(stage1 ? T : 0); std::vector<std::vector<uint32_t> > helds(stage1 ? T : 0);
         const bool quant = P.quantGeneCounts && !pass1;             // twoPassRunPass1.cpp:24-29: no quantification in the 1st pass
@@ -320,6 +326,7 @@ struct Runner {
         }
         static const bool hostTiming = getenv("STARAMD_HOST_TIMING") != nullptr;
         std::vector<double> tThread(hostTiming ? T : 0);
+        const double msBefore = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te1).count();
         int waspEndOfBatch = post->waspCarry;
         auto work = [&](uint32_t t) {
             struct Tm { std::vector<double> &v; uint32_t t; std::chrono::steady_clock::time_point t0; ~Tm() { if (!v.empty()) v[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } tm{tThread, t, std::chrono::steady_clock::now()};
@@ -327,8 +334,8 @@ struct Runner {
             // the thread appends to objects of its own for the length of the range: neighbouring elements of the per-thread vectors share
             // cache lines, and a std::string / std::vector rewrites its size word on every append (measured: 4x per record with 8 threads)
             std::string samL, rawL; OutSJ sjL; Stats stL;
-            samL.swap(o.sams[t]); rawL.swap(o.raws[t]);
-            struct Back { std::string &a, &al, &b, &bl; OutSJ &s, &sl; Stats &st, &stl; ~Back() { a.swap(al); b.swap(bl); s = std::move(sl); st = stl; } } back{o.sams[t], samL, o.raws[t], rawL, sjs[t], sjL, sts[t], stL};
+            samL.swap(o.sams[t]); rawL.swap(o.raws[t]); sjL.data.swap(sjs[t].data);
+            struct Back { std::string &a, &al, &b, &bl; OutSJ &s, &sl; Stats &st, &stl; ~Back() { a.swap(al); b.swap(bl); s.data.swap(sl.data); st = stl; } } back{o.sams[t], samL, o.raws[t], rawL, sjs[t], sjL, sts[t], stL};
             samL.clear();
             const bool bamOut = (P.outBAMunsorted || P.outBAMcoord) && !post->samOff;   // BAM: this thread's records are compressed here, block by block (bgzf.cpp)
             std::string &raw = rawL;
@@ -419,6 +426,8 @@ struct Runner {
         if (waspType && !waspType->empty()) post->waspCarry = waspEndOfBatch;
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
         if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
+        if (hostTiming) fprintf(stderr, "  emit: before the threads %.2f ms, threads %.2f ms, tail %.2f ms\n", std::chrono::duration<double, std::milli>(te1 - te0).count() + msBefore, std::chrono::duration<double, std::milli>(te2 - te1).count() - msBefore,
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te2).count());
         return true;
     }
     // Aligned.sortedByCoord.out.bam (BAMbinSortByCoordinate.cpp, BAMbinSortUnmapped.cpp): mapped records by (refID << 32 | pos, read order,

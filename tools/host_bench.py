@@ -76,7 +76,9 @@ def main():
     if args.null_out:
         os.symlink("/dev/null", sam)
     t0 = time.time()
-    rc, rep = capi.run_cli(argv, lib_path=lib)
+    cpu = {}
+    rc, rep = capi.run_cli(argv, lib_path=lib, warmup_done=lambda: cpu.__setitem__("t0", time.process_time()))
+    cpu["t1"] = time.process_time()
     if rc:
         sys.exit("front end failed: rc %d" % rc)
     nb = max(1, rep.batches)
@@ -86,6 +88,7 @@ def main():
         "timed_pairs": rep.timedReads, "timed_wall_s": round(rep.timedWall, 4), "batches": rep.batches, "batch_pairs": args.block,
         "parse_ms_per_batch": round(1e3 * rep.parseBusy / nb, 2), "emit_ms_per_batch": round(1e3 * rep.emitBusy / nb, 2), "finish_s": round(rep.finishSeconds, 3),
         "parse_pairs_per_s": args.block * nb / rep.parseBusy if rep.parseBusy > 0 else None, "emit_pairs_per_s": args.block * nb / rep.emitBusy if rep.emitBusy > 0 else None,
+        "cpu_us_per_pair": round(1e6 * (cpu["t1"] - cpu["t0"]) / rep.timedReads, 3) if "t0" in cpu and rep.timedReads else None,
         "threads": args.threads, "device_ms": args.device_ms, "contexts": rep.nContexts, "read_len": args.read_len, "total_wall_s": round(time.time() - t0, 2),
         "sam_bytes": os.path.getsize(sam) if os.path.isfile(sam) and not args.null_out else None,
     }
