@@ -42,6 +42,7 @@ typedef struct staramd_cli_report {
     double   pass1Seconds;         /* --twopassMode Basic: 1st pass + junction insertion + index re-upload            */
     double   finishSeconds;        /* after the last batch is handed to the writer: last writes, SJ.out.tab, Log.final.out (inside timedWall) */
     int      nContexts;            /* engine contexts (= mapper threads): nDevices x STARAMD_CONTEXTS_PER_GPU; deviceBusy / deviceMs are per context */
+    double   convertBusy;          /* seconds the second half of the reader (text -> numeric batch, its own thread) was busy, timed region; parseBusy is the first half (input + line table) */
 } staramd_cli_report;
 
 /* Runs the whole job; returns the process exit code (0 ok).  hooks / report may be NULL. */

@@ -59,6 +59,11 @@ int   sah_emit_merged(void *h, const staramd_results *res, const staramd_results
 
 /* pipelined: three batch slots, so that parsing of batch k+1, mapping of batch k and post-map of batch k-1 overlap */
 int   sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
+/* sah_parse_slot in two halves, for two threads (each half called in batch order): sah_fill_slot reads the text of the next batch and finds its lines
+ * (returns the number of reads, 0 at the end of the input, < 0 on error); sah_convert_slot turns it into the numeric batch while sah_fill_slot already
+ * reads the next one */
+int   sah_fill_slot(void *h, int slot, uint64_t maxReads);
+int   sah_convert_slot(void *h, int slot, staramd_batch *out);
 int   sah_merged_slot(void *h, int slot, staramd_batch *out);
 int   sah_wasp_slot(void *h, int slot, const staramd_results *res, staramd_batch *out);
 int   sah_wasp_results_slot(void *h, int slot, const staramd_results *res, const staramd_results *resWasp);

@@ -168,7 +168,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     }
 #endif
     loadLock.drop();
-    const int nSlots = std::min(24, 2 * nDev + 2);
+    const int nSlots = std::min(24, 2 * nDev + 3);      // in flight: one batch in each half of the reader, one per mapper, one in the writer, the rest queued between them
     std::vector<ResBuf> rb(nSlots), rbMerged(nSlots), rbWasp(nSlots);
     std::vector<ResBuf> piecePart(nDev);
     for (auto &r : rb) r.size(batchReads);
@@ -188,7 +188,11 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
         std::mutex doneM; std::condition_variable doneCv; std::map<uint64_t, Msg> done; bool mappersClosed = false;
         for (int i = 0; i < nSlots; i++) slots.give(i);
         { std::lock_guard<std::mutex> l(drainM); seqParsed = seqEmitted = 0; }
-        std::thread reader([&] {
+        // the reader is two stages on two threads: `filler` reads the text of batch k+1 and finds its lines (everything that touches the input) while
+        // `reader` turns the text of batch k into the numeric batch (sah_fill_slot / sah_convert_slot; tools/host_bench.py: the two halves take about
+        // the same time, and their sum was the longest stage of the pipeline at the thread budget of an 8-GPU node)
+        Queue filled;
+        std::thread filler([&] {
             uint64_t seq = 0, readsOut = 0;
             for (;;) {
                 if (warmupPending && readsOut >= flags.warmupReads) {            // drain, barrier, start the clock
@@ -200,12 +204,23 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                 Msg m; m.slot = slots.take();
                 if (failed.load()) { slots.give(m.slot); break; }
                 auto tp = Clock::now();
-                m.n = sah_parse_slot(h, m.slot, batchReads, &m.b);
+                m.n = sah_fill_slot(h, m.slot, batchReads);
                 if (m.n < 0) { fail(sah_error(h)); slots.give(m.slot); break; }
                 if (m.n == 0) { slots.give(m.slot); break; }
                 { std::lock_guard<std::mutex> l(statM); if (timedOn) rep.parseBusy += since(tp); }
                 m.seq = seq++; readsOut += (uint64_t)m.n;
                 { std::lock_guard<std::mutex> l(drainM); seqParsed = seq; }
+                filled.push(m);
+            }
+            filled.close();
+        });
+        std::thread reader([&] {
+            Msg m;
+            while (filled.pop(m)) {
+                auto tp = Clock::now();
+                if (!failed.load() && sah_convert_slot(h, m.slot, &m.b) < 0) fail(sah_error(h));
+                if (failed.load()) m.n = 0;                                      // still goes down the pipeline so that the slot and the sequence number are released
+                { std::lock_guard<std::mutex> l(statM); if (timedOn && m.n > 0) rep.convertBusy += since(tp); }
                 parsed.push(m);
             }
             parsed.close();
@@ -300,7 +315,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
         { std::lock_guard<std::mutex> l(doneM); mappersClosed = true; }
         doneCv.notify_all();
         drainCv.notify_all();
-        reader.join(); writer.join();
+        filler.join(); reader.join(); writer.join();
     };
     // phases (sah_next_phase): plain run = one; --twopassMode Basic adds a 1st pass without SAM, after which the junctions it found
     // are inserted into the index (sjdb_insert.cpp) and every HBM copy is replaced (twoPassRunPass1.cpp:9-96);

@@ -168,6 +168,7 @@ struct ReadBatch {
     uint32_t fileIndex = 0;               // which of the comma-separated input files the batch came from (a batch never spans two)
     std::vector<uint32_t> heldFile;       // 2nd stage of BySJout: the file every held read came from (empty otherwise)
     uint32_t fileOf(uint32_t i) const { return heldFile.empty() ? fileIndex : heldFile[i]; }
+    std::vector<uint64_t> lineStart[2], lineEnd[2];   // line table of text[]: written by the reader's fill stage, turned into the spans above by its convert stage
     std::vector<TextSpan> extraSpan[2];   // SAM input: the attributes of the input record, tab-separated text (readNameExtra, readLoad.cpp:28-29); empty otherwise
     std::string_view extra(int m, uint32_t i) const { return extraSpan[m].empty() ? std::string_view() : std::string_view(text[m].data() + extraSpan[m][i].off, extraSpan[m][i].len); }
     bool fasta = false;                   // the reads came without qualities (FASTA input, readLoad.cpp:84-88): QUAL is * in SAM, 0xFF in BAM, Fastx output is FASTA
@@ -216,7 +217,12 @@ public:
     // mimics ReadAlignChunk::processChunks FASTQ branch (:111-157) + readLoad (readLoad.cpp:4-100)
     // + the PE concatenation of ReadAlign::oneRead (ReadAlign_oneRead.cpp:35-78).
     // The text is read in blocks and the records of a batch are converted on --runThreadN threads.
-    bool nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err);
+    bool nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err) { return fillBatch(b, P, maxReads, err) && convertBatch(b, P, err); }
+    // the two halves of nextBatch, for callers that run them as two pipeline stages on two threads (star_amd CLI): fillBatch reads the text of the next batch
+    // and builds its line table (everything that touches the input and decides where the batch ends); convertBatch turns text + line table into numeric
+    // reads and spans and touches nothing that fillBatch of the NEXT batch uses.  Each half is called from one thread, in batch order.
+    bool fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err);
+    bool convertBatch(ReadBatch &b, const RunParams &P, std::string &err);
     uint64_t readsSoFar = 0;
 private:
     FILE *f[2] = {nullptr, nullptr};
@@ -232,17 +238,16 @@ private:
     bool eof[2] = {false, false};
     std::atomic<int> ioError{0};          // errno of a failed read of an input file (sliced pread path): reported by nextBatch, never taken for the end of the input
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read
-    std::vector<uint64_t> lineStart[2], lineEnd[2];
     std::vector<uint64_t> lineRaw[2];     // positions of the newline bytes of the batch text (fill): the line table is built from them on threads
     bool noQualities = false;             // held FASTA reads (2nd stage of BySJout)
     int samMates_ = 0; bool extras = false;   // SAM text input (ReadAlignChunk_processChunks.cpp:28-107); ID lines may carry attributes after a \x01
     TextBuf samText2; std::vector<uint64_t> samLs2, samLe2;   // mate 2 of the records fillSam parsed for mate 1
-    uint64_t fillSam(uint64_t want, TextBuf &text);
+    uint64_t fillSam(uint64_t want, ReadBatch &b);
     std::string samError; uint64_t firstFlag = 0; std::string lastExtra[2];
     bool fasta = false;                   // '>' records, possibly with the sequence over several lines (ReadAlignChunk_processChunks.cpp:158-190)
-    uint64_t fillFasta(int m, uint64_t want, TextBuf &text);
-    // moves text of up to `want` records into `text`; fills lineStart/lineEnd; returns the number of complete lines
-    uint64_t fill(int m, uint64_t want, TextBuf &text);
+    uint64_t fillFasta(int m, uint64_t want, ReadBatch &b);
+    // moves text of up to `want` records into b.text[m]; fills b.lineStart[m] / b.lineEnd[m]; returns the number of complete lines
+    uint64_t fill(int m, uint64_t want, ReadBatch &b);
 };
 
 // ---- junction insertion into the loaded index (sjdb_insert.cpp) ----

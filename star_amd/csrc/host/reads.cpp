@@ -31,7 +31,7 @@ void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
     nameSpan.clear(); filter.clear(); origIndex.clear(); heldFile.clear();
     for (int m = 0; m < 2; m++) for (int q = 0; q < 2; q++) clipN[m][q].clear();
-    for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); extraSpan[i].clear(); }
+    for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); extraSpan[i].clear(); lineStart[i].clear(); lineEnd[i].clear(); }
 }
 
 void FastqReader::closeFiles() {
@@ -123,8 +123,9 @@ static uint64_t scanNewlines(const char *p, uint64_t from, uint64_t to, std::vec
 
 // FASTA reads: every record is rewritten as four lines (ID, the sequence on one line, +, a quality line of 'A's as readLoad.cpp:84-88 assigns) so that the
 // rest of the batcher is the same for both formats; ReadBatch::fasta tells the writers that there are no real qualities
-uint64_t FastqReader::fillFasta(int m, uint64_t want, TextBuf &text) {
-    std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m];
+uint64_t FastqReader::fillFasta(int m, uint64_t want, ReadBatch &b) {
+    TextBuf &text = b.text[m];
+    std::vector<uint64_t> &ls = b.lineStart[m], &le = b.lineEnd[m];
     ls.clear(); le.clear(); text.clear();
     std::vector<char> &raw = carry[m];              // unparsed input text
     size_t p = 0; uint64_t nRec = 0;
@@ -177,8 +178,9 @@ uint64_t FastqReader::fillFasta(int m, uint64_t want, TextBuf &text) {
 // SAM text input (--readFilesType SAM SE|PE, ReadAlignChunk_processChunks.cpp:28-107): header lines skipped; one record per mate, the two of a pair on
 // consecutive lines; sequences of reverse-strand records are turned back; the attributes go onto the ID line (after a \x01 here) and come out again with
 // every alignment of the read.  Rewritten as four-line records for both mates at once; fill(1) hands out mate 2.
-uint64_t FastqReader::fillSam(uint64_t want, TextBuf &text) {
-    std::vector<uint64_t> *LS[2] = {&lineStart[0], &samLs2}, *LE[2] = {&lineEnd[0], &samLe2};
+uint64_t FastqReader::fillSam(uint64_t want, ReadBatch &b) {
+    TextBuf &text = b.text[0];
+    std::vector<uint64_t> *LS[2] = {&b.lineStart[0], &samLs2}, *LE[2] = {&b.lineEnd[0], &samLe2};
     TextBuf *TX[2] = {&text, &samText2};
     for (int m = 0; m < 2; m++) { LS[m]->clear(); LE[m]->clear(); TX[m]->clear(); }
     std::vector<char> &raw = carry[0];
@@ -248,14 +250,15 @@ uint64_t FastqReader::fillSam(uint64_t want, TextBuf &text) {
     return LS[0]->size();
 }
 
-uint64_t FastqReader::fill(int m, uint64_t want, TextBuf &text) {
+uint64_t FastqReader::fill(int m, uint64_t want, ReadBatch &b) {
+    TextBuf &text = b.text[m];
     if (samMates_ > 0) {
-        if (m == 0) return fillSam(want, text);
-        text.swap(samText2); lineStart[1].swap(samLs2); lineEnd[1].swap(samLe2);
-        return lineStart[1].size();
+        if (m == 0) return fillSam(want, b);
+        text.swap(samText2); b.lineStart[1].swap(samLs2); b.lineEnd[1].swap(samLe2);
+        return b.lineStart[1].size();
     }
-    if (fasta) return fillFasta(m, want, text);
-    std::vector<uint64_t> &ls = lineStart[m], &le = lineEnd[m], &nlp = lineRaw[m];
+    if (fasta) return fillFasta(m, want, b);
+    std::vector<uint64_t> &ls = b.lineStart[m], &le = b.lineEnd[m], &nlp = lineRaw[m];
     ls.clear(); le.clear(); nlp.clear();
     text.assign(carry[m].begin(), carry[m].end());      // (not swap: every buffer keeps its capacity, so no fresh pages per batch)
     carry[m].clear();
@@ -365,7 +368,7 @@ struct NtTable {               // convertNucleotidesToNumbers (SequenceFuns.cpp:
 };
 static const NtTable NT;
 
-bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err) {
+bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err) {
     b.clear();
     b.firstReadIndex = readsSoFar;
     uint64_t want = maxReads;
@@ -384,11 +387,11 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     uint64_t nLines[2] = {0, 0};
     for (;;) {
         if (nMates == 2 && samMates_ == 0 && !fasta) {       // the two mate files are read and scanned for line ends side by side
-            std::thread second([&] { nLines[1] = fill(1, want, b.text[1]); });
-            nLines[0] = fill(0, want, b.text[0]);
+            std::thread second([&] { nLines[1] = fill(1, want, b); });
+            nLines[0] = fill(0, want, b);
             second.join();
         } else
-            for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b.text[m]);
+            for (int m = 0; m < nMates; m++) nLines[m] = fill(m, want, b);
         b.fileIndex = (uint32_t)curFile; b.fasta = fasta || noQualities;
         // a batch never spans two input files: when this one is exhausted the next batch starts with the next file
         if (!fromMemory && nLines[0] == 0 && curFile + 1 < files_[0].size()) { closeFiles(); curFile++; std::string e = openCurrent(); if (!e.empty()) { err = e; return false; } continue; }
@@ -400,8 +403,8 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     // records of mate 1 decide the batch; an empty ID line ends the input
     uint64_t n = nLines[0] / 4;
     bool partial = nLines[0] % 4 != 0;
-    for (uint64_t i = 0; i < n; i++) if (lineEnd[0][4 * i] == lineStart[0][4 * i]) { n = i; partial = false; eof[0] = true; carry[0].clear(); break; }
-    if (partial && lineEnd[0][4 * n] == lineStart[0][4 * n]) partial = false;
+    for (uint64_t i = 0; i < n; i++) if (b.lineEnd[0][4 * i] == b.lineStart[0][4 * i]) { n = i; partial = false; eof[0] = true; carry[0].clear(); break; }
+    if (partial && b.lineEnd[0][4 * n] == b.lineStart[0][4 * n]) partial = false;
     if (partial) { err = "EXITING because of FATAL ERROR in reads input: truncated FASTQ record"; return false; }
     if (n == 0) return false;
     if (nMates == 2 && nLines[1] < 4 * n) {
@@ -409,13 +412,23 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
                                                        : "EXITING because of FATAL ERROR in reads input: truncated FASTQ record";
         return false;
     }
+    if (!samError.empty()) { err = samError; return false; }
     b.n = (uint32_t)n;
+    readsSoFar += n;
+    return true;
+}
+
+bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &err) {
+    static const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
+    const uint64_t n = b.n;
+    const std::vector<uint64_t> *lineStart = b.lineStart, *lineEnd = b.lineEnd;
     b.readOffset.assign(n + 1, 0); b.mate1Length.assign(n, 0); b.mmMaxTotal.assign(n, 0);
     b.nameSpan.assign(n, TextSpan{0, 0}); b.filter.assign(n, 'N');
     if (fromMemory) { b.origIndex.assign(n, 0); b.heldFile.assign(n, 0); }
     if (P.clipYes) for (int m = 0; m < nMates; m++) for (int q = 0; q < 2; q++) b.clipN[m][q].assign(n, 0);
     for (int m = 0; m < nMates; m++) { b.seqSpan[m].assign(n, TextSpan{0, 0}); b.qualSpan[m].assign(n, TextSpan{0, 0}); if (extras) b.extraSpan[m].assign(n, TextSpan{0, 0}); }
-    if (!samError.empty()) { err = samError; return false; }
     lap("alloc");
     const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(std::max(P.runThreadN, 1), 32), n / 2048));
     std::vector<uint32_t> Lread(n);
@@ -518,7 +531,7 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     lap("pass1");
     if (P.outSAMreadIDnumber && !fromMemory)           // --outSAMreadID Number: the read's 1-based index in the input (ReadAlignChunk_processChunks.cpp:117-119)
         for (uint64_t i = 0; i < n; i++) {
-            std::string nm = std::to_string(readsSoFar + i + 1);
+            std::string nm = std::to_string(b.firstReadIndex + i + 1);
             for (char c : P.readNameSeparator) { size_t q = nm.find(c); if (q != std::string::npos) nm.resize(q); }   // readLoad trims the number like any other name (readLoad.cpp:95-98)
             b.nameSpan[i] = TextSpan{(uint64_t)b.text[0].size(), (uint32_t)nm.size()};
             b.text[0].insert(b.text[0].end(), nm.begin(), nm.end());
@@ -551,7 +564,6 @@ bool FastqReader::nextBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
             else if (!lastExtra[m].empty()) { x = TextSpan{(uint64_t)b.text[m].size(), (uint32_t)lastExtra[m].size()}; b.text[m].insert(b.text[m].end(), lastExtra[m].begin(), lastExtra[m].end()); }
         }
     }
-    readsSoFar += n;
     return true;
 }
 

@@ -657,6 +657,22 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
     if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
     return (int)r->slots[slot].n;
 }
+int sah_fill_slot(void *h, int slot, uint64_t maxReads) {
+    Runner *r = (Runner *)h;
+    std::string err;
+    bool ok = r->reader.fillBatch(r->slots[slot], r->P, maxReads, err);
+    if (!err.empty()) { std::lock_guard<std::mutex> l(r->errM); r->parseError = err; return -1; }
+    return ok ? (int)r->slots[slot].n : 0;
+}
+int sah_convert_slot(void *h, int slot, staramd_batch *out) {
+    Runner *r = (Runner *)h;
+    std::string err;
+    bool ok = r->reader.convertBatch(r->slots[slot], r->P, err);
+    if (!ok || !err.empty()) { std::lock_guard<std::mutex> l(r->errM); r->parseError = err.empty() ? "convertBatch failed" : err; return -1; }
+    if (out) *out = r->slots[slot].view();
+    if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
+    return (int)r->slots[slot].n;
+}
 int sah_emit_slot(void *h, int slot, const staramd_results *res) { Runner *r = (Runner *)h; return r->emitBatch(r->slots[slot], res, nullptr, nullptr, r->P.wasp ? &r->waspSlots[slot] : nullptr) ? 0 : -1; }
 int sah_threads(void *h) { return ((Runner *)h)->P.runThreadN; }
 // 2-pass mapping: sah_in_pass1() is 1 after sah_create when --twopassMode Basic was given; map all batches, call sah_pass1_end()
