@@ -651,9 +651,13 @@ VARIANTS = [
     ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
     ("seed_flat_6waves", {"STARAMD_SEED_FLAT": "2"}),
     ("seed_flat_4waves", {"STARAMD_SEED_FLAT": "3"}),
+    ("seed_read_4waves", {"STARAMD_SEED_FLAT": "4"}),
+    ("seed_read_6waves", {"STARAMD_SEED_FLAT": "5"}),
     ("lane_class_post_1", {"STARAMD_LANE_CLASS_POST": "1"}),
     ("lane_class_post_2", {"STARAMD_LANE_CLASS_POST": "2"}),
     ("lane_class_post_2_cap6", {"STARAMD_LANE_CLASS_POST": "2", "STARAMD_LANE_CLASS": "6"}),
+    # not a kernel: the same 2 M pairs as 1 + 1 batches of a million (the launches of a batch end in tails of a few wavefronts; per pair they weigh less in a larger batch)
+    ("batch_1M", {"_batch_reads": "1000000"}),
 ]
 
 
@@ -670,13 +674,23 @@ def variants_leg(args, idx, fq, run_dir, threads, base, log):
         if time.time() - T_START > args.budget_s:
             res[name] = {"skipped": "time budget"}; continue
         pre = os.path.join(run_dir, "var_")
+        total = (nb + w) * args.reads
+        breads = int(env.get("_batch_reads", args.reads))
+        wreads = w * args.reads if breads == args.reads else breads            # (a different batch size: one warm-up batch, the rest timed; the same reads in all)
         argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", pre, "--runThreadN", str(threads),
-                "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
+                "--gpuBatchReads", str(breads), "--benchWarmupReads", str(wreads), "--readMapNumber", str(total)]
         try:
-            e = dict(env); e["STARAMD_CONTEXTS_PER_GPU"] = "1"
-            rep, d = _cli_leg(argv, 2 * args.read_len + 1, e)
+            e = {k: v for k, v in env.items() if not k.startswith("_")}; e["STARAMD_CONTEXTS_PER_GPU"] = "1"
+            # in a child interpreter: a kernel that has never run on hardware may fault, and a GPU memory fault aborts the process it happens in
+            for f in ("Aligned.out.sam", "SJ.out.tab"):
+                if os.path.exists(pre + f):
+                    os.remove(pre + f)
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--variant-child", json.dumps([argv, 2 * args.read_len + 1, e])], timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if p.returncode != 0:
+                raise RuntimeError("child exit code %d: %s" % (p.returncode, p.stderr[-200:]))
+            d = json.loads(p.stdout.strip().splitlines()[-1])
             dig = sam_digest(pre + "Aligned.out.sam")
-            res[name] = {"env": env, "per_kernel_ms": d["per_kernel_ms"], "Mreads_s": d["Mreads_s"], "lane_items_per_pair": d["counters_per_pair"].get("nLaneItems"),
+            res[name] = {"env": env, "batch_pairs": breads, "per_kernel_ms": d["per_kernel_ms"], "Mreads_s": d["Mreads_s"], "lane_items_per_pair": d["counters_per_pair"].get("nLaneItems"),
                          "sam_multiset_identical_to_base": dig == base_dig, "sj_out_tab_identical_to_base": open(pre + "SJ.out.tab", "rb").read() == base_sj}
         except Exception as ex:
             res[name] = {"env": env, "error": repr(ex)[:300]}
@@ -800,6 +814,10 @@ def two_pass(args, idx, fq, run_dir, threads):
 if __name__ == "__main__":
     if sys.argv[1:2] == ["--make-reads"]:
         _make_reads_child(*json.loads(sys.argv[2]))
+    elif sys.argv[1:2] == ["--variant-child"]:
+        _argv, _lread, _env = json.loads(sys.argv[2])
+        _rep, _d = _cli_leg(_argv, _lread, _env)
+        print(json.dumps(_d))
     elif sys.argv[1:2] == ["--sam-digest"]:
         print("%d %d" % _sam_digest_child(sys.argv[2]))
     else:

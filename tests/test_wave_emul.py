@@ -89,6 +89,8 @@ FORCED = {
     # experimental kernels / knobs that are OFF by default until they have a hardware number (bench.py leg `variants` times them at the end of a round):
     "seed_flat": {"STARAMD_SEED_FLAT": "1"},                  # the seed search as a state machine around one load site (k_seed_flat.hip), 8 waves per SIMD
     "seed_flat_4waves": {"STARAMD_SEED_FLAT": "3"},           # ... with 128 VGPRs
+    "seed_read": {"STARAMD_SEED_FLAT": "4"},                  # the whole read as one state machine (k_seed_search_read4)
+    "seed_read_6waves": {"STARAMD_SEED_FLAT": "5"},
     "lane_class_post": {"STARAMD_LANE_CLASS_POST": "2"},      # light reads classed by their two-mate windows (k_window.hip): more of them go through the lane-per-read stitcher
     "lane_class_post_wide": {"STARAMD_LANE_CLASS_POST": "8", "STARAMD_LANE_CLASS": "7"},
 }
