@@ -63,6 +63,9 @@ int   sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out);
  * (returns the number of reads, 0 at the end of the input, < 0 on error); sah_convert_slot turns it into the numeric batch while sah_fill_slot already
  * reads the next one */
 int   sah_fill_slot(void *h, int slot, uint64_t maxReads);
+/* Memory for the numeric arrays of the batches (what staramd_map_batch copies to the device): pass staramd_pinned_alloc / staramd_pinned_free for page-locked
+ * memory.  Process-wide; call once before the first batch is parsed (before sah_create is simplest) and not again. */
+void  sah_set_batch_alloc(void *(*alloc)(uint64_t bytes), void (*release)(void *p));
 int   sah_convert_slot(void *h, int slot, staramd_batch *out);
 int   sah_merged_slot(void *h, int slot, staramd_batch *out);
 int   sah_wasp_slot(void *h, int slot, const staramd_results *res, staramd_batch *out);

@@ -101,6 +101,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     struct LoadLock { int fd = -1; void take() { if (const char *p = getenv("STARAMD_INDEX_LOAD_LOCK")) { fd = open(p, O_CREAT | O_RDWR, 0666); if (fd >= 0 && flock(fd, LOCK_EX) != 0) { close(fd); fd = -1; } } }
                       void drop() { if (fd >= 0) { flock(fd, LOCK_UN); close(fd); fd = -1; } } ~LoadLock() { drop(); } } loadLock;
     loadLock.take();
+    if (!getenv("STARAMD_PAGEABLE_BATCHES")) sah_set_batch_alloc(staramd_pinned_alloc, staramd_pinned_free);      // batch arrays in page-locked memory: the uploads are DMA transfers
     void *h = sah_create((int)flags.rest.size(), flags.rest.data(), err, sizeof(err));
     if (!h) { fprintf(stderr, "\n%s\n", err); return 104; }
     if (sah_tool_done(h)) { sah_destroy(h); return 0; }          // --runMode inputAlignmentsFromBAM: nothing to map

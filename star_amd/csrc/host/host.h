@@ -149,14 +149,32 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 typedef std::vector<char, NoInitAlloc<char>> TextBuf;
 
+// The numeric arrays of a batch are what staramd_map_batch copies to the device: with a caller that provides page-locked memory (sah_set_batch_alloc: the star_amd CLI
+// passes staramd_pinned_alloc / staramd_pinned_free) the copies are DMA transfers straight out of them instead of being staged through the runtime (SURVEY.md 8b:
+// "caller-owned pinned buffers").  The hooks are process-wide, set once before the first batch is allocated; without them: malloc.  Elements are left uninitialised by resize().
+extern void *(*g_batchAllocFn)(uint64_t bytes);
+extern void (*g_batchFreeFn)(void *p);
+template <class T> struct BatchAlloc {
+    typedef T value_type;
+    template <class U> struct rebind { typedef BatchAlloc<U> other; };
+    BatchAlloc() = default;
+    template <class U> BatchAlloc(const BatchAlloc<U> &) {}
+    T *allocate(size_t n) { void *p = g_batchAllocFn ? g_batchAllocFn((uint64_t)n * sizeof(T)) : malloc(n * sizeof(T) ? n * sizeof(T) : 1); if (!p) throw std::bad_alloc(); return (T *)p; }
+    void deallocate(T *p, size_t) { if (g_batchFreeFn) g_batchFreeFn(p); else free(p); }
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const BatchAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const BatchAlloc<U> &) const { return false; }
+};
+
 
 // ---- one batch of reads in the layout of staramd_batch + the text needed for SAM ----
 struct TextSpan { uint64_t off; uint32_t len; };
 struct ReadBatch {
     uint32_t n = 0;
-    std::vector<uint8_t, NoInitAlloc<uint8_t>> bases;   // combined numeric reads (every byte is written by the parser: no zero fill on resize)
-    std::vector<uint64_t> readOffset;     // n+1
-    std::vector<uint16_t> mate1Length, mmMaxTotal;
+    std::vector<uint8_t, BatchAlloc<uint8_t>> bases;    // combined numeric reads (every byte is written by the parser: no zero fill on resize)
+    std::vector<uint64_t, BatchAlloc<uint64_t>> readOffset;     // n+1
+    std::vector<uint16_t, BatchAlloc<uint16_t>> mate1Length, mmMaxTotal;
     TextBuf text[2];                      // the FASTQ text of the batch as read from each mate file; the spans below point into it
     std::vector<TextSpan> nameSpan;       // read ID without '@', trimmed at readNameSeparator (from mate 1's ID line)
     std::vector<TextSpan> seqSpan[2], qualSpan[2];

@@ -21,6 +21,9 @@
 
 namespace staramd {
 
+void *(*g_batchAllocFn)(uint64_t bytes) = nullptr;
+void (*g_batchFreeFn)(void *p) = nullptr;
+
 staramd_batch ReadBatch::view() const {
     staramd_batch b;
     b.nReads = n; b.bases = bases.data(); b.readOffset = readOffset.data();

@@ -657,6 +657,8 @@ int sah_parse_slot(void *h, int slot, uint64_t maxReads, staramd_batch *out) {
     if (r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) r->mergedSlots[slot].build(r->slots[slot], r->P);
     return (int)r->slots[slot].n;
 }
+// page-locked (or any other) memory for the numeric arrays of the batches; call once, before the first batch is parsed and never with batches alive
+void sah_set_batch_alloc(void *(*alloc)(uint64_t), void (*release)(void *)) { staramd::g_batchAllocFn = alloc; staramd::g_batchFreeFn = release; }
 int sah_fill_slot(void *h, int slot, uint64_t maxReads) {
     Runner *r = (Runner *)h;
     std::string err;
