@@ -63,13 +63,26 @@ struct Runner {
     std::mt19937 rngMultOrder; std::uniform_real_distribution<double> rngUniformReal0to1{0.0, 1.0};   // ReadAlign.cpp:11-12 (one stream: iChunk 0)
     std::vector<std::string> coordChunks; std::vector<BamKey> coordKeys;     // --outSAMtype BAM SortedByCoordinate: every record, until finish()
     int wireTable = 0;                                // which junction table sah_sj_export / import / clear address: 0 = sj, 1 = sj1
-    OutSJ &wire() { return wireTable == 1 ? sj1 : sj; }
+    OutSJ &wire() { if (wireTable != 1) sjBg.drainInto(sj); return wireTable == 1 ? sj1 : sj; }
+    // The output junction table grows by one record per junction per read.  Whenever it passes sjKick records it is handed to a thread that collapses it and folds it
+    // into what was collapsed before (collapse is a sum / maximum per junction: the order does not matter), so that what is left to sort when the run ends
+    // (finish() is inside the timed region of a run; SJ.out.tab needs the collapsed table) is less than sjKick records + the last batch, not everything since the
+    // last 4 M-record collapse (ReadAlignChunk_mapChunk.cpp:66-86 collapses when the chunk's buffer is full, for bounded memory; this does the same, off the path)
+    struct SjBackground {
+        OutSJ folded, work; std::thread th;
+        void join() { if (th.joinable()) th.join(); }
+        void kick(OutSJ &live) { join(); work.data.swap(live.data); th = std::thread([this] { work.collapse(); folded.mergeFrom(work); work.data.clear(); folded.collapse(); }); }
+        void drainInto(OutSJ &live) { join(); if (!folded.data.empty()) { live.mergeFrom(folded); folded.data.clear(); } }
+        ~SjBackground() { join(); }
+    } sjBg;
+    size_t sjKick = 1000000;
     int64_t readMapNumberUser = -1;
 
     bool init(int argc, char **argv) {
         time(&stats.timeStart);
         error = P.parse(argc, argv);
         if (!error.empty()) return false;
+        if (const char *e = getenv("STARAMD_SJ_KICK")) sjKick = (size_t)strtoull(e, nullptr, 10);      // (tests: a few hundred records, so that the background collapse runs on small data)
         {   // createDirectory (streamFuns.cpp:10-35): the directory part of --outFileNamePrefix is made, with its parents, mode S_IRWXU
             const std::string dirPath = P.outFileNamePrefix.substr(0, P.outFileNamePrefix.find_last_of('/') + 1);
             if (!dirPath.empty() && mkdir(dirPath.c_str(), S_IRWXU) == -1 && errno != EEXIST) {
@@ -425,7 +438,7 @@ struct Runner {
         }
         if (waspType && !waspType->empty()) post->waspCarry = waspEndOfBatch;
         if (writerFailed) { error = "EXITING because of fatal ERROR: could not write Aligned.out.sam"; return false; }
-        if (sj.data.size() > 4000000) sj.collapse();     // ReadAlignChunk_mapChunk.cpp:66-86 (bounded memory)
+        if (sj.data.size() > sjKick) sjBg.kick(sj);      // (bounded memory: ReadAlignChunk_mapChunk.cpp:66-86)
         if (hostTiming) fprintf(stderr, "  emit: before the threads %.2f ms, threads %.2f ms, tail %.2f ms\n", std::chrono::duration<double, std::milli>(te1 - te0).count() + msBefore, std::chrono::duration<double, std::milli>(te2 - te1).count() - msBefore,
                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te2).count());
         return true;
@@ -478,6 +491,7 @@ struct Runner {
     // junctions into the index, reads rewound.  The caller then re-uploads the index (staramd_update_index).
     bool endPass1() {
         if (!pass1) { error = "not in the 1st pass"; return false; }
+        sjBg.drainInto(sj);
         error = sj.filterAndWrite(P, gi, P.twopassDir + "SJ.out.tab");
         if (!error.empty()) return false;
         stats.reportFinal(P.twopassDir + "Log.final.out");
@@ -517,6 +531,7 @@ struct Runner {
         // it is produced on a thread of its own while the writer drains (outputSJ.cpp:84,129; STAR.cpp:251)
         std::string sjError;
         std::thread sjThread;
+        sjBg.drainInto(sj);
         if (!P.outSJnone) sjThread = std::thread([&] { sjError = sj.filterAndWrite(P, gi, P.outFileNamePrefix + "SJ.out.tab", bySJoutStage == 2); });
         struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } joinSj{sjThread};
         stopWriter();

@@ -90,6 +90,13 @@ def test_cli_pipeline_sliced_input(batch, tmp_path, built):
     run_cli_case(CLI, "pe101", ["--outSAMunmapped", "Within"], batch, tmp_path, env={"STARAMD_READ_SLICE_MIN": "1"})
 
 
+@pytest.mark.parametrize("kick", ["50", "700"])
+def test_cli_pipeline_background_junction_collapse(kick, tmp_path, built):
+    """the junction table is collapsed on a thread of its own whenever it passes a threshold (runner.cpp SjBackground); the threshold is lowered so that it happens
+    after (almost) every batch of these small inputs, in both passes of a 2-pass run: SJ.out.tab of both passes and everything else still equal to the reference's"""
+    run_cli_case(CLI, "pe101", ["--twopassMode", "Basic", "--outSAMunmapped", "Within"], 200, tmp_path, env={"STARAMD_SJ_KICK": kick})
+
+
 CHIM_WASP = ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--chimOutType", "WithinBAM", "--outSAMtype", "BAM", "Unsorted",
              "--waspOutputMode", "SAMtag", "--varVCFfile", "VCF", "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG", "vW"]
 
