@@ -630,7 +630,7 @@ def _cli_leg(argv, lread, env=None):
     return rep, {"Mreads_s": n / float(rep.timedWall) / 1e6, "per_kernel_ms": ms, "timed_reads": n,
                  "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                  "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
-                 "device_Mreads_s": n / (sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nContexts)))) / 1e3) / 1e6,
+                 "device_Mreads_s": n / max(1e-9, sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nContexts)))) / 1e3) / 1e6,
                  "engine_contexts": int(rep.nContexts), "counters_per_pair": {k: v / n for k, v in c.items() if not isinstance(v, dict)}}
 
 

@@ -378,7 +378,7 @@ def run_cli(argv, warmup_done=None, exchange=None, lib_path=None):
     """The whole front end (star_amd/csrc/host/cli_run.cpp) in this process: argv as on the command line; warmup_done() is called when the
     --benchWarmupReads reads are written and the pipeline is empty; exchange(handle, last) at the end of every mapping phase (cross-rank tables).
     Returns (exit code, CliReport)."""
-    lib = C.CDLL(lib_path or _need(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstaramd_cli.so")))
+    lib = C.CDLL(lib_path or os.environ.get("STARAMD_CLI_LIB") or _need(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstaramd_cli.so")))      # (STARAMD_CLI_LIB: tests of bench.py's plumbing on a box without a GPU)
     lib.staramd_cli_main.restype = C.c_int
     lib.staramd_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(CliHooks), C.POINTER(CliReport)]
     args = [b"star_amd"] + [a.encode() for a in argv]
