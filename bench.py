@@ -543,7 +543,9 @@ def main():
         "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s_sum_over_contexts": device_s,
                      "device_s_note": "HIP-event time of the batches summed over the engine contexts of the GPU: with two contexts their launches overlap, so the sum exceeds the wall time; "
                                       "kernel_ms_exclusive has the one-context figures",
-                     "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(n_ctx)), "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)), "parse_busy_s": float(rep.parseBusy), "postmap_write_busy_s": float(rep.emitBusy),
+                     "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(n_ctx)), "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)), "parse_busy_s": float(rep.parseBusy), "convert_busy_s": float(rep.convertBusy), "postmap_write_busy_s": float(rep.emitBusy),
+                     "reader_note": "the reader is two pipeline stages on two threads: parse_* = input + line table (sah_fill_slot), convert_* = text -> numeric batch (sah_convert_slot)",
+                     "convert_Mreads_s": n / float(rep.convertBusy) / 1e6 if rep.convertBusy > 0 else None,
                      "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                      "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                      "finish_s": float(rep.finishSeconds),
@@ -629,6 +631,7 @@ def _cli_leg(argv, lread, env=None):
     n = max(int(rep.timedReads), 1)
     return rep, {"Mreads_s": n / float(rep.timedWall) / 1e6, "per_kernel_ms": ms, "timed_reads": n,
                  "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
+                 "convert_Mreads_s": n / float(rep.convertBusy) / 1e6 if rep.convertBusy > 0 else None,
                  "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                  "device_Mreads_s": n / max(1e-9, sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nContexts)))) / 1e3) / 1e6,
                  "engine_contexts": int(rep.nContexts), "counters_per_pair": {k: v / n for k, v in c.items() if not isinstance(v, dict)}}

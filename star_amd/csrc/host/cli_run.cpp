@@ -157,11 +157,12 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     if (!getenv("STARAMD_SJDB_HOST") && !getenv("STARAMD_SJDB_NO_RESIDENT")) {
         sah_set_sjdb_resident_fn([](void *user, const staramd_sjdb_args *a, staramd_sjdb_result *res) -> int {
             std::vector<staramd_ctx *> &cx = *((ResidentUser *)user)->ctx;
-            std::vector<int> rcs(cx.size(), 0); std::vector<staramd_sjdb_result> rs(cx.size());
+            std::vector<int> rcs(cx.size(), 0); std::vector<staramd_sjdb_result> rs(cx.size()); std::vector<std::string> es(cx.size());
             std::vector<std::thread> th;
-            for (size_t d = 0; d < cx.size(); d++) th.emplace_back([&, d] { rcs[d] = staramd_insert_junctions(cx[d], a, d == 0 ? a->SAout : nullptr, a->saOutCapacity, d == 0 ? a->SAiOut : nullptr, a->saiOutCapacity, &rs[d]); });
+            // (the engine keeps its last error per calling thread: the text is taken on the thread that made the call)
+            for (size_t d = 0; d < cx.size(); d++) th.emplace_back([&, d] { rcs[d] = staramd_insert_junctions(cx[d], a, d == 0 ? a->SAout : nullptr, a->saOutCapacity, d == 0 ? a->SAiOut : nullptr, a->saiOutCapacity, &rs[d]); if (rcs[d]) es[d] = staramd_last_error(); });
             for (auto &t : th) t.join();
-            for (size_t d = 0; d < cx.size(); d++) if (rcs[d]) { fprintf(stderr, "star_amd: junction insertion on device context %zu failed: %s\n", d, staramd_last_error()); return rcs[d]; }
+            for (size_t d = 0; d < cx.size(); d++) if (rcs[d]) { fprintf(stderr, "star_amd: junction insertion on device context %zu failed: %s\n", d, es[d].c_str()); return rcs[d]; }
             *res = rs[0];
             return 0;
         }, &residentUser);
