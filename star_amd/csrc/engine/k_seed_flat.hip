@@ -46,6 +46,7 @@ enum { PH_DONE = 0, PH_SINGLE, PH_L1, PH_L2, PH_MAIN, PH_F1, PH_F2 };
 #ifdef STARAMD_WAVE_EMUL
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 struct SeedTrace { FILE *f; u32 ir, piece, dir, start, step; SeedTrace() : f(getenv("STARAMD_SEED_TRACE") ? fopen(getenv("STARAMD_SEED_TRACE"), "w") : nullptr), ir(0), piece(0), dir(0), start(0), step(0) {} ~SeedTrace() { if (f) fclose(f); } };
 static SeedTrace g_seedTrace;
 #define SEED_TRACE(...) do { if (g_seedTrace.f) fprintf(g_seedTrace.f, __VA_ARGS__); } while (0)
@@ -354,8 +355,24 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
     u32 ph = PH_DONE, cL = 0, i1 = 0, i2 = 0; u64 base = 0;
     u32 L1 = 0, L2 = 0, L3 = 0, L1a = 0, L1b = 0, L2a = 0, L2b = 0, i3 = 0, i1a = 0, i1b = 0, i2a = 0, i2b = 0;
     u32 cI = 0, ii = 0; bool haveSA = false, dirG = true, compRes = false; u64 gAddr = 0;
+#ifdef STARAMD_WAVE_EMUL
+    // STARAMD_SEED_TRACE (emulated builds): one line per read, "M <read> <one letter per trip>": which blocks of the loop the lane went through in the trip
+    // (bit 0 TICKET, 1 SCHED, 2 the load site, 3 POST, as 'A' + bits) -- tools/seed_divergence.py --trips: how often a WAVEFRONT executes each block
+    std::string tripLog;
+#endif
     while (mode != M_EXIT) {
+#ifdef STARAMD_WAVE_EMUL
+        const u32 tripBits = (mode == M_TICKET ? 1u : 0u);
+        u32 tb = tripBits;
+        struct TripEnd { std::string &s; u32 &b; ~TripEnd() { if (g_seedTrace.f) s.push_back((char)('A' + b)); } } tripEnd{tripLog, tb};
+#define TRIP_MARK(bit) (tb |= (bit))
+#else
+#define TRIP_MARK(bit) ((void)0)
+#endif
         if (mode == M_TICKET) {
+#ifdef STARAMD_WAVE_EMUL
+            if (g_seedTrace.f && !tripLog.empty()) { fprintf(g_seedTrace.f, "M %u %s\n", ir, tripLog.c_str()); tripLog.clear(); }     // (one line per READ: the emulator runs the lanes one after the other, lane 0 takes every ticket)
+#endif
             ir = atomicAdd(&B.cursors[CUR_TICKET_SEED], 1u);
             if (ir >= B.nReads) { mode = M_EXIT; continue; }
             R = B.bases + B.readOffset[ir];
@@ -366,6 +383,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             mode = M_SCHED;
         }
         if (mode == M_SCHED) {
+            TRIP_MARK(2u);
             for (;;) {
                 if (!pieceActive) {
                     // qualitySplit (SequenceFuns.cpp:411-444): the next piece, or the end of the read
@@ -438,6 +456,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
         }
         const bool dirR = iDir == 0;
         if (mode == M_SETUP || mode == M_SAI1 || mode == M_SAI2 || mode == M_CMP) {
+            TRIP_MARK(4u);
             if (mode == M_SETUP) {                               // a search begins (one start offset of maxMappableLength2strands)
                 const u32 iDist = it >= nD ? it - nD : it;
                 pieceLength = seedLength - iDist;
@@ -573,6 +592,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             }
         }
         if (mode == M_POST) {
+            TRIP_MARK(8u);
             // one start offset of maxMappableLength2strands is searched (ReadAlign_maxMappableLength2strands.cpp:77-109)
             const u32 phase = it >= nD ? 1u : 0u, iDist = phase ? it - nD : it;
             bool more = true;
@@ -595,6 +615,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             }
         }
     }
+
     atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)cn.nSAi);
     atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)cn.nSAprobe);
     atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);

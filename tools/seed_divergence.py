@@ -3,6 +3,7 @@
 
   STARAMD_SEED_FLAT=1 STARAMD_SEED_TRACE=trace.txt  <an emulated run: tests/emul_run.py ...>      (k_seed_flat.hip logs every search of every read)
   python tools/seed_divergence.py trace.txt
+  python tools/seed_divergence.py trace.txt --trips      (trace of STARAMD_SEED_FLAT=4: how often a wavefront executes each block of the whole-read state machine)
 
 A read is a lane; 64 consecutive reads are a wavefront (the ticket order of the kernel).  Unit of cost: one dependent load round trip of a lane
 (a SAindex look-up, a suffix-array probe, one 8-base compare step).  A wavefront pays for a loop as many trips as its slowest lane makes, level by level:
@@ -17,12 +18,48 @@ import sys
 from collections import defaultdict
 
 
+def trips(path):
+    """whole-read state machine (k_seed_search_read*): 'M <read> <letters>' lines = the blocks of the loop a lane went through for that read, trip by trip.  A lane
+    is taken to map one read (a launch has about as many lanes as a batch has reads), 64 consecutive reads are a wavefront.  A wavefront executes a block in a
+    trip if ANY of its lanes does; it makes as many trips as its longest lane."""
+    lanes = {}
+    for line in open(path):
+        if line.startswith("M "):
+            t = line.split()
+            lanes[int(t[1])] = [ord(c) - 65 for c in (t[2] if len(t) > 2 else "")]
+    ids = sorted(lanes)
+    names = ((1, "TICKET"), (2, "SCHED"), (4, "load site"), (8, "POST"))
+    tot = {b: 0 for b, _ in names}; lane_tot = {b: 0 for b, _ in names}; trips_w = 0; trips_l = 0; nw = 0; reads = 0
+    for w0 in range(0, len(ids) - 63, 64):
+        ws = [lanes[i] for i in ids[w0:w0 + 64]]
+        nw += 1
+        T = max(len(x) for x in ws); trips_w += T; trips_l += sum(len(x) for x in ws) / 64.0
+        for t in range(T):
+            u = 0
+            for x in ws:
+                if t < len(x):
+                    u |= x[t]
+                    for b, _ in names:
+                        if x[t] & b:
+                            lane_tot[b] += 1
+            for b, _ in names:
+                if u & b:
+                    tot[b] += 1
+    print("%d wavefronts; trips per wavefront %.0f (mean lane %.0f)" % (nw, trips_w / nw, trips_l / nw))
+    for b, nm in names:
+        print("  %-10s executed by the wavefront in %5.1f %% of its trips; a lane is in it in %5.1f %% of its own" % (nm, 100.0 * tot[b] / trips_w, 100.0 * lane_tot[b] / 64.0 / trips_l))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "--trips":
+        return trips(sys.argv[1])
     path = sys.argv[1]
     reads = defaultdict(list)          # ir -> list of searches: (key, nSAi, [(phase, words)])
     cur = None
     for line in open(path):
         t = line.split()
+        if t[0] == "M":
+            continue
         if t[0] == "S":
             ir = int(t[1]); key = tuple(int(x) for x in t[2:7])
             cur = [key, 0, []]
@@ -32,6 +69,8 @@ def main():
         else:
             cur[2].append((int(t[1]), int(t[2])))
     irs = sorted(reads)
+    if not irs:
+        sys.exit("no search records in the trace (STARAMD_SEED_FLAT=1 logs them; a whole-read trace has trip lines only: --trips)")
     n_waves = 0; tot = defaultdict(float)
     for w0 in range(0, len(irs), 64):
         lanes = irs[w0:w0 + 64]
