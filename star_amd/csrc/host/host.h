@@ -159,7 +159,7 @@ template <class T> struct BatchAlloc {
     template <class U> struct rebind { typedef BatchAlloc<U> other; };
     BatchAlloc() = default;
     template <class U> BatchAlloc(const BatchAlloc<U> &) {}
-    T *allocate(size_t n) { void *p = g_batchAllocFn ? g_batchAllocFn((uint64_t)n * sizeof(T)) : malloc(n * sizeof(T) ? n * sizeof(T) : 1); if (!p) throw std::bad_alloc(); return (T *)p; }
+    T *allocate(size_t n) { const size_t bytes = n > 0 ? n * sizeof(T) : 1; void *p = g_batchAllocFn ? g_batchAllocFn((uint64_t)bytes) : malloc(bytes); if (!p) throw std::bad_alloc(); return (T *)p; }
     void deallocate(T *p, size_t) { if (g_batchFreeFn) g_batchFreeFn(p); else free(p); }
     template <class U> void construct(U *p) { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }

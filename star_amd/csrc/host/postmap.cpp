@@ -9,6 +9,7 @@
 #include "host.h"
 #include <fstream>
 #include <cstring>
+#include <immintrin.h>
 #include <algorithm>
 
 namespace staramd {
@@ -80,6 +81,35 @@ inline char *putInt(char *p, int64_t v) { if (v < 0) { *p++ = '-'; return putUin
 inline char *putStr(char *p, const char *s, size_t n) { memcpy(p, s, n); return p + n; }
 inline char *putSv(char *p, std::string_view s) { memcpy(p, s.data(), s.size()); return p + s.size(); }
 template <size_t N> inline char *putLit(char *p, const char (&s)[N]) { memcpy(p, s, N - 1); return p + (N - 1); }
+// dst[k] = src[n - 1 - k] (qualities of a reverse-strand mate) and dst[k] = complement of src[n - 1 - k] (its bases), 32 characters per step when the CPU has AVX2.
+// The complement of a chunk that holds nothing but A C G T N (upper case: what a sequencer writes) is one table look-up on the low four bits of the character
+// code (0x41 0x43 0x47 0x54 0x4E: 1 3 7 4 E); any other character in the chunk sends that chunk through the byte table (IUPAC codes, lower case)
+__attribute__((target("avx2"))) static inline __m256i rev32(__m256i c) {
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    const __m256i x = _mm256_shuffle_epi8(c, rev);
+    return _mm256_permute2x128_si256(x, x, 1);
+}
+__attribute__((target("avx2"))) static void revCopyAvx2(char *dst, const char *src, size_t n) {
+    size_t k = 0;
+    for (; k + 32 <= n; k += 32) _mm256_storeu_si256((__m256i *)(dst + k), rev32(_mm256_loadu_si256((const __m256i *)(src + n - 32 - k))));
+    for (; k < n; k++) dst[k] = src[n - 1 - k];
+}
+__attribute__((target("avx2"))) static void revCompCopyAvx2(char *dst, const char *src, size_t n) {
+    const __m256i orig = _mm256_setr_epi8(0, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 'N', 0, 0, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 'N', 0);
+    const __m256i comp = _mm256_setr_epi8(0, 'T', 0, 'G', 'A', 0, 0, 'C', 0, 0, 0, 0, 0, 0, 'N', 0, 0, 'T', 0, 'G', 'A', 0, 0, 'C', 0, 0, 0, 0, 0, 0, 'N', 0);
+    size_t k = 0;
+    for (; k + 32 <= n; k += 32) {
+        const __m256i c = rev32(_mm256_loadu_si256((const __m256i *)(src + n - 32 - k)));
+        const __m256i nib = _mm256_and_si256(c, _mm256_set1_epi8(0x0F));
+        const __m256i ok = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(orig, nib), c);          // (a character code with bit 7 set never equals a table entry)
+        if (_mm256_movemask_epi8(ok) == -1) _mm256_storeu_si256((__m256i *)(dst + k), _mm256_shuffle_epi8(comp, nib));
+        else for (size_t j = 0; j < 32; j++) dst[k + j] = RCT.t[(uint8_t)src[n - 1 - k - j]];
+    }
+    for (; k < n; k++) dst[k] = RCT.t[(uint8_t)src[n - 1 - k]];
+}
+static const bool HAVE_AVX2 = __builtin_cpu_supports("avx2") && !getenv("STARAMD_NO_AVX2");
+inline void revCopy(char *dst, const char *src, size_t n) { if (HAVE_AVX2) revCopyAvx2(dst, src, n); else for (size_t k = 0; k < n; k++) dst[k] = src[n - 1 - k]; }
+inline void revCompCopy(char *dst, const char *src, size_t n) { if (HAVE_AVX2) revCompCopyAvx2(dst, src, n); else for (size_t k = 0; k < n; k++) dst[k] = RCT.t[(uint8_t)src[n - 1 - k]]; }
 enum SamAttr : uint8_t { A_NH, A_HI, A_AS, A_nM, A_jM, A_jI, A_XS, A_NM, A_MD, A_MC, A_RG, A_OTHER };
 inline SamAttr samAttrCode(const std::string &a) {
     static const char *names[] = {"NH", "HI", "AS", "nM", "jM", "jI", "XS", "NM", "MD", "MC", "RG"};
@@ -212,10 +242,10 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         const bool noQS = P.outSAMmodeNoQS || b.fasta;           // readFileType==2 ? Qual : "*" (ReadAlign_outputTranscriptSAM.cpp:215)
         if (Mate == Str) { p = putSv(p, sq); *p++ = '\t'; if (!noQS) p = putSv(p, ql); else *p++ = '*'; }
         else {
-            const size_t n = sq.size(); const char *sp = sq.data() + n, *qp = ql.data() + n;
-            for (size_t k = 0; k < n; k++) p[k] = RCT.t[(uint8_t)*--sp];
+            const size_t n = sq.size();
+            revCompCopy(p, sq.data(), n);
             p += n; *p++ = '\t';
-            if (!noQS) { for (size_t k = 0; k < n; k++) p[k] = *--qp; p += n; } else *p++ = '*';
+            if (!noQS) { revCopy(p, ql.data(), n); p += n; } else *p++ = '*';
         }
         for (uint32_t k = 0; k < nAttr; k++) {
             switch (attr[k]) {

@@ -371,6 +371,33 @@ struct NtTable {               // convertNucleotidesToNumbers (SequenceFuns.cpp:
 };
 static const NtTable NT;
 
+// the same two conversions 32 bases per step: a base is A/C/G/T in either case or it is code 4; (c | 0x20) folds the cases, four compares pick the code
+// (exactly one can match): 4 ^ (eqA & 4 | eqC & 5 | eqG & 6 | eqT & 7) = 0 / 1 / 2 / 3, else 4; the complement has the constants 7 / 6 / 5 / 4
+__attribute__((target("avx2"))) static inline __m256i ntCodes32(__m256i c, bool comp) {
+    const __m256i lower = _mm256_or_si256(c, _mm256_set1_epi8(0x20));
+    const __m256i eA = _mm256_cmpeq_epi8(lower, _mm256_set1_epi8('a')), eC = _mm256_cmpeq_epi8(lower, _mm256_set1_epi8('c'));
+    const __m256i eG = _mm256_cmpeq_epi8(lower, _mm256_set1_epi8('g')), eT = _mm256_cmpeq_epi8(lower, _mm256_set1_epi8('t'));
+    const __m256i m = _mm256_or_si256(_mm256_or_si256(_mm256_and_si256(eA, _mm256_set1_epi8(comp ? 7 : 4)), _mm256_and_si256(eC, _mm256_set1_epi8(comp ? 6 : 5))),
+                                      _mm256_or_si256(_mm256_and_si256(eG, _mm256_set1_epi8(comp ? 5 : 6)), _mm256_and_si256(eT, _mm256_set1_epi8(comp ? 4 : 7))));
+    return _mm256_xor_si256(m, _mm256_set1_epi8(4));
+}
+__attribute__((target("avx2"))) static void ntForwardAvx2(const char *s, uint8_t *r, uint64_t n) {
+    uint64_t k = 0;
+    for (; k + 32 <= n; k += 32) _mm256_storeu_si256((__m256i *)(r + k), ntCodes32(_mm256_loadu_si256((const __m256i *)(s + k)), false));
+    for (; k < n; k++) r[k] = NT.fwd[(uint8_t)s[k]];
+}
+// r[k] = complement code of s[n - 1 - k]
+__attribute__((target("avx2"))) static void ntRevCompAvx2(const char *s, uint8_t *r, uint64_t n) {
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    uint64_t k = 0;
+    for (; k + 32 <= n; k += 32) {
+        __m256i c = _mm256_loadu_si256((const __m256i *)(s + n - 32 - k));
+        c = _mm256_permute2x128_si256(_mm256_shuffle_epi8(c, rev), _mm256_shuffle_epi8(c, rev), 1);      // bytes reversed within the halves, halves swapped
+        _mm256_storeu_si256((__m256i *)(r + k), ntCodes32(c, true));
+    }
+    for (; k < n; k++) r[k] = NT.rc[(uint8_t)s[n - 1 - k]];
+}
+
 bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err) {
     b.clear();
     b.firstReadIndex = readsSoFar;
@@ -543,17 +570,18 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
     b.bases.resize(b.readOffset[n]);
     lap("prefix");
     // pass 2: numeric combined reads
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("STARAMD_NO_AVX2");
     inRanges([&](uint64_t lo, uint64_t hi, int) {
         for (uint64_t i = lo; i < hi; i++) {
             uint8_t *r = b.bases.data() + b.readOffset[i];
             const char *s0 = b.text[0].data() + b.seqSpan[0][i].off + b.clipped(0, 0, (uint32_t)i);
             uint64_t len0 = b.mate1Length[i];
-            for (uint64_t k = 0; k < len0; k++) r[k] = NT.fwd[(uint8_t)s0[k]];
+            if (avx2) ntForwardAvx2(s0, r, len0); else for (uint64_t k = 0; k < len0; k++) r[k] = NT.fwd[(uint8_t)s0[k]];
             if (nMates == 2) {
                 const char *s1 = b.text[1].data() + b.seqSpan[1][i].off + b.clipped(1, 0, (uint32_t)i);
                 uint64_t len1 = Lread[i] - len0 - 1;
                 r[len0] = STARAMD_SPACER_BASE;
-                for (uint64_t k = 0; k < len1; k++) r[len0 + 1 + k] = NT.rc[(uint8_t)s1[len1 - 1 - k]];
+                if (avx2) ntRevCompAvx2(s1, r + len0 + 1, len1); else for (uint64_t k = 0; k < len1; k++) r[len0 + 1 + k] = NT.rc[(uint8_t)s1[len1 - 1 - k]];
             }
         }
     });
