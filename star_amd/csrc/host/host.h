@@ -154,13 +154,15 @@ typedef std::vector<char, NoInitAlloc<char>> TextBuf;
 // "caller-owned pinned buffers").  The hooks are process-wide, set once before the first batch is allocated; without them: malloc.  Elements are left uninitialised by resize().
 extern void *(*g_batchAllocFn)(uint64_t bytes);
 extern void (*g_batchFreeFn)(void *p);
+void *batchAllocate(size_t bytes);       // through the hook; ordinary memory when there is no hook or the hook has none left (reads.cpp)
+void batchRelease(void *p);
 template <class T> struct BatchAlloc {
     typedef T value_type;
     template <class U> struct rebind { typedef BatchAlloc<U> other; };
     BatchAlloc() = default;
     template <class U> BatchAlloc(const BatchAlloc<U> &) {}
-    T *allocate(size_t n) { const size_t bytes = n > 0 ? n * sizeof(T) : 1; void *p = g_batchAllocFn ? g_batchAllocFn((uint64_t)bytes) : malloc(bytes); if (!p) throw std::bad_alloc(); return (T *)p; }
-    void deallocate(T *p, size_t) { if (g_batchFreeFn) g_batchFreeFn(p); else free(p); }
+    T *allocate(size_t n) { void *p = batchAllocate(n > 0 ? n * sizeof(T) : 1); if (!p) throw std::bad_alloc(); return (T *)p; }
+    void deallocate(T *p, size_t) { batchRelease(p); }
     template <class U> void construct(U *p) { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
     template <class U> bool operator==(const BatchAlloc<U> &) const { return true; }

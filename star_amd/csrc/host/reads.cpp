@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <mutex>
 #include <functional>
 #include <immintrin.h>
 #include <chrono>
@@ -23,6 +24,22 @@ namespace staramd {
 
 void *(*g_batchAllocFn)(uint64_t bytes) = nullptr;
 void (*g_batchFreeFn)(void *p) = nullptr;
+// blocks that came from malloc although a hook is set (the hook returned nothing: page-locked memory can run out; or they were allocated before the hook was set)
+static std::mutex g_plainM; static std::vector<void *> g_plain; static std::atomic<size_t> g_plainN{0};
+void *batchAllocate(size_t bytes) {
+    if (g_batchAllocFn) { if (void *p = g_batchAllocFn((uint64_t)bytes)) return p; }
+    void *p = malloc(bytes);
+    if (p) { std::lock_guard<std::mutex> l(g_plainM); g_plain.push_back(p); g_plainN++; }
+    return p;
+}
+void batchRelease(void *p) {
+    if (!p) return;
+    if (g_plainN.load() > 0) {
+        std::lock_guard<std::mutex> l(g_plainM);
+        for (size_t i = 0; i < g_plain.size(); i++) if (g_plain[i] == p) { g_plain[i] = g_plain.back(); g_plain.pop_back(); g_plainN--; free(p); return; }
+    }
+    if (g_batchFreeFn) g_batchFreeFn(p); else free(p);
+}
 
 staramd_batch ReadBatch::view() const {
     staramd_batch b;
