@@ -156,6 +156,9 @@ FORCED = {
 }
 
 
+_EXPERIMENTAL_TIMED_OUT = []      # experimental cases that hit their time limit (a kernel that hangs on hardware must not cost the suite eight time limits)
+
+
 @pytest.mark.parametrize("case", sorted(FORCED))
 def test_forced_rare_paths(case, tmp_path, built):
     import os, subprocess, sys
@@ -164,12 +167,16 @@ def test_forced_rare_paths(case, tmp_path, built):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ); env.update(FORCED[case])
     experimental = "STARAMD_SEED_FLAT" in FORCED[case] or "STARAMD_LANE_CLASS_POST" in FORCED[case]
+    if experimental and _EXPERIMENTAL_TIMED_OUT:
+        pytest.xfail("experimental, off by default: skipped after an earlier experimental case ran into its time limit")
     try:
-        p = subprocess.run([sys.executable, os.path.join(here, "engine_run.py"), "pe150_indel", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        p = subprocess.run([sys.executable, os.path.join(here, "engine_run.py"), "pe150_indel", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150 if experimental else 600)
         ok = p.returncode == 0 and (p.stdout.decode().strip().splitlines() or [""])[-1] == "OK"
         msg = (p.stdout.decode() + p.stderr.decode())[-2000:]
     except subprocess.TimeoutExpired:
         ok, msg = False, "timeout"
+        if experimental:
+            _EXPERIMENTAL_TIMED_OUT.append(case)
     if not ok and experimental:
         # kernels / knobs that are OFF by default and have never run on hardware (written without a GPU; emulator-checked): what they do on the device is recorded
         # here and by bench.py's `variants` leg, and does not decide whether the product's suite is green
