@@ -569,7 +569,6 @@ def main():
             out["full_size_parity"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_extra_legs:
         for name, fn in (("kernel_ms_exclusive", lambda: exclusive_leg(args, idx, fq, run_dir, threads)),
-                         ("variants", lambda: variants_leg(args, idx, fq, run_dir, threads, out.get("kernel_ms_exclusive") or {}, log)),
                          ("host_budget", lambda: host_budget_leg(args, idx, fq, run_dir)),
                          ("all_transcripts", lambda: all_transcripts_leg(args, g, idx, log)),
                          ("config1", lambda: config1_leg(args, log))):
@@ -607,6 +606,13 @@ def main():
             out["two_pass_end_to_end"] = two_pass(args, idx, fq, run_dir, threads)
         except Exception as e:
             out["two_pass_end_to_end"] = {"error": repr(e)[:300]}
+    if world == 1 and not args.no_extra_legs and isinstance(out.get("kernel_ms_exclusive"), dict) and "per_kernel_ms" in out["kernel_ms_exclusive"]:
+        # last: kernels that have never run on hardware are timed here, each in a child process with a time limit; nothing else of the line depends on them
+        try:
+            out["variants"] = variants_leg(args, idx, fq, run_dir, threads, out["kernel_ms_exclusive"], log)
+        except Exception as e:
+            out["variants"] = {"error": repr(e)[:300]}
+        log("variants done")
     out["bench_wall_s"] = time.time() - T_START
     out["notes"] = notes
     print(json.dumps(out))
@@ -650,15 +656,15 @@ def exclusive_leg(args, idx, fq, run_dir, threads):
 # kernels / knobs that are OFF by default because they have no hardware number yet (written when no GPU minutes were left): the leg below times each of them
 # exactly like kernel_ms_exclusive (one context, same index, same reads) and checks its output against that leg's, so that the bench run at the end of a round is
 # also their A/B.  A variant that wins becomes the default (and leaves this list) in the next round; one that loses is deleted.
-VARIANTS = [
-    ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
-    ("seed_flat_6waves", {"STARAMD_SEED_FLAT": "2"}),
-    ("seed_flat_4waves", {"STARAMD_SEED_FLAT": "3"}),
+VARIANTS = [      # (most wanted first: the leg has a time budget of its own)
     ("seed_read_4waves", {"STARAMD_SEED_FLAT": "4"}),
+    ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
+    ("lane_class_post_2", {"STARAMD_LANE_CLASS_POST": "2"}),
+    ("seed_flat_4waves", {"STARAMD_SEED_FLAT": "3"}),
     ("seed_read_6waves", {"STARAMD_SEED_FLAT": "5"}),
     ("lane_class_post_1", {"STARAMD_LANE_CLASS_POST": "1"}),
-    ("lane_class_post_2", {"STARAMD_LANE_CLASS_POST": "2"}),
     ("lane_class_post_2_cap6", {"STARAMD_LANE_CLASS_POST": "2", "STARAMD_LANE_CLASS": "6"}),
+    ("seed_flat_6waves", {"STARAMD_SEED_FLAT": "2"}),
     # not a kernel: the same 2 M pairs as 1 + 1 batches of a million (the launches of a batch end in tails of a few wavefronts; per pair they weigh less in a larger batch)
     ("batch_1M", {"_batch_reads": "1000000"}),
 ]
@@ -673,7 +679,11 @@ def variants_leg(args, idx, fq, run_dir, threads, base, log):
     base_prefix = os.path.join(run_dir, "excl_")
     base_dig = sam_digest(base_prefix + "Aligned.out.sam")
     base_sj = open(base_prefix + "SJ.out.tab", "rb").read()
+    timed_out = set()
+    t_leg = time.time()
     for name, env in VARIANTS:
+        if time.time() - t_leg > 600:
+            res[name] = {"skipped": "the leg's own time budget (600 s)"}; continue
         if time.time() - T_START > args.budget_s:
             res[name] = {"skipped": "time budget"}; continue
         pre = os.path.join(run_dir, "var_")
@@ -688,7 +698,14 @@ def variants_leg(args, idx, fq, run_dir, threads, base, log):
             for f in ("Aligned.out.sam", "SJ.out.tab"):
                 if os.path.exists(pre + f):
                     os.remove(pre + f)
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--variant-child", json.dumps([argv, 2 * args.read_len + 1, e])], timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            fam = "_".join(name.split("_")[:2])
+            if fam in timed_out:
+                res[name] = {"env": env, "skipped": "an earlier variant of this family ran into its time limit"}; continue
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--variant-child", json.dumps([argv, 2 * args.read_len + 1, e])], timeout=180, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            except subprocess.TimeoutExpired:
+                timed_out.add(fam)
+                raise RuntimeError("time limit (180 s)")
             if p.returncode != 0:
                 raise RuntimeError("child exit code %d: %s" % (p.returncode, p.stderr[-200:]))
             d = json.loads(p.stdout.strip().splitlines()[-1])
