@@ -349,6 +349,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
     u32 pS = 0, pL = 0, Nstart = 1, Lstart = 0, iDir = 0, istart = 0, Lmapped = 0, Shift = 0, seedLength = 0;
     // maxMappableLength2strands
     u32 it = 0, nD = 1, maxLbest = 0;
+    u32 lastR = 0, lastL = 0;             // (rStart, L) of the last row of the lane's seed table (valid while st.nP > 0)
     // one search
     u32 pieceStart = 0, pieceLength = 0, Lind = 0; u64 ind1 = 0, iSA1 = 0, iSA2 = 0; bool iSA2good = true;
     u64 Nrep = 0, i0 = 0; u32 maxL = 0;
@@ -598,8 +599,27 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             bool more = true;
             if (phase == 0) { if (maxL + iDist > maxLbest) maxLbest = maxL + iDist; }
             if (!(phase == 0 && nD > 1)) {
-                if (maxL + iDist == maxLbest && Nrep > 0)
-                    storeAligns(X, st, iDir, dirR ? Shift + iDist : Shift - iDist, Nrep, maxL, i0, iFrag);
+                if (maxL + iDist == maxLbest && Nrep > 0) {
+                    // storeAligns (ReadAlign_storeAligns.cpp:10-160) looks at the table from its end; the two commonest outcomes are decided by the LAST row alone, which is
+                    // kept in registers: the new seed starts behind it (a forward walk finds its seeds in that order: append) or equals it (found again: nothing to do).
+                    // Everything else goes through the table in the lane's scratch memory.  Same table, same counters, no load in the common case.
+                    const u32 sShift = dirR ? Shift + iDist : Shift - iDist;
+                    const u32 rStart = iDir == 0 ? sShift : sShift + 1 - maxL;
+                    const bool fits = st.nP + 1 <= X.P.seedPerReadNmax && st.nP + 1 <= st.cap;
+                    if (Nrep <= X.P.seedMultimapNmax && st.nP > 0 && lastR == rStart && lastL == maxL) st.nA |= 1u;                    // the duplicate: (:30-33) return before anything is written
+                    else if (Nrep <= X.P.seedMultimapNmax && fits && (st.nP == 0 || lastR < rStart)) {                                  // the append
+                        st.nA |= 1u;
+                        DSeed sd; sd.saStart = i0; sd.nrep = (u32)Nrep; sd.rStart = (u16)rStart; sd.L = (u16)maxL; sd.dir = (u8)iDir; sd.iFrag = (u8)iFrag;
+                        for (int k = 0; k < 6; k++) sd.pad[k] = 0;
+                        st.PC[st.nP] = sd; st.nP++;
+                        lastR = rStart; lastL = maxL;
+                        if (Nrep != 1) { if (Nrep < st.multNmin || st.multNmin == 0) { st.multNmin = (u32)Nrep; st.multNminL = maxL; } }
+                    } else {
+                        const u32 nBefore = st.nP;
+                        storeAligns(X, st, iDir, sShift, Nrep, maxL, i0, iFrag);
+                        if (st.nP != nBefore) { const DSeed t = st.PC[st.nP - 1]; lastR = t.rStart; lastL = t.L; }                      // (an insertion may have moved the last row)
+                    }
+                }
                 if (nD == 1) more = false;
             }
             it++;
