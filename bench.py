@@ -658,6 +658,7 @@ def exclusive_leg(args, idx, fq, run_dir, threads):
 # also their A/B.  A variant that wins becomes the default (and leaves this list) in the next round; one that loses is deleted.
 VARIANTS = [      # (most wanted first: the leg has a time budget of its own)
     ("seed_read_4waves", {"STARAMD_SEED_FLAT": "4"}),
+    ("seed_staged_4waves", {"STARAMD_SEED_FLAT": "6"}),
     ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
     ("lane_class_post_2", {"STARAMD_LANE_CLASS_POST": "2"}),
     ("seed_flat_4waves", {"STARAMD_SEED_FLAT": "3"}),

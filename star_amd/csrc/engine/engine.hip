@@ -18,9 +18,10 @@ extern "C" __global__ void k_seed_search_flat6(const DevIndex *X, DevBatch B, DS
 extern "C" __global__ void k_seed_search_flat4(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_seed_search_read4(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);     // the whole read as one state machine: 4 (4 waves per SIMD), 5 (6)
 extern "C" __global__ void k_seed_search_read6(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
+extern "C" __global__ void k_seed_search_staged4(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);   // 6: ... with the read staged in LDS (dynamic LDS: 256 * (packWords | 1) words)
 typedef void (*SeedKernel)(const DevIndex *, DevBatch, DSeed *, u32);
-static SeedKernel seedKernel(u32 flat) { return flat == 1 ? k_seed_search_flat : flat == 2 ? k_seed_search_flat6 : flat == 3 ? k_seed_search_flat4 : flat == 4 ? k_seed_search_read4 : flat == 5 ? k_seed_search_read6 : k_seed_search; }
-static const char *seedKernelName(u32 flat) { return flat == 1 ? "k_seed_search_flat" : flat == 2 ? "k_seed_search_flat6" : flat == 3 ? "k_seed_search_flat4" : flat == 4 ? "k_seed_search_read4" : flat == 5 ? "k_seed_search_read6" : "k_seed_search"; }
+static SeedKernel seedKernel(u32 flat) { return flat == 1 ? k_seed_search_flat : flat == 2 ? k_seed_search_flat6 : flat == 3 ? k_seed_search_flat4 : flat == 4 ? k_seed_search_read4 : flat == 5 ? k_seed_search_read6 : flat == 6 ? k_seed_search_staged4 : k_seed_search; }
+static const char *seedKernelName(u32 flat) { return flat == 1 ? "k_seed_search_flat" : flat == 2 ? "k_seed_search_flat6" : flat == 3 ? "k_seed_search_flat4" : flat == 4 ? "k_seed_search_read4" : flat == 5 ? "k_seed_search_read6" : flat == 6 ? "k_seed_search_staged4" : "k_seed_search"; }
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
 extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits, u32 classSlack);
 extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid, u32 classSlack);
@@ -248,7 +249,7 @@ static int allocWork(staramd_ctx *c) {
     const staramd_params &P = c->X.P;
     // ---- seed kernel: one lane per read, PC table per lane sized by the reference's seedPerReadNmax
     int seedPerCU = 2;
-    c->seedFlat = std::min<u32>(envU32("STARAMD_SEED_FLAT", 0), 5);          // the seed search as a state machine around one load site (k_seed_flat.hip); same results
+    c->seedFlat = std::min<u32>(envU32("STARAMD_SEED_FLAT", 0), 6);          // the seed search as a state machine around one load site (k_seed_flat.hip); same results
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&seedPerCU, seedKernel(c->seedFlat), 256, 0) != hipSuccess || seedPerCU < 1) seedPerCU = 2;
     u32 lanes = envU32("STARAMD_SEED_LANES", (u32)c->nCU * (u32)seedPerCU * 256u);
     lanes = std::max<u32>(256, std::min<u32>(lanes, ((N + 255) / 256) * 256));
@@ -518,7 +519,8 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[0], s));
     {
         u32 lanes = std::min<u32>(c->seedLanes, ((n + 255) / 256) * 256);
-        hipLaunchKernelGGL(seedKernel(c->seedFlat), dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane);
+        const size_t seedLds = c->seedFlat == 6 ? 256 * (size_t)(B.packWords | 1u) * 4 : 0;      // the staged form keeps every lane's packed read in LDS
+        hipLaunchKernelGGL(seedKernel(c->seedFlat), dim3(lanes / 256), block, seedLds, s, c->dX, B, c->scrSeed, c->seedPerLane);
     }
     HIPCHK(hipEventRecord(c->ev[1], s));
     {

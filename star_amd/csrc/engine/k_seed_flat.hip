@@ -333,7 +333,26 @@ extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search_flat4(const D
 // in this order, so a lane that finishes a search in one trip issues the first load of its next search in the following one.
 enum { M_TICKET = 0, M_SCHED, M_SETUP, M_SAI1, M_SAI2, M_CMP, M_POST, M_EXIT };
 
-__device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
+// STAGED form (STARAMD_SEED_FLAT = 6): the lane's read lives in LDS, 4 bits per base (the packed copy k_pack_reads makes for the stitch kernels), in a slot of its own
+// (odd stride in words: lanes that read the same word of their reads hit different banks).  That takes the read out of the load site, and with it two things out of
+// the trips: the L-mer prefix of a new search is computed without a memory round trip (no SETUP trip), and the second stream of the load site is free to fetch the
+// upper neighbour of a SAindex entry together with the entry itself (no SAI2 trip): about two trips less per search of about eight.
+extern __shared__ u32 ldsReads[];
+// codes (one per byte) of the 8 bases pos .. pos + 7 of the read in the lane's slot; positions outside the slot read as 15 (never used: masked by every caller)
+__device__ __forceinline__ u64 ldsBases8(u32 slotWord0, u32 nWords, i32 pos) {
+    const __attribute__((address_space(3))) u32 *W = (const __attribute__((address_space(3))) u32 *)ldsReads + slotWord0;
+    const i32 w = pos >> 3; const u32 off = (u32)(pos & 7) * 4u;
+    const u32 lo = (w >= 0 && (u32)w < nWords) ? W[w] : 0xFFFFFFFFu;
+    const u32 hi = (w + 1 >= 0 && (u32)(w + 1) < nWords) ? W[w + 1] : 0xFFFFFFFFu;
+    const u32 x = off ? ((lo >> off) | (hi << (32u - off))) : lo;
+    u64 t = x;
+    t = (t | (t << 16)) & 0x0000FFFF0000FFFFull;
+    t = (t | (t << 8)) & 0x00FF00FF00FF00FFull;
+    t = (t | (t << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    return t;
+}
+
+template <bool STAGED> __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -350,6 +369,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
     // maxMappableLength2strands
     u32 it = 0, nD = 1, maxLbest = 0;
     u32 lastR = 0, lastL = 0;             // (rStart, L) of the last row of the lane's seed table (valid while st.nP > 0)
+    const u32 slotWords = B.packWords | 1u, slotWord0 = threadIdx.x * slotWords;      // STAGED: this lane's slot in ldsReads
     // one search
     u32 pieceStart = 0, pieceLength = 0, Lind = 0; u64 ind1 = 0, iSA1 = 0, iSA2 = 0; bool iSA2good = true;
     u64 Nrep = 0, i0 = 0; u32 maxL = 0;
@@ -381,6 +401,11 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             st.nP = 0; st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
             Nsplit = 0; LgoodMin = 0; iR = 0; iFrag = 0; pieceActive = false;
             sssLmax = min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1)));
+            if constexpr (STAGED) {
+                const u32 *src = B.packed + (u64)ir * B.packWords;
+                __attribute__((address_space(3))) u32 *dst = (__attribute__((address_space(3))) u32 *)ldsReads + slotWord0;
+                for (u32 k = 0; k < B.packWords; k++) dst[k] = GLOBAL(u32, src)[k];
+            }
             mode = M_SCHED;
         }
         if (mode == M_SCHED) {
@@ -456,6 +481,34 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             }
         }
         const bool dirR = iDir == 0;
+        if constexpr (STAGED) {
+            if (mode == M_SETUP) {                               // a search begins: its L-mer prefix from the read in LDS, no trip of its own
+                const u32 iDist = it >= nD ? it - nD : it;
+                pieceLength = seedLength - iDist;
+                pieceStart = dirR ? Shift + iDist : Shift - iDist;
+                const u32 Lmax = min(X.saiNbases, pieceLength);
+                ind1 = 0;
+                for (u32 k8 = 0; k8 < Lmax; k8 += 8) {
+                    const u64 raw = dirR ? ldsBases8(slotWord0, B.packWords, (i32)(pieceStart + k8)) : __builtin_bswap64(ldsBases8(slotWord0, B.packWords, (i32)pieceStart - (i32)k8 - 7));
+                    const u32 nb = min(8u, Lmax - k8);
+                    const u64 used = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+                    if ((raw & used & 0xFCFCFCFCFCFCFCFCull) == 0) {
+                        u64 x = dirR ? raw : (raw ^ 0x0303030303030303ull);
+                        u64 z = __builtin_bswap64(x & 0x0303030303030303ull);
+                        z = (z | (z >> 6)) & 0x000F000F000F000Full;
+                        z = (z | (z >> 12)) & 0x000000FF000000FFull;
+                        z = (z | (z >> 24)) & 0xFFFFull;
+                        ind1 = (ind1 << (2 * nb)) | (z >> (2 * (8 - nb)));
+                    } else {
+                        for (u32 k = 0; k < nb; k++) { const u64 cde = (raw >> (8 * k)) & 0xFFull; ind1 = (ind1 << 2) + (dirR ? cde : 3ull - cde); }
+                    }
+                }
+                Lind = Lmax; iSA1 = 0; iSA2 = 0; iSA2good = true;
+                Nrep = 0; i0 = 0; maxL = 0;
+                while (Lind > 0 && X.saiStart[Lind - 1] + ind1 >= saiEnd) { --Lind; ind1 >>= 2; }
+                mode = Lind > 0 ? M_SAI1 : M_POST;
+            }
+        }
         if (mode == M_SETUP || mode == M_SAI1 || mode == M_SAI2 || mode == M_CMP) {
             TRIP_MARK(4u);
             if (mode == M_SETUP) {                               // a search begins (one start offset of maxMappableLength2strands)
@@ -472,10 +525,18 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
             else if (mode != M_CMP) { const u64 b = (X.saiStart[Lind - 1] + ind1 + (mode == M_SAI2 ? 1ull : 0ull)) * X.saiBits; a = (u64)X.SAi + (b >> 6) * 8ull; sh = (u32)(b & 63ull); }
             else if (!haveSA) { const u64 b = (base + cI) * X.saBits; a = (u64)X.SA + (b >> 6) * 8ull; sh = (u32)(b & 63ull); }
             else { const u64 p = dirG ? gAddr + ii : gAddr - ii - 7ull; a = p & ~7ull; sh = (u32)(p & 7ull) * 8u; }
-            const u64 sp = mode == M_SETUP ? (dirR ? sBase : sBase - 7ull)
-                         : (mode != M_CMP || !haveSA) ? sBase : dirR ? sBase + cL + ii : sBase - cL - ii - 7ull;      // (no compare step in this trip: any address inside the read)
             const u64 v = funnel64(a, sh);
-            u64 s8 = funnel64(sp & ~7ull, (u32)(sp & 7ull) * 8u);
+            u64 s8;
+            if constexpr (STAGED) {
+                // second stream: the upper neighbour of the SAindex entry (SAI1 trips); the read bases of a compare step come from LDS
+                if (mode == M_SAI1) { const u64 b = (X.saiStart[Lind - 1] + ind1 + 1ull) * X.saiBits; s8 = funnel64((u64)X.SAi + (b >> 6) * 8ull, (u32)(b & 63ull)); }
+                else if (mode == M_CMP && haveSA) s8 = dirR ? ldsBases8(slotWord0, B.packWords, (i32)(pieceStart + cL + ii)) : ldsBases8(slotWord0, B.packWords, (i32)pieceStart - (i32)cL - (i32)ii - 7);
+                else s8 = 0;
+            } else {
+                const u64 sp = mode == M_SETUP ? (dirR ? sBase : sBase - 7ull)
+                             : (mode != M_CMP || !haveSA) ? sBase : dirR ? sBase + cL + ii : sBase - cL - ii - 7ull;      // (no compare step in this trip: any address inside the read)
+                s8 = funnel64(sp & ~7ull, (u32)(sp & 7ull) * 8u);
+            }
             const u32 m0 = mode;                                 // what this trip's loads were for
             bool start = false, fin = false; u32 Lc = cN;
             if (m0 == M_SETUP) {
@@ -508,8 +569,14 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
                     --Lind; ind1 >>= 2;
                     while (Lind > 0 && X.saiStart[Lind - 1] + ind1 >= saiEnd) { --Lind; ind1 >>= 2; }
                     if (Lind == 0) mode = M_POST;                // base absent from the genome: Nrep = 0
-                } else if (X.saiStart[Lind - 1] + ind1 + 1 < X.saiStart[Lind]) mode = M_SAI2;
-                else { iSA2 = X.nSA - 1; iSA2good = false; start = true; }
+                } else if (X.saiStart[Lind - 1] + ind1 + 1 < X.saiStart[Lind]) {
+                    if constexpr (STAGED) {                      // the neighbour came with this trip's second stream
+                        iSA2 = s8 & X.saiMask; cn.nSAi++;
+                        if ((iSA2 & X.saiAbsentBit) == 0) iSA2 = (iSA2 & ~X.saiNbit) - 1;
+                        else { iSA2 = X.nSA - 1; iSA2good = false; }
+                        start = true;
+                    } else mode = M_SAI2;
+                } else { iSA2 = X.nSA - 1; iSA2good = false; start = true; }
             } else if (m0 == M_SAI2) {
                 iSA2 = v & X.saiMask; cn.nSAi++;
                 if ((iSA2 & X.saiAbsentBit) == 0) iSA2 = (iSA2 & ~X.saiNbit) - 1;
@@ -641,5 +708,7 @@ __device__ __forceinline__ void seedSearchReadBody(const DevIndex *__restrict__ 
     atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);
     atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
 }
-extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search_read4(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) { seedSearchReadBody(Xp, B, scratch, scratchPerLane); }
-extern "C" __global__ void __launch_bounds__(256, 6) k_seed_search_read6(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) { seedSearchReadBody(Xp, B, scratch, scratchPerLane); }
+extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search_read4(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) { seedSearchReadBody<false>(Xp, B, scratch, scratchPerLane); }
+extern "C" __global__ void __launch_bounds__(256, 6) k_seed_search_read6(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) { seedSearchReadBody<false>(Xp, B, scratch, scratchPerLane); }
+// launched with 256 * (B.packWords | 1) * 4 bytes of dynamic LDS
+extern "C" __global__ void __launch_bounds__(256, 4) k_seed_search_staged4(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) { seedSearchReadBody<true>(Xp, B, scratch, scratchPerLane); }

@@ -91,6 +91,7 @@ FORCED = {
     "seed_flat_4waves": {"STARAMD_SEED_FLAT": "3"},           # ... with 128 VGPRs
     "seed_read": {"STARAMD_SEED_FLAT": "4"},                  # the whole read as one state machine (k_seed_search_read4)
     "seed_read_6waves": {"STARAMD_SEED_FLAT": "5"},
+    "seed_staged": {"STARAMD_SEED_FLAT": "6"},                # ... with the read staged in LDS (k_seed_search_staged4)
     "lane_class_post": {"STARAMD_LANE_CLASS_POST": "2"},      # light reads classed by their two-mate windows (k_window.hip): more of them go through the lane-per-read stitcher
     "lane_class_post_wide": {"STARAMD_LANE_CLASS_POST": "8", "STARAMD_LANE_CLASS": "7"},
 }

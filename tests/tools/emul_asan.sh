@@ -42,5 +42,8 @@ run "STARAMD_SEED_FLAT=4" se50 2000 --seedPerWindowNmax 5
 run "STARAMD_SEED_FLAT=4" pe101 1500 --seedPerWindowNmax 5
 run "STARAMD_SEED_FLAT=5" pe101_sparse3 1000 --seedPerWindowNmax 5 --seedSearchLmax 25
 run "STARAMD_SEED_FLAT=4" pe125_protrude 1000 --seedPerWindowNmax 5 --seedSearchLmax 30 --seedSearchStartLmax 12
+run "STARAMD_SEED_FLAT=6" pe101 1500 --seedPerWindowNmax 5
+run "STARAMD_SEED_FLAT=6" pe101_sparse3 1000 --seedPerWindowNmax 5 --seedSearchLmax 25
+run "STARAMD_SEED_FLAT=6" pe125_protrude 1000 --seedPerWindowNmax 5 --seedSearchLmax 30 --seedSearchStartLmax 12
 echo "$bad case(s) with a report"
 exit $bad
