@@ -1,5 +1,7 @@
-// k_seed_flat.hip -- kernel 1, second and third form: the seed search with ONE memory site (STARAMD_SEED_FLAT=1..5; k_seed.hip is the measured default).
-// Second form (below): a state machine per search.  Third form (end of the file): a state machine over the whole read.
+// k_seed_flat.hip -- kernel 1, experimental forms: the seed search with ONE memory site (STARAMD_SEED_FLAT=1..6; k_seed.hip is the measured default; nothing here
+// has run on hardware yet: bench.py's leg `variants` times all of them, DESIGN.md 5.1.1 has the trace model that motivates them).
+// Second form (below): a state machine per search (1 / 2 / 3 = 8 / 6 / 4 waves per SIMD).  Third form (end of the file): a state machine over the whole read
+// (4 / 5 = 4 / 6 waves per SIMD; 6 = with the read staged in LDS).
 //
 // Same functions of the reference as k_seed.hip (ReadAlign_maxMappableLength2strands.cpp:5-115, SuffixArrayFuns.cpp:10-207,
 // ReadAlign_storeAligns.cpp:10-160), same mapping (one lane = one read), same results bit for bit.  What differs is the shape of the
@@ -18,8 +20,8 @@
 // it (one to three per search) are a loop of their own with one load site.
 // Suffix-array intervals of 2^32 entries or more (a look-up whose upper neighbour is absent can span the array) keep the call-tree code.
 //
-// Parity: buffers identical to the oracle and to k_seed_search on every data set of tests/test_wave_emul.py (emulator) and
-// tests/test_gpu_parity.py (hardware, `seed_flat` cases).
+// Parity: result buffers and the counters nSAi / nSAprobe / nGcmp / nSeeds identical to k_seed_search in the emulator (battery of 14 data set x flag cases, 290
+// fuzz combinations, AddressSanitizer build); forced cases `seed_*` in tests/test_wave_emul.py (emulator) and tests/test_gpu_parity.py (hardware).
 #define k_seed_search k_seed_search_calltree_copy      // the device functions of k_seed.hip are reused as they are; its kernel entry is compiled under another name in this object
 #include "k_seed.hip"
 #undef k_seed_search
