@@ -657,6 +657,7 @@ def exclusive_leg(args, idx, fq, run_dir, threads):
 # exactly like kernel_ms_exclusive (one context, same index, same reads) and checks its output against that leg's, so that the bench run at the end of a round is
 # also their A/B.  A variant that wins becomes the default (and leaves this list) in the next round; one that loses is deleted.
 VARIANTS = [      # (most wanted first: the leg has a time budget of its own)
+    ("base_repeat", {}),      # the default kernels once more, in a child like the others: what two identical runs differ by
     ("seed_read_4waves", {"STARAMD_SEED_FLAT": "4"}),
     ("seed_staged_4waves", {"STARAMD_SEED_FLAT": "6"}),
     ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
