@@ -33,6 +33,14 @@ def _split_fastq(paths, world, outdir):
     return shards
 
 
+def _free_port():
+    """a port nobody listens on right now (a fixed port per process id collides now and then when test workers run side by side)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _worker(rank, world, port, idx, shards, extra, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -70,7 +78,7 @@ def test_two_ranks_match_single_reference_run(name, tmp_path, built):
     info = prepare(name, str(tmp_path))
     world = 2
     shards = _split_fastq(info["fastq"], world, str(tmp_path))
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, info["idx"], shards, info["extra"], str(tmp_path)), nprocs=world, join=True)
     ref = info["ref_prefix"]
     r0 = os.path.join(str(tmp_path), "r0_")
@@ -90,7 +98,7 @@ def test_two_ranks_two_pass_by_sjout_gene_counts(tmp_path, built):
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(str(tmp_path), "ref_"), threads=1, extra=flags)
     world = 2
     shards = _split_fastq(info["fastq"], world, str(tmp_path))
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, info["idx"], shards, flags, str(tmp_path)), nprocs=world, join=True)
     r0 = os.path.join(str(tmp_path), "r0_")
     assert open(ref + "SJ.out.tab", "rb").read() == open(r0 + "SJ.out.tab", "rb").read()
@@ -142,7 +150,7 @@ def test_two_ranks_through_the_front_end_hooks(flags, tmp_path, built):
     ref = refstar.align(info["idx"], info["fastq"], os.path.join(str(tmp_path), "ref_"), threads=1, extra=flags)
     world = 2
     shards = _split_fastq(info["fastq"], world, str(tmp_path))
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_cli_worker, args=(world, port, info["idx"], shards, flags, str(tmp_path)), nprocs=world, join=True)
     c0 = os.path.join(str(tmp_path), "c0_")
     assert open(ref + "SJ.out.tab", "rb").read() == open(c0 + "SJ.out.tab", "rb").read()
