@@ -667,6 +667,7 @@ VARIANTS = [      # (most wanted first: the leg has a time budget of its own)
     ("lane_class_post_1", {"STARAMD_LANE_CLASS_POST": "1"}),
     ("lane_class_post_2_cap6", {"STARAMD_LANE_CLASS_POST": "2", "STARAMD_LANE_CLASS": "6"}),
     ("seed_flat_6waves", {"STARAMD_SEED_FLAT": "2"}),
+    ("seed_read_4waves_half_grid", {"STARAMD_SEED_FLAT": "4", "STARAMD_SEED_LANES": "131072"}),      # ~3 reads per lane instead of ~1.5: better balance inside a wavefront, fewer wavefronts in flight
     # not a kernel: the same 2 M pairs as 1 + 1 batches of a million (the launches of a batch end in tails of a few wavefronts; per pair they weigh less in a larger batch)
     ("batch_1M", {"_batch_reads": "1000000"}),
 ]
