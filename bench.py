@@ -17,6 +17,11 @@ Contract (see the task statement): `python bench.py --gpus N --steps K --warmup 
               input chunk small enough that every thread has work (>= 8 chunks per thread)
 Multi-GPU: one process per GPU (torch.distributed / RCCL for the barriers, the max-over-ranks reduction and the junction-table
 all_gather at the end of the run); reads are sharded, every rank holds a full index replica; no data-path collective (weak scaling).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks.
+
+Output: ONE compact JSON line (< 4 KB) on stdout of rank 0.  Everything else -- the optional legs (host at the 8-GPU thread budget, configs 1 / 4 / 5,
+index-size sweep), per-leg counters, notes -- goes to <workdir>/bench_extra.json (path in the line under "extra"), written by a child process
+so that a fault in an optional leg cannot take the line with it.
 """
 import argparse
 import ctypes as C
@@ -48,7 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the index-size sweep (100 / 400 / 1000 Mb)")
     ap.add_argument("--no-two-pass", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip kernel_ms_exclusive / variants / host_budget / all_transcripts / config1")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the optional legs (bench_extra.json): host_budget / config 5 / config 1 / sweep / 2-pass")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the one-context leg the roofline kernel times come from (they are then the overlapped two-context figures)")
+    ap.add_argument("--cpu-selftest", action="store_true", help="TEST of this script's plumbing on a box without a GPU: gloo, the oracle behind the front end, a tiny genome; the line says selftest")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("STARAMD_BENCH_BUDGET_S", "1500")), help="optional legs are skipped once this much wall time is used")
     ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/dev/shm/star_amd_bench" if os.path.isdir("/dev/shm") else "/tmp/star_amd_bench"))
     return ap.parse_args()
@@ -90,7 +97,7 @@ def build_genome(args, mb, log):
     info["write_fasta_gtf_s"] = time.time() - t
     del seqs
     nb = max(4, min(14, int(math.log2(mb * 1e6) / 2 - 1)))
-    exe = os.path.join(ROOT, "star_amd", "bin", "star_amd")
+    exe = SELFTEST_EXE if getattr(args, "cpu_selftest", False) else os.path.join(ROOT, "star_amd", "bin", "star_amd")
     idx = os.path.join(g, "idx")
     os.makedirs(idx, exist_ok=True)
     cmd = [exe, "--runMode", "genomeGenerate", "--genomeDir", idx, "--genomeFastaFiles", os.path.join(g, "genome.fa"), "--genomeSAindexNbases", str(nb),
@@ -228,7 +235,8 @@ def report_dict(rep, lread):
     # Algorithmic bytes: what the algorithm must fetch / write, from the engine's own counters
     bytes_seed = 8 * c["nSAi"] + 8 * c["nSAprobe"] + c["nGcmp"] + n * lread + 24 * c["nSeeds"]
     bytes_win = 8 * c["nSAenum"] + 24 * c["nSeeds"] + 24 * c["nWA"]
-    bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + (lread // 2) * (c["nWindows"] if c["nWindows"] else n) + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
+    walked = max(0, c["nWindows"] - c["nPrunedWin"]) if c["nWindows"] else n           # the packed read is staged once per WALKED window (pruned windows are never touched)
+    bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + (lread // 2) * walked + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
     kern = {"k_seed_search": (ms["k_seed_search"], bytes_seed / nb), "k_windows": (ms["k_windows"], bytes_win / nb), "k_stitch_win": (ms["k_stitch_win"], bytes_stitch / nb)}
     if os.environ.get("STARAMD_PROFILE_BUILD"):          # libstaramd.so built with -DSTARAMD_PROFILE: shader-clock cycles per section, summed over waves
         pn = ["walk(all)", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime", "windows:passA", "windows:flanks", "windows:passB_enumerate+owner",
@@ -245,119 +253,28 @@ def report_dict(rep, lread):
 def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
     """The reference itself (oracle/_ref/STAR, built from /root/reference by oracle/Makefile.ref), same index, same FASTQ, default parameters.
     STAR deals input to its threads in chunks of limitIObufferSize[0]/nMates bytes (ReadAlignChunk_processChunks.cpp:14-30, Parameters.cpp:1160);
-    the default (30 MB -> ~67 k pairs) would leave most of 256 threads without a chunk on a 10 M-pair sample, so the input buffer is set to
-    2 MB (~4.4 k pairs per chunk: >= 8 chunks per thread).  Mapping time = wall(full run) - wall(run that only loads the index)."""
+    the default (30 MB -> ~67 k pairs) would leave most of 256 threads without a chunk, so the input buffer is set to 2 MB (~4.4 k pairs per
+    chunk).  Mapping time = wall(run) - wall(run that only loads the index).  Two configurations: the box's best thread count (cores / 4: the
+    reference reads and splits its input under one mutex, more threads only wait) on the WHOLE FASTQ -- its output is what full_size_parity
+    compares with -- and all cores (north_star: --runThreadN = all host cores) on a bounded sample (the first 4 M pairs)."""
     from oracle import refstar
     ncpu = os.cpu_count() or 1
     small = ["--limitIObufferSize", "2000000", "50000000"]
-    chunks = n_pairs * 225 // 1000000
 
-    def run(nmap, threads, extra=()):
+    def run(nmap, threads, prefix):
         t = time.perf_counter()
-        refstar.align(idx, fq, out_prefix, threads=threads, extra=["--readMapNumber", str(nmap)] + small + list(extra), timeout=900)
+        refstar.align(idx, fq, prefix, threads=threads, extra=["--readMapNumber", str(nmap)] + small, timeout=900)
         log("reference STAR: %d reads, %d threads: %.1f s" % (nmap, threads, time.perf_counter() - t))
         return time.perf_counter() - t
-    run(1, ncpu)                                    # page cache
-    t_load = min(run(1, ncpu), run(1, ncpu))
-    tried = {}
-    extras = {}
+    run(1, ncpu, out_prefix + "ld_")                                    # page cache
+    t_load = run(1, ncpu, out_prefix + "ld_")
     best_th = max(1, ncpu // 4)
-    try:        # what a user would run on this box instead of one 256-thread process (VERDICT r2 item 4c)
-        t = time.perf_counter()
-        refstar.align(idx, fq, out_prefix + "dflt_", threads=best_th, extra=["--readMapNumber", str(n_pairs)], timeout=900)       # default --limitIObufferSize
-        extras["default_io_buffer"] = {"threads": best_th, "Mreads_s": n_pairs / max(time.perf_counter() - t - t_load, 1e-3) / 1e6}
-        log("reference STAR, default input buffer, %d threads: %.1f s" % (best_th, time.perf_counter() - t))
-    except Exception as e:
-        extras["default_io_buffer"] = {"error": repr(e)[:200]}
-    try:
-        extras["multi_process"] = multi_process_baseline(idx, fq, out_prefix, n_pairs, ncpu, small, log)
-    except Exception as e:
-        extras["multi_process"] = {"error": repr(e)[:300]}
-    for th in sorted(set([best_th, ncpu])):
-        t_full = run(n_pairs, th)
-        tried[th] = n_pairs / max(t_full - t_load, 1e-3) / 1e6
-    # the all-core run is last: its outputs stay for the parity check
-    n1 = min(n_pairs, 60000)
-    one = None
-    try:
-        p1 = out_prefix + "t1_"
-        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", str(n1)], timeout=600); t_one = time.perf_counter() - t
-        t = time.perf_counter(); refstar.align(idx, fq, p1, threads=1, extra=["--readMapNumber", "1"], timeout=600); t_one_load = time.perf_counter() - t
-        one = n1 / max(t_one - t_one_load, 1e-3) / 1e6
-    except Exception:
-        one = None
-    return {"value": tried[ncpu], "unit": "Mreads/s", "cores": ncpu, "kind": "reference",
-            "sample": "%d pairs (the same FASTQ the GPU run maps), STAR 2.7.11b --runThreadN %d, --limitIObufferSize 2000000 (~%d input chunks = %.1f per thread); "
-                      "mapping time = wall(full) - wall(index load only, %.1f s); by thread count (Mreads/s): %s; one thread on %d pairs: %s Mreads/s"
-                      % (n_pairs, ncpu, chunks, chunks / ncpu, t_load, ", ".join("%d: %.4f" % (k, v) for k, v in sorted(tried.items())), n1,
-                         ("%.5f" % one) if one else "n/a"),
-            "by_threads": {str(k): v for k, v in sorted(tried.items())}, "one_thread": one, "index_load_s": t_load,
-            "default_io_buffer": extras.get("default_io_buffer"), "multi_process": extras.get("multi_process")}
-
-
-def memory_headroom_gb():
-    """what this container may still allocate: MemAvailable, capped by the cgroup limit minus its current usage (tmpfs pages included)"""
-    avail = None
-    for l in open("/proc/meminfo"):
-        if l.startswith("MemAvailable:"):
-            avail = int(l.split()[1]) * 1024 / 1e9
-    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"), ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
-        try:
-            a, b = open(lim).read().strip(), open(cur).read().strip()
-            if a != "max" and int(a) < (1 << 60):
-                head = (int(a) - int(b)) / 1e9
-                avail = head if avail is None else min(avail, head)
-        except Exception:
-            pass
-    return avail if avail is not None else 0.0
-
-
-def multi_process_baseline(idx, fq, out_prefix, n_pairs, ncpu, small, log):
-    """8 reference processes side by side, cores/8 threads each, every one on its own eighth of the FASTQ (each holds its own copy of the index, as
-    8 independent STAR runs do): what the box can do when the one input mutex of a single process is taken out of the picture."""
-    from oracle import refstar
-    nproc = 8
-    idx_gb = sum(os.path.getsize(os.path.join(idx, f)) for f in ("Genome", "SA", "SAindex")) / 1e9
-    free_gb = memory_headroom_gb()
-    # every process holds its own copy of the index (+ ~0.1 GB per thread); the copies must fit into what the CONTAINER may still use (its cgroup limit
-    # counts the tmpfs the workload lives in), with a wide margin: a box that runs out of memory is lost, not slowed down
-    while nproc > 1 and nproc * (idx_gb * 1.1 + 2 + 0.1 * (ncpu // nproc)) > 0.7 * free_gb:
-        nproc //= 2
-    if nproc < 2:
-        return {"skipped": "%.0f GB of memory headroom for index copies of %.0f GB" % (free_gb, idx_gb)}
-    per = n_pairs // nproc
-    # the FASTQ records have a fixed size (synth.write_fastq_ids): slices by byte offset
-    slices = []
-    for k in range(nproc):
-        fs = []
-        for m, f in enumerate(fq):
-            rec = os.path.getsize(f) // n_pairs
-            o = "%smp%d_%d.fq" % (out_prefix, k, m + 1)
-            with open(f, "rb") as fi, open(o, "wb") as fo:
-                fi.seek(k * per * rec); left = per * rec
-                while left > 0:
-                    b = fi.read(min(left, 1 << 26)); fo.write(b); left -= len(b)
-            fs.append(o)
-        slices.append(fs)
-    th = max(1, ncpu // nproc)
-
-    def wave(nmap):
-        t = time.perf_counter()
-        ps = [subprocess.Popen([refstar.REF_BIN, "--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + slices[k] + ["--runThreadN", str(th), "--outFileNamePrefix", "%smp%d_" % (out_prefix, k),
-                                "--readMapNumber", str(nmap)] + small, stdout=subprocess.DEVNULL) for k in range(nproc)]
-        rcs = [p.wait(timeout=1200) for p in ps]
-        if any(rcs):
-            raise RuntimeError("exit codes %r" % rcs)
-        return time.perf_counter() - t
-    t_load = wave(1)
-    t_full = wave(per)
-    for fs in slices:
-        for f in fs:
-            os.remove(f)
-    log("reference STAR x %d processes x %d threads: load %.1f s, full %.1f s" % (nproc, th, t_load, t_full))
-    return {"processes": nproc, "threads_each": th, "Mreads_s": nproc * per / max(t_full - t_load, 1e-3) / 1e6, "load_only_s": t_load, "full_s": t_full, "pairs": nproc * per,
-            "memory_headroom_gb": free_gb, "what": "independent reference processes side by side, each on its own slice of the FASTQ with its own index copy; as many (8, 4 or 2) as fit "
-                                                   "into the container's memory limit with a wide margin"}
+    n_all = min(n_pairs, 4000000)
+    v_all = n_all / max(run(n_all, ncpu, out_prefix + "all_") - t_load, 1e-3) / 1e6
+    v_best = n_pairs / max(run(n_pairs, best_th, out_prefix) - t_load, 1e-3) / 1e6       # last: its outputs stay for the parity check
+    return {"value": round(v_all, 4), "unit": "Mreads/s", "cores": ncpu, "kind": "reference", "best_threads": best_th, "best_value": round(v_best, 4),
+            "sample": "STAR 2.7.11b, same index and FASTQ, --limitIObufferSize 2000000; all %d cores on the first %d pairs, %d threads on all %d; index load (%.1f s) subtracted"
+                      % (ncpu, n_all, best_th, n_pairs, t_load), "index_load_s": t_load}
 
 
 def _digest_range(job):
@@ -413,21 +330,78 @@ def full_size_parity(ref, new):
 
 # ---------------------------------------------------------------------------------------------------------------------
 
+SELFTEST_CLI_LIB = os.path.join(ROOT, "oracle", "_build", "libstaramd_cli_oracle.so")      # --cpu-selftest only (test of the plumbing, never a measurement)
+SELFTEST_EXE = os.path.join(ROOT, "oracle", "_build", "star_amd_oracle_cli")
+_CLI_LIB = None       # set by --cpu-selftest
+
+
+def _run_cli(argv, *hooks):
+    return run_cli(argv, *hooks, lib_path=_CLI_LIB)
+
+
+def loaded_libs():
+    """shared objects of this repository mapped into the process (the line records which native code ran)"""
+    out = set()
+    try:
+        for l in open("/proc/self/maps"):
+            p = l.rstrip().split(" ")[-1]
+            if p.endswith(".so") and (p.startswith(ROOT) or "staramd" in p or "oracle" in p):
+                out.add(os.path.relpath(p, ROOT) if p.startswith(ROOT) else p)
+    except OSError:
+        pass
+    return sorted(out)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: the same command line under torch.distributed.run, one rank per GPU of this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
+    global _CLI_LIB
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_ranks(args)                     # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise RuntimeError("bench.py --gpus %d was launched with WORLD_SIZE=%d: one rank per GPU, and the line reports n_gpus = the number of ranks that ran" % (args.gpus, world))
+    selftest = args.cpu_selftest
+    if selftest:
+        _CLI_LIB = SELFTEST_CLI_LIB
+    else:
+        # the timed run maps with the product libraries and nothing else: the variables that redirect the front end / the engine to test stand-ins are refused
+        for v in ("STARAMD_CLI_LIB", "STARAMD_ENGINE_LIB"):
+            if os.environ.get(v):
+                raise RuntimeError("%s is set (%s): bench.py measures star_amd/lib/libstaramd_cli.so + libstaramd.so only" % (v, os.environ[v]))
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
+        if selftest:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise RuntimeError("process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+    if not selftest and not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if selftest else torch.device("cuda", local_rank)
     notes = []
 
     def log(s):
@@ -437,10 +411,14 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not selftest:
+            torch.cuda.synchronize(dev)
 
-    if not os.path.isfile(os.path.join(ROOT, "star_amd", "lib", "libstaramd_cli.so")):
-        raise RuntimeError("star_amd/lib/libstaramd_cli.so is missing (python -c 'import __graft_entry__ as g; g.build()')")
+    cli_lib = _CLI_LIB or os.path.join(ROOT, "star_amd", "lib", "libstaramd_cli.so")
+    if not os.path.isfile(cli_lib):
+        raise RuntimeError(cli_lib + " is missing (python -c 'import __graft_entry__ as g; g.build()')")
+    if selftest:          # tiny stand-in workload, index built by the oracle-backed binary
+        args.genome_mb = min(args.genome_mb, 1) or 1; args.reads = min(args.reads, 2000); args.no_extra_legs = True; args.no_cpu_baseline = True; args.no_exclusive = True
     mb = args.genome_mb
     n_total = (args.steps + args.warmup) * args.reads
     if rank == 0:
@@ -459,7 +437,8 @@ def main():
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
     # (the front end runs STARAMD_CONTEXTS_PER_GPU engine contexts per GPU, default 2: two mapper threads over ONE resident index, so that the copies
     # and the low-occupancy tails of one batch overlap with the kernels of the next; rep.nContexts says how many ran)
-    argv += ["--gpuDevice", str(local_rank)]
+    if not selftest:
+        argv += ["--gpuDevice", str(local_rank)]
     if world > 1:          # the ranks load the 31 GB index into host memory one after the other (each keeps ~5 GB of it after the upload)
         os.environ["STARAMD_INDEX_LOAD_LOCK"] = os.path.join(args.workdir, "index_load.lock")
     t_clock = {}
@@ -483,7 +462,7 @@ def main():
         return 0
 
     barrier()
-    rc, rep = run_cli(argv, warmup_done, exchange)
+    rc, rep = _run_cli(argv, warmup_done, exchange)
     if rc != 0:
         raise RuntimeError("the star_amd pipeline failed with exit code %d" % rc)
     elapsed = float(rep.timedWall)
@@ -505,117 +484,106 @@ def main():
     lread = 2 * args.read_len + 1
     c, ms, kern, bytes_per_pair = report_dict(rep, lread)
     n = max(int(rep.timedReads), 1)
-    dom = max(kern, key=lambda k: kern[k][0])
-    dms, dbytes = kern[dom]
-    achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-    value = timed_reads_all / elapsed / 1e6
-    traffic = None; traffic_all = None
-    issue = None
-    try:        # HBM traffic / issue utilisation from rocprofv3 --pmc passes (profiles/README.md): only when taken on THIS engine source and workload size
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
-        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads:
-            # a kernel's figures are reported only while the sources it is written in hash to what they were when the counters were taken
-            ok = {k for k, v in tj.items() if isinstance(v, dict) and k in KERNEL_SOURCES and v.get("kernel_src_sha") == kernel_src_sha(k)}
-            traffic = tj[dom].get("hbm_bytes_per_launch") if dom in ok else None
-            traffic_all = {k: (tj[k]["hbm_bytes_per_launch"] if k in ok else None) for k in KERNEL_SOURCES if k in tj} or None
-            issue = {k: (tj[k].get("valu_busy_frac") if k in ok else None) for k in KERNEL_SOURCES if k in tj} or None
-    except Exception:
-        traffic = None
     n_ctx = max(1, int(rep.nContexts))
-    device_s = sum(float(rep.deviceMs[k]) for k in range(n_ctx)) / 1e3
-    out = {
-        "metric": "million reads aligned/sec (whole node), 2x101 bp PE human-scale index, FASTQ in -> SAM out",
-        "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8/u64 integer", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2 stand-in: synthetic %d Mb genome (%d chromosomes, %.0f %% of the bases written by repeat families), %d junctions in the index "
-                               "(sjdbOverhang %d, SAindex %d bases, index %.1f GB in HBM), %d DISTINCT pairs 2x%d bp per GPU streamed as %d + %d batches of %d "
-                               "(85%% spliced, 1%% substitutions, 0.1%% N); FASTQ text in -> Aligned.out.sam + SJ.out.tab out, index load excluded"
-                               % (mb, max(1, min(24, mb // 40)), 100 * ginfo.get("repeat_bases_fraction", 0), ginfo.get("junctions_in_index", 0), args.read_len - 1,
-                                  ginfo.get("SAindexNbases", 0), ginfo.get("index_bytes", 0) / 1e9, n_total, args.read_len, args.warmup, args.steps, args.reads),
-                   "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads,
-                   "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_per_kernel": traffic_all, "issue": issue, "engine_src_sha": engine_src_sha(), "algorithmic_bytes_per_launch": dbytes, "kernel_ms": dms, "per_kernel_ms": ms,
-                     "algorithmic_bytes_per_pair_whole_path": bytes_per_pair,
-                     "note": "per launch = per batch of %d pairs, averaged over the %d timed batches of rank 0 (HIP events on the engine's stream)" % (args.reads, int(rep.batches))},
-        "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
-        "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s_sum_over_contexts": device_s,
-                     "device_s_note": "HIP-event time of the batches summed over the engine contexts of the GPU: with two contexts their launches overlap, so the sum exceeds the wall time; "
-                                      "kernel_ms_exclusive has the one-context figures",
-                     "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(n_ctx)), "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)), "parse_busy_s": float(rep.parseBusy), "convert_busy_s": float(rep.convertBusy), "postmap_write_busy_s": float(rep.emitBusy),
-                     "reader_note": "the reader is two pipeline stages on two threads: parse_* = input + line table (sah_fill_slot), convert_* = text -> numeric batch (sah_convert_slot)",
-                     "convert_Mreads_s": n / float(rep.convertBusy) / 1e6 if rep.convertBusy > 0 else None,
-                     "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
-                     "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
-                     "finish_s": float(rep.finishSeconds),
-                     "finish_what": "inside timed_wall_s, after the last batch: last SAM writes, junction collapse + filter + SJ.out.tab, Log.final.out",
-                     "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds)},
-        "index_build": ginfo, "sj_merge_ms": sj_ms.get("ms"),
-    }
+    value = timed_reads_all / elapsed / 1e6
+    extra = {"per_kernel_ms_timed_region": ms, "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
+             "algorithmic_bytes_per_pair_whole_path": bytes_per_pair, "index_build": ginfo, "sj_merge_ms": sj_ms.get("ms"),
+             "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s_sum_over_contexts": sum(float(rep.deviceMs[k]) for k in range(n_ctx)) / 1e3,
+                          "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(n_ctx)), "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)),
+                          "parse_busy_s": float(rep.parseBusy), "convert_busy_s": float(rep.convertBusy), "postmap_write_busy_s": float(rep.emitBusy),
+                          "convert_Mreads_s": n / float(rep.convertBusy) / 1e6 if rep.convertBusy > 0 else None,
+                          "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
+                          "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
+                          "finish_s": float(rep.finishSeconds), "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds)}}
     if dist is not None:
         dist.destroy_process_group()
+    # ---- kernel times for the roofline: ONE engine context (a launch has the GPU to itself); the timed region overlaps the launches of two contexts, so
+    # the HIP events around a launch there also cover the time slices of the other context's kernels
+    kms, kms_src = ms, "timed region (%d engine context(s))" % n_ctx
+    if world == 1 and not args.no_exclusive and n_ctx > max(1, int(rep.nDevices)):
+        try:
+            ex = exclusive_leg(args, idx, fq, run_dir, threads)
+            extra["kernel_ms_exclusive"] = ex
+            kms, kms_src = ex["per_kernel_ms"], "one-context leg of the same run (%d batches of %d pairs; the timed region overlaps two contexts)" % (4, args.reads)
+            log("kernel_ms_exclusive done")
+        except Exception as e:
+            extra["kernel_ms_exclusive"] = {"error": repr(e)[:300]}
+    dom = max(("k_seed_search", "k_windows", "k_stitch_win"), key=lambda k: kms[k])
+    dms, dbytes = kms[dom], kern[dom][1]
+    achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+    traffic = issue = None
+    try:        # HBM traffic / issue utilisation from rocprofv3 --pmc passes (profiles/README.md): only when taken on THIS kernel source and workload size
+        tj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads and dom in tj and tj[dom].get("kernel_src_sha") == kernel_src_sha(dom):
+            traffic = tj[dom].get("hbm_bytes_per_launch"); issue = tj[dom].get("valu_busy_frac")
+    except Exception:
+        pass
+    line = {
+        "metric": "million reads aligned/sec (whole node), 2x101 bp PE human-scale index, FASTQ in -> SAM out",
+        "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/u64 integer", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2 stand-in: synthetic %d Mb genome, %d annotated junctions, %.1f GB index in HBM, %d distinct pairs 2x%d per GPU as %d+%d batches of %d; "
+                               "FASTQ text in -> SAM + SJ.out.tab out, index load excluded"
+                               % (mb, ginfo.get("junctions_in_index", 0), ginfo.get("index_bytes", 0) / 1e9, n_total, args.read_len, args.warmup, args.steps, args.reads),
+                   "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads, "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)),
+                   "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": traffic, "issue": issue, "kernel_ms": round(dms, 3), "algorithmic_bytes_per_launch": int(dbytes),
+                     "per_kernel_ms": {k: round(kms[k], 2) for k in ("k_seed_search", "k_windows", "k_stitch_win", "device_total")},
+                     "kernel_ms_source": kms_src, "algorithmic_bytes_per_pair_whole_path": round(bytes_per_pair, 1)},
+    }
+    if selftest:
+        line["selftest"] = "plumbing test on CPU (oracle behind the front end, gloo): NOT a measurement"
     ref_prefix = os.path.join(run_dir, "cpu_")
     if not args.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(idx, fq, ref_prefix, n_total, log)
+            cb = cpu_baseline(idx, fq, ref_prefix, n_total, log)
+            extra["cpu_baseline"] = cb
+            line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "best_threads", "best_value", "sample")}
         except Exception as e:
-            out["cpu_baseline"] = {"error": repr(e)[:400]}
+            line["cpu_baseline"] = {"error": repr(e)[:300]}
         log("cpu_baseline done")
         try:
-            out["full_size_parity"] = full_size_parity(ref_prefix, outp)
+            fp = full_size_parity(ref_prefix, outp)
+            line["full_size_parity"] = fp
             log("full_size_parity done")
         except Exception as e:
-            out["full_size_parity"] = {"error": repr(e)[:300]}
+            line["full_size_parity"] = {"error": repr(e)[:300]}
+    line["loaded_libs"] = loaded_libs()
+    # ---- everything else: a child process writes it to bench_extra.json (a GPU fault in an optional leg must not cost the line)
+    extra_path = os.path.join(args.workdir, "bench_extra.json")
+    extra["notes"] = notes; extra["line"] = line
+    json.dump(extra, open(extra_path, "w"))
     if world == 1 and not args.no_extra_legs:
-        for name, fn in (("kernel_ms_exclusive", lambda: exclusive_leg(args, idx, fq, run_dir, threads)),
-                         ("host_budget", lambda: host_budget_leg(args, idx, fq, run_dir)),
-                         ("all_transcripts", lambda: all_transcripts_leg(args, g, idx, log)),
-                         ("config1", lambda: config1_leg(args, log))):
-            if time.time() - T_START > args.budget_s:
-                out[name] = {"skipped": "time budget"}; continue
+        left = args.budget_s - (time.time() - T_START)
+        if left > 60:
             try:
-                out[name] = fn()
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--extra-legs-child", json.dumps({"argv": sys.argv[1:], "g": g, "idx": idx, "fq": fq, "run_dir": run_dir, "threads": threads,
+                                                                                                              "extra_path": extra_path, "t_start": T_START, "main_value": value, "main_ms": kms})],
+                               timeout=left + 120, check=False)
             except Exception as e:
-                out[name] = {"error": repr(e)[:400]}
-            log(name + " done")
-        ex = out.get("kernel_ms_exclusive")
-        if isinstance(ex, dict) and "per_kernel_ms" in ex and n_ctx > max(1, int(rep.nDevices)):
-            # The timed region runs two engine contexts per GPU: the HIP events around a launch then also cover the time slices the other context's
-            # launches get, i.e. they no longer measure the kernel.  The roofline figures are therefore taken from the one-context leg (same index,
-            # same reads, same process, minutes later: every launch has the GPU to itself, which is also what the committed rocprofv3 summary
-            # shows); the overlapped figures stay beside them.
-            r = out["roofline"]
-            r["per_kernel_ms_timed_region_two_contexts"] = r["per_kernel_ms"]; r["kernel_ms_timed_region_two_contexts"] = r["kernel_ms"]
-            r["per_kernel_ms"] = ex["per_kernel_ms"]
-            ems = ex["per_kernel_ms"]
-            kd = max(("k_seed_search", "k_windows", "k_stitch_win"), key=lambda k: ems[k])
-            r["kernel"] = kd; r["kernel_ms"] = ems[kd]
-            r["algorithmic_bytes_per_launch"] = kern[kd][1]
-            r["achieved"] = kern[kd][1] / (ems[kd] * 1e-3) / 1e9; r["frac"] = r["achieved"] / HBM_PEAK_GBS
-            if traffic_all:
-                r["traffic"] = traffic_all.get(kd)
-            r["kernel_launches"] = {"k_stitch_win": "the stitch stage of pass 0 = one k_stitch_lane launch (lane per read, cheapest cost classes) + one k_stitch_win launch (wavefront per window, the rest)",
-                                    "k_windows": "k_windows x 2 + k_windows_big"}
-            r["note"] = ("per launch = per batch of %d pairs; kernel times by HIP events on the engine's stream in the ONE-context leg (kernel_ms_exclusive: %d batches, a launch has "
-                         "the GPU to itself); the timed region runs two contexts per GPU whose launches overlap (per_kernel_ms_timed_region_two_contexts)" % (args.reads, 4))
-    if not args.no_sweep and world == 1:
-        out["index_size_sweep"] = sweep(args, mb, out, log)
-    if not args.no_two_pass and world == 1 and time.time() - T_START < args.budget_s:
-        try:
-            out["two_pass_end_to_end"] = two_pass(args, idx, fq, run_dir, threads)
-        except Exception as e:
-            out["two_pass_end_to_end"] = {"error": repr(e)[:300]}
-    if world == 1 and not args.no_extra_legs and isinstance(out.get("kernel_ms_exclusive"), dict) and "per_kernel_ms" in out["kernel_ms_exclusive"]:
-        # last: kernels that have never run on hardware are timed here, each in a child process with a time limit; nothing else of the line depends on them
-        try:
-            out["variants"] = variants_leg(args, idx, fq, run_dir, threads, out["kernel_ms_exclusive"], log)
-        except Exception as e:
-            out["variants"] = {"error": repr(e)[:300]}
-        log("variants done")
-    out["bench_wall_s"] = time.time() - T_START
-    out["notes"] = notes
-    print(json.dumps(out))
+                log("extra legs: " + repr(e)[:200])
+    line["extra"] = extra_path
+    try:
+        keep = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(keep):
+            import shutil
+            shutil.copy(extra_path, os.path.join(keep, "bench_extra.json"))
+    except Exception:
+        pass
+    line["bench_wall_s"] = round(time.time() - T_START, 1)
+    s = json.dumps(line)
+    if len(s) > 3900:           # the driver reads the tail of stdout: the line must stay under 4 KB whatever a leg put into it
+        for k in ("full_size_parity", "loaded_libs"):
+            if len(s) > 3900 and isinstance(line.get(k), (dict, list)):
+                line[k] = str(line[k])[:200]; s = json.dumps(line)
+        if len(s) > 3900:
+            line["config"]["workload"] = line["config"]["workload"][:300]; line.get("cpu_baseline", {}).pop("sample", None); s = json.dumps(line)
+    print(s, flush=True)
+
+
+PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"
 
 
 def _cli_leg(argv, lread, env=None):
@@ -624,7 +592,7 @@ def _cli_leg(argv, lread, env=None):
     for k, v in (env or {}).items():
         old[k] = os.environ.get(k); os.environ[k] = v
     try:
-        rc, rep = run_cli(argv)
+        rc, rep = _run_cli(argv)
     finally:
         for k, v in old.items():
             if v is None:
@@ -644,81 +612,47 @@ def _cli_leg(argv, lread, env=None):
 
 
 def exclusive_leg(args, idx, fq, run_dir, threads):
-    """Per-kernel times with ONE engine context (no second batch sharing the GPU): what a launch costs when it has the device to itself.  The bench
-    line's own per_kernel_ms are taken in the timed region, where the launches of two contexts overlap."""
+    """Per-kernel times with ONE engine context (no second batch sharing the GPU): what a launch costs when it has the device to itself.  The
+    per_kernel_ms of the timed region are taken where the launches of two contexts overlap."""
     nb, w = 4, 1
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "excl_"), "--runThreadN", str(threads),
-            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(min((nb + w), args.steps + args.warmup) * args.reads)]
     rep, d = _cli_leg(argv, 2 * args.read_len + 1, {"STARAMD_CONTEXTS_PER_GPU": "1"})
     return d
 
 
-# kernels / knobs that are OFF by default because they have no hardware number yet (written when no GPU minutes were left): the leg below times each of them
-# exactly like kernel_ms_exclusive (one context, same index, same reads) and checks its output against that leg's, so that the bench run at the end of a round is
-# also their A/B.  A variant that wins becomes the default (and leaves this list) in the next round; one that loses is deleted.
-VARIANTS = [      # (most wanted first: the leg has a time budget of its own)
-    ("base_repeat", {}),      # the default kernels once more, in a child like the others: what two identical runs differ by
-    ("seed_read_4waves", {"STARAMD_SEED_FLAT": "4"}),
-    ("seed_staged_4waves", {"STARAMD_SEED_FLAT": "6"}),
-    ("seed_flat_8waves", {"STARAMD_SEED_FLAT": "1"}),
-    ("lane_class_post_2", {"STARAMD_LANE_CLASS_POST": "2"}),
-    ("seed_flat_4waves", {"STARAMD_SEED_FLAT": "3"}),
-    ("seed_read_6waves", {"STARAMD_SEED_FLAT": "5"}),
-    ("lane_class_post_1", {"STARAMD_LANE_CLASS_POST": "1"}),
-    ("lane_class_post_2_cap6", {"STARAMD_LANE_CLASS_POST": "2", "STARAMD_LANE_CLASS": "6"}),
-    ("seed_flat_6waves", {"STARAMD_SEED_FLAT": "2"}),
-    ("seed_read_4waves_half_grid", {"STARAMD_SEED_FLAT": "4", "STARAMD_SEED_LANES": "131072"}),      # ~3 reads per lane instead of ~1.5: better balance inside a wavefront, fewer wavefronts in flight
-    # not a kernel: the same 2 M pairs as 1 + 1 batches of a million (the launches of a batch end in tails of a few wavefronts; per pair they weigh less in a larger batch)
-    ("batch_1M", {"_batch_reads": "1000000"}),
-]
+def extra_legs_child(spec):
+    """the optional legs, in a process of their own; results merged into bench_extra.json after every leg"""
+    global T_START
+    sys.argv = [sys.argv[0]] + spec["argv"]
+    args = parse()
+    T_START = spec["t_start"]
+    g, idx, fq, run_dir, threads, path = spec["g"], spec["idx"], spec["fq"], spec["run_dir"], spec["threads"], spec["extra_path"]
+    extra = json.load(open(path))
+    notes = extra.setdefault("notes", [])
 
+    def log(s):
+        notes.append("[%.0f s] %s" % (time.time() - T_START, s))
+        print("bench: " + notes[-1], file=sys.stderr, flush=True)
 
-def variants_leg(args, idx, fq, run_dir, threads, base, log):
-    """A/B of the experimental kernels against the defaults of the kernel_ms_exclusive leg (`base` = its summary; its output files are the reference here)."""
-    nb, w = 4, 1
-    res = {"what": "experimental kernels / knobs, OFF by default, timed like kernel_ms_exclusive (ONE engine context, %d batches of %d pairs) and compared with its output "
-                   "(SAM multiset, SJ.out.tab); base = the default kernels in the same process" % (nb, args.reads),
-           "base_per_kernel_ms": base.get("per_kernel_ms")}
-    base_prefix = os.path.join(run_dir, "excl_")
-    base_dig = sam_digest(base_prefix + "Aligned.out.sam")
-    base_sj = open(base_prefix + "SJ.out.tab", "rb").read()
-    timed_out = set()
-    t_leg = time.time()
-    for name, env in VARIANTS:
-        if time.time() - t_leg > 600:
-            res[name] = {"skipped": "the leg's own time budget (600 s)"}; continue
+    legs = [("host_budget", lambda: host_budget_leg(args, idx, fq, run_dir)),
+            ("config5_default_flags", lambda: config5_leg(args, g, idx, log, chim_detection=False)),
+            ("config5_chimeric_detection", lambda: config5_leg(args, g, idx, log, chim_detection=True)),
+            ("config1", lambda: config1_leg(args, log))]
+    if not args.no_two_pass:
+        legs.append(("two_pass_end_to_end", lambda: two_pass(args, idx, fq, run_dir, threads)))
+    if not args.no_sweep:
+        legs.append(("index_size_sweep", lambda: sweep(args, args.genome_mb, spec["main_value"], spec["main_ms"], log)))
+    for name, fn in legs:
         if time.time() - T_START > args.budget_s:
-            res[name] = {"skipped": "time budget"}; continue
-        pre = os.path.join(run_dir, "var_")
-        total = (nb + w) * args.reads
-        breads = int(env.get("_batch_reads", args.reads))
-        wreads = w * args.reads if breads == args.reads else breads            # (a different batch size: one warm-up batch, the rest timed; the same reads in all)
-        argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", pre, "--runThreadN", str(threads),
-                "--gpuBatchReads", str(breads), "--benchWarmupReads", str(wreads), "--readMapNumber", str(total)]
-        try:
-            e = {k: v for k, v in env.items() if not k.startswith("_")}; e["STARAMD_CONTEXTS_PER_GPU"] = "1"
-            # in a child interpreter: a kernel that has never run on hardware may fault, and a GPU memory fault aborts the process it happens in
-            for f in ("Aligned.out.sam", "SJ.out.tab"):
-                if os.path.exists(pre + f):
-                    os.remove(pre + f)
-            fam = "_".join(name.split("_")[:2])
-            if fam in timed_out:
-                res[name] = {"env": env, "skipped": "an earlier variant of this family ran into its time limit"}; continue
+            extra[name] = {"skipped": "time budget"}
+        else:
             try:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--variant-child", json.dumps([argv, 2 * args.read_len + 1, e])], timeout=180, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            except subprocess.TimeoutExpired:
-                timed_out.add(fam)
-                raise RuntimeError("time limit (180 s)")
-            if p.returncode != 0:
-                raise RuntimeError("child exit code %d: %s" % (p.returncode, p.stderr[-200:]))
-            d = json.loads(p.stdout.strip().splitlines()[-1])
-            dig = sam_digest(pre + "Aligned.out.sam")
-            res[name] = {"env": env, "batch_pairs": breads, "per_kernel_ms": d["per_kernel_ms"], "Mreads_s": d["Mreads_s"], "lane_items_per_pair": d["counters_per_pair"].get("nLaneItems"),
-                         "sam_multiset_identical_to_base": dig == base_dig, "sj_out_tab_identical_to_base": open(pre + "SJ.out.tab", "rb").read() == base_sj}
-        except Exception as ex:
-            res[name] = {"env": env, "error": repr(ex)[:300]}
-        log("variant %s done" % name)
-    return res
+                extra[name] = fn()
+            except Exception as e:
+                extra[name] = {"error": repr(e)[:400]}
+            log(name + " done")
+        json.dump(extra, open(path, "w"))
 
 
 def host_budget_leg(args, idx, fq, run_dir):
@@ -726,39 +660,42 @@ def host_budget_leg(args, idx, fq, run_dir):
     th = max(4, (os.cpu_count() or 8) // 8)
     nb, w = 8, 2
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "hb_"), "--runThreadN", str(th),
-            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str((nb + w) * args.reads)]
+            "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(min(nb + w, args.steps + args.warmup) * args.reads)]
     rep, d = _cli_leg(argv, 2 * args.read_len + 1)
     d["host_threads"] = th
     d["what"] = "one GPU, --runThreadN = cores / 8: the host share of one rank on an 8-GPU node"
     return d
 
 
-def all_transcripts_leg(args, g, idx, log):
-    """2x150, 1 % errors, 5 % chimeric pairs, --chimSegmentMin 12: chimeric detection wants EVERY transcript of every window
-    (resultSelect 0, no window pruning: stitchWindowAligns.cpp:245-247).  Same index (sjdbOverhang 100).  Parity against the reference on a bounded
-    sample: SAM multiset, SJ.out.tab, Chimeric.out.junction."""
+def config5_leg(args, g, idx, log, chim_detection):
+    """2x150, 1 % errors, 5 % chimeric pairs.  chim_detection False: default flags (chimeric detection off,
+    /root/reference/source/parametersDefault:690): window pruning on, 301-base reads, 4 starts per mate -- multi-window stitching, extendAlign soft clips and
+    the "too short" path.  True: --chimSegmentMin 12, where chimeric detection wants EVERY transcript of every window (resultSelect 0, no window
+    pruning: stitchWindowAligns.cpp:245-247).  Same index (sjdbOverhang 100).  Parity against the reference on the first 200 k pairs: SAM multiset,
+    SJ.out.tab, Log counters (+ Chimeric.out.junction)."""
     from oracle import refstar
     L = 150; nb, w = 4, 1
     n_total = (nb + w) * args.reads
     rd = os.path.join(g, "chim_n%d" % n_total)
     fq = make_reads(args, g, rd, "chim", n_total, 8100, read_len=L, chim_rate=0.05)
-    flags = ["--chimSegmentMin", "12", "--chimOutType", "Junctions"]
-    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"), "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))),
+    flags = ["--chimSegmentMin", "12", "--chimOutType", "Junctions"] if chim_detection else []
+    tag = "cd_" if chim_detection else "df_"
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, tag + "gpu_"), "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)] + flags
     rep, d = _cli_leg(argv, 2 * L + 1)
-    d["workload"] = "%d pairs 2x%d, 1%% substitutions, 5%% chimeric pairs, --chimSegmentMin 12 (every transcript of every window returned, no window pruning)" % (n_total, L)
-    # parity on a sample both can do quickly: the first 200 k pairs
+    d["workload"] = "%d pairs 2x%d, 1%% substitutions, 5%% chimeric pairs, %s" % (n_total, L, "--chimSegmentMin 12 (every transcript of every window returned, no window pruning)" if chim_detection else "default flags (chimeric detection off)")
     ns = min(200000, n_total)
-    p_new, p_ref = os.path.join(rd, "gpuS_"), os.path.join(rd, "ref_")
-    rc, _ = run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "32", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)] + flags)
+    p_new, p_ref = os.path.join(rd, tag + "gpuS_"), os.path.join(rd, tag + "ref_")
+    rc, _ = _run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "32", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)] + flags)
     if rc:
         raise RuntimeError("sample run: exit code %d" % rc)
     t = time.perf_counter()
     refstar.align(idx, fq, p_ref, threads=min(64, os.cpu_count() or 8), extra=["--readMapNumber", str(ns)] + flags, timeout=900)
     d["reference_sample_s"] = time.perf_counter() - t
     par = full_size_parity(p_ref, p_new) or {}
-    cj = [sorted(l for l in open(p + "Chimeric.out.junction", "rb") if not l.startswith(b"#")) for p in (p_ref, p_new)]
-    par["chimeric_junctions"] = len(cj[1]); par["chimeric_junction_identical"] = cj[0] == cj[1]
+    if chim_detection:
+        cj = [sorted(l for l in open(p + "Chimeric.out.junction", "rb") if not l.startswith(b"#")) for p in (p_ref, p_new)]
+        par["chimeric_junctions"] = len(cj[1]); par["chimeric_junction_identical"] = cj[0] == cj[1]
     d["parity_vs_reference"] = par; d["parity_sample_pairs"] = ns
     return d
 
@@ -780,7 +717,7 @@ def config1_leg(args, log):
     d["workload"] = "%d single-end reads 1x50, synthetic %d Mb genome (yeast size), SAindex %d bases" % (n_total, mb, ginfo.get("SAindexNbases", 0))
     ns = 100000
     p_new, p_ref = os.path.join(rd, "gpuS_"), os.path.join(rd, "ref_")
-    rc, _ = run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "16", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)])
+    rc, _ = _run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "16", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)])
     if rc:
         raise RuntimeError("sample run: exit code %d" % rc)
     t = time.perf_counter(); refstar.align(idx, fq, p_ref, threads=1, extra=["--readMapNumber", str(ns)], timeout=900); t_full = time.perf_counter() - t
@@ -790,7 +727,7 @@ def config1_leg(args, log):
     return d
 
 
-def sweep(args, main_mb, main_out, log):
+def sweep(args, main_mb, main_value, main_ms, log):
     """The same pipeline on smaller indices (100 / 400 / 1000 Mb): how the kernels behave as the index outgrows the 256 MB Infinity Cache."""
     rows = []
     lread = 2 * args.read_len + 1
@@ -805,7 +742,7 @@ def sweep(args, main_mb, main_out, log):
             fq = make_reads(args, g, rd, "reads", n_total, 9000 + mb)
             argv = ["--runMode", "alignReads", "--genomeDir", os.path.join(g, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"),
                     "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))), "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)]
-            rc, rep = run_cli(argv)
+            rc, rep = _run_cli(argv)
             if rc:
                 rows.append({"genome_mb": mb, "error": "exit code %d" % rc}); continue
             c, ms, kern, bpp = report_dict(rep, lread)
@@ -813,19 +750,17 @@ def sweep(args, main_mb, main_out, log):
                          "junctions_in_index": ginfo.get("junctions_in_index"), "algorithmic_bytes_per_pair": bpp})
         except Exception as e:
             rows.append({"genome_mb": mb, "error": repr(e)[:300]})
-    rows.append({"genome_mb": main_mb, "Mreads_s": main_out["value"], "per_kernel_ms": main_out["roofline"]["per_kernel_ms"],
-                 "index_generate_s": main_out["index_build"].get("index_generate_s"), "junctions_in_index": main_out["index_build"].get("junctions_in_index"),
-                 "algorithmic_bytes_per_pair": main_out["roofline"]["algorithmic_bytes_per_pair_whole_path"]})
+    rows.append({"genome_mb": main_mb, "Mreads_s": main_value, "per_kernel_ms": main_ms})
     return rows
 
 
 def two_pass(args, idx, fq, run_dir, threads):
-    """--twopassMode Basic on two batches of the workload: 1st pass on the GPU without SAM, junction insertion, index
-    replaced in HBM, 2nd pass."""
-    n = min(10, args.steps + args.warmup) * args.reads          # (4 M pairs in the default run: the insertion is amortised as in a real run)
+    """--twopassMode Basic on the first 10 batches of the workload (4 M pairs at the default size): 1st pass on the GPU without SAM,
+    junction insertion into the resident index, 2nd pass."""
+    n = min(10, args.steps + args.warmup) * args.reads
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "cli2p_"), "--runThreadN", str(threads),
             "--gpuBatchReads", str(args.reads), "--twopassMode", "Basic", "--readMapNumber", str(n)]
-    rc, rep = run_cli(argv)
+    rc, rep = _run_cli(argv)
     if rc:
         return {"error": "exit code %d" % rc}
     sjdb = sum(1 for _ in open(os.path.join(run_dir, "cli2p__STARgenome", "sjdbList.out.tab")))
@@ -837,11 +772,9 @@ def two_pass(args, idx, fq, run_dir, threads):
 if __name__ == "__main__":
     if sys.argv[1:2] == ["--make-reads"]:
         _make_reads_child(*json.loads(sys.argv[2]))
-    elif sys.argv[1:2] == ["--variant-child"]:
-        _argv, _lread, _env = json.loads(sys.argv[2])
-        _rep, _d = _cli_leg(_argv, _lread, _env)
-        print(json.dumps(_d))
     elif sys.argv[1:2] == ["--sam-digest"]:
         print("%d %d" % _sam_digest_child(sys.argv[2]))
+    elif sys.argv[1:2] == ["--extra-legs-child"]:
+        extra_legs_child(json.loads(sys.argv[2]))
     else:
         main()

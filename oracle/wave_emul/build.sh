@@ -11,13 +11,13 @@ if [ "$1" = asan ]; then SAN="-fsanitize=address -fno-omit-frame-pointer"; FL="$
 #   build.sh variant <tag> <defines>   e.g. build.sh variant w5 -DWIN_WAVES=5  ->  oracle/_build/libstaramd_emul_w5.so  (kernel variants behind compile-time switches)
 if [ "$1" = variant ]; then FL="$FL $3"; O=oracle/_build/emul_$2; OUT=oracle/_build/libstaramd_emul_$2.so; SAN=" "; fi
 mkdir -p $O
-for f in k_window k_seed k_seed_flat k_gather k_stitch_lane engine; do $CL $FL -c star_amd/csrc/engine/$f.hip -o $O/$f.o & done
+for f in k_window k_seed k_gather k_stitch_lane engine; do $CL $FL -c star_amd/csrc/engine/$f.hip -o $O/$f.o & done
 $CL $FL -fno-unroll-loops -c star_amd/csrc/engine/k_stitch.hip -o $O/k_stitch.o &
 $CL $FL -c star_amd/csrc/index/index_gpu.hip -o $O/index_gpu.o &
 $CL -std=c++17 -O1 -g -fPIC $SAN -D_GNU_SOURCE -c oracle/wave_emul/emu.cpp -o $O/emu.o &
 $CL -std=c++17 -O1 -g -fPIC $SAN -c oracle/wave_emul/emu_lds.cpp -o $O/emu_lds.o &
 wait
-for f in k_window k_seed k_seed_flat k_gather k_stitch_lane engine k_stitch index_gpu emu emu_lds; do test -s $O/$f.o; done
+for f in k_window k_seed k_gather k_stitch_lane engine k_stitch index_gpu emu emu_lds; do test -s $O/$f.o; done
 $CL -shared -fPIC $SAN -shared-libsan $O/*.o -o $OUT -ldl
 [ -n "$SAN" ] && exit 0
 $CL -x c++ -std=c++17 -O1 -g -Wno-unknown-attributes -D_GNU_SOURCE -I oracle/wave_emul -I star_amd/csrc/engine -I include oracle/wave_emul/selftest.cpp oracle/wave_emul/emu.cpp oracle/wave_emul/emu_lds.cpp -o oracle/_build/wave_emul_selftest -ldl

@@ -101,12 +101,12 @@ typedef emuStream *hipStream_t;
 struct emuEvent { std::chrono::steady_clock::time_point t; };
 typedef emuEvent *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-struct hipDeviceProp_t { char name[256]; size_t totalGlobalMem; int multiProcessorCount; };
+struct hipDeviceProp_t { char name[256]; size_t totalGlobalMem; int multiProcessorCount; size_t sharedMemPerBlock; };
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory (wave emulator)" : "error (wave emulator)"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "wave emulator"); p->totalGlobalMem = (size_t)64 << 30; p->multiProcessorCount = 2; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "wave emulator"); p->totalGlobalMem = (size_t)64 << 30; p->multiProcessorCount = 2; p->sharedMemPerBlock = 65536; return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
 // device memory is not cleared by hipMalloc: a recognisable pattern instead of zeros, so that a kernel that reads what nobody wrote shows up
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xA5, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }

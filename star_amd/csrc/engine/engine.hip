@@ -13,18 +13,9 @@
 #include <vector>
 
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
-extern "C" __global__ void k_seed_search_flat(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);      // k_seed_flat.hip: STARAMD_SEED_FLAT=1 (8 waves per SIMD), 2 (6), 3 (4)
-extern "C" __global__ void k_seed_search_flat6(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
-extern "C" __global__ void k_seed_search_flat4(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
-extern "C" __global__ void k_seed_search_read4(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);     // the whole read as one state machine: 4 (4 waves per SIMD), 5 (6)
-extern "C" __global__ void k_seed_search_read6(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
-extern "C" __global__ void k_seed_search_staged4(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);   // 6: ... with the read staged in LDS (dynamic LDS: 256 * (packWords | 1) words)
-typedef void (*SeedKernel)(const DevIndex *, DevBatch, DSeed *, u32);
-static SeedKernel seedKernel(u32 flat) { return flat == 1 ? k_seed_search_flat : flat == 2 ? k_seed_search_flat6 : flat == 3 ? k_seed_search_flat4 : flat == 4 ? k_seed_search_read4 : flat == 5 ? k_seed_search_read6 : flat == 6 ? k_seed_search_staged4 : k_seed_search; }
-static const char *seedKernelName(u32 flat) { return flat == 1 ? "k_seed_search_flat" : flat == 2 ? "k_seed_search_flat6" : flat == 3 ? "k_seed_search_flat4" : flat == 4 ? "k_seed_search_read4" : flat == 5 ? "k_seed_search_read6" : flat == 6 ? "k_seed_search_staged4" : "k_seed_search"; }
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
-extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits, u32 classSlack);
-extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid, u32 classSlack);
+extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);
+extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid);
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
 extern "C" __global__ void k_order_scatter(DevBatch B);
@@ -68,7 +59,7 @@ struct staramd_ctx {
     u32 *dPacked = nullptr; u32 packWordsCap = 0;
     int nCU = 256;
     // seed kernel: one lane per read
-    u32 seedLanes = 0; DSeed *scrSeed = nullptr; u32 seedPerLane = 0; u32 seedFlat = 0; u32 classSlack = 0;
+    u32 seedLanes = 0; DSeed *scrSeed = nullptr; u32 seedPerLane = 0;
     // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
@@ -81,7 +72,9 @@ struct staramd_ctx {
     // wavefronts are resident per CU; the others are handed to a second launch with the full-size slice (0 = one full-size launch)
     u32 leanDepth = 0, leanArena = 0, stBlocksLean = 0;
     // lane-per-read stitcher (k_stitch_lane.hip): takes the light reads whose windows hold few seeds; the cooperative kernel gets the rest
-    u32 laneBlocks = 0, laneArenaBytes = 0; u8 *scrLane = nullptr;
+    u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 5; u8 *scrLane = nullptr;
+    u32 prune = 3;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first
+    u32 ldsLimit = 65536;                 // dynamic LDS a block may ask for
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
@@ -204,7 +197,7 @@ template <class T> static int devRealloc(std::vector<void *> &reg, T **p, u64 n)
 static int allocWork(staramd_ctx *c) {
     std::vector<void *> &R = c->workAllocs;
     u32 N = c->maxReads; int rc;
-    hipDeviceProp_t prop;
+    hipDeviceProp_t prop; memset(&prop, 0, sizeof(prop));
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->nCU = prop.multiProcessorCount;
     // 64 bytes of padding either side: the seed search compares 8 bases per step and may read a few bytes past a read
     { u8 *raw = nullptr; if ((rc = devAlloc(R, &raw, c->maxBases + 192))) return rc; if (hipMemset(raw, 4, c->maxBases + 192) != hipSuccess) { g_err = "hipMemset failed"; return STARAMD_ERR_DEVICE; } c->dBases = raw + 64; }
@@ -249,8 +242,7 @@ static int allocWork(staramd_ctx *c) {
     const staramd_params &P = c->X.P;
     // ---- seed kernel: one lane per read, PC table per lane sized by the reference's seedPerReadNmax
     int seedPerCU = 2;
-    c->seedFlat = std::min<u32>(envU32("STARAMD_SEED_FLAT", 0), 6);          // the seed search as a state machine around one load site (k_seed_flat.hip); same results
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&seedPerCU, seedKernel(c->seedFlat), 256, 0) != hipSuccess || seedPerCU < 1) seedPerCU = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&seedPerCU, k_seed_search, 256, 0) != hipSuccess || seedPerCU < 1) seedPerCU = 2;
     u32 lanes = envU32("STARAMD_SEED_LANES", (u32)c->nCU * (u32)seedPerCU * 256u);
     lanes = std::max<u32>(256, std::min<u32>(lanes, ((N + 255) / 256) * 256));
     c->seedLanes = (lanes / 256) * 256;
@@ -258,7 +250,8 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->classSlack = envU32("STARAMD_LANE_CLASS_POST", 0);      // experimental: a light read is classed by its two-mate windows when everything is at most this many classes above them (k_window.hip)
+    c->prune = envU32("STARAMD_PRUNE", 3); c->laneClass = envU32("STARAMD_LANE_CLASS", 5);          // (knobs are read here, once: not on the launch path)
+    if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
     c->capW = envU32("STARAMD_CAP_WINDOWS", 256); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
     int winPerCU = 3;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * (c->capW * 8 + 128) * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
@@ -289,7 +282,7 @@ static int allocWork(staramd_ctx *c) {
     size_t ldsFast = 4 * (size_t)(stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast) + 27 * 4 + 16);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&stPerCU, k_stitch_win, 256, ldsFast) != hipSuccess || stPerCU < 1) stPerCU = 2;
     c->stBlocks = (u32)c->nCU * envU32("STARAMD_STITCH_BLOCKS_PER_CU", (u32)stPerCU);
-    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win %d blocks/CU (LDS %zu B/block), k_windows %d blocks/CU, %s %d blocks/CU\n", stPerCU, ldsFast, winPerCU, seedKernelName(c->seedFlat), seedPerCU);
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win %d blocks/CU (LDS %zu B/block), k_windows %d blocks/CU, k_seed_search %d blocks/CU\n", stPerCU, ldsFast, winPerCU, seedPerCU);
     // the replay kernel needs no walk stack and no read in LDS: more blocks per CU hide the latency of its candidate-log reads
     {
         int rpPerCU = stPerCU;
@@ -519,17 +512,15 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[0], s));
     {
         u32 lanes = std::min<u32>(c->seedLanes, ((n + 255) / 256) * 256);
-        const size_t seedLds = c->seedFlat == 6 ? 256 * (size_t)(B.packWords | 1u) * 4 : 0;      // the staged form keeps every lane's packed read in LDS
-        hipLaunchKernelGGL(seedKernel(c->seedFlat), dim3(lanes / 256), block, seedLds, s, c->dX, B, c->scrSeed, c->seedPerLane);
+        hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane);
     }
     HIPCHK(hipEventRecord(c->ev[1], s));
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
         const u32 useMid = c->capWMid ? 1u : 0u;
-        const u32 classSlack = c->classSlack;
-        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, 4096u, classSlack);
-        if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + c->hashBitsMid / 32) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid, c->hashBitsMid, classSlack);
-        hipLaunchKernelGGL(k_windows_big, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, c->lightEst, useMid, classSlack);
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, 4096u);
+        if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + c->hashBitsMid / 32) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid, c->hashBitsMid);
+        hipLaunchKernelGGL(k_windows_big, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, c->lightEst, useMid);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
         hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(1), 0, s, B);
@@ -539,11 +530,14 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     {
         size_t readBytes = (ldsWords * 4u + 15u) & ~15u;
         size_t ldsFast = 4 * (readBytes + stitchStateBytesH(c->capDepth, c->capRank, c->arenaFast));
-        const u32 prune = envU32("STARAMD_PRUNE", 3);       // bit 0: window pruning, bit 1: two-mate windows of a light read first
+        const u32 prune = c->prune;
+        // the lane kernel keeps the packed read of each of its 256 lanes in LDS: reads beyond ~512 bases (2x250 and longer) do not fit into what a block
+        // may ask for, and the batch takes the cooperative launches alone (same results: the class cap only picks the kernel)
+        const bool laneFits = 256 * (size_t)ldsWords * 4 <= c->ldsLimit;
         size_t ldsLean = c->leanDepth ? 4 * (readBytes + stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena)) : 0;
         for (u32 mode = 0; mode < 2; mode++) {
-            if (mode == 0 && c->laneBlocks) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
-                hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, envU32("STARAMD_LANE_CLASS", 5));
+            if (mode == 0 && c->laneBlocks && laneFits) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
+                hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, c->laneClass);
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
             } else
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest

@@ -227,7 +227,7 @@ extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 +
 // mode 0: every read, table in LDS (capW rows); reads that outgrow it go to list ovfWin
 // mode 2: the reads of ovfWin, table still in LDS but with more rows (blocks of one wavefront); reads that outgrow that go to list ovfWin2
 // mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits (BIG)
-template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits, u32 classSlack) {
+template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
     const u32 big = BIG ? 1u : 0u;
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
@@ -397,7 +397,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
             wo = first32(wo); ao = first32(ao); io = first32(io);
             if (wo + nOut > B.winCap || ao + nWA > B.waCap || io + nIt > B.winCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_WINPOOL); continue; }
             rd.winOffset = wo; rd.nWin = nOut;
-            const u32 ioRead = io; u32 est2 = 0;            // est2: the same estimate over the two-mate windows alone
+            const u32 ioRead = io;
             if (light && lane == 0) B.items[io] = 0x80000000u | ir;
             for (u32 j = 0; j < s.nW; j++) {
                 u32 n = s.t.nwa[j];
@@ -407,7 +407,6 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 u8 fr = 0;
                 if (lane < n) { const DWA row = A[lane]; fr = row.iFrag; B.waPool[ao + lane] = row; }
                 const u8 mates = (u8)((__ballot(lane < n && fr == 0) ? 1u : 0u) | (__ballot(lane < n && fr != 0) ? 2u : 0u));
-                if (mates == 3u) est2 += 1u << min(n, 20u);
                 if (lane == 0) {
                     DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.mates = mates; B.winPool[wo] = d;
                     if (!light) { B.items[io] = wo; B.itemClass[io] = (u8)min(n + 1u, 31u); io++; }
@@ -415,12 +414,8 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 wo++; ao += n;
             }
             if (light && lane == 0) {
-                // cost class of a light read = bits of its walk-size estimate (k_order_* sorts by it, k_stitch_lane takes the classes up to its cap).  With
-                // classSlack > 0 (STARAMD_LANE_CLASS_POST, experimental): a read that has two-mate windows AND others is classed by the two-mate windows alone --
-                // the sweep of the stitch kernels walks those first and, almost always, skips the rest unwalked, so that is its work in fact --
-                // as long as the class of everything is at most classSlack above it (the few reads that fail the bar walk everything on their lane)
-                u32 cls = 32u - (u32)__clz((int)est);
-                if (classSlack > 0 && est2 > 0 && est2 < est) { const u32 c2 = 32u - (u32)__clz((int)est2); if (cls <= c2 + classSlack) cls = c2; }
+                // cost class of a light read = bits of its walk-size estimate (k_order_* sorts by it, k_stitch_lane takes the classes up to its cap)
+                const u32 cls = 32u - (u32)__clz((int)est);
                 B.itemClass[ioRead] = (u8)cls;
             }
             nWAtot += nWA;
@@ -442,11 +437,11 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
 #ifndef WIN_WAVES
 #define WIN_WAVES 4         // minimum waves per SIMD the register allocation of the LDS launches is held to
 #endif
-extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits, u32 classSlack) {
-    windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits, classSlack);
+extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
+    windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits);
 }
-extern "C" __global__ void __launch_bounds__(256, 4) k_windows_big(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid, u32 classSlack) {
-    windowsBody<true>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid, WBITS, classSlack);
+extern "C" __global__ void __launch_bounds__(256, 4) k_windows_big(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid) {
+    windowsBody<true>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid, WBITS);
 }
 
 // ---- stitch order: work items sorted by class ~ log2(estimated walk size), largest first (counting sort

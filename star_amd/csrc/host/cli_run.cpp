@@ -54,8 +54,26 @@ template <class T> struct PinnedAlloc {
     typedef T value_type;
     PinnedAlloc() = default;
     template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
-    T *allocate(size_t n) { void *p = staramd_pinned_alloc((uint64_t)n * sizeof(T)); if (!p) throw std::bad_alloc(); return (T *)p; }
-    void deallocate(T *p, size_t) { staramd_pinned_free(p); }
+    // (page-locked memory is a limited resource: when the runtime has none left the array lives in ordinary memory -- the copies are then staged by the
+    // runtime, nothing else changes; an exception thrown on a mapper thread would end the process)
+    T *allocate(size_t n) {
+        void *p = staramd_pinned_alloc((uint64_t)n * sizeof(T));
+        if (p) return (T *)p;
+        { const size_t bytes = n * sizeof(T); p = malloc(bytes > 0 ? bytes : 1); }
+        if (!p) throw std::bad_alloc();
+        { std::lock_guard<std::mutex> l(pageableMutex()); pageable().push_back(p); }
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) {
+        {
+            std::lock_guard<std::mutex> l(pageableMutex());
+            std::vector<void *> &v = pageable();
+            for (size_t i = 0; i < v.size(); i++) if (v[i] == (void *)p) { v[i] = v.back(); v.pop_back(); free(p); return; }
+        }
+        staramd_pinned_free(p);
+    }
+    static std::vector<void *> &pageable() { static std::vector<void *> v; return v; }
+    static std::mutex &pageableMutex() { static std::mutex m; return m; }
     template <class U> void construct(U *p) { ::new ((void *)p) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
     template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }

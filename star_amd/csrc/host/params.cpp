@@ -206,6 +206,7 @@ std::string RunParams::parse(int argc, char **argv) {
             else if (v.size() == 1 && v[0] == "None") outSAMattrOrder.clear();
             else if (v.size() >= 1 && v[0] == "All") { outSAMattrOrder = {"NH", "HI", "AS", "nM", "NM", "MD", "jM", "jI", "MC", "ch"}; }   // + ch (Parameters_samAttributes.cpp:51-52)
             else { outSAMattrOrder.clear(); for (auto &t : v) { if (t == "NH" || t == "HI" || t == "AS" || t == "nM" || t == "jM" || t == "jI" || t == "XS" || t == "NM" || t == "MD" || t == "MC" || t == "RG" || t == "ch" || t == "vA" || t == "vG" || t == "vW" || t == "rB" || t == "cN") outSAMattrOrder.push_back(t); else err = "EXITING: unsupported SAM attribute " + t; } }
+            if (outSAMattrOrder.size() > 26) err = "EXITING because of fatal PARAMETERS error: --outSAMattributes lists more than 26 attributes";      // (+ up to 4 added below; the formatter holds 32)
         }
         else if (k == "outSAMstrandField") { const std::string &s = one(k, v); if (s == "intronMotif") { dev.outSAMstrandFieldIntronMotif = 1; } else if (s != "None") err = "EXITING: unsupported --outSAMstrandField " + s; }
         else if (k == "outSAMprimaryFlag") { const std::string &s = one(k, v); if (s == "AllBestScore") outSAMprimaryAllBest = true; else if (s != "OneBestScore") err = "EXITING: unsupported --outSAMprimaryFlag " + s; }

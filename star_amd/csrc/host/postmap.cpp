@@ -220,9 +220,11 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         const std::string *mateChrN = (nMates == 1 && chim && chim->mateChr < gi.view.nChrReal) ? &gi.chrName[chim->mateChr] : nullptr;
         const std::string *rg = nullptr;
         for (uint32_t k = 0; k < nAttr; k++) if (attr[k] == A_RG) rg = &P.outSAMattrRG.at(b.fileOf(ir));
-        // upper bound of the line: the variable-length parts + 16 numbers of at most 21 characters + tags and separators
-        const size_t bound = nm.size() + chrN.size() + (mateChrN ? mateChrN->size() : 0) + cigLen[0] + cigLen[1] + 2 * sq.size() + jmLen + jiLen + tagMD.size() + (rg ? rg->size() : 0) + xt.size()
-                             + 16 * 21 + 16 * nAttr + 64;
+        // upper bound of the line: the variable-length columns + 10 numbers of at most 21 characters + per attribute (a list may repeat an attribute) its tag,
+        // a number and the longest variable-length payload an attribute can carry
+        const size_t attrVar = std::max(std::max((size_t)jmLen, (size_t)jiLen), std::max(std::max((size_t)cigLen[0], (size_t)cigLen[1]), std::max(tagMD.size(), rg ? rg->size() : (size_t)0)));
+        const size_t bound = nm.size() + chrN.size() + (mateChrN ? mateChrN->size() : 0) + cigLen[0] + cigLen[1] + 2 * sq.size() + xt.size()
+                             + 10 * 21 + (size_t)nAttr * (8 + 21 + attrVar) + 64;
         const size_t base = out.size();
         out.resize(base + bound);
         char *p = &out[base];

@@ -84,6 +84,7 @@ std::string FastqReader::openCurrent() {
 
 std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand, int samMates) {
     closeFiles();
+    ioError = 0;                                    // (a read error of an earlier pass / file was reported then: not sticky)
     nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false; samMates_ = samMates; extras = samMates > 0;
     for (int i = 0; i < nMates; i++) {              // --readFilesIn a1,a2,... b1,b2,...: the files of a mate are read one after the other
         files_[i].clear();

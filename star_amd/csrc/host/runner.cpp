@@ -594,7 +594,8 @@ void sah_engines_ready(void *h) {
     // index, per process -- one process per GPU on a node) is not needed any more.  SAindex and genome stay (small; the SAM writer reads the genome)
     Runner *r = (Runner *)h;
     r->gi.engineHoldsIndex = true;
-    if (!r->generateMode && !getenv("STARAMD_KEEP_HOST_SA")) { std::vector<uint8_t>().swap(r->gi.SA); r->gi.view.SA = nullptr; }
+    // (--sjdbInsertSave All writes the suffix array into _STARgenome, also when no junction was inserted: it stays)
+    if (!r->generateMode && !r->P.sjdbInsertSaveAll && !getenv("STARAMD_KEEP_HOST_SA")) { std::vector<uint8_t>().swap(r->gi.SA); r->gi.view.SA = nullptr; }
 }
 int sah_index_in_engine(void *h) { Runner *r = (Runner *)h; int v = r->gi.indexInEngine ? 1 : 0; r->gi.indexInEngine = false; return v; }
 int sah_generate_mode(void *h) { return ((Runner *)h)->generateMode ? 1 : 0; }

@@ -271,7 +271,11 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
         }
     }
     lap("prepare");
-    if (sjdbN == 0) return "";                                           // sjdbBuildIndex.cpp:20-23
+    if (sjdbN == 0) {                                                    // sjdbBuildIndex.cpp:20-23: nothing to insert, the index stays as it is
+        // ... also in the engine contexts: they need the new tables / parameters only, not a re-upload (the host copy of the suffix array is gone by then)
+        if (g_sjdbResidentFn != nullptr && gi.engineHoldsIndex) gi.indexInEngine = true;
+        return "";
+    }
 
     // ---------------- sjdbBuildIndex (sjdbBuildIndex.cpp:16-333)
     Gsj[nGsj * 2] = SPACER;
@@ -553,6 +557,7 @@ std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, b
         };
         std::vector<uint64_t> hdr(1, gi.view.gSAindexNbases);
         for (uint32_t i = 0; i <= gi.view.gSAindexNbases; i++) hdr.push_back(gi.view.genomeSAindexStart[i]);
+        if (gi.SA.size() < gi.view.nSAbyte) return "EXITING because of fatal ERROR: --sjdbInsertSave All needs the suffix array on the host, which was released after the upload";
         if (!dump("Genome", gi.G.data(), gi.view.nGenome) || !dump("SA", gi.SA.data(), gi.view.nSAbyte) ||
             !dump("SAindex", gi.SAi.data(), gi.view.nSAibyte, hdr.data(), hdr.size() * 8))
             return "EXITING because of fatal ERROR: could not write the genome files into " + outDir;

@@ -146,18 +146,7 @@ FORCED = {
     "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
     "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
     "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
-    # experimental kernels / knobs that are OFF by default until they have a hardware number (bench.py leg `variants` times them at the end of a round):
-    "seed_flat": {"STARAMD_SEED_FLAT": "1"},                  # the seed search as a state machine around one load site (k_seed_flat.hip), 8 waves per SIMD
-    "seed_flat_4waves": {"STARAMD_SEED_FLAT": "3"},           # ... with 128 VGPRs
-    "seed_read": {"STARAMD_SEED_FLAT": "4"},                  # the whole read as one state machine (k_seed_search_read4)
-    "seed_read_6waves": {"STARAMD_SEED_FLAT": "5"},
-    "seed_staged": {"STARAMD_SEED_FLAT": "6"},                # ... with the read staged in LDS (k_seed_search_staged4)
-    "lane_class_post": {"STARAMD_LANE_CLASS_POST": "2"},      # light reads classed by their two-mate windows (k_window.hip): more of them go through the lane-per-read stitcher
-    "lane_class_post_wide": {"STARAMD_LANE_CLASS_POST": "8", "STARAMD_LANE_CLASS": "7"},
 }
-
-
-_EXPERIMENTAL_TIMED_OUT = []      # experimental cases that hit their time limit (a kernel that hangs on hardware must not cost the suite eight time limits)
 
 
 @pytest.mark.parametrize("case", sorted(FORCED))
@@ -167,19 +156,7 @@ def test_forced_rare_paths(case, tmp_path, built):
         pytest.skip("oracle/_ref/STAR missing")
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ); env.update(FORCED[case])
-    experimental = "STARAMD_SEED_FLAT" in FORCED[case] or "STARAMD_LANE_CLASS_POST" in FORCED[case]
-    if experimental and _EXPERIMENTAL_TIMED_OUT:
-        pytest.xfail("experimental, off by default: skipped after an earlier experimental case ran into its time limit")
-    try:
-        p = subprocess.run([sys.executable, os.path.join(here, "engine_run.py"), "pe150_indel", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150 if experimental else 600)
-        ok = p.returncode == 0 and (p.stdout.decode().strip().splitlines() or [""])[-1] == "OK"
-        msg = (p.stdout.decode() + p.stderr.decode())[-2000:]
-    except subprocess.TimeoutExpired:
-        ok, msg = False, "timeout"
-        if experimental:
-            _EXPERIMENTAL_TIMED_OUT.append(case)
-    if not ok and experimental:
-        # kernels / knobs that are OFF by default and have never run on hardware (written without a GPU; emulator-checked): what they do on the device is recorded
-        # here and by bench.py's `variants` leg, and does not decide whether the product's suite is green
-        pytest.xfail("experimental, off by default: " + msg[-600:])
+    p = subprocess.run([sys.executable, os.path.join(here, "engine_run.py"), "pe150_indel", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    ok = p.returncode == 0 and (p.stdout.decode().strip().splitlines() or [""])[-1] == "OK"
+    msg = (p.stdout.decode() + p.stderr.decode())[-2000:]
     assert ok, msg

@@ -61,7 +61,9 @@ CASES = [("se50", 150, []), ("pe101", 40, []), ("pe101", 25, ["--gpuResultSelect
          ("pe101", 30, ["--gpuResultSelect", "All", "--seedSearchLmax", "30", "--seedSearchStartLmax", "12"]),
          # --alignEndsProtrude + 5' clipping: the second mate starts before the first exon, the extension length of the mate-gap stitch is "negative"
          # (no extension in the reference: `(int) L` loop bound, extendAlign.cpp:59) -- found by the hardware fuzzer, k_stitch.hip coopExtendBody
-         ("pe125_protrude", 160, ["--gpuResultSelect", "All", "--alignEndsProtrude", "15", "ConcordantPair", "--clip5pNbases", "20", "20"])]
+         ("pe125_protrude", 160, ["--gpuResultSelect", "All", "--alignEndsProtrude", "15", "ConcordantPair", "--clip5pNbases", "20", "20"]),
+         # 2x300: the packed reads of a k_stitch_lane block outgrow its dynamic LDS; the batch takes the cooperative launches alone (engine.hip launchAll)
+         ("pe300", 12, [])]
 
 
 # every data set with one lane order, the paired-end set of the forced cases with both (tests/tools/fuzz_engine.py alternates the order over hundreds of
@@ -86,14 +88,6 @@ FORCED = {
     "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
     "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
     "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
-    # experimental kernels / knobs that are OFF by default until they have a hardware number (bench.py leg `variants` times them at the end of a round):
-    "seed_flat": {"STARAMD_SEED_FLAT": "1"},                  # the seed search as a state machine around one load site (k_seed_flat.hip), 8 waves per SIMD
-    "seed_flat_4waves": {"STARAMD_SEED_FLAT": "3"},           # ... with 128 VGPRs
-    "seed_read": {"STARAMD_SEED_FLAT": "4"},                  # the whole read as one state machine (k_seed_search_read4)
-    "seed_read_6waves": {"STARAMD_SEED_FLAT": "5"},
-    "seed_staged": {"STARAMD_SEED_FLAT": "6"},                # ... with the read staged in LDS (k_seed_search_staged4)
-    "lane_class_post": {"STARAMD_LANE_CLASS_POST": "2"},      # light reads classed by their two-mate windows (k_window.hip): more of them go through the lane-per-read stitcher
-    "lane_class_post_wide": {"STARAMD_LANE_CLASS_POST": "8", "STARAMD_LANE_CLASS": "7"},
 }
 
 
@@ -131,6 +125,16 @@ def test_front_end_two_pass_with_resident_junction_insertion(more, n, tmp_path, 
     staramd_update_tables behind cli_run.cpp's hook), 2nd pass -- every output file against one reference run with the same flags"""
     from test_cli_pipeline import run_cli_case
     run_cli_case(emul_cli, "pe101", more + ["--readMapNumber", str(n)], 40, tmp_path, env=SMALL)
+
+
+@pytest.mark.parametrize("more", [[], ["--sjdbInsertSave", "All"]])
+def test_front_end_two_pass_without_any_junction(more, tmp_path, emul_cli):
+    """2-pass on an index without annotation whose 1st pass yields NO junction (filters nobody passes): nothing is inserted, the engine contexts keep the
+    index they hold (the host copy of the suffix array is gone by then: a re-upload read a null pointer) and only get the new tables; with
+    --sjdbInsertSave All the unchanged suffix array is written into _STARgenome as the reference does"""
+    from test_cli_pipeline import run_cli_case
+    none = ["--outSJfilterCountUniqueMin", "1000000", "1000000", "1000000", "1000000", "--outSJfilterCountTotalMin", "1000000", "1000000", "1000000", "1000000"]
+    run_cli_case(emul_cli, "se50", ["--twopassMode", "Basic"] + none + more + ["--readMapNumber", "60"], 40, tmp_path, env=SMALL)
 
 
 def test_front_end_two_contexts_on_one_device(tmp_path, emul_cli):

@@ -34,16 +34,5 @@ run "STARAMD_LANE_CLASS=31" pe101 60 --gpuResultSelect All
 run "STARAMD_LANE_CLASS=31 STARAMD_LANE_ARENA=256" pe125_protrude 160
 # the experimental seed kernel (one load site, both words of a funnel load always read: the padding of the index arrays and of the read buffer is what makes that legal)
 # and the post-pruning cost class; stitching made cheap so that thousands of reads go through the seed search
-run "STARAMD_SEED_FLAT=1 STARAMD_LANE_CLASS_POST=2" se50 2000 --seedPerWindowNmax 5
-run "STARAMD_SEED_FLAT=1 STARAMD_LANE_CLASS_POST=2" pe101 1500 --seedPerWindowNmax 5
-run "STARAMD_SEED_FLAT=3" pe101_sparse3 1000 --seedPerWindowNmax 5 --seedSearchLmax 25
-run "STARAMD_SEED_FLAT=2" pe125_protrude 1000 --seedPerWindowNmax 5 --seedSearchLmax 30 --seedSearchStartLmax 12
-run "STARAMD_SEED_FLAT=4" se50 2000 --seedPerWindowNmax 5
-run "STARAMD_SEED_FLAT=4" pe101 1500 --seedPerWindowNmax 5
-run "STARAMD_SEED_FLAT=5" pe101_sparse3 1000 --seedPerWindowNmax 5 --seedSearchLmax 25
-run "STARAMD_SEED_FLAT=4" pe125_protrude 1000 --seedPerWindowNmax 5 --seedSearchLmax 30 --seedSearchStartLmax 12
-run "STARAMD_SEED_FLAT=6" pe101 1500 --seedPerWindowNmax 5
-run "STARAMD_SEED_FLAT=6" pe101_sparse3 1000 --seedPerWindowNmax 5 --seedSearchLmax 25
-run "STARAMD_SEED_FLAT=6" pe125_protrude 1000 --seedPerWindowNmax 5 --seedSearchLmax 30 --seedSearchStartLmax 12
 echo "$bad case(s) with a report"
 exit $bad

@@ -38,6 +38,9 @@ DATASETS = {
     "pe125_protrude": (dict(seed=936057973, chr_lengths=(132791, 208918, 165515, 93736), n_tr=98, n_reads=2092, read_len=125, paired=True, sub_rate=0.02, n_rate=0.0, indel_rate=0.002,
                             frag=(62, 375)),
                        dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=100), []),
+    # 2x300: the packed reads of 256 lanes do not fit into the dynamic LDS of a k_stitch_lane block; the batch takes the cooperative launches alone
+    "pe300": (dict(seed=11, chr_lengths=(300000, 250000), n_tr=90, n_reads=900, read_len=300, paired=True, sub_rate=0.01, frag=(350, 900)),
+              dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=100), []),
     "pe150_chim": (dict(seed=5, chr_lengths=(350000, 250000, 200000), n_tr=110, n_reads=3000, read_len=150, paired=True, sub_rate=0.01, chim_rate=0.05),
                    dict(sa_index_nbases=8, use_gtf=True, sjdb_overhang=149), []),
 }
