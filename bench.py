@@ -194,7 +194,7 @@ from star_amd.capi import CliHooks, CliReport, run_cli      # the product pipeli
 
 COUNTER_NAMES = ["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut",
                  "nOvfWin", "nOvfStitch", "nRedoWin", "nReplayWin"]
-STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitch_verify+replay+finish", "k_scan+k_gather", "device_total"]
+STAGE_NAMES = ["k_seed_search", "k_windows", "k_order", "k_stitch_win", "k_stitch_verify+replay+finish", "k_scan+k_gather", "device_total", "k_windows:middle+last launch"]
 
 
 def engine_src_sha():
@@ -268,7 +268,7 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
         return time.perf_counter() - t
     run(1, ncpu, out_prefix + "ld_")                                    # page cache
     t_load = run(1, ncpu, out_prefix + "ld_")
-    best_th = max(1, ncpu // 4)
+    best_th = max(1, min(ncpu // 4, 4 * effective_cpus()))          # (the reference waits on its input mutex beyond ~64 threads; a CPU quota lowers that further)
     n_all = min(n_pairs, 4000000)
     v_all = n_all / max(run(n_all, ncpu, out_prefix + "all_") - t_load, 1e-3) / 1e6
     v_best = n_pairs / max(run(n_pairs, best_th, out_prefix) - t_load, 1e-3) / 1e6       # last: its outputs stay for the parity check
@@ -337,6 +337,31 @@ _CLI_LIB = None       # set by --cpu-selftest
 
 def _run_cli(argv, *hooks):
     return run_cli(argv, *hooks, lib_path=_CLI_LIB)
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the smallest of the online CPUs, the affinity mask and the cgroup CPU quota (cpu.max).  The GPU boxes show 256
+    hardware threads to a container whose quota is 16 CPUs: 64 + 32 + 16 busy threads are then throttled by the scheduler in 100 ms periods, and the
+    single-threaded sections of the host pipeline stall for whole periods (measured: profiles/r04_host_diagnostics.txt)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+        except Exception:
+            pass
+    try:        # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return n
 
 
 def loaded_libs():
@@ -432,7 +457,8 @@ def main():
     fq = make_reads(args, g, run_dir, "reads_r%d" % rank, n_total, 7000 + rank)
     log("rank %d: %d pairs of reads in %.1f s" % (rank, n_total, time.time() - t))
     outp = os.path.join(run_dir, "gpu_r%d_" % rank)
-    threads = args.host_threads or max(4, min(64, (os.cpu_count() or 8) // world))
+    ncpu_eff = effective_cpus()
+    threads = args.host_threads or max(4, min(64, ncpu_eff // world))
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", outp, "--runThreadN", str(threads),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
     # (the front end runs STARAMD_CONTEXTS_PER_GPU engine contexts per GPU, default 2: two mapper threads over ONE resident index, so that the copies
@@ -526,7 +552,7 @@ def main():
         "config": {"workload": "BASELINE config 2 stand-in: synthetic %d Mb genome, %d annotated junctions, %.1f GB index in HBM, %d distinct pairs 2x%d per GPU as %d+%d batches of %d; "
                                "FASTQ text in -> SAM + SJ.out.tab out, index load excluded"
                                % (mb, ginfo.get("junctions_in_index", 0), ginfo.get("index_bytes", 0) / 1e9, n_total, args.read_len, args.warmup, args.steps, args.reads),
-                   "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads, "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)),
+                   "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads, "cpus_online": os.cpu_count(), "cpus_usable": ncpu_eff, "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)),
                    "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "issue": issue, "kernel_ms": round(dms, 3), "algorithmic_bytes_per_launch": int(dbytes),
@@ -657,7 +683,7 @@ def extra_legs_child(spec):
 
 def host_budget_leg(args, idx, fq, run_dir):
     """The host at the budget of an 8-GPU node: the same pipeline with cores/8 host threads for this GPU."""
-    th = max(4, (os.cpu_count() or 8) // 8)
+    th = max(2, effective_cpus() // 8)
     nb, w = 8, 2
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "hb_"), "--runThreadN", str(th),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(min(nb + w, args.steps + args.warmup) * args.reads)]
@@ -680,7 +706,7 @@ def config5_leg(args, g, idx, log, chim_detection):
     fq = make_reads(args, g, rd, "chim", n_total, 8100, read_len=L, chim_rate=0.05)
     flags = ["--chimSegmentMin", "12", "--chimOutType", "Junctions"] if chim_detection else []
     tag = "cd_" if chim_detection else "df_"
-    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, tag + "gpu_"), "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))),
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, tag + "gpu_"), "--runThreadN", str(max(4, min(64, effective_cpus()))),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)] + flags
     rep, d = _cli_leg(argv, 2 * L + 1)
     d["workload"] = "%d pairs 2x%d, 1%% substitutions, 5%% chimeric pairs, %s" % (n_total, L, "--chimSegmentMin 12 (every transcript of every window returned, no window pruning)" if chim_detection else "default flags (chimeric detection off)")
@@ -711,7 +737,7 @@ def config1_leg(args, log):
     rd = os.path.join(g, "se_n%d" % n_total)
     fq = make_reads(sub, g, rd, "se", n_total, 8200, read_len=50)[:1]
     idx = os.path.join(g, "idx")
-    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"), "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))),
+    argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"), "--runThreadN", str(max(4, min(64, effective_cpus()))),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)]
     rep, d = _cli_leg(argv, 50)
     d["workload"] = "%d single-end reads 1x50, synthetic %d Mb genome (yeast size), SAindex %d bases" % (n_total, mb, ginfo.get("SAindexNbases", 0))
@@ -741,7 +767,7 @@ def sweep(args, main_mb, main_value, main_ms, log):
             rd = os.path.join(g, "sweep_n%d" % n_total)
             fq = make_reads(args, g, rd, "reads", n_total, 9000 + mb)
             argv = ["--runMode", "alignReads", "--genomeDir", os.path.join(g, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, "gpu_"),
-                    "--runThreadN", str(max(4, min(64, os.cpu_count() or 8))), "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)]
+                    "--runThreadN", str(max(4, min(64, effective_cpus()))), "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)]
             rc, rep = _run_cli(argv)
             if rc:
                 rows.append({"genome_mb": mb, "error": "exit code %d" % rc}); continue

@@ -92,6 +92,10 @@ template <class P, class V> static inline auto emu_fetch_or(P p, V v) { auto o =
 #define __HIP_MEMORY_SCOPE_SYSTEM 4
 #define __hip_atomic_fetch_or(p, v, order, scope) emu_fetch_or((p), (v))
 #define __hip_atomic_load(p, order, scope) (*(p))
+template <class P, class V> static inline auto emu_fetch_max(P p, V v) { auto o = *p; if ((decltype(o))v > o) *p = (decltype(o))v; return o; }
+template <class P, class E, class V> static inline bool emu_cas(P p, E *expected, V desired) { if (*p == *expected) { *p = desired; return true; } *expected = *p; return false; }
+#define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
+#define __hip_atomic_compare_exchange_strong(p, e, d, so, fo, scope) emu_cas((p), (e), (d))
 
 // ---- runtime -----------------------------------------------------------------------------------------------------------------
 typedef int hipError_t;

@@ -36,6 +36,10 @@ struct DevIndex {
     const u64 *sjDstart, *sjAstart, *sjdbStart, *sjdbEnd;
     const u8 *sjdbMotif, *sjdbShiftLeft, *sjdbShiftRight, *sjdbStrand;
     const u64 *sjNovelStart, *sjNovelEnd; u64 sjNovelN;       // whitelist of the 2nd stage of BySJout (staramd_set_novel_junctions)
+    // (start, end) -> junction: open-addressing table over the annotated junctions, built at upload (engine.hip buildSjdbHash).  Slot = two words:
+    // (index + 1) << 40 | start, end; an empty slot is 0.  binarySearch2 (binarySearch2.cpp:3-43) walks ~19 dependent loads through sjdbStart for 350 k
+    // junctions; the table answers with one.  Null when the coordinates / the junction count do not fit the packing: the bisection is used then.
+    const u64 *sjdbHash; u32 sjdbHashMask; u32 padHash;
     u64 nGenome, nSA, sjGstart;
     u64 saiStart[17];
     u64 saMask, saiMask, strandMask, saiAbsentBit, saiNbit;
@@ -82,6 +86,9 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_nPrunedWin,                                                  // windows not walked because no transcript of theirs could be selected (k_stitch_win)
        DC_nRewalkRead,                                                 // light reads whose two-mate windows did not clear the bar: walked again in window order
        DC_nLaneItems,                                                  // reads stitched by the lane-per-read kernel (k_stitch_lane); the others went to the cooperative one
+       DC_nOwnerLookups, DC_nOwnerMisses,                              // k_windows pass B: loci that passed the covered-bins filter / of those, loci no window owns (filter false positives)
+       DC_nAnchorLoci, DC_nAnchorReplayed,                             // k_windows pass A: anchor loci enumerated / replayed one by one (not owned by a window when their chunk was read)
+       DC_wprof5, DC_wprof6, DC_wprof7,                                // -DSTARAMD_PROFILE build: more sections of k_windows
        DC_N };
 
 // cursors[] slots
@@ -144,6 +151,20 @@ __device__ __forceinline__ u8 gcGet(const u8 *G, GCache &c, i64 pos) {
     i64 b = pos & ~7ll;
     if (b != c.base) { c.word = *GLOBAL(u64, G + b); c.base = b; }
     return (u8)(c.word >> ((u32)(pos & 7) * 8));
+}
+
+#define SJH_START_BITS 40u
+__device__ __forceinline__ u32 sjdbHashSlot(u64 start, u32 mask) { return (u32)((start * 0x9E3779B97F4A7C15ull) >> 40) & mask; }
+// one lane: index of the junction (x, y) or -1
+__device__ __forceinline__ int sjdbHashFind(const u64 *tab_, u32 mask, u64 x, u64 y) {
+    const __attribute__((address_space(1))) u64 *tab = GLOBAL(u64, tab_);
+    u32 h = sjdbHashSlot(x, mask);
+    for (u32 n = 0; n <= mask; n++, h = (h + 1u) & mask) {
+        const u64 s = tab[2u * h];
+        if (s == 0) return -1;
+        if ((s & ((1ull << SJH_START_BITS) - 1ull)) == x && tab[2u * h + 1u] == y) return (int)(s >> SJH_START_BITS) - 1;
+    }
+    return -1;
 }
 
 // LOCKSTEP(): marks a place where the lanes of a wavefront exchange data through memory and rely on executing in lock step (all lanes

@@ -64,6 +64,7 @@ struct staramd_ctx {
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
     u32 winBlocksMid = 0, capWMid = 0, capBlocksMid = 0, hashBitsMid = 65536; u8 *scrWinMid = nullptr;
+    u32 hashBits = 4096, winOwnerMap = 1;         // first launch: bits of the covered-bins filter = 32 x slots of the owner map (k_window.hip)
     // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
     u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
     u32 stBlocks = 0, stBlocksBig = 0, replayBlocks = 0; u8 *scrStitch = nullptr, *scrStitchBig = nullptr;
@@ -78,7 +79,7 @@ struct staramd_ctx {
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
-    float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-stage HIP-event times of the last batch (staramd_get_timings)
+    float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; float ms8 = 0;   // per-stage HIP-event times of the last batch (staramd_get_timings)
     u64 counters[DC_N];
     u32 residentReads = 0; u32 residentMaxLread = 0;
     u32 *hostScratch = nullptr;         // pinned: totals + cursors read-back
@@ -127,6 +128,8 @@ static void buildGlBreaks(DevIndex &X, double scale) {
     }
 }
 
+// DevIndex::sjdbHash (dev.h): slots = a power of two >= 2 x junctions, >= 128 (the cooperative look-up probes 64 consecutive slots per step)
+static int buildSjdbHash(staramd_ctx *c, const staramd_genome *g);
 static u32 envU32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)strtoul(s, nullptr, 10) : dflt; }
 // chromosome / junction tables, index geometry, parameters and the DevIndex block (everything but G, SA, SAindex)
 static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
@@ -153,12 +156,31 @@ static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_p
     X.sjdbOverhang = g->sjdbOverhang; X.sjdbLength = g->sjdbLength ? g->sjdbLength : 1; X.sjdbN = g->sjdbN; X.nChrReal = g->nChrReal;
     X.P = *p;
     X.sjNovelStart = X.sjNovelEnd = nullptr; X.sjNovelN = 0;
+    if ((rc = buildSjdbHash(c, g))) return rc;
     buildGlBreaks(X, p->scoreGenomicLengthLog2scale);
     { int rc2 = devAlloc(c->indexAllocs, &c->dX, (u64)1); if (rc2) return rc2; }
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
     return 0;
 }
 
+
+static int buildSjdbHash(staramd_ctx *c, const staramd_genome *g) {
+    DevIndex &X = c->X;
+    X.sjdbHash = nullptr; X.sjdbHashMask = 0; X.padHash = 0;
+    if (g->sjdbN == 0 || g->sjdbN >= (1u << 23) || (g->nGenome >> SJH_START_BITS) != 0 || getenv("STARAMD_NO_SJDB_HASH")) return 0;
+    u32 slots = 128; while (slots < 2u * g->sjdbN) slots <<= 1;
+    std::vector<u64> tab((size_t)slots * 2, 0);
+    const u32 mask = slots - 1;
+    for (u32 i = 0; i < g->sjdbN; i++) {
+        const u64 st = g->sjdbStart[i];
+        u32 h = (u32)((st * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+        while (tab[2 * (size_t)h]) h = (h + 1) & mask;
+        tab[2 * (size_t)h] = ((u64)(i + 1) << SJH_START_BITS) | st; tab[2 * (size_t)h + 1] = g->sjdbEnd[i];
+    }
+    int rc = devUpload(c->indexAllocs, &X.sjdbHash, (const u64 *)tab.data(), (u64)slots * 2);
+    if (!rc) X.sjdbHashMask = mask;
+    return rc;
+}
 
 static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
@@ -252,16 +274,19 @@ static int allocWork(staramd_ctx *c) {
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
     c->prune = envU32("STARAMD_PRUNE", 3); c->laneClass = envU32("STARAMD_LANE_CLASS", 5);          // (knobs are read here, once: not on the launch path)
     if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
-    c->capW = envU32("STARAMD_CAP_WINDOWS", 256); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
+    // first launch: 128 table rows + 512 owner-map slots = 6 KB of LDS per wavefront, 6 blocks of 4 wavefronts per CU (k_windows is held to 6 waves per SIMD)
+    c->capW = envU32("STARAMD_CAP_WINDOWS", 128); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
     int winPerCU = 3;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * (c->capW * 8 + 128) * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
+    c->winOwnerMap = envU32("STARAMD_WIN_OWNER_MAP", 1);
+    { u32 hb = envU32("STARAMD_WIN_HASH_BITS", c->winOwnerMap ? 16384 : 4096); c->hashBits = 1024; while (c->hashBits < hb && c->hashBits < (1u << 18)) c->hashBits <<= 1; }      // a power of two
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * (c->capW * 8 + c->hashBits / 32) * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
     c->winBlocks = (u32)c->nCU * envU32("STARAMD_WIN_BLOCKS_PER_CU", (u32)winPerCU);
     c->winBlocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (N + 3) / 4));
     if ((rc = devAlloc(R, &c->scrWin, (u64)c->winBlocks * 4 * winWaveBytesH(c->capW, c->capBlocks, 0)))) return rc;
     c->capWMid = envU32("STARAMD_CAP_WINDOWS_MID", 1024); c->capBlocksMid = envU32("STARAMD_CAP_WA_BLOCKS_MID", 1024);
     if (c->capWMid <= c->capW || c->capWMid >= P.alignWindowsPerReadNmax) c->capWMid = 0;
     if (c->capWMid) {
-        u32 hb = envU32("STARAMD_WIN_HASH_BITS_MID", 65536);
+        u32 hb = envU32("STARAMD_WIN_HASH_BITS_MID", c->winOwnerMap ? 262144 : 65536);
         c->hashBitsMid = 4096; while (c->hashBitsMid < hb && c->hashBitsMid < (1u << 18)) c->hashBitsMid <<= 1;       // a power of two
         while (c->hashBitsMid > 4096 && ((u64)c->capWMid * 8 + c->hashBitsMid / 32) * 4 > 65536) c->hashBitsMid >>= 1;   // table + map within 64 KB of dynamic LDS
         if (((u64)c->capWMid * 8 + c->hashBitsMid / 32) * 4 > 65536) c->capWMid = (65536 / 4 - c->hashBitsMid / 32) / 8;
@@ -517,9 +542,10 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[1], s));
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
-        const u32 useMid = c->capWMid ? 1u : 0u;
-        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + 128) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, 4096u);
-        if (useMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + c->hashBitsMid / 32) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid, c->hashBitsMid);
+        const u32 useMid = (c->capWMid ? 1u : 0u) | (c->winOwnerMap ? 2u : 0u);
+        hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + c->hashBits / 32) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, c->hashBits);
+        HIPCHK(hipEventRecord(c->ev[7], s));
+        if (c->capWMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + c->hashBitsMid / 32) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid, c->hashBitsMid);
         hipLaunchKernelGGL(k_windows_big, dim3(c->winBlocksBig), block, 0, s, c->dX, B, c->scrWinBig, c->capWBig, c->capBlocksBig, c->lightEst, useMid);
         HIPCHK(hipEventRecord(c->ev[5], s));
         hipLaunchKernelGGL(k_order_hist, dim3(1024), block, 0, s, B);
@@ -534,10 +560,12 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         // the lane kernel keeps the packed read of each of its 256 lanes in LDS: reads beyond ~512 bases (2x250 and longer) do not fit into what a block
         // may ask for, and the batch takes the cooperative launches alone (same results: the class cap only picks the kernel)
         const bool laneFits = 256 * (size_t)ldsWords * 4 <= c->ldsLimit;
+        if (!(c->laneBlocks && laneFits)) HIPCHK(hipEventRecord(c->ev[8], s));
         size_t ldsLean = c->leanDepth ? 4 * (readBytes + stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena)) : 0;
         for (u32 mode = 0; mode < 2; mode++) {
             if (mode == 0 && c->laneBlocks && laneFits) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
                 hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, c->laneClass);
+                HIPCHK(hipEventRecord(c->ev[8], s));
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
             } else
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest
@@ -576,6 +604,8 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventElapsedTime(&c->ms[3], c->ev[2], c->ev[6]));
     HIPCHK(hipEventElapsedTime(&c->ms[4], c->ev[6], c->ev[3]));
     HIPCHK(hipEventElapsedTime(&c->ms[5], c->ev[3], c->ev[4]));
+    HIPCHK(hipEventElapsedTime(&c->ms[7], c->ev[7], c->ev[5]));        // [7] the middle + last k_windows launches alone (part of [1])
+    { float t6 = 0; HIPCHK(hipEventElapsedTime(&t6, c->ev[2], c->ev[8])); c->ms8 = t6; }      // [8] the k_stitch_lane launch alone (part of [3])
     c->ms[6] = r->msTotalDevice;
     *flagsOut = hs[8 + CUR_FLAGS];
     return STARAMD_OK;
@@ -647,8 +677,8 @@ extern "C" int staramd_map_resident(staramd_ctx *c, staramd_results *r) {
 
 extern "C" int staramd_get_timings(staramd_ctx *c, float *out, int n) {
     if (!c || !out) return 0;
-    int k = n < 7 ? n : 7;
-    for (int i = 0; i < k; i++) out[i] = c->ms[i];
+    int k = n < 9 ? n : 9;
+    for (int i = 0; i < k; i++) out[i] = i < 8 ? c->ms[i] : c->ms8;
     return k;
 }
 

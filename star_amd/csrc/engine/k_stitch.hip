@@ -159,6 +159,23 @@ __device__ static int coopSjdbFind(u32 lane, u64 x, u64 y, const u64 *Xs_, const
     return -1;
 }
 
+// the same question through DevIndex::sjdbHash (dev.h): the lanes probe 64 consecutive slots of the table at once -- one round trip instead of the
+// three or four dependent ones of the 64-ary search above (the junction arrays of a human annotation are 2 x 2.8 MB: every round is an L2 access)
+__device__ static int coopSjdbHash(u32 lane, u64 x, u64 y, const u64 *tab_, u32 mask) {
+    const GLOBAL_AS u64 *tab = (const GLOBAL_AS u64 *)tab_;
+    const u32 h0 = sjdbHashSlot(x, mask);
+    for (u32 step = 0; step <= mask; step += NLANE) {
+        const u32 h = (h0 + step + lane) & mask;
+        const u64 s = tab[2u * h], e = tab[2u * h + 1u];
+        const bool empty = s == 0;
+        const bool hit = !empty && (s & ((1ull << SJH_START_BITS) - 1ull)) == x && e == y;
+        const u64 em = __ballot(empty), hm = __ballot(hit);
+        if (hm) { const u32 l = firstLane(hm); if (!em || l < firstLane(em)) return (int)(laneGet64(s, l) >> SJH_START_BITS) - 1; return -1; }
+        if (em) return -1;
+    }
+    return -1;
+}
+
 // ---- stitchAlignToTranscript.cpp:9-415 ------------------------------------------------------------------------------
 // h / eA are working copies (wave-uniform): the caller commits them (and eN when added) only when the returned score is
 // > -1000000, so a failed stitch leaves the transcript untouched.  ex0R / ex0G = start of the first exon.
@@ -319,7 +336,8 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                 }
                 
                 int sjdbInd = -1;
-                if (X.sjdbN > 0) sjdbInd = coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN);
+                if (X.sjdbN > 0) sjdbInd = X.sjdbHash ? coopSjdbHash(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbHash, X.sjdbHashMask)
+                                                      : coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN);
                 
                 if (sjdbInd < 0) {
                     if (isIntron) Score += P.scoreGap + jPen;

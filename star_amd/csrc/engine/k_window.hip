@@ -52,6 +52,8 @@ template <bool BIG> struct WS {
     u32 hashMask;                   // bits of the bitmap - 1 (a power of two; the middle launch has 16x the bits: its reads cover thousands of bins,
                                     // a 4096-bit map is saturated and every locus of a 10000-fold seed would go through the serial owner lookup)
     bool overflow, tooMany, winLimit;
+    bool ownMap;                    // the words at `bitmap` hold the owner map of this read (else the Bloom filter)
+    u32 ownMask;                    // its slots - 1
 };
 
 // after writes to the seed lists (global memory, rows exchanged between lanes): wait for them
@@ -73,7 +75,10 @@ __device__ __forceinline__ u64 waveMax64(u64 v) {
 __device__ __forceinline__ u32 waveMin32(u32 v) { return ~waveMaxU32(~v); }
 
 // ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; all arguments wave-uniform; returns 1 on TOO_MANY_WINDOWS / overflow
-template <bool BIG> __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS<BIG> &s, u64 a1, u32 aStr, u32 lane) {
+// aChr = chrBin[aBin >> winBinChrNbits], looked up by the lane that enumerated the locus.  Every core bin of a window lies on the chromosome the window was
+// created on (a window only grows by bins of its own chromosome, :28,:47,:66), so "is the neighbour on my chromosome" is a comparison with the neighbour's
+// table row: the serial replay of the anchor loci makes no global-memory access at all.
+template <bool BIG> __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS<BIG> &s, u64 a1, u32 aStr, u32 aChr, u32 lane) {
     const staramd_params &P = X.P;
     u32 aBin = (u32)(a1 >> P.winBinNbits);
     u32 lo = aBin > P.winAnchorDistNbins ? aBin - P.winAnchorDistNbins : 0;
@@ -91,10 +96,9 @@ template <bool BIG> __device__ static int createExtendWindowsWithAlign(const Dev
     }
     if (__any(own)) return 0;
     candL = waveMax64(candL); candR = waveMax64(candR);
-    u32 aChr = GLOBAL(u32, X.chrBin)[aBin >> P.winBinChrNbits];
     u32 iWinL = NOWIN, iWinR = NOWIN;
-    if (candL) { u32 ce = (u32)(candL >> 32) - 1; if (GLOBAL(u32, X.chrBin)[ce >> P.winBinChrNbits] == aChr) iWinL = (u32)candL; }
-    if (candR) { u32 cs = ~(u32)(candR >> 32); if (GLOBAL(u32, X.chrBin)[cs >> P.winBinChrNbits] == aChr) iWinR = (u32)candR; }
+    if (candL) { const u32 j = (u32)candL; if ((s.t.meta[j] >> 2) == aChr) iWinL = j; }
+    if (candR) { const u32 j = (u32)candR; if ((s.t.meta[j] >> 2) == aChr) iWinR = j; }
     if (iWinL == NOWIN && iWinR == NOWIN) {
         u32 iWin = s.nW;
         if (iWin >= s.capW) { s.overflow = true; return 1; }
@@ -194,7 +198,42 @@ __device__ __forceinline__ bool sjAlignSplit(const DevIndex &X, u64 a1, u32 aLen
     return false;
 }
 
+// the per-read filter of "bins covered by some window" is a Bloom filter with two hash functions: ~180 covered bins in 4096 bits pass 4 % of the foreign
+// loci with one function, 0.7 % with two -- every false positive is a serial owner look-up, and a repeat seed enumerates hundreds of foreign loci
 __device__ __forceinline__ u32 binHash(u32 str, u32 bin, u32 mask) { return (bin * 2u + str) & mask; }
+__device__ __forceinline__ u32 binHash2(u32 str, u32 bin, u32 mask) { return (((bin * 2u + str) * 0x9E3779B1u) >> 14) & mask; }
+template <class BP> __device__ __forceinline__ bool binCovered(BP bitmap, u32 str, u32 bin, u32 mask) {
+    const u32 h1 = binHash(str, bin, mask), h2 = binHash2(str, bin, mask);
+    return ((bitmap[h1 >> 5] >> (h1 & 31u)) & (bitmap[h2 >> 5] >> (h2 & 31u)) & 1u) != 0;
+}
+
+// ---- owner map: (strand, bin) -> window, an open-addressing hash table in the LDS words that otherwise hold the Bloom filter --------------------------
+// The reference's winBin array answers "which window owns the bin of this locus" with one load; the interval-owner form above answers it with a scan of
+// the window table (ownerWave), one locus at a time -- ~60 serial look-ups per read pair, and for a read in a repeat family with a thousand windows and
+// 10^5 loci the whole of its time.  When the bins the windows of a read cover fit into the table (almost always: ~180 bins), they are entered once after
+// the flank extension -- word = (key + 1) << 11 | flank << 10 | window, where an atomic max per key resolves exactly what the reference's write order
+// into winBin does (ReadAlign_stitchPieces.cpp:96-118: a flank writer beats the core owner, the last flank writer beats the earlier ones) -- and every
+// lane looks its own locus up: one or two LDS probes, 64 loci at once.
+#define OWN_BITS 10u
+template <class BP> __device__ __forceinline__ void ownInsert(BP tab, u32 mask, u32 key, u32 val) {
+    const u32 word = ((key + 1u) << (OWN_BITS + 1u)) | val;
+    u32 h = (key * 0x9E3779B1u >> 12) & mask;
+    for (;;) {
+        u32 expected = 0;
+        if (__hip_atomic_compare_exchange_strong(&tab[h], &expected, word, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        if ((expected >> (OWN_BITS + 1u)) == key + 1u) { __hip_atomic_fetch_max(&tab[h], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+        h = (h + 1u) & mask;
+    }
+}
+template <class BP> __device__ __forceinline__ u32 ownLookup(BP tab, u32 mask, u32 key) {
+    u32 h = (key * 0x9E3779B1u >> 12) & mask;
+    for (;;) {
+        const u32 v = tab[h];
+        if (v == 0) return NOWIN;
+        if ((v >> (OWN_BITS + 1u)) == key + 1u) return v & ((1u << OWN_BITS) - 1u);
+        h = (h + 1u) & mask;
+    }
+}
 
 // pass-B owner of a bin, wave-parallel (lane j tests window j): last flank writer wins, else the core owner
 // (ReadAlign_stitchPieces.cpp:96-118 write order)
@@ -229,6 +268,7 @@ extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 +
 // mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits (BIG)
 template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
     const u32 big = BIG ? 1u : 0u;
+    const bool ownMapEnable = (useMid & 2u) != 0; useMid &= 1u;      // (bit 1 of the argument: owner map on, STARAMD_WIN_OWNER_MAP)
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
@@ -245,6 +285,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
     s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + 6 * capW; s.t.nwa = tab + 7 * capW;
     s.arena = (DWA *)mine; s.capW = capW; s.capBlocks = capBlocks;
     u64 nSAenum = 0, nWindows = 0, nWAtot = 0; u32 nOvf = 0;
+    u32 nOwnerLookups = 0, nOwnerMisses = 0, nAnchorLoci = 0, nAnchorReplayed = 0;
 #ifdef STARAMD_PROFILE
     u64 wprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -272,7 +313,8 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
             for (u32 base = 0; base < sd.nrep && !stop; base += 64) {
                 u32 cnt = min(64u, sd.nrep - base);
                 // lane i: locus i of the chunk
-                u64 a1 = 0, a1A = 0; u32 aStr = 0; u32 kind = 0;       // kind: 0 skip, 1 plain, 2 split (D then A)
+                u64 a1 = 0, a1A = 0; u32 aStr = 0; u32 kind = 0;       // kind: bit 0 = the locus (the donor half of a split one), bit 1 = the acceptor half of a split locus
+                u32 aChr = 0, aChrA = 0;
                 if (lane < cnt) {
                     a1 = packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
                     aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
@@ -282,17 +324,36 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                     kind = 1;
                     if (a1 >= X.sjGstart) {
                         u64 a1D; u32 lD, lA, isj;
-                        if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) { a1 = a1D; kind = 2; } else kind = 0;
+                        if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) { a1 = a1D; kind = 3; } else kind = 0;
                     }
+                    if (kind) aChr = GLOBAL(u32, X.chrBin)[(u32)(a1 >> P.winBinNbits) >> P.winBinChrNbits];
+                    if (kind & 2u) aChrA = GLOBAL(u32, X.chrBin)[(u32)(a1A >> P.winBinNbits) >> P.winBinChrNbits];
                 }
-                nSAenum += cnt;
-                for (u32 l = 0; l < cnt; l++) {
-                    u32 k = laneGet32(kind, l);
-                    if (k == 0) continue;
-                    u64 x1 = laneGet64(a1, l); u32 xs = laneGet32(aStr, l);
-                    if (createExtendWindowsWithAlign(X, s, x1, xs, lane)) { stop = true; break; }
-                    if (k == 2) { u64 x2 = laneGet64(a1A, l); if (createExtendWindowsWithAlign(X, s, x2, xs, lane)) { stop = true; break; } }
+                nSAenum += cnt; nAnchorLoci += cnt;
+                WPROF_MARK(6);
+                // A locus whose bin lies inside the core of a live window changes nothing (:12-17 returns at once), and a bin that is owned stays owned (cores
+                // only grow; a window killed by a bridge lies inside the bridging one).  So the loci owned NOW are dropped from the replay, every lane testing its
+                // own locus against the table rows (all lanes read the same row: a broadcast) -- typically all but the first few loci of a repeat family
+                if (cnt >= 4u && cnt * 16u >= s.nW) {
+                    const u32 bD = (u32)(a1 >> P.winBinNbits), bA = (u32)(a1A >> P.winBinNbits);
+                    bool ownD = false, ownA = false;
+                    for (u32 j = 0; j < s.nW; j++) {
+                        const u32 m = s.t.meta[j];
+                        if (!(m & 1u) || ((m >> 1) & 1u) != aStr) continue;
+                        const u32 cs = s.t.coreS[j], ce = s.t.coreE[j];
+                        ownD |= bD >= cs && bD <= ce; ownA |= bA >= cs && bA <= ce;
+                    }
+                    if (ownD) kind &= ~1u;
+                    if (ownA) kind &= ~2u;
                 }
+                WPROF_MARK(7);
+                for (u64 lm = __ballot(kind != 0); lm; lm &= lm - 1) {
+                    const u32 l = firstLane(lm); nAnchorReplayed++;
+                    const u32 k = laneGet32(kind, l); const u32 xs = laneGet32(aStr, l);
+                    if (k & 1u) { if (createExtendWindowsWithAlign(X, s, laneGet64(a1, l), xs, laneGet32(aChr, l), lane)) { stop = true; break; } }
+                    if (k & 2u) { if (createExtendWindowsWithAlign(X, s, laneGet64(a1A, l), xs, laneGet32(aChrA, l), lane)) { stop = true; break; } }
+                }
+                WPROF_MARK(0);
             }
         }
         WPROF_MARK(0);
@@ -311,11 +372,22 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 s.t.extE[j] = wb;
             }
             for (u32 k = lane; k < hashBits / 32; k += 64) s.bitmap[k] = 0;
+            // bins covered by the windows of this read: into the owner map when they fill at most 5/8 of its slots (keys of 20 bits, windows of 10), else into the Bloom filter
+            u32 nCov = 0;
+            for (u32 j = lane; j < s.nW; j += 64) if (s.t.meta[j] & 1u) nCov += s.t.extE[j] - s.t.extS[j] + 1u;
+            nCov = waveSumU32(min(nCov, 0xFFFFFFu));
+            s.ownMask = hashBits / 32u - 1u;
+            s.ownMap = !BIG && ownMapEnable && s.nW <= (1u << OWN_BITS) && P.winBinN < (1u << 19) && nCov * 8u <= (hashBits / 32u) * 5u;
             rowFence<BIG>();
             for (u32 j = lane; j < s.nW; j += 64) {
                 u32 m = s.t.meta[j];
                 if (!(m & 1u)) continue;
-                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) { u32 hsh = binHash((m >> 1) & 1u, b, s.hashMask); bitOr(&s.bitmap[hsh >> 5], 1u << (hsh & 31u)); }
+                const u32 str = (m >> 1) & 1u, cs = s.t.coreS[j], ce = s.t.coreE[j];
+                for (u32 b = s.t.extS[j]; b <= s.t.extE[j]; b++) {
+                    if (s.ownMap) { ownInsert(s.bitmap, s.ownMask, b * 2u + str, ((b < cs || b > ce) ? (1u << OWN_BITS) : 0u) | j); continue; }
+                    const u32 h1 = binHash(str, b, s.hashMask), h2 = binHash2(str, b, s.hashMask);
+                    bitOr(&s.bitmap[h1 >> 5], 1u << (h1 & 31u)); bitOr(&s.bitmap[h2 >> 5], 1u << (h2 & 31u));
+                }
             }
             rowFence<BIG>();
         }
@@ -342,21 +414,30 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                         if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
                             split = true; a1 = a1D;
                             binD = (u32)(a1D >> P.winBinNbits); binA = (u32)(a1A >> P.winBinNbits); lStr = aStr;
-                            u32 hD = binHash(aStr, binD, s.hashMask), hA = binHash(aStr, binA, s.hashMask);
-                            candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u; candA = (s.bitmap[hA >> 5] >> (hA & 31u)) & 1u;
+                            if (s.ownMap) { wD = ownLookup(s.bitmap, s.ownMask, binD * 2u + aStr); wA = ownLookup(s.bitmap, s.ownMask, binA * 2u + aStr); }
+                            else { candD = binCovered(s.bitmap, aStr, binD, s.hashMask); candA = binCovered(s.bitmap, aStr, binA, s.hashMask); }
                         }
                     } else {
                         lD = aLength;
                         binD = (u32)(a1 >> P.winBinNbits); lStr = aStr;
-                        u32 hD = binHash(aStr, binD, s.hashMask);
-                        candD = (s.bitmap[hD >> 5] >> (hD & 31u)) & 1u;
+                        if (s.ownMap) wD = ownLookup(s.bitmap, s.ownMask, binD * 2u + aStr);
+                        else candD = binCovered(s.bitmap, aStr, binD, s.hashMask);
                     }
                 }
-                // loci that pass the bitmap are looked up one by one, all lanes testing one window each
-                for (u64 cm = __ballot(candD); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binD, l), lane); if (lane == l) wD = w; }
-                for (u64 cm = __ballot(candA); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binA, l), lane); if (lane == l) wA = w; }
-                nSAenum += cnt;
                 WPROF_MARK(2);
+                if (!s.ownMap) {
+                    // loci that pass the Bloom filter are looked up one by one, all lanes testing one window each
+                    for (u64 cm = __ballot(candD); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binD, l), lane); if (lane == l) wD = w; nOwnerLookups++; if (w == NOWIN) nOwnerMisses++; }
+                    for (u64 cm = __ballot(candA); cm; cm &= cm - 1) { u32 l = firstLane(cm); u32 w = ownerWave(s, laneGet32(lStr, l), laneGet32(binA, l), lane); if (lane == l) wA = w; nOwnerLookups++; if (w == NOWIN) nOwnerMisses++; }
+                }
+                // a seed that is no anchor and shorter than what a full window has already turned away (lrec, assignAlignToWindow.cpp:11: it only ever rises) is
+                // dropped here by its own lane instead of in the replay: repeat seeds with thousands of loci leave the replay after the windows have filled up
+                if (!aAnchor) {
+                    if (wD != NOWIN && lD < s.t.lrec[wD]) wD = NOWIN;
+                    if (wA != NOWIN && lA < s.t.lrec[wA]) wA = NOWIN;
+                }
+                nSAenum += cnt;
+                WPROF_MARK(5);
                 u64 hm = __ballot(wD != NOWIN || wA != NOWIN);
                 while (hm) {
                     u32 l = (u32)__ffsll((long long)hm) - 1; hm &= hm - 1;
@@ -425,17 +506,22 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
     }
     if (lane == 0) {
 #ifdef STARAMD_PROFILE
-        if (mode == 0u) for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof8 + k], (unsigned long long)wprof[k]);
+        if (mode == 0u) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof8 + k], (unsigned long long)wprof[k]);
+                          for (int k = 5; k < 8; k++) atomicAdd((unsigned long long *)&B.counters[DC_wprof5 + k - 5], (unsigned long long)wprof[k]); }
 #endif
         atomicAdd((unsigned long long *)&B.counters[DC_nSAenum], (unsigned long long)nSAenum);
         atomicAdd((unsigned long long *)&B.counters[DC_nWindows], (unsigned long long)nWindows);
         atomicAdd((unsigned long long *)&B.counters[DC_nWA], (unsigned long long)nWAtot);
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfWin], (unsigned long long)nOvf);
+        atomicAdd((unsigned long long *)&B.counters[DC_nOwnerLookups], (unsigned long long)nOwnerLookups); atomicAdd((unsigned long long *)&B.counters[DC_nOwnerMisses], (unsigned long long)nOwnerMisses);
+        atomicAdd((unsigned long long *)&B.counters[DC_nAnchorLoci], (unsigned long long)nAnchorLoci); atomicAdd((unsigned long long *)&B.counters[DC_nAnchorReplayed], (unsigned long long)nAnchorReplayed);
     }
 }
 
 #ifndef WIN_WAVES
-#define WIN_WAVES 4         // minimum waves per SIMD the register allocation of the LDS launches is held to
+#define WIN_WAVES 6         // minimum waves per SIMD the register allocation of the LDS launches is held to.  The kernel waits on dependent memory round trips (SA entry ->
+                            // table rows -> seed list): more resident wavefronts is what pays, 80 VGPRs with 32 spilled registers included (same box, 3.1 Gb, ms per
+                            // 400 k pairs, 128-row table: 4 waves 23.6, 5 (192 rows) 22.3, 6 -> 20.9, 7 -> 21.2, 8 -> 22.8; profiles/r04_ab_session*.txt)
 #endif
 extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
     windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits);

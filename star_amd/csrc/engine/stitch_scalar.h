@@ -156,7 +156,8 @@ __device__ static int stitchAlignToTranscript(StitchCtx &c, u32 rAend, u64 gAend
                     }
                 }
                 int sjdbInd = -1;
-                if (X.sjdbN > 0) sjdbInd = binarySearch2(gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, (int)X.sjdbN);
+                if (X.sjdbN > 0) sjdbInd = X.sjdbHash ? sjdbHashFind(X.sjdbHash, X.sjdbHashMask, gAend + (i64)jR + 1, gBstart1 + (i64)jR)
+                                                      : binarySearch2(gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, (int)X.sjdbN);
                 if (sjdbInd < 0) {
                     if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }

@@ -282,7 +282,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                         }
                         if (!e) {
                             msDev += res.msTotalDevice;
-                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 7); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[40] = {0}; int kc = staramd_get_counters(ctx[d], c, 40); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
+                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 8); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[40] = {0}; int kc = staramd_get_counters(ctx[d], c, 40); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
                         }
                         return e;
                     };

@@ -110,7 +110,7 @@ def main():
             if rc:
                 print("%-20s create failed: %s" % (tag, L.staramd_last_error().decode())); continue
             bufs = capi.ResultBuffers(nmax, tr_cap=nmax * 24)
-            acc = [0.0] * 7; cnt = 0; dig = hashlib.sha256(); ok = True
+            acc = [0.0] * 9; cnt = 0; dig = hashlib.sha256(); ok = True
             for rep in range(a.repeat):
                 for ib, ob in enumerate(batches):
                     rc = L.staramd_map_batch(ctx, C.byref(ob.b), C.byref(bufs.res))
@@ -124,13 +124,13 @@ def main():
                             dig.update(part)
                     if rep == 0 and ib == 0:
                         continue                                    # warm-up
-                    ms = (C.c_float * 7)(); L.staramd_get_timings(ctx, ms, 7)
-                    for i in range(7):
+                    ms = (C.c_float * 9)(); L.staramd_get_timings(ctx, ms, 9)
+                    for i in range(9):
                         acc[i] += ms[i]
                     cnt += 1
                 if not ok:
                     break
-            counters = (C.c_uint64 * 40)(); L.staramd_get_counters(ctx, counters, 40)
+            counters = (C.c_uint64 * 48)(); L.staramd_get_counters(ctx, counters, 48)
             L.staramd_destroy(ctx)
             shutil.rmtree(tmp, ignore_errors=True)
             if not ok or cnt == 0:
@@ -138,12 +138,27 @@ def main():
             d = dig.hexdigest()
             if ref_digest is None:
                 ref_digest = d
-            row = {"round": rnd, "ms": {STAGES[i]: acc[i] / cnt for i in range(7)}, "launches_timed": cnt, "results_equal_first_variant": d == ref_digest,
+            row = {"round": rnd, "ms": {STAGES[i]: acc[i] / cnt for i in range(7)}, "launches_timed": cnt, "results_equal_first_variant": d == ref_digest, "windows_mid_big_ms": acc[7] / cnt, "stitch_lane_ms": acc[8] / cnt,
                    "lane_fraction": counters[39] / max(1, batches[-1].b.nReads)}
+            nlast = max(1, batches[-1].b.nReads)         # (the engine's counters are those of the last launch)
+            row["counters_per_pair"] = {k: counters[i] / nlast for i, k in enumerate(["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut"])}
+            row["counters_per_pair"].update({"nPrunedWin": counters[37] / nlast, "nRewalkRead": counters[38] / nlast, "nOwnerLookups": counters[40] / nlast, "nOwnerMisses": counters[41] / nlast,
+                                             "nAnchorLoci": counters[42] / nlast, "nAnchorReplayed": counters[43] / nlast})
+            if sum(counters[21:37]):                     # a -DSTARAMD_PROFILE build: shader-clock cycles per section, summed over wavefronts
+                pn = ["walk(all)", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime", "windows:passA", "windows:flanks", "windows:passB_enumerate+owner",
+                      "windows:passB_assign", "windows:emission", "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
+                row["profile_kcycles_per_pair"] = {pn[i]: round(counters[21 + i] / nlast / 1e3, 2) for i in range(16) if pn[i] != "-"}
+                row["profile_kcycles_per_pair"]["windows:passB_owner_lookups"] = round(counters[44] / nlast / 1e3, 2)       # (then passB_enumerate+owner is the enumeration alone)
+                row["profile_kcycles_per_pair"]["windows:passA_loads"] = round(counters[45] / nlast / 1e3, 2)               # (then passA is the replay alone)
+                row["profile_kcycles_per_pair"]["windows:passA_prefilter"] = round(counters[46] / nlast / 1e3, 2)
+                print("    profile (k cycles per pair):", row["profile_kcycles_per_pair"], flush=True)
+                pass
+            if True:
+                print("    counts per pair:", {k: round(v, 2) for k, v in row["counters_per_pair"].items()}, flush=True)
             table.setdefault(tag, []).append(row)
             m = row["ms"]
-            print("%-20s r%d  seed %6.2f  windows %6.2f  stitch %6.2f  redecide %5.2f  total %7.2f  lane %.3f  %s" %
-                  (tag, rnd, m[STAGES[0]], m[STAGES[1]], m[STAGES[3]], m[STAGES[4]], m[STAGES[6]], row["lane_fraction"], "" if row["results_equal_first_variant"] else "RESULTS DIFFER FROM THE FIRST VARIANT"), flush=True)
+            print("%-20s r%d  seed %6.2f  windows %6.2f (mid+big %5.2f)  stitch %6.2f (lane %5.2f)  redecide %5.2f  total %7.2f  lane %.3f  ovfWin %.5f  %s" %
+                  (tag, rnd, m[STAGES[0]], m[STAGES[1]], acc[7] / cnt, m[STAGES[3]], acc[8] / cnt, m[STAGES[4]], m[STAGES[6]], row["lane_fraction"], counters[13] / max(1, batches[-1].b.nReads), "" if row["results_equal_first_variant"] else "RESULTS DIFFER FROM THE FIRST VARIANT"), flush=True)
     os.environ.clear(); os.environ.update(saved_env)
     run.close()
     if a.out:
