@@ -39,7 +39,7 @@ def test_line_is_compact_and_counts_ranks(gpus, tmp_path):
     extra = json.load(open(d["extra"]))
     assert "counters_per_pair" in extra and "pipeline" in extra
     # reads processed by all ranks: every rank maps (steps) x 2000 pairs in the timed region
-    assert abs(d["value"] * d["ms_per_step"] * d["steps"] * 1e3 - gpus * 2 * 2000) < 1.0 + 0.01 * gpus * 4000
+    assert abs(d["value"] * d["ms_per_step"] * d["steps"] * 1e3 - gpus * 2 * 2000) < 0.05 * gpus * 4000      # (value is rounded to 4 digits: ~1 % at this tiny rate)
 
 
 def test_world_size_must_match_gpus(tmp_path):
