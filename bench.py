@@ -268,7 +268,9 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
         return time.perf_counter() - t
     run(1, ncpu, out_prefix + "ld_")                                    # page cache
     t_load = run(1, ncpu, out_prefix + "ld_")
-    best_th = max(1, min(ncpu // 4, 4 * effective_cpus()))          # (the reference waits on its input mutex beyond ~64 threads; a CPU quota lowers that further)
+    # the reference's best thread count on this box: the CPUs the container may use (measured on a 16-CPU quota behind 256 hardware threads: 16 threads 0.235,
+    # 24 -> 0.230, 32 -> 0.198, 48 -> 0.183, 64 -> 0.231, 256 -> 0.190 M pairs/s; profiles/r04_host_diagnostics.txt)
+    best_th = max(1, min(ncpu, effective_cpus()))
     n_all = min(n_pairs, 4000000)
     v_all = n_all / max(run(n_all, ncpu, out_prefix + "all_") - t_load, 1e-3) / 1e6
     v_best = n_pairs / max(run(n_pairs, best_th, out_prefix) - t_load, 1e-3) / 1e6       # last: its outputs stay for the parity check
@@ -362,6 +364,15 @@ def effective_cpus():
     except Exception:
         pass
     return n
+
+
+def cpu_throttle():
+    """(periods in which the container was throttled, microseconds throttled) so far: cgroup v2 cpu.stat"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except Exception:
+        return None
 
 
 def loaded_libs():
@@ -471,7 +482,7 @@ def main():
 
     def warmup_done():
         barrier()
-        t_clock["t0"] = time.perf_counter()
+        t_clock["t0"] = time.perf_counter(); t_clock["thr0"] = cpu_throttle()
 
     sj_ms = {}
 
@@ -492,6 +503,7 @@ def main():
     if rc != 0:
         raise RuntimeError("the star_amd pipeline failed with exit code %d" % rc)
     elapsed = float(rep.timedWall)
+    thr1 = cpu_throttle()
     barrier()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -514,6 +526,7 @@ def main():
     value = timed_reads_all / elapsed / 1e6
     extra = {"per_kernel_ms_timed_region": ms, "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
              "algorithmic_bytes_per_pair_whole_path": bytes_per_pair, "index_build": ginfo, "sj_merge_ms": sj_ms.get("ms"),
+             "cpu_throttled_in_timed_region": ({"periods": thr1[0] - t_clock["thr0"][0], "ms": (thr1[1] - t_clock["thr0"][1]) / 1e3} if thr1 and t_clock.get("thr0") else None),
              "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s_sum_over_contexts": sum(float(rep.deviceMs[k]) for k in range(n_ctx)) / 1e3,
                           "map_batch_call_s": sum(float(rep.deviceBusy[k]) for k in range(n_ctx)), "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)),
                           "parse_busy_s": float(rep.parseBusy), "convert_busy_s": float(rep.convertBusy), "postmap_write_busy_s": float(rep.emitBusy),

@@ -223,6 +223,11 @@ int  staramd_update_index(staramd_ctx *ctx, const staramd_genome *g, const stara
 struct staramd_sjdb_args; struct staramd_sjdb_result;
 int  staramd_insert_junctions(staramd_ctx *ctx, const struct staramd_sjdb_args *a, uint8_t *SAout, uint64_t saOutCapacity, uint8_t *SAiOut, uint64_t saiOutCapacity,
                               struct staramd_sjdb_result *res);
+/* Does the device have the memory for staramd_insert_junctions of up to maxJunctions junctions of sjdbLength bases each (the transient work space is several
+ * times the suffix array: ~110 GB for a human index)?  1 = yes, 0 = no (or the context is not usable).  The front end asks once, before it releases its host copy
+ * of the suffix array: with 0 it keeps that copy and inserts through host buffers (staramd_sjdb_insert + staramd_update_index) instead
+ * (sjdbInsertJunctions, source/sjdbInsertJunctions.cpp:11-102, needs the suffix array wherever it runs). */
+int  staramd_insert_junctions_fits(staramd_ctx *ctx, uint64_t maxJunctions, uint32_t sjdbLength);
 /* New chromosome / junction tables and parameters for an index whose big arrays (G, SA, SAindex) are already in place in HBM; g->G / SA / SAi are not read. */
 int  staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p);
 /* 2nd stage of --outFilterType BySJout.  Replaces the mutation of P.sjNovelStart / P.sjNovelEnd / P.sjNovelN and

@@ -77,6 +77,9 @@ int   sah_emit_slot_merged(void *h, int slot, const staramd_results *res, const 
 int   sah_next_phase(void *h);                                          /* 0 / 1 / 2, see above; -1 on error */
 uint64_t sah_novel_junctions(void *h, const uint64_t **start, const uint64_t **end);
 int   sah_in_pass1(void *h);
+/* --limitSjdbInsertNsj and the length of one inserted junction sequence (2 * sjdbOverhang + 1) of this run: what a junction insertion can grow the index by at most */
+uint64_t sah_limit_sjdb_insert(void *h);
+uint32_t sah_sjdb_length(void *h);
 int   sah_pass1_end(void *h);
 int   sah_in_stage1(void *h);
 int   sah_finish(void *h);

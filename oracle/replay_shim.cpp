@@ -129,6 +129,7 @@ void *staramd_pinned_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
 void staramd_pinned_free(void *p) { free(p); }
 const char *staramd_last_error(void) { return lastError.c_str(); }
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
+int staramd_insert_junctions_fits(staramd_ctx *, uint64_t, uint32_t) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 int staramd_index_build(int, const uint8_t *, const staramd_index_params *, uint8_t *, uint64_t, uint8_t *, uint64_t, staramd_index_result *) { lastError = "replay shim: no index build"; return STARAMD_ERR_DEVICE; }
 int staramd_sjdb_insert(int, const staramd_sjdb_args *, staramd_sjdb_result *) { lastError = "replay shim: no junction insertion"; return STARAMD_ERR_DEVICE; }

@@ -117,6 +117,7 @@ static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1);
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)48 << 30; *t = (size_t)64 << 30; return hipSuccess; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }

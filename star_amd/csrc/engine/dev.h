@@ -89,6 +89,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_nOwnerLookups, DC_nOwnerMisses,                              // k_windows pass B: loci that passed the covered-bins filter / of those, loci no window owns (filter false positives)
        DC_nAnchorLoci, DC_nAnchorReplayed,                             // k_windows pass A: anchor loci enumerated / replayed one by one (not owned by a window when their chunk was read)
        DC_wprof5, DC_wprof6, DC_wprof7,                                // -DSTARAMD_PROFILE build: more sections of k_windows
+       DC_nSkippedLeaves, DC_nRewalkWin,                               // stitch kernels: single-mate leaves (and subtrees of them) not finalised / two-mate windows walked again in full
        DC_N };
 
 // cursors[] slots

@@ -73,8 +73,8 @@ struct staramd_ctx {
     // wavefronts are resident per CU; the others are handed to a second launch with the full-size slice (0 = one full-size launch)
     u32 leanDepth = 0, leanArena = 0, stBlocksLean = 0;
     // lane-per-read stitcher (k_stitch_lane.hip): takes the light reads whose windows hold few seeds; the cooperative kernel gets the rest
-    u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 5; u8 *scrLane = nullptr;
-    u32 prune = 3;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first
+    u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 4; u8 *scrLane = nullptr;
+    u32 prune = 7;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first, bit 2 = single-mate leaves of two-mate windows skipped (5.6)
     u32 ldsLimit = 65536;                 // dynamic LDS a block may ask for
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
@@ -272,7 +272,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->prune = envU32("STARAMD_PRUNE", 3); c->laneClass = envU32("STARAMD_LANE_CLASS", 5);          // (knobs are read here, once: not on the launch path)
+    c->prune = envU32("STARAMD_PRUNE", 7); c->laneClass = envU32("STARAMD_LANE_CLASS", 4);          // (knobs are read here, once: not on the launch path)
     if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
     // first launch: 128 table rows + 512 owner-map slots = 6 KB of LDS per wavefront, 6 blocks of 4 wavefronts per CU (k_windows is held to 6 waves per SIMD)
     c->capW = envU32("STARAMD_CAP_WINDOWS", 128); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
@@ -445,6 +445,26 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
     refreshSharers(c);
     return STARAMD_OK;
+}
+
+// work space of sjdbInsertDevice (sjdb_core.h) beside the resident index: per new suffix ~7 words (offsets, positions, sort keys and permutations, double buffered);
+// the new packed suffix array + genome + SAindex; and for the SAindex rebuild the text of both strands, one 64-bit word per suffix, one per SAindex entry
+extern "C" int staramd_insert_junctions_fits(staramd_ctx *c, uint64_t maxJunctions, uint32_t sjdbLength) {
+    if (!c || c->owner) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 0;
+    const DevIndex &X = c->X;
+    const u64 nInd = 2ull * maxJunctions * sjdbLength;
+    const u64 nSAnew = X.nSA + nInd, nGnew = X.nGenome + maxJunctions * sjdbLength;
+    const u64 nSAi = X.saiStart[X.saiNbases];
+    u64 need = nInd * 8ull * 8ull                                               // per new suffix
+             + (nSAnew * X.saBits + 7) / 8 + nGnew + 2 * GPAD + (nSAi * X.saiBits + 7) / 8      // the new arrays
+             + 2 * nGnew + nSAnew * 8ull + nSAi * 8ull                          // SAindex rebuild
+             + (2ull << 30);                                                    // sort temporaries, slack
+    if (const char *e = getenv("STARAMD_SJDB_FITS_FREE_GB")) freeB = (size_t)(strtod(e, nullptr) * 1e9);      // (tests: pretend this much is free)
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: resident junction insertion needs up to %.1f GB, %.1f GB free\n", need / 1e9, freeB / 1e9);
+    return (u64)freeB >= need ? 1 : 0;
 }
 
 extern "C" int staramd_update_tables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {

@@ -771,7 +771,9 @@ __device__ __forceinline__ u32 nextSeed(u64 mask, u32 i, u32 nA) {
 
 // depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321):
 // include seed iA (if it stitches), then exclude it.  Wave-uniform control flow.  Returns false when the arena overflowed.
-__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec &wr, const u64 glb0, const u64 glb1) {
+// skipSingle: the leaves whose transcript holds seeds of ONE mate only are not finalised (nSkipped counts them and the subtrees that can
+// only end in such leaves); the caller accepts the result when the window's final best score puts every single-mate transcript below the selection bar.
+__device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec &wr, const u64 glb0, const u64 glb1, const bool skipSingle, u32 &nSkipped) {
     const u32 nA = win.nWA;
     c.str = win.str;
     wr.nWinTr = 0; wr.top = 0; wr.overflow = false; wr.bestScore = 0;
@@ -796,12 +798,24 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     u32 iLast = 0;                                   // last included seed of the working transcript
+    u32 fragFirst = 0, fragLast = 0;                 // mates of its first and of its last seed = of its first and last exon (stitchAlignToTranscript.cpp:413-414)
+    nSkipped = 0;
+    // seeds of mate 2 (the list is sorted by read position: they follow the seeds of mate 1)
+    const u64 mate2 = skipSingle ? __ballot(lane < nA && ldsGet(&WA[lane < nA ? lane : 0u]).iFrag != 0) : 0ull;
+    const u64 allSeeds = nA >= 64u ? ~0ull : ((1ull << nA) - 1ull);
     u64 follow = ~0ull;                              // seeds that can follow the last included one (all, while the transcript is empty)
     DWA a = uni(ldsGet(&WA[0]));
     for (;;) {
         DIAG(c.nNodes++);
-        if (iA >= nA) {                              // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
-            if (h.tR2 != 0) {
+        // every leaf below this node is a single-mate transcript: the transcript holds one mate so far and no seed of the other mate is left
+        bool onlySingle = false;
+        if (skipSingle && h.nExons > 0 && fragFirst == fragLast && iA < nA) {
+            const u64 other = (fragFirst ? (allSeeds & ~mate2) : mate2) >> iA;
+            onlySingle = other == 0;
+        }
+        if (iA >= nA || onlySingle) {                // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
+            if (h.tR2 != 0 && skipSingle && fragFirst == fragLast) nSkipped++;
+            else if (h.tR2 != 0) {
                 if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr, glb0, glb1, m.rec); PROF_ADD(c, 3); }
@@ -810,7 +824,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             if (sp == 0) break;
             sp--;                                    // back to the frame that included a seed: now exclude it
             SFrame f = uni(ldsGet(&stack[sp]));
-            h = f.h; iLast = f.pad; follow = h.nExons > 0 ? first64(m.compat[iLast]) : ~0ull;   // f.pad = last included seed of the restored transcript
+            h = f.h; iLast = f.pad & 255u; fragLast = f.pad >> 8; follow = h.nExons > 0 ? first64(m.compat[iLast]) : ~0ull;   // f.pad = last included seed of the restored transcript | its mate << 8
             iA = nextSeed(follow, f.iA, nA);
             if (h.nExons > 0 && lane == 0) ldsPut(&EX[h.nExons - 1], f.eA);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -841,7 +855,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
 #endif
             if (dScore > -1000000) {
                 if (lane == 0) {
-                    SFrame f; f.h = h; f.iA = iA; f.pad = iLast; f.eA = eAold;
+                    SFrame f; f.h = h; f.iA = iA; f.pad = iLast | (fragLast << 8); f.eA = eAold;
                     ldsPut(&stack[sp], f);
                     ldsPut(&EX[h.nExons - 1], eA);
                     if (added) ldsPut(&EX[h.nExons], eN);
@@ -859,9 +873,9 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             if (a.nrep == 1) hn.nUnique++;
             if (a.anchor > 0) hn.nAnchor++;
             hn.Score = h.Score + dScore; hn.tR2 = (u32)a.rStart + a.L - 1; hn.tG2 = a.gStart + a.L - 1;
-            if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; }
+            if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; fragFirst = a.iFrag; }
             h = hn; sp++;
-            iLast = iA; follow = first64(m.compat[iA]);
+            iLast = iA; fragLast = a.iFrag; follow = first64(m.compat[iA]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
         // include succeeded: continue below it; include failed: exclude branch (:348-351) = same transcript, next seed
@@ -970,8 +984,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_ITEM] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
     else if (mode == 2) { list = B.heavyList; nItems = B.cursors[CUR_ST_HEAVY]; ticketSlot = CUR_ST_TICKETH; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
-    u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0, nRewalk = 0;
-    const bool sweepEnable = (pruneEnable & 2u) != 0;
+    u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0, nRewalk = 0, nRewalkWin = 0, nSkippedLeaves = 0;
+    const bool sweepEnable = (pruneEnable & 2u) != 0, skipEnable = (pruneEnable & 4u) != 0;
     // ---- window pruning (ours; exact for what is returned under resultSelect == 1).  multMapSelect only ever picks transcripts with
     // maxScore >= trBest->maxScore - outFilterMultimapScoreRange (ReadAlign_multMapSelect.cpp:26-44).  The score of a transcript is bounded by
     // the lengths of the mates whose seeds its window holds plus perJ per junction (perJ = the positive part of the junction scores), so once
@@ -981,7 +995,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     // cover (and so remove, :267-285) a two-mate transcript.  Off when every transcript is wanted (resultSelect == 0: chimeric detection,
     // merged mates), with a positive genomic-length term or positive indel scores, and for reads that could reach alignTranscriptsPerReadNmax.
     const i32 perJ = max(0, P.sjdbScore) + max(0, max(max(P.scoreGap, P.scoreGapNoncan), max(P.scoreGapGCAG, P.scoreGapATAC)));
-    const bool pruneOn = pass0 && P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && pruneEnable != 0
+    const bool pruneOn = pass0 && P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && (pruneEnable & 3u) != 0
                          && P.scoreDelOpen <= 0 && P.scoreDelBase <= 0 && P.scoreInsOpen <= 0 && P.scoreInsBase <= 0;
 #ifdef STARAMD_PROFILE
     for (int k = 0; k < 16; k++) c.prof[k] = 0;
@@ -1065,14 +1079,36 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             else { o = uni(B.wout[w]); if (pass0) { o.minIn[0] = o.minIn[1] = 0; } }
             c.logOn = pass0 && !wholeRead;
             const u32 candStart = c.candTop;
+            // Single-mate leaves of a two-mate window: first walked WITHOUT them.  Two-mate records do not depend on single-mate ones (a
+            // single-mate transcript neither covers nor is covered-with-a-higher-score by... it cannot remove or block a two-mate one: stitchWindowAligns.cpp:267-285
+            // act on containment), so the window's two-mate records and its best score H come out as in the full walk.  If every single-mate transcript
+            // of the read is then below the selection bar (mate length + perJ * (MAX_N_EXONS - 1) + range < H), none of them can be returned or change what
+            // is, and the walk stands; else the window is walked again in full.  Same conditions as the window pruning (resultSelect == 1 ...).
+            if (pruneOn && !wholeRead && win.mates == 3u) nWinRead = first32(B.reads[win.read].nWin);
+            bool skipSingle = pruneOn && skipEnable && win.mates == 3u && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax;
             bool ok = false;
-            for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {         // 2nd attempt: same walk, record arena in HBM
-                wr.big = attempt != 0; wr.arenaBytes = wr.big ? wr.arenaBytesG : wr.arenaBytesL;
-                c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
-                c.sens[0] = c.sens[1] = 0x7FFFFFFF;
-                c.candTop = candStart; c.nCand = 0; c.logOvf = false;
-                { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr, glb0, glb1); PROF_ADD(c, 0); }
-                if (!ok) nOvf++;
+            for (;;) {
+                u32 nSkipped = 0;
+                ok = false;
+                for (u32 attempt = 0; attempt < 2 && !ok; attempt++) {         // 2nd attempt: same walk, record arena in HBM
+                    wr.big = attempt != 0; wr.arenaBytes = wr.big ? wr.arenaBytesG : wr.arenaBytesL;
+                    c.maxScoreMate[0] = o.minIn[0]; c.maxScoreMate[1] = o.minIn[1];
+                    c.sens[0] = c.sens[1] = 0x7FFFFFFF;
+                    c.candTop = candStart; c.nCand = 0; c.logOvf = false;
+                    { PROF_T0(); ok = stitchWindow(c, lane, win, m, wr, glb0, glb1, skipSingle, nSkipped); PROF_ADD(c, 0); }
+                    if (!ok) nOvf++;
+                }
+                if (ok && skipSingle && nSkipped) {
+                    const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + perJ * (STARAMD_MAX_N_EXONS - 1) + P.outFilterMultimapScoreRange;
+                    // (a full list may have pushed records out that the junk of the full walk would have pushed out differently: walked again as well)
+                    // (the bar is measured against the best score RECORDED so far in the read -- this window's final head or an earlier window's: trBest can only be higher)
+                    i32 readBest = wr.bestScore;
+                    if (wholeRead) readBest = max(readBest, bestSoFar);
+                    else readBest = max(readBest, firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                    if (!(bar < readBest) || wr.nWinTr >= P.alignTranscriptsPerWindowNmax) { skipSingle = false; nRewalkWin++; continue; }
+                    nSkippedLeaves += nSkipped;
+                }
+                break;
             }
             if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
             if (!flushWindow(B, lane, wr, o)) continue;
@@ -1113,6 +1149,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
         if (nPruned) atomicAdd((unsigned long long *)&B.counters[DC_nPrunedWin], (unsigned long long)nPruned);
         if (nRewalk) atomicAdd((unsigned long long *)&B.counters[DC_nRewalkRead], (unsigned long long)nRewalk);
+        if (nRewalkWin) atomicAdd((unsigned long long *)&B.counters[DC_nRewalkWin], (unsigned long long)nRewalkWin);
+        if (nSkippedLeaves) atomicAdd((unsigned long long *)&B.counters[DC_nSkippedLeaves], (unsigned long long)nSkippedLeaves);
 #ifdef STARAMD_PROFILE
         c.prof[7] = __builtin_readcyclecounter() - profKernelStart;      // whole wave life time
         for (int k = 0; k < 16; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);

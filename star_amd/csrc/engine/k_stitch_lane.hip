@@ -69,6 +69,7 @@ __device__ static void recordLane(const staramd_params &P, const staramd_transcr
         else if (uOld == 0) { for (u32 ii = iTr + 1; ii < wr.nWinTr; ii++) wr.rank[ii - 1] = wr.rank[ii]; wr.nWinTr--; }   // old one adds nothing: removed
         else iTr++;
     }
+    wr.bestScore = wr.nWinTr ? lrecT(wr, 0)->maxScore : 0;                            // (records may have been removed above, the head among them)
     if (iTr != wr.nWinTr) return;
     for (iTr = 0; iTr < wr.nWinTr; iTr++) { const staramd_transcript *r = lrecT(wr, iTr); if (Score > r->maxScore || (Score == r->maxScore && t.gLength < r->gLength)) break; }
     if (iTr >= P.alignTranscriptsPerWindowNmax) return;                               // ranks behind a full list: dropped
@@ -221,7 +222,8 @@ __device__ __forceinline__ u32 nextSeedLane(u32 mask, u32 i, u32 nA) {
 
 // depth-first walk of one window (stitchWindowAligns.cpp:8-353 called from ReadAlign_stitchPieces.cpp:321): include seed iA (if it
 // stitches), then exclude it -- the undo-log walk of k_stitch.hip:stitchWindow, one lane.  Returns false when the records outgrew the lane.
-__device__ static bool stitchWindowLane(StitchCtx &c, const DWin &win, const DWA *WAg, LaneRec &wr) {
+// skipSingle / nSkipped: as in k_stitch.hip:stitchWindow (single-mate leaves of a two-mate window are not finalised)
+__device__ static bool stitchWindowLane(StitchCtx &c, const DWin &win, const DWA *WAg, LaneRec &wr, const bool skipSingle, u32 &nSkipped) {
     const u32 nA = win.nWA;
     c.str = win.str;
     wr.nWinTr = 0; wr.top = 0; wr.overflow = false; wr.bestScore = 0;
@@ -244,17 +246,24 @@ __device__ static bool stitchWindowLane(StitchCtx &c, const DWin &win, const DWA
     h.nUnique = h.nAnchor = 0; h.rStart = 0; h.tR2 = 0;
     u32 iA = 0, sp = 0, ex0R = 0; u64 ex0G = 0;
     u32 iLast = 0; u32 follow = ~0u;
+    u32 fragFirst = 0, fragLast = 0, mate2 = 0;      // mates of the first / last seed of the working transcript; seeds of mate 2
+    nSkipped = 0;
+    if (skipSingle) for (u32 k = 0; k < nA; k++) if (WA[k].iFrag != 0) mate2 |= 1u << k;
+    const u32 allSeeds = (1u << nA) - 1u;
     for (;;) {
         c.nNodes++;
-        if (iA >= nA) {                              // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
-            if (h.tR2 != 0) {
+        bool onlySingle = false;                     // the transcript holds one mate and no seed of the other mate is left: every leaf below is a single-mate one
+        if (skipSingle && h.nExons > 0 && fragFirst == fragLast && iA < nA) onlySingle = (((fragFirst ? (allSeeds & ~mate2) : mate2) >> iA) == 0);
+        if (iA >= nA || onlySingle) {                // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
+            if (h.tR2 != 0 && skipSingle && fragFirst == fragLast) nSkipped++;
+            else if (h.tR2 != 0) {
                 for (u32 k = 0; k < h.nExons; k++) LEAF[k] = EX[k];
                 finalizeLane(c, h, LEAF, win.chr, wr);
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
             sp--;                                    // back to the frame that included a seed: now exclude it
-            h = stack[sp].h; iLast = stack[sp].iLast; follow = h.nExons > 0 ? compat[iLast] : ~0u;
+            h = stack[sp].h; iLast = stack[sp].iLast & 255u; fragLast = stack[sp].iLast >> 8; follow = h.nExons > 0 ? compat[iLast] : ~0u;
             iA = nextSeedLane(follow, stack[sp].iA, nA);
             if (h.nExons > 0) EX[h.nExons - 1] = stack[sp].eA;
             continue;
@@ -267,7 +276,7 @@ __device__ static bool stitchWindowLane(StitchCtx &c, const DWin &win, const DWA
             const staramd_exon eAold = eA;
             dScore = stitchAlignToTranscript(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G);
             if (dScore > -1000000) {
-                stack[sp].h = h; stack[sp].iA = iA; stack[sp].iLast = iLast; stack[sp].eA = eAold;
+                stack[sp].h = h; stack[sp].iA = iA; stack[sp].iLast = iLast | (fragLast << 8); stack[sp].eA = eAold;
                 EX[h.nExons - 1] = eA;
                 if (added) { EX[h.nExons] = eN; hn.nExons = h.nExons + 1; }
             }
@@ -283,9 +292,9 @@ __device__ static bool stitchWindowLane(StitchCtx &c, const DWin &win, const DWA
             if (a.nrep == 1) hn.nUnique++;
             if (a.anchor > 0) hn.nAnchor++;
             hn.Score = h.Score + dScore; hn.tR2 = (u32)a.rStart + a.L - 1; hn.tG2 = a.gStart + a.L - 1;
-            if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; }
+            if (h.nExons == 0) { ex0R = a.rStart; ex0G = a.gStart; fragFirst = a.iFrag; }
             h = hn; sp++;
-            iLast = iA; follow = compat[iA];
+            iLast = iA; fragLast = a.iFrag; follow = compat[iA];
         }
         // include succeeded: continue below it; include failed: exclude branch (:348-351) = same transcript, next seed
         iA = nextSeedLane(follow, iA, nA);
@@ -341,10 +350,10 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
     const u32 posMin = maxClass < 31u ? B.costHist[32u + maxClass + 1u] : 0u;
     const u32 G = (nItemsRaw + 63u) / 64u;            // k_order_scatter: item of rank `pos` (heaviest class first) sits at order[(pos % G) * 64 + pos / G]
     const i32 perJ = max(0, P.sjdbScore) + max(0, max(max(P.scoreGap, P.scoreGapNoncan), max(P.scoreGapGCAG, P.scoreGapATAC)));
-    const bool pruneOn = P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && pruneEnable != 0
+    const bool pruneOn = P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && (pruneEnable & 3u) != 0
                          && P.scoreDelOpen <= 0 && P.scoreDelBase <= 0 && P.scoreInsOpen <= 0 && P.scoreInsBase <= 0;
-    const bool sweepEnable = (pruneEnable & 2u) != 0;
-    u32 nPruned = 0, nRewalk = 0, nLaneItems = 0;
+    const bool sweepEnable = (pruneEnable & 2u) != 0, skipEnable = (pruneEnable & 4u) != 0;
+    u32 nPruned = 0, nRewalk = 0, nLaneItems = 0, nRewalkWin = 0, nSkippedLeaves = 0;
     for (;;) {
         const u32 pos = atomicAdd(&B.cursors[CUR_ST_TICKET0], 1u);
         if (pos >= nItemsRaw) break;
@@ -400,7 +409,22 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
                     DWinOut o;
                     o.minIn[0] = carry[0]; o.minIn[1] = carry[1];
                     c.maxScoreMate[0] = carry[0]; c.maxScoreMate[1] = carry[1];
-                    if (!stitchWindowLane(c, win, B.waPool + win.waOffset, wr)) { defer = true; break; }
+                    {   // two-mate windows: first without their single-mate leaves (see k_stitch_win)
+                        bool skipSingle = pruneOn && skipEnable && win.mates == 3u && (u64)(nWin + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax;
+                        bool okW = true;
+                        for (;;) {
+                            u32 nSkipped = 0;
+                            c.maxScoreMate[0] = carry[0]; c.maxScoreMate[1] = carry[1];
+                            okW = stitchWindowLane(c, win, B.waPool + win.waOffset, wr, skipSingle, nSkipped);
+                            if (okW && skipSingle && nSkipped) {
+                                const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + perJ * (STARAMD_MAX_N_EXONS - 1) + P.outFilterMultimapScoreRange;
+                                if (!(bar < max(wr.bestScore, bestSoFar)) || wr.nWinTr >= P.alignTranscriptsPerWindowNmax) { skipSingle = false; nRewalkWin++; continue; }
+                                nSkippedLeaves += nSkipped;
+                            }
+                            break;
+                        }
+                        if (!okW) { defer = true; break; }
+                    }
                     if (!flushWindowLane(B, wr, o)) continue;
                     o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
                     carry[0] = c.maxScoreMate[0]; carry[1] = c.maxScoreMate[1];
@@ -428,6 +452,8 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
     if (nPruned) atomicAdd((unsigned long long *)&B.counters[DC_nPrunedWin], (unsigned long long)nPruned);
     if (nRewalk) atomicAdd((unsigned long long *)&B.counters[DC_nRewalkRead], (unsigned long long)nRewalk);
     if (nLaneItems) atomicAdd((unsigned long long *)&B.counters[DC_nLaneItems], (unsigned long long)nLaneItems);
+    if (nRewalkWin) atomicAdd((unsigned long long *)&B.counters[DC_nRewalkWin], (unsigned long long)nRewalkWin);
+    if (nSkippedLeaves) atomicAdd((unsigned long long *)&B.counters[DC_nSkippedLeaves], (unsigned long long)nSkippedLeaves);
 #if defined(STARAMD_PROFILE) || defined(STARAMD_SHADOW)
     atomicAdd((unsigned long long *)&B.counters[DC_nStitchCalls], (unsigned long long)c.nStitchCalls);
     atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);

@@ -74,6 +74,15 @@ __device__ __forceinline__ u64 waveMax64(u64 v) {
 }
 __device__ __forceinline__ u32 waveMin32(u32 v) { return ~waveMaxU32(~v); }
 
+// seed `src` (wave-uniform) of the rows the lanes preloaded (lane i = row i of the read's seed table)
+__device__ __forceinline__ DSeed seedOfLane(const DSeed &mine, u32 src) {
+    DSeed r; const u32 *sw = (const u32 *)&mine; u32 *d = (u32 *)&r;
+#pragma unroll
+    for (u32 i = 0; i < 5; i++) d[i] = laneGet32(sw[i], src);
+    d[5] = 0;
+    return r;
+}
+
 // ReadAlign_createExtendWindowsWithAlign.cpp:7-84 ; all arguments wave-uniform; returns 1 on TOO_MANY_WINDOWS / overflow
 // aChr = chrBin[aBin >> winBinChrNbits], looked up by the lane that enumerated the locus.  Every core bin of a window lies on the chromosome the window was
 // created on (a window only grows by bins of its own chromosome, :28,:47,:66), so "is the neighbour on my chromosome" is a comparison with the neighbour's
@@ -304,9 +313,17 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         s.nW = 0; s.nBlocks = 0; s.tooMany = false; s.winLimit = false; s.overflow = false;
         s.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         WPROF_T0();
+        // The seed table of the read and the first suffix-array entry of every seed are fetched up front, lane i = seed i: two round trips for the whole
+        // read.  Most seeds are unique (one locus): walking the table seed by seed, as both passes do, would otherwise wait for a table row and then for a
+        // random suffix-array word, ~34 dependent round trips per read pair.
+        const u32 nPre = min(rd.nSeeds, 64u);
+        DSeed mySeed; { u32 *z = (u32 *)&mySeed; z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = 0; }
+        u64 myA1 = 0;
+        if (lane < nPre) { mySeed = PC[lane]; myA1 = packedGet(X.SA, mySeed.saStart, X.saBits, X.saMask); }
         // ---- pass A: anchors (ReadAlign_stitchPieces.cpp:41-93)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow; iP++) {
-            const DSeed sd = PC[iP];
+            const DSeed sd = iP < nPre ? seedOfLane(mySeed, iP) : PC[iP];
+            const u64 preA1 = laneGet64(myA1, iP < nPre ? iP : 0u);
             if (sd.nrep > P.winAnchorMultimapNmax) continue;
             u32 aDir = sd.dir, aLength = sd.L;
             bool stop = false;
@@ -316,7 +333,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 u64 a1 = 0, a1A = 0; u32 aStr = 0; u32 kind = 0;       // kind: bit 0 = the locus (the donor half of a split one), bit 1 = the acceptor half of a split locus
                 u32 aChr = 0, aChrA = 0;
                 if (lane < cnt) {
-                    a1 = packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
+                    a1 = (sd.nrep == 1u && iP < nPre) ? preA1 : packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
                     aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
                     if (aDir == 1 && aStr == 0) aStr = 1;
                     else if (aDir == 0 && aStr == 1) a1 = X.nGenome - (aLength + a1);
@@ -395,7 +412,8 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         WPROF_MARK(1);
         // ---- pass B: all seeds (:129-185)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooMany; iP++) {
-            const DSeed sd = PC[iP];
+            const DSeed sd = iP < nPre ? seedOfLane(mySeed, iP) : PC[iP];
+            const u64 preA1 = laneGet64(myA1, iP < nPre ? iP : 0u);
             u32 aNrep = sd.nrep, aFrag = sd.iFrag, aLength = sd.L, aDir = sd.dir;
             bool aAnchor = aNrep <= P.winAnchorMultimapNmax;
             for (u32 base = 0; base < aNrep && !s.overflow && !s.tooMany; base += 64) {
@@ -403,7 +421,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 u64 a1 = 0, a1A = 0; u32 aRstart = 0, lD = 0, lA = 0, isj = 0; u32 wD = NOWIN, wA = NOWIN; bool split = false;
                 u32 binD = 0, binA = 0, lStr = 0; bool candD = false, candA = false;
                 if (lane < cnt) {
-                    a1 = packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
+                    a1 = (aNrep == 1u && iP < nPre) ? preA1 : packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
                     u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
                     aRstart = sd.rStart;
                     if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }

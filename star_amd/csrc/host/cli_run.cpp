@@ -172,7 +172,12 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     // junction insertion between the passes runs on the arrays resident in HBM, on every context (no host copy of the new SA unless it is to be saved)
     std::vector<staramd_ctx *> owners(ctx.begin(), ctx.begin() + nOwners);      // index changes go to the owners; the contexts that share an index follow
     struct ResidentUser { std::vector<staramd_ctx *> *ctx; } residentUser{&owners};
-    if (!getenv("STARAMD_SJDB_HOST") && !getenv("STARAMD_SJDB_NO_RESIDENT")) {
+    // ... provided every device has the room for it (the work space of the insertion is several times the suffix array): asked ONCE, here, because the host copy of
+    // the suffix array is released below and nothing could insert without it afterwards.  Without the room: host buffers (staramd_sjdb_insert) + re-upload.
+    bool residentFits = true;
+    for (int d = 0; d < nOwners; d++) if (!staramd_insert_junctions_fits(ctx[d], (uint64_t)sah_limit_sjdb_insert(h), (uint32_t)sah_sjdb_length(h))) residentFits = false;
+    if (!residentFits && (sah_in_pass1(h) || getenv("STARAMD_VERBOSE"))) fprintf(stderr, "star_amd: not enough free device memory to insert junctions into the resident index: the suffix array stays on the host, insertion goes through host buffers\n");
+    if (residentFits && !getenv("STARAMD_SJDB_HOST") && !getenv("STARAMD_SJDB_NO_RESIDENT")) {
         sah_set_sjdb_resident_fn([](void *user, const staramd_sjdb_args *a, staramd_sjdb_result *res) -> int {
             std::vector<staramd_ctx *> &cx = *((ResidentUser *)user)->ctx;
             std::vector<int> rcs(cx.size(), 0); std::vector<staramd_sjdb_result> rs(cx.size()); std::vector<std::string> es(cx.size());

@@ -491,12 +491,18 @@ struct Runner {
     // junctions into the index, reads rewound.  The caller then re-uploads the index (staramd_update_index).
     bool endPass1() {
         if (!pass1) { error = "not in the 1st pass"; return false; }
+        static const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+        auto T0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  end of pass 1: %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
         sjBg.drainInto(sj);
+        lap("junction table drained");
         error = sj.filterAndWrite(P, gi, P.twopassDir + "SJ.out.tab");
         if (!error.empty()) return false;
         stats.reportFinal(P.twopassDir + "Log.final.out");
+        lap("SJ.out.tab + Log.final.out");
         error = sjdbInsertJunctions(P, gi, sjdbLoci, true, P.twopassDir + "SJ.out.tab", insertLog);
         if (!error.empty()) return false;
+        lap("sjdbInsertJunctions");
         error = reader.reopen();
         if (!error.empty()) return false;
         time_t t0 = stats.timeStart;
@@ -696,6 +702,8 @@ int sah_threads(void *h) { return ((Runner *)h)->P.runThreadN; }
 // 2-pass mapping: sah_in_pass1() is 1 after sah_create when --twopassMode Basic was given; map all batches, call sah_pass1_end()
 // (junction insertion on the host), re-upload sah_genome()/sah_params() with staramd_update_index(), map all batches again.
 int sah_in_pass1(void *h) { return ((Runner *)h)->pass1 ? 1 : 0; }
+uint64_t sah_limit_sjdb_insert(void *h) { return (uint64_t)((Runner *)h)->P.limitSjdbInsertNsj; }
+uint32_t sah_sjdb_length(void *h) { Runner *r = (Runner *)h; const uint32_t ov = r->gi.view.sjdbOverhang ? r->gi.view.sjdbOverhang : r->P.sjdbOverhang; return 2 * ov + 1; }
 int sah_pass1_end(void *h) { return ((Runner *)h)->endPass1() ? 0 : -1; }
 // general form (2-pass and/or --outFilterType BySJout): after the last batch call sah_next_phase(): 0 = done, call sah_finish();
 // 1 = the index was rewritten: staramd_update_index(sah_genome(), sah_params()) and map every batch again; 2 = the junction

@@ -129,6 +129,13 @@ def test_front_end_two_pass_with_resident_junction_insertion(more, n, tmp_path, 
     run_cli_case(emul_cli, "pe101", more + ["--readMapNumber", str(n)], 40, tmp_path, env=SMALL)
 
 
+def test_front_end_two_pass_when_the_device_has_no_room_for_resident_insertion(tmp_path, emul_cli):
+    """staramd_insert_junctions_fits says no (STARAMD_SJDB_FITS_FREE_GB: a pretended amount of free device memory): the front end keeps its host copy of the suffix
+    array, the junctions of the 1st pass are inserted through host buffers and the index is uploaded again -- same outputs as the reference's 2-pass run"""
+    from test_cli_pipeline import run_cli_case
+    run_cli_case(emul_cli, "pe101", ["--twopassMode", "Basic", "--readMapNumber", "60"], 40, tmp_path, env=dict(SMALL, STARAMD_SJDB_FITS_FREE_GB="0.001"))
+
+
 @pytest.mark.parametrize("more", [[], ["--sjdbInsertSave", "All"]])
 def test_front_end_two_pass_without_any_junction(more, tmp_path, emul_cli):
     """2-pass on an index without annotation whose 1st pass yields NO junction (filters nobody passes): nothing is inserted, the engine contexts keep the
