@@ -11,6 +11,7 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <mutex>
 
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
@@ -73,9 +74,10 @@ struct staramd_ctx {
     // wavefronts are resident per CU; the others are handed to a second launch with the full-size slice (0 = one full-size launch)
     u32 leanDepth = 0, leanArena = 0, stBlocksLean = 0;
     // lane-per-read stitcher (k_stitch_lane.hip): takes the light reads whose windows hold few seeds; the cooperative kernel gets the rest
-    u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 4; u8 *scrLane = nullptr;
+    u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 3; u8 *scrLane = nullptr;
     u32 prune = 7;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first, bit 2 = single-mate leaves of two-mate windows skipped (5.6)
     u32 ldsLimit = 65536;                 // dynamic LDS a block may ask for
+    u32 kernelTurns = 1;                  // STARAMD_KERNEL_TURNS: the kernel phase of a batch is serialised over the contexts of a device (runDevice)
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
@@ -272,7 +274,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->prune = envU32("STARAMD_PRUNE", 7); c->laneClass = envU32("STARAMD_LANE_CLASS", 4);          // (knobs are read here, once: not on the launch path)
+    c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 1); c->laneClass = envU32("STARAMD_LANE_CLASS", 3);          // (knobs are read here, once: not on the launch path)
     if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
     // first launch: 128 table rows + 512 owner-map slots = 6 KB of LDS per wavefront, 6 blocks of 4 wavefronts per CU (k_windows is held to 6 waves per SIMD)
     c->capW = envU32("STARAMD_CAP_WINDOWS", 128); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
@@ -631,12 +633,20 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     return STARAMD_OK;
 }
 
+// The kernels of the engine are persistent launches sized to fill the GPU: when two contexts of one device (the front end runs two, so that the copies of one
+// batch overlap with the kernels of the other) have their launches in flight at the same time they do not run side by side, they take each other's CUs -- every
+// kernel stretches, and the short ones (k_stitch_verify: 1 ms alone) wait 5-7 ms for a CU behind the other context's persistent blocks (rocprofv3 timeline,
+// profiles/r04_timeline_two_contexts.txt).  So the KERNEL phase of a batch is taken in turns per device; uploads before it and result copies after it still
+// overlap with the other context's kernels, which is what the second context is for.
+static std::mutex g_kernelTurn[64];
 static int runDevice(staramd_ctx *c, staramd_results *r) {
     DevBatch &B = c->B; hipStream_t s = c->stream;
     u32 n = B.nReads;
     u32 flags = 0;
     for (int attempt = 0;; attempt++) {
-        int rc = launchAll(c, r, &flags);
+        int rc;
+        if (c->kernelTurns) { std::lock_guard<std::mutex> turn(g_kernelTurn[c->device & 63]); rc = launchAll(c, r, &flags); }
+        else rc = launchAll(c, r, &flags);
         if (rc) return rc;
         if (flags == 0) break;
         const u32 *cur = c->hostScratch + 8;

@@ -1039,35 +1039,26 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         }
         for (;;) {
         if (sweep == 2) { carry[0] = carry[1] = 0; bestSoFar = 0; }
-        for (u32 iw = 0; iw < nWin; iw++) {
-            const u32 w = w0 + iw;
-            const DWin win = uni(B.winPool[w]);
+        // The windows of the item 64 at a time, lane k = window chunk + k: one load brings the rows of all of them (a read has ~20 windows of which ~3 are
+        // walked: going through them one dependent load at a time cost more round trips than the walks), the windows that are skipped unwalked get their
+        // empty result from their own lane in one store, and only the windows a sweep has to look at are visited.
+        for (u32 chunk = 0; chunk < nWin; chunk += NLANE) {
+        DWin myWin; { u32 *z = (u32 *)&myWin; z[0] = z[1] = z[2] = z[3] = 0; }
+        const bool haveW = chunk + lane < nWin;
+        if (haveW) myWin = B.winPool[w0 + chunk + lane];
+        const u64 validM = __ballot(haveW), pairM = __ballot(haveW && myWin.mates == 3u);
+        u64 emptyM = sweep == 1 ? (validM & ~pairM) : 0ull;            // sweep 1: everything that was not walked in sweep 0
+        for (u64 visit = sweep == 0 ? pairM : sweep == 1 ? 0ull : validM; visit; visit &= visit - 1) {
+            const u32 il = firstLane(visit);
+            const u32 w = w0 + chunk + il;
+            DWin win; { u32 *d = (u32 *)&win; const u32 *sw = (const u32 *)&myWin; d[0] = laneGet32(sw[0], il); d[1] = laneGet32(sw[1], il); d[2] = laneGet32(sw[2], il); d[3] = laneGet32(sw[3], il); }
             if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
             if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-            if (sweep == 0 && win.mates != 3u) continue;
-            if (sweep == 1) {
-                if (win.mates == 3u) continue;                         // walked in sweep 0
-                if (lane == 0) {
-                    DWinOut z; z.trOffset = z.nTr = z.exOffset = z.nEx = 0; z.mm[0] = z.mm[1] = 0; z.sens[0] = z.sens[1] = 0x7FFFFFFF; z.minIn[0] = z.minIn[1] = 0;
-                    z.headScore = 0; z.candOff32 = 0; z.headGlen = 0; z.nCand = 0; z.pad = 0;
-                    B.wout[w] = z;
-                }
-                nPruned++;
-                continue;
-            }
             if (pruneOn && win.mates != 0 && sweep == 2) {
                 if (!wholeRead) { nWinRead = first32(B.reads[win.read].nWin); bestSoFar = firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
                 const i32 bound = (i32)((win.mates & 1u) ? c.readLength[0] : 0u) + (i32)((win.mates & 2u) ? c.readLength[1] : 0u) + perJ * ((i32)win.nWA - 1);
                 if ((u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax
-                    && bound + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1) < bestSoFar) {
-                    if (lane == 0) {
-                        DWinOut z; z.trOffset = z.nTr = z.exOffset = z.nEx = 0; z.mm[0] = z.mm[1] = 0; z.sens[0] = z.sens[1] = 0x7FFFFFFF; z.minIn[0] = z.minIn[1] = 0;
-                        z.headScore = 0; z.candOff32 = 0; z.headGlen = 0; z.nCand = 0; z.pad = 0;
-                        B.wout[w] = z;
-                    }
-                    nPruned++;
-                    continue;
-                }
+                    && bound + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1) < bestSoFar) { emptyM |= 1ull << il; continue; }
             }
             {   // stage the window's seed list in LDS (6 dwords per row)
                 const u32 *src = (const u32 *)(B.waPool + win.waOffset); LDS u32 *dst = (LDS u32 *)m.WA;
@@ -1128,6 +1119,15 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
                 else { c.candTop = candStart; if (sensitive) o.nCand = 0xFFFFFFFFu; }
             }
             if (lane == 0) B.wout[w] = o;
+        }
+        if (emptyM) {                                          // the windows of this chunk that are not walked: an empty result each
+            if ((emptyM >> lane) & 1ull) {
+                DWinOut z; z.trOffset = z.nTr = z.exOffset = z.nEx = 0; z.mm[0] = z.mm[1] = 0; z.sens[0] = z.sens[1] = 0x7FFFFFFF; z.minIn[0] = z.minIn[1] = 0;
+                z.headScore = 0; z.candOff32 = 0; z.headGlen = 0; z.nCand = 0; z.pad = 0;
+                B.wout[w0 + chunk + lane] = z;
+            }
+            nPruned += (u32)__popcll(emptyM);
+        }
         }
         if (sweep == 0) {
             // the bar every single-mate window must stay under: longest mate + junction bonuses of the window with most seeds + the margins

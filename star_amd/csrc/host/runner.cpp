@@ -282,8 +282,13 @@ struct Runner {
         if (P.wasp && !pass1 && !wasp) { error = "EXITING because of FATAL ERROR: --waspOutputMode: the allele-swapped reads of the batch were not mapped (sah_wasp_batch / sah_wasp_results)"; return false; }
         const std::vector<int8_t> *waspType = (wasp && !pass1) ? &wasp->type : nullptr;
         if (mg && (mg->reads.n == 0 || !mgRes)) { if (mg->reads.n > 0) { error = "EXITING because of FATAL ERROR: --peOverlapNbasesMin: the merged mates of the batch were not mapped (sah_merged_batch / sah_emit_merged)"; return false; } mg = nullptr; }
-        uint32_t T = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
-        T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per thread
+        // T contiguous read ranges, each with buffers of its own, formatted by Wk worker threads that take the next range when they are done with one: with as many
+        // ranges as threads the section lasts as long as its slowest thread, and on a shared host (the GPU boxes: 16 CPUs of a 256-thread machine) one descheduled
+        // thread held the batch for several times the mean (per-thread busy 2.5 - 5.6 ms in a 24 ms section).  Four ranges per thread; gene counting keeps one
+        // (a count table per range)
+        const uint32_t Wk = (uint32_t)std::max(1, std::min(P.runThreadN, 256));
+        uint32_t T = (P.quantGeneCounts || P.quantTrSAM) ? Wk : std::min<uint32_t>(4 * Wk, 256);
+        T = std::max<uint32_t>(1, std::min<uint32_t>(T, bt.n / 256));       // at least 256 reads per range
         int k;
         auto te0 = std::chrono::steady_clock::now();
         { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !freeSets.empty(); }); k = freeSets.front(); freeSets.pop_front(); }
@@ -330,9 +335,11 @@ struct Runner {
                     errs[t] = post->processRange(bt, *r, lo, hi, ro, ri);
                     for (const QuantPatch &p : qp0) nAlignT[p.ir] = p.nAlignT + 1;
                 };
+                std::atomic<uint32_t> nextC(0);
+                auto countLoop = [&] { for (;;) { const uint32_t t = nextC.fetch_add(1); if (t >= T) break; count(t); } };
                 std::vector<std::thread> th;
-                for (uint32_t t = 1; t < T; t++) th.emplace_back(count, t);
-                count(0);
+                for (uint32_t w = 1; w < std::min(Wk, T); w++) th.emplace_back(countLoop);
+                countLoop();
                 for (auto &x : th) x.join();
             }
             post->drawMultOrder(bt, *r, [&] { return rngUniformReal0to1(rngMultOrder); }, multOrder, trSAM ? &nAlignT : nullptr, mg, mgRes);
@@ -380,14 +387,16 @@ struct Runner {
         };
         if (T == 1) work(0);
         else {
+            std::atomic<uint32_t> nextR(0);
+            auto workLoop = [&] { for (;;) { const uint32_t t = nextR.fetch_add(1); if (t >= T) break; work(t); } };
             std::vector<std::thread> th;
-            for (uint32_t t = 1; t < T; t++) th.emplace_back(work, t);
-            work(0);
+            for (uint32_t w = 1; w < std::min(Wk, T); w++) th.emplace_back(workLoop);
+            workLoop();
             for (auto &x : th) x.join();
         }
         auto te2 = std::chrono::steady_clock::now(); tEmitFormat += std::chrono::duration<double>(te2 - te1).count();
         if (hostTiming && T > 0) { double mn = 1e9, mx = 0, sm = 0; for (double x : tThread) { mn = std::min(mn, x); mx = std::max(mx, x); sm += x; }
-            fprintf(stderr, "  emit: %u threads, section %.2f ms, per-thread min %.2f / mean %.2f / max %.2f ms\n", T, std::chrono::duration<double, std::milli>(te2 - te1).count(), mn, sm / T, mx); }
+            fprintf(stderr, "  emit: %u ranges on %u threads, section %.2f ms, per-range min %.2f / mean %.2f / max %.2f ms\n", T, std::min(Wk, T), std::chrono::duration<double, std::milli>(te2 - te1).count(), mn, sm / T, mx); }
         struct AddTail { double &acc; std::chrono::steady_clock::time_point t0; ~AddTail() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } addTail{tEmitTail, te2};
         for (uint32_t t = 0; t < T; t++) if (!errs[t].empty() && error.empty()) error = errs[t];
         if (!error.empty()) o.used = 0;

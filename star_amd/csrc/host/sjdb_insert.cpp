@@ -123,9 +123,18 @@ void sjdbLoadFromStream(std::istream &in, SjdbLoci &loci) {
     std::string line;
     while (in.good()) {
         std::getline(in, line);
-        std::istringstream ls(line);
+        // `ls >> chr1 >> u1 >> u2 >> str1` of the reference (sjdbLoadFromStream.cpp:9-12), by hand: a stream object per line was 0.7 s for the two tables of a 2-pass run
         std::string chr1; uint64_t u1 = 0, u2 = 0; char str1 = '.';
-        ls >> chr1 >> u1 >> u2 >> str1;
+        {
+            const char *p = line.c_str();
+            auto ws = [&] { while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f') p++; };
+            ws(); const char *b = p; while (*p && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f')) p++;
+            chr1.assign(b, p);
+            bool ok = !chr1.empty();
+            auto num = [&](uint64_t &v) { ws(); if (!ok || *p < '0' || *p > '9') { ok = false; return; } char *e; v = strtoull(p, &e, 10); p = e; };     // (a failed extraction leaves the rest at its default, as the stream does)
+            num(u1); num(u2);
+            if (ok) { ws(); if (*p) str1 = *p; }
+        }
         if (chr1.empty()) continue;
         loci.chr.push_back(chr1); loci.start.push_back(u1); loci.end.push_back(u2);
         loci.str.push_back((str1 == '1' || str1 == '+') ? '+' : (str1 == '2' || str1 == '-') ? '-' : '.');
@@ -156,8 +165,16 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     const uint64_t nGenomeReal = gi.chrStart[nChr];
     const uint64_t ov = V.sjdbOverhang, sjdbLength = V.sjdbLength;
     // the old index: genome text with spacer padding on both sides, junction table
-    std::vector<uint8_t> Gp(GP + V.nGenome + GP, SPACER);
-    memcpy(Gp.data() + GP, gi.G.data(), V.nGenome);
+    // (3 GB for a human genome: not zero-filled first, copied on threads -- the two single-threaded passes over it were 1.5 s of every insertion)
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> Gp(GP + V.nGenome + GP);
+    memset(Gp.data(), SPACER, GP); memset(Gp.data() + GP + V.nGenome, SPACER, GP);
+    {
+        const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(P.runThreadN, 1), V.nGenome >> 24));
+        const uint64_t per = (V.nGenome + T - 1) / T;
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t] { const uint64_t lo = std::min<uint64_t>(V.nGenome, (uint64_t)t * per), hi = std::min<uint64_t>(V.nGenome, lo + per); if (hi > lo) memcpy(Gp.data() + GP + lo, gi.G.data() + lo, hi - lo); });
+        for (auto &x : th) x.join();
+    }
     const uint8_t *G = Gp.data() + GP;
     const std::vector<uint64_t> oldStart = gi.sjdbStart, oldEnd = gi.sjdbEnd;
     const uint64_t oldSjdbN = V.sjdbN, oldNSA = V.nSA, oldNGenome = V.nGenome;
@@ -482,8 +499,9 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     lap("SAi");
     }
     // ---------------- the index is now the new one
-    gi.G.assign(nGenomeNew, 0);
-    memcpy(gi.G.data(), G, nGenomeReal);
+    // the chromosomes stay where they are; the inserted sequences behind them are replaced (capacity for later insertions is taken once)
+    if (gi.G.capacity() < nGenomeNew) gi.G.reserve(nGenomeNew + (uint64_t)P.limitSjdbInsertNsj * sjdbLength / 4);
+    gi.G.resize(nGenomeNew);
     memcpy(gi.G.data() + nGenomeReal, Gsj.data(), nGsj);
     if (!SA2v.empty()) {
         { Packed SA2f(SA2v.data(), wSA); SA2f.put(nSAnew, 0); }            // sjdbInsertJunctions.cpp:66-68
