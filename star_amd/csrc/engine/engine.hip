@@ -77,10 +77,12 @@ struct staramd_ctx {
     u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 3; u8 *scrLane = nullptr;
     u32 prune = 7;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first, bit 2 = single-mate leaves of two-mate windows skipped (5.6)
     u32 ldsLimit = 65536;                 // dynamic LDS a block may ask for
-    u32 kernelTurns = 1;                  // STARAMD_KERNEL_TURNS: the kernel phase of a batch is serialised over the contexts of a device (runDevice)
+    u32 kernelTurns = 0;                  // STARAMD_KERNEL_TURNS=1: the kernel phase of a batch is serialised over the contexts of a device (runDevice); off: measured no gain
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
     staramd_read_result *dOutReads = nullptr; staramd_transcript *dOutTr = nullptr; staramd_exon *dOutEx = nullptr;
     hipEvent_t ev[10];
+    hipEvent_t evWait = nullptr;          // blocking-sync event: the mapper thread SLEEPS while its batch is on the device (hipStreamSynchronize spins on a core; the
+                                          // front end runs one mapper thread per context beside its parser and formatter threads, on hosts with a CPU quota)
     float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; float ms8 = 0;   // per-stage HIP-event times of the last batch (staramd_get_timings)
     u64 counters[DC_N];
     u32 residentReads = 0; u32 residentMaxLread = 0;
@@ -274,7 +276,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 1); c->laneClass = envU32("STARAMD_LANE_CLASS", 3);          // (knobs are read here, once: not on the launch path)
+    c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 0); c->laneClass = envU32("STARAMD_LANE_CLASS", 3);          // (knobs are read here, once: not on the launch path)
     if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
     // first launch: 128 table rows + 512 owner-map slots = 6 KB of LDS per wavefront, 6 blocks of 4 wavefronts per CU (k_windows is held to 6 waves per SIMD)
     c->capW = envU32("STARAMD_CAP_WINDOWS", 128); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
@@ -362,6 +364,7 @@ extern "C" int staramd_create(staramd_ctx **out, int device, const staramd_genom
     if (!rc) rc = allocWork(c);
     if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
+    if (!rc && !getenv("STARAMD_SPIN_WAIT") && hipEventCreateWithFlags(&c->evWait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) c->evWait = nullptr;
     if (rc) { freeAll(c->indexAllocs); freeAll(c->workAllocs); delete c; return rc; }
     memset(c->counters, 0, sizeof(c->counters));
     *out = c;
@@ -378,6 +381,7 @@ extern "C" int staramd_create_shared(staramd_ctx **out, staramd_ctx *owner, uint
     int rc = allocWork(c);
     if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
+    if (!rc && !getenv("STARAMD_SPIN_WAIT") && hipEventCreateWithFlags(&c->evWait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) c->evWait = nullptr;
     if (rc) { freeAll(c->workAllocs); delete c; return rc; }
     memset(c->counters, 0, sizeof(c->counters));
     owner->sharers.push_back(c);
@@ -513,6 +517,7 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
     if (!c->owner) freeAll(c->indexAllocs);
     freeAll(c->workAllocs);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->evWait) (void)hipEventDestroy(c->evWait);
     if (c->hostScratch) (void)hipHostFree(c->hostScratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -545,6 +550,12 @@ static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
         if ((rc = devRealloc(R, &c->dOutEx, (u64)B.exCap))) return rc;
     }
     return 0;
+}
+
+static hipError_t waitStream(staramd_ctx *c) {
+    if (!c->evWait) return hipStreamSynchronize(c->stream);
+    hipError_t e = hipEventRecord(c->evWait, c->stream);
+    return e != hipSuccess ? e : hipEventSynchronize(c->evWait);
 }
 
 static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
@@ -613,7 +624,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipMemcpyAsync(hs, c->dTotals, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(waitStream(c));
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));
@@ -636,8 +647,9 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
 // The kernels of the engine are persistent launches sized to fill the GPU: when two contexts of one device (the front end runs two, so that the copies of one
 // batch overlap with the kernels of the other) have their launches in flight at the same time they do not run side by side, they take each other's CUs -- every
 // kernel stretches, and the short ones (k_stitch_verify: 1 ms alone) wait 5-7 ms for a CU behind the other context's persistent blocks (rocprofv3 timeline,
-// profiles/r04_timeline_two_contexts.txt).  So the KERNEL phase of a batch is taken in turns per device; uploads before it and result copies after it still
-// overlap with the other context's kernels, which is what the second context is for.
+// profiles/r04_timeline_two_contexts.txt).  STARAMD_KERNEL_TURNS=1 takes the KERNEL phase of a batch in turns per device (uploads before it and result copies after it
+// still overlap with the other context's kernels).  Measured, alternating runs on one box: 6.65 M pairs/s with turns, 6.82 without, 6.78 with ONE context -- the front end
+// runs one context per GPU by default now, and the knob stays off.
 static std::mutex g_kernelTurn[64];
 static int runDevice(staramd_ctx *c, staramd_results *r) {
     DevBatch &B = c->B; hipStream_t s = c->stream;
@@ -665,7 +677,7 @@ static int runDevice(staramd_ctx *c, staramd_results *r) {
     HIPCHK(hipMemcpyAsync(r->reads, c->dOutReads, (u64)n * sizeof(staramd_read_result), hipMemcpyDeviceToHost, s));
     if (totals[0]) HIPCHK(hipMemcpyAsync(r->tr, c->dOutTr, (u64)totals[0] * sizeof(staramd_transcript), hipMemcpyDeviceToHost, s));
     if (totals[1]) HIPCHK(hipMemcpyAsync(r->ex, c->dOutEx, (u64)totals[1] * sizeof(staramd_exon), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(waitStream(c));
     return STARAMD_OK;
 }
 

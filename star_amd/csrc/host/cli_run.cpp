@@ -148,7 +148,10 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     // their own, no second replica); each context has a mapper thread, so a GPU always has a second batch in flight while the results of one are
     // copied out and handed on (the reference: runThreadN workers over one shared genome, STAR.cpp:194-201)
     const int nOwners = (int)devices.size();
-    int perGpu = 2; if (const char *e = getenv("STARAMD_CONTEXTS_PER_GPU")) perGpu = std::max(1, atoi(e));
+    // engine contexts (= mapper threads) per GPU.  A second context over the same resident index was worth +7 % in round 3, when kernels were slower and the host had 64 threads;
+    // with the kernels of round 4 and the 16 CPUs the GPU boxes really give a container, one context is as fast on a quiet box (6.8 M pairs/s either way) and faster on a
+    // loaded one (5.7 vs 5.1): the launches of two contexts do not overlap, they stretch each other (profiles/r04_timeline_two_contexts.txt)
+    int perGpu = 1; if (const char *e = getenv("STARAMD_CONTEXTS_PER_GPU")) perGpu = std::max(1, atoi(e));
     while (nOwners * perGpu > STARAMD_CLI_MAX_DEV) perGpu--;
     const int nDev = nOwners * perGpu;                       // contexts = mapper threads; context d belongs to owner d % nOwners
     rep.nDevices = nOwners; rep.nContexts = nDev; rep.genomeLoadSeconds = sah_genome_load_seconds(h);

@@ -36,6 +36,13 @@ def test_merged_mates_on_gpu(name, more, tmp_path, built):
     tcp.run_cli_case(GPU_CLI, name, more, 600, tmp_path)
 
 
+@pytest.mark.parametrize("turns", ["0", "1"])
+def test_two_contexts_share_one_resident_index(turns, tmp_path, built):
+    """STARAMD_CONTEXTS_PER_GPU=2: the second context maps against the index of the first (staramd_create_shared), 2-pass included (junction insertion on the owner,
+    the sharer follows); with STARAMD_KERNEL_TURNS=1 the kernel phases of the two contexts are taken in turns"""
+    tcp.run_cli_case(GPU_CLI, "pe101", ["--twopassMode", "Basic"], 300, tmp_path, env={"STARAMD_CONTEXTS_PER_GPU": "2", "STARAMD_KERNEL_TURNS": turns})
+
+
 def test_merged_chimeric_fragments_on_gpu(tmp_path, built):
     flags = ["--peOverlapNbasesMin", "10", "--peOverlapMMp", "0.1", "--chimSegmentMin", "12", "--chimJunctionOverhangMin", "10", "--chimMultimapNmax", "10", "--chimMultimapScoreRange", "3",
              "--chimNonchimScoreDropMin", "15", "--chimScoreDropMax", "80", "--chimSegmentReadGapMax", "5", "--outSAMunmapped", "Within"]
