@@ -165,6 +165,9 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     const uint64_t nGenomeReal = gi.chrStart[nChr];
     const uint64_t ov = V.sjdbOverhang, sjdbLength = V.sjdbLength;
     // the old index: genome text with spacer padding on both sides, junction table
+    const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  sjdb insert %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     // (3 GB for a human genome: not zero-filled first, copied on threads -- the two single-threaded passes over it were 1.5 s of every insertion)
     std::vector<uint8_t, NoInitAlloc<uint8_t>> Gp(GP + V.nGenome + GP);
     memset(Gp.data(), SPACER, GP); memset(Gp.data() + GP + V.nGenome, SPACER, GP);
@@ -179,9 +182,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     const std::vector<uint64_t> oldStart = gi.sjdbStart, oldEnd = gi.sjdbEnd;
     const uint64_t oldSjdbN = V.sjdbN, oldNSA = V.nSA, oldNGenome = V.nGenome;
 
-    const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
-    auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  sjdb insert %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
+    lap("genome copy");
     // ---------------- sjdbPrepare (sjdbPrepare.cpp:5-225)
     std::vector<uint64_t> sjdbS(nLoci), sjdbE(nLoci);
     std::vector<uint8_t> motif(nLoci), shL(nLoci), shR(nLoci);
@@ -513,6 +514,7 @@ static std::string sjdbPrepareAndBuild(const RunParams &P, GenomeIndex &gi, cons
     V.sjdbN = (uint32_t)sjdbN; V.sjGstart = nGenomeReal;
     V.nSA = nSAnew; V.nSAbyte = Packed::lengthByte(nSAnew, wSA);
     gi.refreshView();
+    lap("new index");
     log += "Genome size with junctions=" + std::to_string(nGenomeNew) + "  " + std::to_string(nGenomeReal) + "   " + std::to_string(nGsj) + "\n";
     return "";
 }
@@ -526,6 +528,9 @@ static bool copyFile(const std::string &a, const std::string &b) {
 
 std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, bool pass2, const std::string &pass1sjFile, std::string &log) {
     const std::string &outDir = P.sjdbInsertOutDir;
+    const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  sjdbInsertJunctions: %-18s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     if (gi.view.sjdbN > 0 && loci.chr.empty()) {                           // junctions of the generated genome, once
         std::ifstream in(gi.dir + "/sjdbList.out.tab");
         if (!in.good()) return "EXITING because of fatal INPUT error: could not open " + gi.dir + "/sjdbList.out.tab\nSOLUTION: re-generate the genome in " + gi.dir;
@@ -547,8 +552,10 @@ std::string sjdbInsertJunctions(RunParams &P, GenomeIndex &gi, SjdbLoci &loci, b
         std::string e = loadGTFjunctions(P, gi, loci, outDir, log);        // GTF gtf(...); gtf.transcriptGeneSJ(...) (:45-46)
         if (!e.empty()) return e;
     }
+    lap("junction tables read");
     std::string err = sjdbPrepareAndBuild(P, gi, loci, outDir, log);
     if (!err.empty()) return err;
+    lap("prepare + build");
     if (P.sjdbInsertSaveAll) {                                             // sjdbInsertJunctions.cpp:70-98
         if (gi.dir != outDir)
             for (const char *f : {"chrName.txt", "chrStart.txt", "chrNameLength.txt", "chrLength.txt"}) copyFile(gi.dir + "/" + f, outDir + "/" + f);
