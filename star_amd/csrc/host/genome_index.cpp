@@ -11,12 +11,15 @@
 
 namespace staramd {
 
-static bool readFile(const std::string &path, std::vector<uint8_t> &out, size_t extra = 0) {
+// headroom: capacity beyond the file (address space only, untouched) -- the genome text grows by the inserted junction sequences in a 2-pass run, and a
+// vector that has to move for that copies 3 GB on one thread
+static bool readFile(const std::string &path, std::vector<uint8_t> &out, size_t extra = 0, size_t headroom = 0) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
+    if (headroom) out.reserve((size_t)n + extra + headroom);
     out.assign((size_t)n + extra, 0);
     size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
     fclose(f);
@@ -71,7 +74,7 @@ std::string GenomeIndex::load(const std::string &genomeDir) {
         for (uint32_t i = 0; i <= nChrReal; i++) in >> chrStart[i];
     }
     // --- Genome / SA / SAindex (:139-169, 315-336)
-    if (!readFile(dir + "/Genome", G)) return "EXITING because of FATAL ERROR: could not open genome file " + dir + "/Genome";
+    if (!readFile(dir + "/Genome", G, 0, (size_t)320 << 20)) return "EXITING because of FATAL ERROR: could not open genome file " + dir + "/Genome";
     if (!readFile(dir + "/SA", SA, 8)) return "EXITING because of FATAL ERROR: could not open genome file " + dir + "/SA";
     uint64_t nSAbyte = SA.size() - 8;
     std::vector<uint8_t> sai;
