@@ -196,7 +196,11 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     }
 #endif
     loadLock.drop();
-    const int nSlots = std::min(24, 2 * nDev + 3);      // in flight: one batch in each half of the reader, one per mapper, one in the writer, the rest queued between them
+    // in flight: one batch in each half of the reader, one per mapper, one in the writer, the rest queued between them.  Three more than the stages hold: the reader's time per
+    // batch scatters (25 - 80 ms for 400 k pairs on a shared host) around a mean well under the device's 52 ms, and with a queue of one a single slow block left the GPU
+    // idle for 25 - 30 ms every few batches (rocprofv3 timeline, profiles/r04_timeline_*.txt)
+    int extraSlots = 3; if (const char *e = getenv("STARAMD_EXTRA_SLOTS")) extraSlots = std::max(0, atoi(e));
+    const int nSlots = std::min(24, 2 * nDev + 3 + extraSlots);
     std::vector<ResBuf> rb(nSlots), rbMerged(nSlots), rbWasp(nSlots);
     std::vector<ResBuf> piecePart(nDev);
     for (auto &r : rb) r.size(batchReads);
