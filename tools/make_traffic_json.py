@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03_pmc_hbm_traffic.json from the PMC passes of tools/measure_session.sh (FETCH_SIZE, WRITE_SIZE, SQ counters: separate runs):
+"""profiles/r04_pmc_hbm_traffic.json from the PMC passes of tools/measure_session.sh (FETCH_SIZE, WRITE_SIZE, SQ counters: separate runs):
    tools/make_traffic_json.py <session dir> <genome_mb> <reads per launch> <out.json>
 Per kernel: (sum of the counter over every dispatch of the kernel) / (number of batches) * 1024 -- rocprofv3 reports both in KB; a batch
 is one launch of the hot path (k_seed_search runs once per batch, k_windows three times, the stitch stage = k_stitch_lane + k_stitch_win).
