@@ -237,6 +237,8 @@ def report_dict(rep, lread):
     bytes_win = 8 * c["nSAenum"] + 24 * c["nSeeds"] + 24 * c["nWA"]
     walked = max(0, c["nWindows"] - c["nPrunedWin"]) if c["nWindows"] else n           # the packed read is staged once per WALKED window (pruned windows are never touched)
     bytes_stitch = c["nGstitch"] + 24 * c["nWA"] + (lread // 2) * walked + 96 * c["nTrOut"] + 32 * 2 * c["nTrOut"]
+    # (rounds 1-3 counted the packed read once per window, walked or not: kept beside the figure so that the series stays comparable)
+    c["_bytes_stitch_round3_definition"] = (bytes_stitch + (lread // 2) * ((c["nWindows"] if c["nWindows"] else n) - walked)) / nb
     kern = {"k_seed_search": (ms["k_seed_search"], bytes_seed / nb), "k_windows": (ms["k_windows"], bytes_win / nb), "k_stitch_win": (ms["k_stitch_win"], bytes_stitch / nb)}
     if os.environ.get("STARAMD_PROFILE_BUILD"):          # libstaramd.so built with -DSTARAMD_PROFILE: shader-clock cycles per section, summed over waves
         pn = ["walk(all)", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime", "windows:passA", "windows:flanks", "windows:passB_enumerate+owner",
@@ -524,7 +526,7 @@ def main():
     n = max(int(rep.timedReads), 1)
     n_ctx = max(1, int(rep.nContexts))
     value = timed_reads_all / elapsed / 1e6
-    extra = {"per_kernel_ms_timed_region": ms, "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items()},
+    extra = {"per_kernel_ms_timed_region": ms, "counters_per_pair": {k: (v / n if not isinstance(v, dict) else v) for k, v in c.items() if not k.startswith("_")},
              "algorithmic_bytes_per_pair_whole_path": bytes_per_pair, "index_build": ginfo, "sj_merge_ms": sj_ms.get("ms"),
              "cpu_throttled_in_timed_region": ({"periods": thr1[0] - t_clock["thr0"][0], "ms": (thr1[1] - t_clock["thr0"][1]) / 1e3} if thr1 and t_clock.get("thr0") else None),
              "pipeline": {"timed_wall_s": float(rep.timedWall), "device_s_sum_over_contexts": sum(float(rep.deviceMs[k]) for k in range(n_ctx)) / 1e3,
@@ -570,7 +572,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "issue": issue, "kernel_ms": round(dms, 3), "algorithmic_bytes_per_launch": int(dbytes),
                      "per_kernel_ms": {k: round(kms[k], 2) for k in ("k_seed_search", "k_windows", "k_stitch_win", "device_total")},
-                     "kernel_ms_source": kms_src, "algorithmic_bytes_per_pair_whole_path": round(bytes_per_pair, 1)},
+                     "kernel_ms_source": kms_src, "algorithmic_bytes_per_pair_whole_path": round(bytes_per_pair, 1),
+                     "whole_path_frac": round(bytes_per_pair * n / max(int(rep.batches), 1) / (kms["device_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kms["device_total"] > 0 else None,
+                     "frac_with_round3_byte_count": (round(c["_bytes_stitch_round3_definition"] / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom == "k_stitch_win" and dms > 0 else None)},
     }
     if selftest:
         line["selftest"] = "plumbing test on CPU (oracle behind the front end, gloo): NOT a measurement"
@@ -647,7 +651,7 @@ def _cli_leg(argv, lread, env=None):
                  "convert_Mreads_s": n / float(rep.convertBusy) / 1e6 if rep.convertBusy > 0 else None,
                  "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                  "device_Mreads_s": n / max(1e-9, sum(float(rep.deviceMs[k]) for k in range(max(1, int(rep.nContexts)))) / 1e3) / 1e6,
-                 "engine_contexts": int(rep.nContexts), "counters_per_pair": {k: v / n for k, v in c.items() if not isinstance(v, dict)}}
+                 "engine_contexts": int(rep.nContexts), "counters_per_pair": {k: v / n for k, v in c.items() if not isinstance(v, dict) and not k.startswith("_")}}
 
 
 def exclusive_leg(args, idx, fq, run_dir, threads):
