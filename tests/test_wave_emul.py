@@ -88,6 +88,8 @@ FORCED = {
     "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
     "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
     "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
+    "no_sjdb_hash": {"STARAMD_NO_SJDB_HASH": "1"},            # annotated junctions looked up by bisection (what an index does whose coordinates / junction count do not fit the hash)
+    "no_leaf_skipping": {"STARAMD_PRUNE": "3"},               # window pruning as in round 3, every leaf of every walked window finalised
     "win_owner_map_off": {"STARAMD_WIN_OWNER_MAP": "0"},      # k_windows: the covered bins in a Bloom filter + serial owner look-ups (what a read does whose windows cover more bins than the owner map holds)
     "win_owner_map_tiny": {"STARAMD_WIN_HASH_BITS": "1024", "STARAMD_WIN_HASH_BITS_MID": "4096"},     # 32-slot owner map: reads switch between the map and the filter
 }

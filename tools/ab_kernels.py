@@ -125,8 +125,8 @@ def main():
                         # staramd_read_result::maxScoreMate[] (bytes 20-27 of the 32-byte record) is a lower bound under resultSelect = 1 (include/star_amd.h: it covers the
                         # walked windows / finalised leaves only, and for reads whose windows are separate work items what is walked depends on timing): compared apart
                         import numpy as np
-                        a = np.frombuffer(rd, dtype=np.uint32).reshape(-1, 8).copy(); a[:, 5:7] = 0
-                        dig.update(a.tobytes()); dig.update(tr); dig.update(ex)
+                        arr = np.frombuffer(rd, dtype=np.uint32).reshape(-1, 8).copy(); arr[:, 5:7] = 0
+                        dig.update(arr.tobytes()); dig.update(tr); dig.update(ex)
                     if rep == 0 and ib == 0:
                         continue                                    # warm-up
                     ms = (C.c_float * 9)(); L.staramd_get_timings(ctx, ms, 9)
