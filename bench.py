@@ -535,7 +535,8 @@ def main():
                           "convert_Mreads_s": n / float(rep.convertBusy) / 1e6 if rep.convertBusy > 0 else None,
                           "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                           "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
-                          "finish_s": float(rep.finishSeconds), "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds)}}
+                          "finish_s": float(rep.finishSeconds), "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds),
+                          "postmap_whole_run_s": dict(zip(["wait_for_writer", "format_on_threads", "serial_tail", "writer_thread_busy"], [float(x) for x in rep.emitParts]))}}
     if dist is not None:
         dist.destroy_process_group()
     # ---- kernel times for the roofline: ONE engine context (a launch has the GPU to itself); the timed region overlaps the launches of two contexts, so

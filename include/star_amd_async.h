@@ -1,0 +1,23 @@
+/* star_amd_async.h -- optional companion of staramd_map_batch (include/star_amd.h): the upload of the NEXT batch while the current one is on the device.
+ *
+ * staramd_map_batch is a blocking call, as the loop it replaces (ReadAlignChunk_mapChunk.cpp:30-32: one chunk after the other): upload, kernels, download.
+ * The chunk that follows is usually parsed already (ReadAlignChunk_processChunks.cpp fills chunk k+1 while chunk k is mapped); handing it to the context
+ * BEFORE the call for chunk k lets its upload (81 MB for 400 k pairs of 2x101) run beside the kernels of chunk k, on a second stream into a second set
+ * of input buffers.  Nothing else changes: staramd_map_batch recognises the batch it was shown (same `bases` and `readOffset` pointers, same nReads) and skips
+ * its own upload; a batch it was not shown is uploaded as always, and a prefetched batch that never arrives is simply overwritten by the next prefetch.
+ *
+ * The arrays of the prefetched batch must stay unchanged until the staramd_map_batch call for it returns; page-locked arrays (staramd_pinned_alloc) make the
+ * copy asynchronous.  One prefetched batch per context; calls on one context are serialised by the caller, like all others.  Returns 0, or a negative
+ * STARAMD_ERR_* (the batch is then uploaded by staramd_map_batch in the ordinary way: a failed prefetch is never fatal).
+ */
+#ifndef STAR_AMD_ASYNC_H
+#define STAR_AMD_ASYNC_H
+#include "star_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int staramd_prefetch_batch(staramd_ctx *ctx, const staramd_batch *next);
+#ifdef __cplusplus
+}
+#endif
+#endif

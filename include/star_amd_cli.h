@@ -43,6 +43,8 @@ typedef struct staramd_cli_report {
     double   finishSeconds;        /* after the last batch is handed to the writer: last writes, SJ.out.tab, Log.final.out (inside timedWall) */
     int      nContexts;            /* engine contexts (= mapper threads): nDevices x STARAMD_CONTEXTS_PER_GPU; deviceBusy / deviceMs are per context */
     double   convertBusy;          /* seconds the second half of the reader (text -> numeric batch, its own thread) was busy, timed region; parseBusy is the first half (input + line table) */
+    double   emitParts[4];         /* what emitBusy is made of, whole run (seconds): [0] waiting for a free text-buffer set (= for the writer), [1] formatting on the threads, [2] serial tail
+                                      of a batch (junction merge, hand-over); [3] the writer thread's own busy time (write calls into the output file) */
 } staramd_cli_report;
 
 /* Runs the whole job; returns the process exit code (0 ok).  hooks / report may be NULL. */

@@ -48,6 +48,8 @@ uint64_t sah_batch_reads(void *h);                                      /* --gpu
 int   sah_device(void *h);                                              /* --gpuDevice */
 int   sah_threads(void *h);                                             /* --runThreadN */
 double sah_genome_load_seconds(void *h);
+/* seconds of the post-map stage so far: out[0] waiting for a free text-buffer set, [1] formatting on threads, [2] serial tail of the batches, [3] the writer thread busy */
+void  sah_emit_seconds(void *h, double out[4]);
 
 /* one batch at a time */
 int   sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out);   /* number of reads, 0 at the end of the input of this phase */

@@ -4,6 +4,7 @@
 // `make oracle` links it with main.cpp into oracle/_build/star_amd_oracle_cli; tests/test_cli_pipeline.py is the only user.
 #include "../include/star_amd.h"
 #include "../include/star_amd_index.h"
+#include "../include/star_amd_async.h"
 #include <string>
 #include <cstdlib>
 #include <mutex>
@@ -40,6 +41,7 @@ const char *staramd_last_error(void) { return lastError.c_str(); }
 int staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const staramd_params *p) { return staramd_update_index(ctx, g, p); }
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
 int staramd_insert_junctions_fits(staramd_ctx *, uint64_t, uint32_t) { return 0; }
+int staramd_prefetch_batch(staramd_ctx *, const staramd_batch *) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 // index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp
 int staramd_index_build(int, const uint8_t *G, const staramd_index_params *p, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, staramd_index_result *res) {

@@ -8,6 +8,7 @@
 // bench-only tool, never a product path").  `make oracle` links it with cli_run.cpp into oracle/_build/libstaramd_cli_replay.so.
 #include "../include/star_amd.h"
 #include "../include/star_amd_index.h"
+#include "../include/star_amd_async.h"
 #include <string>
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +131,7 @@ void staramd_pinned_free(void *p) { free(p); }
 const char *staramd_last_error(void) { return lastError.c_str(); }
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
 int staramd_insert_junctions_fits(staramd_ctx *, uint64_t, uint32_t) { return 0; }
+int staramd_prefetch_batch(staramd_ctx *, const staramd_batch *) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 int staramd_index_build(int, const uint8_t *, const staramd_index_params *, uint8_t *, uint64_t, uint8_t *, uint64_t, staramd_index_result *) { lastError = "replay shim: no index build"; return STARAMD_ERR_DEVICE; }
 int staramd_sjdb_insert(int, const staramd_sjdb_args *, staramd_sjdb_result *) { lastError = "replay shim: no junction insertion"; return STARAMD_ERR_DEVICE; }

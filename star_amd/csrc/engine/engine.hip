@@ -5,6 +5,7 @@
 #include "../index/hip_backend.h"
 #include "../index/sjdb_core.h"
 #include "../../../include/star_amd_index.h"
+#include "../../../include/star_amd_async.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,6 +58,11 @@ struct staramd_ctx {
     u32 maxReads = 0; u64 maxBases = 0;
     DevBatch B;
     u8 *dBases = nullptr; u64 *dReadOffset = nullptr; u16 *dMate1 = nullptr, *dMM = nullptr;
+    // two sets of input buffers + a copy stream: the batch that follows is uploaded while this one is on the device (staramd_prefetch_batch, include/star_amd_async.h).
+    // in[k].pending: the set holds an uploaded batch that staramd_map_batch has not consumed yet; cur: the set the last mapped batch used (dBases ... above point into it)
+    struct InSet { u8 *bases = nullptr; u64 *readOffset = nullptr; u16 *mate1 = nullptr, *mm = nullptr; hipEvent_t up = nullptr;
+                   const uint8_t *hBases = nullptr; const uint64_t *hReadOffset = nullptr; u32 nReads = 0; bool pending = false; } in[2];
+    int cur = 0; hipStream_t copyStream = nullptr;
     u32 *dPacked = nullptr; u32 packWordsCap = 0;
     int nCU = 256;
     // seed kernel: one lane per read
@@ -230,6 +236,15 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->dReadOffset, (u64)N + 1))) return rc;
     if ((rc = devAlloc(R, &c->dMate1, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dMM, (u64)N))) return rc;
+    c->in[0].bases = c->dBases; c->in[0].readOffset = c->dReadOffset; c->in[0].mate1 = c->dMate1; c->in[0].mm = c->dMM; c->cur = 0;
+    if (envU32("STARAMD_PREFETCH", 1)) {
+        u8 *raw = nullptr; if ((rc = devAlloc(R, &raw, c->maxBases + 192))) return rc; if (hipMemset(raw, 4, c->maxBases + 192) != hipSuccess) { g_err = "hipMemset failed"; return STARAMD_ERR_DEVICE; } c->in[1].bases = raw + 64;
+        if ((rc = devAlloc(R, &c->in[1].readOffset, (u64)N + 1))) return rc;
+        if ((rc = devAlloc(R, &c->in[1].mate1, (u64)N))) return rc;
+        if ((rc = devAlloc(R, &c->in[1].mm, (u64)N))) return rc;
+        if (hipStreamCreate(&c->copyStream) != hipSuccess) { g_err = "hipStreamCreate failed"; return STARAMD_ERR_DEVICE; }
+        for (int k = 0; k < 2; k++) if (hipEventCreateWithFlags(&c->in[k].up, hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return STARAMD_ERR_DEVICE; }
+    }
     c->packWordsCap = 0;
     DevBatch &B = c->B; memset(&B, 0, sizeof(B));
     B.bases = c->dBases; B.readOffset = c->dReadOffset; B.mate1Length = c->dMate1; B.mmMaxTotal = c->dMM;
@@ -518,6 +533,8 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
     freeAll(c->workAllocs);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->evWait) (void)hipEventDestroy(c->evWait);
+    for (int k = 0; k < 2; k++) if (c->in[k].up) (void)hipEventDestroy(c->in[k].up);
+    if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->hostScratch) (void)hipHostFree(c->hostScratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -699,14 +716,48 @@ extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd
         int rc = devRealloc(c->workAllocs, &c->dPacked, (u64)packWords * c->maxReads); if (rc) return rc;
         c->packWordsCap = (u32)std::min<u64>((u64)packWords * c->maxReads, 0xFFFFFFFFull);
     }
-    HIPCHK(hipMemcpyAsync(c->dBases, b->bases + base0, nBases, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->dReadOffset, offs, (u64)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->dMate1, b->mate1Length, (u64)n * 2, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->dMM, b->mmMaxTotal, (u64)n * 2, hipMemcpyHostToDevice, s));
+    {
+        int use = -1;
+        for (int k = 0; k < 2; k++) if (c->in[k].pending && c->in[k].hBases == b->bases && c->in[k].hReadOffset == b->readOffset && c->in[k].nReads == n && base0 == 0) use = k;
+        if (use >= 0) {             // this batch was shown to staramd_prefetch_batch: its upload is in flight (or done) on the copy stream
+            HIPCHK(hipStreamWaitEvent(s, c->in[use].up, 0));
+        } else {                    // not prefetched: into the set that holds nothing pending (both pending: the older one is given up)
+            use = !c->in[c->cur].pending ? c->cur : (c->copyStream && !c->in[1 - c->cur].pending ? 1 - c->cur : c->cur);
+            staramd_ctx::InSet &I = c->in[use];
+            if (I.pending) HIPCHK(hipStreamSynchronize(c->copyStream));          // (an upload nobody asked for any more may still be writing into the set)
+            HIPCHK(hipMemcpyAsync(I.bases, b->bases + base0, nBases, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(I.readOffset, offs, (u64)(n + 1) * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(I.mate1, b->mate1Length, (u64)n * 2, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(I.mm, b->mmMaxTotal, (u64)n * 2, hipMemcpyHostToDevice, s));
+        }
+        c->in[use].pending = false; c->cur = use;
+        c->dBases = c->in[use].bases; c->dReadOffset = c->in[use].readOffset; c->dMate1 = c->in[use].mate1; c->dMM = c->in[use].mm;
+        c->B.bases = c->dBases; c->B.readOffset = c->dReadOffset; c->B.mate1Length = c->dMate1; c->B.mmMaxTotal = c->dMM;
+    }
     c->B.nReads = n; c->residentReads = n; c->residentMaxLread = maxL;
     c->B.packed = c->dPacked; c->B.packWords = packWords;
     hipLaunchKernelGGL(k_pack_reads, dim3(n), dim3(64), 0, s, c->B, c->dPacked, packWords);
     return runDevice(c, r);
+}
+
+extern "C" int staramd_prefetch_batch(staramd_ctx *c, const staramd_batch *b) {
+    if (!c || !b) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    if (!c->copyStream || b->nReads == 0 || b->readOffset[0] != 0) return STARAMD_OK;      // prefetch off, or a batch that map_batch rebases: uploaded there
+    const u64 nBases = b->readOffset[b->nReads];
+    if (b->nReads > c->maxReads || nBases > c->maxBases) return STARAMD_OK;                // (map_batch reports it)
+    // the set that holds nothing pending: the one the last mapped batch used (that call has returned), unless the other one is free too
+    const int k = !c->in[1 - c->cur].pending ? 1 - c->cur : (!c->in[c->cur].pending ? c->cur : -1);
+    if (k < 0) return STARAMD_OK;                                                          // two batches waiting already
+    HIPCHK(hipSetDevice(c->device));
+    staramd_ctx::InSet &I = c->in[k];
+    const u32 n = b->nReads; hipStream_t cs = c->copyStream;
+    HIPCHK(hipMemcpyAsync(I.bases, b->bases, nBases, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(I.readOffset, b->readOffset, (u64)(n + 1) * 8, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(I.mate1, b->mate1Length, (u64)n * 2, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(I.mm, b->mmMaxTotal, (u64)n * 2, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipEventRecord(I.up, cs));
+    I.hBases = b->bases; I.hReadOffset = b->readOffset; I.nReads = n; I.pending = true;
+    return STARAMD_OK;
 }
 
 extern "C" int staramd_map_resident(staramd_ctx *c, staramd_results *r) {

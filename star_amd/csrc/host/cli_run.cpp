@@ -31,6 +31,7 @@
 #include "../../../include/star_amd_host.h"
 #include "../../../include/star_amd_index.h"
 #include "../../../include/star_amd_cli.h"
+#include "../../../include/star_amd_async.h"
 
 namespace {
 typedef std::chrono::steady_clock Clock;
@@ -42,6 +43,7 @@ struct Queue {                                   // hand-off between two pipelin
     void push(const Msg &x) { { std::lock_guard<std::mutex> l(m); q.push_back(x); } cv.notify_all(); }
     void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
     bool pop(Msg &x) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; x = q.front(); q.pop_front(); return true; }
+    bool peek(Msg &x) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; x = q.front(); return true; }          // what the next pop would hand out, if anything is waiting
 };
 struct Tokens {                                  // counting semaphore over a small set of buffer indices
     std::mutex m; std::condition_variable cv; std::deque<int> free;
@@ -298,6 +300,8 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                         }
                         return e;
                     };
+                    // the batch that is next in line (if the reader is ahead, as it normally is) starts its upload now, beside the kernels of this one
+                    { Msg nx; if (nDev == 1 && parsed.peek(nx) && nx.n > 0) (void)staramd_prefetch_batch(ctx[d], &nx.b); }
                     rc = mapInto(m.b, rb[m.slot], true);
                     m.merged = false;
                     if (!rc) {                                           // --peOverlapNbasesMin: the overlapping mates of the batch, merged into single reads, are a second batch
@@ -383,6 +387,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     if (failed.load()) { fprintf(stderr, "\n%s\n", failure.c_str()); exitCode = 104; }
     else if (hooks && hooks->exchange && hooks->exchange(hooks->user, h, 1)) { fprintf(stderr, "\ncross-rank exchange failed\n"); exitCode = 104; }
     else { const auto tf = Clock::now(); if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); exitCode = 104; } rep.finishSeconds = since(tf); }
+    sah_emit_seconds(h, rep.emitParts);
     double sec = since(t0);
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",

@@ -631,6 +631,7 @@ int sah_generate_finish(void *h, uint64_t nSA, uint64_t nSAbyte, uint64_t nSAiby
 int sah_tool_done(void *h) { return ((Runner *)h)->toolDone ? 1 : 0; }     // 1: the run was a tool mode (--runMode inputAlignmentsFromBAM) and is finished
 int sah_device(void *h) { return ((Runner *)h)->P.gpuDevice; }
 double sah_genome_load_seconds(void *h) { return ((Runner *)h)->gi.loadSeconds; }
+void sah_emit_seconds(void *h, double out[4]) { Runner *r = (Runner *)h; out[0] = r->tEmitWaitSet; out[1] = r->tEmitFormat; out[2] = r->tEmitTail; out[3] = r->tWriter; }
 int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {
     Runner *r = (Runner *)h;
     int n = r->nextBatch(maxReads);
