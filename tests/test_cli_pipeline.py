@@ -147,3 +147,10 @@ def test_sam_into_a_named_pipe(tmp_path, built):
     assert p.returncode == 0, p.stderr[-1500:]
     body = sorted(l for l in got[0].splitlines(keepends=True) if not l.startswith(b"@"))
     assert body == refstar.sam_body_sorted(ref + "Aligned.out.sam")
+
+
+@pytest.mark.parametrize("mode,more", [("2", []), ("2", ["--outSAMtype", "BAM", "Unsorted"]), ("0", []), ("2", ["--twopassMode", "Basic"])])
+def test_writer_through_a_mapping_of_the_output_file(mode, more, tmp_path, built):
+    """the SAM / unsorted-BAM writer grows the file and copies the batch's text into a mapping of the new part (STARAMD_WRITER_MMAP=2: whatever the size of a batch;
+    the default does so from 1 MB per batch); =0: positional writes.  Same bytes either way, and the file ends where the last record ends"""
+    run_cli_case(CLI, "pe101", more, 150, tmp_path, env={"STARAMD_WRITER_MMAP": mode, "STARAMD_WRITER_THREADS": "3"})
