@@ -17,10 +17,6 @@
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
 extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);
-#include "win_pool.h"
-#if WIN_POOL_ROWS
-extern "C" __global__ void k_windows_pool(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);    // candidate build only (win_pool.h)
-#endif
 extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid);
 extern "C" __global__ void k_order_hist(DevBatch B);
 extern "C" __global__ void k_order_offsets(DevBatch B);
@@ -75,7 +71,6 @@ struct staramd_ctx {
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
     u32 winBlocksMid = 0, capWMid = 0, capBlocksMid = 0, hashBitsMid = 65536; u8 *scrWinMid = nullptr;
-    u32 winPool = 0;                              // first launch = k_windows_pool (candidate build, win_pool.h)
     u32 hashBits = 4096, winOwnerMap = 1;         // first launch: bits of the covered-bins filter = 32 x slots of the owner map (k_window.hip)
     // stitch kernel: one lane per read; fast pass (compact arena) + big pass (worst-case arena)
     u32 lightEst = 65536;                 // reads whose walk-size estimate is at most this are ONE stitch work item
@@ -303,12 +298,6 @@ static int allocWork(staramd_ctx *c) {
     int winPerCU = 3;
     c->winOwnerMap = envU32("STARAMD_WIN_OWNER_MAP", 1);
     { u32 hb = envU32("STARAMD_WIN_HASH_BITS", c->winOwnerMap ? 16384 : 4096); c->hashBits = 1024; while (c->hashBits < hb && c->hashBits < (1u << 18)) c->hashBits <<= 1; }      // a power of two
-#if WIN_POOL_ROWS
-    c->winPool = envU32("STARAMD_WIN_POOL", 1);
-    if (c->winPool && c->capBlocks > LST_MAX_AT) c->capBlocks = LST_MAX_AT;       // (the list word has 12 bits for the block)
-    if (c->winPool && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows_pool, 256, 4 * winLdsWords(c->capW, c->hashBits, true) * sizeof(u32)) != hipSuccess || winPerCU < 1)) winPerCU = 3;
-    if (!c->winPool)
-#endif
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&winPerCU, k_windows, 256, 4 * (c->capW * 8 + c->hashBits / 32) * sizeof(u32)) != hipSuccess || winPerCU < 1) winPerCU = 3;
     c->winBlocks = (u32)c->nCU * envU32("STARAMD_WIN_BLOCKS_PER_CU", (u32)winPerCU);
     c->winBlocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (N + 3) / 4));
@@ -604,10 +593,6 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     {
         u32 blocks = std::max<u32>(1, std::min<u32>(c->winBlocks, (n + 3) / 4));
         const u32 useMid = (c->capWMid ? 1u : 0u) | (c->winOwnerMap ? 2u : 0u);
-#if WIN_POOL_ROWS
-        if (c->winPool) hipLaunchKernelGGL(k_windows_pool, dim3(blocks), block, 4 * winLdsWords(c->capW, c->hashBits, true) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, c->hashBits);
-        else
-#endif
         hipLaunchKernelGGL(k_windows, dim3(blocks), block, 4 * (c->capW * 8 + c->hashBits / 32) * sizeof(u32), s, c->dX, B, c->scrWin, c->capW, c->capBlocks, 0u, c->lightEst, useMid, c->hashBits);
         HIPCHK(hipEventRecord(c->ev[7], s));
         if (c->capWMid) hipLaunchKernelGGL(k_windows, dim3(c->winBlocksMid), dim3(64), (c->capWMid * 8 + c->hashBitsMid / 32) * sizeof(u32), s, c->dX, B, c->scrWinMid, c->capWMid, c->capBlocksMid, 2u, c->lightEst, useMid, c->hashBitsMid);

@@ -25,7 +25,6 @@
 // Reads that need more windows / seed-list blocks than the compact per-wave work space are deferred to a second
 // launch of the same kernel (big = 1) whose table lives in global memory with the reference's own limits.
 #include "dev.h"
-#include "win_pool.h"
 
 #define NOWIN 0xFFFFFFFFu
 #ifdef STARAMD_PROFILE
@@ -43,13 +42,12 @@ template <bool BIG> struct WPtr;
 template <> struct WPtr<true> { typedef u32 *P; };
 template <> struct WPtr<false> { typedef __attribute__((address_space(3))) u32 *P; };
 template <bool BIG> struct WTab {   // per-wave window table
-    typename WPtr<BIG>::P coreS, coreE, extS, extE, meta, blk, lrec, nwa;      // (with the seed lists in LDS, WIN_POOL_ROWS below: blk = the list word, lrec / nwa unused)
+    typename WPtr<BIG>::P coreS, coreE, extS, extE, meta, blk, lrec, nwa;
 };
 // meta = chr << 2 | str << 1 | alive
 #define WBITS 4096u                 // per-read hash bitmap of the bins covered by windows (quick reject of loci outside every window): bits in the first and last launch
-template <bool BIG, bool LL = false> struct WS {          // LL: the seed lists of the read live in the LDS pool (win_pool.h)
+template <bool BIG> struct WS {
     WTab<BIG> t; DWA *arena; typename WPtr<BIG>::P bitmap;
-    typename WPtr<BIG>::P pool; u32 used;     // LL: the pool (6 words per row) and the rows in use
     u32 nW, capW, nBlocks, capBlocks, Lread;
     u32 hashMask;                   // bits of the bitmap - 1 (a power of two; the middle launch has 16x the bits: its reads cover thousands of bins,
                                     // a 4096-bit map is saturated and every locus of a 10000-fold seed would go through the serial owner lookup)
@@ -89,7 +87,7 @@ __device__ __forceinline__ DSeed seedOfLane(const DSeed &mine, u32 src) {
 // aChr = chrBin[aBin >> winBinChrNbits], looked up by the lane that enumerated the locus.  Every core bin of a window lies on the chromosome the window was
 // created on (a window only grows by bins of its own chromosome, :28,:47,:66), so "is the neighbour on my chromosome" is a comparison with the neighbour's
 // table row: the serial replay of the anchor loci makes no global-memory access at all.
-template <bool BIG, bool LL> __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS<BIG, LL> &s, u64 a1, u32 aStr, u32 aChr, u32 lane) {
+template <bool BIG> __device__ static int createExtendWindowsWithAlign(const DevIndex &X, WS<BIG> &s, u64 a1, u32 aStr, u32 aChr, u32 lane) {
     const staramd_params &P = X.P;
     u32 aBin = (u32)(a1 >> P.winBinNbits);
     u32 lo = aBin > P.winAnchorDistNbins ? aBin - P.winAnchorDistNbins : 0;
@@ -116,8 +114,7 @@ template <bool BIG, bool LL> __device__ static int createExtendWindowsWithAlign(
         if (lane == 0) {
             s.t.meta[iWin] = (aChr << 2) | (aStr << 1) | 1u;
             s.t.coreS[iWin] = aBin; s.t.coreE[iWin] = aBin; s.t.extS[iWin] = aBin; s.t.extE[iWin] = aBin;
-            if constexpr (LL) s.t.blk[iWin] = 0;
-            else { s.t.blk[iWin] = NOWIN; s.t.lrec[iWin] = 0; s.t.nwa[iWin] = 0; }
+            s.t.blk[iWin] = NOWIN; s.t.lrec[iWin] = 0; s.t.nwa[iWin] = 0;
         }
         s.nW++;
         rowFence<BIG>();
@@ -136,13 +133,12 @@ template <bool BIG, bool LL> __device__ static int createExtendWindowsWithAlign(
 }
 
 // ReadAlign_assignAlignToWindow.cpp:6-130 ; all arguments wave-uniform; lane j holds row j of the window's list
-template <bool BIG, bool LL> __device__ static void assignAlignToWindow(const DevIndex &X, WS<BIG, LL> &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
+template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X, WS<BIG> &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
     const staramd_params &P = X.P;
-    u32 n, lrec, b;
-    if constexpr (LL) { const u32 w = s.t.blk[iW]; n = LST_NWA(w); lrec = LST_LREC(w); b = LST_AT(w); }     // (a list in the arena: where = 2, assignPooled has seen to that)
-    else { n = s.t.nwa[iW]; lrec = s.t.lrec[iW]; b = s.t.blk[iW]; }
+    u32 n = s.t.nwa[iW]; u32 lrec = s.t.lrec[iW];
     if (!aAnchor && aLength < lrec) return;
-    if (!LL && b == NOWIN) {
+    u32 b = s.t.blk[iW];
+    if (b == NOWIN) {
         if (s.nBlocks >= s.capBlocks) { s.overflow = true; return; }
         b = s.nBlocks++;
         LOCKSTEP();                               // every lane has read blk[iW] (and counted the block) before lane 0 fills it in
@@ -174,7 +170,7 @@ template <bool BIG, bool LL> __device__ static void assignAlignToWindow(const De
     }
     if (n == P.seedPerWindowNmax) {
         lrec = waveMin32((have && e.anchor != 1) ? (u32)e.L : s.Lread + 1);
-        if (lane == 0) { if constexpr (LL) s.t.blk[iW] = LST_WORD(2u, b, lrec, n); else s.t.lrec[iW] = lrec; }
+        if (lane == 0) s.t.lrec[iW] = lrec;
         if (lrec == s.Lread + 1) { s.tooMany = true; tabFence(); return; }
         if (!aAnchor && aLength < lrec) { tabFence(); return; }
         bool keep = have && (e.anchor == 1 || e.L > lrec);
@@ -182,7 +178,7 @@ template <bool BIG, bool LL> __device__ static void assignAlignToWindow(const De
         u32 pos = (u32)__popcll(km & ((1ull << lane) - 1ull));
         if (keep) A[pos] = e;
         n = (u32)__popcll(km);
-        if (lane == 0) { if constexpr (LL) s.t.blk[iW] = LST_WORD(2u, b, lrec, n); else s.t.nwa[iW] = n; }
+        if (lane == 0) s.t.nwa[iW] = n;
         tabFence();
         have = lane < n;
         if (have) e = A[lane];
@@ -191,108 +187,8 @@ template <bool BIG, bool LL> __device__ static void assignAlignToWindow(const De
         u64 m3 = __ballot(have && aRstart < e.rStart);
         u32 iA = m3 ? (u32)__ffsll((long long)m3) - 1 : n;
         if (have && lane >= iA) A[lane + 1] = e;
-        if (lane == 0) { A[iA] = nw; if constexpr (LL) s.t.blk[iW] = LST_WORD(2u, b, lrec, n + 1u); else s.t.nwa[iW] = n + 1; }
+        if (lane == 0) { A[iA] = nw; s.t.nwa[iW] = n + 1; }
         tabFence();
-    }
-}
-
-
-// ---- seed lists in the LDS pool (win_pool.h; compiled in with -DWIN_POOL_ROWS=64 only) ------------------------------------------------------------------
-template <class LP> __device__ __forceinline__ DWA poolGet(LP pool, u32 r) {
-    DWA e; u32 *d = (u32 *)&e;
-#pragma unroll
-    for (u32 i = 0; i < 6; i++) d[i] = pool[r * 6u + i];
-    return e;
-}
-template <class LP> __device__ __forceinline__ void poolPut(LP pool, u32 r, const DWA &e) {
-    const u32 *d = (const u32 *)&e;
-#pragma unroll
-    for (u32 i = 0; i < 6; i++) pool[r * 6u + i] = d[i];
-}
-// the list of window iW (rows [at, at + n) of the pool) moves to a block of the arena; the rows behind it close the gap.  false: no block left
-template <bool BIG> __device__ static bool poolMigrate(WS<BIG, true> &s, u32 iW, u32 lane) {
-    const u32 w = s.t.blk[iW]; const u32 n = LST_NWA(w), at = LST_AT(w), lrec = LST_LREC(w);
-    if (s.nBlocks >= s.capBlocks) { s.overflow = true; return false; }
-    const u32 b = s.nBlocks++;
-    DWA *A = s.arena + (u64)b * WA_MAX;
-    if (lane < n) A[lane] = poolGet(s.pool, at + lane);
-    const bool moves = lane >= at + n && lane < s.used;
-    DWA mv; if (moves) mv = poolGet(s.pool, lane);
-    LOCKSTEP();                                   // every lane has read its row before a neighbour overwrites it
-    if (moves) poolPut(s.pool, lane - n, mv);
-    s.used -= n;
-    for (u32 j = lane; j < s.nW; j += 64) {
-        const u32 x = s.t.blk[j];
-        if (j == iW) s.t.blk[j] = LST_WORD(2u, b, lrec, n);
-        else if (LST_WHERE(x) == 1u && LST_AT(x) > at) s.t.blk[j] = x - (n << 20);
-    }
-    tabFence(); rowFence<BIG>();
-    return true;
-}
-// ReadAlign_assignAlignToWindow.cpp:6-130 with the list in the pool; all arguments wave-uniform, lane j holds row j of the window's list
-template <bool BIG> __device__ static void assignPooled(const DevIndex &X, WS<BIG, true> &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
-    const staramd_params &P = X.P;
-    u32 w = s.t.blk[iW];
-    if (LST_WHERE(w) == 2u) { assignAlignToWindow<BIG, true>(X, s, iW, a1, aLength, aNrep, aFrag, aRstart, aAnchor, sjA, lane); return; }
-    const u32 n = LST_NWA(w), lrec = LST_LREC(w);           // (lrec only rises under the eviction rule, which runs on lists in the arena: 0 here)
-    if (!aAnchor && aLength < lrec) return;
-    // the eviction rule (:57-93) and long lists are the arena's business
-    if (n >= P.seedPerWindowNmax || n >= WIN_POOL_LIST) {
-        if (!poolMigrate<BIG>(s, iW, lane)) return;
-        assignAlignToWindow<BIG, true>(X, s, iW, a1, aLength, aNrep, aFrag, aRstart, aAnchor, sjA, lane);
-        return;
-    }
-    u32 at = LST_WHERE(w) == 1u ? LST_AT(w) : s.used;
-    DWA nw; nw.gStart = a1; nw.nrep = aNrep; nw.L = (u16)aLength; nw.rStart = (u16)aRstart; nw.sjA = sjA; nw.anchor = aAnchor ? 1 : 0; nw.iFrag = (u8)aFrag; nw.pad[0] = nw.pad[1] = 0;
-    const bool have = lane < n;
-    DWA e; e.gStart = 0; e.nrep = 0; e.L = 0; e.rStart = 0; e.sjA = 0; e.anchor = 0; e.iFrag = 0; e.pad[0] = e.pad[1] = 0;
-    if (have) e = poolGet(s.pool, at + lane);
-    {
-        bool ov = have && aFrag == e.iFrag && e.sjA == sjA && a1 + e.rStart == e.gStart + aRstart
-                  && ((aRstart >= e.rStart && aRstart < (u32)e.rStart + e.L) || (aRstart + aLength >= e.rStart && aRstart + aLength < (u32)e.rStart + e.L));
-        u64 m = __ballot(ov);
-        if (m) {
-            u32 iA = (u32)__ffsll((long long)m) - 1;
-            u32 Lold = laneGet32(e.L, iA);
-            if (aLength > Lold) {
-                u64 m2 = __ballot(have && lane != iA && aRstart < e.rStart);
-                u32 iA0 = m2 ? (u32)__ffsll((long long)m2) - 1 : n;
-                if (iA0 > iA) --iA0;
-                if (iA0 < iA) { if (lane >= iA0 && lane < iA) poolPut(s.pool, at + lane + 1, e); }
-                else if (iA0 > iA) { if (lane > iA && lane <= iA0) poolPut(s.pool, at + lane - 1, e); }
-                if (lane == 0) poolPut(s.pool, at + iA0, nw);
-                rowFence<BIG>();
-            }
-            return;
-        }
-    }
-    if (aAnchor || aLength > lrec) {
-        if (s.used >= WIN_POOL_ROWS) {            // the pool is full: its longest list moves to the arena
-            u64 key = 0;
-            for (u32 j = lane; j < s.nW; j += 64) { const u32 x = s.t.blk[j]; if (LST_WHERE(x) == 1u) { const u64 v = ((u64)LST_NWA(x) << 32) | j; if (v > key) key = v; } }
-            // (lengths tie: the wave-wide maximum below needs distinct keys where they are not zero -- the window index breaks the tie)
-            key = ((key >> 32) << 12 | (key & 0xFFFu)) << 32 | (key & 0xFFFFFFFFu);
-            const u32 victim = (u32)waveMax64(key);
-            if (!poolMigrate<BIG>(s, victim, lane)) return;
-            if (victim == iW) { assignAlignToWindow<BIG, true>(X, s, iW, a1, aLength, aNrep, aFrag, aRstart, aAnchor, sjA, lane); return; }
-            w = s.t.blk[iW];
-            at = LST_WHERE(w) == 1u ? LST_AT(w) : s.used;
-        }
-        const u64 m3 = __ballot(have && aRstart < e.rStart);
-        const u32 iA = m3 ? (u32)__ffsll((long long)m3) - 1 : n;
-        const u32 g = at + iA;                    // the row that becomes free: every pool row from here on moves up by one (lane r = pool row r)
-        const bool moves = lane >= g && lane < s.used;
-        DWA mv; if (moves) mv = poolGet(s.pool, lane);
-        LOCKSTEP();                               // every lane has read its row before a neighbour overwrites it
-        if (moves) poolPut(s.pool, lane + 1, mv);
-        if (lane == 0) poolPut(s.pool, g, nw);
-        s.used++;
-        for (u32 j = lane; j < s.nW; j += 64) {
-            const u32 x = s.t.blk[j];
-            if (j == iW) s.t.blk[j] = LST_WORD(1u, at, lrec, n + 1u);
-            else if (LST_WHERE(x) == 1u && LST_AT(x) > at) s.t.blk[j] = x + (1u << 20);
-        }
-        rowFence<BIG>();
     }
 }
 
@@ -350,7 +246,7 @@ template <class BP> __device__ __forceinline__ u32 ownLookup(BP tab, u32 mask, u
 
 // pass-B owner of a bin, wave-parallel (lane j tests window j): last flank writer wins, else the core owner
 // (ReadAlign_stitchPieces.cpp:96-118 write order)
-template <bool BIG, bool LL> __device__ static u32 ownerWave(const WS<BIG, LL> &s, u32 str, u32 bin, u32 lane) {
+template <bool BIG> __device__ static u32 ownerWave(const WS<BIG> &s, u32 str, u32 bin, u32 lane) {
     u32 core = NOWIN, flank = NOWIN;
     for (u32 j0 = 0; j0 < s.nW; j0 += 64) {
         u32 j = j0 + lane; bool inExt = false, inCore = false;
@@ -379,8 +275,7 @@ extern __shared__ u32 ldsTab[];     // LDS launches: wavesPerBlock * (capW * 8 +
 // mode 0: every read, table in LDS (capW rows); reads that outgrow it go to list ovfWin
 // mode 2: the reads of ovfWin, table still in LDS but with more rows (blocks of one wavefront); reads that outgrow that go to list ovfWin2
 // mode 1: the reads of ovfWin2 (of ovfWin when no mode-2 launch ran: useMid = 0), table in global memory with the reference's own limits (BIG)
-template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
-    static_assert(!(BIG && LL) && WIN_POOL_ROWS <= 64, "the pool lives in LDS, one lane per row");
+template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
     const u32 big = BIG ? 1u : 0u;
     const bool ownMapEnable = (useMid & 2u) != 0; useMid &= 1u;      // (bit 1 of the argument: owner map on, STARAMD_WIN_OWNER_MAP)
     const DevIndex &X = *Xp;
@@ -388,16 +283,15 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
     u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
     u32 wavesPerBlock = blockDim.x >> 6;
     u32 wave = blockIdx.x * wavesPerBlock + waveInBlock;
-    WS<BIG, LL> s;
+    WS<BIG> s;
     u8 *mine = scratch + (u64)wave * winWaveBytes(capW, capBlocks, big);
     typename WPtr<BIG>::P tab;
     if constexpr (BIG) tab = (u32 *)(mine + (u64)capBlocks * WA_MAX * sizeof(DWA));
-    else tab = (typename WPtr<false>::P)ldsTab + waveInBlock * winLdsWords(capW, hashBits, LL);
+    else tab = (typename WPtr<false>::P)ldsTab + waveInBlock * (capW * 8 + hashBits / 32);
     s.hashMask = hashBits - 1u;
-    s.bitmap = tab + capW * (LL ? 6 : 8);
+    s.bitmap = tab + capW * 8;
     s.t.coreS = tab; s.t.coreE = tab + capW; s.t.extS = tab + 2 * capW; s.t.extE = tab + 3 * capW;
-    s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + (LL ? 5 : 6) * capW; s.t.nwa = tab + (LL ? 5 : 7) * capW;
-    s.pool = s.bitmap + hashBits / 32; s.used = 0;
+    s.t.meta = tab + 4 * capW; s.t.blk = tab + 5 * capW; s.t.lrec = tab + 6 * capW; s.t.nwa = tab + 7 * capW;
     s.arena = (DWA *)mine; s.capW = capW; s.capBlocks = capBlocks;
     u64 nSAenum = 0, nWindows = 0, nWAtot = 0; u32 nOvf = 0;
     u32 nOwnerLookups = 0, nOwnerMisses = 0, nAnchorLoci = 0, nAnchorReplayed = 0;
@@ -416,7 +310,7 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
         DRead rd = B.reads[ir];
         if (rd.nSeeds == 0) continue;
         const DSeed *PC = B.seedPool + rd.seedOffset;
-        s.nW = 0; s.nBlocks = 0; s.tooMany = false; s.winLimit = false; s.overflow = false; s.used = 0;
+        s.nW = 0; s.nBlocks = 0; s.tooMany = false; s.winLimit = false; s.overflow = false;
         s.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         WPROF_T0();
         // The seed table of the read and the first suffix-array entry of every seed are fetched up front, lane i = seed i: two round trips for the whole
@@ -484,8 +378,7 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
         if (!s.overflow) {
             for (u32 j = lane; j < s.nW; j += 64) {
                 u32 m = s.t.meta[j];
-                if constexpr (LL) s.t.blk[j] = 0;
-                else { s.t.nwa[j] = 0; s.t.lrec[j] = 0; s.t.blk[j] = NOWIN; }
+                s.t.nwa[j] = 0; s.t.lrec[j] = 0; s.t.blk[j] = NOWIN;
                 if (!(m & 1u)) continue;
                 u32 chr = m >> 2;
                 u32 wb = s.t.coreS[j];
@@ -558,13 +451,8 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
                 // a seed that is no anchor and shorter than what a full window has already turned away (lrec, assignAlignToWindow.cpp:11: it only ever rises) is
                 // dropped here by its own lane instead of in the replay: repeat seeds with thousands of loci leave the replay after the windows have filled up
                 if (!aAnchor) {
-                    if constexpr (LL) {
-                        if (wD != NOWIN && lD < LST_LREC(s.t.blk[wD])) wD = NOWIN;
-                        if (wA != NOWIN && lA < LST_LREC(s.t.blk[wA])) wA = NOWIN;
-                    } else {
-                        if (wD != NOWIN && lD < s.t.lrec[wD]) wD = NOWIN;
-                        if (wA != NOWIN && lA < s.t.lrec[wA]) wA = NOWIN;
-                    }
+                    if (wD != NOWIN && lD < s.t.lrec[wD]) wD = NOWIN;
+                    if (wA != NOWIN && lA < s.t.lrec[wA]) wA = NOWIN;
                 }
                 nSAenum += cnt;
                 WPROF_MARK(5);
@@ -575,13 +463,8 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
                     u32 xsplit = laneGet32(split ? 1u : 0u, l);
                     u32 xr = laneGet32(aRstart, l), xlD = laneGet32(lD, l);
                     i32 xsj = xsplit ? (i32)laneGet32(isj, l) : -1;
-                    if constexpr (LL) {
-                        if (xwD != NOWIN) assignPooled<BIG>(X, s, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
-                        if (xwA != NOWIN && !s.tooMany && !s.overflow) assignPooled<BIG>(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
-                    } else {
-                        if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
-                        if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
-                    }
+                    if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
+                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
                     if (s.tooMany || s.overflow) break;
                 }
                 WPROF_MARK(3);
@@ -599,7 +482,7 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
         if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
         // ---- emit windows that hold seeds, in window order
         u32 nOut = 0, nWA = 0; u32 est = 0, nMax = 0;
-        for (u32 j = lane; j < s.nW; j += 64) { u32 n = LL ? LST_NWA(s.t.blk[j]) : s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 20u); nMax = max(nMax, n); } }
+        for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 20u); nMax = max(nMax, n); } }
         for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); est += (u32)__shfl_xor((int)est, o, 64); nMax = max(nMax, (u32)__shfl_xor((int)nMax, o, 64)); }
         rd.wtOffset = nMax;
         if (nOut > 0) {
@@ -616,14 +499,12 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
             const u32 ioRead = io;
             if (light && lane == 0) B.items[io] = 0x80000000u | ir;
             for (u32 j = 0; j < s.nW; j++) {
-                u32 lw = 0, n;
-                if constexpr (LL) { lw = s.t.blk[j]; n = LST_NWA(lw); } else n = s.t.nwa[j];
+                u32 n = s.t.nwa[j];
                 if (n == 0) continue;
                 u32 m = s.t.meta[j];
-                if constexpr (!LL) lw = s.t.blk[j];
-                const DWA *A = s.arena + (u64)(LL ? LST_AT(lw) : lw) * WA_MAX;
+                const DWA *A = s.arena + (u64)s.t.blk[j] * WA_MAX;
                 u8 fr = 0;
-                if (lane < n) { const DWA row = (LL && LST_WHERE(lw) == 1u) ? poolGet(s.pool, LST_AT(lw) + lane) : A[lane]; fr = row.iFrag; B.waPool[ao + lane] = row; }
+                if (lane < n) { const DWA row = A[lane]; fr = row.iFrag; B.waPool[ao + lane] = row; }
                 const u8 mates = (u8)((__ballot(lane < n && fr == 0) ? 1u : 0u) | (__ballot(lane < n && fr != 0) ? 2u : 0u));
                 if (lane == 0) {
                     DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = ao; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.mates = mates; B.winPool[wo] = d;
@@ -661,16 +542,10 @@ template <bool BIG, bool LL> __device__ __forceinline__ void windowsBody(const D
                             // 400 k pairs, 128-row table: 4 waves 23.6, 5 (192 rows) 22.3, 6 -> 20.9, 7 -> 21.2, 8 -> 22.8; profiles/r04_ab_session*.txt)
 #endif
 extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
-    windowsBody<false, false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits);
+    windowsBody<false>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits);
 }
-#if WIN_POOL_ROWS
-// the first launch with the seed lists in LDS (win_pool.h); same arguments, same outputs
-extern "C" __global__ void __launch_bounds__(256, WIN_WAVES) k_windows_pool(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits) {
-    windowsBody<false, true>(Xp, B, scratch, capW, capBlocks, mode, lightEst, useMid, hashBits);
-}
-#endif
 extern "C" __global__ void __launch_bounds__(256, 4) k_windows_big(const DevIndex *__restrict__ Xp, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid) {
-    windowsBody<true, false>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid, WBITS);
+    windowsBody<true>(Xp, B, scratch, capW, capBlocks, 1u, lightEst, useMid, WBITS);
 }
 
 // ---- stitch order: work items sorted by class ~ log2(estimated walk size), largest first (counting sort

@@ -104,28 +104,6 @@ def test_forced_rare_paths(case, tmp_path, built):
         _run("pe101", 30, [], tmp_path, env=FORCED[case], order="desc" if i % 4 == 1 else "asc")
 
 
-# ---- k_windows with the seed lists of a read in LDS (star_amd/csrc/engine/win_pool.h): a candidate build, not part of the product -- the kernel sources compiled with
-# -DWIN_POOL_ROWS=..., once with the pool the candidate would ship with and once with a pool of 4 rows and lists of at most 2 (every read moves lists to the arena in
-# global memory and evicts the longest list of a full pool)
-POOL_BUILDS = {"win_pool": "-DWIN_POOL_ROWS=64", "win_pool_tiny": "-DWIN_POOL_ROWS=4 -DWIN_POOL_LIST=3"}
-
-
-@pytest.mark.parametrize("tag", sorted(POOL_BUILDS))
-def test_window_seed_lists_in_lds_candidate(tag, tmp_path, built):
-    import fcntl
-    lib = os.path.join(ROOT, "oracle", "_build", "libstaramd_emul_%s.so" % tag)
-    with open(os.path.join(ROOT, "oracle", "_build", ".emul_%s.lock" % tag), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        subprocess.check_call([os.path.join(ROOT, "oracle", "wave_emul", "build.sh"), "variant", tag, POOL_BUILDS[tag]], cwd=ROOT, stdout=subprocess.DEVNULL)
-    env = {"STARAMD_EMUL_LIB": lib}
-    _run("pe101", 40, [], tmp_path / "a", env=env, order="asc")
-    _run("pe101", 25, ["--gpuResultSelect", "All"], tmp_path / "b", env=env, order="desc")
-    _run("pe150_chim", 20, ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"], tmp_path / "c", env=env, order="asc")
-    _run("pe101", 30, ["--seedPerWindowNmax", "3"], tmp_path / "d", env=env, order="desc")                 # the reference's eviction rule at 3 seeds per window
-    _run("pe101", 30, [], tmp_path / "e", env=dict(env, **FORCED["block_overflow"]), order="asc")          # no block left in the arena for a list that has to move
-    _run("pe101", 30, [], tmp_path / "f", env=dict(env, STARAMD_WIN_POOL="0"), order="asc")                # the candidate library with its switch off = the product kernel
-
-
 # ---- the shipped front end (main.cpp + cli_run.cpp) linked against the emulated engine: oracle/_build/star_amd_emul_cli -------------------------
 EMUL_CLI = os.path.join(ROOT, "oracle", "_build", "star_amd_emul_cli")
 SMALL = {"STARAMD_WIN_BLOCKS_BIG": "2"}       # (the 64 blocks of the last k_windows launch own 3.9 GB of work space, which the emulated hipMalloc fills with its pattern)
