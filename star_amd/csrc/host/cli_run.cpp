@@ -47,7 +47,10 @@ struct Queue {                                   // hand-off between two pipelin
 };
 struct Tokens {                                  // counting semaphore over a small set of buffer indices
     std::mutex m; std::condition_variable cv; std::deque<int> free;
-    int take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free.empty(); }); int v = free.front(); free.pop_front(); return v; }
+    // the slot that was given back LAST is handed out first: the pipeline then lives in as many slots as it has batches in flight (4 - 5 of the 8), whose ~300 MB
+    // each of text, line tables and page-locked arrays are mapped and warm; going round all slots in turn touched every buffer of every slot (first use = page
+    // faults and hipHostMalloc inside the reader, on 8 of the first 8 batches) and kept none of them in any cache
+    int take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free.empty(); }); static const bool fifo = getenv("STARAMD_SLOTS_FIFO") != nullptr; int v = fifo ? free.front() : free.back(); if (fifo) free.pop_front(); else free.pop_back(); return v; }
     void give(int v) { { std::lock_guard<std::mutex> l(m); free.push_back(v); } cv.notify_all(); }
 };
 // result arrays of a batch: page-locked (staramd_pinned_alloc), so that the engine's device-to-host copies are DMA transfers straight into them;

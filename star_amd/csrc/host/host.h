@@ -246,7 +246,7 @@ public:
     uint64_t readsSoFar = 0;
 private:
     FILE *f[2] = {nullptr, nullptr};
-    unsigned readSlices = 4;                         // slices a block of a regular input file is read in (threads per mate): --runThreadN / 8 in [4, 16], STARAMD_READ_SLICES
+    unsigned readSlices = 4;                         // slices a block of a regular input file is read in (threads per mate): --runThreadN / 2 in [4, 16], STARAMD_READ_SLICES
     std::atomic<uint64_t> slicedBlocks{0};           // blocks of a regular file read in slices on threads (reads.cpp fill)
     int nMates = 0;
     std::vector<std::string> paths_; std::string command_;

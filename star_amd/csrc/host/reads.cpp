@@ -428,7 +428,9 @@ bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     static const bool timing = getenv("STARAMD_HOST_TIMING") != nullptr;
     {   // a block of ~100 MB per mate and batch is copied out of the page cache and scanned for line ends by this many threads per mate
         static const unsigned fixed = getenv("STARAMD_READ_SLICES") ? (unsigned)atoi(getenv("STARAMD_READ_SLICES")) : 0u;
-        readSlices = fixed ? std::max(1u, std::min(fixed, 64u)) : (unsigned)std::max(4, std::min(16, P.runThreadN / 8));
+        // (measured on a GPU box with 16 CPUs, profiles/r04_host_stages_on_the_gpu_box.txt: read + scan of one mate's block 20.6 ms with 4 slices, 7.3 ms with 8 -- the
+        // fill stage is the longest host stage of a batch and runs once per batch on its own thread, so its slices are what the other stages leave idle)
+        readSlices = fixed ? std::max(1u, std::min(fixed, 64u)) : (unsigned)std::max(4, std::min(16, P.runThreadN / 2));
     }
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
