@@ -958,7 +958,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     const u32 lane = threadIdx.x & 63u;
-    u32 waveInBlock = threadIdx.x >> 6, wavesPerBlock = blockDim.x >> 6;
+    u32 waveInBlock = first32(threadIdx.x >> 6), wavesPerBlock = blockDim.x >> 6;      // (the same for all lanes of a wavefront: said so, or everything addressed through it counts as divergent)
     u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
     u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
     LaneMem m;
@@ -1197,7 +1197,7 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_replay(const DevIndex
     if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const staramd_params &P = Xp->P;
     const u32 lane = threadIdx.x & 63u;
-    u32 waveInBlock = threadIdx.x >> 6, wavesPerBlock = blockDim.x >> 6;
+    u32 waveInBlock = first32(threadIdx.x >> 6), wavesPerBlock = blockDim.x >> 6;      // (the same for all lanes of a wavefront: said so, or everything addressed through it counts as divergent)
     u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
     u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
     LaneMem m;
