@@ -60,8 +60,8 @@ __device__ static bool coopExtendBody(StitchCtx &c, u32 lane, u32 rStart, u64 gS
         for (iExt = 0; iExt < (int)L; iExt++) {
             int iS = dR * iExt, iG = dG * iExt;
             u8 gc = 5;
-            if ((gStart + (i64)iG) == (u64)(-1) || (gc = gByte(c, gStart + (i64)iG)) == 5) { e.extendL = 0; e.maxScore = -999999999; e.nMatch = 0; e.nMM = nMMmax + 1; return true; }
-            u8 rc = RD(c, (u32)((int)rStart + iS));
+            if ((gStart + (i64)iG) == (u64)(-1) || (gc = (u8)first32(gByte(c, gStart + (i64)iG))) == 5) { e.extendL = 0; e.maxScore = -999999999; e.nMatch = 0; e.nMM = nMMmax + 1; return true; }
+            u8 rc = (u8)first32(RD(c, (u32)((int)rStart + iS)));
             if (rc == STARAMD_SPACER_BASE) break;
             if (rc > 3 || gc > 3) continue;
             if (gc == rc) { nMatch++; Score += 1; } else { nMM++; Score -= 1; }
