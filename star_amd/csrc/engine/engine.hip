@@ -265,6 +265,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.replayList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.heavyList, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.heavyList2, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.trPool, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
     if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
@@ -336,7 +337,8 @@ static int allocWork(staramd_ctx *c) {
         if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_replay %d blocks/CU (LDS %zu B/block)\n", rpPerCU, ldsReplay);
     }
     // lean launch geometry
-    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 9); c->leanArena = envU32("STARAMD_LEAN_ARENA", 2048) & ~31u;
+    // (with the lane kernel in front: windows of up to 15 seeds in a slice of 7.5 KB per wavefront -- 5 wavefronts per SIMD -- against 12.5 KB for the full-size slice)
+    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 16); c->leanArena = envU32("STARAMD_LEAN_ARENA", 3072) & ~31u;
     if (c->leanDepth >= c->capDepth) c->leanDepth = 0;
     c->stBlocksLean = 0;
     if (c->leanDepth) {
@@ -558,6 +560,7 @@ static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
         if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.heavyList, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.heavyList2, (u64)B.winCap))) return rc;
     }
     if (flags & OVF_TRPOOL) {
         B.trCap = grow(B.trCap, cur[CUR_TR]); B.exCap = grow(B.exCap, cur[CUR_EX]);
@@ -616,6 +619,10 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
             if (mode == 0 && c->laneBlocks && laneFits) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
                 hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, c->laneClass);
                 HIPCHK(hipEventRecord(c->ev[8], s));
+                if (c->leanDepth) {     // ... the cooperative walk itself in two launches: a lean LDS slice (more resident wavefronts) for the windows of few seeds, the full-size slice for the rest
+                    hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksLean), block, ldsLean, s, c->dX, B, c->scrStitchBig, c->leanDepth, c->capRank, c->leanArena, c->arenaBig, ldsWords, 3u, prune);
+                    hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 4u, prune);
+                } else
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
             } else
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest
