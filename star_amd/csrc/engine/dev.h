@@ -189,6 +189,15 @@ __device__ __forceinline__ u64 bcast64(u64 v, u32 srcLane) {
 __device__ __forceinline__ u32 first32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ i32 firstI(i32 v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 first64(u64 v) { return ((u64)first32((u32)(v >> 32)) << 32) | first32((u32)v); }
+// The index of a wavefront inside its block, threadIdx.x >> 6, is the same for all 64 lanes -- which nothing tells the compiler.  Left as it is, the wavefront's LDS slice,
+// every pointer into it, every value loaded through them and every branch on those values count as lane-dependent: k_stitch_win then keeps ~140 wave-uniform values in
+// vector registers (168 VGPRs + 82 spilled instead of 106 and none) and compiles 325 wave-uniform branches to exec-mask sequences.  -DWAVE_INDEX_PLAIN restores that
+// (the kernels of round 4), for A/B runs.
+#ifdef WAVE_INDEX_PLAIN
+#define WAVE_INDEX(x) (x)
+#else
+#define WAVE_INDEX(x) first32(x)
+#endif
 // number of set bits of a 64-lane ballot mask in the lanes strictly below / up to and including this lane
 __device__ __forceinline__ u32 cntBelow(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 __device__ __forceinline__ u32 cntUpTo(u64 m, u32 lane) { return cntBelow(m) + (u32)((m >> lane) & 1ull); }

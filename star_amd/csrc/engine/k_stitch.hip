@@ -958,7 +958,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
     const u32 lane = threadIdx.x & 63u;
-    u32 waveInBlock = first32(threadIdx.x >> 6), wavesPerBlock = blockDim.x >> 6;      // (the same for all lanes of a wavefront: said so, or everything addressed through it counts as divergent)
+    u32 waveInBlock = WAVE_INDEX(threadIdx.x >> 6), wavesPerBlock = blockDim.x >> 6;
     u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
     u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
     LaneMem m;
@@ -1018,12 +1018,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         u32 maxSeeds; i32 bestSoFar = 0; u32 nWinRead = 0;
         if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; maxSeeds = rd.wtOffset; nWinRead = rd.nWin; }
         else maxSeeds = first32(B.winPool[item].nWA);
-        if (mode == 0 && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {       // more seeds than this (lean) launch has LDS rows for: the full-size launch takes the item
-            if (lane == 0) { u32 k = atomicAdd(&B.cursors[CUR_ST_HEAVY], 1u); B.heavyList[k] = item; }
-            continue;
-        }
-        if (mode == 3 && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {
-            if (lane == 0) { u32 k = atomicAdd(&B.cursors[CUR_ST_HEAVY2], 1u); B.heavyList2[k] = item; }
+        if ((mode == 0 || mode == 3) && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {       // more seeds than this (lean) launch has LDS rows for: the full-size launch takes the item
+            if (lane == 0) { u32 k = atomicAdd(&B.cursors[mode == 0 ? CUR_ST_HEAVY : CUR_ST_HEAVY2], 1u); (mode == 0 ? B.heavyList : B.heavyList2)[k] = item; }
             continue;
         }
         // A light read is walked in up to two sweeps.  Sweep 0 (only when some of its windows hold seeds of both mates and some do not): the
@@ -1204,7 +1200,7 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_replay(const DevIndex
     if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const staramd_params &P = Xp->P;
     const u32 lane = threadIdx.x & 63u;
-    u32 waveInBlock = first32(threadIdx.x >> 6), wavesPerBlock = blockDim.x >> 6;      // (the same for all lanes of a wavefront: said so, or everything addressed through it counts as divergent)
+    u32 waveInBlock = WAVE_INDEX(threadIdx.x >> 6), wavesPerBlock = blockDim.x >> 6;
     u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
     u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
     LaneMem m;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 5, GPU session 1: the kernels with the wave index declared uniform (dev.h WAVE_INDEX) against the kernels of round 4 (-DWAVE_INDEX_PLAIN), and what the registers it frees
+# are worth in resident wavefronts.  Build the variants BEFORE the call (they travel with the snapshot):
+#   tools/build_variants.sh r4:k_stitch+k_window:"-DWAVE_INDEX_PLAIN" st5:k_stitch:"-DSTITCH_WAVES=5" st4:k_stitch:"-DSTITCH_WAVES=4" \
+#        w7:k_window:"-DWIN_WAVES=7" w8:k_window:"-DWIN_WAVES=8" st5w8:k_stitch+k_window:"-DSTITCH_WAVES=5 -DWIN_WAVES=8"
+# every variant's resource figures: tools/isa_stats.sh k_stitch -DSTITCH_WAVES=5 ...   (a variant that does not show ~106 / 96 VGPRs for k_stitch_win has fallen back into the
+# other regime of the register allocator: it flips on small edits -- check before spending GPU time)
+cd ${GRAFT_REPO_ROOT:-.}
+O=gpurun_out/r05s1; mkdir -p $O
+V=star_amd/lib/variants
+timeout 600 python tools/ab_kernels.py --genome-mb 3100 --batches 3 --repeat 2 --rounds 2 --out $O/ab.json \
+  "r4_kernels|$V/libstaramd_r4.so|STARAMD_LEAN_DEPTH=0" \
+  "uniform_same_occupancy|-|STARAMD_LEAN_DEPTH=0" \
+  "uniform_lean16|-|" \
+  "uniform_lean16_stitch5|$V/libstaramd_st5.so|" \
+  "uniform_lean12_stitch5|$V/libstaramd_st5.so|STARAMD_LEAN_DEPTH=12" \
+  "uniform_lean16_stitch4|$V/libstaramd_st4.so|" \
+  "uniform_win7_rows112|$V/libstaramd_w7.so|STARAMD_CAP_WINDOWS=112 STARAMD_LEAN_DEPTH=0" \
+  "uniform_win8_rows96|$V/libstaramd_w8.so|STARAMD_CAP_WINDOWS=96 STARAMD_LEAN_DEPTH=0" \
+  "uniform_all|$V/libstaramd_st5w8.so|STARAMD_CAP_WINDOWS=96" > $O/ab.txt 2> $O/ab.err
+echo "ab rc $?"
+grep -v "counts per pair" $O/ab.txt | tail -20
+tail -3 $O/ab.err
