@@ -117,7 +117,7 @@ __device__ static bool coopExtendBody(StitchCtx &c, u32 lane, u32 rStart, u64 gS
 #ifdef STARAMD_SHADOW
 __device__ static bool coopExtendChecked(StitchCtx &c, u32 lane, u32 rStart, u64 gStart, int dR, int dG, u32 L, u32 Lprev, u32 nMMprev, u32 nMMmax, double pMMmax, bool extendToEnd, ExtRes &e) {
     bool r = coopExtend(c, lane, rStart, gStart, dR, dG, L, Lprev, nMMprev, nMMmax, pMMmax, extendToEnd, e);
-    ExtRes s; bool rs = extendAlign(c, rStart, gStart, dR, dG, L, Lprev, nMMprev, nMMmax, pMMmax, extendToEnd, s);
+    ExtRes s; bool rs = growOnLane(c, rStart, gStart, dR, dG, L, Lprev, nMMprev, nMMmax, pMMmax, extendToEnd, s);
     bool bad = r != rs || (r && (s.maxScore != e.maxScore || s.extendL != e.extendL || s.nMatch != e.nMatch || s.nMM != e.nMM));
     if (lane == 0) { if (bad) atomicAdd((unsigned long long *)&c.shadow[2], 1ull); atomicAdd((unsigned long long *)&c.shadow[3], 1ull); }
     return r;
@@ -842,7 +842,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
             { PROF_T0(); dScore = coopStitch(c, lane, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G); PROF_ADD(c, 1); }
 #ifdef STARAMD_SHADOW
             {   // every lane re-runs the call through the scalar restatement (same inputs): any disagreement is counted
-                int dS = stitchAlignToTranscript(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hs, eAs, eNs, addedS, ex0R, ex0G);
+                int dS = joinOnLane(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hs, eAs, eNs, addedS, ex0R, ex0G);
                 bool bad = dS != dScore;
                 if (!bad && dS > -1000000) {
                     bad = hs.nMatch != hn.nMatch || hs.nMM != hn.nMM || hs.nGap != hn.nGap || hs.lGap != hn.lGap || hs.nDel != hn.nDel || hs.lDel != hn.lDel || hs.nIns != hn.nIns || hs.lIns != hn.lIns
