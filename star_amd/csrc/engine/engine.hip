@@ -337,8 +337,9 @@ static int allocWork(staramd_ctx *c) {
         if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_replay %d blocks/CU (LDS %zu B/block)\n", rpPerCU, ldsReplay);
     }
     // lean launch geometry
-    // (with the lane kernel in front: windows of up to 15 seeds in a slice of 7.5 KB per wavefront -- 5 wavefronts per SIMD -- against 12.5 KB for the full-size slice)
-    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 16); c->leanArena = envU32("STARAMD_LEAN_ARENA", 3072) & ~31u;
+    // (with the lane kernel in front: windows of up to 19 seeds -- a pair has ~17 seeds in all, its best window holds most of them -- in a slice of 7.6 KB per wavefront,
+    // 5 wavefronts per SIMD, against 12.5 KB for the full-size slice)
+    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 20); c->leanArena = envU32("STARAMD_LEAN_ARENA", 3072) & ~31u;
     if (c->leanDepth >= c->capDepth) c->leanDepth = 0;
     c->stBlocksLean = 0;
     if (c->leanDepth) {
@@ -649,6 +650,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
     HIPCHK(waitStream(c));
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: stitch work items %u, handed on by the lane kernel %u, handed on by the lean launch %u\n", hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY], hs[8 + CUR_ST_HEAVY2]);
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));
