@@ -19,6 +19,7 @@ timeout 600 python tools/ab_kernels.py --genome-mb 3100 --batches 3 --repeat 2 -
   "uniform_lean16_stitch5|$V/libstaramd_st5.so|STARAMD_LEAN_DEPTH=16" \
   "uniform_lean20_stitch4|$V/libstaramd_st4.so|" \
   "uniform_lean16_stitch6|$V/libstaramd_st6.so|STARAMD_LEAN_DEPTH=16 STARAMD_LEAN_ARENA=2048" \
+  "uniform_lean20_arena2048_stitch6|$V/libstaramd_st6.so|STARAMD_LEAN_ARENA=2048" \
   "uniform_lean12_stitch8|$V/libstaramd_st8.so|STARAMD_LEAN_DEPTH=12 STARAMD_LEAN_ARENA=1024" \
   "uniform_win7_rows112|$V/libstaramd_w7.so|STARAMD_CAP_WINDOWS=112 STARAMD_LEAN_DEPTH=0" \
   "uniform_win8_rows96|$V/libstaramd_w8.so|STARAMD_CAP_WINDOWS=96 STARAMD_LEAN_DEPTH=0" \
