@@ -178,6 +178,8 @@ struct ReadBatch {
     std::vector<uint64_t, BatchAlloc<uint64_t>> readOffset;     // n+1
     std::vector<uint16_t, BatchAlloc<uint16_t>> mate1Length, mmMaxTotal;
     TextBuf text[2];                      // the FASTQ text of the batch as read from each mate file; the spans below point into it
+    const char *mapped[2] = {nullptr, nullptr};   // ... or, for a regular input file, the batch's part of the MAPPING of the file (FastqReader): nothing is copied, text[] stays empty
+    const char *txt(int m) const { return mapped[m] ? mapped[m] : text[m].data(); }
     std::vector<TextSpan> nameSpan;       // read ID without '@', trimmed at readNameSeparator (from mate 1's ID line)
     std::vector<TextSpan> seqSpan[2], qualSpan[2];
     std::vector<char> filter;             // 'Y'/'N' Illumina pass-filter field
@@ -190,12 +192,12 @@ struct ReadBatch {
     uint32_t fileOf(uint32_t i) const { return heldFile.empty() ? fileIndex : heldFile[i]; }
     std::vector<uint64_t> lineStart[2], lineEnd[2];   // line table of text[]: written by the reader's fill stage, turned into the spans above by its convert stage
     std::vector<TextSpan> extraSpan[2];   // SAM input: the attributes of the input record, tab-separated text (readNameExtra, readLoad.cpp:28-29); empty otherwise
-    std::string_view extra(int m, uint32_t i) const { return extraSpan[m].empty() ? std::string_view() : std::string_view(text[m].data() + extraSpan[m][i].off, extraSpan[m][i].len); }
+    std::string_view extra(int m, uint32_t i) const { return extraSpan[m].empty() ? std::string_view() : std::string_view(txt(m) + extraSpan[m][i].off, extraSpan[m][i].len); }
     bool fasta = false;                   // the reads came without qualities (FASTA input, readLoad.cpp:84-88): QUAL is * in SAM, 0xFF in BAM, Fastx output is FASTA
     uint64_t readIndex(uint32_t i) const { return origIndex.empty() ? firstReadIndex + i : origIndex[i]; }
-    std::string_view name(uint32_t i) const { return std::string_view(text[0].data() + nameSpan[i].off, nameSpan[i].len); }
-    std::string_view seq(int m, uint32_t i) const { return std::string_view(text[m].data() + seqSpan[m][i].off, seqSpan[m][i].len); }
-    std::string_view qual(int m, uint32_t i) const { return std::string_view(text[m].data() + qualSpan[m][i].off, qualSpan[m][i].len); }
+    std::string_view name(uint32_t i) const { return std::string_view(txt(0) + nameSpan[i].off, nameSpan[i].len); }
+    std::string_view seq(int m, uint32_t i) const { return std::string_view(txt(m) + seqSpan[m][i].off, seqSpan[m][i].len); }
+    std::string_view qual(int m, uint32_t i) const { return std::string_view(txt(m) + qualSpan[m][i].off, qualSpan[m][i].len); }
     staramd_batch view() const;
     void clear();
 };
@@ -255,6 +257,13 @@ private:
     void closeFiles();
     std::string mem[2]; size_t memPos[2] = {0, 0}; bool fromMemory = false;
     std::vector<char> carry[2];           // text read from the file but not yet part of a batch
+    // A regular, uncompressed input file is MAPPED: a batch is a range of the mapping (ReadBatch::mapped), found by scanning for line ends in place -- the ~250 bytes per read
+    // and mate that the block reads copied out of the page cache are not copied at all.  Mappings live until the reader is reopened or destroyed (batches in flight point
+    // into them).  Not for pipes (--readFilesCommand), SAM / FASTA input, or options that rewrite the text of a batch in place (--outQSconversionAdd, --outSAMreadID Number).
+    struct Mapped { const char *p = nullptr; size_t n = 0; };
+    std::vector<Mapped> allMaps; Mapped curMap[2]; size_t mapPos[2] = {0, 0}; int useMap = -1;      // useMap: -1 undecided, 0 copy, 1 mapping
+    void dropMaps();
+    uint64_t fillMapped(int m, uint64_t want, ReadBatch &b);
     bool eof[2] = {false, false};
     std::atomic<int> ioError{0};          // errno of a failed read of an input file (sliced pread path): reported by nextBatch, never taken for the end of the input
     double bytesPerRecord[2] = {512, 512};   // running estimate, sizes the next block read

@@ -9,6 +9,7 @@
 // names, sequences and qualities are spans into it (nothing is copied per read until the SAM line is formatted).
 #include "host.h"
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <cstring>
 #include <algorithm>
@@ -51,13 +52,14 @@ void ReadBatch::clear() {
     n = 0; bases.clear(); readOffset.assign(1, 0); mate1Length.clear(); mmMaxTotal.clear();
     nameSpan.clear(); filter.clear(); origIndex.clear(); heldFile.clear();
     for (int m = 0; m < 2; m++) for (int q = 0; q < 2; q++) clipN[m][q].clear();
-    for (int i = 0; i < 2; i++) { text[i].clear(); seqSpan[i].clear(); qualSpan[i].clear(); extraSpan[i].clear(); lineStart[i].clear(); lineEnd[i].clear(); }
+    for (int i = 0; i < 2; i++) { text[i].clear(); mapped[i] = nullptr; seqSpan[i].clear(); qualSpan[i].clear(); extraSpan[i].clear(); lineStart[i].clear(); lineEnd[i].clear(); }
 }
 
 void FastqReader::closeFiles() {
     for (int i = 0; i < 2; i++) if (f[i]) { if (command_.empty()) fclose(f[i]); else pclose(f[i]); f[i] = nullptr; }
 }
-FastqReader::~FastqReader() { closeFiles(); }
+void FastqReader::dropMaps() { for (Mapped &m : allMaps) if (m.p) munmap((void *)m.p, m.n); allMaps.clear(); curMap[0] = curMap[1] = Mapped(); }
+FastqReader::~FastqReader() { closeFiles(); dropMaps(); }
 
 std::string FastqReader::openCurrent() {
     for (int i = 0; i < (samMates_ > 0 ? 1 : nMates); i++) {
@@ -72,6 +74,14 @@ std::string FastqReader::openCurrent() {
         if (!f[i]) return "EXITING because of fatal input ERROR: could not open readFilesIn=" + path;
         setvbuf(f[i], nullptr, _IONBF, 0);          // blocks are read straight into the batch text
         carry[i].clear(); eof[i] = false;
+        curMap[i] = Mapped(); mapPos[i] = 0; useMap = -1;
+        if (command_.empty() && samMates_ == 0 && !getenv("STARAMD_NO_INPUT_MMAP")) {
+            struct stat st;
+            if (fstat(fileno(f[i]), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                void *p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f[i]), 0);
+                if (p != MAP_FAILED) { (void)madvise(p, (size_t)st.st_size, MADV_SEQUENTIAL); curMap[i].p = (const char *)p; curMap[i].n = (size_t)st.st_size; allMaps.push_back(curMap[i]); }
+            }
+        }
     }
     {   // the first character of the first mate's file decides the format (ReadAlignChunk_processChunks.cpp:111,158)
         char c = 0;
@@ -83,7 +93,7 @@ std::string FastqReader::openCurrent() {
 }
 
 std::string FastqReader::open(const std::vector<std::string> &paths, const std::string &readCommand, int samMates) {
-    closeFiles();
+    closeFiles(); dropMaps(); useMap = -1;          // (every batch of the pass before has been written by now)
     ioError = 0;                                    // (a read error of an earlier pass / file was reported then: not sticky)
     nMates = (int)paths.size(); paths_ = paths; command_ = readCommand; fromMemory = false; samMates_ = samMates; extras = samMates > 0;
     for (int i = 0; i < nMates; i++) {              // --readFilesIn a1,a2,... b1,b2,...: the files of a mate are read one after the other
@@ -99,7 +109,7 @@ std::string FastqReader::open(const std::vector<std::string> &paths, const std::
 }
 
 void FastqReader::openMemory(std::string mate1, std::string mate2, int nMatesIn) {
-    nMates = nMatesIn; fromMemory = true;
+    nMates = nMatesIn; fromMemory = true; useMap = 0;      // (the mappings of the files stay: batches of the stage before may still be in flight)
     noQualities = noQualities || fasta; fasta = false; samMates_ = 0;     // held reads are kept as four-line records whatever the input format was
     mem[0].swap(mate1); mem[1].swap(mate2);
     for (int i = 0; i < 2; i++) { memPos[i] = 0; carry[i].clear(); eof[i] = false; }
@@ -271,6 +281,70 @@ uint64_t FastqReader::fillSam(uint64_t want, ReadBatch &b) {
     return LS[0]->size();
 }
 
+// The batch as a range of the file's mapping: line ends are looked for in place, in slices on threads, from where the batch before ended; nothing is copied.
+uint64_t FastqReader::fillMapped(int m, uint64_t want, ReadBatch &b) {
+    std::vector<uint64_t> &ls = b.lineStart[m], &le = b.lineEnd[m], &nlp = lineRaw[m];
+    ls.clear(); le.clear(); nlp.clear(); b.text[m].clear();
+    const char *tx = curMap[m].p ? curMap[m].p + mapPos[m] : nullptr;
+    const uint64_t avail = curMap[m].p ? curMap[m].n - mapPos[m] : 0;
+    b.mapped[m] = tx;
+    const uint64_t wantLines = want * 4;
+    static const uint64_t sliceMin = getenv("STARAMD_READ_SLICE_MIN") ? strtoull(getenv("STARAMD_READ_SLICE_MIN"), nullptr, 10) : (8u << 20);
+    auto onThreads = [&](unsigned K, const std::function<void(unsigned)> &fn) {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < K; k++) th.emplace_back(fn, k);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    uint64_t scanned = 0;
+    while (nlp.size() < wantLines && scanned < avail) {
+        const uint64_t missing = (wantLines - nlp.size() + 3) / 4;
+        const uint64_t block = std::min<uint64_t>(avail - scanned, std::max<uint64_t>(1u << 16, std::min<uint64_t>(256u << 20, (uint64_t)((double)missing * bytesPerRecord[m] * 1.01) + 4096)));
+        if (block >= sliceMin) {
+            const unsigned K = std::max(1u, readSlices);
+            std::vector<std::vector<uint64_t>> nl(K);
+            const uint64_t per = (block + K - 1) / K;
+            onThreads(K, [&](unsigned k) {
+                const uint64_t lo = std::min(block, k * per), hi = std::min(block, lo + per);
+                nl[k].reserve((size_t)((double)(hi - lo) / bytesPerRecord[m] * 4.2) + 16);
+                scanNewlines(tx, scanned + lo, scanned + hi, nl[k], UINT64_MAX);
+            });
+            std::vector<size_t> off(K + 1, nlp.size());
+            for (unsigned k = 0; k < K; k++) off[k + 1] = off[k] + nl[k].size();
+            const size_t total = std::min<size_t>(off[K], wantLines);
+            nlp.resize(total);
+            onThreads(K, [&](unsigned k) { if (off[k] < total) memcpy(nlp.data() + off[k], nl[k].data(), (std::min(off[k + 1], total) - off[k]) * sizeof(uint64_t)); });
+            slicedBlocks++;
+        } else scanNewlines(tx, scanned, scanned + block, nlp, wantLines);
+        scanned += block;
+    }
+    if (nlp.size() >= 4) bytesPerRecord[m] = (double)(nlp.back() + 1) / (double)(nlp.size() / 4);
+    const size_t nNl = nlp.size();
+    const uint64_t lineBeg = nNl == 0 ? 0 : nlp.back() + 1;
+    const bool tailLine = nNl < wantLines && lineBeg < avail;           // end of file without a final newline: the tail is a line
+    ls.resize(nNl + (tailLine ? 1 : 0)); le.resize(ls.size());
+    {
+        const unsigned K = nNl >= (1u << 16) ? std::max(1u, readSlices) : 1u;
+        const size_t per = (nNl + K - 1) / K;
+        onThreads(K, [&](unsigned k) {
+            const size_t lo = std::min(nNl, k * per), hi = std::min(nNl, lo + per);
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t s0 = i ? nlp[i - 1] + 1 : 0; uint64_t e0 = nlp[i];
+                if (e0 > s0 && (unsigned char)tx[e0 - 1] < 33) e0--;
+                ls[i] = s0; le[i] = e0;
+            }
+        });
+    }
+    if (tailLine) {
+        uint64_t e0 = avail;
+        if (e0 > lineBeg && (unsigned char)tx[e0 - 1] < 33) e0--;
+        ls[nNl] = lineBeg; le[nNl] = e0;
+    }
+    mapPos[m] += nNl >= wantLines ? lineBeg : avail;                     // what follows belongs to the next batches
+    eof[m] = mapPos[m] >= curMap[m].n;
+    return ls.size();
+}
+
 uint64_t FastqReader::fill(int m, uint64_t want, ReadBatch &b) {
     TextBuf &text = b.text[m];
     if (samMates_ > 0) {
@@ -279,6 +353,7 @@ uint64_t FastqReader::fill(int m, uint64_t want, ReadBatch &b) {
         return b.lineStart[1].size();
     }
     if (fasta) return fillFasta(m, want, b);
+    if (useMap == 1) return fillMapped(m, want, b);
     std::vector<uint64_t> &ls = b.lineStart[m], &le = b.lineEnd[m], &nlp = lineRaw[m];
     ls.clear(); le.clear(); nlp.clear();
     text.assign(carry[m].begin(), carry[m].end());      // (not swap: every buffer keeps its capacity, so no fresh pages per batch)
@@ -436,6 +511,7 @@ bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };
     uint64_t nLines[2] = {0, 0};
     for (;;) {
+        if (useMap < 0) useMap = (!fromMemory && samMates_ == 0 && !fasta && command_.empty() && P.outQSconversionAdd == 0 && !P.outSAMreadIDnumber && curMap[0].p && (nMates < 2 || curMap[1].p)) ? 1 : 0;
         if (nMates == 2 && samMates_ == 0 && !fasta) {       // the two mate files are read and scanned for line ends side by side
             std::thread second([&] { nLines[1] = fill(1, want, b); });
             nLines[0] = fill(0, want, b);
@@ -495,7 +571,7 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
     inRanges([&](uint64_t lo, uint64_t hi, int t) {
         auto bad = [&](uint64_t i, const char *msg) { uint64_t cur = firstBad.load(); while (i < cur && !firstBad.compare_exchange_weak(cur, i)) {} if (errs[t].empty()) errs[t] = msg; };
         for (uint64_t i = lo; i < hi; i++) {
-            const char *t0 = b.text[0].data();
+            const char *t0 = b.txt(0);
             uint64_t s0 = lineStart[0][4 * i], e0 = lineEnd[0][4 * i];
             if (t0[s0] != '@') { bad(i, "EXITING because of FATAL ERROR in input reads: wrong read ID line format: the read ID lines should start with @ (FASTA/SAM input: out of scope)"); return; }
             uint64_t len[2] = {0, 0};
@@ -507,7 +583,7 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
                 if (qe - qs != len[m]) { bad(i, "EXITING because of FATAL ERROR in reads input: quality string length is not equal to sequence length"); return; }
                 b.seqSpan[m][i] = TextSpan{ss, (uint32_t)len[m]}; b.qualSpan[m][i] = TextSpan{qs, (uint32_t)len[m]};
                 if (extras) {                           // attributes of the input SAM record, kept on the ID line after a \x01
-                    const char *tm = b.text[m].data(); const uint64_t is = lineStart[m][4 * i], ie = lineEnd[m][4 * i];
+                    const char *tm = b.txt(m); const uint64_t is = lineStart[m][4 * i], ie = lineEnd[m][4 * i];
                     const char *x = (const char *)memchr(tm + is, '\x01', ie - is);
                     b.extraSpan[m][i] = x ? TextSpan{(uint64_t)(x + 1 - tm), (uint32_t)(tm + ie - x - 1)} : TextSpan{0, 0};
                 }
@@ -516,7 +592,7 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
                     for (uint64_t k = 0; k < len[m]; k++) { int v = int(q[k]) + P.outQSconversionAdd; q[k] = (char)(v < 33 ? 33 : v > 126 ? 126 : v); }
                 }
                 if (P.clipYes) {                        // ClipMate::clip (ClipMate_clip.cpp:5-78), 5' then 3' (readLoad.cpp:57-58); len[] becomes the clipped length
-                    const char *sq = b.text[m].data() + ss;
+                    const char *sq = b.txt(m) + ss;
                     uint64_t L = len[m], cN[2] = {0, 0};
                     for (int ip = 0; ip < 2; ip++) {
                         const RunParams::ClipEnd &c = P.clip[m][ip];
@@ -594,11 +670,11 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
     inRanges([&](uint64_t lo, uint64_t hi, int) {
         for (uint64_t i = lo; i < hi; i++) {
             uint8_t *r = b.bases.data() + b.readOffset[i];
-            const char *s0 = b.text[0].data() + b.seqSpan[0][i].off + b.clipped(0, 0, (uint32_t)i);
+            const char *s0 = b.txt(0) + b.seqSpan[0][i].off + b.clipped(0, 0, (uint32_t)i);
             uint64_t len0 = b.mate1Length[i];
             if (avx2) ntForwardAvx2(s0, r, len0); else for (uint64_t k = 0; k < len0; k++) r[k] = NT.fwd[(uint8_t)s0[k]];
             if (nMates == 2) {
-                const char *s1 = b.text[1].data() + b.seqSpan[1][i].off + b.clipped(1, 0, (uint32_t)i);
+                const char *s1 = b.txt(1) + b.seqSpan[1][i].off + b.clipped(1, 0, (uint32_t)i);
                 uint64_t len1 = Lread[i] - len0 - 1;
                 r[len0] = STARAMD_SPACER_BASE;
                 if (avx2) ntRevCompAvx2(s1, r + len0 + 1, len1); else for (uint64_t k = 0; k < len1; k++) r[len0 + 1 + k] = NT.rc[(uint8_t)s1[len1 - 1 - k]];
@@ -611,7 +687,7 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
         // (readLoad.cpp:28-29); reproduced for the one-thread order of the reference
         for (uint64_t i = 0; i < n; i++) for (int m = 0; m < nMates; m++) {
             TextSpan &x = b.extraSpan[m][i];
-            if (x.len > 0) lastExtra[m].assign(b.text[m].data() + x.off, x.len);
+            if (x.len > 0) lastExtra[m].assign(b.txt(m) + x.off, x.len);
             else if (!lastExtra[m].empty()) { x = TextSpan{(uint64_t)b.text[m].size(), (uint32_t)lastExtra[m].size()}; b.text[m].insert(b.text[m].end(), lastExtra[m].begin(), lastExtra[m].end()); }
         }
     }

@@ -149,6 +149,17 @@ def test_sam_into_a_named_pipe(tmp_path, built):
     assert body == refstar.sam_body_sorted(ref + "Aligned.out.sam")
 
 
+@pytest.mark.parametrize("name,more,env", [("pe101", [], {"STARAMD_NO_INPUT_MMAP": "1"}), ("pe101", [], {"STARAMD_READ_SLICE_MIN": "4096", "STARAMD_READ_SLICES": "5"}),
+                                           ("pe150_indel", ["--outFilterType", "BySJout", "--outSAMunmapped", "Within"], {"STARAMD_READ_SLICE_MIN": "4096"}),
+                                           ("se50", ["--twopassMode", "Basic", "--outReadsUnmapped", "Fastx"], {"STARAMD_READ_SLICE_MIN": "2048", "STARAMD_READ_SLICES": "3"}),
+                                           ("pe101", ["--outSAMreadID", "Number"], {}), ("pe101", ["--outQSconversionAdd", "-2"], {})])
+def test_reader_over_a_mapping_of_the_input_files(name, more, env, tmp_path, built):
+    """a regular input file is mapped and a batch is a range of the mapping (reads.cpp fillMapped), line ends looked for in slices on threads (STARAMD_READ_SLICE_MIN lowers
+    the size from which a block is sliced); STARAMD_NO_INPUT_MMAP=1 and the options that rewrite the text of a batch (--outSAMreadID Number, --outQSconversionAdd) take
+    the copying reader; a held-reads stage (BySJout) and a second pass follow a mapped first one.  Same outputs as the reference either way"""
+    run_cli_case(CLI, name, more, 170, tmp_path, env=env)
+
+
 @pytest.mark.parametrize("mode,more", [("2", []), ("2", ["--outSAMtype", "BAM", "Unsorted"]), ("0", []), ("2", ["--twopassMode", "Basic"])])
 def test_writer_through_a_mapping_of_the_output_file(mode, more, tmp_path, built):
     """the SAM / unsorted-BAM writer grows the file and copies the batch's text into a mapping of the new part (STARAMD_WRITER_MMAP=2: whatever the size of a batch;
