@@ -19,3 +19,7 @@ run one_context_b X=1
 run two_contexts_turns_b STARAMD_CONTEXTS_PER_GPU=2 STARAMD_KERNEL_TURNS=1
 run two_contexts_free STARAMD_CONTEXTS_PER_GPU=2
 run one_context_fifo_slots STARAMD_SLOTS_FIFO=1
+# the SAM writer is busy 53 ms per batch with 4 copy threads (round 4): with kernels below that it is the next stage to wait for
+run writer_8_threads STARAMD_WRITER_THREADS=8
+run writer_12_threads STARAMD_WRITER_THREADS=12
+run copied_input STARAMD_NO_INPUT_MMAP=1
