@@ -259,7 +259,8 @@ struct Runner {
                     void *m = mmap(nullptr, (size_t)mapLen, PROT_READ | PROT_WRITE, MAP_SHARED, samFd, (off_t)mapOff);
                     if (m != MAP_FAILED) map = (char *)m;
                 }
-                const uint32_t W = std::min<uint32_t>(map ? wantW : 2u, o.used);
+                static const uint32_t pwriteW = getenv("STARAMD_WRITER_PWRITE_THREADS") ? (uint32_t)std::max(1, atoi(getenv("STARAMD_WRITER_PWRITE_THREADS"))) : 2u;      // (positional writes: 1 = one stream, no contention for the inode lock)
+                const uint32_t W = std::min<uint32_t>(map ? wantW : pwriteW, o.used);
                 std::atomic<uint32_t> next(0); std::atomic<bool> bad(false);
                 auto put = [&] {
                     for (;;) {

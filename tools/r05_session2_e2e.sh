@@ -22,4 +22,5 @@ run one_context_fifo_slots STARAMD_SLOTS_FIFO=1
 # the SAM writer is busy 53 ms per batch with 4 copy threads (round 4): with kernels below that it is the next stage to wait for
 run writer_8_threads STARAMD_WRITER_THREADS=8
 run writer_12_threads STARAMD_WRITER_THREADS=12
+run writer_one_pwrite_stream STARAMD_WRITER_MMAP=0 STARAMD_WRITER_PWRITE_THREADS=1      # (development box: 4.3 M pairs/s and 1.33 us of a core per pair against 3.8 and 1.5 for the mapped writer)
 run copied_input STARAMD_NO_INPUT_MMAP=1
