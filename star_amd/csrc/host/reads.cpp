@@ -529,7 +529,7 @@ bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     // records of mate 1 decide the batch; an empty ID line ends the input
     uint64_t n = nLines[0] / 4;
     bool partial = nLines[0] % 4 != 0;
-    for (uint64_t i = 0; i < n; i++) if (b.lineEnd[0][4 * i] == b.lineStart[0][4 * i]) { n = i; partial = false; eof[0] = true; carry[0].clear(); break; }
+    for (uint64_t i = 0; i < n; i++) if (b.lineEnd[0][4 * i] == b.lineStart[0][4 * i]) { n = i; partial = false; eof[0] = true; carry[0].clear(); mapPos[0] = curMap[0].n; break; }     // (mapped input: nothing behind the empty line is read either)
     if (partial && b.lineEnd[0][4 * n] == b.lineStart[0][4 * n]) partial = false;
     if (partial) { err = "EXITING because of FATAL ERROR in reads input: truncated FASTQ record"; return false; }
     if (n == 0) return false;

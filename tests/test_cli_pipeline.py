@@ -160,6 +160,44 @@ def test_reader_over_a_mapping_of_the_input_files(name, more, env, tmp_path, bui
     run_cli_case(CLI, name, more, 170, tmp_path, env=env)
 
 
+def _rewrite(info, d, fn, tag):
+    out = []
+    for m, f in enumerate(info["fastq"]):
+        text = open(f, "rb").read()
+        g = os.path.join(d, "%s_%d.fq" % (tag, m + 1))
+        r = fn(text, m)
+        if isinstance(r, list):
+            names = []
+            for k, part in enumerate(r):
+                gk = os.path.join(d, "%s_%d_%d.fq" % (tag, m + 1, k)); open(gk, "wb").write(part); names.append(gk)
+            out.append(",".join(names))
+        else:
+            open(g, "wb").write(r); out.append(g)
+    return out
+
+
+def _records(text):
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    return [b"\n".join(lines[i:i + 4]) + b"\n" for i in range(0, len(lines), 4)]
+
+
+INPUT_SHAPES = {
+    "empty_line_ends_the_input": lambda t, m: b"".join(_records(t)[:230]) + b"\n" + b"".join(_records(t)[230:]),       # what follows an empty ID line is not read (both mates cut alike)
+    "two_files_per_mate": lambda t, m: [b"".join(_records(t)[:333]), b"".join(_records(t)[333:])],
+}
+
+
+@pytest.mark.parametrize("shape", sorted(INPUT_SHAPES))
+@pytest.mark.parametrize("mapped", [True, False])
+def test_reader_on_input_shapes(shape, mapped, tmp_path, built):
+    """file shapes the reader meets and the reference accepts (it exits on \\r\\n line ends and on a last line without a newline), with the mapped and with the copying reader;
+    batches of 100 reads, so that the odd place falls inside a batch"""
+    run_cli_case(CLI, "pe101", ["--outSAMunmapped", "Within"], 100, tmp_path, fastq_hook=lambda info, d: _rewrite(info, d, INPUT_SHAPES[shape], shape),
+                 env=None if mapped else {"STARAMD_NO_INPUT_MMAP": "1"})
+
+
 @pytest.mark.parametrize("mode,more", [("2", []), ("2", ["--outSAMtype", "BAM", "Unsorted"]), ("0", []), ("2", ["--twopassMode", "Basic"])])
 def test_writer_through_a_mapping_of_the_output_file(mode, more, tmp_path, built):
     """the SAM / unsorted-BAM writer grows the file and copies the batch's text into a mapping of the new part (STARAMD_WRITER_MMAP=2: whatever the size of a batch;
