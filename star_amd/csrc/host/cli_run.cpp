@@ -47,9 +47,9 @@ struct Queue {                                   // hand-off between two pipelin
 };
 struct Tokens {                                  // counting semaphore over a small set of buffer indices
     std::mutex m; std::condition_variable cv; std::deque<int> free;
-    // the slot that was given back LAST is handed out first: the pipeline then lives in as many slots as it has batches in flight (4 - 5 of the 8), whose ~300 MB
-    // each of text, line tables and page-locked arrays are mapped and warm; going round all slots in turn touched every buffer of every slot (first use = page
-    // faults and hipHostMalloc inside the reader, on 8 of the first 8 batches) and kept none of them in any cache
+    // the slot that was given back LAST is handed out first: a batch then lands in buffers (line tables, page-locked numeric arrays, result arrays) that were in use a
+    // moment ago, and a slot is used for the first time (page faults and hipHostMalloc inside the reader) only when the pipeline really is that deep.  Round-robin order
+    // went round all slots whatever the depth: 4.94 / 5.56 M pairs/s against 6.84 / 6.19 with the host stages alone on a GPU box (profiles/r04_host_stages_on_the_gpu_box.txt)
     int take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !free.empty(); }); static const bool fifo = getenv("STARAMD_SLOTS_FIFO") != nullptr; int v = fifo ? free.front() : free.back(); if (fifo) free.pop_front(); else free.pop_back(); return v; }
     void give(int v) { { std::lock_guard<std::mutex> l(m); free.push_back(v); } cv.notify_all(); }
 };
