@@ -100,6 +100,7 @@ enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS 
        CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
        CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
        CUR_ST_HEAVY = 23, CUR_ST_TICKETH = 24,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
+       CUR_ST_HEAVY2 = 27, CUR_ST_TICKETH2 = 28,                         // pass 0 in three launches (lane kernel, lean cooperative, full-size): what the lean launch defers
        CUR_N = 32 };
 // CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
 enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };
@@ -122,6 +123,7 @@ struct DevBatch {
     u32 *ovfWin2;      // reads deferred by the middle pass (larger LDS table) to the pass with the table in global memory
     u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
     u32 *heavyList;                    // pass-0 items whose windows hold more seeds than the lean launch has LDS for
+    u32 *heavyList2;                   // ... and, when the lane kernel fills heavyList, what the lean launch behind it hands on to the full-size one
     u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win
     u32 *candTops;                     // bytes of its region a wavefront of the first pass-0 launch used (the second one goes on behind them)
     u32 *cursors;      // CUR_*
@@ -187,6 +189,15 @@ __device__ __forceinline__ u64 bcast64(u64 v, u32 srcLane) {
 __device__ __forceinline__ u32 first32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ i32 firstI(i32 v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 first64(u64 v) { return ((u64)first32((u32)(v >> 32)) << 32) | first32((u32)v); }
+// The index of a wavefront inside its block, threadIdx.x >> 6, is the same for all 64 lanes -- which nothing tells the compiler.  Left as it is, the wavefront's LDS slice,
+// every pointer into it, every value loaded through them and every branch on those values count as lane-dependent: k_stitch_win then keeps ~140 wave-uniform values in
+// vector registers (168 VGPRs + 82 spilled instead of 106 and none) and compiles 325 wave-uniform branches to exec-mask sequences.  -DWAVE_INDEX_PLAIN restores that
+// (the kernels of round 4), for A/B runs.
+#ifdef WAVE_INDEX_PLAIN
+#define WAVE_INDEX(x) (x)
+#else
+#define WAVE_INDEX(x) first32(x)
+#endif
 // number of set bits of a 64-lane ballot mask in the lanes strictly below / up to and including this lane
 __device__ __forceinline__ u32 cntBelow(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 __device__ __forceinline__ u32 cntUpTo(u64 m, u32 lane) { return cntBelow(m) + (u32)((m >> lane) & 1ull); }

@@ -100,7 +100,7 @@ __device__ static void finalizeLane(StitchCtx &c, Hdr h, staramd_exon *ex, u32 c
         if (which == 0) {
             if (h.rStart > 0) {
                 const u32 imate = ex[0].iFrag;
-                if (extendAlign(c, h.rStart - 1, h.gStart - 1, -1, -1, h.rStart, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
+                if (growOnLane(c, h.rStart - 1, h.gStart - 1, -1, -1, h.rStart, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
                                 P.alignEndsTypeExt[imate][(int)(Str != imate)] != 0, e)) {
                     h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
                     h.rStart -= e.extendL; h.gStart -= e.extendL;
@@ -110,7 +110,7 @@ __device__ static void finalizeLane(StitchCtx &c, Hdr h, staramd_exon *ex, u32 c
         } else {
             if (tR2 < Lread) {
                 const u32 imate = ex[ne - 1].iFrag;
-                if (extendAlign(c, tR2 + 1, tG2 + 1, +1, +1, Lread - tR2 - 1, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
+                if (growOnLane(c, tR2 + 1, tG2 + 1, +1, +1, Lread - tR2 - 1, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
                                 P.alignEndsTypeExt[imate][(int)(imate == Str)] != 0, e)) {
                     h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
                     tR2 += e.extendL; tG2 += e.extendL;
@@ -160,7 +160,7 @@ __device__ static void finalizeLane(StitchCtx &c, Hdr h, staramd_exon *ex, u32 c
         for (u32 k = 0; k + 1 < ne; k++)
             if (ex[k].canonSJ >= 0 && ex[k].sjAnnot == 0) {
                 const u64 jS = ex[k].G + ex[k].L, jE = ex[k + 1].G - 1;
-                if (binarySearch2(jS, jE, X.sjNovelStart, X.sjNovelEnd, (int)X.sjNovelN) < 0) return;
+                if (junctionOnLane(jS, jE, X.sjNovelStart, X.sjNovelEnd, (int)X.sjNovelN) < 0) return;
             }
     }
     if (ex[0].iFrag != ex[ne - 1].iFrag) {             // both mates (:179-219)
@@ -274,7 +274,7 @@ __device__ static bool stitchWindowLane(StitchCtx &c, const DWin &win, const DWA
         if (h.nExons > 0) {
             eA = EX[h.nExons - 1];
             const staramd_exon eAold = eA;
-            dScore = stitchAlignToTranscript(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G);
+            dScore = joinOnLane(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G);
             if (dScore > -1000000) {
                 stack[sp].h = h; stack[sp].iA = iA; stack[sp].iLast = iLast | (fragLast << 8); stack[sp].eA = eAold;
                 EX[h.nExons - 1] = eA;

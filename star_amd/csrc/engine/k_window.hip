@@ -280,7 +280,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
     const bool ownMapEnable = (useMid & 2u) != 0; useMid &= 1u;      // (bit 1 of the argument: owner map on, STARAMD_WIN_OWNER_MAP)
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
-    u32 lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
+    u32 lane = threadIdx.x & 63u, waveInBlock = WAVE_INDEX(threadIdx.x >> 6);
     u32 wavesPerBlock = blockDim.x >> 6;
     u32 wave = blockIdx.x * wavesPerBlock + waveInBlock;
     WS<BIG> s;

@@ -1,0 +1,29 @@
+"""Static figures of the two wave-cooperative kernels as the compiler reports them (tools/isa_stats.sh; hipcc cross-compiles without a GPU).
+The register allocator has two regimes for k_stitch_win -- wave-uniform state in scalar registers (106 VGPRs, no scratch) or in vector registers (168 + spills) -- and
+small edits of the kernel flip it back into the second (tools/R05_PLAN.md).  This test is what notices."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc missing")
+
+
+def _figures(src, kernel, *flags):
+    out = subprocess.run([os.path.join(ROOT, "tools", "isa_stats.sh"), src] + list(flags), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900).stdout
+    line = [l for l in out.splitlines() if l.split() and l.split()[0] == kernel]
+    assert line, out[-2000:]
+    g = lambda k: int(re.search(k + r"\s+(\d+)", line[0]).group(1))
+    return {"vgprs": g("VGPRs"), "vgpr_spills": g("VGPR spills"), "scratch": int(re.search(r"scratch\s+(\d+) B", line[0]).group(1)), "saveexec": g("saveexec")}
+
+
+def test_stitch_kernel_keeps_its_uniform_state_in_scalar_registers():
+    f = _figures("k_stitch", "k_stitch_win")
+    assert f["vgprs"] <= 112 and f["vgpr_spills"] == 0 and f["scratch"] == 0 and f["saveexec"] <= 160, f
+
+
+def test_window_kernel_does_not_spill_vector_registers():
+    f = _figures("k_window", "k_windows")
+    assert f["vgprs"] <= 80 and f["vgpr_spills"] == 0 and f["saveexec"] <= 200, f
