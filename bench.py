@@ -474,8 +474,7 @@ def main():
     threads = args.host_threads or max(4, min(64, ncpu_eff // world))
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", outp, "--runThreadN", str(threads),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(args.warmup * args.reads), "--readMapNumber", str(n_total)]
-    # (the front end runs STARAMD_CONTEXTS_PER_GPU engine contexts per GPU, default 2: two mapper threads over ONE resident index, so that the copies
-    # and the low-occupancy tails of one batch overlap with the kernels of the next; rep.nContexts says how many ran)
+    # (the front end runs STARAMD_CONTEXTS_PER_GPU engine contexts per GPU, default 1; rep.nContexts says how many ran)
     if not selftest:
         argv += ["--gpuDevice", str(local_rank)]
     if world > 1:          # the ranks load the 31 GB index into host memory one after the other (each keeps ~5 GB of it after the upload)
@@ -536,6 +535,8 @@ def main():
                           "parse_Mreads_s": n / float(rep.parseBusy) / 1e6 if rep.parseBusy > 0 else None,
                           "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                           "finish_s": float(rep.finishSeconds), "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds),
+                          "cpu_us_per_pair_by_stage": dict(zip(["input_line_table", "text_to_numeric", "mapper_threads", "postmap_format", "file_writes", "other"], [round(float(x) * 1e6 / n, 4) for x in list(rep.cpuSeconds)[:6]])),
+                          "fast_path_batches": dict(zip(["output_through_file_mapping", "input_from_file_mapping", "upload_prefetched"], [int(x) for x in list(rep.fastPaths)[:3]])),
                           "postmap_whole_run_s": dict(zip(["wait_for_writer", "format_on_threads", "serial_tail", "writer_thread_busy"], [float(x) for x in rep.emitParts]))}}
     if dist is not None:
         dist.destroy_process_group()

@@ -17,6 +17,13 @@
 extern "C" {
 #endif
 int staramd_prefetch_batch(staramd_ctx *ctx, const staramd_batch *next);
+/* A prefetched batch is recognised by its `bases` / `readOffset` pointers and nReads alone, so: between staramd_prefetch_batch(next) and the staramd_map_batch
+ * call for `next` the caller must not refill those arrays with another batch.  A caller that gives a prefetched batch up (an error path, a phase that ends
+ * early) calls staramd_prefetch_cancel before it reuses the arrays; staramd_map_batch does the same by itself whenever it returns an error, and
+ * staramd_map_resident refuses to run when a prefetch has overwritten the resident batch. */
+int staramd_prefetch_cancel(staramd_ctx *ctx);
+/* staramd_map_batch calls of this context that found their upload done ahead (tests and the front end's report: a prefetch path that never runs is not a fast path) */
+uint64_t staramd_prefetch_hits(staramd_ctx *ctx);
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ typedef struct staramd_cli_report {
     double   convertBusy;          /* seconds the second half of the reader (text -> numeric batch, its own thread) was busy, timed region; parseBusy is the first half (input + line table) */
     double   emitParts[4];         /* what emitBusy is made of, whole run (seconds): [0] waiting for a free text-buffer set (= for the writer), [1] formatting on the threads, [2] serial tail
                                       of a batch (junction merge, hand-over); [3] the writer thread's own busy time (write calls into the output file) */
+    uint64_t fastPaths[4];         /* batches that took a path with a silent fallback behind it, whole run: [0] SAM / BAM text written through a mapping of the output file (fallback: positional
+                                      writes), [1] read in place from mappings of the input files (fallback: copied out of the page cache), [2] uploaded ahead of their staramd_map_batch call
+                                      (staramd_prefetch_batch; fallback: uploaded by the call), [3] reserved */
+    double   cpuSeconds[8];        /* thread-CPU seconds per stage in the timed region (sah_cpu_seconds): input + line table, text -> numeric, mapper threads, post-map + formatting, file writes, other */
 } staramd_cli_report;
 
 /* Runs the whole job; returns the process exit code (0 ok).  hooks / report may be NULL. */

@@ -50,6 +50,12 @@ int   sah_threads(void *h);                                             /* --run
 double sah_genome_load_seconds(void *h);
 /* seconds of the post-map stage so far: out[0] waiting for a free text-buffer set, [1] formatting on threads, [2] serial tail of the batches, [3] the writer thread busy */
 void  sah_emit_seconds(void *h, double out[4]);
+/* batches so far that were [0] written through a mapping of the output file, [1] read in place from mappings of the input files */
+void  sah_fast_path_counts(void *h, uint64_t out[2]);
+/* thread-CPU seconds per pipeline stage, process-wide, since the last reset: [0] input + line table, [1] text -> numeric batch, [2] mapper threads (the host side of
+ * staramd_map_batch), [3] post-map + formatting, [4] output file writes, [5] everything else that was counted.  sah_cpu_add: the stage threads of the front end add their own. */
+void  sah_cpu_add(int stage, uint64_t ns);
+void  sah_cpu_seconds(double out[8], int reset);
 
 /* one batch at a time */
 int   sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out);   /* number of reads, 0 at the end of the input of this phase */

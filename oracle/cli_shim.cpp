@@ -42,6 +42,8 @@ int staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const stara
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
 int staramd_insert_junctions_fits(staramd_ctx *, uint64_t, uint32_t) { return 0; }
 int staramd_prefetch_batch(staramd_ctx *, const staramd_batch *) { return 0; }
+int staramd_prefetch_cancel(staramd_ctx *) { return 0; }
+uint64_t staramd_prefetch_hits(staramd_ctx *) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 // index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp
 int staramd_index_build(int, const uint8_t *G, const staramd_index_params *p, uint8_t *SA, uint64_t saCap, uint8_t *SAi, uint64_t saiCap, staramd_index_result *res) {

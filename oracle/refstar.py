@@ -10,18 +10,17 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_BIN = os.path.join(HERE, "_ref", "STAR")
-REF_DUMP = os.path.join(HERE, "_ref", "star_dump")
 
 
 def have_ref():
     return os.path.isfile(REF_BIN) and os.access(REF_BIN, os.X_OK)
 
 
-def build_ref(jobs=8, dump=True):
-    """Compile oracle/_ref/STAR (and the stage dumper) if /root/reference is present."""
+def build_ref(jobs=8):
+    """Compile oracle/_ref/STAR if /root/reference is present."""
     if not os.path.isdir("/root/reference/source"):
         return have_ref()
-    targets = ["all"] + (["dump"] if dump else [])
+    targets = ["all"]
     subprocess.check_call(["make", "-f", os.path.join(HERE, "Makefile.ref"), "-j%d" % jobs] + targets,
                           cwd=os.path.dirname(HERE), stdout=subprocess.DEVNULL)
     return have_ref()

@@ -132,6 +132,8 @@ const char *staramd_last_error(void) { return lastError.c_str(); }
 int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
 int staramd_insert_junctions_fits(staramd_ctx *, uint64_t, uint32_t) { return 0; }
 int staramd_prefetch_batch(staramd_ctx *, const staramd_batch *) { return 0; }
+int staramd_prefetch_cancel(staramd_ctx *) { return 0; }
+uint64_t staramd_prefetch_hits(staramd_ctx *) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 int staramd_index_build(int, const uint8_t *, const staramd_index_params *, uint8_t *, uint64_t, uint8_t *, uint64_t, staramd_index_result *) { lastError = "replay shim: no index build"; return STARAMD_ERR_DEVICE; }
 int staramd_sjdb_insert(int, const staramd_sjdb_args *, staramd_sjdb_result *) { lastError = "replay shim: no junction insertion"; return STARAMD_ERR_DEVICE; }

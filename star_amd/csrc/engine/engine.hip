@@ -62,6 +62,7 @@ struct staramd_ctx {
     // in[k].pending: the set holds an uploaded batch that staramd_map_batch has not consumed yet; cur: the set the last mapped batch used (dBases ... above point into it)
     struct InSet { u8 *bases = nullptr; u64 *readOffset = nullptr; u16 *mate1 = nullptr, *mm = nullptr; hipEvent_t up = nullptr;
                    const uint8_t *hBases = nullptr; const uint64_t *hReadOffset = nullptr; u32 nReads = 0; bool pending = false; } in[2];
+    u64 nPrefetchHits = 0;      // staramd_map_batch calls that found their upload done ahead (staramd_prefetch_hits)
     int cur = 0; hipStream_t copyStream = nullptr;
     u32 *dPacked = nullptr; u32 packWordsCap = 0;
     int nCU = 256;
@@ -707,8 +708,22 @@ static int runDevice(staramd_ctx *c, staramd_results *r) {
     return STARAMD_OK;
 }
 
+// an upload that was started for a batch which will not be mapped: waited for and forgotten (the sets are free again)
+static void dropPrefetched(staramd_ctx *c) {
+    if (!c->copyStream || (!c->in[0].pending && !c->in[1].pending)) return;
+    (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->copyStream);
+    c->in[0].pending = c->in[1].pending = false;
+}
+
+static int mapBatchImpl(staramd_ctx *c, const staramd_batch *b, staramd_results *r);
 extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd_results *r) {
     if (!c || !b || !r || !r->reads) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    const int rc = mapBatchImpl(c, b, r);
+    if (rc != STARAMD_OK) dropPrefetched(c);        // after an error nothing uploaded ahead is trusted: the caller's next batch is uploaded by its own call
+    return rc;
+}
+
+static int mapBatchImpl(staramd_ctx *c, const staramd_batch *b, staramd_results *r) {
     if (b->nReads == 0) { r->trCount = r->exCount = 0; return STARAMD_OK; }
     // a batch may be a slice of a larger one (readOffset[0] > 0: the pieces of a WASP re-mapping batch): sized and uploaded from its own first base
     const u64 base0 = b->readOffset[0], nBases = b->readOffset[b->nReads] - base0;
@@ -730,6 +745,7 @@ extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd
         for (int k = 0; k < 2; k++) if (c->in[k].pending && c->in[k].hBases == b->bases && c->in[k].hReadOffset == b->readOffset && c->in[k].nReads == n && base0 == 0) use = k;
         if (use >= 0) {             // this batch was shown to staramd_prefetch_batch: its upload is in flight (or done) on the copy stream
             HIPCHK(hipStreamWaitEvent(s, c->in[use].up, 0));
+            c->nPrefetchHits++;
         } else {                    // not prefetched: into the set that holds nothing pending (both pending: the older one is given up)
             use = !c->in[c->cur].pending ? c->cur : (c->copyStream && !c->in[1 - c->cur].pending ? 1 - c->cur : c->cur);
             staramd_ctx::InSet &I = c->in[use];
@@ -769,9 +785,18 @@ extern "C" int staramd_prefetch_batch(staramd_ctx *c, const staramd_batch *b) {
     return STARAMD_OK;
 }
 
+extern "C" int staramd_prefetch_cancel(staramd_ctx *c) {
+    if (!c) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    dropPrefetched(c);
+    return STARAMD_OK;
+}
+
+extern "C" uint64_t staramd_prefetch_hits(staramd_ctx *c) { return c ? c->nPrefetchHits : 0; }
+
 extern "C" int staramd_map_resident(staramd_ctx *c, staramd_results *r) {
     if (!c || !r || !r->reads) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
     if (c->residentReads == 0) { g_err = "no batch resident in HBM: call staramd_map_batch first"; return STARAMD_ERR_ARG; }
+    if (c->in[c->cur].pending) { g_err = "the resident batch was overwritten by staramd_prefetch_batch"; return STARAMD_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     c->B.nReads = c->residentReads;
     return runDevice(c, r);

@@ -16,10 +16,13 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <map>
+#include <array>
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -111,7 +114,29 @@ CliFlags splitFlags(int argc, char **argv) {
 }
 } // namespace
 
-extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, staramd_cli_report *report) {
+extern "C" namespace {
+// STARAMD_PIPELINE_LOG=<file>: one line per batch and stage (stage, batch number, start and end in ms since the run's first batch) -- where a batch waited and for what
+struct PipeLog {
+    std::mutex m; std::vector<std::array<double, 4> > ev; const char *path = getenv("STARAMD_PIPELINE_LOG"); std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double now() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    void add(int stage, uint64_t seq, double a, double b) { if (!path) return; std::lock_guard<std::mutex> l(m); ev.push_back({(double)stage, (double)seq, a, b}); }
+    void dump() {
+        if (!path) return;
+        FILE *f = fopen(path, "w"); if (!f) return;
+        static const char *names[] = {"fill", "convert", "map", "emit"};
+        std::sort(ev.begin(), ev.end(), [](const std::array<double, 4> &x, const std::array<double, 4> &y) { return x[2] < y[2]; });
+        for (auto &e : ev) fprintf(f, "%-8s %4.0f %10.2f %10.2f %8.2f\n", names[(int)e[0]], e[1], e[2], e[3], e[3] - e[2]);
+        fclose(f);
+    }
+};
+struct StageCpu {           // thread CPU of one batch's work on a stage thread (sah_cpu_seconds; the helper threads of a stage count their own)
+    int stage; timespec t0;
+    explicit StageCpu(int st) : stage(st) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0); }
+    ~StageCpu() { timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1); sah_cpu_add(stage, (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec))); }
+};
+}
+
+int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, staramd_cli_report *report) {
     staramd_cli_report rep; memset(&rep, 0, sizeof(rep));
     auto publish = [&]() { if (report) *report = rep; };
     for (int i = 1; i < argc; i++) if (std::string(argv[i]) == "--version") { printf("2.7.11b\n"); return 0; }      // the version whose behaviour is reproduced (Parameters.cpp:340-343)
@@ -212,6 +237,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     std::string failure; std::mutex failM; std::atomic<bool> failed(false);
     auto fail = [&](const std::string &s) { std::lock_guard<std::mutex> l(failM); if (failure.empty()) failure = s; failed = true; };
     // ---- timing state
+    PipeLog plog;
     std::mutex statM;
     uint64_t nReads = 0; double msDeviceAll = 0;
     bool timedOn = flags.warmupReads == 0; bool warmupPending = flags.warmupReads > 0;
@@ -237,11 +263,12 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                     if (hooks && hooks->warmup_done) hooks->warmup_done(hooks->user);
                     std::lock_guard<std::mutex> l(statM);
                     warmupPending = false; timedOn = true; tTimed = Clock::now();
+                    { double z[8]; sah_cpu_seconds(z, 1); }
                 }
                 Msg m; m.slot = slots.take();
                 if (failed.load()) { slots.give(m.slot); break; }
                 auto tp = Clock::now();
-                m.n = sah_fill_slot(h, m.slot, batchReads);
+                { StageCpu sc(0); const double a = plog.now(); m.n = sah_fill_slot(h, m.slot, batchReads); plog.add(0, seq, a, plog.now()); }
                 if (m.n < 0) { fail(sah_error(h)); slots.give(m.slot); break; }
                 if (m.n == 0) { slots.give(m.slot); break; }
                 { std::lock_guard<std::mutex> l(statM); if (timedOn) rep.parseBusy += since(tp); }
@@ -255,7 +282,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
             Msg m;
             while (filled.pop(m)) {
                 auto tp = Clock::now();
-                if (!failed.load() && sah_convert_slot(h, m.slot, &m.b) < 0) fail(sah_error(h));
+                { StageCpu sc(1); const double a = plog.now(); if (!failed.load() && sah_convert_slot(h, m.slot, &m.b) < 0) fail(sah_error(h)); plog.add(1, m.seq, a, plog.now()); }
                 if (failed.load()) m.n = 0;                                      // still goes down the pipeline so that the slot and the sequence number are released
                 { std::lock_guard<std::mutex> l(statM); if (timedOn && m.n > 0) rep.convertBusy += since(tp); }
                 parsed.push(m);
@@ -275,8 +302,10 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                 }
                 next++;
                 auto te = Clock::now();
+                StageCpu sc(3); const double ea = plog.now();
                 if (!failed.load() && m.n > 0 && (m.merged ? sah_emit_slot_merged(h, m.slot, &rb[m.slot].res, &rbMerged[m.slot].res) : sah_emit_slot(h, m.slot, &rb[m.slot].res))) fail(sah_error(h));
                 { std::lock_guard<std::mutex> l(statM); if (timedOn && m.n > 0) { rep.emitBusy += since(te); rep.timedReads += (uint64_t)m.n; rep.batches++; } if (m.n > 0) nReads += (uint64_t)m.n; }
+                plog.add(3, m.seq, ea, plog.now());
                 slots.give(m.slot);
                 { std::lock_guard<std::mutex> l(drainM); seqEmitted = next; }
                 drainCv.notify_all();
@@ -287,6 +316,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
             Msg m;
             while (parsed.pop(m)) {
                 int rc = 0;
+                StageCpu sc(2); const double ma = plog.now();
                 if (!failed.load()) {
                     auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[40] = {0};
                     auto mapInto = [&](const staramd_batch &bt, ResBuf &r, bool main) {
@@ -346,6 +376,7 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
                     if (timedOn && !rc) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += msDev; for (int i = 0; i < 8; i++) rep.stageMs[i] += stage[i]; for (int i = 0; i < 40; i++) rep.counters[i] += cnt[i]; }
                 }
                 if (failed.load()) m.n = 0;                              // still goes through the writer so that the slot and the sequence number are released
+                plog.add(2, m.seq, ma, plog.now());
                 { std::lock_guard<std::mutex> l(doneM); done[m.seq] = m; }
                 doneCv.notify_all();
             }
@@ -391,6 +422,10 @@ extern "C" int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *
     else if (hooks && hooks->exchange && hooks->exchange(hooks->user, h, 1)) { fprintf(stderr, "\ncross-rank exchange failed\n"); exitCode = 104; }
     else { const auto tf = Clock::now(); if (sah_finish(h)) { fprintf(stderr, "\n%s\n", sah_error(h)); exitCode = 104; } rep.finishSeconds = since(tf); }
     sah_emit_seconds(h, rep.emitParts);
+    plog.dump();
+    sah_fast_path_counts(h, rep.fastPaths);
+    sah_cpu_seconds(rep.cpuSeconds, 0);
+    for (int d = 0; d < nDev; d++) if (ctx[d]) rep.fastPaths[2] += staramd_prefetch_hits(ctx[d]);
     double sec = since(t0);
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",

@@ -5,6 +5,7 @@
 // that must reproduce the reference byte for byte; none of it is accelerated.  Each function
 // cites the reference file:line whose behaviour it reproduces.
 #pragma once
+#include <ctime>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -17,6 +18,16 @@
 #include "../../../include/star_amd_index.h"
 
 namespace staramd {
+// CPU seconds per pipeline stage (thread CPU clocks: what a stage COSTS, beside the wall-clock busy times that say how long it TAKES): every thread of the front end
+// carries exactly one CpuScope for its whole life -- the five stage threads of cli_run.cpp and each helper thread a stage starts for a batch (sah_cpu_seconds)
+enum { CPU_FILL = 0, CPU_CONVERT, CPU_MAP, CPU_EMIT, CPU_WRITE, CPU_OTHER, CPU_NSTAGE = 8 };
+void cpuAdd(int stage, uint64_t ns);
+uint64_t cpuTake(int stage, bool reset);
+struct CpuScope {
+    int stage; timespec t0;
+    explicit CpuScope(int st) : stage(st) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0); }
+    ~CpuScope() { timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1); cpuAdd(stage, (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec))); }
+};
 
 // ---- genomeDir on disk -> host arrays (Genome::genomeLoad, source/Genome_genomeLoad.cpp:18-467) ----
 struct GenomeIndex {
@@ -246,6 +257,7 @@ public:
     bool fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads, std::string &err);
     bool convertBatch(ReadBatch &b, const RunParams &P, std::string &err);
     uint64_t readsSoFar = 0;
+    std::atomic<uint64_t> mappedBatches{0};          // batches handed out as ranges of the input files' mappings (reads.cpp fillMapped)
 private:
     FILE *f[2] = {nullptr, nullptr};
     unsigned readSlices = 4;                         // slices a block of a regular input file is read in (threads per mate): --runThreadN / 2 in [4, 16], STARAMD_READ_SLICES

@@ -22,6 +22,10 @@
 #include <unistd.h>
 
 namespace staramd {
+static std::atomic<uint64_t> g_cpuNs[CPU_NSTAGE];
+void cpuAdd(int stage, uint64_t ns) { if (stage >= 0 && stage < CPU_NSTAGE) g_cpuNs[stage] += ns; }
+uint64_t cpuTake(int stage, bool reset) { if (stage < 0 || stage >= CPU_NSTAGE) return 0; return reset ? g_cpuNs[stage].exchange(0) : g_cpuNs[stage].load(); }
+
 
 void *(*g_batchAllocFn)(uint64_t bytes) = nullptr;
 void (*g_batchFreeFn)(void *p) = nullptr;
@@ -292,7 +296,7 @@ uint64_t FastqReader::fillMapped(int m, uint64_t want, ReadBatch &b) {
     static const uint64_t sliceMin = getenv("STARAMD_READ_SLICE_MIN") ? strtoull(getenv("STARAMD_READ_SLICE_MIN"), nullptr, 10) : (8u << 20);
     auto onThreads = [&](unsigned K, const std::function<void(unsigned)> &fn) {
         std::vector<std::thread> th;
-        for (unsigned k = 1; k < K; k++) th.emplace_back(fn, k);
+        for (unsigned k = 1; k < K; k++) th.emplace_back([&fn, k] { CpuScope cs(CPU_FILL); fn(k); });
         fn(0);
         for (auto &x : th) x.join();
     };
@@ -347,6 +351,7 @@ uint64_t FastqReader::fillMapped(int m, uint64_t want, ReadBatch &b) {
 
 uint64_t FastqReader::fill(int m, uint64_t want, ReadBatch &b) {
     TextBuf &text = b.text[m];
+    b.mapped[m] = nullptr;          // (only fillMapped points the batch at a file mapping: a file of the list that cannot be mapped -- a FIFO -- after one that was must not inherit the pointer)
     if (samMates_ > 0) {
         if (m == 0) return fillSam(want, b);
         text.swap(samText2); b.lineStart[1].swap(samLs2); b.lineEnd[1].swap(samLe2);
@@ -366,7 +371,7 @@ uint64_t FastqReader::fill(int m, uint64_t want, ReadBatch &b) {
     static const uint64_t sliceMin = getenv("STARAMD_READ_SLICE_MIN") ? strtoull(getenv("STARAMD_READ_SLICE_MIN"), nullptr, 10) : (8u << 20);   // (tests lower it)
     auto onThreads = [&](unsigned K, const std::function<void(unsigned)> &fn) {
         std::vector<std::thread> th;
-        for (unsigned k = 1; k < K; k++) th.emplace_back(fn, k);
+        for (unsigned k = 1; k < K; k++) th.emplace_back([&fn, k] { CpuScope cs(CPU_FILL); fn(k); });
         fn(0);
         for (auto &x : th) x.join();
     };
@@ -513,7 +518,7 @@ bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     for (;;) {
         if (useMap < 0) useMap = (!fromMemory && samMates_ == 0 && !fasta && command_.empty() && P.outQSconversionAdd == 0 && !P.outSAMreadIDnumber && curMap[0].p && (nMates < 2 || curMap[1].p)) ? 1 : 0;
         if (nMates == 2 && samMates_ == 0 && !fasta) {       // the two mate files are read and scanned for line ends side by side
-            std::thread second([&] { nLines[1] = fill(1, want, b); });
+            std::thread second([&] { CpuScope cs(CPU_FILL); nLines[1] = fill(1, want, b); });
             nLines[0] = fill(0, want, b);
             second.join();
         } else
@@ -541,6 +546,7 @@ bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
     if (!samError.empty()) { err = samError; return false; }
     b.n = (uint32_t)n;
     readsSoFar += n;
+    if (b.mapped[0]) mappedBatches++;
     return true;
 }
 
@@ -564,7 +570,7 @@ bool FastqReader::convertBatch(ReadBatch &b, const RunParams &P, std::string &er
         if (T == 1) { fn(0, n, 0); return; }
         std::vector<std::thread> th;
         uint64_t per = (n + T - 1) / T;
-        for (int t = 0; t < T; t++) th.emplace_back([&, t] { uint64_t lo = std::min<uint64_t>(n, t * per), hi = std::min<uint64_t>(n, lo + per); fn(lo, hi, t); });
+        for (int t = 0; t < T; t++) th.emplace_back([&, t] { CpuScope cs(CPU_CONVERT); uint64_t lo = std::min<uint64_t>(n, t * per), hi = std::min<uint64_t>(n, lo + per); fn(lo, hi, t); });
         for (auto &x : th) x.join();
     };
     // pass 1: spans, checks, lengths

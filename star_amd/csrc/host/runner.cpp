@@ -5,6 +5,7 @@
 // in tests only, by the CPU oracle.
 #include "host.h"
 #include <unistd.h>
+#include <fcntl.h>
 #include <atomic>
 #include <sys/stat.h>
 #include <cerrno>
@@ -182,7 +183,10 @@ struct Runner {
         else if (P.outBAMcoord && !P.outBAMunsorted) {}             // only Aligned.sortedByCoord.out.bam, written at the end of the run
         else {
             std::string samPath = P.outFileNamePrefix + (P.outBAMunsorted ? "Aligned.out.bam" : "Aligned.out.sam");
-            samOut = (P.outBAMunsorted ? P.outStd == "BAM_Unsorted" : P.outStd == "SAM") ? stdout : fopen(samPath.c_str(), "wb");
+            // a regular file is opened for reading too: the writer maps the part of the file a batch goes to, and a shared writable mapping needs a descriptor open read-write
+            // (a FIFO or a device keeps "wb": opening a FIFO read-write would not wait for its reader)
+            struct stat stOut; const bool special = stat(samPath.c_str(), &stOut) == 0 && !S_ISREG(stOut.st_mode);
+            samOut = (P.outBAMunsorted ? P.outStd == "BAM_Unsorted" : P.outStd == "SAM") ? stdout : fopen(samPath.c_str(), special ? "wb" : "w+b");
             if (!samOut) { error = "EXITING because of fatal ERROR: could not create output file " + samPath; return false; }
             setvbuf(samOut, nullptr, _IOFBF, 1 << 22);
             std::string h;
@@ -230,12 +234,14 @@ struct Runner {
     std::thread writerThread;
     int samFd = -1; uint64_t samPos = 0;     // positional writes of the SAM / unsorted BAM text (regular file)
     int samSeekable = -1;                    // -1 not looked at yet, 0 pipe / FIFO / character device (sequential fwrite), 1 regular file
+    uint64_t nMappedWrites = 0;              // batches whose text went out through a mapping of the output file (sah_fast_path_counts)
     double tWriter = 0, tEmitWaitSet = 0, tEmitFormat = 0, tEmitTail = 0;      // seconds, whole run (STARAMD_HOST_TIMING prints them at the end)
     void writerLoop() {
         for (;;) {
             int k;
             { std::unique_lock<std::mutex> l(wm); wcv.wait(l, [&] { return !fullSets.empty() || writerStop; }); if (fullSets.empty()) return; k = fullSets.front(); fullSets.pop_front(); }
             OutSet &o = outSets[k];
+            CpuScope cpuScope(CPU_WRITE);
             const auto tw0 = std::chrono::steady_clock::now();
             struct AddTime { double &acc; std::chrono::steady_clock::time_point t0; ~AddTime() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } addTime{tWriter, tw0};
             if (samSeekable < 0 && samOut) {            // a named pipe (mkfifo Aligned.out.sam | samtools ...) or a device has no offsets: pwrite fails with ESPIPE there
@@ -254,10 +260,11 @@ struct Runner {
                 static const uint32_t wantW = getenv("STARAMD_WRITER_THREADS") ? (uint32_t)std::max(1, atoi(getenv("STARAMD_WRITER_THREADS"))) : 4u;
                 const uint64_t total = at[o.used] - samPos;
                 char *map = nullptr; uint64_t mapOff = 0, mapLen = 0;
-                if (wantMmap && total > 0 && (wantMmap >= 2 || total >= (1u << 20)) && ftruncate(samFd, (off_t)at[o.used]) == 0) {      // (2: whatever the size -- tests)
-                    const uint64_t page = 4096; mapOff = samPos & ~(page - 1); mapLen = at[o.used] - mapOff;
+                // the blocks are reserved before they are written to (posix_fallocate also sets the new size): a full file system is an error return here, not a SIGBUS in a copy
+                if (wantMmap && total > 0 && (wantMmap >= 2 || total >= (1u << 20)) && posix_fallocate(samFd, (off_t)samPos, (off_t)total) == 0) {      // (2: whatever the size -- tests)
+                    static const uint64_t page = (uint64_t)std::max<long>(sysconf(_SC_PAGESIZE), 4096); mapOff = samPos & ~(page - 1); mapLen = at[o.used] - mapOff;
                     void *m = mmap(nullptr, (size_t)mapLen, PROT_READ | PROT_WRITE, MAP_SHARED, samFd, (off_t)mapOff);
-                    if (m != MAP_FAILED) map = (char *)m;
+                    if (m != MAP_FAILED) { map = (char *)m; nMappedWrites++; }
                 }
                 static const uint32_t pwriteW = getenv("STARAMD_WRITER_PWRITE_THREADS") ? (uint32_t)std::max(1, atoi(getenv("STARAMD_WRITER_PWRITE_THREADS"))) : 2u;      // (positional writes: 1 = one stream, no contention for the inode lock)
                 const uint32_t W = std::min<uint32_t>(map ? wantW : pwriteW, o.used);
@@ -272,7 +279,7 @@ struct Runner {
                     }
                 };
                 std::vector<std::thread> th;
-                for (uint32_t i = 1; i < W; i++) th.emplace_back(put);
+                for (uint32_t i = 1; i < W; i++) th.emplace_back([&] { CpuScope cs(CPU_WRITE); put(); });
                 put();
                 for (auto &x : th) x.join();
                 if (map) munmap(map, (size_t)mapLen);
@@ -354,7 +361,7 @@ struct Runner {
                 std::atomic<uint32_t> nextC(0);
                 auto countLoop = [&] { for (;;) { const uint32_t t = nextC.fetch_add(1); if (t >= T) break; count(t); } };
                 std::vector<std::thread> th;
-                for (uint32_t w = 1; w < std::min(Wk, T); w++) th.emplace_back(countLoop);
+                for (uint32_t w = 1; w < std::min(Wk, T); w++) th.emplace_back([&] { CpuScope cs(CPU_EMIT); countLoop(); });
                 countLoop();
                 for (auto &x : th) x.join();
             }
@@ -406,7 +413,7 @@ struct Runner {
             std::atomic<uint32_t> nextR(0);
             auto workLoop = [&] { for (;;) { const uint32_t t = nextR.fetch_add(1); if (t >= T) break; work(t); } };
             std::vector<std::thread> th;
-            for (uint32_t w = 1; w < std::min(Wk, T); w++) th.emplace_back(workLoop);
+            for (uint32_t w = 1; w < std::min(Wk, T); w++) th.emplace_back([&] { CpuScope cs(CPU_EMIT); workLoop(); });
             workLoop();
             for (auto &x : th) x.join();
         }
@@ -647,6 +654,9 @@ int sah_generate_finish(void *h, uint64_t nSA, uint64_t nSAbyte, uint64_t nSAiby
 int sah_tool_done(void *h) { return ((Runner *)h)->toolDone ? 1 : 0; }     // 1: the run was a tool mode (--runMode inputAlignmentsFromBAM) and is finished
 int sah_device(void *h) { return ((Runner *)h)->P.gpuDevice; }
 double sah_genome_load_seconds(void *h) { return ((Runner *)h)->gi.loadSeconds; }
+void sah_cpu_add(int stage, uint64_t ns) { staramd::cpuAdd(stage, ns); }
+void sah_cpu_seconds(double out[8], int reset) { for (int i = 0; i < staramd::CPU_NSTAGE; i++) out[i] = (double)staramd::cpuTake(i, reset != 0) * 1e-9; }
+void sah_fast_path_counts(void *h, uint64_t out[2]) { Runner *r = (Runner *)h; out[0] = r->nMappedWrites; out[1] = r->reader.mappedBatches.load(); }
 void sah_emit_seconds(void *h, double out[4]) { Runner *r = (Runner *)h; out[0] = r->tEmitWaitSet; out[1] = r->tEmitFormat; out[2] = r->tEmitTail; out[3] = r->tWriter; }
 int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {
     Runner *r = (Runner *)h;

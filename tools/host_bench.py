@@ -88,6 +88,8 @@ def main():
         "timed_pairs": rep.timedReads, "timed_wall_s": round(rep.timedWall, 4), "batches": rep.batches, "batch_pairs": args.block,
         "parse_ms_per_batch": round(1e3 * rep.parseBusy / nb, 2), "emit_ms_per_batch": round(1e3 * rep.emitBusy / nb, 2), "finish_s": round(rep.finishSeconds, 3),
         "parse_pairs_per_s": args.block * nb / rep.parseBusy if rep.parseBusy > 0 else None, "emit_pairs_per_s": args.block * nb / rep.emitBusy if rep.emitBusy > 0 else None,
+        "cpu_us_per_pair_by_stage": dict(zip(["input_line_table", "text_to_numeric", "mapper_threads", "postmap_format", "file_writes", "other"], [round(float(x) * 1e6 / max(1, rep.timedReads), 4) for x in list(rep.cpuSeconds)[:6]])),
+        "fast_path_batches": [int(x) for x in list(rep.fastPaths)[:3]],
         "cpu_us_per_pair": round(1e6 * (cpu["t1"] - cpu["t0"]) / rep.timedReads, 3) if "t0" in cpu and rep.timedReads else None,
         "threads": args.threads, "device_ms": args.device_ms, "contexts": rep.nContexts, "read_len": args.read_len, "total_wall_s": round(time.time() - t0, 2),
         "sam_bytes": os.path.getsize(sam) if os.path.isfile(sam) and not args.null_out else None,
