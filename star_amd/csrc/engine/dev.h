@@ -100,7 +100,6 @@ enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS 
        CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
        CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
        CUR_ST_HEAVY = 23, CUR_ST_TICKETH = 24,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
-       CUR_ST_HEAVY2 = 27, CUR_ST_TICKETH2 = 28,                         // pass 0 in three launches (lane kernel, lean cooperative, full-size): what the lean launch defers
        CUR_N = 32 };
 // CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
 enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };
@@ -123,7 +122,6 @@ struct DevBatch {
     u32 *ovfWin2;      // reads deferred by the middle pass (larger LDS table) to the pass with the table in global memory
     u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
     u32 *heavyList;                    // pass-0 items whose windows hold more seeds than the lean launch has LDS for
-    u32 *heavyList2;                   // ... and, when the lane kernel fills heavyList, what the lean launch behind it hands on to the full-size one
     u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win
     u32 *candTops;                     // bytes of its region a wavefront of the first pass-0 launch used (the second one goes on behind them)
     u32 *cursors;      // CUR_*

@@ -266,7 +266,6 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.replayList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.heavyList, (u64)B.winCap))) return rc;
-    if ((rc = devAlloc(R, &B.heavyList2, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.trPool, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
     if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
@@ -337,10 +336,9 @@ static int allocWork(staramd_ctx *c) {
         c->replayBlocks = (u32)c->nCU * envU32("STARAMD_REPLAY_BLOCKS_PER_CU", (u32)std::min(rpPerCU, 8));
         if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_replay %d blocks/CU (LDS %zu B/block)\n", rpPerCU, ldsReplay);
     }
-    // lean launch geometry
-    // (with the lane kernel in front: windows of up to 19 seeds -- a pair has ~17 seeds in all, its best window holds most of them -- in a slice of 7.6 KB per wavefront,
-    // 5 wavefronts per SIMD, against 12.5 KB for the full-size slice)
-    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 20); c->leanArena = envU32("STARAMD_LEAN_ARENA", 3072) & ~31u;
+    // lean launch geometry (used when the lane kernel is off or does not fit: with the lane kernel in front a lean middle launch -- 20 frames, 7.6 KB per wavefront, 5 wavefronts
+    // per SIMD -- was measured and removed in round 5: stitch stage 24.6 ms against 22.7, profiles/r05_ab_session1_*.txt)
+    c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 9); c->leanArena = envU32("STARAMD_LEAN_ARENA", 2048) & ~31u;
     if (c->leanDepth >= c->capDepth) c->leanDepth = 0;
     c->stBlocksLean = 0;
     if (c->leanDepth) {
@@ -562,7 +560,6 @@ static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
         if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.heavyList, (u64)B.winCap))) return rc;
-        if ((rc = devRealloc(R, &B.heavyList2, (u64)B.winCap))) return rc;
     }
     if (flags & OVF_TRPOOL) {
         B.trCap = grow(B.trCap, cur[CUR_TR]); B.exCap = grow(B.exCap, cur[CUR_EX]);
@@ -621,10 +618,6 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
             if (mode == 0 && c->laneBlocks && laneFits) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
                 hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, c->laneClass);
                 HIPCHK(hipEventRecord(c->ev[8], s));
-                if (c->leanDepth) {     // ... the cooperative walk itself in two launches: a lean LDS slice (more resident wavefronts) for the windows of few seeds, the full-size slice for the rest
-                    hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksLean), block, ldsLean, s, c->dX, B, c->scrStitchBig, c->leanDepth, c->capRank, c->leanArena, c->arenaBig, ldsWords, 3u, prune);
-                    hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 4u, prune);
-                } else
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
             } else
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest
@@ -651,7 +644,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
     HIPCHK(waitStream(c));
-    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: stitch work items %u, handed on by the lane kernel %u, handed on by the lean launch %u\n", hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY], hs[8 + CUR_ST_HEAVY2]);
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: stitch work items %u, handed on to the full-size launch %u\n", hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY]);
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));

@@ -430,6 +430,8 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",
                            (unsigned long long)nReads, sec, msDeviceAll / 1e3 / nDev, sec > 0 ? (double)nReads / sec / 1e6 : 0.0, nOwners);
+    if (!exitCode) fprintf(stderr, "star_amd: fast paths: output through a file mapping %llu batches, input from file mappings %llu, uploads prefetched %llu\n",
+                           (unsigned long long)rep.fastPaths[0], (unsigned long long)rep.fastPaths[1], (unsigned long long)rep.fastPaths[2]);
     sah_set_sjdb_resident_fn(nullptr, nullptr);
     destroyAll();
     sah_destroy(h);

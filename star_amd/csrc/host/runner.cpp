@@ -247,7 +247,8 @@ struct Runner {
             if (samSeekable < 0 && samOut) {            // a named pipe (mkfifo Aligned.out.sam | samtools ...) or a device has no offsets: pwrite fails with ESPIPE there
                 struct stat st; samSeekable = (samOut != stdout && fstat(fileno(samOut), &st) == 0 && S_ISREG(st.st_mode) && ftello(samOut) >= 0) ? 1 : 0;
             }
-            if (samOut && samSeekable == 1 && (o.used > 1 || samFd >= 0)) {
+            static const int wantMmap = getenv("STARAMD_WRITER_MMAP") ? atoi(getenv("STARAMD_WRITER_MMAP")) : 1;
+            if (samOut && samSeekable == 1 && (o.used > 1 || samFd >= 0 || wantMmap >= 2)) {
                 // a regular file: the per-thread text buffers go out side by side, each at its own offset (one fwrite stream tops out near
                 // 2 GB/s on tmpfs, the SAM text of one GPU runs at about that)
                 if (samFd < 0) { fflush(samOut); samFd = fileno(samOut); samPos = (uint64_t)ftello(samOut); }
@@ -256,7 +257,6 @@ struct Runner {
                 // write() / pwrite() into ONE file are serialised by the inode lock (tmpfs: 2.9 GB/s from two threads on a box whose tmpfs takes 5.8 / 11.7 / 18.5 GB/s from
                 // 1 / 2 / 4 streams into separate files: the SAM writer at 230 MB per batch was the slowest stage of the pipeline there, 80 ms against 52 ms of kernels).  So the
                 // file is grown to the batch's end and the new part mapped: the threads copy their ranges into the mapping and take their page faults side by side.
-                static const int wantMmap = getenv("STARAMD_WRITER_MMAP") ? atoi(getenv("STARAMD_WRITER_MMAP")) : 1;
                 static const uint32_t wantW = getenv("STARAMD_WRITER_THREADS") ? (uint32_t)std::max(1, atoi(getenv("STARAMD_WRITER_THREADS"))) : 4u;
                 const uint64_t total = at[o.used] - samPos;
                 char *map = nullptr; uint64_t mapOff = 0, mapLen = 0;

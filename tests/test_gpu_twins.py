@@ -26,6 +26,13 @@ def test_cli_cases_on_gpu(name, more, batch, tmp_path, built):
     tcp.run_cli_case(GPU_CLI, name, more, batch, tmp_path)
 
 
+def test_uploads_run_ahead_of_their_batches(tmp_path, built):
+    """staramd_prefetch_batch (include/star_amd_async.h): with one context the front end shows the engine the batch that is next in line; the run must report batches whose
+    upload was done when staramd_map_batch was called for them -- the ordinary upload behind a prefetch that never matches returns the same bytes"""
+    fp = tcp.run_cli_case(GPU_CLI, "pe101", [], 60, tmp_path)
+    assert fp["prefetched"] >= 2, fp
+
+
 @pytest.mark.parametrize("name,more,batch,devices", [(c[0], c[1], c[2], "0,0") for c in tcp.MULTI[:3]])
 def test_two_contexts_on_one_gpu(name, more, batch, devices, tmp_path, built):
     tcp.run_cli_case(GPU_CLI, name, more + ["--gpuDevices", devices], batch, tmp_path)

@@ -87,8 +87,6 @@ FORCED = {
     "no_pruning": {"STARAMD_PRUNE": "0"},
     "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
     "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
-    "lean_tiny": {"STARAMD_LEAN_DEPTH": "3"},                 # the lean cooperative launch behind the lane kernel holds windows of 2 seeds: almost everything goes on to the full-size launch
-    "lean_off": {"STARAMD_LEAN_DEPTH": "0"},                  # no lean launch: lane kernel + full-size launch
     "lean_tiny_lane_off": {"STARAMD_LEAN_DEPTH": "3", "STARAMD_LANE": "0"},
     "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
     "no_sjdb_hash": {"STARAMD_NO_SJDB_HASH": "1"},            # annotated junctions looked up by bisection (what an index does whose coordinates / junction count do not fit the hash)
