@@ -51,6 +51,13 @@ struct DevIndex {
 
 // seed = one row of the reference's PC table (IncludeDefine.h:181-189); saEnd = saStart+nrep-1
 struct DSeed { u64 saStart; u32 nrep; u16 rStart, L; u8 dir, iFrag; u8 pad[6]; };
+// seed stage, lane = unit (k_seed.hip): what a unit keeps of a seed until the read's units are all done; one (piece, direction, start point) of a read's schedule;
+// per read: where its groups start, how many, and what the classification needs of qualitySplit
+#define SEED_SLOTS 8u
+struct SeedSlot { u64 i0; u32 nrep; u16 shift, L; };                                   // L bit 15: Nrep does not fit 32 bits
+struct SeedUnit { u32 read, group; u16 pS, pL; u8 iFrag, istart, nstart, kind; };      // kind 0: forward + backward from start point 0; 1: forward; 2: backward
+struct SeedPlan { u32 group0; u16 nGroups, nSplit, LgoodMin, handOn; u32 pad; };
+struct SeedWork { SeedUnit *units; u32 unitCap; SeedSlot *slots; u32 *groupHead; u32 groupCap; SeedPlan *plan; u32 *handOn; u32 slotLimit; };      // slotLimit <= SEED_SLOTS (tests lower it)
 // one row of the reference's WA table (IncludeDefine.h:197-204)
 struct DWA { u64 gStart; u32 nrep; u16 L, rStart; i32 sjA; u8 anchor, iFrag; u8 pad[2]; };
 // window with seeds, output of the window kernel
@@ -100,6 +107,8 @@ enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS 
        CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
        CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
        CUR_ST_HEAVY = 23, CUR_ST_TICKETH = 24,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
+       // seed stage, lane = unit (k_seed.hip): groups and units handed out by k_seed_plan, the ticket of k_seed_units, reads handed on to k_seed_search
+       CUR_SEED_GROUPS = 26, CUR_SEED_UNITS = 27, CUR_TICKET_SEED_UNITS = 28, CUR_OVF_SEED = 29,
        CUR_N = 32 };
 // CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
 enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };

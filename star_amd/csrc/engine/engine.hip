@@ -14,7 +14,10 @@
 #include <vector>
 #include <mutex>
 
-extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane);
+extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane, const u32 *inList);
+extern "C" __global__ void k_seed_plan(const DevIndex *X, DevBatch B, SeedWork W);
+extern "C" __global__ void k_seed_units(const DevIndex *X, DevBatch B, SeedWork W);
+extern "C" __global__ void k_seed_merge(const DevIndex *X, DevBatch B, SeedWork W, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
 extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);
 extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid);
@@ -68,6 +71,7 @@ struct staramd_ctx {
     int nCU = 256;
     // seed kernel: one lane per read
     u32 seedLanes = 0; DSeed *scrSeed = nullptr; u32 seedPerLane = 0;
+    SeedWork seedWork = {}; u32 seedUnits = 1, seedUnitLanes = 0;      // lane = unit mapping of the seed stage (STARAMD_SEED_UNITS=0: lane = read, k_seed_search over every read)
     // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
@@ -290,6 +294,23 @@ static int allocWork(staramd_ctx *c) {
     c->seedLanes = (lanes / 256) * 256;
     c->seedPerLane = P.seedPerReadNmax + 1;
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
+    c->seedUnits = envU32("STARAMD_SEED_UNITS", 1);
+    if (c->seedUnits) {
+        // 2x101 has 12 groups / 10 units per pair, 2x150 16 / 14; a read that does not fit what is left of the pools takes k_seed_search (no regrowth, no re-run)
+        SeedWork &W = c->seedWork;
+        W.groupCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_SEED_GROUPS_PER_READ", 20) + 256, 0xFFFFFFF0ull);
+        W.unitCap = (u32)std::min<u64>((u64)N * envU32("STARAMD_SEED_GROUPS_PER_READ", 20) + 256, 0xFFFFFFF0ull);
+        W.slotLimit = std::min<u32>(SEED_SLOTS, std::max<u32>(1, envU32("STARAMD_SEED_SLOT_LIMIT", SEED_SLOTS)));
+        if ((rc = devAlloc(R, &W.units, (u64)W.unitCap))) return rc;
+        if ((rc = devAlloc(R, &W.slots, (u64)W.groupCap * SEED_SLOTS))) return rc;
+        if ((rc = devAlloc(R, &W.groupHead, (u64)W.groupCap))) return rc;
+        if ((rc = devAlloc(R, &W.plan, (u64)N))) return rc;
+        if ((rc = devAlloc(R, &W.handOn, (u64)N))) return rc;
+        int upCU = seedPerCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&upCU, k_seed_units, 256, 0) != hipSuccess || upCU < 1) upCU = seedPerCU;
+        c->seedUnitLanes = envU32("STARAMD_SEED_UNIT_LANES", (u32)c->nCU * (u32)upCU * 256u) / 256u * 256u;
+        if (c->seedUnitLanes < 256) c->seedUnitLanes = 256;
+    }
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
     c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 0); c->laneClass = envU32("STARAMD_LANE_CLASS", 3);          // (knobs are read here, once: not on the launch path)
@@ -589,7 +610,13 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[0], s));
     {
         u32 lanes = std::min<u32>(c->seedLanes, ((n + 255) / 256) * 256);
-        hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane);
+        if (c->seedUnits) {
+            hipLaunchKernelGGL(k_seed_plan, dim3((n + 255) / 256), block, 0, s, c->dX, B, c->seedWork);
+            hipLaunchKernelGGL(k_seed_units, dim3(c->seedUnitLanes / 256), block, 0, s, c->dX, B, c->seedWork);
+            hipLaunchKernelGGL(k_seed_merge, dim3(lanes / 256), block, 0, s, c->dX, B, c->seedWork, c->scrSeed, c->seedPerLane);
+            hipLaunchKernelGGL(k_seed_search, dim3(std::min<u32>(lanes / 256, 64u)), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane, (const u32 *)c->seedWork.handOn);      // what the units handed on (rarely anything)
+        } else
+        hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane, (const u32 *)nullptr);
     }
     HIPCHK(hipEventRecord(c->ev[1], s));
     {
@@ -644,7 +671,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
     HIPCHK(waitStream(c));
-    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: stitch work items %u, handed on to the full-size launch %u\n", hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY]);
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: seed units %u in %u groups, reads handed on to k_seed_search %u; stitch work items %u, handed on to the full-size launch %u\n", hs[8 + CUR_SEED_UNITS], hs[8 + CUR_SEED_GROUPS], hs[8 + CUR_OVF_SEED], hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY]);
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));

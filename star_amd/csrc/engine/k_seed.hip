@@ -5,12 +5,19 @@
 // (ReadAlign_maxMappableLength2strands.cpp:5-115), maxMappableLength / findMultRange /
 // compareSeqToGenome (SuffixArrayFuns.cpp:10-207) and storeAligns (ReadAlign_storeAligns.cpp:10-160).
 //
-// Mapping: one lane = one read, 64 independent reads per wavefront, persistent lanes pulling
-// read ids from a device-wide ticket counter.  The kernel is a chain of dependent random gathers
-// (SAindex entry -> packed SA word -> genome bytes), so throughput is set by the number of
-// independent chains in flight; every lane carries one.  The seed schedule inside a read is kept
-// strictly in the reference's order because storeAligns' de-duplication is order dependent
-// (first (rStart,Length) in schedule order wins).
+// Mapping (round 5): one lane = one UNIT of a read's search schedule.  The schedule of mapOneRead is a nest -- pieces x directions x start points x the loop that
+// restarts a search behind the last maximal mappable prefix -- around a search that is itself a chain of dependent gathers (SAindex entry -> packed SA word ->
+// genome bytes, ~18 round trips).  With a read per lane (rounds 1-4) the 64 lanes of a wavefront sat at 64 different places of that nest and the wavefront
+// paid every level at the pace of its slowest lane: ~4 200 serialised load round trips per wavefront for 470 in the mean lane, 84 % of the wave cycles waiting.
+// The searches of different (piece, direction, start point) triples do not depend on each other -- only the ORDER in which their results reach storeAligns
+// matters (its de-duplication keeps the first (rStart, Length) in schedule order), and one quirk: the backward search from the first start point is skipped when
+// the forward one mapped the whole piece (ReadAlign_mapOneRead.cpp:74).  So:
+//   k_seed_plan   lane = read: qualitySplit, the start points of every piece; one unit per (piece, direction, start point), the forward and the backward
+//                 search of start point 0 in one unit (the quirk stays inside a lane); slots for what each unit finds, in schedule order
+//   k_seed_units  lane = unit (persistent lanes, ticket): the restart loop of one start point -- one to three searches -- into its slots
+//   k_seed_merge  lane = read: the slots in schedule order through storeAligns, classification of the read, seeds into the pool
+// A wavefront of k_seed_units holds 64 chains that are all at the same level of the same (shallow) nest.  Reads whose units or slots do not fit the pools, or a
+// unit that finds more than SEED_SLOTS seeds, take k_seed_search (lane = read, the whole nest: the general form, no limits of its own) through a list.
 #include "dev.h"
 
 struct SeedCnt { u32 nSAi, nSAprobe, nGcmp; };     // per lane and kernel: a lane compares < 2^32 bases
@@ -193,7 +200,12 @@ __device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u3
 // array in small tables and stores the best ones afterwards; indexed local tables would live in scratch memory here, so with
 // genomeSAsparseD > 1 the offsets are simply searched twice (first for the best length, then to store) -- with the default
 // full suffix array there is one offset and one search.
-__device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R, SeedState &st, u32 pieceStartIn, u32 pieceLengthIn, u32 iDir, u32 &maxLbest, u32 iFrag, SeedCnt &cn) {
+// SINK: where a seed goes -- storeAligns at once (lane = read), or the slots of the unit (lane = unit; storeAligns runs later, in schedule order)
+struct StoreNow {
+    const DevIndex &X; SeedState &st;
+    __device__ __forceinline__ void operator()(u32 iDir, u32 Shift, u64 Nrep, u32 L, u64 ind0, u32 iFrag) { storeAligns(X, st, iDir, Shift, Nrep, L, ind0, iFrag); }
+};
+template <class SINK> __device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R, SINK &sink, u32 pieceStartIn, u32 pieceLengthIn, u32 iDir, u32 &maxLbest, u32 iFrag, SeedCnt &cn) {
     const bool dirR = iDir == 0;
     const u32 nD = min(pieceLengthIn, X.sparseD);
     maxLbest = 0;
@@ -206,95 +218,218 @@ __device__ static void maxMappableLength2strands(const DevIndex &X, const u8 *R,
             if (nD > 1) continue;
         }
         if (maxL + iDist == maxLbest && Nrep > 0)
-            storeAligns(X, st, iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, Nrep, maxL, i0, iFrag);
+            sink(iDir, dirR ? pieceStartIn + iDist : pieceStartIn - iDist, Nrep, maxL, i0, iFrag);
         if (nD == 1) break;
     }
+}
+
+// ReadAlign_mapOneRead.cpp:57-92, the body of the loop over start points for one direction: the search restarts behind the last maximal mappable prefix until the
+// piece is used up, then the extra search of --seedSearchLmax.  flagDirMap: :62 / :74
+template <class SINK> __device__ __forceinline__ void searchFromStart(const DevIndex &X, const u8 *R, SINK &sink, u32 pS, u32 pL, u32 iDir, u32 istart, u32 Lstart, u32 iFrag, bool &flagDirMap, SeedCnt &cn) {
+    const staramd_params &P = X.P;
+    u32 Lm;
+    if (flagDirMap || istart > 0) {
+        u32 Lmapped = 0;
+        while (istart * Lstart + Lmapped + P.seedMapMin < pL) {
+            u32 Shift = iDir == 0 ? (pS + istart * Lstart + Lmapped) : (pS + pL - istart * Lstart - 1 - Lmapped);
+            u32 seedLength = pL - Lmapped - istart * Lstart;
+            maxMappableLength2strands(X, R, sink, Shift, seedLength, iDir, Lm, iFrag, cn);
+            if (iDir == 0 && istart == 0 && Lmapped == 0 && Shift + Lm == pL) flagDirMap = false;
+            Lmapped += Lm;
+            if (Lm == 0) break;
+        }
+    }
+    if (P.seedSearchLmax > 0) {
+        u32 Shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1);
+        u32 seedLength = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - Shift) : (Shift + 1));
+        maxMappableLength2strands(X, R, sink, Shift, seedLength, iDir, Lm, iFrag, cn);
+    }
+}
+
+// qualitySplit (SequenceFuns.cpp:411-444), one piece at a time: the next run of codes <= 3 from iR on; false at the end of the read.  iFrag counts the mate spacers passed
+__device__ __forceinline__ bool nextPiece(const u8 *R, u32 Lread, u32 &iR, u32 &iFrag, u32 &pS, u32 &pL) {
+    while (iR < Lread && R[iR] > 3) { if (R[iR] == STARAMD_SPACER_BASE) iFrag++; iR++; }
+    if (iR == Lread) return false;
+    pS = iR;
+    for (;;) {                                                  // end of the run of good bases, 8 bases per step
+        const u64 bad = load8(R + iR) & 0xFCFCFCFCFCFCFCFCull;
+        const u32 k = bad ? ((u32)__builtin_ctzll(bad) >> 3) : 8u;
+        iR += k;
+        if (iR >= Lread) { iR = Lread; break; }
+        if (k < 8u) break;
+    }
+    pL = iR - pS;
+    return true;
+}
+__device__ __forceinline__ u32 startLmaxOf(const staramd_params &P, u32 Lread) { return min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1))); }
+__device__ __forceinline__ u32 nStartOf(const staramd_params &P, u32 startLmax, u32 pL) { return (P.seedSearchStartLmax > 0 && startLmax < pL) ? pL / startLmax + 1 : 1; }
+
+// classification of a read whose searches are done (ReadAlign_mapOneRead.cpp:100-115) and its seeds into the pool
+__device__ static void finishRead(const DevIndex &X, DevBatch &B, u32 ir, u32 Lread, const SeedState &st, u32 Nsplit, u32 LgoodMin) {
+    const staramd_params &P = X.P;
+    DRead rd;
+    rd.status = 0; rd.seedOffset = 0; rd.nSeeds = 0; rd.unmappedLength = 0; rd.winOffset = 0; rd.nWin = 0; rd.wtOffset = 0; rd.nWt = 0; rd.pruneBest = 0; rd.pad0 = 0;
+    rd.maxScoreMate[0] = rd.maxScoreMate[1] = 0; rd.bestW = -1; rd.nTr = 0; rd.nEx = 0;
+    if (st.fatal) rd.status |= STARAMD_ST_FATAL_SEEDS_PER_READ;
+    else if (Lread < P.outFilterMatchNmin) { rd.status |= STARAMD_ST_READ_TOO_SHORT; rd.unmappedLength = 0; }
+    else if (Nsplit == 0) { rd.status |= STARAMD_ST_NO_GOOD_PIECES; rd.unmappedLength = LgoodMin; }
+    else if (st.nA == 0) { rd.status |= STARAMD_ST_ALL_PIECES_MULTI; rd.unmappedLength = st.multNminL; }
+    else {
+        u32 off = atomicAdd(&B.cursors[CUR_SEED], st.nP);
+        if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_SEEDPOOL); }
+        else {
+            rd.seedOffset = off; rd.nSeeds = st.nP;
+            for (u32 k = 0; k < st.nP; k++) B.seedPool[off + k] = st.PC[k];
+        }
+    }
+    B.reads[ir] = rd;
 }
 
 #ifndef SEED_WAVES
 #define SEED_WAVES 8        // minimum waves per SIMD the register allocation is held to (8: 64 VGPRs + spills, 10 % faster than 4 at 1 Gb: more gather chains in flight)
 #endif
-extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_search(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane) {
+// the whole nest of one read on one lane: the general form (any number of pieces, start points and seeds per search).  Runs over the reads of `inList`
+// (B.cursors[CUR_OVF_SEED] of them: what the unit mapping below handed on), or over every read when inList is null (STARAMD_SEED_UNITS=0)
+extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_search(const DevIndex *__restrict__ Xp, DevBatch B, DSeed *scratch, u32 scratchPerLane, const u32 *inList) {
     const DevIndex &X = *Xp;
     u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     SeedState st; st.PC = scratch + (u64)lane * scratchPerLane; st.cap = scratchPerLane;
+    StoreNow sink{X, st};
     SeedCnt cn = {0, 0, 0}; u64 nSeedsTot = 0;
     const staramd_params &P = X.P;
+    const u32 nItems = inList ? B.cursors[CUR_OVF_SEED] : B.nReads;
     for (;;) {
-        u32 ir = atomicAdd(&B.cursors[CUR_TICKET_SEED], 1u);
-        if (ir >= B.nReads) break;
+        u32 it = atomicAdd(&B.cursors[CUR_TICKET_SEED], 1u);
+        if (it >= nItems) break;
+        const u32 ir = inList ? inList[it] : it;
         const u8 *R = B.bases + B.readOffset[ir];
         u32 Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         st.nP = 0; st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
-        // qualitySplit (SequenceFuns.cpp:411-444) and the loop over its pieces (ReadAlign_mapOneRead.cpp:40-93) fused: a piece is searched as soon as its
-        // end is found -- the pieces are processed in the order the reference stores them, and a table of pieces indexed at run time would live in
-        // scratch memory (it did: 80 bytes per lane, re-read for every seed)
+        // qualitySplit and the loop over its pieces (ReadAlign_mapOneRead.cpp:40-93) fused: a piece is searched as soon as its end is found
         u32 Nsplit = 0, LgoodMin = 0;
-        const u32 seedSearchStartLmax = min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1)));
-        {
-            u32 iR = 0, iFrag = 0;
-            while ((iR < Lread) & (Nsplit < P.maxNsplit)) {
-                while (iR < Lread && R[iR] > 3) { if (R[iR] == STARAMD_SPACER_BASE) iFrag++; iR++; }
-                if (iR == Lread) break;
-                const u32 pS = iR;
-                for (;;) {                                                  // end of the run of good bases, 8 bases per step
-                    const u64 bad = load8(R + iR) & 0xFCFCFCFCFCFCFCFCull;
-                    const u32 k = bad ? ((u32)__builtin_ctzll(bad) >> 3) : 8u;
-                    iR += k;
-                    if (iR >= Lread) { iR = Lread; break; }
-                    if (k < 8u) break;
-                }
-                const u32 pL = iR - pS;
-                if (pL > LgoodMin) LgoodMin = pL;
-                if (pL < P.seedSplitMin) continue;
-                Nsplit++;
-                const u32 Nstart = (P.seedSearchStartLmax > 0 && seedSearchStartLmax < pL) ? pL / seedSearchStartLmax + 1 : 1;
-                const u32 Lstart = pL / Nstart;
-                bool flagDirMap = true;
-                for (u32 iDir = 0; iDir < 2; iDir++) {
-                    for (u32 istart = 0; istart < Nstart; istart++) {
-                        u32 Lm;
-                        if (flagDirMap || istart > 0) {
-                            u32 Lmapped = 0;
-                            while (istart * Lstart + Lmapped + P.seedMapMin < pL) {
-                                u32 Shift = iDir == 0 ? (pS + istart * Lstart + Lmapped) : (pS + pL - istart * Lstart - 1 - Lmapped);
-                                u32 seedLength = pL - Lmapped - istart * Lstart;
-                                maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, iFrag, cn);
-                                if (iDir == 0 && istart == 0 && Lmapped == 0 && Shift + Lm == pL) flagDirMap = false;
-                                Lmapped += Lm;
-                                if (Lm == 0) break;
-                            }
-                        }
-                        if (P.seedSearchLmax > 0) {
-                            u32 Shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1);
-                            u32 seedLength = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - Shift) : (Shift + 1));
-                            maxMappableLength2strands(X, R, st, Shift, seedLength, iDir, Lm, iFrag, cn);
-                        }
-                    }
-                }
-            }
+        const u32 startLmax = startLmaxOf(P, Lread);
+        u32 iR = 0, iFrag = 0, pS = 0, pL = 0;
+        while (Nsplit < P.maxNsplit && nextPiece(R, Lread, iR, iFrag, pS, pL)) {
+            if (pL > LgoodMin) LgoodMin = pL;
+            if (pL < P.seedSplitMin) continue;
+            Nsplit++;
+            const u32 Nstart = nStartOf(P, startLmax, pL), Lstart = pL / Nstart;
+            bool flagDirMap = true;
+            for (u32 iDir = 0; iDir < 2; iDir++)
+                for (u32 istart = 0; istart < Nstart; istart++) searchFromStart(X, R, sink, pS, pL, iDir, istart, Lstart, iFrag, flagDirMap, cn);
         }
-        // classification, ReadAlign_mapOneRead.cpp:100-115
-        DRead rd;
-        rd.status = 0; rd.seedOffset = 0; rd.nSeeds = 0; rd.unmappedLength = 0; rd.winOffset = 0; rd.nWin = 0; rd.wtOffset = 0; rd.nWt = 0; rd.pruneBest = 0; rd.pad0 = 0;
-        rd.maxScoreMate[0] = rd.maxScoreMate[1] = 0; rd.bestW = -1; rd.nTr = 0; rd.nEx = 0;
         nSeedsTot += st.nP;
-        if (st.fatal) rd.status |= STARAMD_ST_FATAL_SEEDS_PER_READ;
-        else if (Lread < P.outFilterMatchNmin) { rd.status |= STARAMD_ST_READ_TOO_SHORT; rd.unmappedLength = 0; }
-        else if (Nsplit == 0) { rd.status |= STARAMD_ST_NO_GOOD_PIECES; rd.unmappedLength = LgoodMin; }
-        else if (st.nA == 0) { rd.status |= STARAMD_ST_ALL_PIECES_MULTI; rd.unmappedLength = st.multNminL; }
-        else {
-            u32 off = atomicAdd(&B.cursors[CUR_SEED], st.nP);
-            if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_SEEDPOOL); }
-            else {
-                rd.seedOffset = off; rd.nSeeds = st.nP;
-                for (u32 k = 0; k < st.nP; k++) B.seedPool[off + k] = st.PC[k];
-            }
-        }
-        B.reads[ir] = rd;
+        finishRead(X, B, ir, Lread, st, Nsplit, LgoodMin);
     }
     atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)cn.nSAi);
     atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)cn.nSAprobe);
     atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);
+    atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
+}
+
+// ---- lane = unit -------------------------------------------------------------------------------------------------------------------------------------------
+// group = one (piece, direction, start point) of a read, in schedule order: piece by piece, all start points forward, then all start points backward.
+// A group owns SEED_SLOTS slots; its header word says how many are filled and what storeAligns needs beside them.
+struct SlotSink {
+    SeedSlot *slot; u32 n, limit; bool over;
+    __device__ __forceinline__ void operator()(u32, u32 Shift, u64 Nrep, u32 L, u64 ind0, u32) {
+        if (n >= limit) { over = true; return; }
+        SeedSlot c; c.i0 = ind0; c.nrep = (u32)min(Nrep, (u64)0xFFFFFFFFu); c.shift = (u16)Shift; c.L = (u16)(L | (Nrep > 0xFFFFFFFFull ? 0x8000u : 0u));
+        slot[n++] = c;
+    }
+};
+
+extern "C" __global__ void __launch_bounds__(256) k_seed_plan(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W) {
+    const DevIndex &X = *Xp; const staramd_params &P = X.P;
+    const u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ir >= B.nReads) return;
+    const u8 *R = B.bases + B.readOffset[ir];
+    const u32 Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
+    const u32 startLmax = startLmaxOf(P, Lread);
+    u32 Nsplit = 0, LgoodMin = 0, nGroups = 0, nUnits = 0;
+    { u32 iR = 0, iFrag = 0, pS = 0, pL = 0;
+      while (Nsplit < P.maxNsplit && nextPiece(R, Lread, iR, iFrag, pS, pL)) {
+          if (pL > LgoodMin) LgoodMin = pL;
+          if (pL < P.seedSplitMin) continue;
+          Nsplit++;
+          const u32 Nstart = nStartOf(P, startLmax, pL);
+          nGroups += 2u * Nstart; nUnits += 2u * Nstart - 1u;
+      } }
+    SeedPlan pl; pl.group0 = 0; pl.nGroups = (u16)min(nGroups, 0xFFFFu); pl.nSplit = (u16)Nsplit; pl.LgoodMin = (u16)min(LgoodMin, 0xFFFFu); pl.handOn = 0; pl.pad = 0;
+    if (nGroups) {
+        const u32 g0 = atomicAdd(&B.cursors[CUR_SEED_GROUPS], nGroups), u0 = atomicAdd(&B.cursors[CUR_SEED_UNITS], nUnits);
+        const bool fits = g0 + nGroups <= W.groupCap && u0 + nUnits <= W.unitCap && nGroups <= 0xFFFFu && Lread <= 0x7FFFu;
+        if (!fits) {
+            // the unit slots of this read that lie inside the pool are marked empty (the cursor has counted them); the read takes the general kernel
+            for (u32 u = u0; u < u0 + nUnits && u < W.unitCap; u++) W.units[u].read = 0xFFFFFFFFu;
+            pl.handOn = 1;
+        } else {
+            pl.group0 = g0;
+            u32 iR = 0, iFrag = 0, pS = 0, pL = 0, g = g0, u = u0, k = 0;
+            while (k < Nsplit && nextPiece(R, Lread, iR, iFrag, pS, pL)) {
+                if (pL < P.seedSplitMin) continue;
+                k++;
+                const u32 Nstart = nStartOf(P, startLmax, pL);
+                for (u32 istart = 0; istart < Nstart; istart++)
+                    for (u32 iDir = 0; iDir < 2; iDir++) {
+                        if (istart == 0 && iDir == 1) continue;                       // backward from start point 0: second half of the unit of (forward, 0)
+                        SeedUnit un; un.read = ir; un.group = g + iDir * Nstart + istart; un.pS = (u16)pS; un.pL = (u16)pL; un.iFrag = (u8)iFrag; un.istart = (u8)istart;
+                        un.nstart = (u8)Nstart; un.kind = (u8)(istart == 0 ? 0u : 1u + iDir);
+                        W.units[u++] = un;
+                    }
+                g += 2u * Nstart;
+            }
+        }
+    }
+    W.plan[ir] = pl;
+}
+
+extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_units(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W) {
+    const DevIndex &X = *Xp;
+    SeedCnt cn = {0, 0, 0};
+    const u32 nUnits = min(B.cursors[CUR_SEED_UNITS], W.unitCap);
+    for (;;) {
+        const u32 u = atomicAdd(&B.cursors[CUR_TICKET_SEED_UNITS], 1u);
+        if (u >= nUnits) break;
+        const SeedUnit un = W.units[u];
+        if (un.read == 0xFFFFFFFFu) continue;
+        const u8 *R = B.bases + B.readOffset[un.read];
+        const u32 pS = un.pS, pL = un.pL, Nstart = un.nstart, Lstart = pL / Nstart, istart = un.istart, iFrag = un.iFrag;
+        bool flagDirMap = true;
+        const u32 dir0 = un.kind == 2u ? 1u : 0u, dir1 = un.kind == 1u ? 0u : 1u;      // kind 0: forward then backward; 1: forward; 2: backward
+        for (u32 iDir = dir0; iDir <= dir1; iDir++) {
+            const u32 g = un.group + (un.kind == 0u && iDir == 1u ? Nstart : 0u);
+            SlotSink sink; sink.slot = W.slots + (u64)g * SEED_SLOTS; sink.n = 0; sink.limit = W.slotLimit; sink.over = false;
+            searchFromStart(X, R, sink, pS, pL, iDir, istart, Lstart, iFrag, flagDirMap, cn);
+            W.groupHead[g] = sink.n | (iDir << 8) | (iFrag << 16) | (sink.over ? 0x80000000u : 0u);
+        }
+    }
+    atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)cn.nSAi);
+    atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)cn.nSAprobe);
+    atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);
+}
+
+extern "C" __global__ void __launch_bounds__(256) k_seed_merge(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, DSeed *scratch, u32 scratchPerLane) {
+    const DevIndex &X = *Xp;
+    const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+    SeedState st; st.PC = scratch + (u64)lane * scratchPerLane; st.cap = scratchPerLane;
+    u64 nSeedsTot = 0;
+    for (u32 ir = lane; ir < B.nReads; ir += gridDim.x * blockDim.x) {
+        const SeedPlan pl = W.plan[ir];
+        bool handOn = pl.handOn != 0;
+        for (u32 g = 0; g < pl.nGroups && !handOn; g++) handOn = (W.groupHead[pl.group0 + g] & 0x80000000u) != 0;       // a unit found more seeds than it has slots
+        if (handOn) { const u32 k = atomicAdd(&B.cursors[CUR_OVF_SEED], 1u); W.handOn[k] = ir; continue; }
+        st.nP = 0; st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
+        for (u32 g = 0; g < pl.nGroups; g++) {
+            const u32 h = W.groupHead[pl.group0 + g];
+            const SeedSlot *c = W.slots + (u64)(pl.group0 + g) * SEED_SLOTS;
+            for (u32 k = 0; k < (h & 0xFFu); k++) {
+                const SeedSlot x = c[k];
+                storeAligns(X, st, (h >> 8) & 1u, x.shift, (x.L & 0x8000u) ? 0x100000000ull : (u64)x.nrep, x.L & 0x7FFFu, x.i0, (h >> 16) & 0xFFu);
+            }
+        }
+        nSeedsTot += st.nP;
+        finishRead(X, B, ir, (u32)(B.readOffset[ir + 1] - B.readOffset[ir]), st, pl.nSplit, pl.LgoodMin);
+    }
     atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
 }

@@ -93,6 +93,9 @@ FORCED = {
     "no_leaf_skipping": {"STARAMD_PRUNE": "3"},               # window pruning as in round 3, every leaf of every walked window finalised
     "win_owner_map_off": {"STARAMD_WIN_OWNER_MAP": "0"},      # k_windows: the covered bins in a Bloom filter + serial owner look-ups (what a read does whose windows cover more bins than the owner map holds)
     "win_owner_map_tiny": {"STARAMD_WIN_HASH_BITS": "1024", "STARAMD_WIN_HASH_BITS_MID": "4096"},     # 32-slot owner map: reads switch between the map and the filter
+    "seed_lane_per_read": {"STARAMD_SEED_UNITS": "0"},         # the seed stage as one nest per lane (k_seed_search over every read) instead of lane = unit
+    "seed_unit_pool_tiny": {"STARAMD_SEED_GROUPS_PER_READ": "1"},   # the group / unit pools hold less than half of the batch: the rest is handed on to k_seed_search
+    "seed_one_slot_per_unit": {"STARAMD_SEED_SLOT_LIMIT": "1"},     # a unit that finds a second seed hands its read on
 }
 
 
