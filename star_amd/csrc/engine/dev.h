@@ -57,7 +57,16 @@ struct DSeed { u64 saStart; u32 nrep; u16 rStart, L; u8 dir, iFrag; u8 pad[6]; }
 struct SeedSlot { u64 i0; u32 nrep; u16 shift, L; };                                   // L bit 15: Nrep does not fit 32 bits
 struct SeedUnit { u32 read, group; u16 pS, pL; u8 iFrag, istart, nstart, kind; };      // kind 0: forward + backward from start point 0; 1: forward; 2: backward
 struct SeedPlan { u32 group0; u16 nGroups, nSplit, LgoodMin, handOn; u32 pad; };
-struct SeedWork { SeedUnit *units; u32 unitCap; SeedSlot *slots; u32 *groupHead; u32 groupCap; SeedPlan *plan; u32 *handOn; u32 slotLimit; };      // slotLimit <= SEED_SLOTS (tests lower it)
+// the unit mapping in ROUNDS (k_seed_lookup / k_seed_bisect): what is left of a unit between two rounds, and a bisection waiting in its bucket
+struct SeedUState { u16 Lmapped; u8 leg, flags; u8 n0, n1; u8 pad[2]; };              // leg: SEED_LEG_*; flags: bit 0 flagDirMap, bit 1 handed on (slots full / interval too long); n0 / n1: slots filled, first / second direction
+struct SeedTask { u64 i1; u32 range, unit; u16 shift, N, maxL; u8 dirR, pad; };        // [i1, i1 + range] with a common length of maxL; the search: N bases from `shift` on
+enum { SEED_LEG_LOOP0 = 0, SEED_LEG_LMAX0 = 1, SEED_LEG_LOOP1 = 2, SEED_LEG_LMAX1 = 3, SEED_LEG_DONE = 4 };
+#define SEED_CLASSES 6u             // buckets of interval length: [1,4) [4,16) [16,64) [64,256) [256,4096) [4096,2^32)
+#define SEED_ROUNDS_MAX 12u
+// round cursors (u32 words of SeedWork::rc, zeroed per batch): active units of round r, tickets of the two kernels of round r, tasks and tickets per bucket of round r
+enum { RC_ACT = 0, RC_TICKET_L = RC_ACT + SEED_ROUNDS_MAX + 1, RC_BUCKET = RC_TICKET_L + SEED_ROUNDS_MAX + 1, RC_TICKET_B = RC_BUCKET + SEED_ROUNDS_MAX * SEED_CLASSES, RC_N = RC_TICKET_B + SEED_ROUNDS_MAX * SEED_CLASSES };
+struct SeedWork { SeedUnit *units; u32 unitCap; SeedSlot *slots; u32 *groupHead; u32 groupCap; SeedPlan *plan; u32 *handOn; u32 slotLimit;      // slotLimit <= SEED_SLOTS (tests lower it)
+                  SeedUState *ustate; u32 *act[2]; SeedTask *bucket[SEED_CLASSES]; u32 *rc; u32 rounds; };
 // one row of the reference's WA table (IncludeDefine.h:197-204)
 struct DWA { u64 gStart; u32 nrep; u16 L, rStart; i32 sjA; u8 anchor, iFrag; u8 pad[2]; };
 // window with seeds, output of the window kernel
@@ -99,17 +108,19 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_nSkippedLeaves, DC_nRewalkWin,                               // stitch kernels: single-mate leaves (and subtrees of them) not finalised / two-mate windows walked again in full
        DC_N };
 
-// cursors[] slots
-enum { CUR_SEED = 0, CUR_WIN = 1, CUR_WA = 2, CUR_TR = 4, CUR_EX = 5, CUR_FLAGS = 6,
-       CUR_TICKET_SEED = 8, CUR_TICKET_WIN = 9, CUR_OVF_WIN = 11, CUR_TICKET_WIN2 = 13, CUR_OVF_WIN2 = 12, CUR_TICKET_WIN3 = 14,
+// cursors[] slots.  Every counter has a 128-byte line of its own (CS words apart): an L2 channel serves the atomics of one line one after the other (~2 ns each, measured:
+// an empty launch of 524 288 lanes that each fail one ticket costs 1 ms), and the allocation cursors of a kernel -- windows, seed rows, work items -- would share a line and a queue
+#define CS 32
+enum { CUR_SEED = 0 * CS, CUR_WIN = 1 * CS, CUR_WA = 2 * CS, CUR_TR = 4 * CS, CUR_EX = 5 * CS, CUR_FLAGS = 6 * CS,
+       CUR_TICKET_SEED = 8 * CS, CUR_TICKET_WIN = 9 * CS, CUR_OVF_WIN = 11 * CS, CUR_TICKET_WIN2 = 13 * CS, CUR_OVF_WIN2 = 12 * CS, CUR_TICKET_WIN3 = 14 * CS,
        // stitch stage: work lists of window ids and their tickets
-       CUR_ST_TICKET0 = 16, CUR_ITEM = 25,                               // pass 0: all work items (reads or windows)
-       CUR_ST_REDO = 19, CUR_ST_TICKET1 = 20,                            // pass 1, full re-walk (no candidate log available)
-       CUR_ST_REPLAY = 21, CUR_ST_TICKETR = 22,                          // pass 1, replay of the candidate log
-       CUR_ST_HEAVY = 23, CUR_ST_TICKETH = 24,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
+       CUR_ST_TICKET0 = 16 * CS, CUR_ITEM = 25 * CS,                               // pass 0: all work items (reads or windows)
+       CUR_ST_REDO = 19 * CS, CUR_ST_TICKET1 = 20 * CS,                            // pass 1, full re-walk (no candidate log available)
+       CUR_ST_REPLAY = 21 * CS, CUR_ST_TICKETR = 22 * CS,                          // pass 1, replay of the candidate log
+       CUR_ST_HEAVY = 23 * CS, CUR_ST_TICKETH = 24 * CS,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
        // seed stage, lane = unit (k_seed.hip): groups and units handed out by k_seed_plan, the ticket of k_seed_units, reads handed on to k_seed_search
-       CUR_SEED_GROUPS = 26, CUR_SEED_UNITS = 27, CUR_TICKET_SEED_UNITS = 28, CUR_OVF_SEED = 29,
-       CUR_N = 32 };
+       CUR_SEED_GROUPS = 26 * CS, CUR_SEED_UNITS = 27 * CS, CUR_TICKET_SEED_UNITS = 28 * CS, CUR_OVF_SEED = 29 * CS,
+       CUR_N = 32 * CS };
 // CUR_FLAGS bits: pool overflows (the host grows the pool and re-runs the batch)
 enum { OVF_SEEDPOOL = 1, OVF_WINPOOL = 4, OVF_TRPOOL = 16, OVF_HARD = 64 };
 

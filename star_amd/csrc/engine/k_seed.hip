@@ -143,14 +143,15 @@ __device__ static void storeAligns(const DevIndex &X, SeedState &st, u32 iDir, u
     if (Nrep != 1) { if (Nrep < st.multNmin || st.multNmin == 0) { st.multNmin = (u32)Nrep; st.multNminL = L; } }
 }
 
-// ReadAlign_maxMappableLength2strands.cpp:12-109: one start offset iDist of the sparse-SA loop
-__device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u32 pieceStartIn, u32 pieceLengthIn, bool dirR, u32 iDist, u64 &Nrep, u64 &i0, u32 &maxL, SeedCnt &cn) {
-    u32 pieceStart; u32 pieceLength = pieceLengthIn - iDist;
+// ReadAlign_maxMappableLength2strands.cpp:23-84: the L-mer prefix of the piece, its SAindex entry (shortened while absent), the entry behind it, and what they say:
+//   kind 0  the first base is absent from the genome: nothing           kind 1  a prefix shorter than the table's L-mers pins the interval: [i1, i2], length maxL, no search
+//   kind 2  one suffix: its length is one compare away                   kind 3  bisection over [i1, i2] from a common length of maxL
+struct SeedLook { u64 i1, i2; u32 maxL, kind; };
+__device__ __forceinline__ SeedLook seedLookup(const DevIndex &X, const u8 *R, u32 pieceStart, u32 pieceLength, bool dirR, SeedCnt &cn) {
+    SeedLook k; k.i1 = 0; k.i2 = 0; k.maxL = 0; k.kind = 0;
     u32 Lmax = min(X.saiNbases, pieceLength);
     u64 ind1 = 0;
-    // L-mer prefix (ReadAlign_maxMappableLength2strands.cpp:23-37): 2 bits per base, first base most significant;
-    // the bases of a piece are all 0..3, so 8 of them are packed from one 8-byte word with shifts and masks
-    if (dirR) pieceStart = pieceStartIn + iDist; else pieceStart = pieceStartIn - iDist;
+    // L-mer prefix (:23-37): 2 bits per base, first base most significant; the bases of a piece are all 0..3, so 8 of them are packed from one 8-byte word with shifts and masks
     for (u32 ii = 0; ii < Lmax; ii += 8) {
         const u64 raw = dirR ? load8(R + pieceStart + ii) : load8rev(R + pieceStart - ii);     // byte k = code of the (ii+k)-th base of the scan
         const u32 nb = min(8u, Lmax - ii);
@@ -166,7 +167,7 @@ __device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u3
             // a code above 3 inside the prefix: only with --seedSearchLmax, whose backward search is given Shift + 1 bases (:from ReadAlign_mapOneRead.cpp:81-86)
             // and so runs over the start of its piece into an N, the mate spacer or the other mate.  The reference adds the code as it is
             // (index*4 + code, index*4 + (3 - code) in unsigned 64-bit arithmetic): the carries and borrows are part of its result
-            for (u32 k = 0; k < nb; k++) { const u64 cde = (raw >> (8 * k)) & 0xFFull; ind1 = (ind1 << 2) + (dirR ? cde : 3ull - cde); }
+            for (u32 k2 = 0; k2 < nb; k2++) { const u64 cde = (raw >> (8 * k2)) & 0xFFull; ind1 = (ind1 << 2) + (dirR ? cde : 3ull - cde); }
         }
     }
     u32 Lind = Lmax; u64 iSA1 = 0, iSA2;
@@ -177,23 +178,29 @@ __device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u3
         if ((iSA1 & X.saiAbsentBit) == 0) break;
         --Lind; ind1 >>= 2;
     }
-    if (Lind == 0) { Nrep = 0; i0 = 0; maxL = 0; return; }   // base absent from the genome (reference: out-of-bounds)
+    if (Lind == 0) return k;                                  // base absent from the genome (reference: out-of-bounds)
     bool iSA2good = true;
     if (X.saiStart[Lind - 1] + ind1 + 1 < X.saiStart[Lind]) {
         iSA2 = packedGet(X.SAi, X.saiStart[Lind - 1] + ind1 + 1, X.saiBits, X.saiMask); cn.nSAi++;
         if ((iSA2 & X.saiAbsentBit) == 0) iSA2 = (iSA2 & ~X.saiNbit) - 1;
         else { iSA2 = X.nSA - 1; iSA2good = false; }
     } else { iSA2 = X.nSA - 1; iSA2good = false; }
-    bool iSA1noN = (iSA1 & X.saiNbit) == 0;
+    const bool iSA1noN = (iSA1 & X.saiNbit) == 0;
+    if (Lind < X.saiNbases && iSA1noN && iSA2good) { k.i1 = iSA1; k.i2 = iSA2; k.maxL = Lind; k.kind = 1; }
+    else if (iSA1 == iSA2 && iSA1noN && iSA2good) { k.i1 = k.i2 = iSA1; k.maxL = Lind; k.kind = 2; }
+    else { k.i1 = iSA1 & ~X.saiNbit; k.i2 = iSA2; k.maxL = (iSA2good && iSA1noN) ? Lind : 0; k.kind = 3; }
+    return k;
+}
+
+// ReadAlign_maxMappableLength2strands.cpp:12-109: one start offset iDist of the sparse-SA loop
+__device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u32 pieceStartIn, u32 pieceLengthIn, bool dirR, u32 iDist, u64 &Nrep, u64 &i0, u32 &maxL, SeedCnt &cn) {
+    const u32 pieceLength = pieceLengthIn - iDist, pieceStart = dirR ? pieceStartIn + iDist : pieceStartIn - iDist;
+    const SeedLook k = seedLookup(X, R, pieceStart, pieceLength, dirR, cn);
     u64 i1;
-    if (Lind < X.saiNbases && iSA1noN && iSA2good) { i0 = iSA1; i1 = iSA2; Nrep = i1 - i0 + 1; maxL = Lind; }
-    else if (iSA1 == iSA2 && iSA1noN && iSA2good) {
-        i0 = i1 = iSA1; Nrep = 1; bool cr;
-        maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, Lind, iSA1, dirR, cr, cn);
-    } else {
-        maxL = (iSA2good && iSA1noN) ? Lind : 0;
-        Nrep = maxMappableLength(X, R, pieceStart, pieceLength, iSA1 & ~X.saiNbit, iSA2, dirR, maxL, i0, i1, cn);
-    }
+    if (k.kind == 0) { Nrep = 0; i0 = 0; maxL = 0; }
+    else if (k.kind == 1) { i0 = k.i1; Nrep = k.i2 - k.i1 + 1; maxL = k.maxL; }
+    else if (k.kind == 2) { i0 = k.i1; Nrep = 1; bool cr; maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, k.maxL, k.i1, dirR, cr, cn); }
+    else { maxL = k.maxL; Nrep = maxMappableLength(X, R, pieceStart, pieceLength, k.i1, k.i2, dirR, maxL, i0, i1, cn); }
 }
 
 // ReadAlign_maxMappableLength2strands.cpp:5-115.  The reference keeps (Nrep, ind0, maxL) of every start offset of a sparse suffix
@@ -264,27 +271,49 @@ __device__ __forceinline__ bool nextPiece(const u8 *R, u32 Lread, u32 &iR, u32 &
 __device__ __forceinline__ u32 startLmaxOf(const staramd_params &P, u32 Lread) { return min(P.seedSearchStartLmax, (u32)(u64)(P.seedSearchStartLmaxOverLread * (double)(u64)(Lread - 1))); }
 __device__ __forceinline__ u32 nStartOf(const staramd_params &P, u32 startLmax, u32 pL) { return (P.seedSearchStartLmax > 0 && startLmax < pL) ? pL / startLmax + 1 : 1; }
 
-// classification of a read whose searches are done (ReadAlign_mapOneRead.cpp:100-115) and its seeds into the pool
-__device__ static void finishRead(const DevIndex &X, DevBatch &B, u32 ir, u32 Lread, const SeedState &st, u32 Nsplit, u32 LgoodMin) {
-    const staramd_params &P = X.P;
-    DRead rd;
+// classification of a read whose searches are done (ReadAlign_mapOneRead.cpp:100-115); true: its st.nP seeds want a place in the pool
+__device__ __forceinline__ bool classifyRead(const staramd_params &P, DRead &rd, u32 Lread, const SeedState &st, u32 Nsplit, u32 LgoodMin) {
     rd.status = 0; rd.seedOffset = 0; rd.nSeeds = 0; rd.unmappedLength = 0; rd.winOffset = 0; rd.nWin = 0; rd.wtOffset = 0; rd.nWt = 0; rd.pruneBest = 0; rd.pad0 = 0;
     rd.maxScoreMate[0] = rd.maxScoreMate[1] = 0; rd.bestW = -1; rd.nTr = 0; rd.nEx = 0;
     if (st.fatal) rd.status |= STARAMD_ST_FATAL_SEEDS_PER_READ;
     else if (Lread < P.outFilterMatchNmin) { rd.status |= STARAMD_ST_READ_TOO_SHORT; rd.unmappedLength = 0; }
     else if (Nsplit == 0) { rd.status |= STARAMD_ST_NO_GOOD_PIECES; rd.unmappedLength = LgoodMin; }
     else if (st.nA == 0) { rd.status |= STARAMD_ST_ALL_PIECES_MULTI; rd.unmappedLength = st.multNminL; }
-    else {
-        u32 off = atomicAdd(&B.cursors[CUR_SEED], st.nP);
-        if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_SEEDPOOL); }
-        else {
-            rd.seedOffset = off; rd.nSeeds = st.nP;
-            for (u32 k = 0; k < st.nP; k++) B.seedPool[off + k] = st.PC[k];
-        }
-    }
+    else return true;
+    return false;
+}
+__device__ __forceinline__ void placeSeeds(DevBatch &B, DRead &rd, const SeedState &st, u32 off) {
+    if (off + st.nP > B.seedCap) { atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_SEEDPOOL); return; }
+    rd.seedOffset = off; rd.nSeeds = st.nP;
+    for (u32 k = 0; k < st.nP; k++) B.seedPool[off + k] = st.PC[k];
+}
+__device__ static void finishRead(const DevIndex &X, DevBatch &B, u32 ir, u32 Lread, const SeedState &st, u32 Nsplit, u32 LgoodMin) {
+    DRead rd;
+    if (classifyRead(X.P, rd, Lread, st, Nsplit, LgoodMin)) placeSeeds(B, rd, st, atomicAdd(&B.cursors[CUR_SEED], st.nP));
     B.reads[ir] = rd;
 }
 
+// 64 consecutive tickets for the wavefront, one atomic (all lanes arrive together): lane i holds base + i.  A counter serves ~0.5 G atomics/s whoever asks: 3.9 M units that each take
+// their own ticket are 8 ms of tickets (the whole of k_seed_units, session 4 of round 5)
+__device__ __forceinline__ u32 waveTickets(u32 *ctr, u32 lane) { u32 b = 0; if (lane == 0) b = atomicAdd(ctr, 64u); return first32(b) + lane; }
+// the lanes that `want` get consecutive places behind *ctr, one atomic per wavefront (all lanes arrive together)
+__device__ __forceinline__ u32 waveAppend(u32 *ctr, bool want, u32 lane) {
+    const u64 m = __ballot(want);
+    if (!m) return 0;
+    const u32 leader = firstLane(m);
+    u32 b = 0;
+    if (lane == leader) b = atomicAdd(ctr, (u32)__popcll(m));
+    return laneGet32(b, leader) + cntBelow(m);
+}
+__device__ __forceinline__ void addCounters(DevBatch &B, const SeedCnt &cn) {
+    const u32 a = waveSumU32(cn.nSAi), b = waveSumU32(cn.nSAprobe), c = waveSumU32(cn.nGcmp);
+    if (laneId() == 0) {
+        atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)a);
+        atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)b);
+        atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)c);
+    }
+}
+#define RCI(k) ((k) * CS)           // every round cursor in a cache line of its own (dev.h CS)
 #ifndef SEED_WAVES
 #define SEED_WAVES 8        // minimum waves per SIMD the register allocation is held to (8: 64 VGPRs + spills, 10 % faster than 4 at 1 Gb: more gather chains in flight)
 #endif
@@ -299,6 +328,7 @@ extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_search(cons
     const staramd_params &P = X.P;
     const u32 nItems = inList ? B.cursors[CUR_OVF_SEED] : B.nReads;
     for (;;) {
+        if (*(volatile u32 *)&B.cursors[CUR_TICKET_SEED] >= nItems) break;          // (a lane that comes for nothing does not queue for the counter)
         u32 it = atomicAdd(&B.cursors[CUR_TICKET_SEED], 1u);
         if (it >= nItems) break;
         const u32 ir = inList ? inList[it] : it;
@@ -321,10 +351,8 @@ extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_search(cons
         nSeedsTot += st.nP;
         finishRead(X, B, ir, Lread, st, Nsplit, LgoodMin);
     }
-    atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)cn.nSAi);
-    atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)cn.nSAprobe);
-    atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);
-    atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
+    addCounters(B, cn);
+    { const u32 ns = waveSumU32((u32)nSeedsTot); if (laneId() == 0) atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)ns); }
 }
 
 // ---- lane = unit -------------------------------------------------------------------------------------------------------------------------------------------
@@ -341,10 +369,11 @@ struct SlotSink {
 
 extern "C" __global__ void __launch_bounds__(256) k_seed_plan(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W) {
     const DevIndex &X = *Xp; const staramd_params &P = X.P;
-    const u32 ir = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ir >= B.nReads) return;
+    const u32 ir0 = blockIdx.x * blockDim.x + threadIdx.x, lane = laneId();
+    const bool live = ir0 < B.nReads;
+    const u32 ir = live ? ir0 : 0u;                  // (the lanes behind the last read stay for the wavefront's scan and write nothing)
     const u8 *R = B.bases + B.readOffset[ir];
-    const u32 Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
+    const u32 Lread = live ? (u32)(B.readOffset[ir + 1] - B.readOffset[ir]) : 0u;
     const u32 startLmax = startLmaxOf(P, Lread);
     u32 Nsplit = 0, LgoodMin = 0, nGroups = 0, nUnits = 0;
     { u32 iR = 0, iFrag = 0, pS = 0, pL = 0;
@@ -356,9 +385,19 @@ extern "C" __global__ void __launch_bounds__(256) k_seed_plan(const DevIndex *__
           nGroups += 2u * Nstart; nUnits += 2u * Nstart - 1u;
       } }
     SeedPlan pl; pl.group0 = 0; pl.nGroups = (u16)min(nGroups, 0xFFFFu); pl.nSplit = (u16)Nsplit; pl.LgoodMin = (u16)min(LgoodMin, 0xFFFFu); pl.handOn = 0; pl.pad = 0;
-    if (nGroups) {
-        const u32 g0 = atomicAdd(&B.cursors[CUR_SEED_GROUPS], nGroups), u0 = atomicAdd(&B.cursors[CUR_SEED_UNITS], nUnits);
-        const bool fits = g0 + nGroups <= W.groupCap && u0 + nUnits <= W.unitCap && nGroups <= 0xFFFFu && Lread <= 0x7FFFu;
+    // groups and units of the wavefront's 64 reads in one piece each: two atomics per wavefront (an exclusive scan over the lanes gives every read its place)
+    const bool huge = nGroups > 0x3FFu;              // (a read of hundreds of pieces: the general kernel)
+    u32 packed = huge ? 0u : (nGroups | (nUnits << 16)), incl = packed;
+    for (u32 d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl((int)incl, (int)(lane >= d ? lane - d : 0u), 64); if (lane >= d) incl += o; }
+    const u32 tot = (u32)__shfl((int)incl, 63, 64);
+    u32 gBase = 0, uBase = 0;
+    if (lane == 0 && tot) { gBase = atomicAdd(&B.cursors[CUR_SEED_GROUPS], tot & 0xFFFFu); uBase = atomicAdd(&B.cursors[CUR_SEED_UNITS], tot >> 16); }
+    gBase = first32(gBase); uBase = first32(uBase);
+    if (!live) return;
+    if (huge) pl.handOn = 1;
+    else if (nGroups) {
+        const u32 g0 = gBase + ((incl - packed) & 0xFFFFu), u0 = uBase + ((incl - packed) >> 16);
+        const bool fits = g0 + nGroups <= W.groupCap && u0 + nUnits <= W.unitCap && Lread <= 0x7FFFu;
         if (!fits) {
             // the unit slots of this read that lie inside the pool are marked empty (the cursor has counted them); the read takes the general kernel
             for (u32 u = u0; u < u0 + nUnits && u < W.unitCap; u++) W.units[u].read = 0xFFFFFFFFu;
@@ -389,6 +428,7 @@ extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_units(const
     SeedCnt cn = {0, 0, 0};
     const u32 nUnits = min(B.cursors[CUR_SEED_UNITS], W.unitCap);
     for (;;) {
+        if (*(volatile u32 *)&B.cursors[CUR_TICKET_SEED_UNITS] >= nUnits) break;      // (a lane that comes for nothing does not queue for the counter)
         const u32 u = atomicAdd(&B.cursors[CUR_TICKET_SEED_UNITS], 1u);
         if (u >= nUnits) break;
         const SeedUnit un = W.units[u];
@@ -404,32 +444,205 @@ extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_units(const
             W.groupHead[g] = sink.n | (iDir << 8) | (iFrag << 16) | (sink.over ? 0x80000000u : 0u);
         }
     }
-    atomicAdd((unsigned long long *)&B.counters[DC_nSAi], (unsigned long long)cn.nSAi);
-    atomicAdd((unsigned long long *)&B.counters[DC_nSAprobe], (unsigned long long)cn.nSAprobe);
-    atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)cn.nGcmp);
+    addCounters(B, cn);
 }
 
 extern "C" __global__ void __launch_bounds__(256) k_seed_merge(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, DSeed *scratch, u32 scratchPerLane) {
     const DevIndex &X = *Xp;
-    const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
-    SeedState st; st.PC = scratch + (u64)lane * scratchPerLane; st.cap = scratchPerLane;
-    u64 nSeedsTot = 0;
-    for (u32 ir = lane; ir < B.nReads; ir += gridDim.x * blockDim.x) {
-        const SeedPlan pl = W.plan[ir];
-        bool handOn = pl.handOn != 0;
-        for (u32 g = 0; g < pl.nGroups && !handOn; g++) handOn = (W.groupHead[pl.group0 + g] & 0x80000000u) != 0;       // a unit found more seeds than it has slots
-        if (handOn) { const u32 k = atomicAdd(&B.cursors[CUR_OVF_SEED], 1u); W.handOn[k] = ir; continue; }
-        st.nP = 0; st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
-        for (u32 g = 0; g < pl.nGroups; g++) {
-            const u32 h = W.groupHead[pl.group0 + g];
-            const SeedSlot *c = W.slots + (u64)(pl.group0 + g) * SEED_SLOTS;
-            for (u32 k = 0; k < (h & 0xFFu); k++) {
-                const SeedSlot x = c[k];
-                storeAligns(X, st, (h >> 8) & 1u, x.shift, (x.L & 0x8000u) ? 0x100000000ull : (u64)x.nrep, x.L & 0x7FFFu, x.i0, (h >> 16) & 0xFFu);
+    const u32 gl = blockIdx.x * blockDim.x + threadIdx.x, lane = laneId();
+    SeedState st; st.PC = scratch + (u64)gl * scratchPerLane; st.cap = scratchPerLane;
+    u32 nSeedsTot = 0;
+    for (u32 ir0 = 0; ir0 < B.nReads; ir0 += gridDim.x * blockDim.x) {           // (the lanes of a wavefront go round together: one pool allocation per wavefront and trip)
+        const u32 ir = ir0 + gl;
+        bool live = ir < B.nReads, wants = false;
+        SeedPlan pl; DRead rd;
+        if (live) {
+            pl = W.plan[ir];
+            bool handOn = pl.handOn != 0;
+            for (u32 g = 0; g < pl.nGroups && !handOn; g++) handOn = (W.groupHead[pl.group0 + g] & 0x80000000u) != 0;       // a unit ran out of slots (or met an interval of > 2^32 entries)
+            if (handOn) { const u32 k = atomicAdd(&B.cursors[CUR_OVF_SEED], 1u); W.handOn[k] = ir; live = false; }
+        }
+        st.nP = 0;
+        if (live) {
+            st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
+            for (u32 g = 0; g < pl.nGroups; g++) {
+                const u32 h = W.groupHead[pl.group0 + g];
+                const SeedSlot *c = W.slots + (u64)(pl.group0 + g) * SEED_SLOTS;
+                for (u32 k = 0; k < (h & 0xFFu); k++) {
+                    const SeedSlot x = c[k];
+                    storeAligns(X, st, (h >> 8) & 1u, x.shift, (x.L & 0x8000u) ? 0x100000000ull : (u64)x.nrep, x.L & 0x7FFFu, x.i0, (h >> 16) & 0xFFu);
+                }
+            }
+            nSeedsTot += st.nP;
+            wants = classifyRead(X.P, rd, (u32)(B.readOffset[ir + 1] - B.readOffset[ir]), st, pl.nSplit, pl.LgoodMin);
+        }
+        const u32 need = wants ? st.nP : 0u;
+        u32 incl = need;
+        for (u32 d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl((int)incl, (int)(lane >= d ? lane - d : 0u), 64); if (lane >= d) incl += o; }
+        const u32 tot = (u32)__shfl((int)incl, 63, 64);
+        u32 base = 0;
+        if (lane == 0 && tot) base = atomicAdd(&B.cursors[CUR_SEED], tot);
+        base = first32(base);
+        if (live) { if (wants) placeSeeds(B, rd, st, base + incl - need); B.reads[ir] = rd; }
+    }
+    { const u32 ns = waveSumU32(nSeedsTot); if (lane == 0) atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)ns); }
+}
+
+// ---- lane = unit, in ROUNDS ----------------------------------------------------------------------------------------------------------------------------------
+// k_seed_units runs the one to three searches of a unit back to back on its lane; what the 64 lanes of its wavefronts then disagree on is the inside of a search: bisections of 2 to
+// 30 steps, compares of 1 to 13 words, two boundary bisections -- ~3 of 64 lanes active on the average instruction.  A round takes ONE search of every unit that has one left, in
+// two kernels with the work sorted in between:
+//   k_seed_lookup  lane = unit: the L-mer prefix, its SAindex entries (two or three dependent loads, the same for every lane) and the searches that end there (interval pinned by
+//                  a short prefix; one suffix to compare with); a bisection goes into the bucket of its interval length
+//   k_seed_bisect  lane = bisection, bucket by bucket: the lanes of a wavefront bisect intervals of about the same length, i.e. about the same number of steps
+// and both hand the unit on to the next round when it has a search left.  The state of a unit between rounds is 8 bytes.  Full suffix arrays only (one start offset per search).
+struct UnitSearch { u32 shift, N, iDir; };
+// the search a unit is at, or false (and leg = DONE) when it has none left: the loop conditions of ReadAlign_mapOneRead.cpp:57-92 as transitions
+__device__ __forceinline__ bool currentSearch(const staramd_params &P, const SeedUnit &un, SeedUState &st, UnitSearch &q) {
+    const u32 pS = un.pS, pL = un.pL, istart = un.istart, Lstart = pL / un.nstart;
+    for (;;) {
+        if (st.leg >= SEED_LEG_DONE) return false;
+        const u32 second = st.leg >> 1;                                              // 0: the unit's first direction, 1: its second
+        const u32 iDir = un.kind == 2u ? 1u : (un.kind == 1u ? 0u : second);
+        if (second == 1u && un.kind != 0u) { st.leg = SEED_LEG_DONE; return false; }
+        if ((st.leg & 1u) == 0u) {                                                  // the restart loop (:62-80)
+            // (:62 looks at flagDirMap once, before the loop: a loop that is under way -- Lmapped > 0 -- goes on whatever its first search did to the flag)
+            const bool enter = (st.Lmapped > 0 || (st.flags & 1u) || istart > 0) && istart * Lstart + st.Lmapped + P.seedMapMin < pL;
+            if (enter) { q.iDir = iDir; q.shift = iDir == 0 ? (pS + istart * Lstart + st.Lmapped) : (pS + pL - istart * Lstart - 1 - st.Lmapped); q.N = pL - st.Lmapped - istart * Lstart; return true; }
+            st.leg++;
+        } else {                                                                     // the extra search of --seedSearchLmax (:81-91)
+            if (P.seedSearchLmax > 0) { q.iDir = iDir; q.shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1); q.N = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - q.shift) : (q.shift + 1)); return true; }
+            st.leg++; st.Lmapped = 0;
+        }
+    }
+}
+// the result of the search currentSearch returned: the seed into its slot (:99-109 of maxMappableLength2strands: stored when it has loci), the state one step on
+__device__ __forceinline__ void searchDone(const staramd_params &P, const SeedWork &W, const SeedUnit &un, SeedUState &st, const UnitSearch &q, u32 Lm, u64 Nrep, u64 i0) {
+    const u32 second = st.leg >> 1;
+    if (Nrep > 0) {
+        u8 &n = second ? st.n1 : st.n0;
+        if (n >= W.slotLimit) { st.flags |= 2u; st.leg = SEED_LEG_DONE; return; }
+        SeedSlot c; c.i0 = i0; c.nrep = (u32)min(Nrep, (u64)0xFFFFFFFFu); c.shift = (u16)q.shift; c.L = (u16)(Lm | (Nrep > 0xFFFFFFFFull ? 0x8000u : 0u));
+        W.slots[(u64)(un.group + (second ? un.nstart : 0u)) * SEED_SLOTS + n] = c;
+        n++;
+    }
+    if ((st.leg & 1u) == 0u) {
+        if (q.iDir == 0 && un.istart == 0 && st.Lmapped == 0 && q.shift + Lm == (u32)un.pL) st.flags &= ~1u;      // :74
+        st.Lmapped = (u16)(st.Lmapped + Lm);
+        if (Lm == 0) st.leg++;                                                     // (else the loop condition is looked at again by currentSearch)
+    } else { st.leg++; st.Lmapped = 0; }
+}
+__device__ __forceinline__ u32 seedClassOf(u32 range) { return range < 3u ? 0u : range < 15u ? 1u : range < 63u ? 2u : range < 255u ? 3u : range < 4095u ? 4u : 5u; }
+
+extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_lookup(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, u32 round) {
+    const DevIndex &X = *Xp; const staramd_params &P = X.P;
+    const u32 lane = laneId();
+    SeedCnt cn = {0, 0, 0};
+    const u32 nAct = round == 0u ? min(B.cursors[CUR_SEED_UNITS], W.unitCap) : W.rc[RCI(RC_ACT + round)];
+    const u32 *act = W.act[round & 1u]; u32 *next = W.act[(round + 1u) & 1u];
+    for (;;) {
+        const u32 t = waveTickets(&W.rc[RCI(RC_TICKET_L + round)], lane);
+        if (first32(t) >= nAct) break;
+        u32 u = 0, cls = SEED_CLASSES; bool again = false; SeedTask tk;
+        if (t < nAct) {
+            u = round == 0u ? t : act[t];
+            const SeedUnit un = W.units[u];
+            if (un.read != 0xFFFFFFFFu) {
+                SeedUState st;
+                if (round == 0u) { st.Lmapped = 0; st.leg = SEED_LEG_LOOP0; st.flags = 1u; st.n0 = st.n1 = 0; st.pad[0] = st.pad[1] = 0; } else st = W.ustate[u];
+                UnitSearch q;
+                if (currentSearch(P, un, st, q)) {
+                    const u8 *R = B.bases + B.readOffset[un.read];
+                    const bool dirR = q.iDir == 0;
+                    const SeedLook k = seedLookup(X, R, q.shift, q.N, dirR, cn);
+                    if (k.kind == 0) searchDone(P, W, un, st, q, 0, 0, 0);
+                    else if (k.kind == 1) searchDone(P, W, un, st, q, k.maxL, k.i2 - k.i1 + 1, k.i1);
+                    else if (k.kind == 2) { bool cr; const u32 L = compareSeqToGenome(X, R, q.shift, q.N, k.maxL, k.i1, dirR, cr, cn); searchDone(P, W, un, st, q, L, 1, k.i1); }
+                    else if (k.i2 - k.i1 >= 0xFFFFFFFFull) { st.flags |= 2u; st.leg = SEED_LEG_DONE; }        // an interval up to the end of the suffix array: the general kernel bisects it in 64 bits
+                    else {
+                        const u32 range = (u32)(k.i2 - k.i1); cls = seedClassOf(range);
+                        tk.i1 = k.i1; tk.range = range; tk.unit = u; tk.shift = (u16)q.shift; tk.N = (u16)q.N; tk.maxL = (u16)k.maxL; tk.dirR = dirR ? 1 : 0; tk.pad = 0;
+                    }
+                    UnitSearch q2;
+                    again = cls == SEED_CLASSES && currentSearch(P, un, st, q2);
+                }
+                W.ustate[u] = st;
             }
         }
-        nSeedsTot += st.nP;
-        finishRead(X, B, ir, (u32)(B.readOffset[ir + 1] - B.readOffset[ir]), st, pl.nSplit, pl.LgoodMin);
+        for (u32 c = 0; c < SEED_CLASSES; c++) { const u32 at = waveAppend(&W.rc[RCI(RC_BUCKET + round * SEED_CLASSES + c)], cls == c, lane); if (cls == c) W.bucket[c][at] = tk; }
+        { const u32 at = waveAppend(&W.rc[RCI(RC_ACT + round + 1u)], again, lane); if (again) next[at] = u; }
     }
-    atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
+    addCounters(B, cn);
+}
+
+extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_bisect(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, u32 round) {
+    const DevIndex &X = *Xp; const staramd_params &P = X.P;
+    const u32 lane = laneId();
+    SeedCnt cn = {0, 0, 0};
+    u32 *next = W.act[(round + 1u) & 1u];
+    for (u32 c = 0; c < SEED_CLASSES; c++) {
+        const u32 nTask = W.rc[RCI(RC_BUCKET + round * SEED_CLASSES + c)];
+        for (;;) {
+            const u32 t = waveTickets(&W.rc[RCI(RC_TICKET_B + round * SEED_CLASSES + c)], lane);
+            if (first32(t) >= nTask) break;
+            bool again = false; u32 unit = 0;
+            if (t < nTask) {
+                const SeedTask tk = W.bucket[c][t];
+                unit = tk.unit;
+                const SeedUnit un = W.units[unit];
+                SeedUState st = W.ustate[unit];
+                const u8 *R = B.bases + B.readOffset[un.read];
+                u32 L = tk.maxL; u64 i0, i1;
+                const u64 Nrep = maxMappableLengthT<u32>(X, R, tk.shift, tk.N, tk.i1, tk.i1 + tk.range, tk.dirR != 0, L, i0, i1, cn);
+                UnitSearch q; q.shift = tk.shift; q.N = tk.N; q.iDir = tk.dirR ? 0u : 1u;
+                searchDone(P, W, un, st, q, L, Nrep, i0);
+                UnitSearch q2;
+                again = currentSearch(P, un, st, q2);
+                W.ustate[unit] = st;
+            }
+            const u32 at = waveAppend(&W.rc[RCI(RC_ACT + round + 1u)], again, lane);
+            if (again) next[at] = unit;
+        }
+    }
+    addCounters(B, cn);
+}
+
+// the units that still have searches left after the last round finish them back to back (error-rich reads: a restart loop of many short prefixes)
+extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_tail(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, u32 round) {
+    const DevIndex &X = *Xp; const staramd_params &P = X.P;
+    SeedCnt cn = {0, 0, 0};
+    const u32 nAct = W.rc[RCI(RC_ACT + round)];
+    const u32 *act = W.act[round & 1u];
+    for (;;) {
+        if (*(volatile u32 *)&W.rc[RCI(RC_TICKET_L + round)] >= nAct) break;         // (a lane that comes for nothing does not queue for the counter)
+        const u32 t = atomicAdd(&W.rc[RCI(RC_TICKET_L + round)], 1u);
+        if (t >= nAct) break;
+        const u32 u = act[t];
+        const SeedUnit un = W.units[u];
+        SeedUState st = W.ustate[u];
+        const u8 *R = B.bases + B.readOffset[un.read];
+        UnitSearch q;
+        while (currentSearch(P, un, st, q)) {
+            const bool dirR = q.iDir == 0;
+            u64 Nrep, i0; u32 L;
+            searchOneDist(X, R, q.shift, q.N, dirR, 0u, Nrep, i0, L, cn);
+            searchDone(P, W, un, st, q, L, Nrep, i0);
+        }
+        W.ustate[u] = st;
+    }
+    addCounters(B, cn);
+}
+
+// after the last round: the header of every group of every unit -- slots filled, direction, mate; handed on when the unit ran out of slots or of rounds
+extern "C" __global__ void __launch_bounds__(256) k_seed_heads(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W) {
+    const u32 nUnits = min(B.cursors[CUR_SEED_UNITS], W.unitCap);
+    for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < nUnits; u += gridDim.x * blockDim.x) {
+        const SeedUnit un = W.units[u];
+        if (un.read == 0xFFFFFFFFu) continue;
+        const SeedUState st = W.ustate[u];
+        const u32 over = ((st.flags & 2u) || st.leg < SEED_LEG_DONE) ? 0x80000000u : 0u;
+        const u32 dir0 = un.kind == 2u ? 1u : 0u;
+        W.groupHead[un.group] = st.n0 | (dir0 << 8) | ((u32)un.iFrag << 16) | over;
+        if (un.kind == 0u) W.groupHead[un.group + un.nstart] = st.n1 | (1u << 8) | ((u32)un.iFrag << 16) | over;
+    }
 }
