@@ -57,16 +57,7 @@ struct DSeed { u64 saStart; u32 nrep; u16 rStart, L; u8 dir, iFrag; u8 pad[6]; }
 struct SeedSlot { u64 i0; u32 nrep; u16 shift, L; };                                   // L bit 15: Nrep does not fit 32 bits
 struct SeedUnit { u32 read, group; u16 pS, pL; u8 iFrag, istart, nstart, kind; };      // kind 0: forward + backward from start point 0; 1: forward; 2: backward
 struct SeedPlan { u32 group0; u16 nGroups, nSplit, LgoodMin, handOn; u32 pad; };
-// the unit mapping in ROUNDS (k_seed_lookup / k_seed_bisect): what is left of a unit between two rounds, and a bisection waiting in its bucket
-struct SeedUState { u16 Lmapped; u8 leg, flags; u8 n0, n1; u8 pad[2]; };              // leg: SEED_LEG_*; flags: bit 0 flagDirMap, bit 1 handed on (slots full / interval too long); n0 / n1: slots filled, first / second direction
-struct SeedTask { u64 i1; u32 range, unit; u16 shift, N, maxL; u8 dirR, pad; };        // [i1, i1 + range] with a common length of maxL; the search: N bases from `shift` on
-enum { SEED_LEG_LOOP0 = 0, SEED_LEG_LMAX0 = 1, SEED_LEG_LOOP1 = 2, SEED_LEG_LMAX1 = 3, SEED_LEG_DONE = 4 };
-#define SEED_CLASSES 6u             // buckets of interval length: [1,4) [4,16) [16,64) [64,256) [256,4096) [4096,2^32)
-#define SEED_ROUNDS_MAX 12u
-// round cursors (u32 words of SeedWork::rc, zeroed per batch): active units of round r, tickets of the two kernels of round r, tasks and tickets per bucket of round r
-enum { RC_ACT = 0, RC_TICKET_L = RC_ACT + SEED_ROUNDS_MAX + 1, RC_BUCKET = RC_TICKET_L + SEED_ROUNDS_MAX + 1, RC_TICKET_B = RC_BUCKET + SEED_ROUNDS_MAX * SEED_CLASSES, RC_N = RC_TICKET_B + SEED_ROUNDS_MAX * SEED_CLASSES };
-struct SeedWork { SeedUnit *units; u32 unitCap; SeedSlot *slots; u32 *groupHead; u32 groupCap; SeedPlan *plan; u32 *handOn; u32 slotLimit;      // slotLimit <= SEED_SLOTS (tests lower it)
-                  SeedUState *ustate; u32 *act[2]; SeedTask *bucket[SEED_CLASSES]; u32 *rc; u32 rounds; };
+struct SeedWork { SeedUnit *units; u32 unitCap; SeedSlot *slots; u32 *groupHead; u32 groupCap; SeedPlan *plan; u32 *handOn; u32 slotLimit; };      // slotLimit <= SEED_SLOTS (tests lower it)
 // one row of the reference's WA table (IncludeDefine.h:197-204)
 struct DWA { u64 gStart; u32 nrep; u16 L, rStart; i32 sjA; u8 anchor, iFrag; u8 pad[2]; };
 // window with seeds, output of the window kernel

@@ -17,10 +17,6 @@
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane, const u32 *inList);
 extern "C" __global__ void k_seed_plan(const DevIndex *X, DevBatch B, SeedWork W);
 extern "C" __global__ void k_seed_units(const DevIndex *X, DevBatch B, SeedWork W);
-extern "C" __global__ void k_seed_lookup(const DevIndex *X, DevBatch B, SeedWork W, u32 round);
-extern "C" __global__ void k_seed_bisect(const DevIndex *X, DevBatch B, SeedWork W, u32 round);
-extern "C" __global__ void k_seed_tail(const DevIndex *X, DevBatch B, SeedWork W, u32 round);
-extern "C" __global__ void k_seed_heads(const DevIndex *X, DevBatch B, SeedWork W);
 extern "C" __global__ void k_seed_merge(const DevIndex *X, DevBatch B, SeedWork W, DSeed *scratch, u32 scratchPerLane);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
 extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);
@@ -298,8 +294,7 @@ static int allocWork(staramd_ctx *c) {
     c->seedLanes = (lanes / 256) * 256;
     c->seedPerLane = P.seedPerReadNmax + 1;
     if ((rc = devAlloc(R, &c->scrSeed, (u64)c->seedLanes * c->seedPerLane))) return rc;
-    // 0: a lane per read (k_seed_search over every read); 1: a lane per unit, its searches back to back (k_seed_units); 2: a lane per unit in rounds, the bisections of a round
-    // sorted by interval length (k_seed_lookup / k_seed_bisect) -- full suffix arrays only
+    // 0: a lane per read (k_seed_search over every read); 1: a lane per unit of the search schedule (k_seed_plan / k_seed_units / k_seed_merge)
     c->seedUnits = envU32("STARAMD_SEED_UNITS", 1);
     if (c->seedUnits) {
         // 2x101 has 12 groups / 10 units per pair, 2x150 16 / 14; a read that does not fit what is left of the pools takes k_seed_search (no regrowth, no re-run)
@@ -312,13 +307,6 @@ static int allocWork(staramd_ctx *c) {
         if ((rc = devAlloc(R, &W.groupHead, (u64)W.groupCap))) return rc;
         if ((rc = devAlloc(R, &W.plan, (u64)N))) return rc;
         if ((rc = devAlloc(R, &W.handOn, (u64)N))) return rc;
-        if (c->seedUnits >= 2) {
-            W.rounds = std::min<u32>(SEED_ROUNDS_MAX, std::max<u32>(1, envU32("STARAMD_SEED_ROUNDS", 6)));
-            if ((rc = devAlloc(R, &W.ustate, (u64)W.unitCap))) return rc;
-            for (int k = 0; k < 2; k++) if ((rc = devAlloc(R, &W.act[k], (u64)W.unitCap))) return rc;
-            for (u32 k = 0; k < SEED_CLASSES; k++) if ((rc = devAlloc(R, &W.bucket[k], (u64)W.unitCap))) return rc;
-            if ((rc = devAlloc(R, &W.rc, (u64)RC_N * CS))) return rc;
-        }
         int upCU = seedPerCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&upCU, k_seed_units, 256, 0) != hipSuccess || upCU < 1) upCU = seedPerCU;
         c->seedUnitLanes = envU32("STARAMD_SEED_UNIT_LANES", (u32)c->nCU * (u32)upCU * 256u) / 256u * 256u;
@@ -625,15 +613,6 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
         u32 lanes = std::min<u32>(c->seedLanes, ((n + 255) / 256) * 256);
         if (c->seedUnits) {
             hipLaunchKernelGGL(k_seed_plan, dim3((n + 255) / 256), block, 0, s, c->dX, B, c->seedWork);
-            if (c->seedUnits >= 2 && c->X.sparseD == 1) {          // (a sparse suffix array has several start offsets per search: the units then run their searches back to back)
-                HIPCHK(hipMemsetAsync(c->seedWork.rc, 0, (size_t)RC_N * CS * sizeof(u32), s));
-                for (u32 r = 0; r < c->seedWork.rounds; r++) {
-                    hipLaunchKernelGGL(k_seed_lookup, dim3(c->seedUnitLanes / 256), block, 0, s, c->dX, B, c->seedWork, r);
-                    hipLaunchKernelGGL(k_seed_bisect, dim3(c->seedUnitLanes / 256), block, 0, s, c->dX, B, c->seedWork, r);
-                }
-                hipLaunchKernelGGL(k_seed_tail, dim3(std::min<u32>(c->seedUnitLanes / 256, 1024u)), block, 0, s, c->dX, B, c->seedWork, c->seedWork.rounds);
-                hipLaunchKernelGGL(k_seed_heads, dim3(std::min<u32>(c->seedUnitLanes / 256, 2048u)), block, 0, s, c->dX, B, c->seedWork);
-            } else
             hipLaunchKernelGGL(k_seed_units, dim3(c->seedUnitLanes / 256), block, 0, s, c->dX, B, c->seedWork);
             hipLaunchKernelGGL(k_seed_merge, dim3(lanes / 256), block, 0, s, c->dX, B, c->seedWork, c->scrSeed, c->seedPerLane);
             hipLaunchKernelGGL(k_seed_search, dim3(std::min<u32>(lanes / 256, 64u)), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane, (const u32 *)c->seedWork.handOn);      // what the units handed on (rarely anything)

@@ -16,7 +16,10 @@
 //                 search of start point 0 in one unit (the quirk stays inside a lane); slots for what each unit finds, in schedule order
 //   k_seed_units  lane = unit (persistent lanes, ticket): the restart loop of one start point -- one to three searches -- into its slots
 //   k_seed_merge  lane = read: the slots in schedule order through storeAligns, classification of the read, seeds into the pool
-// A wavefront of k_seed_units holds 64 chains that are all at the same level of the same (shallow) nest.  Reads whose units or slots do not fit the pools, or a
+// A wavefront of k_seed_units holds 64 chains that are all at the same level of the same (shallow) nest.  Measured (profiles/r05_ab_session3_*, r05_ab_sessions4-6_*): on
+// par with the lane-per-read form (k_seed_units 8.9 + k_seed_merge 1.45 + k_seed_plan 0.25 ms against 10.3): the stage does not wait for its divergence.  A third form -- the
+// searches of all units in ROUNDS, a lookup kernel and a bisection kernel per round with the bisections sorted by interval length -- was built, measured (11.4 - 19.8 ms:
+// every kernel boundary waits for the slowest chain, a search in a repeat) and removed the same day.  Reads whose units or slots do not fit the pools, or a
 // unit that finds more than SEED_SLOTS seeds, take k_seed_search (lane = read, the whole nest: the general form, no limits of its own) through a list.
 #include "dev.h"
 
@@ -293,18 +296,7 @@ __device__ static void finishRead(const DevIndex &X, DevBatch &B, u32 ir, u32 Lr
     B.reads[ir] = rd;
 }
 
-// 64 consecutive tickets for the wavefront, one atomic (all lanes arrive together): lane i holds base + i.  A counter serves ~0.5 G atomics/s whoever asks: 3.9 M units that each take
-// their own ticket are 8 ms of tickets (the whole of k_seed_units, session 4 of round 5)
-__device__ __forceinline__ u32 waveTickets(u32 *ctr, u32 lane) { u32 b = 0; if (lane == 0) b = atomicAdd(ctr, 64u); return first32(b) + lane; }
-// the lanes that `want` get consecutive places behind *ctr, one atomic per wavefront (all lanes arrive together)
-__device__ __forceinline__ u32 waveAppend(u32 *ctr, bool want, u32 lane) {
-    const u64 m = __ballot(want);
-    if (!m) return 0;
-    const u32 leader = firstLane(m);
-    u32 b = 0;
-    if (lane == leader) b = atomicAdd(ctr, (u32)__popcll(m));
-    return laneGet32(b, leader) + cntBelow(m);
-}
+// (a counter in global memory serves ~0.5 G atomics/s whoever asks -- profiles/r05_ab_sessions4-6_*: what every lane of a kernel adds at its end is summed per wavefront first)
 __device__ __forceinline__ void addCounters(DevBatch &B, const SeedCnt &cn) {
     const u32 a = waveSumU32(cn.nSAi), b = waveSumU32(cn.nSAprobe), c = waveSumU32(cn.nGcmp);
     if (laneId() == 0) {
@@ -313,7 +305,6 @@ __device__ __forceinline__ void addCounters(DevBatch &B, const SeedCnt &cn) {
         atomicAdd((unsigned long long *)&B.counters[DC_nGcmp], (unsigned long long)c);
     }
 }
-#define RCI(k) ((k) * CS)           // every round cursor in a cache line of its own (dev.h CS)
 #ifndef SEED_WAVES
 #define SEED_WAVES 8        // minimum waves per SIMD the register allocation is held to (8: 64 VGPRs + spills, 10 % faster than 4 at 1 Gb: more gather chains in flight)
 #endif
@@ -486,163 +477,4 @@ extern "C" __global__ void __launch_bounds__(256) k_seed_merge(const DevIndex *_
         if (live) { if (wants) placeSeeds(B, rd, st, base + incl - need); B.reads[ir] = rd; }
     }
     { const u32 ns = waveSumU32(nSeedsTot); if (lane == 0) atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)ns); }
-}
-
-// ---- lane = unit, in ROUNDS ----------------------------------------------------------------------------------------------------------------------------------
-// k_seed_units runs the one to three searches of a unit back to back on its lane; what the 64 lanes of its wavefronts then disagree on is the inside of a search: bisections of 2 to
-// 30 steps, compares of 1 to 13 words, two boundary bisections -- ~3 of 64 lanes active on the average instruction.  A round takes ONE search of every unit that has one left, in
-// two kernels with the work sorted in between:
-//   k_seed_lookup  lane = unit: the L-mer prefix, its SAindex entries (two or three dependent loads, the same for every lane) and the searches that end there (interval pinned by
-//                  a short prefix; one suffix to compare with); a bisection goes into the bucket of its interval length
-//   k_seed_bisect  lane = bisection, bucket by bucket: the lanes of a wavefront bisect intervals of about the same length, i.e. about the same number of steps
-// and both hand the unit on to the next round when it has a search left.  The state of a unit between rounds is 8 bytes.  Full suffix arrays only (one start offset per search).
-struct UnitSearch { u32 shift, N, iDir; };
-// the search a unit is at, or false (and leg = DONE) when it has none left: the loop conditions of ReadAlign_mapOneRead.cpp:57-92 as transitions
-__device__ __forceinline__ bool currentSearch(const staramd_params &P, const SeedUnit &un, SeedUState &st, UnitSearch &q) {
-    const u32 pS = un.pS, pL = un.pL, istart = un.istart, Lstart = pL / un.nstart;
-    for (;;) {
-        if (st.leg >= SEED_LEG_DONE) return false;
-        const u32 second = st.leg >> 1;                                              // 0: the unit's first direction, 1: its second
-        const u32 iDir = un.kind == 2u ? 1u : (un.kind == 1u ? 0u : second);
-        if (second == 1u && un.kind != 0u) { st.leg = SEED_LEG_DONE; return false; }
-        if ((st.leg & 1u) == 0u) {                                                  // the restart loop (:62-80)
-            // (:62 looks at flagDirMap once, before the loop: a loop that is under way -- Lmapped > 0 -- goes on whatever its first search did to the flag)
-            const bool enter = (st.Lmapped > 0 || (st.flags & 1u) || istart > 0) && istart * Lstart + st.Lmapped + P.seedMapMin < pL;
-            if (enter) { q.iDir = iDir; q.shift = iDir == 0 ? (pS + istart * Lstart + st.Lmapped) : (pS + pL - istart * Lstart - 1 - st.Lmapped); q.N = pL - st.Lmapped - istart * Lstart; return true; }
-            st.leg++;
-        } else {                                                                     // the extra search of --seedSearchLmax (:81-91)
-            if (P.seedSearchLmax > 0) { q.iDir = iDir; q.shift = iDir == 0 ? (pS + istart * Lstart) : (pS + pL - istart * Lstart - 1); q.N = min(P.seedSearchLmax, iDir == 0 ? (pS + pL - q.shift) : (q.shift + 1)); return true; }
-            st.leg++; st.Lmapped = 0;
-        }
-    }
-}
-// the result of the search currentSearch returned: the seed into its slot (:99-109 of maxMappableLength2strands: stored when it has loci), the state one step on
-__device__ __forceinline__ void searchDone(const staramd_params &P, const SeedWork &W, const SeedUnit &un, SeedUState &st, const UnitSearch &q, u32 Lm, u64 Nrep, u64 i0) {
-    const u32 second = st.leg >> 1;
-    if (Nrep > 0) {
-        u8 &n = second ? st.n1 : st.n0;
-        if (n >= W.slotLimit) { st.flags |= 2u; st.leg = SEED_LEG_DONE; return; }
-        SeedSlot c; c.i0 = i0; c.nrep = (u32)min(Nrep, (u64)0xFFFFFFFFu); c.shift = (u16)q.shift; c.L = (u16)(Lm | (Nrep > 0xFFFFFFFFull ? 0x8000u : 0u));
-        W.slots[(u64)(un.group + (second ? un.nstart : 0u)) * SEED_SLOTS + n] = c;
-        n++;
-    }
-    if ((st.leg & 1u) == 0u) {
-        if (q.iDir == 0 && un.istart == 0 && st.Lmapped == 0 && q.shift + Lm == (u32)un.pL) st.flags &= ~1u;      // :74
-        st.Lmapped = (u16)(st.Lmapped + Lm);
-        if (Lm == 0) st.leg++;                                                     // (else the loop condition is looked at again by currentSearch)
-    } else { st.leg++; st.Lmapped = 0; }
-}
-__device__ __forceinline__ u32 seedClassOf(u32 range) { return range < 3u ? 0u : range < 15u ? 1u : range < 63u ? 2u : range < 255u ? 3u : range < 4095u ? 4u : 5u; }
-
-extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_lookup(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, u32 round) {
-    const DevIndex &X = *Xp; const staramd_params &P = X.P;
-    const u32 lane = laneId();
-    SeedCnt cn = {0, 0, 0};
-    const u32 nAct = round == 0u ? min(B.cursors[CUR_SEED_UNITS], W.unitCap) : W.rc[RCI(RC_ACT + round)];
-    const u32 *act = W.act[round & 1u]; u32 *next = W.act[(round + 1u) & 1u];
-    for (;;) {
-        const u32 t = waveTickets(&W.rc[RCI(RC_TICKET_L + round)], lane);
-        if (first32(t) >= nAct) break;
-        u32 u = 0, cls = SEED_CLASSES; bool again = false; SeedTask tk;
-        if (t < nAct) {
-            u = round == 0u ? t : act[t];
-            const SeedUnit un = W.units[u];
-            if (un.read != 0xFFFFFFFFu) {
-                SeedUState st;
-                if (round == 0u) { st.Lmapped = 0; st.leg = SEED_LEG_LOOP0; st.flags = 1u; st.n0 = st.n1 = 0; st.pad[0] = st.pad[1] = 0; } else st = W.ustate[u];
-                UnitSearch q;
-                if (currentSearch(P, un, st, q)) {
-                    const u8 *R = B.bases + B.readOffset[un.read];
-                    const bool dirR = q.iDir == 0;
-                    const SeedLook k = seedLookup(X, R, q.shift, q.N, dirR, cn);
-                    if (k.kind == 0) searchDone(P, W, un, st, q, 0, 0, 0);
-                    else if (k.kind == 1) searchDone(P, W, un, st, q, k.maxL, k.i2 - k.i1 + 1, k.i1);
-                    else if (k.kind == 2) { bool cr; const u32 L = compareSeqToGenome(X, R, q.shift, q.N, k.maxL, k.i1, dirR, cr, cn); searchDone(P, W, un, st, q, L, 1, k.i1); }
-                    else if (k.i2 - k.i1 >= 0xFFFFFFFFull) { st.flags |= 2u; st.leg = SEED_LEG_DONE; }        // an interval up to the end of the suffix array: the general kernel bisects it in 64 bits
-                    else {
-                        const u32 range = (u32)(k.i2 - k.i1); cls = seedClassOf(range);
-                        tk.i1 = k.i1; tk.range = range; tk.unit = u; tk.shift = (u16)q.shift; tk.N = (u16)q.N; tk.maxL = (u16)k.maxL; tk.dirR = dirR ? 1 : 0; tk.pad = 0;
-                    }
-                    UnitSearch q2;
-                    again = cls == SEED_CLASSES && currentSearch(P, un, st, q2);
-                }
-                W.ustate[u] = st;
-            }
-        }
-        for (u32 c = 0; c < SEED_CLASSES; c++) { const u32 at = waveAppend(&W.rc[RCI(RC_BUCKET + round * SEED_CLASSES + c)], cls == c, lane); if (cls == c) W.bucket[c][at] = tk; }
-        { const u32 at = waveAppend(&W.rc[RCI(RC_ACT + round + 1u)], again, lane); if (again) next[at] = u; }
-    }
-    addCounters(B, cn);
-}
-
-extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_bisect(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, u32 round) {
-    const DevIndex &X = *Xp; const staramd_params &P = X.P;
-    const u32 lane = laneId();
-    SeedCnt cn = {0, 0, 0};
-    u32 *next = W.act[(round + 1u) & 1u];
-    for (u32 c = 0; c < SEED_CLASSES; c++) {
-        const u32 nTask = W.rc[RCI(RC_BUCKET + round * SEED_CLASSES + c)];
-        for (;;) {
-            const u32 t = waveTickets(&W.rc[RCI(RC_TICKET_B + round * SEED_CLASSES + c)], lane);
-            if (first32(t) >= nTask) break;
-            bool again = false; u32 unit = 0;
-            if (t < nTask) {
-                const SeedTask tk = W.bucket[c][t];
-                unit = tk.unit;
-                const SeedUnit un = W.units[unit];
-                SeedUState st = W.ustate[unit];
-                const u8 *R = B.bases + B.readOffset[un.read];
-                u32 L = tk.maxL; u64 i0, i1;
-                const u64 Nrep = maxMappableLengthT<u32>(X, R, tk.shift, tk.N, tk.i1, tk.i1 + tk.range, tk.dirR != 0, L, i0, i1, cn);
-                UnitSearch q; q.shift = tk.shift; q.N = tk.N; q.iDir = tk.dirR ? 0u : 1u;
-                searchDone(P, W, un, st, q, L, Nrep, i0);
-                UnitSearch q2;
-                again = currentSearch(P, un, st, q2);
-                W.ustate[unit] = st;
-            }
-            const u32 at = waveAppend(&W.rc[RCI(RC_ACT + round + 1u)], again, lane);
-            if (again) next[at] = unit;
-        }
-    }
-    addCounters(B, cn);
-}
-
-// the units that still have searches left after the last round finish them back to back (error-rich reads: a restart loop of many short prefixes)
-extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_tail(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, u32 round) {
-    const DevIndex &X = *Xp; const staramd_params &P = X.P;
-    SeedCnt cn = {0, 0, 0};
-    const u32 nAct = W.rc[RCI(RC_ACT + round)];
-    const u32 *act = W.act[round & 1u];
-    for (;;) {
-        if (*(volatile u32 *)&W.rc[RCI(RC_TICKET_L + round)] >= nAct) break;         // (a lane that comes for nothing does not queue for the counter)
-        const u32 t = atomicAdd(&W.rc[RCI(RC_TICKET_L + round)], 1u);
-        if (t >= nAct) break;
-        const u32 u = act[t];
-        const SeedUnit un = W.units[u];
-        SeedUState st = W.ustate[u];
-        const u8 *R = B.bases + B.readOffset[un.read];
-        UnitSearch q;
-        while (currentSearch(P, un, st, q)) {
-            const bool dirR = q.iDir == 0;
-            u64 Nrep, i0; u32 L;
-            searchOneDist(X, R, q.shift, q.N, dirR, 0u, Nrep, i0, L, cn);
-            searchDone(P, W, un, st, q, L, Nrep, i0);
-        }
-        W.ustate[u] = st;
-    }
-    addCounters(B, cn);
-}
-
-// after the last round: the header of every group of every unit -- slots filled, direction, mate; handed on when the unit ran out of slots or of rounds
-extern "C" __global__ void __launch_bounds__(256) k_seed_heads(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W) {
-    const u32 nUnits = min(B.cursors[CUR_SEED_UNITS], W.unitCap);
-    for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < nUnits; u += gridDim.x * blockDim.x) {
-        const SeedUnit un = W.units[u];
-        if (un.read == 0xFFFFFFFFu) continue;
-        const SeedUState st = W.ustate[u];
-        const u32 over = ((st.flags & 2u) || st.leg < SEED_LEG_DONE) ? 0x80000000u : 0u;
-        const u32 dir0 = un.kind == 2u ? 1u : 0u;
-        W.groupHead[un.group] = st.n0 | (dir0 << 8) | ((u32)un.iFrag << 16) | over;
-        if (un.kind == 0u) W.groupHead[un.group + un.nstart] = st.n1 | (1u << 8) | ((u32)un.iFrag << 16) | over;
-    }
 }

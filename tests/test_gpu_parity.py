@@ -154,8 +154,6 @@ FORCED = {
     "seed_lane_per_read": {"STARAMD_SEED_UNITS": "0"},         # the seed stage as one nest per lane (k_seed_search over every read) instead of lane = unit
     "seed_unit_pool_tiny": {"STARAMD_SEED_GROUPS_PER_READ": "1"},   # the group / unit pools hold less than half of the batch: the rest is handed on to k_seed_search
     "seed_one_slot_per_unit": {"STARAMD_SEED_SLOT_LIMIT": "1"},     # a unit that finds a second seed hands its read on
-    "seed_units_back_to_back": {"STARAMD_SEED_UNITS": "1"},          # lane = unit without rounds (k_seed_units: what an index with a sparse suffix array takes)
-    "seed_one_round": {"STARAMD_SEED_ROUNDS": "1"},                  # every unit with a second search finishes in k_seed_tail
 }
 
 
