@@ -276,7 +276,9 @@ def cpu_baseline(idx, fq, out_prefix, n_pairs, log=lambda s: None):
     n_all = min(n_pairs, 4000000)
     v_all = n_all / max(run(n_all, ncpu, out_prefix + "all_") - t_load, 1e-3) / 1e6
     v_best = n_pairs / max(run(n_pairs, best_th, out_prefix) - t_load, 1e-3) / 1e6       # last: its outputs stay for the parity check
-    return {"value": round(v_all, 4), "unit": "Mreads/s", "cores": ncpu, "kind": "reference", "best_threads": best_th, "best_value": round(v_best, 4),
+    # value = the reference at its best thread count on this box (the comparator); all_threads_value = --runThreadN <all host cores> as north_star words it (slower: the
+    # box's CPU quota is 16 of 256 hardware threads, and the reference reads its input under one mutex)
+    return {"value": round(v_best, 4), "unit": "Mreads/s", "cores": best_th, "kind": "reference", "all_threads": ncpu, "all_threads_value": round(v_all, 4),
             "sample": "STAR 2.7.11b, same index and FASTQ, --limitIObufferSize 2000000; all %d cores on the first %d pairs, %d threads on all %d; index load (%.1f s) subtracted"
                       % (ncpu, n_all, best_th, n_pairs, t_load), "index_load_s": t_load}
 
@@ -555,16 +557,33 @@ def main():
     dms, dbytes = kms[dom], kern[dom][1]
     achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
     traffic = issue = None
+    per_kernel = {}
     try:        # HBM traffic / issue utilisation from rocprofv3 --pmc passes (profiles/README.md): only when taken on THIS kernel source and workload size
         tj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-        if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads and dom in tj and tj[dom].get("kernel_src_sha") == kernel_src_sha(dom):
-            traffic = tj[dom].get("hbm_bytes_per_launch"); issue = tj[dom].get("valu_busy_frac")
+        ceiling = tj.get("gather_ceiling_Gsectors_s")
+        for k in ("k_seed_search", "k_windows", "k_stitch_win"):
+            e = {"ms": round(kms[k], 2), "alg_MB": round(kern[k][1] / 1e6, 1)}
+            if tj.get("genome_mb") == mb and tj.get("reads_per_launch") == args.reads and k in tj and tj[k].get("kernel_src_sha") == kernel_src_sha(k):
+                t = tj[k]
+                hb = t.get("hbm_bytes_per_launch")
+                if hb and kms[k] > 0:
+                    # sectors = counter bytes / 64: what HBM moves for gathers of 1-8 bytes; the rate against the measured dependent-gather ceiling of the session
+                    e.update({"traffic_MB": round(hb / 1e6, 1), "traffic_over_alg": round(hb / max(kern[k][1], 1.0), 2), "Msectors": round(hb / 64e6, 1),
+                              "Gsectors_s": round(hb / 64.0 / (kms[k] * 1e-3) / 1e9, 2), "of_gather_ceiling": (round(hb / 64.0 / (kms[k] * 1e-3) / 1e9 / ceiling, 3) if ceiling else None)})
+                for kk in ("valu_busy_frac", "waves_per_simd_resident", "scratch_bytes_per_lane", "vgprs"):
+                    if t.get(kk) is not None:
+                        e[kk] = round(t[kk], 3) if isinstance(t[kk], float) else t[kk]
+                if k == dom:
+                    traffic = hb; issue = t.get("valu_busy_frac")
+            per_kernel[k] = e
     except Exception:
         pass
     line = {
         "metric": "million reads aligned/sec (whole node), 2x101 bp PE human-scale index, FASTQ in -> SAM out",
         "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # what the kernels alone allow (pairs of a step / HIP-event device time of a step): the distance to `value` is the host pipeline + copies
+        "device_only_value": (round(args.reads * world / (kms["device_total"] * 1e-3) / 1e6, 4) if kms.get("device_total", 0) > 0 else None),
         "dtype": "u8/u64 integer", "data": "synthetic",
         "config": {"workload": "BASELINE config 2 stand-in: synthetic %d Mb genome, %d annotated junctions, %.1f GB index in HBM, %d distinct pairs 2x%d per GPU as %d+%d batches of %d; "
                                "FASTQ text in -> SAM + SJ.out.tab out, index load excluded"
@@ -574,6 +593,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "issue": issue, "kernel_ms": round(dms, 3), "algorithmic_bytes_per_launch": int(dbytes),
                      "per_kernel_ms": {k: round(kms[k], 2) for k in ("k_seed_search", "k_windows", "k_stitch_win", "device_total")},
+                     "per_kernel": per_kernel,
                      "kernel_ms_source": kms_src, "algorithmic_bytes_per_pair_whole_path": round(bytes_per_pair, 1),
                      "whole_path_frac": round(bytes_per_pair * n / max(int(rep.batches), 1) / (kms["device_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kms["device_total"] > 0 else None,
                      "frac_with_round3_byte_count": (round(c["_bytes_stitch_round3_definition"] / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom == "k_stitch_win" and dms > 0 else None)},
@@ -585,7 +605,7 @@ def main():
         try:
             cb = cpu_baseline(idx, fq, ref_prefix, n_total, log)
             extra["cpu_baseline"] = cb
-            line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "best_threads", "best_value", "sample")}
+            line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "all_threads", "all_threads_value", "sample")}
         except Exception as e:
             line["cpu_baseline"] = {"error": repr(e)[:300]}
         log("cpu_baseline done")
@@ -628,7 +648,7 @@ def main():
     print(s, flush=True)
 
 
-PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_hbm_traffic.json"
 
 
 def _cli_leg(argv, lread, env=None):
@@ -686,6 +706,7 @@ def extra_legs_child(spec):
             ("config1", lambda: config1_leg(args, log))]
     if not args.no_two_pass:
         legs.append(("two_pass_end_to_end", lambda: two_pass(args, idx, fq, run_dir, threads)))
+        legs.append(("two_pass_parity_400mb", lambda: two_pass_parity(args, log)))
     if not args.no_sweep:
         legs.append(("index_size_sweep", lambda: sweep(args, args.genome_mb, spec["main_value"], spec["main_ms"], log)))
     for name, fn in legs:
@@ -706,9 +727,22 @@ def host_budget_leg(args, idx, fq, run_dir):
     nb, w = 8, 2
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(run_dir, "hb_"), "--runThreadN", str(th),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(min(nb + w, args.steps + args.warmup) * args.reads)]
-    rep, d = _cli_leg(argv, 2 * args.read_len + 1)
+    # the share of ONE rank of eight, enforced: the leg's threads are confined to `th` CPUs (the front end derives every helper thread count -- read slices, writer
+    # copy threads -- from --runThreadN, and whatever it starts beyond that shares these CPUs)
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(old_aff)[:th]))
+    except Exception:
+        old_aff = None
+    try:
+        rep, d = _cli_leg(argv, 2 * args.read_len + 1)
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
     d["host_threads"] = th
-    d["what"] = "one GPU, --runThreadN = cores / 8: the host share of one rank on an 8-GPU node"
+    d["cpus_the_leg_was_confined_to"] = th if old_aff is not None else None
+    d["what"] = "one GPU, --runThreadN = cores / 8 on that many CPUs (affinity): the host share of one rank on an 8-GPU node"
     return d
 
 
@@ -812,6 +846,35 @@ def two_pass(args, idx, fq, run_dir, threads):
     return {"value": n / float(rep.wallMapping) / 1e6, "unit": "Mreads/s (each read counted once, both passes + insertion in the wall time)", "reads": n,
             "wall_s": float(rep.wallMapping), "pass1_plus_insertion_plus_reupload_s": float(rep.pass1Seconds), "junctions_in_index_after_pass1": sjdb,
             "host_threads": threads, "what": "star_amd --twopassMode Basic end to end (index load excluded)"}
+
+
+def two_pass_parity(args, log):
+    """SURVEY.md 8d config 4 PINNED at scale: --twopassMode Basic on the 400 Mb index of the sweep, one batch of reads, star_amd against the reference's own 2-pass run
+    (twoPassRunPass1.cpp:17-49, sjdbInsertJunctions.cpp:11-102, sjdbBuildIndex.cpp:141-284): the SAM records as a multiset, SJ.out.tab (column 6 = 1 for the junctions the
+    1st pass inserted), the inserted junction list of the 2nd-pass index and the Log.final.out counters."""
+    from oracle import refstar
+    mb = 400
+    g, ginfo = build_genome(args, mb, log)
+    n = args.reads
+    rd = os.path.join(g, "twopass_n%d" % n)
+    fq = make_reads(args, g, rd, "reads", n, 9400)
+    th = max(4, min(64, effective_cpus()))
+    new, ref = os.path.join(rd, "gpu2p_"), os.path.join(rd, "ref2p_")
+    t = time.perf_counter()
+    rc, rep = _run_cli(["--runMode", "alignReads", "--genomeDir", os.path.join(g, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", new, "--runThreadN", str(th),
+                        "--gpuBatchReads", str(args.reads), "--twopassMode", "Basic"])
+    t_new = time.perf_counter() - t
+    if rc:
+        return {"error": "star_amd exit code %d" % rc}
+    t = time.perf_counter()
+    refstar.align(os.path.join(g, "idx"), fq, ref, threads=th, extra=["--twopassMode", "Basic"], timeout=1200)
+    t_ref = time.perf_counter() - t
+    fp = full_size_parity(ref, new) or {}
+    la, lb = (open(p + "_STARgenome/sjdbList.out.tab", "rb").read() for p in (ref, new))
+    fp.update({"genome_mb": ginfo.get("genome_mb", mb), "pairs": n, "inserted_junction_list_identical": la == lb, "junctions_inserted_by_pass1": la.count(b"\n"),
+               "star_amd_wall_s_with_index_load": round(t_new, 1), "reference_wall_s_with_index_load": round(t_ref, 1), "reference_threads": th,
+               "star_amd_pass1_plus_insertion_s": float(rep.pass1Seconds)})
+    return fp
 
 
 if __name__ == "__main__":

@@ -510,7 +510,8 @@ bool FastqReader::fillBatch(ReadBatch &b, const RunParams &P, uint64_t maxReads,
         static const unsigned fixed = getenv("STARAMD_READ_SLICES") ? (unsigned)atoi(getenv("STARAMD_READ_SLICES")) : 0u;
         // (measured on a GPU box with 16 CPUs, profiles/r04_host_stages_on_the_gpu_box.txt: read + scan of one mate's block 20.6 ms with 4 slices, 7.3 ms with 8 -- the
         // fill stage is the longest host stage of a batch and runs once per batch on its own thread, so its slices are what the other stages leave idle)
-        readSlices = fixed ? std::max(1u, std::min(fixed, 64u)) : (unsigned)std::max(4, std::min(16, P.runThreadN / 2));
+        // (all helper thread counts follow --runThreadN: a rank of an 8-GPU node that is given 2 host threads must not start 8 slice readers beside them)
+        readSlices = fixed ? std::max(1u, std::min(fixed, 64u)) : (unsigned)std::max(1, std::min(16, P.runThreadN / 2));
     }
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; } };

@@ -42,3 +42,30 @@ def _run(work):
     par = bench.full_size_parity(ref, new)
     assert par and par["sam_multiset_identical"] and par["sj_out_tab_identical"] and par["log_final_counters_identical"], par
     assert par["sam_records_star_amd"] > 1.5 * n          # (mapped pairs write two records)
+
+
+def test_100mb_index_two_pass_against_the_reference(tmp_path, built):
+    """config 4 pinned in the GPU suite at a size where coordinates and the junction count are not toy-sized: --twopassMode Basic on a 100 Mb index with
+    annotation, 100 k pairs -- the 1st pass's junctions inserted into the index resident in HBM -- against the reference's own 2-pass run: SAM multiset, SJ.out.tab
+    (column 6), the inserted junction list, Log.final.out counters (bench.py:two_pass_parity is the same at 400 Mb in every default bench run)"""
+    sys.path.insert(0, ROOT)
+    import shutil
+    import tempfile
+    import bench
+    work = tempfile.mkdtemp(prefix="staramd_t100_", dir="/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path))
+    try:
+        args = argparse.Namespace(read_len=101, reads=50000, workdir=work)
+        notes = []
+        orig = bench.build_genome
+        par = None
+        # the leg itself, on a 100 Mb genome
+        bench.build_genome = lambda a, mb, log: orig(a, 100, log)
+        try:
+            par = bench.two_pass_parity(args, notes.append)
+        finally:
+            bench.build_genome = orig
+        assert par and "error" not in par, par
+        assert par["sam_multiset_identical"] and par["sj_out_tab_identical"] and par["log_final_counters_identical"] and par["inserted_junction_list_identical"], par
+        assert par["junctions_inserted_by_pass1"] > 100, par
+    finally:
+        shutil.rmtree(work, ignore_errors=True)

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/r04_pmc_hbm_traffic.json from the PMC passes of tools/measure_session.sh (FETCH_SIZE, WRITE_SIZE, SQ counters: separate runs):
+"""profiles/r05_pmc_hbm_traffic.json from the PMC passes of tools/measure_session.sh (FETCH_SIZE, WRITE_SIZE, SQ counters: separate runs):
    tools/make_traffic_json.py <session dir> <genome_mb> <reads per launch> <out.json>
+The seed stage is the sum of its kernels (k_seed_plan + k_seed_units + k_seed_merge + k_seed_search).  Beside the counters: the dependent-gather ceiling of the same session
+(<session dir>/gather_ceiling.txt, tools/gather_ceiling at 16 GiB, 524 288 lanes in flight: G sectors/s) and the static resources of the dominant kernel of each stage as the
+compiler reports them (registers, scratch bytes per lane, wavefronts per SIMD: -Rpass-analysis=kernel-resource-usage on the committed sources).
 Per kernel: (sum of the counter over every dispatch of the kernel) / (number of batches) * 1024 -- rocprofv3 reports both in KB; a batch
 is one launch of the hot path (k_seed_search runs once per batch, k_windows three times, the stitch stage = k_stitch_lane + k_stitch_win).
 FETCH_SIZE is NOT doubled: MI355X_MICROARCH.md's gfx950 x2 correction is calibrated for wide coalesced 16 B/lane streams only; these kernels
@@ -26,11 +29,11 @@ def main():
     if os.path.isfile(d + "/kernel_stats.csv"):
         for r in csv.DictReader(open(d + "/kernel_stats.csv")):
             dur[r["Name"]] = float(r["TotalDurationNs"])
-    nb = fe["k_seed_search"]["dispatches"]
-    assert nb == wr["k_seed_search"]["dispatches"]
+    nb = fe["k_windows_big"]["dispatches"]             # (launched once per batch whatever the data)
+    assert nb == wr["k_windows_big"]["dispatches"]
     res = {"genome_mb": mb, "reads_per_launch": reads, "batches_in_each_pass": nb, "engine_src_sha": bench.engine_src_sha(),
            "_how": __doc__.split("\n", 2)[2].strip()}
-    names = {"k_windows": ["k_windows", "k_windows_big"], "k_stitch_win": ["k_stitch_win", "k_stitch_lane"], "k_seed_search": ["k_seed_search"],
+    names = {"k_windows": ["k_windows", "k_windows_big"], "k_stitch_win": ["k_stitch_win", "k_stitch_lane"], "k_seed_search": ["k_seed_search", "k_seed_plan", "k_seed_units", "k_seed_merge"],
              "k_stitch_replay": ["k_stitch_replay"], "k_stitch_finish": ["k_stitch_finish"], "k_gather": ["k_gather"]}
     for k, parts in names.items():
         f = sum(fe[p]["counters"]["FETCH_SIZE"] for p in parts if p in fe)
@@ -43,6 +46,33 @@ def main():
             res[k]["valu_insts_per_launch"] = valu / nb; res[k]["salu_insts_per_launch"] = salu / nb
             res[k]["kernel_ms_per_launch_stats_pass"] = t_ns / nb / 1e6
             res[k]["valu_busy_frac"] = valu * 4.0 / (t_ns * 1e-9 * 2.4e9 * 1024)
+    # static resources of the kernel that dominates each stage
+    import re, subprocess
+    main_kernel = {"k_seed_search": ("k_seed", "k_seed_units", []), "k_windows": ("k_window", "k_windows", []), "k_stitch_win": ("k_stitch", "k_stitch_win", ["-fno-unroll-loops", "-DSTITCH_WAVES=3"])}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k, (src, kern, extra) in main_kernel.items():
+        try:
+            p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"] + extra +
+                               ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-S", os.path.join(root, "star_amd", "csrc", "engine", src + ".hip"), "-o", "/dev/null"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            b = [x for x in p.stderr.split("Function Name: ")[1:] if x.split()[0] == kern][0]
+            g = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+            res[k].update({"vgprs": g("VGPRs"), "scratch_bytes_per_lane": g(r"ScratchSize \[bytes/lane\]"), "waves_per_simd": g(r"Occupancy \[waves/SIMD\]"), "static_resources_of": kern})
+        except Exception as e:
+            res[k]["static_resources_error"] = repr(e)[:200]
+    # resident blocks of 4 wavefronts per CU = wavefronts per SIMD, as the engine sized its launches in the session (STARAMD_VERBOSE line of the plain bench run)
+    try:
+        m = re.search(r"staramd: k_stitch_win (\d+) blocks/CU \(LDS \d+ B/block\), k_windows (\d+) blocks/CU, k_seed_search (\d+) blocks/CU", open(os.path.join(d, "bench_plain.err")).read())
+        if m:
+            res["k_stitch_win"]["waves_per_simd_resident"] = int(m.group(1)); res["k_windows"]["waves_per_simd_resident"] = int(m.group(2)); res["k_seed_search"]["waves_per_simd_resident"] = int(m.group(3))
+    except Exception:
+        pass
+    gc = os.path.join(d, "gather_ceiling.txt")
+    if os.path.isfile(gc):
+        for line in open(gc):
+            m = re.search(r"524288 lanes in flight: ([0-9.]+) G gathers/s", line)
+            if m:
+                res["gather_ceiling_Gsectors_s"] = float(m.group(1)); res["gather_ceiling_how"] = "tools/gather_ceiling 16384 MiB table, 524288 lanes in flight, same session"
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: (round(v["hbm_bytes_per_launch"] / 1e9, 2), round(v.get("valu_busy_frac", 0), 3)) for k, v in res.items() if isinstance(v, dict)}))
 

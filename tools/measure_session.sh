@@ -6,7 +6,7 @@ O=$R/gpurun_out/$TAG; mkdir -p $O
 export STARAMD_BENCH_GENOME_MB=$MB
 B="python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-sweep --no-two-pass --no-extra-legs"
 # data + an unprofiled line first (the profiled runs reuse the cached genome / reads in /dev/shm)
-timeout 1200 $B > $O/bench_plain.json 2> $O/bench_plain.err || { tail -5 $O/bench_plain.err; exit 1; }
+STARAMD_VERBOSE=1 timeout 1200 $B > $O/bench_plain.json 2> $O/bench_plain.err || { tail -5 $O/bench_plain.err; exit 1; }
 python -c "import json;d=json.load(open('$O/bench_plain.json'));print('plain', d['value'], d['roofline']['per_kernel_ms'])"
 cd /tmp && export TMPDIR=/tmp
 for p in $PASSES; do
@@ -22,6 +22,8 @@ for p in $PASSES; do
   echo "pass $p done: $(find $O -name '*counter_collection.csv' -o -name '*kernel_stats.csv' | wc -l) csv so far"
 done
 cd $R
+# the dependent-gather ceiling of this box, this session (roofline.per_kernel.*.of_gather_ceiling)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/gather_ceiling.hip -o /tmp/gather_ceiling 2> /dev/null && timeout 120 /tmp/gather_ceiling 16384 256 > $O/gather_ceiling.txt 2>&1
 for d in pmc_sq1 pmc_sq2 pmc_sq3 pmc_tcp pmc_fetch pmc_write; do
   f=$(find $O/$d -name "*counter_collection.csv" 2>/dev/null | head -1)
   [ -n "$f" ] && python profiles/pmc_summary.py $f > $O/$d.summary.json
