@@ -538,7 +538,7 @@ def main():
                           "postmap_write_Mreads_s": n / float(rep.emitBusy) / 1e6 if rep.emitBusy > 0 else None,
                           "finish_s": float(rep.finishSeconds), "genome_load_s": float(rep.genomeLoadSeconds), "index_upload_s": float(rep.indexUploadSeconds),
                           "cpu_us_per_pair_by_stage": dict(zip(["input_line_table", "text_to_numeric", "mapper_threads", "postmap_format", "file_writes", "other"], [round(float(x) * 1e6 / n, 4) for x in list(rep.cpuSeconds)[:6]])),
-                          "fast_path_batches": dict(zip(["output_through_file_mapping", "input_from_file_mapping", "upload_prefetched"], [int(x) for x in list(rep.fastPaths)[:3]])),
+                          "fast_path_batches": dict(zip(["output_through_file_mapping", "input_from_file_mapping", "upload_prefetched", "kernels_begun_beside_result_copy"], [int(x) for x in list(rep.fastPaths)[:4]])),
                           "postmap_whole_run_s": dict(zip(["wait_for_writer", "format_on_threads", "serial_tail", "writer_thread_busy"], [float(x) for x in rep.emitParts]))}}
     if dist is not None:
         dist.destroy_process_group()

@@ -24,6 +24,24 @@ int staramd_prefetch_batch(staramd_ctx *ctx, const staramd_batch *next);
 int staramd_prefetch_cancel(staramd_ctx *ctx);
 /* staramd_map_batch calls of this context that found their upload done ahead (tests and the front end's report: a prefetch path that never runs is not a fast path) */
 uint64_t staramd_prefetch_hits(staramd_ctx *ctx);
+
+/* The two halves of staramd_map_batch, for a caller that keeps the device busy across the copy of the results (~100 MB per batch of 400 k pairs: 2 ms of a 47 ms call):
+ *   staramd_map_begin(ctx, batch)        upload (unless staramd_prefetch_batch has done it) and every kernel of the batch enqueued; returns without waiting.
+ *                                        One batch in flight per context; staramd_map_batch / staramd_map_resident refuse to run meanwhile.
+ *   staramd_map_end(ctx, results, next)  waits for the kernels of the batch in flight (a work-space overflow is handled as in staramd_map_batch: grown, run again);
+ *                                        starts the copy of its results on the copy stream; begins `next` (may be NULL) at once, so that its kernels run beside that
+ *                                        copy; returns when `results` is complete.  STARAMD_ERR_RESULT_OVERFLOW leaves the batch in flight: call again with larger
+ *                                        arrays (trCount / exCount say how large).  Any other error ends the batch in flight; an error of `next`'s begin is returned
+ *                                        with `results` complete (staramd_last_error says which it was).
+ * The arrays of `batch` / `next` must stay unchanged until the staramd_map_end call that finishes them returns; results as for staramd_map_batch.
+ * Same kernels, same order, same buffers as staramd_map_batch: the results are identical. */
+int staramd_map_begin(staramd_ctx *ctx, const staramd_batch *batch);
+/* waits for the kernels of the batch in flight and nothing else (the first step of staramd_map_end): a caller that wants to hand staramd_map_end the batch that is next
+ * in line looks for it AFTER this wait -- it may have arrived meanwhile */
+int staramd_map_wait(staramd_ctx *ctx);
+int staramd_map_end(staramd_ctx *ctx, staramd_results *results, const staramd_batch *next);
+/* batches whose kernels were begun inside staramd_map_end, beside the copy of the results before them (tests and the front end's report) */
+uint64_t staramd_overlapped_batches(staramd_ctx *ctx);
 #ifdef __cplusplus
 }
 #endif

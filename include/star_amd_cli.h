@@ -47,7 +47,8 @@ typedef struct staramd_cli_report {
                                       of a batch (junction merge, hand-over); [3] the writer thread's own busy time (write calls into the output file) */
     uint64_t fastPaths[4];         /* batches that took a path with a silent fallback behind it, whole run: [0] SAM / BAM text written through a mapping of the output file (fallback: positional
                                       writes), [1] read in place from mappings of the input files (fallback: copied out of the page cache), [2] uploaded ahead of their staramd_map_batch call
-                                      (staramd_prefetch_batch; fallback: uploaded by the call), [3] reserved */
+                                      (staramd_prefetch_batch; fallback: uploaded by the call), [3] begun inside staramd_map_end, beside the copy of the results of the batch before (fallback: one
+                                      blocking staramd_map_batch per batch) */
     double   cpuSeconds[8];        /* thread-CPU seconds per stage in the timed region (sah_cpu_seconds): input + line table, text -> numeric, mapper threads, post-map + formatting, file writes, other */
 } staramd_cli_report;
 

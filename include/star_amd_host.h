@@ -52,6 +52,7 @@ double sah_genome_load_seconds(void *h);
 void  sah_emit_seconds(void *h, double out[4]);
 /* batches so far that were [0] written through a mapping of the output file, [1] read in place from mappings of the input files */
 void  sah_fast_path_counts(void *h, uint64_t out[2]);
+int   sah_needs_second_batch(void *h);                                 /* 1: batches of this run can have a second batch built from them (sah_merged_slot / sah_wasp_slot) */
 /* thread-CPU seconds per pipeline stage, process-wide, since the last reset: [0] input + line table, [1] text -> numeric batch, [2] mapper threads (the host side of
  * staramd_map_batch), [3] post-map + formatting, [4] output file writes, [5] everything else that was counted.  sah_cpu_add: the stage threads of the front end add their own. */
 void  sah_cpu_add(int stage, uint64_t ns);

@@ -43,6 +43,12 @@ int staramd_get_timings(staramd_ctx *, float *, int) { return 0; }
 int staramd_insert_junctions_fits(staramd_ctx *, uint64_t, uint32_t) { return 0; }
 int staramd_prefetch_batch(staramd_ctx *, const staramd_batch *) { return 0; }
 int staramd_prefetch_cancel(staramd_ctx *) { return 0; }
+// the two halves of staramd_map_batch: the stand-in maps when the batch is finished
+static thread_local staramd_batch g_inFlight;          // (the descriptor by value: the caller's struct need not outlive the call, only the arrays it points at)
+int staramd_map_begin(staramd_ctx *, const staramd_batch *b) { g_inFlight = *b; return 0; }
+int staramd_map_wait(staramd_ctx *) { return 0; }
+int staramd_map_end(staramd_ctx *ctx, staramd_results *r, const staramd_batch *next) { const int rc = staramd_map_batch(ctx, &g_inFlight, r); if (rc == STARAMD_ERR_RESULT_OVERFLOW) return rc; if (next) g_inFlight = *next; return rc; }
+uint64_t staramd_overlapped_batches(staramd_ctx *) { return 0; }
 uint64_t staramd_prefetch_hits(staramd_ctx *) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 // index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp

@@ -65,6 +65,9 @@ struct staramd_ctx {
     // in[k].pending: the set holds an uploaded batch that staramd_map_batch has not consumed yet; cur: the set the last mapped batch used (dBases ... above point into it)
     struct InSet { u8 *bases = nullptr; u64 *readOffset = nullptr; u16 *mate1 = nullptr, *mm = nullptr; hipEvent_t up = nullptr;
                    const uint8_t *hBases = nullptr; const uint64_t *hReadOffset = nullptr; u32 nReads = 0; bool pending = false; } in[2];
+    // staramd_map_begin / staramd_map_end (include/star_amd_async.h): a batch whose kernels are enqueued; its flags and totals looked at; the copy of the results of the
+    // batch before still running on the copy stream (the next k_gather waits for it)
+    bool inFlight = false, collected = false, downloadPending = false; hipEvent_t evDownload = nullptr; u64 nOverlapped = 0; staramd_results msRes = {};
     u64 nPrefetchHits = 0;      // staramd_map_batch calls that found their upload done ahead (staramd_prefetch_hits)
     int cur = 0; hipStream_t copyStream = nullptr;
     u32 *dPacked = nullptr; u32 packWordsCap = 0;
@@ -404,6 +407,7 @@ extern "C" int staramd_create(staramd_ctx **out, int device, const staramd_genom
     if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (!rc && !getenv("STARAMD_SPIN_WAIT") && hipEventCreateWithFlags(&c->evWait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) c->evWait = nullptr;
+    if (!rc && hipEventCreateWithFlags(&c->evDownload, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (rc) { freeAll(c->indexAllocs); freeAll(c->workAllocs); delete c; return rc; }
     memset(c->counters, 0, sizeof(c->counters));
     *out = c;
@@ -421,6 +425,7 @@ extern "C" int staramd_create_shared(staramd_ctx **out, staramd_ctx *owner, uint
     if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (!rc && !getenv("STARAMD_SPIN_WAIT") && hipEventCreateWithFlags(&c->evWait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) c->evWait = nullptr;
+    if (!rc && hipEventCreateWithFlags(&c->evDownload, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (rc) { freeAll(c->workAllocs); delete c; return rc; }
     memset(c->counters, 0, sizeof(c->counters));
     owner->sharers.push_back(c);
@@ -557,6 +562,7 @@ extern "C" void staramd_destroy(staramd_ctx *c) {
     freeAll(c->workAllocs);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->evWait) (void)hipEventDestroy(c->evWait);
+    if (c->evDownload) (void)hipEventDestroy(c->evDownload);
     for (int k = 0; k < 2; k++) if (c->in[k].up) (void)hipEventDestroy(c->in[k].up);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->hostScratch) (void)hipHostFree(c->hostScratch);
@@ -599,7 +605,8 @@ static hipError_t waitStream(staramd_ctx *c) {
     return e != hipSuccess ? e : hipEventSynchronize(c->evWait);
 }
 
-static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
+// every kernel of a batch and the read-back of its totals, cursors and counters, enqueued; nothing is waited for
+static int enqueueAll(staramd_ctx *c) {
     DevBatch &B = c->B; hipStream_t s = c->stream;
     u32 n = B.nReads;
     HIPCHK(hipMemsetAsync(B.cursors, 0, CUR_N * sizeof(u32), s));
@@ -664,6 +671,7 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(k_scan_local, dim3((n + 255) / 256), block, 0, s, B, c->dTrBase, c->dExBase, c->dBlockTot);
     hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, s, B, c->dBlockTot, (n + 255) / 256, c->dTotals);
+    if (c->downloadPending) { HIPCHK(hipStreamWaitEvent(s, c->evDownload, 0)); c->downloadPending = false; }      // the results of the batch before may still be on their way out of dOut* (staramd_map_end)
     hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), block, 0, s, B, c->dTrBase, c->dExBase, c->dBlockTot, c->dOutReads, c->dOutTr, B.trCap, c->dOutEx, B.exCap);
     HIPCHK(hipEventRecord(c->ev[4], s));
     HIPCHK(hipGetLastError());
@@ -671,6 +679,11 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     HIPCHK(hipMemcpyAsync(hs, c->dTotals, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
+    return STARAMD_OK;
+}
+// ... waited for: stage times, overflow flags
+static int collectAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
+    u32 *hs = c->hostScratch;
     HIPCHK(waitStream(c));
     if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: seed units %u in %u groups, reads handed on to k_seed_search %u; stitch work items %u, handed on to the full-size launch %u\n", hs[8 + CUR_SEED_UNITS], hs[8 + CUR_SEED_GROUPS], hs[8 + CUR_OVF_SEED], hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY]);
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
@@ -690,6 +703,10 @@ static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     c->ms[6] = r->msTotalDevice;
     *flagsOut = hs[8 + CUR_FLAGS];
     return STARAMD_OK;
+}
+static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
+    int rc = enqueueAll(c);
+    return rc ? rc : collectAll(c, r, flagsOut);
 }
 
 // The kernels of the engine are persistent launches sized to fill the GPU: when two contexts of one device (the front end runs two, so that the copies of one
@@ -737,6 +754,7 @@ static void dropPrefetched(staramd_ctx *c) {
 }
 
 static int mapBatchImpl(staramd_ctx *c, const staramd_batch *b, staramd_results *r);
+static int runDevice(staramd_ctx *c, staramd_results *r);
 extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd_results *r) {
     if (!c || !b || !r || !r->reads) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
     const int rc = mapBatchImpl(c, b, r);
@@ -744,8 +762,8 @@ extern "C" int staramd_map_batch(staramd_ctx *c, const staramd_batch *b, staramd
     return rc;
 }
 
-static int mapBatchImpl(staramd_ctx *c, const staramd_batch *b, staramd_results *r) {
-    if (b->nReads == 0) { r->trCount = r->exCount = 0; return STARAMD_OK; }
+// checks, upload (unless staramd_prefetch_batch has done it) and the packed copy of the reads: the batch is resident, nothing is waited for
+static int stageBatch(staramd_ctx *c, const staramd_batch *b) {
     // a batch may be a slice of a larger one (readOffset[0] > 0: the pieces of a WASP re-mapping batch): sized and uploaded from its own first base
     const u64 base0 = b->readOffset[0], nBases = b->readOffset[b->nReads] - base0;
     if (b->nReads > c->maxReads || nBases > c->maxBases) { g_err = "batch larger than the context's work space"; return STARAMD_ERR_ARG; }
@@ -783,8 +801,66 @@ static int mapBatchImpl(staramd_ctx *c, const staramd_batch *b, staramd_results 
     c->B.nReads = n; c->residentReads = n; c->residentMaxLread = maxL;
     c->B.packed = c->dPacked; c->B.packWords = packWords;
     hipLaunchKernelGGL(k_pack_reads, dim3(n), dim3(64), 0, s, c->B, c->dPacked, packWords);
-    return runDevice(c, r);
+    return STARAMD_OK;
 }
+static int mapBatchImpl(staramd_ctx *c, const staramd_batch *b, staramd_results *r) {
+    if (b->nReads == 0) { r->trCount = r->exCount = 0; return STARAMD_OK; }
+    if (c->inFlight) { g_err = "a batch begun with staramd_map_begin is in flight: staramd_map_end first"; return STARAMD_ERR_ARG; }
+    const int rc = stageBatch(c, b);
+    return rc ? rc : runDevice(c, r);
+}
+
+// ---- the two halves of staramd_map_batch (include/star_amd_async.h) ----
+extern "C" int staramd_map_begin(staramd_ctx *c, const staramd_batch *b) {
+    if (!c || !b || b->nReads == 0) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    if (c->inFlight) { g_err = "a batch is in flight already: staramd_map_end first"; return STARAMD_ERR_ARG; }
+    int rc = stageBatch(c, b);
+    if (!rc) rc = enqueueAll(c);
+    if (rc) { dropPrefetched(c); return rc; }
+    c->inFlight = true; c->collected = false;
+    return STARAMD_OK;
+}
+extern "C" int staramd_map_wait(staramd_ctx *c) {
+    if (!c) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    if (!c->inFlight) { g_err = "no batch in flight: staramd_map_begin first"; return STARAMD_ERR_ARG; }
+    if (c->collected) return STARAMD_OK;
+    HIPCHK(hipSetDevice(c->device));
+    u32 flags = 0;
+    int rc = collectAll(c, &c->msRes, &flags);
+    for (int attempt = 0; !rc && flags; attempt++) {          // a pool overflowed: grown, and the batch (its inputs are resident) run again -- as staramd_map_batch does
+        const u32 *cur = c->hostScratch + 8;
+        if ((flags & OVF_HARD) || attempt >= 12) { g_err = "device work-space overflow (flags " + std::to_string(flags) + ")"; rc = STARAMD_ERR_SCRATCH_OVERFLOW; break; }
+        rc = growPools(c, flags, cur);
+        if (!rc) rc = launchAll(c, &c->msRes, &flags);
+    }
+    if (rc) { c->inFlight = false; dropPrefetched(c); return rc; }
+    c->collected = true;
+    return STARAMD_OK;
+}
+extern "C" int staramd_map_end(staramd_ctx *c, staramd_results *r, const staramd_batch *next) {
+    if (!c || !r || !r->reads) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
+    if (!c->inFlight) { g_err = "no batch in flight: staramd_map_begin first"; return STARAMD_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    DevBatch &B = c->B; const u32 n = B.nReads;
+    { const int rc = staramd_map_wait(c); if (rc) return rc; }
+    r->msSeed = c->msRes.msSeed; r->msWindows = c->msRes.msWindows; r->msStitch = c->msRes.msStitch; r->msTotalDevice = c->msRes.msTotalDevice;
+    const u32 *totals = c->hostScratch;
+    r->trCount = totals[0]; r->exCount = totals[1];
+    if (totals[0] > r->trCapacity || totals[1] > r->exCapacity) { g_err = "result arrays too small: need " + std::to_string(totals[0]) + " transcripts, " + std::to_string(totals[1]) + " exons"; return STARAMD_ERR_RESULT_OVERFLOW; }   // (the batch stays in flight: call again with larger arrays)
+    // the results leave on the copy stream; the kernels of `next` start beside them (its k_gather, the only writer of dOut*, waits for the copy)
+    hipStream_t cs = c->copyStream ? c->copyStream : c->stream;
+    HIPCHK(hipMemcpyAsync(r->reads, c->dOutReads, (u64)n * sizeof(staramd_read_result), hipMemcpyDeviceToHost, cs));
+    if (totals[0]) HIPCHK(hipMemcpyAsync(r->tr, c->dOutTr, (u64)totals[0] * sizeof(staramd_transcript), hipMemcpyDeviceToHost, cs));
+    if (totals[1]) HIPCHK(hipMemcpyAsync(r->ex, c->dOutEx, (u64)totals[1] * sizeof(staramd_exon), hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipEventRecord(c->evDownload, cs));
+    c->downloadPending = c->copyStream != nullptr;
+    c->inFlight = false; c->collected = false;
+    int rcNext = STARAMD_OK;
+    if (next && next->nReads) { rcNext = staramd_map_begin(c, next); if (!rcNext) c->nOverlapped++; }
+    HIPCHK(hipEventSynchronize(c->evDownload));
+    return rcNext;
+}
+extern "C" uint64_t staramd_overlapped_batches(staramd_ctx *c) { return c ? c->nOverlapped : 0; }
 
 extern "C" int staramd_prefetch_batch(staramd_ctx *c, const staramd_batch *b) {
     if (!c || !b) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }

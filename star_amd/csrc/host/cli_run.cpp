@@ -46,6 +46,7 @@ struct Queue {                                   // hand-off between two pipelin
     void push(const Msg &x) { { std::lock_guard<std::mutex> l(m); q.push_back(x); } cv.notify_all(); }
     void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
     bool pop(Msg &x) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; x = q.front(); q.pop_front(); return true; }
+    bool tryPop(Msg &x) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; x = q.front(); q.pop_front(); return true; }        // what is waiting, without waiting for it
     bool peek(Msg &x) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; x = q.front(); return true; }          // what the next pop would hand out, if anything is waiting
 };
 struct Tokens {                                  // counting semaphore over a small set of buffer indices
@@ -312,7 +313,67 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
             }
         });
         std::vector<std::thread> mappers;
-        for (int d = 0; d < nDev; d++) mappers.emplace_back([&, d] {
+        // One context per device and no second batch per batch (merged mates, allele-swapped reads): the mapper keeps TWO batches going -- when the kernels of batch k are done it
+        // begins batch k+1 before the results of k leave the device (staramd_map_begin / _wait / _end, include/star_amd_async.h), so the ~100 MB copy runs beside kernels.
+        // STARAMD_NO_OVERLAP=1: one blocking staramd_map_batch call per batch (the loop below, which every other configuration takes).
+        const bool overlapCopies = nDev == nOwners && !sah_needs_second_batch(h) && !getenv("STARAMD_NO_OVERLAP");
+        for (int d = 0; d < nDev && overlapCopies; d++) mappers.emplace_back([&, d] {
+            auto pushDone = [&](const Msg &m) { { std::lock_guard<std::mutex> l(doneM); done[m.seq] = m; } doneCv.notify_all(); };
+            auto begin = [&](Msg &m) -> bool {            // false: the batch goes down the pipeline unmapped (an error is recorded, or it carries no reads)
+                if (failed.load() || m.n <= 0) { if (failed.load()) m.n = 0; return false; }
+                ResBuf &r = rb[m.slot];
+                if (r.reads.size() < m.b.nReads || r.tr.empty()) r.size(std::max<uint64_t>(m.b.nReads, 1024));
+                if (staramd_map_begin(ctx[d], &m.b)) { fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error()); m.n = 0; return false; }
+                return true;
+            };
+            Msg cur; bool have = false; double curStart = 0;
+            for (;;) {
+                if (!have) {
+                    if (!parsed.pop(cur)) break;
+                    curStart = plog.now();
+                    StageCpu sc(2);
+                    if (!begin(cur)) { cur.merged = false; plog.add(2, cur.seq, curStart, plog.now()); pushDone(cur); continue; }
+                    have = true;
+                }
+                StageCpu sc(2);
+                auto tm = Clock::now();
+                { Msg pk; if (parsed.peek(pk) && pk.n > 0) (void)staramd_prefetch_batch(ctx[d], &pk.b); }      // the upload of the batch behind it, beside the kernels of this one
+                int rc = staramd_map_wait(ctx[d]);
+                Msg nx; bool haveNx = false, begunNx = false;
+                ResBuf &r = rb[cur.slot];
+                if (!rc) {
+                    haveNx = parsed.tryPop(nx);
+                    const bool passNx = haveNx && !failed.load() && nx.n > 0;
+                    if (passNx) { ResBuf &rn = rb[nx.slot]; if (rn.reads.size() < nx.b.nReads || rn.tr.empty()) rn.size(std::max<uint64_t>(nx.b.nReads, 1024)); }
+                    rc = staramd_map_end(ctx[d], &r.res, passNx ? &nx.b : nullptr);
+                    if (rc == STARAMD_ERR_RESULT_OVERFLOW) {             // more transcripts than the buffers hold -> grow and ask again (the batch is still in flight)
+                        r.tr.resize(r.res.trCount + r.res.trCount / 4 + 4096); r.ex.resize(r.res.exCount + r.res.exCount / 4 + 4096); r.point();
+                        rc = staramd_map_end(ctx[d], &r.res, passNx ? &nx.b : nullptr);
+                    }
+                    begunNx = passNx && !rc;
+                }
+                if (rc) { fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error()); cur.n = 0; }
+                else {
+                    float st8[8] = {0}; uint64_t cnt[40] = {0};
+                    const int k = staramd_get_timings(ctx[d], st8, 8); const int kc = staramd_get_counters(ctx[d], cnt, 40);
+                    std::lock_guard<std::mutex> l(statM);
+                    msDeviceAll += r.res.msTotalDevice;
+                    if (timedOn) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += r.res.msTotalDevice; for (int i = 0; i < k && i < 8; i++) rep.stageMs[i] += st8[i]; for (int i = 0; i < kc && i < 40; i++) rep.counters[i] += cnt[i]; }
+                }
+                cur.merged = false;
+                if (failed.load()) cur.n = 0;
+                plog.add(2, cur.seq, curStart, plog.now());
+                pushDone(cur);
+                have = false;
+                if (haveNx) {
+                    curStart = plog.now();
+                    if (begunNx) { cur = nx; have = true; }
+                    else if (begin(nx)) { cur = nx; have = true; }       // (it was not handed to staramd_map_end, or that call failed before it began it)
+                    else { nx.merged = false; pushDone(nx); }
+                }
+            }
+        });
+        for (int d = 0; d < nDev && !overlapCopies; d++) mappers.emplace_back([&, d] {
             Msg m;
             while (parsed.pop(m)) {
                 int rc = 0;
@@ -425,13 +486,13 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
     plog.dump();
     sah_fast_path_counts(h, rep.fastPaths);
     sah_cpu_seconds(rep.cpuSeconds, 0);
-    for (int d = 0; d < nDev; d++) if (ctx[d]) rep.fastPaths[2] += staramd_prefetch_hits(ctx[d]);
+    for (int d = 0; d < nDev; d++) if (ctx[d]) { rep.fastPaths[2] += staramd_prefetch_hits(ctx[d]); rep.fastPaths[3] += staramd_overlapped_batches(ctx[d]); }
     double sec = since(t0);
     rep.reads = nReads; rep.wallMapping = sec; rep.timedWall = since(tTimed);
     if (!exitCode) fprintf(stderr, "star_amd: %llu reads, %.3f s wall in the mapping loop (%.3f s on the device) -> %.3f Mreads/s end to end, %d GPU(s)\n",
                            (unsigned long long)nReads, sec, msDeviceAll / 1e3 / nDev, sec > 0 ? (double)nReads / sec / 1e6 : 0.0, nOwners);
-    if (!exitCode) fprintf(stderr, "star_amd: fast paths: output through a file mapping %llu batches, input from file mappings %llu, uploads prefetched %llu\n",
-                           (unsigned long long)rep.fastPaths[0], (unsigned long long)rep.fastPaths[1], (unsigned long long)rep.fastPaths[2]);
+    if (!exitCode) fprintf(stderr, "star_amd: fast paths: output through a file mapping %llu batches, input from file mappings %llu, uploads prefetched %llu, kernels begun beside the copy of the results before them %llu\n",
+                           (unsigned long long)rep.fastPaths[0], (unsigned long long)rep.fastPaths[1], (unsigned long long)rep.fastPaths[2], (unsigned long long)rep.fastPaths[3]);
     sah_set_sjdb_resident_fn(nullptr, nullptr);
     destroyAll();
     sah_destroy(h);

@@ -656,6 +656,8 @@ int sah_device(void *h) { return ((Runner *)h)->P.gpuDevice; }
 double sah_genome_load_seconds(void *h) { return ((Runner *)h)->gi.loadSeconds; }
 void sah_cpu_add(int stage, uint64_t ns) { staramd::cpuAdd(stage, ns); }
 void sah_cpu_seconds(double out[8], int reset) { for (int i = 0; i < staramd::CPU_NSTAGE; i++) out[i] = (double)staramd::cpuTake(i, reset != 0) * 1e-9; }
+// 1: a batch of this run can be followed by a second one built from it (merged mates of --peOverlapNbasesMin, allele-swapped reads of --waspOutputMode)
+int sah_needs_second_batch(void *h) { Runner *r = (Runner *)h; return ((r->P.peOverlapNbasesMin > 0 && r->P.dev.readNmates == 2) || r->P.wasp) ? 1 : 0; }
 void sah_fast_path_counts(void *h, uint64_t out[2]) { Runner *r = (Runner *)h; out[0] = r->nMappedWrites; out[1] = r->reader.mappedBatches.load(); }
 void sah_emit_seconds(void *h, double out[4]) { Runner *r = (Runner *)h; out[0] = r->tEmitWaitSet; out[1] = r->tEmitFormat; out[2] = r->tEmitTail; out[3] = r->tWriter; }
 int sah_next_batch(void *h, uint64_t maxReads, staramd_batch *out) {

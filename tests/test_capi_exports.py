@@ -13,7 +13,8 @@ HEADER = os.path.join(ROOT, "include", "star_amd.h")
 
 
 def _declared():
-    txt = open(HEADER).read()
+    """every entry point of the engine's headers: the boundary itself (star_amd.h) and its optional companion (star_amd_async.h: upload ahead, the two halves of a batch)"""
+    txt = open(HEADER).read() + open(os.path.join(ROOT, "include", "star_amd_async.h")).read()
     return sorted(set(re.findall(r"\b(staramd_[a-z_]+)\s*\(", txt)))
 
 
@@ -22,7 +23,8 @@ def test_engine_exports_every_declared_symbol():
     lib = C.CDLL(capi.ENGINE_PATH)
     names = _declared()
     assert {"staramd_create", "staramd_map_batch", "staramd_map_resident", "staramd_update_index", "staramd_destroy",
-            "staramd_last_error", "staramd_get_counters", "staramd_get_timings"} <= set(names)
+            "staramd_last_error", "staramd_get_counters", "staramd_get_timings", "staramd_prefetch_batch", "staramd_prefetch_cancel", "staramd_map_begin", "staramd_map_wait",
+            "staramd_map_end"} <= set(names)
     for n in names:
         assert hasattr(lib, n), "libstaramd.so does not export " + n
 

@@ -84,9 +84,9 @@ def fast_paths(stderr):
     """the front end's count of batches that took a path with a silent fallback behind it (include/star_amd_cli.h fastPaths): output written through a mapping of the
     file, input read in place from mappings of the files, uploads started ahead of their staramd_map_batch call"""
     import re
-    m = re.search(r"fast paths: output through a file mapping (\d+) batches, input from file mappings (\d+), uploads prefetched (\d+)", stderr)
+    m = re.search(r"fast paths: output through a file mapping (\d+) batches, input from file mappings (\d+), uploads prefetched (\d+), kernels begun beside the copy of the results before them (\d+)", stderr)
     assert m, stderr[-800:]
-    return {"out_mapped": int(m.group(1)), "in_mapped": int(m.group(2)), "prefetched": int(m.group(3))}
+    return {"out_mapped": int(m.group(1)), "in_mapped": int(m.group(2)), "prefetched": int(m.group(3)), "overlapped": int(m.group(4))}
 
 
 @pytest.mark.parametrize("name,more,batch", CASES)
