@@ -17,7 +17,7 @@
 extern "C" __global__ void k_seed_search(const DevIndex *X, DevBatch B, DSeed *scratch, u32 scratchPerLane, const u32 *inList);
 extern "C" __global__ void k_seed_plan(const DevIndex *X, DevBatch B, SeedWork W);
 extern "C" __global__ void k_seed_units(const DevIndex *X, DevBatch B, SeedWork W);
-extern "C" __global__ void k_seed_merge(const DevIndex *X, DevBatch B, SeedWork W, DSeed *scratch, u32 scratchPerLane);
+extern "C" __global__ void k_seed_merge(const DevIndex *X, DevBatch B, SeedWork W);
 extern "C" __global__ void k_pack_reads(DevBatch B, u32 *packed, u32 packWords);
 extern "C" __global__ void k_windows(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 mode, u32 lightEst, u32 useMid, u32 hashBits);
 extern "C" __global__ void k_windows_big(const DevIndex *X, DevBatch B, u8 *scratch, u32 capW, u32 capBlocks, u32 lightEst, u32 useMid);
@@ -621,7 +621,7 @@ static int enqueueAll(staramd_ctx *c) {
         if (c->seedUnits) {
             hipLaunchKernelGGL(k_seed_plan, dim3((n + 255) / 256), block, 0, s, c->dX, B, c->seedWork);
             hipLaunchKernelGGL(k_seed_units, dim3(c->seedUnitLanes / 256), block, 0, s, c->dX, B, c->seedWork);
-            hipLaunchKernelGGL(k_seed_merge, dim3(lanes / 256), block, 0, s, c->dX, B, c->seedWork, c->scrSeed, c->seedPerLane);
+            hipLaunchKernelGGL(k_seed_merge, dim3(std::min<u32>((n + 3) / 4, (u32)c->nCU * 8u)), block, 0, s, c->dX, B, c->seedWork);
             hipLaunchKernelGGL(k_seed_search, dim3(std::min<u32>(lanes / 256, 64u)), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane, (const u32 *)c->seedWork.handOn);      // what the units handed on (rarely anything)
         } else
         hipLaunchKernelGGL(k_seed_search, dim3(lanes / 256), block, 0, s, c->dX, B, c->scrSeed, c->seedPerLane, (const u32 *)nullptr);

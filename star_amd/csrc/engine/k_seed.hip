@@ -438,43 +438,70 @@ extern "C" __global__ void __launch_bounds__(256, SEED_WAVES) k_seed_units(const
     addCounters(B, cn);
 }
 
-extern "C" __global__ void __launch_bounds__(256) k_seed_merge(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W, DSeed *scratch, u32 scratchPerLane) {
-    const DevIndex &X = *Xp;
-    const u32 gl = blockIdx.x * blockDim.x + threadIdx.x, lane = laneId();
-    SeedState st; st.PC = scratch + (u64)gl * scratchPerLane; st.cap = scratchPerLane;
+// storeAligns (ReadAlign_storeAligns.cpp:10-160) over ALL seeds of a read at once, wave = read, lane = seed (in schedule order).  What the sequential inserts produce is a
+// function of the set: the table sorted by (rStart ascending, Length descending) (:31-42: a seed goes in front of the shorter ones with its rStart and behind everything that
+// starts earlier), a seed dropped when an EARLIER one of the schedule has its (rStart, Length) (:38: the first one stays -- their `dir` may differ), seeds with more loci than
+// seedMultimapNmax never stored (:14-21); multNmin / multNminL = the smallest number of loci among the seeds that were too many and the stored multimappers, the first of the
+// schedule among equals (:16-19, :152-158: strictly smaller replaces).  So: a key per lane, two all-pairs passes over broadcast keys (duplicates, then ranks) -- no sorted
+// inserts through memory, which took k_seed_merge 1.45 ms with a lane per read.
+extern "C" __global__ void __launch_bounds__(256) k_seed_merge(const DevIndex *__restrict__ Xp, DevBatch B, SeedWork W) {
+    const DevIndex &X = *Xp; const staramd_params &P = X.P;
+    const u32 lane = laneId(), nWaves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + WAVE_INDEX(threadIdx.x >> 6);
+    u32 poolNext = 0, poolEnd = 0;                   // the wavefront's piece of the seed pool: taken 256 rows at a time (one allocation per read would be 400 k atomics on one counter)
     u32 nSeedsTot = 0;
-    for (u32 ir0 = 0; ir0 < B.nReads; ir0 += gridDim.x * blockDim.x) {           // (the lanes of a wavefront go round together: one pool allocation per wavefront and trip)
-        const u32 ir = ir0 + gl;
-        bool live = ir < B.nReads, wants = false;
-        SeedPlan pl; DRead rd;
-        if (live) {
-            pl = W.plan[ir];
-            bool handOn = pl.handOn != 0;
-            for (u32 g = 0; g < pl.nGroups && !handOn; g++) handOn = (W.groupHead[pl.group0 + g] & 0x80000000u) != 0;       // a unit ran out of slots (or met an interval of > 2^32 entries)
-            if (handOn) { const u32 k = atomicAdd(&B.cursors[CUR_OVF_SEED], 1u); W.handOn[k] = ir; live = false; }
-        }
-        st.nP = 0;
-        if (live) {
-            st.nA = 0; st.multNmin = 0; st.multNminL = 0; st.fatal = false;
-            for (u32 g = 0; g < pl.nGroups; g++) {
-                const u32 h = W.groupHead[pl.group0 + g];
-                const SeedSlot *c = W.slots + (u64)(pl.group0 + g) * SEED_SLOTS;
-                for (u32 k = 0; k < (h & 0xFFu); k++) {
-                    const SeedSlot x = c[k];
-                    storeAligns(X, st, (h >> 8) & 1u, x.shift, (x.L & 0x8000u) ? 0x100000000ull : (u64)x.nrep, x.L & 0x7FFFu, x.i0, (h >> 16) & 0xFFu);
-                }
-            }
-            nSeedsTot += st.nP;
-            wants = classifyRead(X.P, rd, (u32)(B.readOffset[ir + 1] - B.readOffset[ir]), st, pl.nSplit, pl.LgoodMin);
-        }
-        const u32 need = wants ? st.nP : 0u;
-        u32 incl = need;
+    for (u32 ir = wave; ir < B.nReads; ir += nWaves) {
+        const SeedPlan pl = W.plan[ir];
+        const u32 nG = pl.nGroups;
+        u32 head = 0;
+        if (lane < nG) head = W.groupHead[pl.group0 + lane];
+        bool handOn = pl.handOn != 0 || nG > 64u || __ballot(lane < nG && (head & 0x80000000u)) != 0;          // a unit ran out of slots (or met an interval of > 2^32 entries)
+        // seeds of the groups, one behind the other: inclusive sums of the counts over the lanes
+        u32 incl = lane < nG ? (head & 0xFFu) : 0u;
         for (u32 d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl((int)incl, (int)(lane >= d ? lane - d : 0u), 64); if (lane >= d) incl += o; }
-        const u32 tot = (u32)__shfl((int)incl, 63, 64);
-        u32 base = 0;
-        if (lane == 0 && tot) base = atomicAdd(&B.cursors[CUR_SEED], tot);
-        base = first32(base);
-        if (live) { if (wants) placeSeeds(B, rd, st, base + incl - need); B.reads[ir] = rd; }
+        const u32 T = (u32)__shfl((int)incl, 63, 64);
+        if (T > 64u) handOn = true;
+        if (handOn) { if (lane == 0) { const u32 k = atomicAdd(&B.cursors[CUR_OVF_SEED], 1u); W.handOn[k] = ir; } continue; }
+        // lane i < T: the group its seed is in = the first group whose inclusive sum is above i
+        u32 g = 0;
+        for (u32 k = 0; k < nG; k++) { const u32 e = laneGet32(incl, k); if (lane >= e) g = k + 1u; }
+        const bool have = lane < T;
+        if (!have) g = 0;
+        const u32 hg = (u32)__shfl((int)head, (int)g, 64), eg = (u32)__shfl((int)incl, (int)g, 64);
+        SeedSlot c; c.i0 = 0; c.nrep = 0; c.shift = 0; c.L = 0;
+        if (have) c = W.slots[(u64)(pl.group0 + g) * SEED_SLOTS + (lane - (eg - (hg & 0xFFu)))];
+        const u32 iDir = (hg >> 8) & 1u, iFrag = (hg >> 16) & 0xFFu, L = c.L & 0x7FFFu;
+        const bool tooMany = have && ((c.L & 0x8000u) != 0 || c.nrep > P.seedMultimapNmax), stor = have && !tooMany;
+        const u32 rStart = iDir == 0 ? c.shift : c.shift + 1u - L;
+        const u32 key = (rStart << 16) | (0xFFFFu - L);
+        const u64 storMask = __ballot(stor);
+        bool dup = false;
+        for (u64 m = storMask; m; m &= m - 1) { const u32 j = firstLane(m); const u32 kj = laneGet32(key, j); dup |= j < lane && kj == key; }
+        const bool kept = stor && !dup;
+        const u64 keptMask = __ballot(kept);
+        u32 rank = 0;
+        for (u64 m = keptMask; m; m &= m - 1) { const u32 j = firstLane(m); const u32 kj = laneGet32(key, j); rank += kj < key ? 1u : 0u; }
+        SeedState st; st.PC = nullptr; st.cap = 0;
+        st.nP = (u32)__popcll(keptMask); st.nA = storMask ? 1u : 0u;
+        st.fatal = st.nP > P.seedPerReadNmax;
+        // multNmin / multNminL
+        const bool counts = tooMany || (kept && c.nrep != 1u);
+        const u32 v = counts ? c.nrep : 0xFFFFFFFFu;          // (a number of loci beyond 32 bits is kept as 0xFFFFFFFF, as storeAligns keeps it)
+        const u64 cm = __ballot(counts);
+        st.multNmin = 0; st.multNminL = 0;
+        if (cm) { const u32 vmin = ~waveMaxU32(~v); const u64 at = __ballot(counts && v == vmin); const u32 f = firstLane(at); st.multNmin = vmin; st.multNminL = laneGet32(L, f); }
+        nSeedsTot += st.nP;
+        DRead rd;
+        const bool wants = classifyRead(P, rd, (u32)(B.readOffset[ir + 1] - B.readOffset[ir]), st, pl.nSplit, pl.LgoodMin);
+        if (wants) {
+            if (poolNext + st.nP > poolEnd) { u32 b = 0; if (lane == 0) b = atomicAdd(&B.cursors[CUR_SEED], 256u); poolNext = first32(b); poolEnd = poolNext + 256u; }
+            if (poolNext + st.nP > B.seedCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_SEEDPOOL); }
+            else {
+                rd.seedOffset = poolNext; rd.nSeeds = st.nP;
+                if (kept) { DSeed sd; sd.saStart = c.i0; sd.nrep = c.nrep; sd.rStart = (u16)rStart; sd.L = (u16)L; sd.dir = (u8)iDir; sd.iFrag = (u8)iFrag; for (int k = 0; k < 6; k++) sd.pad[k] = 0; B.seedPool[poolNext + rank] = sd; }
+            }
+            poolNext += st.nP;
+        }
+        if (lane == 0) B.reads[ir] = rd;
     }
-    { const u32 ns = waveSumU32(nSeedsTot); if (lane == 0) atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)ns); }
+    if (lane == 0 && nSeedsTot) atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
 }

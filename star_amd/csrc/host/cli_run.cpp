@@ -313,10 +313,12 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
             }
         });
         std::vector<std::thread> mappers;
-        // One context per device and no second batch per batch (merged mates, allele-swapped reads): the mapper keeps TWO batches going -- when the kernels of batch k are done it
-        // begins batch k+1 before the results of k leave the device (staramd_map_begin / _wait / _end, include/star_amd_async.h), so the ~100 MB copy runs beside kernels.
-        // STARAMD_NO_OVERLAP=1: one blocking staramd_map_batch call per batch (the loop below, which every other configuration takes).
-        const bool overlapCopies = nDev == nOwners && !sah_needs_second_batch(h) && !getenv("STARAMD_NO_OVERLAP");
+        // STARAMD_OVERLAP_COPIES=1 (one context per device, no second batch per batch -- merged mates, allele-swapped reads): the mapper keeps TWO batches going -- when the kernels
+        // of batch k are done it begins batch k+1 before the results of k leave the device (staramd_map_begin / _wait / _end, include/star_amd_async.h), so the ~100 MB copy runs
+        // beside kernels.  Measured (profiles/r05_e2e_session8_*): a batch every 46.2 ms instead of 47.7 -- but the copy is a shader ("blit") kernel of the runtime, the persistent
+        // kernels of batch k+1 leave it no CU, and it completes when THEY do: the results of every batch arrive one batch late, the post-map stage and the writer run one
+        // batch behind, and a run of 20 batches ends 40 ms later than with blocking calls.  Worth 3 % on a long run, a loss on a short one: off by default.
+        const bool overlapCopies = nDev == nOwners && !sah_needs_second_batch(h) && getenv("STARAMD_OVERLAP_COPIES") && atoi(getenv("STARAMD_OVERLAP_COPIES")) > 0;
         for (int d = 0; d < nDev && overlapCopies; d++) mappers.emplace_back([&, d] {
             auto pushDone = [&](const Msg &m) { { std::lock_guard<std::mutex> l(doneM); done[m.seq] = m; } doneCv.notify_all(); };
             auto begin = [&](Msg &m) -> bool {            // false: the batch goes down the pipeline unmapped (an error is recorded, or it carries no reads)

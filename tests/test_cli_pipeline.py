@@ -212,6 +212,11 @@ def test_reader_on_input_shapes(shape, mapped, tmp_path, built):
                  env=None if mapped else {"STARAMD_NO_INPUT_MMAP": "1"})
 
 
+def test_mapper_loop_with_two_batches_going(tmp_path, built):
+    """STARAMD_OVERLAP_COPIES=1: the front end's second mapper loop (begin / wait / end; here over the oracle stand-in, which maps at `end`): same outputs"""
+    run_cli_case(CLI, "pe101", ["--outSAMunmapped", "Within"], 70, tmp_path, env={"STARAMD_OVERLAP_COPIES": "1"})
+
+
 @pytest.mark.parametrize("mapped", [True, False])
 def test_regular_file_then_fifo_in_one_list(mapped, tmp_path, built):
     """--readFilesIn a.fq,<fifo>: the first file of a mate is read through its mapping, the second cannot be mapped and takes the copying reader -- the batch that starts the
