@@ -109,6 +109,7 @@ enum { CUR_SEED = 0 * CS, CUR_WIN = 1 * CS, CUR_WA = 2 * CS, CUR_TR = 4 * CS, CU
        CUR_ST_REDO = 19 * CS, CUR_ST_TICKET1 = 20 * CS,                            // pass 1, full re-walk (no candidate log available)
        CUR_ST_REPLAY = 21 * CS, CUR_ST_TICKETR = 22 * CS,                          // pass 1, replay of the candidate log
        CUR_ST_HEAVY = 23 * CS, CUR_ST_TICKETH = 24 * CS,                           // pass 0, items deferred by the lean-LDS launch to the full-size launch
+       CUR_ST_HEAVY2 = 30 * CS, CUR_ST_TICKETH2 = 31 * CS,                         // pass 0 in three launches (lane kernel, main cooperative launch, full-depth launch): what the main launch defers
        // seed stage, lane = unit (k_seed.hip): groups and units handed out by k_seed_plan, the ticket of k_seed_units, reads handed on to k_seed_search
        CUR_SEED_GROUPS = 26 * CS, CUR_SEED_UNITS = 27 * CS, CUR_TICKET_SEED_UNITS = 28 * CS, CUR_OVF_SEED = 29 * CS,
        CUR_N = 32 * CS };
@@ -133,6 +134,7 @@ struct DevBatch {
     u32 *ovfWin2;      // reads deferred by the middle pass (larger LDS table) to the pass with the table in global memory
     u32 *redoList, *replayList;        // stitch pass-1 work lists (window ids)
     u32 *heavyList;                    // pass-0 items whose windows hold more seeds than the lean launch has LDS for
+    u32 *heavyList2;                   // ... and, when the lane kernel fills heavyList, what the main cooperative launch behind it hands on to the full-depth one
     u8 *candPool; u64 candWaveBytes;   // candidate logs: one private region per wavefront of k_stitch_win
     u32 *candTops;                     // bytes of its region a wavefront of the first pass-0 launch used (the second one goes on behind them)
     u32 *cursors;      // CUR_*

@@ -87,6 +87,9 @@ struct staramd_ctx {
     // lean pass-0 launch: windows of at most leanDepth-1 seeds (almost all) walked with a small LDS slice per wavefront, so that more
     // wavefronts are resident per CU; the others are handed to a second launch with the full-size slice (0 = one full-size launch)
     u32 leanDepth = 0, leanArena = 0, stBlocksLean = 0;
+    // main cooperative launch behind the lane kernel: a walk stack of mainDepth frames (windows of up to mainDepth - 1 seeds: all but a handful) makes the wavefront's LDS
+    // slice 10 KB instead of 12.5 = a FOURTH block per CU; what holds more seeds goes on to the full-depth launch
+    u32 mainDepth = 0, stBlocksMain = 0;
     // lane-per-read stitcher (k_stitch_lane.hip): takes the light reads whose windows hold few seeds; the cooperative kernel gets the rest
     u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 3; u8 *scrLane = nullptr;
     u32 prune = 7;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first, bit 2 = single-mate leaves of two-mate windows skipped (5.6)
@@ -273,6 +276,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &B.redoList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.replayList, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.heavyList, (u64)B.winCap))) return rc;
+    if ((rc = devAlloc(R, &B.heavyList2, (u64)B.winCap))) return rc;
     if ((rc = devAlloc(R, &B.trPool, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &B.exPool, (u64)B.exCap))) return rc;
     if ((rc = devAlloc(R, &B.costHist, (u64)64))) return rc;
@@ -365,6 +369,15 @@ static int allocWork(staramd_ctx *c) {
     // per SIMD -- was measured and removed in round 5: stitch stage 24.6 ms against 22.7, profiles/r05_ab_session1_*.txt)
     c->leanDepth = envU32("STARAMD_LEAN_DEPTH", 9); c->leanArena = envU32("STARAMD_LEAN_ARENA", 2048) & ~31u;
     if (c->leanDepth >= c->capDepth) c->leanDepth = 0;
+    c->mainDepth = envU32("STARAMD_MAIN_DEPTH", 33);
+    if (c->mainDepth < 3 || c->mainDepth >= c->capDepth) c->mainDepth = 0;
+    if (c->mainDepth) {
+        int mpCU = stPerCU;
+        size_t ldsMain = 4 * (size_t)(stitchStateBytesH(c->mainDepth, c->capRank, c->arenaFast) + 27 * 4 + 16);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&mpCU, k_stitch_win, 256, ldsMain) != hipSuccess || mpCU < 1) mpCU = stPerCU;
+        c->stBlocksMain = (u32)c->nCU * envU32("STARAMD_MAIN_BLOCKS_PER_CU", (u32)mpCU);
+        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_win main launch: depth %u, %d blocks/CU (LDS %zu B/block)\n", c->mainDepth, mpCU, ldsMain);
+    }
     c->stBlocksLean = 0;
     if (c->leanDepth) {
         int lpCU = stPerCU;
@@ -385,12 +398,12 @@ static int allocWork(staramd_ctx *c) {
         if ((rc = devAlloc(R, &c->scrLane, (u64)c->laneBlocks * 256 * c->laneArenaBytes))) return rc;
         if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: k_stitch_lane %d blocks/CU (LDS %zu B/block), %u blocks, %u B of record arena per lane\n", lnPerCU, ldsLane, c->laneBlocks, c->laneArenaBytes);
     }
-    const u32 maxStBlocks = std::max(std::max(c->stBlocks, c->stBlocksLean), c->replayBlocks);
+    const u32 maxStBlocks = std::max(std::max(std::max(c->stBlocks, c->stBlocksMain), c->stBlocksLean), c->replayBlocks);
     if ((rc = devAlloc(R, &c->scrStitchBig, (u64)maxStBlocks * 4 * c->arenaBig))) return rc;
     // candidate logs: one private region per wavefront; sized so that a wavefront's share of a full batch fits
     B.candWaveBytes = ((u64)envU32("STARAMD_CAND_KB_PER_WAVE", 0) * 1024) & ~31ull;
     if (B.candWaveBytes == 0) { u64 per = (u64)N * 6144 / ((u64)c->stBlocks * 4) + 262144; B.candWaveBytes = std::min<u64>(per, 0xFFFF0000ull) & ~31ull; }
-    if ((rc = devAlloc(R, &B.candPool, (u64)std::max(c->stBlocks, c->stBlocksLean) * 4 * B.candWaveBytes))) return rc;
+    if ((rc = devAlloc(R, &B.candPool, (u64)std::max(std::max(c->stBlocks, c->stBlocksMain), c->stBlocksLean) * 4 * B.candWaveBytes))) return rc;
     if ((rc = devAlloc(R, &B.candTops, (u64)maxStBlocks * 4 + 64))) return rc;
     return 0;
 }
@@ -588,6 +601,7 @@ static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
         if ((rc = devRealloc(R, &B.redoList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.replayList, (u64)B.winCap))) return rc;
         if ((rc = devRealloc(R, &B.heavyList, (u64)B.winCap))) return rc;
+        if ((rc = devRealloc(R, &B.heavyList2, (u64)B.winCap))) return rc;
     }
     if (flags & OVF_TRPOOL) {
         B.trCap = grow(B.trCap, cur[CUR_TR]); B.exCap = grow(B.exCap, cur[CUR_EX]);
@@ -612,7 +626,7 @@ static int enqueueAll(staramd_ctx *c) {
     HIPCHK(hipMemsetAsync(B.cursors, 0, CUR_N * sizeof(u32), s));
     HIPCHK(hipMemsetAsync(B.counters, 0, DC_N * sizeof(u64), s));
     HIPCHK(hipMemsetAsync(B.costHist, 0, 64 * sizeof(u32), s));
-    HIPCHK(hipMemsetAsync(B.candTops, 0, ((size_t)std::max(std::max(c->stBlocks, c->stBlocksLean), c->replayBlocks) * 4 + 64) * sizeof(u32), s));
+    HIPCHK(hipMemsetAsync(B.candTops, 0, ((size_t)std::max(std::max(std::max(c->stBlocks, c->stBlocksMain), c->stBlocksLean), c->replayBlocks) * 4 + 64) * sizeof(u32), s));
     dim3 block(256);
     u32 ldsWords = ((c->residentMaxLread + 7) / 8) | 1u;              // odd stride: conflict-free LDS staging
     HIPCHK(hipEventRecord(c->ev[0], s));
@@ -653,6 +667,11 @@ static int enqueueAll(staramd_ctx *c) {
             if (mode == 0 && c->laneBlocks && laneFits) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
                 hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, c->laneClass);
                 HIPCHK(hipEventRecord(c->ev[8], s));
+                if (c->mainDepth) {     // the cooperative walk in two launches: windows of up to mainDepth - 1 seeds at four blocks per CU, the few that hold more at full depth
+                    const size_t ldsMain = 4 * (readBytes + stitchStateBytesH(c->mainDepth, c->capRank, c->arenaFast));
+                    hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocksMain), block, ldsMain, s, c->dX, B, c->scrStitchBig, c->mainDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 3u, prune);
+                    hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 4u, prune);
+                } else
                 hipLaunchKernelGGL(k_stitch_win, dim3(c->stBlocks), block, ldsFast, s, c->dX, B, c->scrStitchBig, c->capDepth, c->capRank, c->arenaFast, c->arenaBig, ldsWords, 2u, prune);
             } else
             if (mode == 0 && c->leanDepth) {       // pass 0 in two launches: lean LDS slices for the windows of few seeds, full-size slices for the rest
@@ -685,7 +704,7 @@ static int enqueueAll(staramd_ctx *c) {
 static int collectAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     u32 *hs = c->hostScratch;
     HIPCHK(waitStream(c));
-    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: seed units %u in %u groups, reads handed on to k_seed_search %u; stitch work items %u, handed on to the full-size launch %u\n", hs[8 + CUR_SEED_UNITS], hs[8 + CUR_SEED_GROUPS], hs[8 + CUR_OVF_SEED], hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY]);
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: seed units %u in %u groups, reads handed on to k_seed_search %u; stitch work items %u, handed on by the lane kernel %u, by the main cooperative launch to the full-depth one %u\n", hs[8 + CUR_SEED_UNITS], hs[8 + CUR_SEED_GROUPS], hs[8 + CUR_OVF_SEED], hs[8 + CUR_ITEM], hs[8 + CUR_ST_HEAVY], hs[8 + CUR_ST_HEAVY2]);
     HIPCHK(hipEventElapsedTime(&r->msSeed, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&r->msWindows, c->ev[1], c->ev[2]));
     HIPCHK(hipEventElapsedTime(&r->msStitch, c->ev[2], c->ev[3]));

@@ -973,16 +973,19 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     gcInit(c.ca); gcInit(c.cb);
     // mode 0: pass 0 over every item; mode 2: pass 0 over the items the lean-LDS launch (mode 0 with a small capDepth) handed on;
     // mode 1: pass 1, full re-walk of the windows on the redo list
+    // mode 3: pass 0 with a lean LDS slice over the items the LANE kernel handed on (heavyList); what outgrows the slice goes to heavyList2, which
+    // mode 4 = mode 2 over that list takes
     const bool pass0 = mode != 1;
     c.candBase = B.candPool + (u64)waveId * B.candWaveBytes; c.candTop = 0; c.candCap = (u32)B.candWaveBytes; c.nCand = 0; c.logOn = pass0; c.logOvf = false;
-    if (mode == 2) {               // the log region of a wavefront is shared by the pass-0 launches: go on behind what the launch before wrote
+    if (mode == 2 || mode == 3 || mode == 4) {               // the log region of a wavefront is shared by the pass-0 launches: go on behind what the launch before wrote
         c.candTop = (u32)B.candTops[waveId];
     }
     // break points of the genomic-length score term: lane k keeps points k and k+64 in registers for the whole kernel
     const u64 glb0 = lane < X.nBreak ? X.glBreak[lane] : ~0ull, glb1 = lane + 64u < X.nBreak ? X.glBreak[lane + 64u] : ~0ull;
     const u32 *list; u32 nItems, ticketSlot;
     if (mode == 0) { list = B.order; nItems = ((B.cursors[CUR_ITEM] + 63u) / 64u) * 64u; ticketSlot = CUR_ST_TICKET0; }
-    else if (mode == 2) { list = B.heavyList; nItems = B.cursors[CUR_ST_HEAVY]; ticketSlot = CUR_ST_TICKETH; }
+    else if (mode == 2 || mode == 3) { list = B.heavyList; nItems = B.cursors[CUR_ST_HEAVY]; ticketSlot = CUR_ST_TICKETH; }
+    else if (mode == 4) { list = B.heavyList2; nItems = B.cursors[CUR_ST_HEAVY2]; ticketSlot = CUR_ST_TICKETH2; }
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
     u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0, nRewalk = 0, nRewalkWin = 0, nSkippedLeaves = 0;
     const bool sweepEnable = (pruneEnable & 2u) != 0, skipEnable = (pruneEnable & 4u) != 0;
@@ -1015,8 +1018,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         u32 maxSeeds; i32 bestSoFar = 0; u32 nWinRead = 0;
         if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; maxSeeds = rd.wtOffset; nWinRead = rd.nWin; }
         else maxSeeds = first32(B.winPool[item].nWA);
-        if (mode == 0 && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {       // more seeds than this (lean) launch has LDS rows for: the full-size launch takes the item
-            if (lane == 0) { u32 k = atomicAdd(&B.cursors[CUR_ST_HEAVY], 1u); B.heavyList[k] = item; }
+        if ((mode == 0 || mode == 3) && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {       // more seeds than this (lean) launch has LDS rows for: the full-size launch takes the item
+            if (lane == 0) { u32 k = atomicAdd(&B.cursors[mode == 0 ? CUR_ST_HEAVY : CUR_ST_HEAVY2], 1u); (mode == 0 ? B.heavyList : B.heavyList2)[k] = item; }
             continue;
         }
         // A light read is walked in up to two sweeps.  Sweep 0 (only when some of its windows hold seeds of both mates and some do not): the
@@ -1140,7 +1143,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         }
     }
     if (lane == 0) {
-        if (mode == 0) B.candTops[waveId] = c.candTop;
+        if (mode == 0 || mode == 3) B.candTops[waveId] = c.candTop;
         atomicAdd((unsigned long long *)&B.counters[DC_nGstitch], (unsigned long long)c.nGstitch);
         atomicAdd((unsigned long long *)&B.counters[DC_nStitchCalls], (unsigned long long)c.nStitchCalls);
         atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);

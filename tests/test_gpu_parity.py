@@ -146,6 +146,8 @@ FORCED = {
     "lane_all_classes": {"STARAMD_LANE_CLASS": "31"},         # every light read of few seeds per window through the lane-per-read stitcher (k_stitch_lane.hip), not only the cheapest classes
     "lane_off": {"STARAMD_LANE": "0"},                        # ... and none of them: the cooperative walk alone
     "lean_tiny_lane_off": {"STARAMD_LEAN_DEPTH": "3", "STARAMD_LANE": "0"},
+    "main_depth_tiny": {"STARAMD_MAIN_DEPTH": "3"},           # the main cooperative launch behind the lane kernel holds windows of 2 seeds: almost everything goes on to the full-depth launch
+    "main_depth_off": {"STARAMD_MAIN_DEPTH": "0"},            # one cooperative launch at full depth (three blocks per CU)
     "lane_tiny_arena": {"STARAMD_LANE_CLASS": "31", "STARAMD_LANE_ARENA": "256"},   # records outgrow the lane's arena: the read goes on to the cooperative kernel
     "no_sjdb_hash": {"STARAMD_NO_SJDB_HASH": "1"},            # annotated junctions looked up by bisection (what an index does whose coordinates / junction count do not fit the hash)
     "no_leaf_skipping": {"STARAMD_PRUNE": "3"},               # window pruning as in round 3, every leaf of every walked window finalised
