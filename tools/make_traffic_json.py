@@ -65,6 +65,9 @@ def main():
         m = re.search(r"staramd: k_stitch_win (\d+) blocks/CU \(LDS \d+ B/block\), k_windows (\d+) blocks/CU, k_seed_search (\d+) blocks/CU", open(os.path.join(d, "bench_plain.err")).read())
         if m:
             res["k_stitch_win"]["waves_per_simd_resident"] = int(m.group(1)); res["k_windows"]["waves_per_simd_resident"] = int(m.group(2)); res["k_seed_search"]["waves_per_simd_resident"] = int(m.group(3))
+        m = re.search(r"staramd: k_stitch_win main launch: depth (\d+), (\d+) blocks/CU", open(os.path.join(d, "bench_plain.err")).read())
+        if m:           # (the launch that walks all but a handful of the windows; the full-depth launch behind it keeps the figure above)
+            res["k_stitch_win"]["waves_per_simd_resident_full_depth_launch"] = res["k_stitch_win"].get("waves_per_simd_resident"); res["k_stitch_win"]["waves_per_simd_resident"] = int(m.group(2))
     except Exception:
         pass
     gc = os.path.join(d, "gather_ceiling.txt")
