@@ -289,6 +289,9 @@ uint64_t FastqReader::fillSam(uint64_t want, ReadBatch &b) {
 uint64_t FastqReader::fillMapped(int m, uint64_t want, ReadBatch &b) {
     std::vector<uint64_t> &ls = b.lineStart[m], &le = b.lineEnd[m], &nlp = lineRaw[m];
     ls.clear(); le.clear(); nlp.clear(); b.text[m].clear();
+    // a file that shrank under its mapping (truncated or rewritten while the run reads it) would end the process with SIGBUS inside the scan: looked at before every
+    // batch and reported like any other read error (it cannot close the window between this look and the scan; it does turn the common accident into a message)
+    if (curMap[m].p && f[m]) { struct stat st; if (fstat(fileno(f[m]), &st) != 0 || (uint64_t)st.st_size < (uint64_t)curMap[m].n) { ioError = EIO; eof[m] = true; return 0; } }
     const char *tx = curMap[m].p ? curMap[m].p + mapPos[m] : nullptr;
     const uint64_t avail = curMap[m].p ? curMap[m].n - mapPos[m] : 0;
     b.mapped[m] = tx;

@@ -249,3 +249,4 @@ def test_writer_through_a_mapping_of_the_output_file(mode, more, tmp_path, built
     fp = run_cli_case(CLI, "pe101", more, 150, tmp_path, env={"STARAMD_WRITER_MMAP": mode, "STARAMD_WRITER_THREADS": "3"})
     # round 4 shipped this test with a writer whose mapping always failed (output opened write-only) and whose fallback produced the same bytes: the count is the test
     assert (fp["out_mapped"] == 0) if mode == "0" else (fp["out_mapped"] >= 2), fp
+
