@@ -1,6 +1,6 @@
 """Static figures of the two wave-cooperative kernels as the compiler reports them (tools/isa_stats.sh; hipcc cross-compiles without a GPU).
 The register allocator has two regimes for k_stitch_win -- wave-uniform state in scalar registers (106 VGPRs, no scratch) or in vector registers (168 + spills) -- and
-small edits of the kernel flip it back into the second (tools/R05_PLAN.md).  This test is what notices."""
+small edits of the kernel flip it back into the second (tools/isa_stats.sh k_stitch shows which one a build is in).  This test is what notices."""
 import os
 import re
 import subprocess
