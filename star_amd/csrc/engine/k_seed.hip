@@ -2,7 +2,7 @@
 //
 // Replaces, per read, the seed phase of ReadAlign::mapOneRead (source/ReadAlign_mapOneRead.cpp:17-93):
 // qualitySplit (SequenceFuns.cpp:411-444), maxMappableLength2strands
-// (ReadAlign_maxMappableLength2strands.cpp:5-115), maxMappableLength / findMultRange /
+// (ReadAlign_maxMappableLength2strands.cpp:5-115), maxMappableLength / findMultRange (here: mmpRun) /
 // compareSeqToGenome (SuffixArrayFuns.cpp:10-207) and storeAligns (ReadAlign_storeAligns.cpp:10-160).
 //
 // Mapping (round 5): one lane = one UNIT of a read's search schedule.  The schedule of mapOneRead is a nest -- pieces x directions x start points x the loop that
@@ -70,51 +70,53 @@ __device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, 
     return N;
 }
 
-__device__ __forceinline__ u64 medianUint2(u64 a, u64 b) { return a / 2 + b / 2 + (a % 2 + b % 2) / 2; }
-
-// SuffixArrayFuns.cpp:106-131.  IDX: suffix-array indices inside one search are offsets from `base` (the lower end of the interval the SAindex
-// look-up returned).  An interval is almost always shorter than 2^32 entries; then the seven indices of a search are 32-bit values (IDX = u32),
-// which halves the registers they take in a kernel that is held to 64.  The same code with IDX = u64 serves the rest (a look-up whose upper
-// neighbour is absent searches up to the end of a suffix array of 6.3 * 10^9 entries).
-template <class IDX> __device__ static IDX findMultRange(const DevIndex &X, const u8 *R, u64 base, IDX i3, u32 L3, IDX i1, u32 L1, IDX i1a, u32 L1a, IDX i1b, u32 L1b, bool dirR, u32 S, SeedCnt &cn) {
-    bool compRes;
-    if (L1 < L3) { L1b = L1; i1b = i1; i1a = i3; }
-    else if (L1a < L1) { L1b = L1a; i1b = i1a; i1a = i1; }
-    while (((u64)i1b + 1 < (u64)i1a) | ((u64)i1b > (u64)i1a + 1)) {
-        IDX i1c = (IDX)medianUint2(i1a, i1b);
-        u32 L1c = compareSeqToGenome(X, R, S, L3, L1b, base + i1c, dirR, compRes, cn);
-        if (L1c == L3) i1a = i1c; else { i1b = i1c; L1b = L1c; }
+// The maximal mappable prefix of the piece among the suffixes SA[first .. last] and the run of entries that reach it -- what SuffixArrayFuns.cpp:133-207 (maxMappableLength) and
+// :106-131 (findMultRange, twice) compute, in this engine's own shape.  The entries are sorted, so the match length of the piece rises towards the place where the piece itself
+// would be inserted and falls behind it; its maximum Lmax is reached by one contiguous run.  Three bisections over ONE kind of state, a pair (entry known to match less, entry
+// known to match at least as much):
+//   1. the insertion place: a bracket (lo, hi), lo sorts before the piece, hi behind it.  While it narrows, each side remembers the nearest entry outside that matched LESS than
+//      the bracket's end does (`loLess`: set when a step raised lo's match length) and the first entry that reached the end's length (`loSame`); an entry that matches all N
+//      bases ends the search at once.  Lmax = the longer of the two ends (the right one on a tie, as the reference decides), or N.
+//   2. the run's first entry: between the nearest entry known to match less than Lmax on the left and the nearest one known to reach it; compares stop at Lmax.
+//   3. its last entry, mirrored.
+// Which entries are probed on the way is an implementation detail (the result is a function of the interval and the piece); the probes here start every compare at the length
+// both ends of the current pair are known to share, as the reference's do.  IDX: offsets from `first` (u32 when the interval is shorter than 2^32 entries: half the registers).
+template <class IDX> struct LessSame { IDX less, same; u32 Lless; bool haveLess; };        // `less` matches Lless < the length `same` reaches; haveLess = false: nothing known, the interval's end
+template <class IDX> __device__ static IDX runEnd(const DevIndex &X, const u8 *R, u64 first, LessSame<IDX> p, u32 Lmax, u32 S, bool dirR, SeedCnt &cn) {
+    bool above;
+    if (!p.haveLess) return p.less;                             // (`less` then names the interval's own end, which reaches Lmax like everything up to `same`)
+    while (((u64)p.less + 1 < (u64)p.same) | ((u64)p.less > (u64)p.same + 1)) {
+        const IDX mid = (IDX)((u64)p.less / 2 + (u64)p.same / 2 + ((u64)p.less % 2 + (u64)p.same % 2) / 2);
+        const u32 Lm = compareSeqToGenome(X, R, S, Lmax, p.Lless, first + mid, dirR, above, cn);
+        if (Lm == Lmax) p.same = mid; else { p.less = mid; p.Lless = Lm; }
     }
-    return i1a;
+    return p.same;
 }
-
-// SuffixArrayFuns.cpp:133-207
-template <class IDX> __device__ static u64 maxMappableLengthT(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1in, u64 i2in, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
-    bool compRes;
-    const u64 base = i1in;
-    u32 L1, L2, L3, L1a, L1b, L2a, L2b; IDX i1 = 0, i2 = (IDX)(i2in - i1in), i3, i1a, i1b, i2a, i2b;
-    L1 = compareSeqToGenome(X, R, S, N, L, base + i1, dirR, compRes, cn);
-    L2 = compareSeqToGenome(X, R, S, N, L, base + i2, dirR, compRes, cn);
-    L = min(L1, L2);
-    L1a = L1; L1b = L1; i1a = i1; i1b = i1; L2a = L2; L2b = L2; i2a = i2; i2b = i2;
-    i3 = i1; L3 = L1;
-    while ((u64)i1 + 1 < (u64)i2) {
-        i3 = (IDX)medianUint2(i1, i2);
-        L3 = compareSeqToGenome(X, R, S, N, L, base + i3, dirR, compRes, cn);
-        if (L3 == N) break;
-        if (compRes) { if (L3 > L1) { L1b = L1a; L1a = L1; i1b = i1a; i1a = i1; } i1 = i3; L1 = L3; }
-        else { if (L3 > L2) { L2b = L2a; L2a = L2; i2b = i2a; i2a = i2; } i2 = i3; L2 = L3; }
-        L = min(L1, L2);
+template <class IDX> __device__ static u64 mmpRunT(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 first, u64 last, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
+    bool above;                                                   // the piece sorts behind the entry just compared
+    IDX lo = 0, hi = (IDX)(last - first);
+    u32 Llo = compareSeqToGenome(X, R, S, N, L, first + lo, dirR, above, cn);
+    u32 Lhi = compareSeqToGenome(X, R, S, N, L, first + hi, dirR, above, cn);
+    LessSame<IDX> left = {lo, lo, Llo, false}, right = {hi, hi, Lhi, false};
+    IDX top = lo; u32 Lmax = 0; bool full = false;
+    while ((u64)lo + 1 < (u64)hi) {
+        const IDX mid = (IDX)((u64)lo / 2 + (u64)hi / 2 + ((u64)lo % 2 + (u64)hi % 2) / 2);
+        const u32 Lm = compareSeqToGenome(X, R, S, N, min(Llo, Lhi), first + mid, dirR, above, cn);
+        if (Lm == N) { top = mid; full = true; break; }
+        if (above) { if (Lm > Llo) { left.less = lo; left.Lless = Llo; left.haveLess = true; left.same = mid; } lo = mid; Llo = Lm; }
+        else       { if (Lm > Lhi) { right.less = hi; right.Lless = Lhi; right.haveLess = true; right.same = mid; } hi = mid; Lhi = Lm; }
     }
-    if (L3 < N) { if (L1 > L2) { i3 = i1; L3 = L1; } else { i3 = i2; L3 = L2; } }
-    i1 = findMultRange<IDX>(X, R, base, i3, L3, i1, L1, i1a, L1a, i1b, L1b, dirR, S, cn);
-    i2 = findMultRange<IDX>(X, R, base, i3, L3, i2, L2, i2a, L2a, i2b, L2b, dirR, S, cn);
-    L = L3; ind0 = base + i1; ind1 = base + i2;
-    return (u64)i2 - (u64)i1 + 1;
+    if (full) Lmax = N; else if (Llo > Lhi) { top = lo; Lmax = Llo; } else { top = hi; Lmax = Lhi; }
+    // a side whose bracket end falls short of Lmax: the run begins between that end and `top`
+    if (Llo < Lmax) { left.less = lo; left.Lless = Llo; left.haveLess = true; left.same = top; }
+    if (Lhi < Lmax) { right.less = hi; right.Lless = Lhi; right.haveLess = true; right.same = top; }
+    const IDX r0 = runEnd<IDX>(X, R, first, left, Lmax, S, dirR, cn), r1 = runEnd<IDX>(X, R, first, right, Lmax, S, dirR, cn);
+    L = Lmax; ind0 = first + r0; ind1 = first + r1;
+    return (u64)r1 - (u64)r0 + 1;
 }
-__device__ __forceinline__ u64 maxMappableLength(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
-    if (i2 - i1 < 0xFFFFFFFFull) return maxMappableLengthT<u32>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
-    return maxMappableLengthT<u64>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
+__device__ __forceinline__ u64 mmpRun(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
+    if (i2 - i1 < 0xFFFFFFFFull) return mmpRunT<u32>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
+    return mmpRunT<u64>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
 }
 
 struct SeedState {
@@ -203,7 +205,7 @@ __device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u3
     if (k.kind == 0) { Nrep = 0; i0 = 0; maxL = 0; }
     else if (k.kind == 1) { i0 = k.i1; Nrep = k.i2 - k.i1 + 1; maxL = k.maxL; }
     else if (k.kind == 2) { i0 = k.i1; Nrep = 1; bool cr; maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, k.maxL, k.i1, dirR, cr, cn); }
-    else { maxL = k.maxL; Nrep = maxMappableLength(X, R, pieceStart, pieceLength, k.i1, k.i2, dirR, maxL, i0, i1, cn); }
+    else { maxL = k.maxL; Nrep = mmpRun(X, R, pieceStart, pieceLength, k.i1, k.i2, dirR, maxL, i0, i1, cn); }
 }
 
 // ReadAlign_maxMappableLength2strands.cpp:5-115.  The reference keeps (Nrep, ind0, maxL) of every start offset of a sparse suffix
