@@ -134,7 +134,5 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static const hipError_t hipErrorNotReady = (hipError_t)600;
-static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(#kernel, dim3(grid), dim3(block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); })

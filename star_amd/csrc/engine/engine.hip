@@ -7,7 +7,6 @@
 #include "../../../include/star_amd_index.h"
 #include "../../../include/star_amd_async.h"
 #include <cstdio>
-#include <time.h>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
@@ -614,24 +613,10 @@ static int growPools(staramd_ctx *c, u32 flags, const u32 *cur) {
     return 0;
 }
 
-// STARAMD_WAIT_NAP_US=n (set by the front end when a device has few host CPUs to itself; 0 / unset: off): the calling thread looks at the event every n microseconds and
-// sleeps in between.  hipEventSynchronize on a blocking-sync event still costs its thread a whole core on this runtime -- the thread-CPU clock of the mapper threads reads
-// 0.11 us per pair = 44 ms of the 47 ms a batch takes (profiles/r05_e2e_session2_*, cpu_us_per_pair_by_stage.mapper_threads) -- which is half of what a rank of an 8-GPU node
-// with 16 CPUs has.  A nap costs up to n us of latency per wait (two waits per batch).
-static hipError_t waitEvent(hipEvent_t ev) {
-    static const unsigned napUs = getenv("STARAMD_WAIT_NAP_US") ? (unsigned)std::max(0, atoi(getenv("STARAMD_WAIT_NAP_US"))) : 0u;
-    if (!napUs) return hipEventSynchronize(ev);
-    for (;;) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-        struct timespec ts = {0, (long)napUs * 1000L};
-        nanosleep(&ts, nullptr);
-    }
-}
 static hipError_t waitStream(staramd_ctx *c) {
     if (!c->evWait) return hipStreamSynchronize(c->stream);
     hipError_t e = hipEventRecord(c->evWait, c->stream);
-    return e != hipSuccess ? e : waitEvent(c->evWait);
+    return e != hipSuccess ? e : hipEventSynchronize(c->evWait);
 }
 
 // every kernel of a batch and the read-back of its totals, cursors and counters, enqueued; nothing is waited for
@@ -891,7 +876,7 @@ extern "C" int staramd_map_end(staramd_ctx *c, staramd_results *r, const staramd
     c->inFlight = false; c->collected = false;
     int rcNext = STARAMD_OK;
     if (next && next->nReads) { rcNext = staramd_map_begin(c, next); if (!rcNext) c->nOverlapped++; }
-    HIPCHK(waitEvent(c->evDownload));
+    HIPCHK(hipEventSynchronize(c->evDownload));
     return rcNext;
 }
 extern "C" uint64_t staramd_overlapped_batches(staramd_ctx *c) { return c ? c->nOverlapped : 0; }

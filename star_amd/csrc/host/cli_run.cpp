@@ -179,9 +179,6 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
     // their own, no second replica); each context has a mapper thread, so a GPU always has a second batch in flight while the results of one are
     // copied out and handed on (the reference: runThreadN workers over one shared genome, STAR.cpp:194-201)
     const int nOwners = (int)devices.size();
-    // a device with few host CPUs to itself (a rank of an 8-GPU node with 16 CPUs: --runThreadN 2-4): its mapper thread naps between looks at the device instead of holding a
-    // core while the batch is there (engine.hip waitEvent; measured: profiles/r05_e2e_session13_*)
-    if (!getenv("STARAMD_WAIT_NAP_US") && sah_threads(h) / std::max(1, nOwners) < 6) setenv("STARAMD_WAIT_NAP_US", "150", 1);
     // engine contexts (= mapper threads) per GPU.  A second context over the same resident index was worth +7 % in round 3, when kernels were slower and the host had 64 threads;
     // with the kernels of round 4 and the 16 CPUs the GPU boxes really give a container, one context is as fast on a quiet box (6.8 M pairs/s either way) and faster on a
     // loaded one (5.7 vs 5.1): the launches of two contexts do not overlap, they stretch each other (profiles/r04_timeline_two_contexts.txt)
