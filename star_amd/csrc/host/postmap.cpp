@@ -225,9 +225,13 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         const size_t attrVar = std::max(std::max((size_t)jmLen, (size_t)jiLen), std::max(std::max((size_t)cigLen[0], (size_t)cigLen[1]), std::max(tagMD.size(), rg ? rg->size() : (size_t)0)));
         const size_t bound = nm.size() + chrN.size() + (mateChrN ? mateChrN->size() : 0) + cigLen[0] + cigLen[1] + 2 * sq.size() + xt.size()
                              + 10 * 21 + (size_t)nAttr * (8 + 21 + attrVar) + 64;
+        // the line is built in a buffer on the stack and appended once: growing `out` by the BOUND first (std::string::resize) zero-fills ~3x the bytes the line ends up with
+        char lineBuf[4096];
+        const bool onStack = bound <= sizeof(lineBuf);
         const size_t base = out.size();
-        out.resize(base + bound);
-        char *p = &out[base];
+        if (!onStack) out.resize(base + bound);
+        char *const p0 = onStack ? lineBuf : &out[base];
+        char *p = p0;
         p = putSv(p, nm); *p++ = '\t';
         p = putUint(p, (samFLAG & P.outSAMflagAND) | P.outSAMflagOR); *p++ = '\t';
         p = putStr(p, chrN.data(), chrN.size()); *p++ = '\t';
@@ -268,7 +272,7 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
         // SAM input: its attributes go out again; indexed by the position of the mate in the alignment, not by the mate, as the reference does (:351-353)
         if (!xt.empty()) { *p++ = '\t'; p = putSv(p, xt); }
         *p++ = '\n';
-        out.resize((size_t)(p - out.data()));
+        if (onStack) out.append(lineBuf, (size_t)(p - p0)); else out.resize(base + (size_t)(p - p0));
     }
 }
 
