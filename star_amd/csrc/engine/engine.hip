@@ -913,6 +913,7 @@ extern "C" int staramd_map_resident(staramd_ctx *c, staramd_results *r) {
     if (!c || !r || !r->reads) { g_err = "bad arguments"; return STARAMD_ERR_ARG; }
     if (c->residentReads == 0) { g_err = "no batch resident in HBM: call staramd_map_batch first"; return STARAMD_ERR_ARG; }
     if (c->in[c->cur].pending) { g_err = "the resident batch was overwritten by staramd_prefetch_batch"; return STARAMD_ERR_ARG; }
+    if (c->inFlight) { g_err = "a batch begun with staramd_map_begin is in flight: staramd_map_end first"; return STARAMD_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     c->B.nReads = c->residentReads;
     return runDevice(c, r);
