@@ -139,8 +139,16 @@ static void samMapped(std::string &out, const RunParams &P, const GenomeIndex &g
     uint32_t leftMate = flagPaired ? Str : 0;
     uint64_t chrS = gi.chrStart[t.Chr];
     // the attributes of the run as codes (the list is a parameter: the same for every record)
-    SamAttr attr[32]; uint32_t nAttr = 0; bool wantJ = false;
-    for (const std::string &a : P.outSAMattrOrder) { if (nAttr < 32) { attr[nAttr] = samAttrCode(a); wantJ = wantJ || attr[nAttr] == A_jM || attr[nAttr] == A_jI; nAttr++; } }
+    // (decoded once per thread and run: eleven string compares per attribute and record were a tenth of the formatter's time)
+    static thread_local const RunParams *attrOf = nullptr; static thread_local SamAttr attr[32]; static thread_local uint32_t nAttr = 0; static thread_local bool wantJ = false;
+    static thread_local uint64_t attrKey = 0;
+    uint64_t key = P.outSAMattrOrder.size();                                  // the tags are two characters: a hash of them, not the address of P alone, says whether the list is the one decoded
+    for (const std::string &a : P.outSAMattrOrder) key = key * 1000003ull + (a.size() >= 2 ? (uint64_t)(uint8_t)a[0] * 257u + (uint8_t)a[1] : 0xFFFFu) + a.size();
+    if (attrOf != &P || attrKey != key) {
+        nAttr = 0; wantJ = false;
+        for (const std::string &a : P.outSAMattrOrder) { if (nAttr < 32) { attr[nAttr] = samAttrCode(a); wantJ = wantJ || attr[nAttr] == A_jM || attr[nAttr] == A_jI; nAttr++; } }
+        attrOf = &P; attrKey = key;
+    }
     // ReadAlign::calcCIGAR (ReadAlign_calcCIGAR.cpp:3-58): the CIGAR of both mates first, the MC tag needs the other mate's.  At most 3 operations per exon + 2 clips,
     // 21 characters each at the very most
     char cig[2][(3 * STARAMD_MAX_N_EXONS + 2) * 21]; size_t cigLen[2] = {0, 0};
