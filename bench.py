@@ -468,6 +468,12 @@ def main():
         g, ginfo = build_genome(args, mb, log)          # cached by rank 0
     idx = os.path.join(g, "idx")
     run_dir = os.path.join(g, "run_w%d_n%d" % (world, n_total))
+    if rank == 0:          # runs of other world sizes on this box (the driver's 1 / 2 / 4 / 8-GPU series) leave ~11 GB of FASTQ + SAM per rank in tmpfs: dropped before this one adds its own
+        import shutil
+        for dname in os.listdir(g):
+            if dname.startswith("run_w") and os.path.join(g, dname) != run_dir:
+                shutil.rmtree(os.path.join(g, dname), ignore_errors=True)
+    barrier()
     t = time.time()
     fq = make_reads(args, g, run_dir, "reads_r%d" % rank, n_total, 7000 + rank)
     log("rank %d: %d pairs of reads in %.1f s" % (rank, n_total, time.time() - t))
