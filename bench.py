@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the optional legs (bench_extra.json): host_budget / config 5 / config 1 / sweep / 2-pass")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the one-context leg the roofline kernel times come from (they are then the overlapped two-context figures)")
     ap.add_argument("--cpu-selftest", action="store_true", help="TEST of this script's plumbing on a box without a GPU: gloo, the oracle behind the front end, a tiny genome; the line says selftest")
+    ap.add_argument("--keep-run-dirs", action="store_true", help="do not delete the run directories (FASTQ + SAM) that earlier bench.py runs of other sizes left in the genome cache")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("STARAMD_BENCH_BUDGET_S", "1500")), help="optional legs are skipped once this much wall time is used")
     ap.add_argument("--workdir", default=os.environ.get("STARAMD_BENCH_DIR", "/dev/shm/star_amd_bench" if os.path.isdir("/dev/shm") else "/tmp/star_amd_bench"))
     return ap.parse_args()
@@ -229,6 +230,7 @@ def report_dict(rep, lread):
     n = max(int(rep.timedReads), 1); nb = max(int(rep.batches), 1)
     c = dict(zip(COUNTER_NAMES, [int(x) for x in rep.counters]))
     c["nPrunedWin"], c["nRewalkRead"], c["nLaneItems"] = int(rep.counters[37]), int(rep.counters[38]), int(rep.counters[39])     # dev.h: DC_nPrunedWin, DC_nRewalkRead, DC_nLaneItems
+    c["nSkippedLeaves"], c["nRewalkWin"] = int(rep.counters[47]), int(rep.counters[48])                                            # dev.h: DC_nSkippedLeaves, DC_nRewalkWin
     for k in ("nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"):      # kept by the profile / shadow builds only
         c.pop(k, None)
     ms = dict(zip(STAGE_NAMES, [float(x) / nb for x in rep.stageMs]))       # per launch = per batch
@@ -245,7 +247,7 @@ def report_dict(rep, lread):
               "windows:passB_assign", "windows:emission", "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
         raw = [int(x) for x in rep.counters]
         c["profile_cycles_per_pair"] = dict(zip(pn, [v / n for v in raw[21:37]]))
-        c["profile_counts_per_pair"] = dict(zip(["nNodes", "nLeaves", "nStitchCalls", "nExtendCalls"], [v / n for v in raw[8:12]]))
+        c["profile_counts_per_pair"] = dict(zip(["nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nLeavesBound", "nLeavesEarly"], [v / n for v in raw[8:12] + raw[49:51]]))
     return c, ms, kern, (bytes_seed + bytes_win + bytes_stitch) / n
 
 
@@ -468,11 +470,32 @@ def main():
         g, ginfo = build_genome(args, mb, log)          # cached by rank 0
     idx = os.path.join(g, "idx")
     run_dir = os.path.join(g, "run_w%d_n%d" % (world, n_total))
-    if rank == 0:          # runs of other world sizes on this box (the driver's 1 / 2 / 4 / 8-GPU series) leave ~11 GB of FASTQ + SAM per rank in tmpfs: dropped before this one adds its own
+    if rank == 0:
+        # runs of other world sizes on this box (the driver's 1 / 2 / 4 / 8-GPU series) leave ~11 GB of FASTQ + SAM per rank in tmpfs: dropped before this one adds its own.
+        # Only directories that a bench.py run marked as its own (.bench_run_owner = pid of its rank 0) and whose owner is no longer alive: a bench running beside this
+        # one on the same cache keeps its files, and so does anything a person put there.  --keep-run-dirs leaves everything.
         import shutil
-        for dname in os.listdir(g):
-            if dname.startswith("run_w") and os.path.join(g, dname) != run_dir:
-                shutil.rmtree(os.path.join(g, dname), ignore_errors=True)
+        for dname in ([] if args.keep_run_dirs else os.listdir(g)):
+            d = os.path.join(g, dname)
+            if not dname.startswith("run_w") or d == run_dir:
+                continue
+            try:
+                owner = int(open(os.path.join(d, ".bench_run_owner")).read().strip() or "0")
+            except (OSError, ValueError):
+                continue                                     # not marked: not ours to delete
+            alive = False
+            if owner > 0 and owner != os.getpid():
+                try:
+                    os.kill(owner, 0); alive = True
+                except ProcessLookupError:
+                    alive = False
+                except PermissionError:
+                    alive = True
+            if not alive:
+                shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(run_dir, exist_ok=True)
+        with open(os.path.join(run_dir, ".bench_run_owner"), "w") as f:
+            f.write(str(os.getpid()))
     barrier()
     t = time.time()
     fq = make_reads(args, g, run_dir, "reads_r%d" % rank, n_total, 7000 + rank)

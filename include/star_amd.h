@@ -119,7 +119,7 @@ typedef struct staramd_params {
      *      (ReadAlign_multMapSelect.cpp:26-44).  That is all the default post-map path reads; it cuts the result copy ~10x.
      *      Must be 0 when chimeric detection (chimSegmentMin > 0) wants the other windows.
      * Contract of 1: trBest, status, unmappedLength and every field of the RETURNED transcripts / exons are the reference's exactly; nW / nTr
-     * count what is returned; maxScoreMate[] is unspecified (see staramd_read_result) and the windows that cannot reach the selection threshold are not stitched at all
+     * count what is returned; maxScoreMate[] is 0 (see staramd_read_result) and the windows that cannot reach the selection threshold are not stitched at all
      * (INTEGRATION.md "Which outputs are the reference's exactly").  A caller that needs trAll[][] or maxScoreMate[] themselves passes 0. */
     uint32_t resultSelect;
 } staramd_params;
@@ -152,9 +152,9 @@ typedef struct staramd_read_result {
     uint32_t nTr;             /* total transcripts over those windows                                    */
     uint32_t trOffset;        /* first transcript of this read in staramd_results.tr                     */
     int32_t  trBest;          /* index (relative to trOffset) of trBest, -1 if none                      */
-    int32_t  maxScoreMate[2]; /* resultSelect 0: exactly ReadAlign::maxScoreMate[].  resultSelect 1: UNSPECIFIED -- some value between 0 and
-                               * ReadAlign::maxScoreMate[] that depends on which windows were walked and in which order wavefronts saw each
-                               * other's bounds; it may differ between two runs over the same batch.  Nothing outside the hot path reads it. */
+    int32_t  maxScoreMate[2]; /* resultSelect 0: exactly ReadAlign::maxScoreMate[].  resultSelect 1: always 0 (windows that cannot hold a selectable
+                               * transcript are not stitched, so the running maxima do not exist).  Nothing outside the hot path reads the field
+                               * (stitchWindowAligns.cpp:234,246 are its only uses in the reference). */
     uint32_t unmappedLength;  /* trBest->rLength of the unmapped classifications (mapOneRead.cpp:100-111); 0 for a read of length 0, where the
                                * reference reports what the previous read of the same thread left in splitR[1][0] */
 } staramd_read_result;

@@ -36,7 +36,7 @@ typedef struct staramd_cli_report {
     double   deviceBusy[STARAMD_CLI_MAX_DEV];     /* seconds inside staramd_map_batch per engine context, timed region */
     double   deviceMs[STARAMD_CLI_MAX_DEV];       /* HIP-event device time per device, timed region                   */
     double   stageMs[8];           /* engine stages summed over the timed batches (staramd_get_timings order)         */
-    uint64_t counters[40];         /* engine counters summed over the timed batches (staramd_get_counters order)      */
+    uint64_t counters[64];         /* engine counters summed over the timed batches (staramd_get_counters order)      */
     double   parseBusy, emitBusy;  /* seconds the reader / the post-map+writer stage were busy, timed region          */
     uint64_t batches;              /* timed batches                                                                   */
     double   pass1Seconds;         /* --twopassMode Basic: 1st pass + junction insertion + index re-upload            */

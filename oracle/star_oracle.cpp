@@ -926,6 +926,7 @@ struct Oracle {
             cnt[C_nTrOut] += rr.nTr;
         }
         rr.maxScoreMate[0] = maxScoreMate[0]; rr.maxScoreMate[1] = maxScoreMate[1];
+        if (P.resultSelect) rr.maxScoreMate[0] = rr.maxScoreMate[1] = 0;      // the ABI's rule (include/star_amd.h staramd_read_result): 0 under resultSelect 1
     }
 };
 

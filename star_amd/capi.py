@@ -370,7 +370,7 @@ class CliHooks(C.Structure):
 class CliReport(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("wallMapping", C.c_double), ("timedReads", C.c_uint64), ("timedWall", C.c_double),
                 ("genomeLoadSeconds", C.c_double), ("indexUploadSeconds", C.c_double), ("nDevices", C.c_int),
-                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 40),
+                ("deviceBusy", C.c_double * 16), ("deviceMs", C.c_double * 16), ("stageMs", C.c_double * 8), ("counters", C.c_uint64 * 64),
                 ("parseBusy", C.c_double), ("emitBusy", C.c_double), ("batches", C.c_uint64), ("pass1Seconds", C.c_double), ("finishSeconds", C.c_double), ("nContexts", C.c_int), ("convertBusy", C.c_double), ("emitParts", C.c_double * 4), ("fastPaths", C.c_uint64 * 4), ("cpuSeconds", C.c_double * 8)]
 
 

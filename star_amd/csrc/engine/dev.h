@@ -97,6 +97,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_nAnchorLoci, DC_nAnchorReplayed,                             // k_windows pass A: anchor loci enumerated / replayed one by one (not owned by a window when their chunk was read)
        DC_wprof5, DC_wprof6, DC_wprof7,                                // -DSTARAMD_PROFILE build: more sections of k_windows
        DC_nSkippedLeaves, DC_nRewalkWin,                               // stitch kernels: single-mate leaves (and subtrees of them) not finalised / two-mate windows walked again in full
+       DC_nLeavesBound, DC_nLeavesEarly,                               // profile / shadow builds: leaves dropped by their score bound before the extensions / by their score after them (k_stitch.hip finalizeTranscript)
        DC_N };
 
 // cursors[] slots.  Every counter has a 128-byte line of its own (CS words apart): an L2 channel serves the atomics of one line one after the other (~2 ns each, measured:

@@ -103,7 +103,7 @@ struct staramd_ctx {
     float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; float ms8 = 0;   // per-stage HIP-event times of the last batch (staramd_get_timings)
     u64 counters[DC_N];
     u32 residentReads = 0; u32 residentMaxLread = 0;
-    u32 *hostScratch = nullptr;         // pinned: totals + cursors read-back
+    u32 *hostScratch = nullptr;         // pinned: totals + cursors + counters read-back
     std::vector<u64> rebased;           // read offsets of a batch that does not start at base 0
     // a context created with staramd_create_shared maps against the resident index of its OWNER (same device): work space, stream and
     // events are its own, X / dX are copies of the owner's, refreshed whenever the owner's index changes
@@ -291,7 +291,7 @@ static int allocWork(staramd_ctx *c) {
     if ((rc = devAlloc(R, &c->dOutReads, (u64)N))) return rc;
     if ((rc = devAlloc(R, &c->dOutTr, (u64)B.trCap))) return rc;
     if ((rc = devAlloc(R, &c->dOutEx, (u64)B.exCap))) return rc;
-    if (hipHostMalloc((void **)&c->hostScratch, (64 + CUR_N) * sizeof(u32)) != hipSuccess) { g_err = "hipHostMalloc failed"; return STARAMD_ERR_DEVICE; }
+    if (hipHostMalloc((void **)&c->hostScratch, (64 + CUR_N) * sizeof(u32) + DC_N * sizeof(u64)) != hipSuccess) { g_err = "hipHostMalloc failed"; return STARAMD_ERR_DEVICE; }
     const staramd_params &P = c->X.P;
     // ---- seed kernel: one lane per read, PC table per lane sized by the reference's seedPerReadNmax
     int seedPerCU = 2;
@@ -697,8 +697,8 @@ static int enqueueAll(staramd_ctx *c) {
     u32 *hs = c->hostScratch;
     HIPCHK(hipMemcpyAsync(hs, c->dTotals, 2 * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hs + 8, B.cursors, CUR_N * sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(c->counters, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));
-    return STARAMD_OK;
+    HIPCHK(hipMemcpyAsync(hs + 8 + CUR_N, B.counters, DC_N * sizeof(u64), hipMemcpyDeviceToHost, s));      // pinned; collectAll copies them into c->counters: staramd_get_counters
+    return STARAMD_OK;                                                                                     // then always describes the last COLLECTED batch, whatever is in flight
 }
 // ... waited for: stage times, overflow flags
 static int collectAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
@@ -721,6 +721,7 @@ static int collectAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
     { float t6 = 0; HIPCHK(hipEventElapsedTime(&t6, c->ev[2], c->ev[8])); c->ms8 = t6; }      // [8] the k_stitch_lane launch alone (part of [3])
     c->ms[6] = r->msTotalDevice;
     *flagsOut = hs[8 + CUR_FLAGS];
+    memcpy(c->counters, hs + 8 + CUR_N, DC_N * sizeof(u64));
     return STARAMD_OK;
 }
 static int launchAll(staramd_ctx *c, staramd_results *r, u32 *flagsOut) {
@@ -887,8 +888,9 @@ extern "C" int staramd_prefetch_batch(staramd_ctx *c, const staramd_batch *b) {
     const u64 nBases = b->readOffset[b->nReads];
     if (b->nReads > c->maxReads || nBases > c->maxBases) return STARAMD_OK;                // (map_batch reports it)
     // the set that holds nothing pending: the one the last mapped batch used (that call has returned), unless the other one is free too
-    const int k = !c->in[1 - c->cur].pending ? 1 - c->cur : (!c->in[c->cur].pending ? c->cur : -1);
-    if (k < 0) return STARAMD_OK;                                                          // two batches waiting already
+    // (while a batch begun with staramd_map_begin is in flight its kernels read in[cur]: only the other set may be written)
+    const int k = !c->in[1 - c->cur].pending ? 1 - c->cur : (!c->in[c->cur].pending && !c->inFlight ? c->cur : -1);
+    if (k < 0) return STARAMD_OK;                                                          // two batches waiting already, or the free set is being read by kernels
     HIPCHK(hipSetDevice(c->device));
     staramd_ctx::InSet &I = c->in[k];
     const u32 n = b->nReads; hipStream_t cs = c->copyStream;

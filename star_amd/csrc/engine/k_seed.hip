@@ -368,18 +368,21 @@ extern "C" __global__ void __launch_bounds__(256) k_seed_plan(const DevIndex *__
     const u8 *R = B.bases + B.readOffset[ir];
     const u32 Lread = live ? (u32)(B.readOffset[ir + 1] - B.readOffset[ir]) : 0u;
     const u32 startLmax = startLmaxOf(P, Lread);
-    u32 Nsplit = 0, LgoodMin = 0, nGroups = 0, nUnits = 0;
+    u32 Nsplit = 0, LgoodMin = 0, nGroups = 0, nUnits = 0, maxNstart = 0;
     { u32 iR = 0, iFrag = 0, pS = 0, pL = 0;
       while (Nsplit < P.maxNsplit && nextPiece(R, Lread, iR, iFrag, pS, pL)) {
           if (pL > LgoodMin) LgoodMin = pL;
           if (pL < P.seedSplitMin) continue;
           Nsplit++;
           const u32 Nstart = nStartOf(P, startLmax, pL);
+          if (Nstart > maxNstart) maxNstart = Nstart;
           nGroups += 2u * Nstart; nUnits += 2u * Nstart - 1u;
       } }
     SeedPlan pl; pl.group0 = 0; pl.nGroups = (u16)min(nGroups, 0xFFFFu); pl.nSplit = (u16)Nsplit; pl.LgoodMin = (u16)min(LgoodMin, 0xFFFFu); pl.handOn = 0; pl.pad = 0;
     // groups and units of the wavefront's 64 reads in one piece each: two atomics per wavefront (an exclusive scan over the lanes gives every read its place)
-    const bool huge = nGroups > 0x3FFu;              // (a read of hundreds of pieces: the general kernel)
+    // a read of more groups than k_seed_merge has lanes for (one per group), or with more start points per piece than SeedUnit::istart / nstart hold (u8):
+    // the general kernel -- handed on HERE, so that no unit of it is allocated, searched and thrown away
+    const bool huge = nGroups > 64u || maxNstart > 255u;
     u32 packed = huge ? 0u : (nGroups | (nUnits << 16)), incl = packed;
     for (u32 d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl((int)incl, (int)(lane >= d ? lane - d : 0u), 64); if (lane >= d) incl += o; }
     const u32 tot = (u32)__shfl((int)incl, 63, 64);

@@ -579,12 +579,45 @@ template <class EXP, class HP> __device__ static void recordCandidate(const star
 }
 
 // leaf of the recursion: stitchWindowAligns.cpp:16-307.  Works on a scratch copy (ex) of the used exons.
-__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS staramd_exon *ex, u32 chr, WinRec &wr, const u64 glb0, const u64 glb1, LDS u64 *recSlot) {
+// the score below which a finished leaf of mate class iFragT (-1: both mates) leaves no trace -- see the note at finalizeTranscript
+__device__ __forceinline__ i32 leafNeedScore(const StitchCtx &c, const staramd_params &P, const WinRec &wr, const i32 iFragT) {
+    const i32 mateBest = iFragT < 0 ? 0x7FFFFFFF : (iFragT == 0 ? c.maxScoreMate[0] : c.maxScoreMate[1]);      // (two-mate: the clause does not apply)
+    return firstI(min(wr.bestScore, mateBest) - P.outFilterMultimapScoreRange);                                // (wave-uniform: said so)
+}
+// (a) of that note: can the leaf of the working transcript h still reach needScore?  Its score is at most the score of the stitched part + one point per base the two
+// extensions can reach (they stop at the mate spacer and at the ends of the read) + the largest value of the genomic-length term
+__device__ __forceinline__ bool leafCanCount(const StitchCtx &c, const DevIndex &X, const Hdr &h, const WinRec &wr, const u32 fragFirst, const u32 fragLast) {
+    const staramd_params &P = X.P;
+#ifdef STARAMD_NO_LEAF_BOUND           // A/B builds (tools/build_variants.sh): without test (a)
+    return true;
+#endif
+    if (P.chimSegmentMinPositive) return true;
+    const u32 Lread = c.Lread;
+    const u32 spacer = c.readLength[0] < Lread ? (c.str == 0 ? c.readLength[0] : Lread - 1u - c.readLength[0]) : Lread;       // position of the mate spacer in R[] (none: Lread)
+    const u32 availL = h.rStart > spacer ? h.rStart - spacer - 1u : h.rStart, availR = h.tR2 < spacer ? spacer - 1u - h.tR2 : Lread - 1u - h.tR2;
+    i32 U = h.Score + (i32)availL + (i32)availR;
+    if (X.glStep != 0) U = max(0, U + (X.glStep < 0 ? X.glScoreAt1 : X.glScoreAt1 + (i32)X.nBreak));
+    return U >= leafNeedScore(c, P, wr, fragFirst == fragLast ? (i32)fragFirst : -1);
+}
+
+// fragFirst / fragLast: mates of the first and the last exon (the walk keeps them).
+//
+// Leaves that cannot leave a trace are dropped early (ours; exact in every mode).  A finished leaf acts on the state of the read in two places only: a single-mate
+// transcript raises maxScoreMate[its mate] to its score (:232-235), and a transcript is recorded when Score + range >= the window's best or >= maxScoreMate[its mate]
+// (:245-247) -- all the filters in between can only drop it.  So a leaf with  Score + range < window best  and (two-mate, or  Score + range < maxScoreMate[mate] --
+// which also says Score < maxScoreMate[mate]) changes nothing whatever the filters say.  (a) BEFORE the extensions Score is bounded by the score of the stitched part
+// + one point per base the two extensions can reach (they stop at the mate spacer and at the ends of the read) + the largest value of the genomic-length term;
+// (b) AFTER them it is known exactly.  (a) is leafCanCount above, asked by the walk before it calls this function (inside it, as an early return, the test tipped
+// the register allocation into its vector-register regime: tools/isa_stats.sh); (b) is below, behind the extensions.
+__device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, const LDS staramd_exon *EX, LDS staramd_exon *ex, u32 chr, WinRec &wr, const u64 glb0, const u64 glb1, LDS u64 *recSlot, const u32 fragFirst, const u32 fragLast) {
     const DevIndex &X = *c.X; const staramd_params &P = X.P;
-    DIAG(c.nLeaves++);
     u32 Lread = c.Lread; u32 Str = c.str;
     int Score = h.Score; u32 tR2 = h.tR2; u64 tG2 = h.tG2;
     u32 ne = h.nExons;
+    const i32 iFragT = fragFirst == fragLast ? (i32)fragFirst : -1;
+    const i32 needScore = leafNeedScore(c, P, wr, iFragT);
+    if (lane < ne) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&ex[lane], t); }           // the leaf works on a copy of the exon rows (the walk goes on with the originals)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     ExtRes e;
     PROF_T0();
     int vOrder0 = (Str == 0) ? 0 : 1;                  // EXTEND_ORDER==1, roStr==Str
@@ -592,7 +625,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
         int which = iOrd == 0 ? vOrder0 : 1 - vOrder0;
         if (which == 0) {
             if (h.rStart > 0) {
-                u32 imate = ex[0].iFrag;
+                const u32 imate = fragFirst;
                 if (COOP_EXTEND(c, lane, h.rStart - 1, h.gStart - 1, -1, -1, h.rStart, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
                                 P.alignEndsTypeExt[imate][(int)(Str != imate)] != 0, e)) {
                     h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
@@ -603,7 +636,7 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             }
         } else {
             if (tR2 < Lread) {
-                u32 imate = ex[ne - 1].iFrag;
+                const u32 imate = fragLast;
                 if (COOP_EXTEND(c, lane, tR2 + 1, tG2 + 1, +1, +1, Lread - tR2 - 1, tR2 - h.rStart + 1, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax,
                                 P.alignEndsTypeExt[imate][(int)(imate == Str)] != 0, e)) {
                     h.nMatch += e.nMatch; h.nMM += e.nMM; Score += e.maxScore;
@@ -615,6 +648,15 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
         }
     }
     PROF_MARK(c, 13);
+    u64 gLength = tG2 + 1 - h.gStart;
+    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points: lane k holds break points k, k+64.  (last exon end - first exon start = gLength)
+        const u32 nAbove = (u32)__popcll(__ballot(gLength >= glb0)) + (u32)__popcll(__ballot(gLength >= glb1));   // break points <= gLength (this lane holds points lane, lane+64)
+        Score += X.glScoreAt1 + X.glStep * (i32)nAbove;
+        Score = max(0, Score);
+    }
+#ifndef STARAMD_NO_LEAF_EARLY          // A/B builds: without test (b)
+    if (Score < needScore && !P.chimSegmentMinPositive) { DIAG(c.nLeavesEarly++); return; }      // (b) of the note above: the final score is known, the filters cannot make it count
+#endif
     // ---- leaf filters (:83-219), lane = exon row: every lane holds one exon of the transcript in registers, neighbours
     // come over the DPP wave shift, sums are DPP reductions, "any exon fails" is a ballot
     staramd_exon xe;
@@ -627,11 +669,10 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
     const u32 last = ne - 1;
     const u64 ex0G = ((u64)laneGet32((u32)(xe.G >> 32), 0) << 32) | laneGet32((u32)xe.G, 0), exLG = ((u64)laneGet32((u32)(xe.G >> 32), last) << 32) | laneGet32((u32)xe.G, last);
     const u32 ex0R = laneGet32(xe.R, 0), exLR = laneGet32(xe.R, last), exLL = laneGet32(exL, last);
-    const u32 ex0Frag = laneGet32(xe.iFrag, 0), exLFrag = laneGet32(xe.iFrag, last);
+    const u32 ex0Frag = fragFirst, exLFrag = fragLast;
     if (!P.alignSoftClipAtReferenceEnds &&
         ((exLG + Lread - exLR) > (GLOBAL(u64, X.chrStart)[chr] + GLOBAL(u64, X.chrLength)[chr]) || ex0G < (GLOBAL(u64, X.chrStart)[chr] + ex0R))) return;
     const u32 rLength = waveSumU32(exL);
-    u64 gLength = tG2 + 1 - h.gStart;
     {   // junction overhangs (:97-108)
         bool fail = false;
         if (lane < last && canon >= 0) {
@@ -694,17 +735,8 @@ __device__ static void finalizeTranscript(StitchCtx &c, u32 lane, Hdr h, LDS sta
             }
         }
     }
-    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points: lane k holds break points k, k+64
-        u64 gl = exLG + exLL - ex0G;
-        const u32 nAbove = (u32)__popcll(__ballot(gl >= glb0)) + (u32)__popcll(__ballot(gl >= glb1));   // break points <= gl (this lane holds points lane, lane+64)
-        i32 term = X.glScoreAt1 + X.glStep * (i32)nAbove;
-        Score += term;
-        Score = max(0, Score);
-    }
-    i32 iFragT;
     // (constant indices only: a dynamic index would pin the whole context in scratch memory)
-    if (ex0Frag == exLFrag) { iFragT = (i32)ex0Frag; if (iFragT == 0) c.maxScoreMate[0] = max(c.maxScoreMate[0], Score); else c.maxScoreMate[1] = max(c.maxScoreMate[1], Score); }
-    else iFragT = -1;
+    if (iFragT == 0) c.maxScoreMate[0] = max(c.maxScoreMate[0], Score); else if (iFragT == 1) c.maxScoreMate[1] = max(c.maxScoreMate[1], Score);
     PROF_MARK(c, 14);
     i32 winBest = wr.bestScore;            // wTr[0]->maxScore (trA with score 0 before any record)
     {
@@ -816,9 +848,9 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
         if (iA >= nA || onlySingle) {                // leaf (stitchWindowAligns.cpp:14-16: nothing to do when tR2==0)
             if (h.tR2 != 0 && skipSingle && fragFirst == fragLast) nSkipped++;
             else if (h.tR2 != 0) {
-                if (lane < h.nExons) { staramd_exon t = ldsGet(&EX[lane]); ldsPut(&LEAF[lane], t); }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                { PROF_T0(); finalizeTranscript(c, lane, h, LEAF, win.chr, wr, glb0, glb1, m.rec); PROF_ADD(c, 3); }
+                DIAG(c.nLeaves++);
+                if (!leafCanCount(c, *c.X, h, wr, fragFirst, fragLast)) { DIAG(c.nLeavesBound++); }
+                else { PROF_T0(); finalizeTranscript(c, lane, h, EX, LEAF, win.chr, wr, glb0, glb1, m.rec, fragFirst, fragLast); PROF_ADD(c, 3); }
                 if (wr.overflow) return false;
             }
             if (sp == 0) break;
@@ -931,7 +963,7 @@ __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRan
 
 __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBatch &B, const staramd_params &P, u32 ir) {
     c.Lread = first32((u32)(B.readOffset[ir + 1] - B.readOffset[ir]));
-    c.readLength[0] = first32(B.mate1Length[ir]); c.readLength[1] = P.readNmates == 2 ? c.Lread - c.readLength[0] - 1 : 0;
+    c.readLength[0] = first32(B.mate1Length[ir]); c.readLength[1] = (P.readNmates == 2 && c.readLength[0] < c.Lread) ? c.Lread - c.readLength[0] - 1 : 0;      // (a read of merged mates in a paired-end run: one piece, no second mate)
     c.mmMaxTotal = first32(B.mmMaxTotal[ir]);
     const u32 *src = B.packed + (u64)ir * B.packWords;       // stage the 4-bit packed read in this wavefront's LDS slice
     u32 nw = (c.Lread + 7) / 8;
@@ -962,7 +994,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     u32 stateBytes = stitchStateBytes(capDepth, capRank, arenaBytes);
     u32 readBytes = (ldsWords * 4u + 15u) & ~15u;
     LaneMem m;
-    StitchCtx c; c.X = &X; c.nGstitch = 0; c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = 0;
+    StitchCtx c; c.X = &X; c.nGstitch = 0; c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = c.nLeavesBound = c.nLeavesEarly = 0;
 #ifdef STARAMD_SHADOW
     c.shadow = B.counters + DC_shadowBad;
 #endif
@@ -989,14 +1021,11 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     else { list = B.redoList; nItems = B.cursors[CUR_ST_REDO]; ticketSlot = CUR_ST_TICKET1; }
     u32 nOvf = 0, lastRead = 0xFFFFFFFFu, nPruned = 0, nRewalk = 0, nRewalkWin = 0, nSkippedLeaves = 0;
     const bool sweepEnable = (pruneEnable & 2u) != 0, skipEnable = (pruneEnable & 4u) != 0;
-    // ---- window pruning (ours; exact for what is returned under resultSelect == 1).  multMapSelect only ever picks transcripts with
-    // maxScore >= trBest->maxScore - outFilterMultimapScoreRange (ReadAlign_multMapSelect.cpp:26-44).  The score of a transcript is bounded by
-    // the lengths of the mates whose seeds its window holds plus perJ per junction (perJ = the positive part of the junction scores), so once
-    // some window of the read has recorded a score `best`, a window with  bound + range + perJ * (MAX_N_EXONS - 1) < best  cannot contribute
-    // a selected transcript and is not walked.  What the skipped windows would have done to maxScoreMate[] (stitchWindowAligns.cpp:232-247)
-    // only moves record decisions of single-mate transcripts, all of which are below the selection threshold by the extra perJ term and cannot
-    // cover (and so remove, :267-285) a two-mate transcript.  Off when every transcript is wanted (resultSelect == 0: chimeric detection,
-    // merged mates), with a positive genomic-length term or positive indel scores, and for reads that could reach alignTranscriptsPerReadNmax.
+    // ---- window pruning (ours; exact for what is returned under resultSelect == 1): stitch_common.h pruneWindow / pruneSingleBar have the rule and the argument.
+    // Once some window of the read has RECORDED a score `best`, a window whose score bound + range < best is not walked -- for a paired-end read provided that no
+    // single-mate transcript of the read can be selected either (singleBar < best); windows of single-end reads do not depend on each other at all.  Off when every
+    // transcript is wanted (resultSelect == 0: chimeric detection, merged mates), with a positive genomic-length term or positive indel scores, and for reads that
+    // could reach alignTranscriptsPerReadNmax.
     const i32 perJ = max(0, P.sjdbScore) + max(0, max(max(P.scoreGap, P.scoreGapNoncan), max(P.scoreGapGCAG, P.scoreGapATAC)));
     const bool pruneOn = pass0 && P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && (pruneEnable & 3u) != 0
                          && P.scoreDelOpen <= 0 && P.scoreDelBase <= 0 && P.scoreInsOpen <= 0 && P.scoreInsBase <= 0;
@@ -1015,8 +1044,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         const bool wholeRead = (item & 0x80000000u) != 0;
         u32 w0 = item, nWin = 1;
         i32 carry[2] = {0, 0};
-        u32 maxSeeds; i32 bestSoFar = 0; u32 nWinRead = 0;
-        if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; maxSeeds = rd.wtOffset; nWinRead = rd.nWin; }
+        u32 maxSeeds; i32 bestSoFar = 0; u32 nWinRead = 0, maxSeedsRead = 0;
+        if (wholeRead) { const DRead rd = uni(B.reads[item & 0x7FFFFFFFu]); w0 = rd.winOffset; nWin = rd.nWin; maxSeeds = rd.wtOffset; nWinRead = rd.nWin; maxSeedsRead = rd.wtOffset; }
         else maxSeeds = first32(B.winPool[item].nWA);
         if ((mode == 0 || mode == 3) && maxSeeds + 1u > capDepth && maxSeeds <= WA_MAX) {       // more seeds than this (lean) launch has LDS rows for: the full-size launch takes the item
             if (lane == 0) { u32 k = atomicAdd(&B.cursors[mode == 0 ? CUR_ST_HEAVY : CUR_ST_HEAVY2], 1u); (mode == 0 ? B.heavyList : B.heavyList2)[k] = item; }
@@ -1027,16 +1056,13 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         // those are all skipped unwalked (sweep 1) -- the reasoning of the pruning note above holds for any order of the walked windows, because
         // all that order changes are maxScoreMate-dependent decisions about single-mate transcripts, none of which can be selected then.  If it
         // does not, nothing is kept: the read is walked again from scratch, every window in the reference's order (sweep 2).
-        u32 sweep = 2; i32 barAll = 0;
+        u32 sweep = 2;
         if (wholeRead && pruneOn && sweepEnable && nWin > 1 && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax) {
             bool anyPair = false, anySingle = false;
             for (u32 base = 0; base < nWin; base += NLANE) {
-                const u32 k = base + lane; u32 mt = 0, na = 0;
-                if (k < nWin) { const DWin wk = B.winPool[w0 + k]; mt = wk.mates; na = wk.nWA; }
+                const u32 k = base + lane; u32 mt = 0;
+                if (k < nWin) mt = B.winPool[w0 + k].mates;
                 anyPair |= __ballot(k < nWin && mt == 3u) != 0; anySingle |= __ballot(k < nWin && mt != 3u) != 0;
-                // bound of a single-mate window needs the mate lengths: taken from the read below (same for all its windows)
-                const i32 extra = (k < nWin && mt != 3u) ? perJ * ((i32)na - 1) + (i32)(mt & 1u) * 0 : -0x40000000;
-                barAll = max(barAll, (i32)waveMaxU32((u32)(extra + 0x40000000)) - 0x40000000);
             }
             if (anyPair && anySingle) sweep = 0;
         }
@@ -1057,11 +1083,12 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             DWin win; { u32 *d = (u32 *)&win; const u32 *sw = (const u32 *)&myWin; d[0] = laneGet32(sw[0], il); d[1] = laneGet32(sw[1], il); d[2] = laneGet32(sw[2], il); d[3] = laneGet32(sw[3], il); }
             if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
             if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
+            if (!wholeRead && pruneOn) { nWinRead = first32(B.reads[win.read].nWin); maxSeedsRead = first32(B.reads[win.read].wtOffset); }
+            const i32 singleBar = pruneSingleBar(P, perJ, c.readLength[0], c.readLength[1], maxSeedsRead);
             if (pruneOn && win.mates != 0 && sweep == 2) {
-                if (!wholeRead) { nWinRead = first32(B.reads[win.read].nWin); bestSoFar = firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-                const i32 bound = (i32)((win.mates & 1u) ? c.readLength[0] : 0u) + (i32)((win.mates & 2u) ? c.readLength[1] : 0u) + perJ * ((i32)win.nWA - 1);
+                if (!wholeRead) bestSoFar = firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if ((u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax
-                    && bound + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1) < bestSoFar) { emptyM |= 1ull << il; continue; }
+                    && pruneWindow(P, perJ, win.mates, win.nWA, c.readLength[0], c.readLength[1], singleBar, bestSoFar)) { emptyM |= 1ull << il; continue; }
             }
             {   // stage the window's seed list in LDS (6 dwords per row)
                 const u32 *src = (const u32 *)(B.waPool + win.waOffset); LDS u32 *dst = (LDS u32 *)m.WA;
@@ -1076,9 +1103,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             // Single-mate leaves of a two-mate window: first walked WITHOUT them.  Two-mate records do not depend on single-mate ones (a
             // single-mate transcript neither covers nor is covered-with-a-higher-score by... it cannot remove or block a two-mate one: stitchWindowAligns.cpp:267-285
             // act on containment), so the window's two-mate records and its best score H come out as in the full walk.  If every single-mate transcript
-            // of the read is then below the selection bar (mate length + perJ * (MAX_N_EXONS - 1) + range < H), none of them can be returned or change what
+            // of the read is then below the selection bar (singleBar < H, stitch_common.h), none of them can be returned or change what
             // is, and the walk stands; else the window is walked again in full.  Same conditions as the window pruning (resultSelect == 1 ...).
-            if (pruneOn && !wholeRead && win.mates == 3u) nWinRead = first32(B.reads[win.read].nWin);
             bool skipSingle = pruneOn && skipEnable && win.mates == 3u && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax;
             bool ok = false;
             for (;;) {
@@ -1093,7 +1119,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
                     if (!ok) nOvf++;
                 }
                 if (ok && skipSingle && nSkipped) {
-                    const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + perJ * (STARAMD_MAX_N_EXONS - 1) + P.outFilterMultimapScoreRange;
+                    const i32 bar = singleBar;
                     // (a full list may have pushed records out that the junk of the full walk would have pushed out differently: walked again as well)
                     // (the bar is measured against the best score RECORDED so far in the read -- this window's final head or an earlier window's: trBest can only be higher)
                     i32 readBest = wr.bestScore;
@@ -1133,9 +1159,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         }
         }
         if (sweep == 0) {
-            // the bar every single-mate window must stay under: longest mate + junction bonuses of the window with most seeds + the margins
-            const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + barAll + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1);
-            if (bar < bestSoFar) { sweep = 1; continue; }
+            // the bar every single-mate transcript of the read must stay under (stitch_common.h pruneSingleBar; it bounds the single-mate windows as well)
+            if (pruneSingleBar(P, perJ, c.readLength[0], c.readLength[1], maxSeedsRead) < bestSoFar) { sweep = 1; continue; }
             sweep = 2; nRewalk++;
             continue;
         }
@@ -1149,6 +1174,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         atomicAdd((unsigned long long *)&B.counters[DC_nExtendCalls], (unsigned long long)c.nExtendCalls);
         atomicAdd((unsigned long long *)&B.counters[DC_nNodes], (unsigned long long)c.nNodes);
         atomicAdd((unsigned long long *)&B.counters[DC_nLeaves], (unsigned long long)c.nLeaves);
+        DIAG(atomicAdd((unsigned long long *)&B.counters[DC_nLeavesBound], (unsigned long long)c.nLeavesBound); atomicAdd((unsigned long long *)&B.counters[DC_nLeavesEarly], (unsigned long long)c.nLeavesEarly));
         if (nOvf) atomicAdd((unsigned long long *)&B.counters[DC_nOvfStitch], (unsigned long long)nOvf);
         if (nPruned) atomicAdd((unsigned long long *)&B.counters[DC_nPrunedWin], (unsigned long long)nPruned);
         if (nRewalk) atomicAdd((unsigned long long *)&B.counters[DC_nRewalkRead], (unsigned long long)nRewalk);
@@ -1294,6 +1320,9 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_finish(const DevIndex
         nWt = kept; bestW = bestOrd;
     }
     rd.nWt = nWt; rd.nTr = nTr; rd.nEx = nEx; rd.bestW = bestW;
+    // resultSelect 1: windows that cannot hold a selectable transcript are not walked, so the running maxima cover only some windows (and which ones depends on the order
+    // wavefronts saw each other's bounds): the field is returned as 0, always (include/star_amd.h); resultSelect 0 returns ReadAlign::maxScoreMate[] exactly
+    if (P.resultSelect) M0 = M1 = 0;
     rd.maxScoreMate[0] = M0; rd.maxScoreMate[1] = M1;
     B.reads[ir] = rd;
     if (nTr) atomicAdd((unsigned long long *)&B.counters[DC_nTrOut], (unsigned long long)nTr);

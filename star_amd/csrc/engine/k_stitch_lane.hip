@@ -1,4 +1,4 @@
-// k_stitch_lane.hip -- kernel 3a: stitch, ONE LANE PER READ, for the reads whose windows hold few seeds (almost all of them).
+// k_stitch_lane.hip -- kernel 3a: stitch, ONE LANE PER READ, for the reads of the lowest cost classes (class <= 3: ~5 % of the reads of a 2x101 batch; the cooperative kernel takes the rest).
 //
 // Replaces, per read, the second half of ReadAlign::stitchPieces (source/ReadAlign_stitchPieces.cpp:260-348) and below it
 //   stitchWindowAligns      source/stitchWindowAligns.cpp:8-353     include/exclude recursion + leaf filters + ranked insert
@@ -93,6 +93,17 @@ __device__ static void finalizeLane(StitchCtx &c, Hdr h, staramd_exon *ex, u32 c
     const u32 Lread = c.Lread, Str = c.str;
     int Score = h.Score; u32 tR2 = h.tR2; u64 tG2 = h.tG2;
     const u32 ne = h.nExons;
+    // leaves that cannot leave a trace end here / behind the extensions (k_stitch.hip finalizeTranscript has the argument)
+    const i32 iFragT = ex[0].iFrag == ex[ne - 1].iFrag ? (i32)ex[0].iFrag : -1;
+    const i32 mateBest = iFragT < 0 ? 0x7FFFFFFF : (iFragT == 0 ? c.maxScoreMate[0] : c.maxScoreMate[1]);
+    const i32 needScore = min(wr.bestScore, mateBest) - P.outFilterMultimapScoreRange;
+    if (!P.chimSegmentMinPositive) {
+        const u32 spacer = c.readLength[0] < Lread ? (Str == 0 ? c.readLength[0] : Lread - 1u - c.readLength[0]) : Lread;      // position of the mate spacer in R[] (none: Lread)
+        const u32 availL = h.rStart > spacer ? h.rStart - spacer - 1u : h.rStart, availR = tR2 < spacer ? spacer - 1u - tR2 : Lread - 1u - tR2;
+        i32 U = Score + (i32)availL + (i32)availR;
+        if (X.glStep != 0) U = max(0, U + (X.glStep < 0 ? X.glScoreAt1 : X.glScoreAt1 + (i32)X.nBreak));
+        if (U < needScore) return;
+    }
     ExtRes e;
     const int vOrder0 = (Str == 0) ? 0 : 1;            // EXTEND_ORDER==1, roStr==Str
     for (int iOrd = 0; iOrd < 2; iOrd++) {
@@ -119,12 +130,19 @@ __device__ static void finalizeLane(StitchCtx &c, Hdr h, staramd_exon *ex, u32 c
             }
         }
     }
+    const u64 gLength = tG2 + 1 - h.gStart;
+    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points (ascending): how many are <= last exon end - first exon start = gLength
+        u32 lo = 0, hi = X.nBreak;
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (gLength >= X.glBreak[mid]) lo = mid + 1; else hi = mid; }
+        Score += X.glScoreAt1 + X.glStep * (i32)lo;
+        Score = max(0, Score);
+    }
+    if (Score < needScore && !P.chimSegmentMinPositive) return;
     // ---- leaf filters (:83-219)
     if (!P.alignSoftClipAtReferenceEnds &&
         ((ex[ne - 1].G + Lread - ex[ne - 1].R) > (GLOBAL(u64, X.chrStart)[chr] + GLOBAL(u64, X.chrLength)[chr]) || ex[0].G < (GLOBAL(u64, X.chrStart)[chr] + ex[0].R))) return;
     u32 rLength = 0;
     for (u32 k = 0; k < ne; k++) rLength += ex[k].L;
-    const u64 gLength = tG2 + 1 - h.gStart;
     for (u32 k = 0; k + 1 < ne; k++) {                 // junction overhangs (:97-108)
         if (ex[k].canonSJ >= 0) {
             if (ex[k].sjAnnot == 1) {
@@ -180,16 +198,7 @@ __device__ static void finalizeLane(StitchCtx &c, Hdr h, staramd_exon *ex, u32 c
             }
         }
     }
-    if (X.glStep != 0) {             // scoreGenomicLengthLog2scale != 0 (:221-225) as integer break points (ascending): how many are <= gl
-        const u64 gl = ex[ne - 1].G + ex[ne - 1].L - ex[0].G;
-        u32 lo = 0, hi = X.nBreak;
-        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (gl >= X.glBreak[mid]) lo = mid + 1; else hi = mid; }
-        Score += X.glScoreAt1 + X.glStep * (i32)lo;
-        Score = max(0, Score);
-    }
-    i32 iFragT;
-    if (ex[0].iFrag == ex[ne - 1].iFrag) { iFragT = (i32)ex[0].iFrag; if (iFragT == 0) c.maxScoreMate[0] = max(c.maxScoreMate[0], Score); else c.maxScoreMate[1] = max(c.maxScoreMate[1], Score); }
-    else iFragT = -1;
+    if (iFragT == 0) c.maxScoreMate[0] = max(c.maxScoreMate[0], Score); else if (iFragT == 1) c.maxScoreMate[1] = max(c.maxScoreMate[1], Score);
     {
         const bool c1 = Score + P.outFilterMultimapScoreRange >= wr.bestScore || P.chimSegmentMinPositive;
         const bool c2 = iFragT >= 0 && Score + P.outFilterMultimapScoreRange >= (iFragT == 0 ? c.maxScoreMate[0] : c.maxScoreMate[1]);
@@ -339,7 +348,7 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
     if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch
     const DevIndex &X = *Xp;
     const staramd_params &P = X.P;
-    StitchCtx c; c.X = &X; c.nGstitch = 0; c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = 0;
+    StitchCtx c; c.X = &X; c.nGstitch = 0; c.nStitchCalls = c.nExtendCalls = c.nNodes = c.nLeaves = c.nLeavesBound = c.nLeavesEarly = 0;
     c.ldsByte = threadIdx.x * (ldsWords * 4u);
     c.sens[0] = c.sens[1] = 0x7FFFFFFF; c.logOn = false; c.logOvf = false; c.candBase = nullptr; c.candTop = c.candCap = c.nCand = 0;
     gcInit(c.ca); gcInit(c.cb);
@@ -366,7 +375,7 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
             const u32 w0 = rd.winOffset, nWin = rd.nWin;
             // ---- the read: lengths, mismatch budget, 4-bit packed copy into this lane's LDS slot
             c.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
-            c.readLength[0] = B.mate1Length[ir]; c.readLength[1] = P.readNmates == 2 ? c.Lread - c.readLength[0] - 1 : 0;
+            c.readLength[0] = B.mate1Length[ir]; c.readLength[1] = (P.readNmates == 2 && c.readLength[0] < c.Lread) ? c.Lread - c.readLength[0] - 1 : 0;      // (a read of merged mates in a paired-end run: one piece, no second mate)
             c.mmMaxTotal = B.mmMaxTotal[ir];
             {
                 const u32 *src = B.packed + (u64)ir * B.packWords;
@@ -375,13 +384,11 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
                 for (u32 k = 0; k < nw; k++) dst[k] = GLOBAL(u32, src)[k];
             }
             // sweeps: see k_stitch_win (two-mate windows first; if their best clears the bar of every other window those are skipped unwalked)
-            u32 sweep = 2; i32 barAll = 0;
+            u32 sweep = 2;
+            const i32 singleBar = pruneSingleBar(P, perJ, c.readLength[0], c.readLength[1], rd.wtOffset);
             if (pruneOn && sweepEnable && nWin > 1 && (u64)(nWin + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax) {
                 bool anyPair = false, anySingle = false;
-                for (u32 k = 0; k < nWin; k++) {
-                    const DWin wk = B.winPool[w0 + k];
-                    if (wk.mates == 3u) anyPair = true; else { anySingle = true; barAll = max(barAll, perJ * ((i32)wk.nWA - 1)); }
-                }
+                for (u32 k = 0; k < nWin; k++) { if (B.winPool[w0 + k].mates == 3u) anyPair = true; else anySingle = true; }
                 if (anyPair && anySingle) sweep = 0;
             }
             i32 carry[2] = {0, 0}; i32 bestSoFar = 0;
@@ -398,9 +405,8 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
                         continue;
                     }
                     if (pruneOn && win.mates != 0 && sweep == 2) {
-                        const i32 bound = (i32)((win.mates & 1u) ? c.readLength[0] : 0u) + (i32)((win.mates & 2u) ? c.readLength[1] : 0u) + perJ * ((i32)win.nWA - 1);
                         if ((u64)(nWin + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax
-                            && bound + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1) < bestSoFar) {
+                            && pruneWindow(P, perJ, win.mates, win.nWA, c.readLength[0], c.readLength[1], singleBar, bestSoFar)) {
                             DWinOut z; emptyWout(z); B.wout[w] = z;
                             nPruned++;
                             continue;
@@ -417,7 +423,7 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
                             c.maxScoreMate[0] = carry[0]; c.maxScoreMate[1] = carry[1];
                             okW = stitchWindowLane(c, win, B.waPool + win.waOffset, wr, skipSingle, nSkipped);
                             if (okW && skipSingle && nSkipped) {
-                                const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + perJ * (STARAMD_MAX_N_EXONS - 1) + P.outFilterMultimapScoreRange;
+                                const i32 bar = singleBar;
                                 if (!(bar < max(wr.bestScore, bestSoFar)) || wr.nWinTr >= P.alignTranscriptsPerWindowNmax) { skipSingle = false; nRewalkWin++; continue; }
                                 nSkippedLeaves += nSkipped;
                             }
@@ -435,8 +441,7 @@ extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(cons
                 }
                 if (defer) break;
                 if (sweep == 0) {
-                    const i32 bar = (i32)max(c.readLength[0], c.readLength[1]) + barAll + P.outFilterMultimapScoreRange + perJ * (STARAMD_MAX_N_EXONS - 1);
-                    if (bar < bestSoFar) { sweep = 1; continue; }
+                    if (singleBar < bestSoFar) { sweep = 1; continue; }
                     sweep = 2; nRewalk++;
                     continue;
                 }

@@ -28,7 +28,7 @@ struct StitchCtx {
     i32 maxScoreMate[2];
     i32 sens[2];                           // see DWinOut::sens
     GCache ca, cb;                         // donor-side and acceptor-side genome streams
-    u64 nGstitch; u32 nStitchCalls, nExtendCalls, nNodes, nLeaves;
+    u64 nGstitch; u32 nStitchCalls, nExtendCalls, nNodes, nLeaves, nLeavesBound, nLeavesEarly;      // (all but the first: DIAG builds only)
     u64 *shadow;                           // shadow-validation build: disagreement counters
 #ifdef STARAMD_PROFILE
     u64 prof[16];
@@ -52,6 +52,33 @@ __device__ __forceinline__ u8 RD(const StitchCtx &c, u32 i) {        // R[i], Re
 __device__ __forceinline__ u8 GA(StitchCtx &c, u64 pos) { c.nGstitch++; return gcGet(c.X->G, c.ca, (i64)pos); }
 __device__ __forceinline__ u8 GB(StitchCtx &c, u64 pos) { c.nGstitch++; return gcGet(c.X->G, c.cb, (i64)pos); }
 
+
+// ---- windows and leaves that are not walked (both stitch kernels) -----------------------------------------------------------------------
+// Score bound: every read base scores at most +1 (seed, gap fill, extension), every junction at most perJ (the positive part of the junction scores), and a
+// transcript of a window with n seeds has at most n - 1 junctions: a transcript over the mates `mates` of a window scores <= their lengths + perJ * (n - 1).
+// multMapSelect only picks transcripts with maxScore >= trBest->maxScore - range (ReadAlign_multMapSelect.cpp:26-44), and trBest >= every recorded score `best`.
+//
+// What a window W that is not walked changes elsewhere: only maxScoreMate[f], f in mates(W) (stitchWindowAligns.cpp:232-247), which the walk of a LATER window W'
+// reads in one place -- the clause that records a single-mate-f transcript T' although it is out of range of the best of W'.  In a window that holds one mate only,
+// and in every window of a single-end read, that clause can never decide (there maxScoreMate[f] >= every leaf score of the window so far >= the window's best, so
+// "in range of maxScoreMate" implies "in range of the window's best"): single-end reads have no cross-window dependence at all.  In a two-mate window W' a lower
+// maxScoreMate[f] records MORE such T' (all of them out of range of W's bound, hence unselectable), and the only thing a recorded T' does to other records is to
+// remove single-mate-f transcripts R whose blocks it covers (:267-285; a two-mate transcript is never covered by a single-mate one, and a T' that pushes a record off a
+// full list ranks above it).  So the result is exact for what is selected as soon as, besides W's own bound, NO single-mate transcript of the read can be selected:
+//     singleBar = longest mate + perJ * (most seeds of any window of the read - 1) + range  <  best.
+// The same bar covers the single-mate leaves of a two-mate window that are not finalised (5.6) and the single-mate windows skipped after the two-mate ones (sweep 1).
+__device__ __forceinline__ i32 pruneSingleBar(const staramd_params &P, i32 perJ, u32 len0, u32 len1, u32 maxSeedsRead) {
+#ifdef STARAMD_PRUNE_SLACK_R5          // A/B builds: the slack of rounds 2-5 (as many junctions as a transcript has exon slots)
+    maxSeedsRead = STARAMD_MAX_N_EXONS;
+#endif
+    const u32 nj = maxSeedsRead > 0 ? min(maxSeedsRead - 1u, (u32)STARAMD_MAX_N_EXONS - 1u) : 0u;
+    return (i32)max(len0, len1) + perJ * (i32)nj + P.outFilterMultimapScoreRange;
+}
+// a window (mates, nWA seeds) of a read with mate lengths len0 / len1 need not be walked once a score `best` is recorded in the read
+__device__ __forceinline__ bool pruneWindow(const staramd_params &P, i32 perJ, u32 mates, u32 nWA, u32 len0, u32 len1, i32 singleBar, i32 best) {
+    const i32 bound = (i32)((mates & 1u) ? len0 : 0u) + (i32)((mates & 2u) ? len1 : 0u) + perJ * ((i32)nWA - 1);
+    return bound + P.outFilterMultimapScoreRange < best && (P.readNmates != 2 || singleBar < best);
+}
 
 #ifdef STARAMD_PROFILE
 #define PROF_T0() u64 prof_t0_ = __builtin_readcyclecounter()

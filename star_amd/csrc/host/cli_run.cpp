@@ -339,12 +339,16 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                 }
                 StageCpu sc(2);
                 auto tm = Clock::now();
-                { Msg pk; if (parsed.peek(pk) && pk.n > 0) (void)staramd_prefetch_batch(ctx[d], &pk.b); }      // the upload of the batch behind it, beside the kernels of this one
+                // the upload of the batch behind it, beside the kernels of this one.  Only with ONE mapper: with several, another mapper may pop the batch that was peeked
+                // here, and this context would keep a stale upload (the blocking loop below has the same guard)
+                uint64_t peekedSeq = ~0ull; bool peeked = false;
+                { Msg pk; if (nDev == 1 && parsed.peek(pk) && pk.n > 0) { (void)staramd_prefetch_batch(ctx[d], &pk.b); peeked = true; peekedSeq = pk.seq; } }
                 int rc = staramd_map_wait(ctx[d]);
                 Msg nx; bool haveNx = false, begunNx = false;
                 ResBuf &r = rb[cur.slot];
                 if (!rc) {
                     haveNx = parsed.tryPop(nx);
+                    if (peeked && (!haveNx || nx.seq != peekedSeq)) (void)staramd_prefetch_cancel(ctx[d]);      // the batch shown to the engine is not the one that follows: its upload is forgotten
                     const bool passNx = haveNx && !failed.load() && nx.n > 0;
                     if (passNx) { ResBuf &rn = rb[nx.slot]; if (rn.reads.size() < nx.b.nReads || rn.tr.empty()) rn.size(std::max<uint64_t>(nx.b.nReads, 1024)); }
                     rc = staramd_map_end(ctx[d], &r.res, passNx ? &nx.b : nullptr);
@@ -356,11 +360,11 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                 }
                 if (rc) { fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error()); cur.n = 0; }
                 else {
-                    float st8[8] = {0}; uint64_t cnt[40] = {0};
-                    const int k = staramd_get_timings(ctx[d], st8, 8); const int kc = staramd_get_counters(ctx[d], cnt, 40);
+                    float st8[8] = {0}; uint64_t cnt[64] = {0};
+                    const int k = staramd_get_timings(ctx[d], st8, 8); const int kc = staramd_get_counters(ctx[d], cnt, 64);
                     std::lock_guard<std::mutex> l(statM);
                     msDeviceAll += r.res.msTotalDevice;
-                    if (timedOn) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += r.res.msTotalDevice; for (int i = 0; i < k && i < 8; i++) rep.stageMs[i] += st8[i]; for (int i = 0; i < kc && i < 40; i++) rep.counters[i] += cnt[i]; }
+                    if (timedOn) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += r.res.msTotalDevice; for (int i = 0; i < k && i < 8; i++) rep.stageMs[i] += st8[i]; for (int i = 0; i < kc && i < 64; i++) rep.counters[i] += cnt[i]; }
                 }
                 cur.merged = false;
                 if (failed.load()) cur.n = 0;
@@ -381,7 +385,7 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                 int rc = 0;
                 StageCpu sc(2); const double ma = plog.now();
                 if (!failed.load()) {
-                    auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[40] = {0};
+                    auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[64] = {0};
                     auto mapInto = [&](const staramd_batch &bt, ResBuf &r, bool main) {
                         if (r.reads.size() < bt.nReads || r.tr.empty()) r.size(std::max<uint64_t>(bt.nReads, 1024));
                         staramd_results &res = r.res;
@@ -392,7 +396,7 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                         }
                         if (!e) {
                             msDev += res.msTotalDevice;
-                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 8); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[40] = {0}; int kc = staramd_get_counters(ctx[d], c, 40); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
+                            if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 8); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[64] = {0}; int kc = staramd_get_counters(ctx[d], c, 64); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
                         }
                         return e;
                     };
@@ -436,7 +440,7 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                     if (rc) fail(std::string("EXITING because of FATAL ERROR in the MI355X engine: ") + staramd_last_error());
                     std::lock_guard<std::mutex> l(statM);
                     msDeviceAll += msDev;
-                    if (timedOn && !rc) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += msDev; for (int i = 0; i < 8; i++) rep.stageMs[i] += stage[i]; for (int i = 0; i < 40; i++) rep.counters[i] += cnt[i]; }
+                    if (timedOn && !rc) { rep.deviceBusy[d] += since(tm); rep.deviceMs[d] += msDev; for (int i = 0; i < 8; i++) rep.stageMs[i] += stage[i]; for (int i = 0; i < 64; i++) rep.counters[i] += cnt[i]; }
                 }
                 if (failed.load()) m.n = 0;                              // still goes through the writer so that the slot and the sequence number are released
                 plog.add(2, m.seq, ma, plog.now());

@@ -148,7 +148,8 @@ def main():
             nlast = max(1, batches[-1].b.nReads)         # (the engine's counters are those of the last launch)
             row["counters_per_pair"] = {k: counters[i] / nlast for i, k in enumerate(["nSAi", "nSAprobe", "nGcmp", "nSAenum", "nGstitch", "nSeeds", "nWindows", "nWA", "nNodes", "nLeaves", "nStitchCalls", "nExtendCalls", "nTrOut"])}
             row["counters_per_pair"].update({"nPrunedWin": counters[37] / nlast, "nRewalkRead": counters[38] / nlast, "nOwnerLookups": counters[40] / nlast, "nOwnerMisses": counters[41] / nlast,
-                                             "nAnchorLoci": counters[42] / nlast, "nAnchorReplayed": counters[43] / nlast, "nSkippedLeaves": counters[47] / nlast, "nRewalkWin": counters[48] / nlast})
+                                             "nAnchorLoci": counters[42] / nlast, "nAnchorReplayed": counters[43] / nlast, "nSkippedLeaves": counters[47] / nlast, "nRewalkWin": counters[48] / nlast,
+                                             "nLeavesBound": counters[49] / nlast, "nLeavesEarly": counters[50] / nlast})       # (the last two: profile / shadow builds only)
             if sum(counters[21:37]):                     # a -DSTARAMD_PROFILE build: shader-clock cycles per section, summed over wavefronts
                 pn = ["walk(all)", "coopStitch", "coopExtend", "finalize(all)", "recordCandidate", "-", "-", "wave_lifetime", "windows:passA", "windows:flanks", "windows:passB_enumerate+owner",
                       "windows:passB_assign", "windows:emission", "finalize:extends", "finalize:filters+score", "finalize:candidate+log"]
