@@ -10,7 +10,7 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wno-sign-compare -pthread
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
 # k_stitch.hip is compiled without loop unrolling (round 2: fewer spills, 3 % faster; round 5: 106 VGPRs, no scratch -- tools/isa_stats.sh k_stitch says which of the
 # register allocator's two regimes a build is in, tests/test_isa_static.py notices a flip); the other kernels keep the default
-STITCH_WAVES ?= 3
+STITCH_WAVES ?= 4
 STITCH_FLAGS := -fno-unroll-loops -DSTITCH_WAVES=$(STITCH_WAVES)
 
 # $(call build_engine,<variant>,<extra defines>): every .hip file to its own object (in parallel), then one shared library

@@ -732,10 +732,12 @@ def extra_legs_child(spec):
     legs = [("host_budget", lambda: host_budget_leg(args, idx, fq, run_dir)),
             ("config5_default_flags", lambda: config5_leg(args, g, idx, log, chim_detection=False)),
             ("config5_chimeric_detection", lambda: config5_leg(args, g, idx, log, chim_detection=True)),
-            ("config1", lambda: config1_leg(args, log))]
+            ("config1", lambda: config1_leg(args, log)),
+            ("bam_output", lambda: bam_leg(args, idx, fq, run_dir, threads))]
     if not args.no_two_pass:
         legs.append(("two_pass_end_to_end", lambda: two_pass(args, idx, fq, run_dir, threads)))
         legs.append(("two_pass_parity_400mb", lambda: two_pass_parity(args, log)))
+        legs.append(("two_pass_parity_full_index", lambda: two_pass_parity(args, log, full=(g, idx, fq, run_dir))))
     if not args.no_sweep:
         legs.append(("index_size_sweep", lambda: sweep(args, args.genome_mb, spec["main_value"], spec["main_ms"], log)))
     for name, fn in legs:
@@ -773,6 +775,34 @@ def host_budget_leg(args, idx, fq, run_dir):
     d["cpus_the_leg_was_confined_to"] = th if old_aff is not None else None
     d["what"] = "one GPU, --runThreadN = cores / 8 on that many CPUs (affinity): the host share of one rank on an 8-GPU node"
     return d
+
+
+def bam_leg(args, idx, fq, run_dir, threads):
+    """BAM output (ReadAlign_alignBAM.cpp, BAMoutput.cpp, bamSortByCoordinate.cpp): the headline workload's first batches written as BAM instead of SAM text,
+    unsorted and sorted by coordinate.  Throughput only (parity of both forms: tests/test_bam.py -m gpu); the host compresses (bgzf / zlib level 1 as the reference) on its threads."""
+    out = {}
+    nb, w = 6, 2
+    for name, typ in (("unsorted", ["BAM", "Unsorted"]), ("sorted_by_coordinate", ["BAM", "SortedByCoordinate"])):
+        prefix = os.path.join(run_dir, "bam_%s_" % name)
+        argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", prefix, "--runThreadN", str(threads), "--gpuBatchReads", str(args.reads),
+                "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(min(nb + w, args.steps + args.warmup) * args.reads), "--outSAMtype"] + typ
+        t = time.perf_counter()
+        rc, rep = _run_cli(argv)
+        wall = time.perf_counter() - t
+        if rc:
+            out[name] = {"error": "exit code %d" % rc}
+            continue
+        f = prefix + ("Aligned.out.bam" if name == "unsorted" else "Aligned.sortedByCoord.out.bam")
+        out[name] = {"Mreads_s_timed_region": int(rep.timedReads) / max(float(rep.timedWall), 1e-9) / 1e6, "Mreads_s_whole_run_incl_sort_and_index_load": int(rep.reads) / wall / 1e6,
+                     "timed_reads": int(rep.timedReads), "bam_bytes": os.path.getsize(f) if os.path.isfile(f) else None, "host_threads": threads,
+                     "device_Mreads_s": int(rep.timedReads) / max(sum(float(x) for x in rep.deviceMs) / 1e3, 1e-9) / 1e6}
+        for q in (f,):
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+    out["what"] = "--outSAMtype BAM Unsorted / SortedByCoordinate on the first batches of the headline workload; timed region = after the warm-up batches up to the last output byte, as the main line (the final merge of the sorted form included)"
+    return out
 
 
 def config5_leg(args, g, idx, log, chim_detection):
@@ -877,26 +907,36 @@ def two_pass(args, idx, fq, run_dir, threads):
             "host_threads": threads, "what": "star_amd --twopassMode Basic end to end (index load excluded)"}
 
 
-def two_pass_parity(args, log):
-    """SURVEY.md 8d config 4 PINNED at scale: --twopassMode Basic on the 400 Mb index of the sweep, one batch of reads, star_amd against the reference's own 2-pass run
-    (twoPassRunPass1.cpp:17-49, sjdbInsertJunctions.cpp:11-102, sjdbBuildIndex.cpp:141-284): the SAM records as a multiset, SJ.out.tab (column 6 = 1 for the junctions the
-    1st pass inserted), the inserted junction list of the 2nd-pass index and the Log.final.out counters."""
+def two_pass_parity(args, log, full=None):
+    """SURVEY.md 8d config 4 PINNED at scale: --twopassMode Basic, star_amd against the reference's own 2-pass run (twoPassRunPass1.cpp:17-49, sjdbInsertJunctions.cpp:11-102,
+    sjdbBuildIndex.cpp:141-284): the SAM records as a multiset, SJ.out.tab (column 6 = 1 for the junctions the 1st pass inserted), the inserted junction list of the 2nd-pass
+    index and the Log.final.out counters.  Two sizes: the 400 Mb index of the sweep with one batch of reads, and (full = the main workload) the index of the headline run --
+    3.1 Gb, 6.3e9 suffixes -- with the first three batches (1.2 M pairs) of its FASTQ."""
     from oracle import refstar
-    mb = 400
-    g, ginfo = build_genome(args, mb, log)
-    n = args.reads
-    rd = os.path.join(g, "twopass_n%d" % n)
-    fq = make_reads(args, g, rd, "reads", n, 9400)
+    more = []
+    if full:
+        g, idx_dir, fq, rd = full
+        ginfo = json.load(open(os.path.join(g, "build.json"))) if os.path.isfile(os.path.join(g, "build.json")) else {}
+        mb = args.genome_mb
+        n = min(3, args.steps + args.warmup) * args.reads
+        more = ["--readMapNumber", str(n)]
+    else:
+        mb = 400
+        g, ginfo = build_genome(args, mb, log)
+        idx_dir = os.path.join(g, "idx")
+        n = args.reads
+        rd = os.path.join(g, "twopass_n%d" % n)
+        fq = make_reads(args, g, rd, "reads", n, 9400)
     th = max(4, min(64, effective_cpus()))
     new, ref = os.path.join(rd, "gpu2p_"), os.path.join(rd, "ref2p_")
     t = time.perf_counter()
-    rc, rep = _run_cli(["--runMode", "alignReads", "--genomeDir", os.path.join(g, "idx"), "--readFilesIn"] + fq + ["--outFileNamePrefix", new, "--runThreadN", str(th),
-                        "--gpuBatchReads", str(args.reads), "--twopassMode", "Basic"])
+    rc, rep = _run_cli(["--runMode", "alignReads", "--genomeDir", idx_dir, "--readFilesIn"] + fq + ["--outFileNamePrefix", new, "--runThreadN", str(th),
+                        "--gpuBatchReads", str(args.reads), "--twopassMode", "Basic"] + more)
     t_new = time.perf_counter() - t
     if rc:
         return {"error": "star_amd exit code %d" % rc}
     t = time.perf_counter()
-    refstar.align(os.path.join(g, "idx"), fq, ref, threads=th, extra=["--twopassMode", "Basic"], timeout=1200)
+    refstar.align(idx_dir, fq, ref, threads=th, extra=["--twopassMode", "Basic"] + more, timeout=1200)
     t_ref = time.perf_counter() - t
     fp = full_size_parity(ref, new) or {}
     la, lb = (open(p + "_STARgenome/sjdbList.out.tab", "rb").read() for p in (ref, new))

@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
     DevIndex X; memset(&X, 0, sizeof(X));
     X.G = G; X.nGenome = NG;
     long bad = 0, nJoin = 0, nOK = 0, nGrow = 0;
-    std::vector<u64> sjS, sjE; std::vector<u8> sjM, sjL, sjR, sjStr;
+    std::vector<u64> sjS, sjE; std::vector<u8> sjM, sjL, sjR, sjStr; std::vector<u32> sjInfo;
     for (long t = 0; t < trials; t++) {
         staramd_params &P = X.P;
         P.scoreStitchSJshift = (int)rnd(3); P.alignIntronMin = 21; P.alignIntronMax = rnd(3) == 0 ? 500 : 0;
@@ -76,6 +76,8 @@ int main(int argc, char **argv) {
             std::sort(js.begin(), js.end());
             for (auto &j : js) { sjS.push_back(j.first); sjE.push_back(j.second); sjM.push_back((u8)rnd(7)); sjL.push_back((u8)rnd(4)); sjR.push_back((u8)rnd(4)); sjStr.push_back((u8)rnd(3)); }
             X.sjdbN = (u32)js.size(); X.sjdbStart = sjS.data(); X.sjdbEnd = sjE.data(); X.sjdbMotif = sjM.data(); X.sjdbShiftLeft = sjL.data(); X.sjdbShiftRight = sjR.data(); X.sjdbStrand = sjStr.data();
+            sjInfo.clear(); for (size_t k = 0; k < js.size(); k++) sjInfo.push_back(SJ_INFO(sjM[k], sjStr[k], sjL[k], sjR[k]));      // the engine's packed form of the same four (dev.h); the restatement reads the arrays
+            X.sjdbInfo = sjInfo.data();
         }
         // ---- the two seeds: A ends somewhere in piece A, B starts somewhere around the start of piece B
         const u32 cutA = 5 + rnd(lenA - 5);                       // A covers read [.., cutA-1]

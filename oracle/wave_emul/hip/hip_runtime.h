@@ -125,6 +125,7 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, 
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { static emuStream one; *s = &one; return hipSuccess; }      // (everything runs in order anyway)
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *, uint32_t, const uint32_t *) { return hipErrorInvalidValue; }      // (the engine falls back to a plain stream)
 static inline hipError_t hipStreamWaitEvent(hipStream_t, struct emuEvent *, unsigned) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -35,9 +35,11 @@ struct DevIndex {
     const u64 *chrStart, *chrLength;
     const u64 *sjDstart, *sjAstart, *sjdbStart, *sjdbEnd;
     const u8 *sjdbMotif, *sjdbShiftLeft, *sjdbShiftRight, *sjdbStrand;
+    // the four of them in one word per junction (built at upload): motif | strand << 3 | shiftLeft << 8 | shiftRight << 16 -- the stitcher wants all four at once, one load
+    const u32 *sjdbInfo;
     const u64 *sjNovelStart, *sjNovelEnd; u64 sjNovelN;       // whitelist of the 2nd stage of BySJout (staramd_set_novel_junctions)
     // (start, end) -> junction: open-addressing table over the annotated junctions, built at upload (engine.hip buildSjdbHash).  Slot = two words:
-    // (index + 1) << 40 | start, end; an empty slot is 0.  binarySearch2 (binarySearch2.cpp:3-43) walks ~19 dependent loads through sjdbStart for 350 k
+    // (index + 1) << 40 | start, sjdbInfo << 40 | end; an empty slot is 0.  binarySearch2 (binarySearch2.cpp:3-43) walks ~19 dependent loads through sjdbStart for 350 k
     // junctions; the table answers with one.  Null when the coordinates / the junction count do not fit the packing: the bisection is used then.
     const u64 *sjdbHash; u32 sjdbHashMask; u32 padHash;
     u64 nGenome, nSA, sjGstart;
@@ -98,6 +100,7 @@ enum { DC_nSAi, DC_nSAprobe, DC_nGcmp, DC_nSAenum, DC_nGstitch, DC_nSeeds, DC_nW
        DC_wprof5, DC_wprof6, DC_wprof7,                                // -DSTARAMD_PROFILE build: more sections of k_windows
        DC_nSkippedLeaves, DC_nRewalkWin,                               // stitch kernels: single-mate leaves (and subtrees of them) not finalised / two-mate windows walked again in full
        DC_nLeavesBound, DC_nLeavesEarly,                               // profile / shadow builds: leaves dropped by their score bound before the extensions / by their score after them (k_stitch.hip finalizeTranscript)
+       DC_sprof0, DC_sprof1, DC_sprof2, DC_sprof3, DC_sprof4, DC_sprof5, DC_sprof6, DC_sprof7, DC_sprof8, DC_sprof9, DC_sprof10, DC_sprof11,   // -DSTARAMD_PROFILE build: coopStitch by kind of join (cycles, calls) and the walk's own parts
        DC_N };
 
 // cursors[] slots.  Every counter has a 128-byte line of its own (CS words apart): an L2 channel serves the atomics of one line one after the other (~2 ns each, measured:
@@ -169,6 +172,11 @@ __device__ __forceinline__ u8 gcGet(const u8 *G, GCache &c, i64 pos) {
 }
 
 #define SJH_START_BITS 40u
+#define SJ_INFO(motif, strand, shL, shR) ((u32)(motif) | ((u32)(strand) << 3) | ((u32)(shL) << 8) | ((u32)(shR) << 16))
+#define SJ_INFO_MOTIF(i) ((i) & 7u)
+#define SJ_INFO_STRAND(i) (((i) >> 3) & 3u)
+#define SJ_INFO_SHL(i) (((i) >> 8) & 255u)
+#define SJ_INFO_SHR(i) (((i) >> 16) & 255u)
 __device__ __forceinline__ u32 sjdbHashSlot(u64 start, u32 mask) { return (u32)((start * 0x9E3779B97F4A7C15ull) >> 40) & mask; }
 // one lane: index of the junction (x, y) or -1
 __device__ __forceinline__ int sjdbHashFind(const u64 *tab_, u32 mask, u64 x, u64 y) {
@@ -177,7 +185,7 @@ __device__ __forceinline__ int sjdbHashFind(const u64 *tab_, u32 mask, u64 x, u6
     for (u32 n = 0; n <= mask; n++, h = (h + 1u) & mask) {
         const u64 s = tab[2u * h];
         if (s == 0) return -1;
-        if ((s & ((1ull << SJH_START_BITS) - 1ull)) == x && tab[2u * h + 1u] == y) return (int)(s >> SJH_START_BITS) - 1;
+        if ((s & ((1ull << SJH_START_BITS) - 1ull)) == x && (tab[2u * h + 1u] & ((1ull << SJH_START_BITS) - 1ull)) == y) return (int)(s >> SJH_START_BITS) - 1;
     }
     return -1;
 }

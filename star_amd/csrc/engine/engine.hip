@@ -112,6 +112,26 @@ struct staramd_ctx {
 static void refreshSharers(staramd_ctx *c) { for (staramd_ctx *s : c->sharers) { s->X = c->X; s->dX = c->dX; } }
 #define OWNER_ONLY(c) do { if ((c)->owner) { g_err = "this context shares the index of another one (staramd_create_shared): change the index through its owner"; return STARAMD_ERR_ARG; } } while (0)
 
+static u32 envU32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)strtoul(s, nullptr, 10) : dflt; }
+// Streams.  The copies of this runtime are shader kernels (rocprofv3: __amd_rocclr_copyBuffer; no SDMA engine is used on this pool), so a copy that is to run BESIDE the
+// persistent kernels of the next batch needs compute units those kernels do not hold: with STARAMD_COPY_CUS = k > 0 the copy stream of a context is confined to the last k
+// CUs of the device and its kernel stream to the others (hipExtStreamCreateWithCUMask).  The kernels lose k / nCU of the chip; the result copy of batch i then completes
+// ~2 ms after its kernels while batch i + 1 runs (staramd_map_end), instead of behind them.  0 (or a runtime that refuses the mask): plain streams.
+static hipError_t makeStream(staramd_ctx *c, hipStream_t *s, bool copySide) {
+    const u32 k = envU32("STARAMD_COPY_CUS", 0), n = (u32)c->nCU;
+    if (k > 0 && k < n) {
+        std::vector<uint32_t> mask((n + 31) / 32, 0u);
+        for (u32 i = 0; i < n; i++) if ((i >= n - k) == copySide) mask[i >> 5] |= 1u << (i & 31u);
+        if (hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+            if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: %s stream confined to %u of %u CUs\n", copySide ? "copy" : "kernel", copySide ? k : n - k, n);
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: hipExtStreamCreateWithCUMask refused, plain stream\n");
+    }
+    return hipStreamCreate(s);
+}
+
 template <class T> static int devAlloc(std::vector<void *> &reg, T **p, u64 n) {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, std::max<u64>(n * sizeof(T), 16));
@@ -151,7 +171,6 @@ static void buildGlBreaks(DevIndex &X, double scale) {
 
 // DevIndex::sjdbHash (dev.h): slots = a power of two >= 2 x junctions, >= 128 (the cooperative look-up probes 64 consecutive slots per step)
 static int buildSjdbHash(staramd_ctx *c, const staramd_genome *g);
-static u32 envU32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)strtoul(s, nullptr, 10) : dflt; }
 // chromosome / junction tables, index geometry, parameters and the DevIndex block (everything but G, SA, SAindex)
 static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
@@ -167,6 +186,11 @@ static int uploadTables(staramd_ctx *c, const staramd_genome *g, const staramd_p
     if ((rc = devUpload(c->indexAllocs, &X.sjdbShiftLeft, g->sjdbShiftLeft, (u64)g->sjdbN))) return rc;
     if ((rc = devUpload(c->indexAllocs, &X.sjdbShiftRight, g->sjdbShiftRight, (u64)g->sjdbN))) return rc;
     if ((rc = devUpload(c->indexAllocs, &X.sjdbStrand, g->sjdbStrand, (u64)g->sjdbN))) return rc;
+    {
+        std::vector<u32> info((size_t)g->sjdbN);
+        for (u32 i = 0; i < g->sjdbN; i++) info[i] = SJ_INFO(g->sjdbMotif[i] & 7u, g->sjdbStrand[i] & 3u, g->sjdbShiftLeft[i], g->sjdbShiftRight[i]);
+        if ((rc = devUpload(c->indexAllocs, &X.sjdbInfo, (const u32 *)info.data(), (u64)g->sjdbN))) return rc;
+    }
     X.nGenome = g->nGenome; X.nSA = g->nSA; X.sjGstart = g->sjGstart;
     for (int i = 0; i < 17; i++) X.saiStart[i] = g->genomeSAindexStart[i];
     X.strandBit = g->GstrandBit; X.saBits = g->GstrandBit + 1; X.saiBits = g->GstrandBit + 3;
@@ -196,7 +220,8 @@ static int buildSjdbHash(staramd_ctx *c, const staramd_genome *g) {
         const u64 st = g->sjdbStart[i];
         u32 h = (u32)((st * 0x9E3779B97F4A7C15ull) >> 40) & mask;
         while (tab[2 * (size_t)h]) h = (h + 1) & mask;
-        tab[2 * (size_t)h] = ((u64)(i + 1) << SJH_START_BITS) | st; tab[2 * (size_t)h + 1] = g->sjdbEnd[i];
+        tab[2 * (size_t)h] = ((u64)(i + 1) << SJH_START_BITS) | st;
+        tab[2 * (size_t)h + 1] = g->sjdbEnd[i] | ((u64)SJ_INFO(g->sjdbMotif[i] & 7u, g->sjdbStrand[i] & 3u, g->sjdbShiftLeft[i], g->sjdbShiftRight[i]) << SJH_START_BITS);
     }
     int rc = devUpload(c->indexAllocs, &X.sjdbHash, (const u64 *)tab.data(), (u64)slots * 2);
     if (!rc) X.sjdbHashMask = mask;
@@ -253,7 +278,7 @@ static int allocWork(staramd_ctx *c) {
         if ((rc = devAlloc(R, &c->in[1].readOffset, (u64)N + 1))) return rc;
         if ((rc = devAlloc(R, &c->in[1].mate1, (u64)N))) return rc;
         if ((rc = devAlloc(R, &c->in[1].mm, (u64)N))) return rc;
-        if (hipStreamCreate(&c->copyStream) != hipSuccess) { g_err = "hipStreamCreate failed"; return STARAMD_ERR_DEVICE; }
+        if (makeStream(c, &c->copyStream, true) != hipSuccess) { g_err = "hipStreamCreate failed"; return STARAMD_ERR_DEVICE; }
         for (int k = 0; k < 2; k++) if (hipEventCreateWithFlags(&c->in[k].up, hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return STARAMD_ERR_DEVICE; }
     }
     c->packWordsCap = 0;
@@ -417,7 +442,7 @@ extern "C" int staramd_create(staramd_ctx **out, int device, const staramd_genom
     c->device = device; c->maxReads = maxBatchReads; c->maxBases = maxBatchBases ? maxBatchBases : (u64)maxBatchReads * (STARAMD_READ_LEN_MAX + 1);
     int rc = uploadIndex(c, g, p);
     if (!rc) rc = allocWork(c);
-    if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
+    if (!rc) { if (makeStream(c, &c->stream, false) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (!rc && !getenv("STARAMD_SPIN_WAIT") && hipEventCreateWithFlags(&c->evWait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) c->evWait = nullptr;
     if (!rc && hipEventCreateWithFlags(&c->evDownload, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
@@ -435,7 +460,7 @@ extern "C" int staramd_create_shared(staramd_ctx **out, staramd_ctx *owner, uint
     c->device = owner->device; c->maxReads = maxBatchReads; c->maxBases = maxBatchBases ? maxBatchBases : (u64)maxBatchReads * (STARAMD_READ_LEN_MAX + 1);
     c->owner = owner; c->X = owner->X; c->dX = owner->dX;
     int rc = allocWork(c);
-    if (!rc) { if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
+    if (!rc) { if (makeStream(c, &c->stream, false) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = STARAMD_ERR_DEVICE; } }
     if (!rc) for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }
     if (!rc && !getenv("STARAMD_SPIN_WAIT") && hipEventCreateWithFlags(&c->evWait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) c->evWait = nullptr;
     if (!rc && hipEventCreateWithFlags(&c->evDownload, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; rc = STARAMD_ERR_DEVICE; }

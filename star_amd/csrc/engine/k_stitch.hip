@@ -161,16 +161,16 @@ __device__ static int coopSjdbFind(u32 lane, u64 x, u64 y, const u64 *Xs_, const
 
 // the same question through DevIndex::sjdbHash (dev.h): the lanes probe 64 consecutive slots of the table at once -- one round trip instead of the
 // three or four dependent ones of the 64-ary search above (the junction arrays of a human annotation are 2 x 2.8 MB: every round is an L2 access)
-__device__ static int coopSjdbHash(u32 lane, u64 x, u64 y, const u64 *tab_, u32 mask) {
+__device__ static int coopSjdbHash(u32 lane, u64 x, u64 y, const u64 *tab_, u32 mask, u32 &info) {
     const GLOBAL_AS u64 *tab = (const GLOBAL_AS u64 *)tab_;
     const u32 h0 = sjdbHashSlot(x, mask);
     for (u32 step = 0; step <= mask; step += NLANE) {
         const u32 h = (h0 + step + lane) & mask;
         const u64 s = tab[2u * h], e = tab[2u * h + 1u];
         const bool empty = s == 0;
-        const bool hit = !empty && (s & ((1ull << SJH_START_BITS) - 1ull)) == x && e == y;
+        const bool hit = !empty && (s & ((1ull << SJH_START_BITS) - 1ull)) == x && (e & ((1ull << SJH_START_BITS) - 1ull)) == y;
         const u64 em = __ballot(empty), hm = __ballot(hit);
-        if (hm) { const u32 l = firstLane(hm); if (!em || l < firstLane(em)) return (int)(laneGet64(s, l) >> SJH_START_BITS) - 1; return -1; }
+        if (hm) { const u32 l = firstLane(hm); if (!em || l < firstLane(em)) { info = laneGet32((u32)(e >> SJH_START_BITS), l); return (int)(laneGet64(s, l) >> SJH_START_BITS) - 1; } return -1; }
         if (em) return -1;
     }
     return -1;
@@ -188,11 +188,12 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
     int Score = 0;
     if (sjAB != -1 && eA.sjA == sjAB && eA.iFrag == iFragB && rBstart == rAend + 1 && gAend + 1 < gBstart) {
         // both seeds come from the same inserted sjdb sequence: the junction is the annotated one (:18-34)
-        const u32 sMotif = first32(GLOBAL(u8, X.sjdbMotif)[sjAB]), sShL = first32(GLOBAL(u8, X.sjdbShiftLeft)[sjAB]), sShR = first32(GLOBAL(u8, X.sjdbShiftRight)[sjAB]);
+        SPROF_KIND(0);
+        const u32 sInfo = first32(GLOBAL(u32, X.sjdbInfo)[sjAB]), sMotif = SJ_INFO_MOTIF(sInfo), sShL = SJ_INFO_SHL(sInfo), sShR = SJ_INFO_SHR(sInfo);
         if (sMotif == 0 && (L <= sShR || eA.L <= sShL)) return -1000006;
         eN.L = (u16)L; eN.R = (u16)rBstart; eN.G = gBstart;
         eA.canonSJ = (i8)sMotif; eA.shiftSJ[0] = (u16)sShL; eA.shiftSJ[1] = (u16)sShR;
-        eA.sjAnnot = 1; eA.sjStr = (u8)first32(GLOBAL(u8, X.sjdbStrand)[sjAB]);
+        eA.sjAnnot = 1; eA.sjStr = (u8)SJ_INFO_STRAND(sInfo);
         added = true; h.nMatch += L;
         Score += (int)L; Score += P.sjdbScore;
     } else {
@@ -208,8 +209,9 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
             u32 nMatch = L, nMM = 0; u64 Del = 0; u32 Ins = 0, nIns = 0, nDel = 0;
             int jR = 0, jCan = 999;
             u64 gBstart1 = gBstart - (u64)(i64)rGap - 1;
-            if (gGap == 0 && rGap == 0) {
+            if (gGap == 0 && rGap == 0) { SPROF_KIND(1);
             } else if (gGap > 0 && rGap > 0 && rGap == gGap) {
+                SPROF_KIND(1);
                 // ---- equal gap: score the bases in between (:80-93)
                 for (int base = 1; base <= rGap; base += (int)NLANE) {
                     int ii = base + (int)lane;
@@ -225,6 +227,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                 // ---- deletion or junction (:95-253)
                 nDel = 1; Del = (u64)(i64)(gGap - rGap);
                 if (Del > P.alignIntronMax && P.alignIntronMax > 0) return -1000003;
+                SPROF_KIND(2);
                 const int eAL = (int)eA.L;
                 PROF_T0();
                 // left scan (:104-109): walk left from the end of A while fewer than scoreStitchSJshift+1 positions
@@ -335,23 +338,25 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
                     c.nGstitch += (u32)(i1 - i0 + 1);
                 }
                 
-                int sjdbInd = -1;
-                if (X.sjdbN > 0) sjdbInd = X.sjdbHash ? coopSjdbHash(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbHash, X.sjdbHashMask)
-                                                      : coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN);
+                int sjdbInd = -1; u32 jInfo = 0;          // the table answers with the junction's motif / strand / shifts in the same slot
+                if (X.sjdbN > 0) {
+                    if (X.sjdbHash) sjdbInd = coopSjdbHash(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbHash, X.sjdbHashMask, jInfo);
+                    else { sjdbInd = coopSjdbFind(lane, gAend + (i64)jR + 1, gBstart1 + (i64)jR, X.sjdbStart, X.sjdbEnd, X.sjdbN); if (sjdbInd >= 0) jInfo = first32(GLOBAL(u32, X.sjdbInfo)[sjdbInd]); }
+                }
                 
                 if (sjdbInd < 0) {
                     if (isIntron) Score += P.scoreGap + jPen;
                     else { Score += (int)Del * P.scoreDelBase + P.scoreDelOpen; jCan = -1; eA.sjAnnot = 0; }
                 } else {
-                    jCan = (int)first32(GLOBAL(u8, X.sjdbMotif)[sjdbInd]);
+                    jCan = (int)SJ_INFO_MOTIF(jInfo);
                     if (jCan == 0) {
-                        const u32 sShL = first32(GLOBAL(u8, X.sjdbShiftLeft)[sjdbInd]);
+                        const u32 sShL = SJ_INFO_SHL(jInfo);
                         if (L <= sShL || eA.L <= sShL) return -1000006;
                         jR += (int)sShL;
                         if ((u64)rAend + (i64)jR >= rBend) return -1000006;
-                        jjL = sShL; jjR = first32(GLOBAL(u8, X.sjdbShiftRight)[sjdbInd]);
+                        jjL = sShL; jjR = SJ_INFO_SHR(jInfo);
                     }
-                    eA.sjAnnot = 1; eA.sjStr = (u8)first32(GLOBAL(u8, X.sjdbStrand)[sjdbInd]);
+                    eA.sjAnnot = 1; eA.sjStr = (u8)SJ_INFO_STRAND(jInfo);
                     Score += P.sjdbScore;
                 }
                 eA.shiftSJ[0] = (u16)jjL; eA.shiftSJ[1] = (u16)jjR; eA.canonSJ = (i8)jCan;
@@ -402,6 +407,7 @@ __device__ static int coopStitch(StitchCtx &c, u32 lane, u32 rAend, u64 gAend, u
         } else if (gBstart + ex0R + (i64)P.alignEndsProtrudeNbasesMax >= ex0G || ex0G < ex0R) {
             // ---- mate 2 after mate 1 (:352-405)
             if (P.alignMatesGapMax > 0 && gBstart > eA.G + eA.L + P.alignMatesGapMax) return -1000004;
+            SPROF_KIND(3);
             Score += (int)L;
             ExtRes e;
             if (coopExtend(c, lane, rAend + 1, gAend + 1, 1, 1, STARAMD_READ_LEN_MAX, h.nMatch, h.nMM, c.mmMaxTotal, P.outFilterMismatchNoverLmax, P.alignEndsTypeExt[eA.iFrag][1] != 0, e)) {
@@ -807,6 +813,7 @@ __device__ __forceinline__ u32 nextSeed(u64 mask, u32 i, u32 nA) {
 // only end in such leaves); the caller accepts the result when the window's final best score puts every single-mate transcript below the selection bar.
 __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, const LaneMem &m, WinRec &wr, const u64 glb0, const u64 glb1, const bool skipSingle, u32 &nSkipped) {
     const u32 nA = win.nWA;
+    PROF_T0();
     c.str = win.str;
     wr.nWinTr = 0; wr.top = 0; wr.overflow = false; wr.bestScore = 0;
     LDS SFrame *stack = m.stack; LDS staramd_exon *EX = m.EX, *LEAF = m.LEAF; LDS DWA *WA = m.WA;
@@ -829,6 +836,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
         m.compat[lane] = mk;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    PROF_ADD(c, 5);                                  // (window set-up: compat masks)
     u32 iLast = 0;                                   // last included seed of the working transcript
     u32 fragFirst = 0, fragLast = 0;                 // mates of its first and of its last seed = of its first and last exon (stitchAlignToTranscript.cpp:413-414)
     nSkipped = 0;
@@ -871,7 +879,7 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
 #ifdef STARAMD_SHADOW
             Hdr hs = h; staramd_exon eAs = eA, eNs; bool addedS = false;
 #endif
-            { PROF_T0(); dScore = coopStitch(c, lane, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G); PROF_ADD(c, 1); }
+            { PROF_T0(); SPROF_KIND(4); dScore = coopStitch(c, lane, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hn, eA, eN, added, ex0R, ex0G); PROF_ADD(c, 1); SPROF_ADD(c); }
 #ifdef STARAMD_SHADOW
             {   // every lane re-runs the call through the scalar restatement (same inputs): any disagreement is counted
                 int dS = joinOnLane(c, h.tR2, h.tG2, a.rStart, a.gStart, a.L, a.iFrag, a.sjA, hs, eAs, eNs, addedS, ex0R, ex0G);
@@ -982,7 +990,7 @@ __device__ __forceinline__ void ctxLoadRead(StitchCtx &c, u32 lane, const DevBat
 // A window whose recorded transcripts outgrow the LDS arena is walked again at once by the same wavefront with its
 // arena in global memory (bigArena: one worst-case arena per wavefront).
 #ifndef STITCH_WAVES
-#define STITCH_WAVES 3      // minimum waves per SIMD the register allocation of the walk kernel is held to (Makefile: STITCH_WAVES)
+#define STITCH_WAVES 4      // minimum waves per SIMD the register allocation of the walk kernel is held to (Makefile: STITCH_WAVES)
 #endif
 extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(const DevIndex *__restrict__ Xp, DevBatch B, u8 *bigArena, u32 capDepth, u32 capRank, u32 arenaBytes,
                                                              u32 bigArenaBytes, u32 ldsWords, u32 mode, u32 pruneEnable) {
@@ -1031,6 +1039,8 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
                          && P.scoreDelOpen <= 0 && P.scoreDelBase <= 0 && P.scoreInsOpen <= 0 && P.scoreInsBase <= 0;
 #ifdef STARAMD_PROFILE
     for (int k = 0; k < 16; k++) c.prof[k] = 0;
+    for (int k = 0; k < 12; k++) c.sprof[k] = 0;
+    c.sprofKind = 0;
     const u64 profKernelStart = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -1183,6 +1193,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
 #ifdef STARAMD_PROFILE
         c.prof[7] = __builtin_readcyclecounter() - profKernelStart;      // whole wave life time
         for (int k = 0; k < 16; k++) atomicAdd((unsigned long long *)&B.counters[DC_prof0 + k], (unsigned long long)c.prof[k]);
+        for (int k = 0; k < 12; k++) atomicAdd((unsigned long long *)&B.counters[DC_sprof0 + k], (unsigned long long)c.sprof[k]);
 #endif
     }
 }

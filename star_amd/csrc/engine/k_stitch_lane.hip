@@ -342,7 +342,13 @@ __device__ __forceinline__ void emptyWout(DWinOut &z) {
 }
 
 #ifndef LANE_WAVES
-#define LANE_WAVES 3        // minimum waves per SIMD the register allocation is held to (same box, 1000 Mb, stitch stage: 2 -> 43.6 ms (three runs 41.6-45.6), 3 -> 37.8, 4 -> 46.3)
+// Minimum waves per SIMD the register allocation is held to: 2 = up to 256 vector registers, which this kernel needs (202) to stay WITHOUT vector-register spills.
+// Held to 3 (168 registers + ~40 spilled to scratch, beside 106 scalar registers spilled into vector-register lanes and 1.9 KB of per-lane arrays) the kernel returned
+// transcripts whose exon rows were garbage, on hardware only, for ~1 read in 3 000 of a single-end set -- and whether it did depended on an unrelated edit of a branch that
+// the set never takes (round 6, profiles/r06_lane_kernel_spill_corruption.txt: the same source is clean in the wavefront emulator under AddressSanitizer, clean at 2, and was
+// clean at 3 until the scalar routines loaded one word instead of four bytes).  tests/test_isa_static.py holds the kernel to zero vector-register spills.  The kernel takes
+// ~5 % of the reads of a 2x101 batch in 0.3 ms: its occupancy is not what the stage waits for (round 3, 1000 Mb, when it took most reads: 2 -> 43.6 ms, 3 -> 37.8, 4 -> 46.3).
+#define LANE_WAVES 2
 #endif
 extern "C" __global__ void __launch_bounds__(256, LANE_WAVES) k_stitch_lane(const DevIndex *__restrict__ Xp, DevBatch B, u8 *laneArena, u32 laneArenaBytes, u32 ldsWords, u32 pruneEnable, u32 maxClass) {
     if (B.cursors[CUR_FLAGS] != 0) return;          // a pool overflowed in an earlier kernel: the host grows it and re-runs the batch

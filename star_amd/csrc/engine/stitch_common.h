@@ -32,6 +32,7 @@ struct StitchCtx {
     u64 *shadow;                           // shadow-validation build: disagreement counters
 #ifdef STARAMD_PROFILE
     u64 prof[16];
+    u32 sprofKind; u64 sprof[12];       // coopStitch by kind of join: [0,1] annotated (cycles, calls) [2,3] no gap / equal gap [4,5] deletion / junction [6,7] mate join [8,9] insertion / rejected early; [10] window set-up [11] item fetch + flush
 #endif
     u8 *candBase; u32 candTop, candCap, nCand; bool logOn, logOvf;   // candidate log of the current window (see DWinOut)
 };
@@ -84,7 +85,13 @@ __device__ __forceinline__ bool pruneWindow(const staramd_params &P, i32 perJ, u
 #define PROF_T0() u64 prof_t0_ = __builtin_readcyclecounter()
 #define PROF_ADD(c, k) (c).prof[k] += __builtin_readcyclecounter() - prof_t0_
 #define PROF_MARK(c, k) { u64 prof_t1_ = __builtin_readcyclecounter(); (c).prof[k] += prof_t1_ - prof_t0_; prof_t0_ = prof_t1_; }
+#define SPROF_KIND(k) (c).sprofKind = (k)
+#define SPROF_ADD(c) { const u64 d_ = __builtin_readcyclecounter() - prof_t0_; const u32 k_ = (c).sprofKind; \
+    if (k_ == 0) { (c).sprof[0] += d_; (c).sprof[1]++; } else if (k_ == 1) { (c).sprof[2] += d_; (c).sprof[3]++; } else if (k_ == 2) { (c).sprof[4] += d_; (c).sprof[5]++; } \
+    else if (k_ == 3) { (c).sprof[6] += d_; (c).sprof[7]++; } else { (c).sprof[8] += d_; (c).sprof[9]++; } }
 #else
+#define SPROF_KIND(k)
+#define SPROF_ADD(c)
 #define PROF_T0()
 #define PROF_ADD(c, k)
 #define PROF_MARK(c, k)

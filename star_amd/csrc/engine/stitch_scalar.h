@@ -182,10 +182,10 @@ __device__ static int joinOnLane(StitchCtx &c, u32 rAend, u64 gAend, u32 rBstart
     int total = 0;
     if (sjAB != -1 && eA.sjA == sjAB && eA.iFrag == iFragB && rBstart == rAend + 1 && gAend + 1 < gBstart) {
         // the two seeds are the two halves of one inserted junction sequence: the junction is the annotated one (:18-34)
-        const u32 motif = GLOBAL(u8, X.sjdbMotif)[sjAB], shL = GLOBAL(u8, X.sjdbShiftLeft)[sjAB], shR = GLOBAL(u8, X.sjdbShiftRight)[sjAB];
+        const u32 sInfo = GLOBAL(u32, X.sjdbInfo)[sjAB], motif = SJ_INFO_MOTIF(sInfo), shL = SJ_INFO_SHL(sInfo), shR = SJ_INFO_SHR(sInfo);
         if (motif == 0 && (L <= shR || eA.L <= shL)) return -1000006;
         eN.L = (u16)L; eN.R = (u16)rBstart; eN.G = gBstart;
-        eA.canonSJ = (i8)motif; eA.shiftSJ[0] = (u16)shL; eA.shiftSJ[1] = (u16)shR; eA.sjAnnot = 1; eA.sjStr = GLOBAL(u8, X.sjdbStrand)[sjAB];
+        eA.canonSJ = (i8)motif; eA.shiftSJ[0] = (u16)shL; eA.shiftSJ[1] = (u16)shR; eA.sjAnnot = 1; eA.sjStr = (u8)SJ_INFO_STRAND(sInfo);
         added = true; h.nMatch += L;
         total = (int)L + P.sjdbScore;
     } else if (eA.iFrag == iFragB) {
@@ -314,15 +314,15 @@ __device__ static int joinOnLane(StitchCtx &c, u32 rAend, u64 gAend, u32 rBstart
                 if (intron) total += P.scoreGap + bestPen;
                 else { total += (int)delLen * P.scoreDelBase + P.scoreDelOpen; kind = -1; eA.sjAnnot = 0; }
             } else {
-                const u32 motif = GLOBAL(u8, X.sjdbMotif)[known], shL = GLOBAL(u8, X.sjdbShiftLeft)[known];
+                const u32 jInfo = GLOBAL(u32, X.sjdbInfo)[known], motif = SJ_INFO_MOTIF(jInfo), shL = SJ_INFO_SHL(jInfo);
                 kind = (int)motif;
                 if (motif == 0) {
                     if (L <= shL || eA.L <= shL) return -1000006;
                     cut += (int)shL;
                     if ((u64)rAend + (i64)cut >= rBend) return -1000006;
-                    slideL = shL; slideR = GLOBAL(u8, X.sjdbShiftRight)[known];
+                    slideL = shL; slideR = SJ_INFO_SHR(jInfo);
                 }
-                eA.sjAnnot = 1; eA.sjStr = GLOBAL(u8, X.sjdbStrand)[known];
+                eA.sjAnnot = 1; eA.sjStr = (u8)SJ_INFO_STRAND(jInfo);
                 total += P.sjdbScore;
             }
             eA.shiftSJ[0] = (u16)slideL; eA.shiftSJ[1] = (u16)slideR; eA.canonSJ = (i8)kind;

@@ -24,6 +24,13 @@ def test_stitch_kernel_keeps_its_uniform_state_in_scalar_registers():
     assert f["vgprs"] <= 112 and f["vgpr_spills"] == 0 and f["scratch"] == 0 and f["saveexec"] <= 160, f
 
 
+def test_lane_kernel_spills_no_vector_registers():
+    """k_stitch_lane with spilled vector registers (beside its spilled scalar registers and per-lane arrays in scratch) corrupted results on hardware in round 6
+    (k_stitch_lane.hip LANE_WAVES has the story): the kernel is held to an occupancy at which nothing of its vector state spills."""
+    f = _figures("k_stitch_lane", "k_stitch_lane")
+    assert f["vgpr_spills"] == 0, f
+
+
 def test_window_kernel_does_not_spill_vector_registers():
     f = _figures("k_window", "k_windows")
     assert f["vgprs"] <= 80 and f["vgpr_spills"] == 0 and f["saveexec"] <= 200, f

@@ -135,7 +135,7 @@ def main():
                     cnt += 1
                 if not ok:
                     break
-            counters = (C.c_uint64 * 56)(); L.staramd_get_counters(ctx, counters, 56)
+            counters = (C.c_uint64 * 64)(); L.staramd_get_counters(ctx, counters, 64)
             L.staramd_destroy(ctx)
             shutil.rmtree(tmp, ignore_errors=True)
             if not ok or cnt == 0:
@@ -157,7 +157,11 @@ def main():
                 row["profile_kcycles_per_pair"]["windows:passB_owner_lookups"] = round(counters[44] / nlast / 1e3, 2)       # (then passB_enumerate+owner is the enumeration alone)
                 row["profile_kcycles_per_pair"]["windows:passA_loads"] = round(counters[45] / nlast / 1e3, 2)               # (then passA is the replay alone)
                 row["profile_kcycles_per_pair"]["windows:passA_prefilter"] = round(counters[46] / nlast / 1e3, 2)
+                row["profile_kcycles_per_pair"]["window_setup"] = round(counters[21 + 5] / nlast / 1e3, 2)
+                kinds = ["annotated", "no/equal gap", "deletion/junction", "mate join", "insertion/rejected"]      # dev.h DC_sprof0..: coopStitch by kind of join
+                row["stitch_calls_by_kind"] = {kinds[i]: {"calls_per_pair": round(counters[51 + 2 * i + 1] / nlast, 2), "kcycles_per_call": round(counters[51 + 2 * i] / max(1, counters[51 + 2 * i + 1]) / 1e3, 2)} for i in range(5)}
                 print("    profile (k cycles per pair):", row["profile_kcycles_per_pair"], flush=True)
+                print("    coopStitch by kind:", row["stitch_calls_by_kind"], flush=True)
                 pass
             if True:
                 print("    counts per pair:", {k: round(v, 2) for k, v in row["counters_per_pair"].items()}, flush=True)

@@ -6,7 +6,7 @@ A wave-cooperative kernel branches on wave-uniform conditions almost everywhere;
 import collections, os, re, subprocess, sys
 f, kernel, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-flags = ["-fno-unroll-loops", "-DSTITCH_WAVES=3"] if f == "k_stitch" else []
+flags = ["-fno-unroll-loops", "-DSTITCH_WAVES=4"] if f == "k_stitch" else []
 ll = "/tmp/div_%d.ll" % os.getpid()
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "-gline-tables-only", "--cuda-device-only",
                        "-emit-llvm", "-S"] + flags + extra + [os.path.join(root, "star_amd/csrc/engine", f + ".hip"), "-o", ll], stderr=subprocess.DEVNULL)

@@ -2,7 +2,7 @@
 # static figures of the kernels of one engine source file: registers and spills as the compiler reports them, and the instruction mix of the ISA
 # (exec-mask bookkeeping, lane moves of spilled scalars, scratch traffic)       tools/isa_stats.sh k_stitch [extra hipcc flags]
 f=$1; shift
-extra=""; if [ "$f" = k_stitch ]; then extra="-fno-unroll-loops -DSTITCH_WAVES=${STITCH_WAVES:-3}"; fi
+extra=""; if [ "$f" = k_stitch ]; then extra="-fno-unroll-loops -DSTITCH_WAVES=${STITCH_WAVES:-4}"; fi
 S=/tmp/isa_$$.s
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $extra "$@" -Rpass-analysis=kernel-resource-usage --cuda-device-only -S star_amd/csrc/engine/$f.hip -o $S 2> /tmp/isa_$$.err || { grep error /tmp/isa_$$.err | head; exit 1; }
 python3 - $S /tmp/isa_$$.err <<'PY'
