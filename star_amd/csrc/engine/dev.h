@@ -31,6 +31,7 @@ typedef int8_t i8;
 struct DevIndex {
     const u8 *G;                  // points at genome base 0 (GPAD bytes of 5 precede it); 8-byte aligned
     const u64 *SA, *SAi;          // packed arrays as 64-bit words
+    const void *SAK; u32 sakBases, padSak;      // keys beside the suffix array (k_seed.hip: two words per entry), or null; sakBases = the prefix length the keys lie behind (saiNbases)
     const u32 *chrBin;
     const u64 *chrStart, *chrLength;
     const u64 *sjDstart, *sjAstart, *sjdbStart, *sjdbEnd;

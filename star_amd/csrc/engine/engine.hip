@@ -228,6 +228,45 @@ static int buildSjdbHash(staramd_ctx *c, const staramd_genome *g) {
     return rc;
 }
 
+// The keys beside the suffix array (dev.h DevIndex::SAK, k_seed.hip): 16 bytes per suffix -- 99 GB for a human-size index, out of HBM that is otherwise empty.  Built on the
+// device from the resident genome and suffix array (~1 s at 6.3e9 suffixes); skipped (the seed stage then probes the packed array and the genome, as before) when
+// STARAMD_SA_KEYS=0, with a sparse suffix array, or when the array would not leave `reserve` bytes of HBM for the work space.
+extern "C" __global__ void k_sak_build(const DevIndex *Xp, u64 *out, u64 n0, u64 n1);
+static void dropSak(staramd_ctx *c) {
+    DevIndex &X = c->X;
+    if (X.SAK) for (size_t i = 0; i < c->indexAllocs.size(); i++) if (c->indexAllocs[i] == X.SAK) { (void)hipFree(c->indexAllocs[i]); c->indexAllocs.erase(c->indexAllocs.begin() + i); break; }
+    X.SAK = nullptr; X.sakBases = 0;
+}
+static int buildSak(staramd_ctx *c) {
+    DevIndex &X = c->X;
+    dropSak(c);
+    HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    if (!envU32("STARAMD_SA_KEYS", 1) || X.sparseD != 1 || X.saBits > 58 || X.saiNbases == 0 || X.nSA == 0) return 0;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 0;
+    const u64 need = X.nSA * 16ull, reserve = (u64)envU32("STARAMD_SA_KEYS_RESERVE_GB", 48) << 30;
+    if ((u64)freeB < need + std::min<u64>(reserve, (u64)totalB / 4)) {
+        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: no keys beside the suffix array: %.1f GB needed, %.1f GB free\n", need / 1e9, freeB / 1e9);
+        return 0;
+    }
+    u64 *out = nullptr;
+    if (hipMalloc((void **)&out, need) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, 0);
+    const u64 chunk = 1ull << 30;                      // (grids of at most 2^30 lanes)
+    for (u64 n0 = 0; n0 < X.nSA; n0 += chunk) {
+        const u64 n1 = std::min<u64>(X.nSA, n0 + chunk);
+        hipLaunchKernelGGL(k_sak_build, dim3((u32)((n1 - n0 + 255) / 256)), dim3(256), 0, 0, (const DevIndex *)c->dX, out, n0, n1);
+    }
+    (void)hipEventRecord(e1, 0);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(out); g_err = "k_sak_build failed"; return STARAMD_ERR_DEVICE; }
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    c->indexAllocs.push_back(out);
+    X.SAK = out; X.sakBases = X.saiNbases;
+    HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: keys beside the suffix array: %.1f GB, built in %.0f ms\n", need / 1e9, ms);
+    return 0;
+}
+
 static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
     memset(&X, 0, sizeof(X));
@@ -252,7 +291,8 @@ static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_pa
         rc = devAlloc(c->indexAllocs, &d, nW); if (rc) return rc;
         HIPCHK(hipMemset(d, 0, nW * 8)); HIPCHK(hipMemcpy(d, g->SAi, g->nSAibyte, hipMemcpyHostToDevice)); X.SAi = d;
     }
-    return uploadTables(c, g, p);
+    const int rc = uploadTables(c, g, p);
+    return rc ? rc : buildSak(c);
 }
 
 
@@ -502,6 +542,7 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
     HIPCHK(hipDeviceSynchronize());
     using namespace staridx;
     DevIndex &X = c->X;
+    dropSak(c);                                        // (the keys describe the old suffix array, and the insertion wants the memory: rebuilt below)
     HipBackend be; be.s = c->stream;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, be.s);
     SjdbParams P; P.nGenomeOld = X.nGenome; P.nGenomeReal = a->nGenomeReal; P.nSAold = X.nSA; P.GstrandBit = X.strandBit;
@@ -524,13 +565,14 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); res->msTotal = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (be.tmp) (void)hipFree(be.tmp);
-    if (rc) { if (R.dSApacked) (void)hipFree(R.dSApacked); if (R.dGnew) (void)hipFree(R.dGnew); if (R.dSAiPacked) (void)hipFree(R.dSAiPacked); return rc; }
+    if (rc) { if (R.dSApacked) (void)hipFree(R.dSApacked); if (R.dGnew) (void)hipFree(R.dGnew); if (R.dSAiPacked) (void)hipFree(R.dSAiPacked); (void)buildSak(c); refreshSharers(c); return rc; }
     // the new arrays take the place of the old ones
     dropAlloc(c->indexAllocs, X.G - GPAD); dropAlloc(c->indexAllocs, X.SA); dropAlloc(c->indexAllocs, X.SAi);
     c->indexAllocs.push_back(R.dGnew); c->indexAllocs.push_back(R.dSApacked); c->indexAllocs.push_back(R.dSAiPacked);
     X.G = R.dGnew + GPAD; X.SA = R.dSApacked; X.SAi = R.dSAiPacked;
     X.nGenome = R.nGenomeNew; X.nSA = R.nSAnew;
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
+    { const int rcK = buildSak(c); if (rcK) return rcK; }
     refreshSharers(c);
     return STARAMD_OK;
 }
@@ -562,11 +604,11 @@ extern "C" int staramd_update_tables(staramd_ctx *c, const staramd_genome *g, co
     HIPCHK(hipDeviceSynchronize());
     DevIndex &X = c->X;
     if (g->nGenome != X.nGenome || g->nSA != X.nSA) { g_err = "staramd_update_tables: the resident arrays belong to another index (nGenome / nSA differ)"; return STARAMD_ERR_ARG; }
-    const void *keep[3] = {X.G - GPAD, X.SA, X.SAi};
+    const void *keep[4] = {X.G - GPAD, X.SA, X.SAi, X.SAK};
     std::vector<void *> kept;
-    for (void *q : c->indexAllocs) { if (q == keep[0] || q == keep[1] || q == keep[2]) kept.push_back(q); else (void)hipFree(q); }
+    for (void *q : c->indexAllocs) { if (q == keep[0] || q == keep[1] || q == keep[2] || (keep[3] && q == keep[3])) kept.push_back(q); else (void)hipFree(q); }
     c->indexAllocs.swap(kept);
-    const int rc = uploadTables(c, g, p);
+    const int rc = uploadTables(c, g, p);          // (X.SAK / sakBases stay: same genome, same suffix array; uploadTables copies X to the device)
     refreshSharers(c);
     return rc;
 }

@@ -40,11 +40,68 @@ __device__ __forceinline__ u64 comp8(u64 x) {
     return x ^ (0x0303030303030303ull & ~(ge4 * 0xFFull));
 }
 
+// ---- keys beside the suffix array (DevIndex::SAK, built at upload by k_sak_build below) ----------------------------------------------------------------------------
+// A probe of the bisection reads a suffix-array entry and then the genome AT that entry: two dependent random gathers, two 64-byte sectors for 8 + a few bytes.  The
+// companion array holds, per entry, the entry itself and beside it -- in the same 16 bytes -- the 32 bases of its suffix that follow the SAindex prefix (all suffixes of a
+// search share that prefix), 2 bits per base in the order the compare walks them, with the number of bases before the first non-ACGT code in the spare top bits of the
+// entry word.  The piece's own bases at the same offsets are packed once per search (QKey).  A probe then is ONE gather: XOR of the two keys, first differing pair = the
+// match length and the order -- unless all 32 bases agree (then the genome decides, from offset prefix + 32 on).  Suffixes that differ from the piece within 46 bases are
+// most probes of most searches.  Results are unchanged: the key is the genome's own text (k_sak_build), compared by the same rule.
+struct alignas(16) SakRec { u64 w0, key; };
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+struct QKey { u64 key; u32 valid; };       // bases P0 .. P0+31 of the piece in scan order (complemented for a backward scan); valid = how many before the piece ends / a non-ACGT code
+__device__ __forceinline__ u64 pack8to16(u64 x) {       // 8 codes 0..3, one per byte -> 16 bits, first byte lowest
+    u64 z = x & 0x0303030303030303ull;
+    z = (z | (z >> 6)) & 0x000F000F000F000Full;
+    z = (z | (z >> 12)) & 0x000000FF000000FFull;
+    return (z | (z >> 24)) & 0xFFFFull;
+}
+__device__ __forceinline__ QKey makeQKey(const DevIndex &X, const u8 *R, u32 S, u32 N, bool dirR) {
+    QKey q; q.key = 0; q.valid = 0;
+    const u32 P0 = X.sakBases;
+    if (X.SAK == nullptr || N <= P0) return q;
+    u32 valid = 32;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        u64 raw = dirR ? load8(R + S + P0 + 8u * j) : load8rev(R + S - P0 - 8u * j);
+        const u64 bad = raw & 0xFCFCFCFCFCFCFCFCull;
+        if (bad && valid == 32) valid = 8u * j + ((u32)__builtin_ctzll(bad) >> 3);
+        if (!dirR) raw ^= 0x0303030303030303ull;                                          // 3 - base (codes above 3 lie behind `valid`)
+        q.key |= pack8to16(raw) << (16u * j);
+    }
+    q.valid = min(valid, N - P0);
+    return q;
+}
+
 // SuffixArrayFuns.cpp:10-104 -- the four read/genome direction variants folded into one loop, 8 bases per step:
 // read and genome are both 1 byte/base, so a step is two 8-byte words, one XOR and a count-trailing-zeros
-__device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, u32 N, u32 L, u64 iSA, bool dirR, bool &compRes, SeedCnt &cn) {
+__device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, u32 N, u32 L, u64 iSA, bool dirR, bool &compRes, SeedCnt &cn, const QKey &qk) {
     cn.nSAprobe++;
-    u64 SAstr = packedGet(X.SA, iSA, X.saBits, X.saMask);
+    u64 SAstr;
+    if (X.SAK) {
+        const u64x2 rec = GLOBAL(u64x2, X.SAK)[iSA];                    // one 16-byte gather
+        const u64 w0 = rec.x, tkey = rec.y;
+        SAstr = w0 & X.saMask;
+        const u32 P0 = X.sakBases;
+        if (L >= P0 && L < P0 + 32u && N > P0) {
+            const u32 klen = (u32)(w0 >> 58), sh = L - P0, lim = min(min(klen, qk.valid), N - P0);        // (N: the caller's bound, which may be shorter than the piece)
+            u64 d = tkey ^ qk.key;
+            d = (d | (d >> 1)) & 0x5555555555555555ull & ~((1ull << (2u * sh)) - 1ull);
+            const u32 k = d ? ((u32)__builtin_ctzll(d) >> 1) : 32u;
+            if (k < lim) {                                                    // the first base that differs lies inside both keys
+                cn.nGcmp += k + 1u - sh;
+                compRes = ((qk.key >> (2u * k)) & 3ull) > ((tkey >> (2u * k)) & 3ull);
+                return P0 + k;
+            }
+            if (lim >= sh) cn.nGcmp += lim - sh;
+            if (lim == N - P0) return N;                                      // the piece ends inside the key: all of it matches
+            if (!(lim == qk.valid && lim < 32u)) {                            // (a non-ACGT code of the READ inside the key -- only the --seedSearchLmax leg: the genome path below decides)
+                if (lim < 32u) { compRes = false; return P0 + lim; }           // the suffix meets a non-ACGT code of the genome: a mismatch there, the piece never sorts above it
+            }
+            L = P0 + lim;                                                     // all bases of the keys agree: on in the genome
+        }
+    } else
+    SAstr = packedGet(X.SA, iSA, X.saBits, X.saMask);
     bool dirG = (SAstr >> X.strandBit) == 0;
     SAstr &= X.strandMask;
     bool useComp = dirR != dirG;
@@ -82,26 +139,26 @@ __device__ static u32 compareSeqToGenome(const DevIndex &X, const u8 *R, u32 S, 
 // Which entries are probed on the way is an implementation detail (the result is a function of the interval and the piece); the probes here start every compare at the length
 // both ends of the current pair are known to share, as the reference's do.  IDX: offsets from `first` (u32 when the interval is shorter than 2^32 entries: half the registers).
 template <class IDX> struct LessSame { IDX less, same; u32 Lless; bool haveLess; };        // `less` matches Lless < the length `same` reaches; haveLess = false: nothing known, the interval's end
-template <class IDX> __device__ static IDX runEnd(const DevIndex &X, const u8 *R, u64 first, LessSame<IDX> p, u32 Lmax, u32 S, bool dirR, SeedCnt &cn) {
+template <class IDX> __device__ static IDX runEnd(const DevIndex &X, const u8 *R, u64 first, LessSame<IDX> p, u32 Lmax, u32 S, bool dirR, SeedCnt &cn, const QKey &qk) {
     bool above;
     if (!p.haveLess) return p.less;                             // (`less` then names the interval's own end, which reaches Lmax like everything up to `same`)
     while (((u64)p.less + 1 < (u64)p.same) | ((u64)p.less > (u64)p.same + 1)) {
         const IDX mid = (IDX)((u64)p.less / 2 + (u64)p.same / 2 + ((u64)p.less % 2 + (u64)p.same % 2) / 2);
-        const u32 Lm = compareSeqToGenome(X, R, S, Lmax, p.Lless, first + mid, dirR, above, cn);
+        const u32 Lm = compareSeqToGenome(X, R, S, Lmax, p.Lless, first + mid, dirR, above, cn, qk);
         if (Lm == Lmax) p.same = mid; else { p.less = mid; p.Lless = Lm; }
     }
     return p.same;
 }
-template <class IDX> __device__ static u64 mmpRunT(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 first, u64 last, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
+template <class IDX> __device__ static u64 mmpRunT(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 first, u64 last, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn, const QKey &qk) {
     bool above;                                                   // the piece sorts behind the entry just compared
     IDX lo = 0, hi = (IDX)(last - first);
-    u32 Llo = compareSeqToGenome(X, R, S, N, L, first + lo, dirR, above, cn);
-    u32 Lhi = compareSeqToGenome(X, R, S, N, L, first + hi, dirR, above, cn);
+    u32 Llo = compareSeqToGenome(X, R, S, N, L, first + lo, dirR, above, cn, qk);
+    u32 Lhi = compareSeqToGenome(X, R, S, N, L, first + hi, dirR, above, cn, qk);
     LessSame<IDX> left = {lo, lo, Llo, false}, right = {hi, hi, Lhi, false};
     IDX top = lo; u32 Lmax = 0; bool full = false;
     while ((u64)lo + 1 < (u64)hi) {
         const IDX mid = (IDX)((u64)lo / 2 + (u64)hi / 2 + ((u64)lo % 2 + (u64)hi % 2) / 2);
-        const u32 Lm = compareSeqToGenome(X, R, S, N, min(Llo, Lhi), first + mid, dirR, above, cn);
+        const u32 Lm = compareSeqToGenome(X, R, S, N, min(Llo, Lhi), first + mid, dirR, above, cn, qk);
         if (Lm == N) { top = mid; full = true; break; }
         if (above) { if (Lm > Llo) { left.less = lo; left.Lless = Llo; left.haveLess = true; left.same = mid; } lo = mid; Llo = Lm; }
         else       { if (Lm > Lhi) { right.less = hi; right.Lless = Lhi; right.haveLess = true; right.same = mid; } hi = mid; Lhi = Lm; }
@@ -110,13 +167,13 @@ template <class IDX> __device__ static u64 mmpRunT(const DevIndex &X, const u8 *
     // a side whose bracket end falls short of Lmax: the run begins between that end and `top`
     if (Llo < Lmax) { left.less = lo; left.Lless = Llo; left.haveLess = true; left.same = top; }
     if (Lhi < Lmax) { right.less = hi; right.Lless = Lhi; right.haveLess = true; right.same = top; }
-    const IDX r0 = runEnd<IDX>(X, R, first, left, Lmax, S, dirR, cn), r1 = runEnd<IDX>(X, R, first, right, Lmax, S, dirR, cn);
+    const IDX r0 = runEnd<IDX>(X, R, first, left, Lmax, S, dirR, cn, qk), r1 = runEnd<IDX>(X, R, first, right, Lmax, S, dirR, cn, qk);
     L = Lmax; ind0 = first + r0; ind1 = first + r1;
     return (u64)r1 - (u64)r0 + 1;
 }
-__device__ __forceinline__ u64 mmpRun(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn) {
-    if (i2 - i1 < 0xFFFFFFFFull) return mmpRunT<u32>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
-    return mmpRunT<u64>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn);
+__device__ __forceinline__ u64 mmpRun(const DevIndex &X, const u8 *R, u32 S, u32 N, u64 i1, u64 i2, bool dirR, u32 &L, u64 &ind0, u64 &ind1, SeedCnt &cn, const QKey &qk) {
+    if (i2 - i1 < 0xFFFFFFFFull) return mmpRunT<u32>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn, qk);
+    return mmpRunT<u64>(X, R, S, N, i1, i2, dirR, L, ind0, ind1, cn, qk);
 }
 
 struct SeedState {
@@ -204,8 +261,8 @@ __device__ __forceinline__ void searchOneDist(const DevIndex &X, const u8 *R, u3
     u64 i1;
     if (k.kind == 0) { Nrep = 0; i0 = 0; maxL = 0; }
     else if (k.kind == 1) { i0 = k.i1; Nrep = k.i2 - k.i1 + 1; maxL = k.maxL; }
-    else if (k.kind == 2) { i0 = k.i1; Nrep = 1; bool cr; maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, k.maxL, k.i1, dirR, cr, cn); }
-    else { maxL = k.maxL; Nrep = mmpRun(X, R, pieceStart, pieceLength, k.i1, k.i2, dirR, maxL, i0, i1, cn); }
+    else if (k.kind == 2) { i0 = k.i1; Nrep = 1; bool cr; const QKey qk = makeQKey(X, R, pieceStart, pieceLength, dirR); maxL = compareSeqToGenome(X, R, pieceStart, pieceLength, k.maxL, k.i1, dirR, cr, cn, qk); }
+    else { maxL = k.maxL; const QKey qk = makeQKey(X, R, pieceStart, pieceLength, dirR); Nrep = mmpRun(X, R, pieceStart, pieceLength, k.i1, k.i2, dirR, maxL, i0, i1, cn, qk); }
 }
 
 // ReadAlign_maxMappableLength2strands.cpp:5-115.  The reference keeps (Nrep, ind0, maxL) of every start offset of a sparse suffix
@@ -308,7 +365,9 @@ __device__ __forceinline__ void addCounters(DevBatch &B, const SeedCnt &cn) {
     }
 }
 #ifndef SEED_WAVES
-#define SEED_WAVES 8        // minimum waves per SIMD the register allocation is held to (8: 64 VGPRs + spills, 10 % faster than 4 at 1 Gb: more gather chains in flight)
+#define SEED_WAVES 7        // minimum waves per SIMD the register allocation is held to.  With the keys beside the suffix array (round 6) a probe is one gather and the stage needs
+                            // fewer chains in flight than it needs registers: same box, 3.1 Gb, ms per 400 k pairs: 8 (64 VGPRs, 67 spilled) 7.4, 7 (72, 33 spilled) 6.8, 6 (80, 28) 6.85
+                            // (profiles/r06_ab_session6_*); without the keys 8 was 10 % faster than 4 (round 3)
 #endif
 // the whole nest of one read on one lane: the general form (any number of pieces, start points and seeds per search).  Runs over the reads of `inList`
 // (B.cursors[CUR_OVF_SEED] of them: what the unit mapping below handed on), or over every read when inList is null (STARAMD_SEED_UNITS=0)
@@ -509,4 +568,28 @@ extern "C" __global__ void __launch_bounds__(256) k_seed_merge(const DevIndex *_
         if (lane == 0) B.reads[ir] = rd;
     }
     if (lane == 0 && nSeedsTot) atomicAdd((unsigned long long *)&B.counters[DC_nSeeds], (unsigned long long)nSeedsTot);
+}
+
+// ---- the companion array: per suffix-array entry {entry | bases-before-the-first-non-ACGT << 58, 32 bases of the suffix behind the SAindex prefix, 2 bits each} ------------
+// lane = entry.  The text of an entry of the reverse strand is the complement of the genome walked backwards -- what compareSeqToGenome's dirG = false branch compares against.
+extern "C" __global__ void __launch_bounds__(256) k_sak_build(const DevIndex *__restrict__ Xp, u64 *__restrict__ out_, u64 n0, u64 n1) {
+    SakRec *out = (SakRec *)out_;
+    const DevIndex &X = *Xp;
+    const u32 P0 = X.saiNbases;
+    for (u64 i = n0 + (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (u64)gridDim.x * blockDim.x) {
+        const u64 v = packedGet(X.SA, i, X.saBits, X.saMask);
+        const bool fwd = (v >> X.strandBit) == 0;
+        const u64 p = v & X.strandMask;
+        const u8 *g = fwd ? X.G + p + P0 : X.G + (X.nGenome - 1 - p) - P0;
+        u64 key = 0; u32 klen = 32;
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) {
+            u64 raw = fwd ? load8(g + 8u * j) : load8rev(g - 8u * j);
+            const u64 bad = raw & 0xFCFCFCFCFCFCFCFCull;
+            if (bad && klen == 32) klen = 8u * j + ((u32)__builtin_ctzll(bad) >> 3);
+            if (!fwd) raw ^= 0x0303030303030303ull;
+            key |= pack8to16(raw) << (16u * j);
+        }
+        SakRec r; r.w0 = v | ((u64)klen << 58); r.key = key; out[i] = r;
+    }
 }
