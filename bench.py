@@ -599,7 +599,7 @@ def main():
                     # sectors = counter bytes / 64: what HBM moves for gathers of 1-8 bytes; the rate against the measured dependent-gather ceiling of the session
                     e.update({"traffic_MB": round(hb / 1e6, 1), "traffic_over_alg": round(hb / max(kern[k][1], 1.0), 2), "Msectors": round(hb / 64e6, 1),
                               "Gsectors_s": round(hb / 64.0 / (kms[k] * 1e-3) / 1e9, 2), "of_gather_ceiling": (round(hb / 64.0 / (kms[k] * 1e-3) / 1e9 / ceiling, 3) if ceiling else None)})
-                for kk in ("valu_busy_frac", "waves_per_simd_resident", "scratch_bytes_per_lane", "vgprs"):
+                for kk in ("valu_busy_frac", "valu_busy_frac_simd32", "wave_instructions_per_read", "waves_per_simd_resident", "scratch_bytes_per_lane", "vgprs"):
                     if t.get(kk) is not None:
                         e[kk] = round(t[kk], 3) if isinstance(t[kk], float) else t[kk]
                 if k == dom:
@@ -619,7 +619,9 @@ def main():
                                % (mb, ginfo.get("junctions_in_index", 0), ginfo.get("index_bytes", 0) / 1e9, n_total, args.read_len, args.warmup, args.steps, args.reads),
                    "reads_per_gpu_per_step": args.reads, "genome_mb": mb, "host_threads_per_rank": threads, "cpus_online": os.cpu_count(), "cpus_usable": ncpu_eff, "engine_contexts_per_gpu": n_ctx // max(1, int(rep.nDevices)),
                    "parallelism": "reads sharded over %d GPU(s), one process per GPU, full index replica each" % world},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        # "bound": the roofline the path is priced against (integer gathers: HBM, no MFMA anywhere).  What the counters say limits the kernels is in "limited_by": none of them is
+        # anywhere near the HBM roof; they issue 0.2 - 0.3 wave-instructions per SIMD cycle out of chains of dependent gathers / LDS / scalar operations at 4 - 7 wavefronts per SIMD
+        "roofline": {"bound": "hbm", "limited_by": "instruction issue and dependent-access latency at 4-7 wavefronts per SIMD, not HBM bandwidth (per_kernel: valu_busy_frac, traffic_MB, of_gather_ceiling)", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "issue": issue, "kernel_ms": round(dms, 3), "algorithmic_bytes_per_launch": int(dbytes),
                      "per_kernel_ms": {k: round(kms[k], 2) for k in ("k_seed_search", "k_windows", "k_stitch_win", "device_total")},
                      "per_kernel": per_kernel,
@@ -677,7 +679,7 @@ def main():
     print(s, flush=True)
 
 
-PMC_TRAFFIC_FILE = "r05_pmc_hbm_traffic.json"
+PMC_TRAFFIC_FILE = "r06_pmc_hbm_traffic.json"
 
 
 def _cli_leg(argv, lread, env=None):

@@ -6,7 +6,7 @@ out = {}
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if not (k.startswith("k_") or "radix" in k or "scan" in k):
+        if not (k.startswith("k_") or "radix" in k or "scan" in k or k.startswith("chase")):       # chase: tools/gather_ceiling.hip (the calibration pass of tools/measure_session.sh)
             continue
         k = k.split("(")[0][:60]
         d = out.setdefault(k, {"dispatch_ids": set(), "counters": {}, "vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "lds": r.get("LDS_Block_Size"), "scratch": r.get("Scratch_Size")})

@@ -386,7 +386,7 @@ static int allocWork(staramd_ctx *c) {
     }
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 0); c->laneClass = envU32("STARAMD_LANE_CLASS", 3);          // (knobs are read here, once: not on the launch path)
+    c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 0); c->laneClass = envU32("STARAMD_LANE_CLASS", 0);          // (knobs are read here, once: not on the launch path)
     if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
     // first launch: 128 table rows + 512 owner-map slots = 6 KB of LDS per wavefront, 6 blocks of 4 wavefronts per CU (k_windows is held to 6 waves per SIMD)
     c->capW = envU32("STARAMD_CAP_WINDOWS", 128); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);
@@ -732,7 +732,10 @@ static int enqueueAll(staramd_ctx *c) {
         size_t ldsLean = c->leanDepth ? 4 * (readBytes + stitchStateBytesH(c->leanDepth, c->capRank, c->leanArena)) : 0;
         for (u32 mode = 0; mode < 2; mode++) {
             if (mode == 0 && c->laneBlocks && laneFits) {      // pass 0 in two launches: one LANE per read for the light reads of few seeds per window, the cooperative walk for the rest
-                hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, c->laneClass);
+                // highest cost class the lane kernel takes (STARAMD_LANE_CLASS; 0 = by the kind of reads): 3 for paired-end reads, 5 for single-end ones, whose windows are cheap enough for a lane up
+                // to there (same box, ms of the stitch stage per 400 k: 2x101 at 3.1 Gb 14.5 / 15.7 / 16.5 / 18.2 at 3 / 4 / 5 / 6; 1x50 at 12 Mb 37.3 / 32.3 / 33.3 / 35.0 at 3 / 5 / 6 / 7: profiles/r06_ab_session7_*)
+                const u32 laneClass = c->laneClass ? c->laneClass : (c->X.P.readNmates == 2 ? 3u : 5u);
+                hipLaunchKernelGGL(k_stitch_lane, dim3(c->laneBlocks), block, 256 * (size_t)ldsWords * 4, s, c->dX, B, c->scrLane, c->laneArenaBytes, ldsWords, prune, laneClass);
                 HIPCHK(hipEventRecord(c->ev[8], s));
                 if (c->mainDepth) {     // the cooperative walk in two launches: windows of up to mainDepth - 1 seeds at four blocks per CU, the few that hold more at full depth
                     const size_t ldsMain = 4 * (readBytes + stitchStateBytesH(c->mainDepth, c->capRank, c->arenaFast));

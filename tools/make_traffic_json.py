@@ -45,10 +45,12 @@ def main():
         if valu and t_ns:
             res[k]["valu_insts_per_launch"] = valu / nb; res[k]["salu_insts_per_launch"] = salu / nb
             res[k]["kernel_ms_per_launch_stats_pass"] = t_ns / nb / 1e6
-            res[k]["valu_busy_frac"] = valu * 4.0 / (t_ns * 1e-9 * 2.4e9 * 1024)
+            res[k]["valu_busy_frac"] = valu * 4.0 / (t_ns * 1e-9 * 2.4e9 * 1024)          # (4 cycles per wave64 instruction as in rounds 2-5, for the series; MI355X_MICROARCH.md gives 2 on the SIMD-32 of CDNA4: valu_busy_frac_simd32)
+            res[k]["valu_busy_frac_simd32"] = valu * 2.0 / (t_ns * 1e-9 * 2.4e9 * 1024)
+            res[k]["wave_instructions_per_read"] = (valu + salu) / nb / reads
     # static resources of the kernel that dominates each stage
     import re, subprocess
-    main_kernel = {"k_seed_search": ("k_seed", "k_seed_units", []), "k_windows": ("k_window", "k_windows", []), "k_stitch_win": ("k_stitch", "k_stitch_win", ["-fno-unroll-loops", "-DSTITCH_WAVES=3"])}
+    main_kernel = {"k_seed_search": ("k_seed", "k_seed_units", []), "k_windows": ("k_window", "k_windows", []), "k_stitch_win": ("k_stitch", "k_stitch_win", ["-fno-unroll-loops", "-DSTITCH_WAVES=4"])}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for k, (src, kern, extra) in main_kernel.items():
         try:
@@ -70,6 +72,19 @@ def main():
             res["k_stitch_win"]["waves_per_simd_resident_full_depth_launch"] = res["k_stitch_win"].get("waves_per_simd_resident"); res["k_stitch_win"]["waves_per_simd_resident"] = int(m.group(2))
     except Exception:
         pass
+    cal = os.path.join(d, "pmc_calib.summary.json")
+    if os.path.isfile(cal):
+        try:
+            cj = json.load(open(cal))
+            ck = [k for k in cj if k.startswith("chase")][0]
+            steps = 64                                                        # tools/measure_session.sh: gather_ceiling 16384 64; per lane count 1, 2, 4, 8 blocks per CU a warm-up launch of 16 steps + the timed one
+            gathers = 256 * 256 * (1 + 2 + 4 + 8) * (16 + steps)
+            fetch_bytes = cj[ck]["counters"]["FETCH_SIZE"] * 1024.0
+            res["fetch_size_calibration"] = {"pattern": "dependent random 8-byte gathers over a 16 GiB table (tools/gather_ceiling.hip), rocprofv3 --pmc FETCH_SIZE", "gathers": gathers,
+                                             "FETCH_SIZE_bytes": fetch_bytes, "FETCH_SIZE_bytes_per_gather": fetch_bytes / gathers,
+                                             "reading": "a random 8-byte gather moves one 64-byte sector from HBM; FETCH_SIZE_bytes_per_gather / 64 is what the counter reports of it -- divide the traffic figures of the gather-bound kernels by that ratio for absolute bytes"}
+        except Exception as e:
+            res["fetch_size_calibration"] = {"error": repr(e)[:200]}
     gc = os.path.join(d, "gather_ceiling.txt")
     if os.path.isfile(gc):
         for line in open(gc):
@@ -77,7 +92,7 @@ def main():
             if m:
                 res["gather_ceiling_Gsectors_s"] = float(m.group(1)); res["gather_ceiling_how"] = "tools/gather_ceiling 16384 MiB table, 524288 lanes in flight, same session"
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: (round(v["hbm_bytes_per_launch"] / 1e9, 2), round(v.get("valu_busy_frac", 0), 3)) for k, v in res.items() if isinstance(v, dict)}))
+    print(json.dumps({k: (round(v["hbm_bytes_per_launch"] / 1e9, 2), round(v.get("valu_busy_frac", 0), 3)) for k, v in res.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}))
 
 
 if __name__ == "__main__":

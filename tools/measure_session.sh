@@ -24,7 +24,10 @@ done
 cd $R
 # the dependent-gather ceiling of this box, this session (roofline.per_kernel.*.of_gather_ceiling)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/gather_ceiling.hip -o /tmp/gather_ceiling 2> /dev/null && timeout 120 /tmp/gather_ceiling 16384 256 > $O/gather_ceiling.txt 2>&1
-for d in pmc_sq1 pmc_sq2 pmc_sq3 pmc_tcp pmc_fetch pmc_write; do
+# calibration of FETCH_SIZE on this engine's own access pattern (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern"): the dependent random
+# 8-byte gathers of tools/gather_ceiling.hip under the same counter -- a known number of gathers, each of which moves one 64-byte sector
+cd /tmp; timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib -o c -- /tmp/gather_ceiling 16384 64 > $O/gather_ceiling_under_pmc.txt 2> $O/pmc_calib.err; cd $R
+for d in pmc_sq1 pmc_sq2 pmc_sq3 pmc_tcp pmc_fetch pmc_write pmc_calib; do
   f=$(find $O/$d -name "*counter_collection.csv" 2>/dev/null | head -1)
   [ -n "$f" ] && python profiles/pmc_summary.py $f > $O/$d.summary.json
 done
