@@ -98,6 +98,7 @@ FORCED = {
     "seed_lane_per_read": {"STARAMD_SEED_UNITS": "0"},         # the seed stage as one nest per lane (k_seed_search over every read) instead of lane = unit
     "seed_unit_pool_tiny": {"STARAMD_SEED_GROUPS_PER_READ": "1"},   # the group / unit pools hold less than half of the batch: the rest is handed on to k_seed_search
     "seed_one_slot_per_unit": {"STARAMD_SEED_SLOT_LIMIT": "1"},     # a unit that finds a second seed hands its read on
+    "no_sa_keys": {"STARAMD_SA_KEYS": "0"},                         # the seed stage probes the packed suffix array and the genome (what it does with a sparse suffix array, or when 16 bytes per suffix do not fit)
 }
 
 
