@@ -120,8 +120,14 @@ typedef struct staramd_params {
      *      Must be 0 when chimeric detection (chimSegmentMin > 0) wants the other windows.
      * Contract of 1: trBest, status, unmappedLength and every field of the RETURNED transcripts / exons are the reference's exactly; nW / nTr
      * count what is returned; maxScoreMate[] is 0 (see staramd_read_result) and the windows that cannot reach the selection threshold are not stitched at all
-     * (INTEGRATION.md "Which outputs are the reference's exactly").  A caller that needs trAll[][] or maxScoreMate[] themselves passes 0. */
+     * (INTEGRATION.md "Which outputs are the reference's exactly").  A caller that needs trAll[][] or maxScoreMate[] themselves passes 0.
+     *   2  chimeric detection with the partner chosen on the device (chimSegmentMinPositive 1): every window is stitched and recorded as under 0, the engine
+     *      runs the partner loop of ReadAlign::chimericDetectionOld (ReadAlign_chimericDetectionOld.cpp:50-108: best window against the heads of the other
+     *      windows and the other transcripts of its own) and returns what 1 returns plus the partner.  A read with a partner has STARAMD_ST_CHIM_PARTNER set;
+     *      then maxScoreMate[0] / [1] = chimScoreBest / chimScoreNext of that loop and unmappedLength = index of the partner (relative to trOffset) |
+     *      chimStr of the partner << 30.  Without the bit the loop found none (chimScoreBest 0).  Cuts the result copy of the chimeric configuration ~15x. */
     uint32_t resultSelect;
+    uint32_t chimSegmentMin, chimSegmentReadGapMax;   /* P.pCh.segmentMin, P.pCh.segmentReadGapMax: read by resultSelect 2 only */
 } staramd_params;
 
 /* ---- one batch of reads: what ReadAlign::oneRead prepares before calling mapOneRead
@@ -144,6 +150,7 @@ typedef struct staramd_batch {
 #define STARAMD_ST_FATAL_SEEDS_PER_READ  0x0100u  /* reference exits: storeAligns.cpp:46-51 */
 #define STARAMD_ST_TR_PER_READ_LIMIT     0x0200u  /* reference logs a WARNING and stops: stitchPieces.cpp:290-294 */
 #define STARAMD_ST_WINDOWS_LIMIT         0x0400u  /* alignWindowsPerReadNmax reached (silent in the reference)    */
+#define STARAMD_ST_CHIM_PARTNER          0x0800u  /* resultSelect 2: a chimeric partner was chosen (maxScoreMate[] / unmappedLength carry it, see staramd_params) */
 #define STARAMD_ST_SCRATCH_OVERFLOW      0x8000u  /* device work-space cap exceeded: results for this read invalid */
 
 typedef struct staramd_read_result {
@@ -238,7 +245,12 @@ int  staramd_update_tables(staramd_ctx *ctx, const staramd_genome *g, const star
  * (start, end) -- the order of the collapsed junction table it is built from.  stage 0 / 1 turn the check off again.
  * Only the two small arrays and the parameter block are uploaded; the index stays where it is. */
 int  staramd_set_novel_junctions(staramd_ctx *ctx, const uint64_t *start, const uint64_t *end, uint64_t n, uint32_t stage);
-/* Map one batch: replaces the per-read loop around ReadAlign::mapOneRead. */
+/* what this engine library can do beyond the base contract, a bit mask: STARAMD_CAP_CHIM_SELECT = staramd_params::resultSelect 2 */
+#define STARAMD_CAP_CHIM_SELECT 1u
+uint32_t staramd_capabilities(void);
+/* Map one batch: replaces the per-read loop around ReadAlign::mapOneRead.
+ * STARAMD_ERR_RESULT_OVERFLOW: r->trCount / r->exCount say what the batch needs; its results stay resident, and the next call with the SAME batch
+ * (same arrays, same reads) and larger result arrays copies them out without mapping anything again. */
 int  staramd_map_batch(staramd_ctx *ctx, const staramd_batch *b, staramd_results *r);
 /* Same, but the batch is taken from the copy already resident in HBM from the previous call with
  * identical geometry (bench: inputs resident before the timed region). */

@@ -42,6 +42,8 @@ int staramd_map_wait(staramd_ctx *ctx);
 int staramd_map_end(staramd_ctx *ctx, staramd_results *results, const staramd_batch *next);
 /* batches whose kernels were begun inside staramd_map_end, beside the copy of the results before them (tests and the front end's report) */
 uint64_t staramd_overlapped_batches(staramd_ctx *ctx);
+/* times the kernels of a batch were enqueued on this context -- a batch whose work space or result arrays were too small is counted as often as it ran (tests) */
+uint64_t staramd_launch_count(staramd_ctx *ctx);
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ void  sah_set_sjdb_device_fn(int (*fn)(int device, const staramd_sjdb_args *, st
  * (follow with staramd_update_tables instead of staramd_update_index); reading it clears it */
 void  sah_set_sjdb_resident_fn(int (*fn)(void *user, const staramd_sjdb_args *, staramd_sjdb_result *), void *user);
 void  sah_engines_ready(void *h);
+/* chimeric detection (--chimSegmentMin > 0, --chimMultimapNmax 0, no merging of overlapping mates): the engine runs the partner loop (staramd_params::resultSelect 2)
+ * instead of returning every transcript of every window.  Call before the engine contexts are created, when staramd_capabilities() has STARAMD_CAP_CHIM_SELECT;
+ * returns 1 when the run's parameters now say so, 0 when they do not qualify. */
+int   sah_chim_select_on_device(void *h);
 int   sah_index_in_engine(void *h);
 int   sah_generate_mode(void *h);
 int   sah_generate_buffers(void *h, const uint8_t **G, uint64_t *nGenome, uint32_t *GstrandBit, uint32_t *saIndexNbases,

@@ -49,6 +49,8 @@ int staramd_map_begin(staramd_ctx *, const staramd_batch *b) { g_inFlight = *b; 
 int staramd_map_wait(staramd_ctx *) { return 0; }
 int staramd_map_end(staramd_ctx *ctx, staramd_results *r, const staramd_batch *next) { const int rc = staramd_map_batch(ctx, &g_inFlight, r); if (rc == STARAMD_ERR_RESULT_OVERFLOW) return rc; if (next) g_inFlight = *next; return rc; }
 uint64_t staramd_overlapped_batches(staramd_ctx *) { return 0; }
+uint64_t staramd_launch_count(staramd_ctx *) { return 0; }
+uint32_t staramd_capabilities(void) { return 0; }      // (the restatement returns what staramd_params::resultSelect 0 / 1 ask for)
 uint64_t staramd_prefetch_hits(staramd_ctx *) { return 0; }
 int staramd_get_counters(staramd_ctx *, uint64_t *, int) { return 0; }
 // index build: the same algorithm code as the device build (star_amd/csrc/index/index_core.h) on the plain-loop backend of oracle/index_emul.cpp

@@ -65,6 +65,7 @@ class Params(C.Structure):
         ("outFilterMismatchNoverLmax", C.c_double),
         ("outFilterMatchNmin", C.c_uint32),
         ("resultSelect", C.c_uint32),
+        ("chimSegmentMin", C.c_uint32), ("chimSegmentReadGapMax", C.c_uint32),
     ]
 
 
@@ -206,6 +207,8 @@ def engine_lib():
         L.staramd_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.staramd_get_counters.restype = C.c_int
         L.staramd_get_counters.argtypes = [C.c_void_p, u64p, C.c_int]
+        if hasattr(L, "staramd_launch_count"):
+            L.staramd_launch_count.restype = C.c_uint64; L.staramd_launch_count.argtypes = [C.c_void_p]
         _engine = L
     return _engine
 

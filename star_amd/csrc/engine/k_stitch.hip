@@ -1286,6 +1286,73 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_verify(const DevIndex
     if (nReplay) atomicAdd((unsigned long long *)&B.counters[DC_nReplayWin], (unsigned long long)nReplay);
 }
 
+// ---- resultSelect 2: the partner loop of chimeric detection on the device (include/star_amd.h) --------------------------------------------------------------------------
+// ReadAlign_chimericDetectionOld.cpp:50-108 over the records of the pools: trBest against the head of every other window and the other transcripts of its own.  One lane
+// per read (k_stitch_finish); the arithmetic is the reference's (unsigned 64-bit read coordinates, the `roStart > readLength[0]` step over the mate spacer).
+struct ChimSel { i32 scoreBest, scoreNext; u32 strBest; u32 win, rank; bool have; };       // win: index among the read's windows (winOffset + win), rank inside it
+__device__ __forceinline__ u32 chimStrOf(const staramd_transcript &t) {                      // :40-46, :59-65
+    if (t.intronMotifs[1] == 0 && t.intronMotifs[2] == 0) return 0u;
+    return ((t.Str == 0) == (t.intronMotifs[1] > 0)) ? 1u : 2u;
+}
+// blocksOverlap.cpp:3-41 on two transcripts of the pools (ea / eb: their first exons)
+__device__ static u64 chimBlocksOverlap(const staramd_transcript &a, const staramd_exon *ea, const staramd_transcript &b, const staramd_exon *eb) {
+    u32 i1 = 0, i2 = 0; u64 n = 0;
+    while (i1 < a.nExons && i2 < b.nExons) {
+        const u64 rs1 = ea[i1].R, rs2 = eb[i2].R, re1 = rs1 + ea[i1].L, re2 = rs2 + eb[i2].L, gs1 = ea[i1].G, gs2 = eb[i2].G;
+        if (rs1 >= re2) i2++;
+        else if (rs2 >= re1) i1++;
+        else if (gs1 - rs1 != gs2 - rs2) { if (re1 >= re2) i2++; if (re2 >= re1) i1++; }
+        else { n += min(re1, re2) - max(rs1, rs2); if (re1 >= re2) i2++; if (re2 >= re1) i1++; }
+    }
+    return n;
+}
+__device__ static ChimSel chimSelectPartner(const staramd_params &P, const DevBatch &B, const DRead &rd, u32 ir, u32 bestWin) {
+    ChimSel c; c.scoreBest = 0; c.scoreNext = 0; c.strBest = 0; c.win = 0; c.rank = 0; c.have = false;
+    const u64 Lread = B.readOffset[ir + 1] - B.readOffset[ir], len0 = B.mate1Length[ir];
+    const DWinOut ob = B.wout[rd.winOffset + bestWin];
+    const staramd_transcript tb = B.trPool[ob.trOffset];
+    const staramd_exon *xb = B.exPool + ob.exOffset + tb.exonOffset;
+    const u32 nb = tb.nExons;
+    u64 roStart1 = tb.Str == 0 ? (u64)xb[0].R : Lread - xb[nb - 1].R - xb[nb - 1].L;
+    u64 roEnd1 = tb.Str == 0 ? (u64)xb[nb - 1].R + xb[nb - 1].L - 1 : Lread - xb[0].R - 1;
+    if (roStart1 > len0) roStart1--;
+    if (roEnd1 > len0) roEnd1--;
+    const u32 chimStr = chimStrOf(tb);
+    const u64 segMin = P.chimSegmentMin, gapMax = P.chimSegmentReadGapMax;
+    for (u32 w = 0; w < rd.nWin; w++) {
+        const DWinOut o = B.wout[rd.winOffset + w];
+        const u32 nt = w == bestWin ? o.nTr : min(o.nTr, 1u);                       // other windows: their head only (:52)
+        for (u32 k = (w == bestWin ? 1u : 0u); k < nt; k++) {                       // the best window: everything but trBest itself (:53)
+            const staramd_transcript t = B.trPool[o.trOffset + k];
+            if (t.intronMotifs[0] > 0) continue;
+            const u32 chimStr1 = chimStrOf(t);
+            if (chimStr != 0 && chimStr1 != 0 && chimStr != chimStr1) continue;
+            const staramd_exon *x = B.exPool + o.exOffset + t.exonOffset; const u32 ne = t.nExons;
+            u64 roStart2 = t.Str == 0 ? (u64)x[0].R : Lread - x[ne - 1].R - x[ne - 1].L;
+            u64 roEnd2 = t.Str == 0 ? (u64)x[ne - 1].R + x[ne - 1].L - 1 : Lread - x[0].R - 1;
+            if (roStart2 > len0) roStart2--;
+            if (roEnd2 > len0) roEnd2--;
+            const u64 chimOverlap = roStart2 > roStart1 ? (roStart2 > roEnd1 ? 0 : roEnd1 - roStart2 + 1) : (roEnd2 < roStart1 ? 0 : roEnd2 - roStart1 + 1);
+            const bool diffMates = (roEnd1 < len0 && roStart2 >= len0) || (roEnd2 < len0 && roStart1 >= len0);
+            if (!(roEnd1 > segMin + roStart1 + chimOverlap && roEnd2 > segMin + roStart2 + chimOverlap
+                  && (diffMates || ((roEnd1 + gapMax + 1) >= roStart2 && (roEnd2 + gapMax + 1) >= roStart1)))) continue;
+            const i32 chimScore = tb.maxScore + t.maxScore - (i32)chimOverlap;
+            u64 overlap1 = 0;
+            if (k > 0 && c.scoreBest > 0) {                                         // :84-88 (only ever non-zero for two transcripts of one window)
+                const DWinOut op = B.wout[rd.winOffset + c.win];
+                const staramd_transcript tp = B.trPool[op.trOffset + c.rank];
+                overlap1 = chimBlocksOverlap(tp, B.exPool + op.exOffset + tp.exonOffset, t, x);
+            }
+            if (chimScore > c.scoreBest) {
+                c.win = w; c.rank = k; c.have = true;
+                if (overlap1 == 0) c.scoreNext = c.scoreBest;
+                c.scoreBest = chimScore; c.strBest = chimStr1;
+            } else if (chimScore > c.scoreNext && overlap1 == 0) c.scoreNext = chimScore;
+        }
+    }
+    return c;
+}
+
 // ---- per read: totals, trBest, maxScoreMate (ReadAlign_stitchPieces.cpp:288-348) ----
 // alignTranscriptsPerReadNmax (:290-294) stops the reference's walk before window k when the transcripts recorded so
 // far reach the limit; windows < k do not depend on windows >= k, so the exact result is the prefix.
@@ -1316,24 +1383,33 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_finish(const DevIndex
     else if (P.resultSelect) {
         // staramd_params::resultSelect: return only what multMapSelect can pick (ReadAlign_multMapSelect.cpp:26-44):
         // per window the best-first prefix with maxScore + outFilterMultimapScoreRange >= trBest->maxScore
+        // (resultSelect 2: ... and the partner chimeric detection would choose -- the prefix of its window reaches up to it)
+        ChimSel cs; cs.have = false; cs.scoreBest = cs.scoreNext = 0; cs.strBest = 0; cs.win = cs.rank = 0;
+        if (P.resultSelect == 2u) {
+            u32 ordB = 0, winB = 0;
+            for (u32 iw = 0; iw < rd.nWin; iw++) { if (B.wout[rd.winOffset + iw].nTr == 0) continue; if ((i32)ordB == bestW) { winB = iw; break; } ordB++; }
+            cs = chimSelectPartner(P, B, rd, ir, winB);
+        }
         const int selMin = bestScore - P.outFilterMultimapScoreRange;
-        i32 bestOrd = -1; u32 ord = 0, kept = 0; nTr = 0; nEx = 0;
+        i32 bestOrd = -1; u32 ord = 0, kept = 0; nTr = 0; nEx = 0; u32 partnerIdx = 0;
         for (u32 iw = 0; iw < rd.nWin; iw++) {
             DWinOut o = B.wout[rd.winOffset + iw];
             if (o.nTr == 0) continue;
             u32 sel = 0, selEx = 0;
-            for (; sel < o.nTr; sel++) { const staramd_transcript &t = B.trPool[o.trOffset + sel]; if (t.maxScore < selMin) break; selEx += t.nExons; }
+            for (; sel < o.nTr; sel++) { const staramd_transcript &t = B.trPool[o.trOffset + sel]; if (t.maxScore < selMin && !(cs.have && cs.win == iw && sel <= cs.rank)) break; selEx += t.nExons; }
             if ((i32)ord == bestW) bestOrd = (i32)kept;
             ord++;
+            if (cs.have && cs.win == iw) partnerIdx = nTr + cs.rank;
             if (sel != o.nTr) { B.wout[rd.winOffset + iw].nTr = sel; B.wout[rd.winOffset + iw].nEx = selEx; }
             if (sel) { kept++; nTr += sel; nEx += selEx; }
         }
         nWt = kept; bestW = bestOrd;
+        if (cs.have) { rd.status |= STARAMD_ST_CHIM_PARTNER; M0 = cs.scoreBest; M1 = cs.scoreNext; rd.unmappedLength = partnerIdx | (cs.strBest << 30); }
     }
     rd.nWt = nWt; rd.nTr = nTr; rd.nEx = nEx; rd.bestW = bestW;
     // resultSelect 1: windows that cannot hold a selectable transcript are not walked, so the running maxima cover only some windows (and which ones depends on the order
     // wavefronts saw each other's bounds): the field is returned as 0, always (include/star_amd.h); resultSelect 0 returns ReadAlign::maxScoreMate[] exactly
-    if (P.resultSelect) M0 = M1 = 0;
+    if (P.resultSelect && !(rd.status & STARAMD_ST_CHIM_PARTNER)) M0 = M1 = 0;
     rd.maxScoreMate[0] = M0; rd.maxScoreMate[1] = M1;
     B.reads[ir] = rd;
     if (nTr) atomicAdd((unsigned long long *)&B.counters[DC_nTrOut], (unsigned long long)nTr);

@@ -27,12 +27,6 @@
 #include "dev.h"
 
 #define NOWIN 0xFFFFFFFFu
-#ifndef WIN_CACHE
-#define WIN_CACHE 1                 // the seed list of the window last assigned to stays in registers (assignAlignToWindow)
-#endif
-#ifndef WIN_UNIQ
-#define WIN_UNIQ 1                  // one-locus seeds converted and looked up together (windowsBody)
-#endif
 #ifdef STARAMD_PROFILE
 #define WPROF_T0() u64 wprof_t0_ = __builtin_readcyclecounter()
 #define WPROF_MARK(k) { u64 t1_ = __builtin_readcyclecounter(); wprof[k] += t1_ - wprof_t0_; wprof_t0_ = t1_; }
@@ -138,53 +132,23 @@ template <bool BIG> __device__ static int createExtendWindowsWithAlign(const Dev
     return 0;
 }
 
-// ---- the seed list of ONE window in registers (lane j = row j) --------------------------------------------------------------------------------------------------
-// assignAlignToWindow as the reference writes it reads the window's list, tests the new seed against every row and stores a shifted list: here a load of the rows, a store
-// and a wait for the store per seed, one dependent round trip after the other -- and the seeds of a read go to the same window again and again (both mates of a pair lie
-// in one window: ~12 one-locus seeds, one list).  So the list of the window that was assigned to last stays in registers, is edited there (a row moves to the next lane
-// with one DPP move per word) and is written back when another window's turn comes or pass B ends.  (WIN_CACHE=0: every assign through memory, A/B builds.)
-struct WList { u32 w, n; bool dirty, pending; DWA e; };        // w: window (NOWIN: none); n rows; dirty: registers newer than memory; pending: stores on their way
-__device__ __forceinline__ DWA rowFromLaneBelow(const DWA &e) { DWA r; const int *sw = (const int *)&e; int *d = (int *)&r;
-#pragma unroll
-    for (u32 i = 0; i < 6; i++) d[i] = __builtin_amdgcn_update_dpp(0, sw[i], 0x138, 0xf, 0xf, false);       // wave_shr:1 -- lane i takes the word of lane i - 1
-    return r; }
-__device__ __forceinline__ DWA rowFromLaneAbove(const DWA &e) { DWA r; const int *sw = (const int *)&e; int *d = (int *)&r;
-#pragma unroll
-    for (u32 i = 0; i < 6; i++) d[i] = __builtin_amdgcn_update_dpp(0, sw[i], 0x130, 0xf, 0xf, false);       // wave_shl:1 -- lane i takes the word of lane i + 1
-    return r; }
-static_assert(sizeof(DWA) == 24, "a seed-list row is six words");
-template <bool BIG> __device__ __forceinline__ void listFlush(WS<BIG> &s, WList &c, u32 lane) {
-    if (c.w != NOWIN && c.dirty) { DWA *A = s.arena + (u64)s.t.blk[c.w] * WA_MAX; if (lane < c.n) A[lane] = c.e; c.pending = true; }
-    c.dirty = false;
-}
-
 // ReadAlign_assignAlignToWindow.cpp:6-130 ; all arguments wave-uniform; lane j holds row j of the window's list
-template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X, WS<BIG> &s, WList &c, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
+template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X, WS<BIG> &s, u32 iW, u64 a1, u32 aLength, u32 aNrep, u32 aFrag, u32 aRstart, bool aAnchor, i32 sjA, u32 lane) {
     const staramd_params &P = X.P;
-    u32 lrec = s.t.lrec[iW];
+    u32 n = s.t.nwa[iW]; u32 lrec = s.t.lrec[iW];
     if (!aAnchor && aLength < lrec) return;
-    DWA &e = c.e;
-#if WIN_CACHE
-    if (c.w != iW)
-#endif
-    {
-        listFlush(s, c, lane);
-        c.w = NOWIN;
-        u32 b = s.t.blk[iW];
-        if (b == NOWIN) {
-            if (s.nBlocks >= s.capBlocks) { s.overflow = true; return; }
-            b = s.nBlocks++;
-            LOCKSTEP();                               // every lane has read blk[iW] (and counted the block) before lane 0 fills it in
-            if (lane == 0) s.t.blk[iW] = b;
-        }
-        if (c.pending) { tabFence(); c.pending = false; }
-        c.w = iW; c.n = s.t.nwa[iW];
-        e.gStart = 0; e.nrep = 0; e.L = 0; e.rStart = 0; e.sjA = 0; e.anchor = 0; e.iFrag = 0; e.pad[0] = e.pad[1] = 0;
-        if (lane < c.n) e = (s.arena + (u64)b * WA_MAX)[lane];
+    u32 b = s.t.blk[iW];
+    if (b == NOWIN) {
+        if (s.nBlocks >= s.capBlocks) { s.overflow = true; return; }
+        b = s.nBlocks++;
+        LOCKSTEP();                               // every lane has read blk[iW] (and counted the block) before lane 0 fills it in
+        if (lane == 0) s.t.blk[iW] = b;
     }
-    u32 n = c.n;
+    DWA *A = s.arena + (u64)b * WA_MAX;
     DWA nw; nw.gStart = a1; nw.nrep = aNrep; nw.L = (u16)aLength; nw.rStart = (u16)aRstart; nw.sjA = sjA; nw.anchor = aAnchor ? 1 : 0; nw.iFrag = (u8)aFrag; nw.pad[0] = nw.pad[1] = 0;
     bool have = lane < n;
+    DWA e; e.gStart = 0; e.nrep = 0; e.L = 0; e.rStart = 0; e.sjA = 0; e.anchor = 0; e.iFrag = 0; e.pad[0] = e.pad[1] = 0;
+    if (have) e = A[lane];
     {
         bool ov = have && aFrag == e.iFrag && e.sjA == sjA && a1 + e.rStart == e.gStart + aRstart
                   && ((aRstart >= e.rStart && aRstart < (u32)e.rStart + e.L) || (aRstart + aLength >= e.rStart && aRstart + aLength < (u32)e.rStart + e.L));
@@ -192,25 +156,23 @@ template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X
         if (m) {
             u32 iA = (u32)__ffsll((long long)m) - 1;
             u32 Lold = laneGet32(e.L, iA);
-            if (aLength > Lold) {                 // the longer seed takes the place of the one it overlaps, at the position its read start gives it (:52-80)
+            if (aLength > Lold) {
                 u64 m2 = __ballot(have && lane != iA && aRstart < e.rStart);
                 u32 iA0 = m2 ? (u32)__ffsll((long long)m2) - 1 : n;
                 if (iA0 > iA) --iA0;
-                if (iA0 < iA) { const DWA below = rowFromLaneBelow(e); if (lane > iA0 && lane <= iA) e = below; }          // rows iA0 .. iA-1 move up by one
-                else if (iA0 > iA) { const DWA above = rowFromLaneAbove(e); if (lane >= iA && lane < iA0) e = above; }     // rows iA+1 .. iA0 move down by one
-                if (lane == iA0) e = nw;
-                c.dirty = true;
+                if (iA0 < iA) { if (lane >= iA0 && lane < iA) A[lane + 1] = e; }
+                else if (iA0 > iA) { if (lane > iA && lane <= iA0) A[lane - 1] = e; }
+                if (lane == 0) A[iA0] = nw;
+                tabFence();
             }
             return;
         }
     }
-    if (n == P.seedPerWindowNmax) {               // a full window (:84-118): rare -- through memory
+    if (n == P.seedPerWindowNmax) {
         lrec = waveMin32((have && e.anchor != 1) ? (u32)e.L : s.Lread + 1);
         if (lane == 0) s.t.lrec[iW] = lrec;
-        if (lrec == s.Lread + 1) { s.tooMany = true; return; }
-        if (!aAnchor && aLength < lrec) return;
-        DWA *A = s.arena + (u64)s.t.blk[iW] * WA_MAX;
-        if (c.pending) { tabFence(); c.pending = false; }
+        if (lrec == s.Lread + 1) { s.tooMany = true; tabFence(); return; }
+        if (!aAnchor && aLength < lrec) { tabFence(); return; }
         bool keep = have && (e.anchor == 1 || e.L > lrec);
         u64 km = __ballot(keep);
         u32 pos = (u32)__popcll(km & ((1ull << lane) - 1ull));
@@ -219,19 +181,14 @@ template <bool BIG> __device__ static void assignAlignToWindow(const DevIndex &X
         if (lane == 0) s.t.nwa[iW] = n;
         tabFence();
         have = lane < n;
-        e.gStart = 0; e.nrep = 0; e.L = 0; e.rStart = 0; e.sjA = 0; e.anchor = 0; e.iFrag = 0; e.pad[0] = e.pad[1] = 0;
         if (have) e = A[lane];
-        c.n = n; c.dirty = false;                 // (memory and registers agree)
     }
     if (aAnchor || aLength > lrec) {
         u64 m3 = __ballot(have && aRstart < e.rStart);
         u32 iA = m3 ? (u32)__ffsll((long long)m3) - 1 : n;
-        const DWA below = rowFromLaneBelow(e);
-        if (lane > iA && lane <= n) e = below;
-        if (lane == iA) e = nw;
-        c.n = n + 1;
-        if (lane == 0) s.t.nwa[iW] = n + 1;
-        c.dirty = true;
+        if (have && lane >= iA) A[lane + 1] = e;
+        if (lane == 0) { A[iA] = nw; s.t.nwa[iW] = n + 1; }
+        tabFence();
     }
 }
 
@@ -363,34 +320,8 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         DSeed mySeed; { u32 *z = (u32 *)&mySeed; z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = 0; }
         u64 myA1 = 0;
         if (lane < nPre) { mySeed = PC[lane]; myA1 = packedGet(X.SA, mySeed.saStart, X.saBits, X.saMask); }
-        // Seeds of ONE locus outside the inserted junction sequences (12 of the 17 seeds of a pair) are converted here once, lane i = seed i -- strand flip, read
-        // start, chromosome of the bin -- instead of one seed per trip of the loops of pass A and pass B with one lane at work: myA1 becomes the converted locus,
-        // uInfo = 1 << 31 | strand << 30 | rStart as pass B wants it.  Both passes then take such a seed with three lane reads.  (WIN_UNIQ=0: A/B builds without.)
-        u32 uInfo = 0, uChr = 0;
-#if WIN_UNIQ
-        if (lane < nPre && mySeed.nrep == 1u) {
-            u64 a1 = myA1; u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-            const u32 aL = mySeed.L; u32 aR = mySeed.rStart;
-            if (mySeed.dir == 1 && aStr == 0) { aStr = 1; aR = s.Lread - (aL + aR); }
-            else if (mySeed.dir == 0 && aStr == 1) { aR = s.Lread - (aL + aR); a1 = X.nGenome - (aL + a1); }
-            else if (mySeed.dir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aL + a1); }
-            if (a1 < X.sjGstart) {
-                myA1 = a1; uInfo = 0x80000000u | (aStr << 30) | (aR & 0xFFFFu);
-                uChr = GLOBAL(u32, X.chrBin)[(u32)(a1 >> P.winBinNbits) >> P.winBinChrNbits];
-            }
-        }
-#endif
         // ---- pass A: anchors (ReadAlign_stitchPieces.cpp:41-93)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow; iP++) {
-#if WIN_UNIQ
-            const u32 xInfo = laneGet32(uInfo, iP < nPre ? iP : 0u);
-            if (iP < nPre && (xInfo & 0x80000000u)) {          // a seed converted above: its one locus goes straight into the replay
-                if (1u > P.winAnchorMultimapNmax) continue;
-                nSAenum++; nAnchorLoci++; nAnchorReplayed++;
-                createExtendWindowsWithAlign(X, s, laneGet64(myA1, iP), (xInfo >> 30) & 1u, laneGet32(uChr, iP), lane);
-                continue;
-            }
-#endif
             const DSeed sd = iP < nPre ? seedOfLane(mySeed, iP) : PC[iP];
             const u64 preA1 = laneGet64(myA1, iP < nPre ? iP : 0u);
             if (sd.nrep > P.winAnchorMultimapNmax) continue;
@@ -480,27 +411,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         nWindows += s.nW;
         WPROF_MARK(1);
         // ---- pass B: all seeds (:129-185)
-#if WIN_UNIQ
-        // the converted one-locus seeds look their windows up together (owner map only: the Bloom-filter form keeps them in the loop)
-        u32 uW = NOWIN;
-        const bool uniqB = s.ownMap && !s.overflow;
-        if (uniqB && (uInfo & 0x80000000u)) uW = ownLookup(s.bitmap, s.ownMask, (u32)(myA1 >> P.winBinNbits) * 2u + ((uInfo >> 30) & 1u));
-#endif
-        WList wl; wl.w = NOWIN; wl.n = 0; wl.dirty = false; wl.pending = false;
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooMany; iP++) {
-#if WIN_UNIQ
-            const u32 xInfo = laneGet32(uInfo, iP < nPre ? iP : 0u);
-            if (uniqB && iP < nPre && (xInfo & 0x80000000u)) {
-                nSAenum++;
-                const u32 w = laneGet32(uW, iP);
-                if (w == NOWIN) continue;
-                const u32 x3 = laneGet32(((const u32 *)&mySeed)[3], iP), x4 = laneGet32(((const u32 *)&mySeed)[4], iP);       // rStart | L << 16, dir | iFrag << 8
-                const u32 uL = x3 >> 16; const bool uAnchor = 1u <= P.winAnchorMultimapNmax;
-                if (!uAnchor && uL < s.t.lrec[w]) continue;
-                assignAlignToWindow(X, s, wl, w, laneGet64(myA1, iP), uL, 1u, (x4 >> 8) & 0xFFu, xInfo & 0xFFFFu, uAnchor, -1, lane);
-                continue;
-            }
-#endif
             const DSeed sd = iP < nPre ? seedOfLane(mySeed, iP) : PC[iP];
             const u64 preA1 = laneGet64(myA1, iP < nPre ? iP : 0u);
             u32 aNrep = sd.nrep, aFrag = sd.iFrag, aLength = sd.L, aDir = sd.dir;
@@ -511,18 +422,11 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 u32 binD = 0, binA = 0, lStr = 0; bool candD = false, candA = false;
                 if (lane < cnt) {
                     a1 = (aNrep == 1u && iP < nPre) ? preA1 : packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
-                    u32 aStr;
-#if WIN_UNIQ
-                    if (iP < nPre && (xInfo & 0x80000000u)) { aStr = (xInfo >> 30) & 1u; aRstart = xInfo & 0xFFFFu; }       // (converted above; here because the read has no owner map)
-                    else
-#endif
-                    {
-                        aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-                        aRstart = sd.rStart;
-                        if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
-                        else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
-                        else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
-                    }
+                    u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
+                    aRstart = sd.rStart;
+                    if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
+                    else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
+                    else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
                     if (a1 >= X.sjGstart) {
                         u64 a1D;
                         if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
@@ -559,15 +463,13 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                     u32 xsplit = laneGet32(split ? 1u : 0u, l);
                     u32 xr = laneGet32(aRstart, l), xlD = laneGet32(lD, l);
                     i32 xsj = xsplit ? (i32)laneGet32(isj, l) : -1;
-                    if (xwD != NOWIN) assignAlignToWindow(X, s, wl, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
-                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, wl, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
+                    if (xwD != NOWIN) assignAlignToWindow(X, s, xwD, laneGet64(a1, l), xlD, aNrep, aFrag, xr, aAnchor, xsj, lane);
+                    if (xwA != NOWIN && !s.tooMany && !s.overflow) assignAlignToWindow(X, s, xwA, laneGet64(a1A, l), laneGet32(lA, l), aNrep, aFrag, xr + xlD, aAnchor, xsj, lane);
                     if (s.tooMany || s.overflow) break;
                 }
                 WPROF_MARK(3);
             }
         }
-        listFlush(s, wl, lane);
-        if (wl.pending) tabFence();               // the emission below reads the lists
         if (s.winLimit) rd.status |= STARAMD_ST_WINDOWS_LIMIT;
         if (s.overflow) {
             if (lane == 0) {

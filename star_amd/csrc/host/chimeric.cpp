@@ -6,7 +6,8 @@
 //   ReadAlign::outputTranscriptCIGARp       source/ReadAlign_outputTranscriptCIGARp.cpp:4-68
 //   blocksOverlap                           source/blocksOverlap.cpp:3-41
 // Host post-map code.  The device returns every recorded transcript of every window for it (resultSelect 0,
-// chimSegmentMinPositive 1: stitchWindowAligns.cpp:247).
+// chimSegmentMinPositive 1: stitchWindowAligns.cpp:247) -- or, for chimericDetectionOld on an engine that can (resultSelect 2), runs the partner loop itself and
+// returns its outcome beside the transcripts multMapSelect can pick (k_stitch.hip chimSelectPartner).
 #include "host.h"
 #include <algorithm>
 #include <cstring>
@@ -223,6 +224,10 @@ bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadB
     if (trBest->intronMotifs[1] == 0 && trBest->intronMotifs[2] == 0) chimStr = 0;
     else if ((trBest->Str == 0) == (trBest->intronMotifs[1] > 0)) chimStr = 1;
     else chimStr = 2;
+    if (ra.pre) {             // the engine has run the loop below on all windows and returned its outcome with the partner (include/star_amd.h, resultSelect 2)
+        chimScoreBest = ra.pre->scoreBest; chimScoreNext = ra.pre->scoreNext; chimStrBest = ra.pre->strBest;
+        if (ra.pre->partner >= 0 && (uint32_t)ra.pre->partner < rr.nTr) { const staramd_transcript &t = T[ra.pre->partner]; load(trChim[1], t, r.ex + t.exonOffset); trChim1 = &t; }
+    } else
     // windows: consecutive transcripts with the same iW, best first
     for (uint32_t k0 = 0; k0 < rr.nTr;) {
         uint32_t k1 = k0;

@@ -90,9 +90,20 @@ template <class T> struct PinnedAlloc {
 };
 struct ResBuf {
     std::vector<staramd_read_result, PinnedAlloc<staramd_read_result>> reads; std::vector<staramd_transcript, PinnedAlloc<staramd_transcript>> tr; std::vector<staramd_exon, PinnedAlloc<staramd_exon>> ex; staramd_results res;
+    // what the batches of this run have needed per read so far (x 1024): a slot that is used for the first time starts there instead of learning it by an overflow of its own
+    // (--chimSegmentMin returns every transcript of every window: 32 per pair, 2 GB of page-locked memory per slot)
+    static std::atomic<uint64_t> &seenTr() { static std::atomic<uint64_t> v(0); return v; }
+    static std::atomic<uint64_t> &seenEx() { static std::atomic<uint64_t> v(0); return v; }
+    static void learn(uint64_t nReads, uint64_t trCount, uint64_t exCount) {
+        if (!nReads) return;
+        const uint64_t t = trCount * 1024 / nReads + 1, e = exCount * 1024 / nReads + 1;
+        for (uint64_t o = seenTr().load(); o < t && !seenTr().compare_exchange_weak(o, t); ) {}
+        for (uint64_t o = seenEx().load(); o < e && !seenEx().compare_exchange_weak(o, e); ) {}
+    }
     void size(uint64_t nReads) {
         if (reads.size() < nReads) reads.resize(nReads);
-        if (tr.size() < nReads * 4 + 4096) { tr.resize(nReads * 4 + 4096); ex.resize(tr.size() * 3); }
+        const uint64_t wantTr = std::max<uint64_t>(nReads * 4 + 4096, nReads * seenTr().load() / 1024 * 5 / 4 + 4096);
+        if (tr.size() < wantTr) { tr.resize(wantTr); ex.resize(std::max<uint64_t>(tr.size() * 3, nReads * seenEx().load() / 1024 * 5 / 4 + 4096)); }
         memset(&res, 0, sizeof(res));
         point();
     }
@@ -186,6 +197,9 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
     while (nOwners * perGpu > STARAMD_CLI_MAX_DEV) perGpu--;
     const int nDev = nOwners * perGpu;                       // contexts = mapper threads; context d belongs to owner d % nOwners
     rep.nDevices = nOwners; rep.nContexts = nDev; rep.genomeLoadSeconds = sah_genome_load_seconds(h);
+    // chimeric detection: the partner loop on the device when the engine can (the stand-ins of the CPU tests cannot) -- STARAMD_CHIM_ON_DEVICE=0: every transcript of every
+    // window comes back and the loop runs here, as in rounds 1 - 5
+    if ((staramd_capabilities() & STARAMD_CAP_CHIM_SELECT) && !(getenv("STARAMD_CHIM_ON_DEVICE") && atoi(getenv("STARAMD_CHIM_ON_DEVICE")) == 0)) { if (sah_chim_select_on_device(h) && getenv("STARAMD_VERBOSE")) fprintf(stderr, "star_amd: partner of chimeric detection chosen on the device (resultSelect 2)\n"); }
     std::vector<staramd_ctx *> ctx(nDev, nullptr);
     auto destroyAll = [&]() { for (int d = nDev - 1; d >= 0; d--) if (ctx[d]) { staramd_destroy(ctx[d]); ctx[d] = nullptr; } };      // sharers before their owners
     {
@@ -285,6 +299,9 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                 auto tp = Clock::now();
                 { StageCpu sc(1); const double a = plog.now(); if (!failed.load() && sah_convert_slot(h, m.slot, &m.b) < 0) fail(sah_error(h)); plog.add(1, m.seq, a, plog.now()); }
                 if (failed.load()) m.n = 0;                                      // still goes down the pipeline so that the slot and the sequence number are released
+                // a slot on its first way down the pipeline gets result arrays of the size the batches before it needed, here, beside the kernels of the batch ahead -- not on
+                // the mapper thread between two launches (page-locked memory: ~0.1 s per GB)
+                if (m.n > 0 && rb[m.slot].tr.size() < (uint64_t)m.n * ResBuf::seenTr().load() / 1024) rb[m.slot].size((uint64_t)m.n);
                 { std::lock_guard<std::mutex> l(statM); if (timedOn && m.n > 0) rep.convertBusy += since(tp); }
                 parsed.push(m);
             }
@@ -387,14 +404,16 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
                 if (!failed.load()) {
                     auto tm = Clock::now(); double msDev = 0; float stage[8] = {0}; uint64_t cnt[64] = {0};
                     auto mapInto = [&](const staramd_batch &bt, ResBuf &r, bool main) {
-                        if (r.reads.size() < bt.nReads || r.tr.empty()) r.size(std::max<uint64_t>(bt.nReads, 1024));
+                        if (r.reads.size() < bt.nReads || r.tr.empty() || r.tr.size() < bt.nReads * ResBuf::seenTr().load() / 1024) r.size(std::max<uint64_t>(bt.nReads, 1024));
                         staramd_results &res = r.res;
                         int e = staramd_map_batch(ctx[d], &bt, &res);
-                        if (e == STARAMD_ERR_RESULT_OVERFLOW) {          // more transcripts than the buffers hold -> grow and retry
+                        if (e == STARAMD_ERR_RESULT_OVERFLOW) {          // more transcripts than the buffers hold -> grow and ask again (the results are resident: the engine copies them, nothing is mapped twice)
+                            ResBuf::learn(bt.nReads, res.trCount, res.exCount);
                             r.tr.resize(res.trCount + res.trCount / 4 + 4096); r.ex.resize(res.exCount + res.exCount / 4 + 4096); r.point();
                             e = staramd_map_batch(ctx[d], &bt, &res);
                         }
                         if (!e) {
+                            ResBuf::learn(bt.nReads, res.trCount, res.exCount);
                             msDev += res.msTotalDevice;
                             if (main) { float s[8] = {0}; int k = staramd_get_timings(ctx[d], s, 8); for (int i = 0; i < k; i++) stage[i] += s[i]; uint64_t c[64] = {0}; int kc = staramd_get_counters(ctx[d], c, 64); for (int i = 0; i < kc; i++) cnt[i] += c[i]; }
                         }

@@ -378,7 +378,9 @@ struct ReadBatch;
 struct ChimTr { staramd_transcript t; staramd_exon ex[STARAMD_MAX_N_EXONS]; };
 struct ChimPair { ChimTr a1, a2; bool best; VarOverlap var1, var2; };   // var1/2: the SNVs under the two alignments as they were BEFORE the junction shift (what the reference's copies carry)   // the two segments, in read order; best = the top-scoring chimera of the read (the primary one in the BAM)
 // the recorded alignments of one read, window by window, best first in each: T[k].exonOffset indexes ex
-struct ReadAligns { const staramd_transcript *T; uint32_t nTr; const staramd_exon *ex; };
+// pre: the partner loop of chimeric detection was run by the engine (staramd_params::resultSelect 2) -- its outcome; partner = index into T, -1 none
+struct ChimPre { int32_t partner; int scoreBest, scoreNext; uint32_t strBest; };
+struct ReadAligns { const staramd_transcript *T; uint32_t nTr; const staramd_exon *ex; const ChimPre *pre = nullptr; };
 bool chimericDetectionOld(const RunParams &P, const GenomeIndex &gi, const ReadBatch &b, uint32_t ir, const ReadAligns &ra,
                           const staramd_transcript *trBest, uint64_t nTr, const staramd_transcript *trMult0, const staramd_transcript *trMult1, std::string &out,
                           std::vector<ChimPair> *bamOut = nullptr, const ReadBatch *nameBatch = nullptr, uint32_t nameIr = 0, const uint32_t *mateStart = nullptr);

@@ -428,6 +428,7 @@ std::string RunParams::parse(int argc, char **argv) {
         if (outSAMattrRG.empty() && hasRG) return "EXITING because of fatal PARAMETER error: --outSAMattributes contains RG tag, but --outSAMattrRGline is not set\nSOLUTION: re-run STAR with a valid read group parameter --outSAMattrRGline.\n";
     }
     if (peOverlapNbasesMin > 0 && (readFilesIn.size() == 2 || readFilesSAMmates == 2)) dev.resultSelect = 0;          // every alignment of the merged mates is cut back into a pair and re-scored (ReadAlign_peOverlapMergeMap.cpp:279-296)
+    dev.chimSegmentMin = (uint32_t)std::min<uint64_t>(chim.segmentMin, 0xFFFFFFFFull); dev.chimSegmentReadGapMax = (uint32_t)std::min<uint64_t>(chim.segmentReadGapMax, 0xFFFFFFFFull);
     if (chim.segmentMin > 0) { dev.chimSegmentMinPositive = 1; dev.resultSelect = 0; }      // every transcript of every window is needed (stitchWindowAligns.cpp:247)
     // ch marks chimeric alignments (never produced here) but the reference insists on BAM output for it (Parameters_samAttributes.cpp)
     attrHasCh = std::find(outSAMattrOrder.begin(), outSAMattrOrder.end(), "ch") != outSAMattrOrder.end();

@@ -998,7 +998,12 @@ std::string PostMap::processRange(const ReadBatch &b, const staramd_results &r, 
         else if (nTr > P.outFilterMultimapNmax) { st.unmappedMulti++; unmapType = 3; }
         // ---- chimericDetection (ReadAlign_oneRead.cpp:95-97; not in the 2nd stage of BySJout, ReadAlign_chimericDetection.cpp:23)
         if (chimJunction && nW > 0 && P.dev.outFilterBySJoutStage <= 1 && !peOvYes) {       // ReadAlign_oneRead.cpp:95-97
-            const ReadAligns ra{T, nTrAll, EX};
+            ReadAligns ra{T, nTrAll, EX};
+            ChimPre pre{-1, 0, 0, 0};
+            if (P.dev.resultSelect == 2) {              // the engine chose the partner (include/star_amd.h)
+                if (rr.status & STARAMD_ST_CHIM_PARTNER) { pre.partner = (int32_t)(rr.unmappedLength & 0x3FFFFFFFu); pre.strBest = rr.unmappedLength >> 30; pre.scoreBest = rr.maxScoreMate[0]; pre.scoreNext = rr.maxScoreMate[1]; }
+                ra.pre = &pre;
+            }
             chimRecord = false;
             if (P.chim.multimapNmax == 0) chimRecord = chimericDetectionOld(P, gi, b, ir, ra, trBest, nTr, nTr > 0 ? trMult[0].t : nullptr, nTr > 1 ? trMult[1].t : nullptr, *chimJunction, cpp);
             else if (trBest->maxScore <= (int)(rc.readLength[0] + rc.readLength[1]) - (int)P.chim.nonchimScoreDropMin)       // ReadAlign_chimericDetection.cpp:48

@@ -627,6 +627,14 @@ void sah_set_sjdb_device_fn(int (*fn)(int, const staramd_sjdb_args *, staramd_sj
 // the same on the arrays resident in the engine contexts (staramd_insert_junctions for every context): fn(user, args, result); the front end calls
 // sah_engines_ready once its contexts hold the index, and asks sah_index_in_engine after a phase change whether a re-upload is needed at all
 void sah_set_sjdb_resident_fn(int (*fn)(void *, const staramd_sjdb_args *, staramd_sjdb_result *), void *user) { staramd::setSjdbResidentFn(fn, user); }
+int sah_chim_select_on_device(void *h) {
+    Runner *r = (Runner *)h;
+    staramd::RunParams &P = r->P;
+    const bool mergedMates = P.peOverlapNbasesMin > 0 && P.dev.readNmates == 2;
+    if (!(P.chim.segmentMin > 0 && P.chim.multimapNmax == 0 && !mergedMates && P.dev.resultSelect == 0 && P.dev.chimSegmentMinPositive)) return 0;
+    P.dev.resultSelect = 2;
+    return 1;
+}
 void sah_engines_ready(void *h) {
     // every engine context holds the index now, and junction insertion runs on the resident arrays: the host copy of the suffix array (26 GB of a human
     // index, per process -- one process per GPU on a node) is not needed any more.  SAindex and genome stay (small; the SAM writer reads the genome)

@@ -91,6 +91,48 @@ def _compare_buffers(info, more, prefix):
         eng.close(); orc.close(); run.close()
 
 
+def test_result_arrays_too_small_then_copied_without_a_second_run(tmp_path, built):
+    """STARAMD_ERR_RESULT_OVERFLOW (include/star_amd.h): the call says what the batch needs, its results stay resident, and the same batch handed in again with
+    larger arrays gets them copied -- the same bytes as a call that had room at once, and no kernel runs a second time (the engine's launch counter does not move).
+    A DIFFERENT batch in the same host arrays is mapped, not answered from what is resident."""
+    import ctypes as C
+    if not refstar.have_ref():
+        pytest.skip("oracle/_ref/STAR missing (needed to build the index)")
+    info = prepare("pe101", str(tmp_path), need_ref=False)
+    argv = ["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "ro_"), "--gpuResultSelect", "All"] + info["extra"]
+    run = capi.HostRun(argv)
+    eng = _engine(run.genome, run.params)
+    try:
+        b = run.next_batch(1200)
+        n = b.nReads
+        full = capi.ResultBuffers(n, tr_cap=n * 400)
+        eng.map_batch(b, full)
+        want = full.as_bytes(n)
+        assert full.res.trCount > 64
+        launches0 = eng.L.staramd_launch_count(eng.ctx)
+        small = capi.ResultBuffers(n, tr_cap=64, ex_cap=64)
+        rc = eng.L.staramd_map_batch(eng.ctx, C.byref(b), C.byref(small.res))
+        assert rc == -3 and small.res.trCount == full.res.trCount and small.res.exCount == full.res.exCount
+        launches1 = eng.L.staramd_launch_count(eng.ctx)
+        assert launches1 == launches0 + 1
+        big = capi.ResultBuffers(n, tr_cap=n * 400)
+        rc = eng.L.staramd_map_batch(eng.ctx, C.byref(b), C.byref(big.res))
+        assert rc == 0 and big.as_bytes(n) == want
+        assert eng.L.staramd_launch_count(eng.ctx) == launches1, "the batch was mapped a second time"
+        # the overflow again, then another batch: mapped (the resident results are not handed out for it)
+        rc = eng.L.staramd_map_batch(eng.ctx, C.byref(b), C.byref(small.res))
+        assert rc == -3
+        b2 = run.next_batch(1200)
+        if b2 is not None:
+            n2 = b2.nReads
+            r2 = capi.ResultBuffers(n2, tr_cap=n2 * 400)
+            before = eng.L.staramd_launch_count(eng.ctx)
+            eng.map_batch(b2, r2)
+            assert eng.L.staramd_launch_count(eng.ctx) == before + 1
+    finally:
+        eng.close(); run.close()
+
+
 @pytest.fixture(scope="module")
 def sweep_data(tmp_path_factory, built):
     if not refstar.have_ref():

@@ -76,3 +76,26 @@ def test_clipped_single_on_gpu(tag, tmp_path, built):
 def test_wasp_in_pieces_on_gpu(tmp_path, built):
     """batch of 150 reads: the WASP re-mapping batch (several copies per read) is larger than the context and goes through in rebased pieces"""
     tcp.run_cli_case(GPU_CLI, "pe101", ["--waspOutputMode", "SAMtag", "--varVCFfile", "VCF", "--outSAMtype", "BAM", "Unsorted", "--outSAMattributes", "NH", "HI", "AS", "nM", "vA", "vG", "vW"], 150, tmp_path)
+
+
+@pytest.mark.parametrize("tag", ["pe", "se"])
+def test_chimeric_partner_chosen_on_the_device(tag, tmp_path, built):
+    """staramd_params::resultSelect 2: the partner loop of chimericDetectionOld in k_stitch_finish.  The stress sets of tests/test_chimeric.py (60 % chimeric fragments,
+    hundreds of junction lines) through the shipped binary, partner chosen on the device (default) and on the host (STARAMD_CHIM_ON_DEVICE=0): both equal to the reference,
+    and the device form returns a fraction of the transcripts"""
+    import subprocess
+    import test_chimeric as tch
+    info, d = tch._stress(tag, tmp_path)
+    ref = tcp.refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=info["extra"])
+    lines = lambda p: [l for l in open(p + "Chimeric.out.junction") if not l.startswith("# 2.7.11b")]
+    assert len(lines(ref)) >= 400
+    for on in ("1", "0"):
+        new = os.path.join(d, "cli%s_" % on)
+        p = subprocess.run([GPU_CLI, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", "700"] + info["extra"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, STARAMD_CHIM_ON_DEVICE=on, STARAMD_VERBOSE="1"), timeout=600)
+        assert p.returncode == 0, p.stderr[-1500:]
+        assert ("partner of chimeric detection chosen on the device" in p.stderr) == (on == "1"), p.stderr[-800:]
+        assert lines(ref) == lines(new)
+        assert tcp.refstar.sam_body_sorted(ref + "Aligned.out.sam") == tcp.refstar.sam_body_sorted(new + "Aligned.out.sam")
+        assert open(ref + "SJ.out.tab", "rb").read() == open(new + "SJ.out.tab", "rb").read()
+        assert tcp.refstar.final_log_counters(ref + "Log.final.out") == tcp.refstar.final_log_counters(new + "Log.final.out")

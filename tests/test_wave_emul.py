@@ -155,6 +155,22 @@ def test_front_end_two_pass_without_any_junction(more, tmp_path, emul_cli):
     run_cli_case(emul_cli, "se50", ["--twopassMode", "Basic"] + none + more + ["--readMapNumber", "60"], 40, tmp_path, env=SMALL)
 
 
+CHIM_FE = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"], 30),
+           ("pe150_chim", ["--chimSegmentMin", "20", "--chimOutJunctionFormat", "1", "--chimScoreDropMax", "30", "--chimScoreSeparation", "5", "--chimSegmentReadGapMax", "3"], 30),
+           ("se50", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--chimFilter", "None"], 120),
+           ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMainSegmentMultNmax", "1"], 40)]
+
+
+@pytest.mark.parametrize("name,more,n", CHIM_FE)
+@pytest.mark.parametrize("on_device", ["1", "0"])
+def test_front_end_chimeric_detection_partner_chosen_on_the_device(name, more, n, on_device, tmp_path, emul_cli):
+    """--chimSegmentMin > 0 through the shipped front end on the emulated engine: the partner loop of chimericDetectionOld runs in k_stitch_finish
+    (staramd_params::resultSelect 2; STARAMD_CHIM_ON_DEVICE=0: on the host over every transcript of every window, as before) -- Chimeric.out.junction, SAM,
+    SJ.out.tab against one reference run"""
+    from test_cli_pipeline import run_cli_case
+    run_cli_case(emul_cli, name, more + ["--readMapNumber", str(n)], 25, tmp_path, env=dict(SMALL, STARAMD_CHIM_ON_DEVICE=on_device))
+
+
 def test_front_end_two_contexts_on_one_device(tmp_path, emul_cli):
     """`--gpuDevices 0,0`: two engine contexts, two mapper threads (each OS thread runs its own emulated launches), batches emitted in input order;
     with the 1st-pass junctions inserted into BOTH contexts' resident arrays"""
