@@ -810,8 +810,8 @@ def bam_leg(args, idx, fq, run_dir, threads):
 def config5_leg(args, g, idx, log, chim_detection):
     """2x150, 1 % errors, 5 % chimeric pairs.  chim_detection False: default flags (chimeric detection off,
     /root/reference/source/parametersDefault:690): window pruning on, 301-base reads, 4 starts per mate -- multi-window stitching, extendAlign soft clips and
-    the "too short" path.  True: --chimSegmentMin 12, where chimeric detection wants EVERY transcript of every window (resultSelect 0, no window
-    pruning: stitchWindowAligns.cpp:245-247).  Same index (sjdbOverhang 100).  Parity against the reference on the first 200 k pairs: SAM multiset,
+    the "too short" path.  True: --chimSegmentMin 12, where chimeric detection wants EVERY transcript of every window (no window
+    pruning: stitchWindowAligns.cpp:245-247; the partner is chosen on the device, resultSelect 2, and what comes back is what multMapSelect can pick + the partner).  Same index (sjdbOverhang 100).  Parity against the reference on the first 200 k pairs: SAM multiset,
     SJ.out.tab, Log counters (+ Chimeric.out.junction)."""
     from oracle import refstar
     L = 150; nb, w = 4, 1
@@ -823,7 +823,7 @@ def config5_leg(args, g, idx, log, chim_detection):
     argv = ["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", os.path.join(rd, tag + "gpu_"), "--runThreadN", str(max(4, min(64, effective_cpus()))),
             "--gpuBatchReads", str(args.reads), "--benchWarmupReads", str(w * args.reads), "--readMapNumber", str(n_total)] + flags
     rep, d = _cli_leg(argv, 2 * L + 1)
-    d["workload"] = "%d pairs 2x%d, 1%% substitutions, 5%% chimeric pairs, %s" % (n_total, L, "--chimSegmentMin 12 (every transcript of every window returned, no window pruning)" if chim_detection else "default flags (chimeric detection off)")
+    d["workload"] = "%d pairs 2x%d, 1%% substitutions, 5%% chimeric pairs, %s" % (n_total, L, "--chimSegmentMin 12 (every window stitched and recorded, no window pruning; the partner loop of chimericDetectionOld on the device: staramd_params::resultSelect 2)" if chim_detection else "default flags (chimeric detection off)")
     ns = min(200000, n_total)
     p_new, p_ref = os.path.join(rd, tag + "gpuS_"), os.path.join(rd, tag + "ref_")
     rc, _ = _run_cli(["--runMode", "alignReads", "--genomeDir", idx, "--readFilesIn"] + fq + ["--outFileNamePrefix", p_new, "--runThreadN", "32", "--gpuBatchReads", str(args.reads), "--readMapNumber", str(ns)] + flags)
