@@ -27,6 +27,9 @@
 #include "dev.h"
 
 #define NOWIN 0xFFFFFFFFu
+#ifndef WIN_UNIQ
+#define WIN_UNIQ 1                  // one-locus seeds converted and looked up together (windowsBody)
+#endif
 #ifdef STARAMD_PROFILE
 #define WPROF_T0() u64 wprof_t0_ = __builtin_readcyclecounter()
 #define WPROF_MARK(k) { u64 t1_ = __builtin_readcyclecounter(); wprof[k] += t1_ - wprof_t0_; wprof_t0_ = t1_; }
@@ -307,9 +310,13 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         it = first32(it);
         if (it >= nItems) break;
         u32 ir = inList ? inList[it] : it;
-        DRead rd = B.reads[ir];
+        // (of the read's record only these three words are kept -- as scalars; the words the kernel changes are stored one by one at the end: the record itself would
+        // sit in 16 vector registers from here to there)
+        struct { u32 nSeeds, status; } rd;
+        rd.nSeeds = first32(B.reads[ir].nSeeds);
         if (rd.nSeeds == 0) continue;
-        const DSeed *PC = B.seedPool + rd.seedOffset;
+        rd.status = first32(B.reads[ir].status);
+        const DSeed *PC = B.seedPool + first32(B.reads[ir].seedOffset);
         s.nW = 0; s.nBlocks = 0; s.tooMany = false; s.winLimit = false; s.overflow = false;
         s.Lread = (u32)(B.readOffset[ir + 1] - B.readOffset[ir]);
         WPROF_T0();
@@ -320,8 +327,35 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         DSeed mySeed; { u32 *z = (u32 *)&mySeed; z[0] = z[1] = z[2] = z[3] = z[4] = z[5] = 0; }
         u64 myA1 = 0;
         if (lane < nPre) { mySeed = PC[lane]; myA1 = packedGet(X.SA, mySeed.saStart, X.saBits, X.saMask); }
+        // Seeds of ONE locus outside the inserted junction sequences (12 of the 17 seeds of a pair) are converted here once, lane i = seed i -- strand flip, read
+        // start, chromosome of the bin -- instead of one seed per trip of the loops of pass A and pass B with one lane at work: myA1 becomes the converted locus,
+        // uInfo = 1 << 31 | strand << 30 | x << 16 | rStart as pass B wants it, x = the chromosome in pass A, the window + 1 in pass B (14 bits: genomes of up to
+        // 16 383 sequences; others keep the loops).  Both passes then take such a seed with two lane reads.  (WIN_UNIQ=0: A/B builds without.)
+        u32 uInfo = 0;
+#if WIN_UNIQ
+        if (lane < nPre && mySeed.nrep == 1u && X.nChrReal < 0x3FFFu) {
+            u64 a1 = myA1; u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
+            const u32 aL = mySeed.L; u32 aR = mySeed.rStart;
+            if (mySeed.dir == 1 && aStr == 0) { aStr = 1; aR = s.Lread - (aL + aR); }
+            else if (mySeed.dir == 0 && aStr == 1) { aR = s.Lread - (aL + aR); a1 = X.nGenome - (aL + a1); }
+            else if (mySeed.dir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aL + a1); }
+            if (a1 < X.sjGstart) {
+                const u32 chr = GLOBAL(u32, X.chrBin)[(u32)(a1 >> P.winBinNbits) >> P.winBinChrNbits];
+                if (chr < 0x3FFFu) { myA1 = a1; uInfo = 0x80000000u | (aStr << 30) | (chr << 16) | (aR & 0xFFFFu); }
+            }
+        }
+#endif
         // ---- pass A: anchors (ReadAlign_stitchPieces.cpp:41-93)
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow; iP++) {
+#if WIN_UNIQ
+            const u32 xInfo = laneGet32(uInfo, iP < nPre ? iP : 0u);
+            if (iP < nPre && (xInfo & 0x80000000u)) {          // a seed converted above: its one locus goes straight into the replay
+                if (1u > P.winAnchorMultimapNmax) continue;
+                nSAenum++; nAnchorLoci++; nAnchorReplayed++;
+                createExtendWindowsWithAlign(X, s, laneGet64(myA1, iP), (xInfo >> 30) & 1u, (xInfo >> 16) & 0x3FFFu, lane);
+                continue;
+            }
+#endif
             const DSeed sd = iP < nPre ? seedOfLane(mySeed, iP) : PC[iP];
             const u64 preA1 = laneGet64(myA1, iP < nPre ? iP : 0u);
             if (sd.nrep > P.winAnchorMultimapNmax) continue;
@@ -411,7 +445,28 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         nWindows += s.nW;
         WPROF_MARK(1);
         // ---- pass B: all seeds (:129-185)
+#if WIN_UNIQ
+        // the converted one-locus seeds look their windows up together (owner map only: the Bloom-filter form keeps them in the loop); window + 1 takes the chromosome's place
+        const bool uniqB = s.ownMap && !s.overflow;
+        if (uniqB && (uInfo & 0x80000000u)) {
+            const u32 w = ownLookup(s.bitmap, s.ownMask, (u32)(myA1 >> P.winBinNbits) * 2u + ((uInfo >> 30) & 1u));
+            uInfo = (uInfo & 0xC000FFFFu) | ((w == NOWIN ? 0u : w + 1u) << 16);
+        }
+#endif
         for (u32 iP = 0; iP < rd.nSeeds && !s.overflow && !s.tooMany; iP++) {
+#if WIN_UNIQ
+            const u32 xInfo = laneGet32(uInfo, iP < nPre ? iP : 0u);
+            if (uniqB && iP < nPre && (xInfo & 0x80000000u)) {
+                nSAenum++;
+                const u32 w1 = (xInfo >> 16) & 0x3FFFu;
+                if (w1 == 0u) continue;
+                const u32 x3 = laneGet32(((const u32 *)&mySeed)[3], iP), x4 = laneGet32(((const u32 *)&mySeed)[4], iP);       // rStart | L << 16, dir | iFrag << 8
+                const u32 uL = x3 >> 16; const bool uAnchor = 1u <= P.winAnchorMultimapNmax;
+                if (!uAnchor && uL < s.t.lrec[w1 - 1u]) continue;
+                assignAlignToWindow(X, s, w1 - 1u, laneGet64(myA1, iP), uL, 1u, (x4 >> 8) & 0xFFu, xInfo & 0xFFFFu, uAnchor, -1, lane);
+                continue;
+            }
+#endif
             const DSeed sd = iP < nPre ? seedOfLane(mySeed, iP) : PC[iP];
             const u64 preA1 = laneGet64(myA1, iP < nPre ? iP : 0u);
             u32 aNrep = sd.nrep, aFrag = sd.iFrag, aLength = sd.L, aDir = sd.dir;
@@ -422,11 +477,18 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 u32 binD = 0, binA = 0, lStr = 0; bool candD = false, candA = false;
                 if (lane < cnt) {
                     a1 = (aNrep == 1u && iP < nPre) ? preA1 : packedGet(X.SA, sd.saStart + base + lane, X.saBits, X.saMask);
-                    u32 aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
-                    aRstart = sd.rStart;
-                    if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
-                    else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
-                    else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
+                    u32 aStr;
+#if WIN_UNIQ
+                    if (iP < nPre && (xInfo & 0x80000000u)) { aStr = (xInfo >> 30) & 1u; aRstart = xInfo & 0xFFFFu; }       // (converted above; here because the read has no owner map)
+                    else
+#endif
+                    {
+                        aStr = (u32)(a1 >> X.strandBit); a1 &= X.strandMask;
+                        aRstart = sd.rStart;
+                        if (aDir == 1 && aStr == 0) { aStr = 1; aRstart = s.Lread - (aLength + aRstart); }
+                        else if (aDir == 0 && aStr == 1) { aRstart = s.Lread - (aLength + aRstart); a1 = X.nGenome - (aLength + a1); }
+                        else if (aDir == 1 && aStr == 1) { aStr = 0; a1 = X.nGenome - (aLength + a1); }
+                    }
                     if (a1 >= X.sjGstart) {
                         u64 a1D;
                         if (sjAlignSplit(X, a1, aLength, a1D, lD, a1A, lA, isj)) {
@@ -473,18 +535,18 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
         if (s.winLimit) rd.status |= STARAMD_ST_WINDOWS_LIMIT;
         if (s.overflow) {
             if (lane == 0) {
-                if (big) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); B.reads[ir] = rd; }
+                if (big) { rd.status |= STARAMD_ST_SCRATCH_OVERFLOW; atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); B.reads[ir].status = rd.status; }
                 else if (mode == 2u) { u32 k = atomicAdd(&B.cursors[CUR_OVF_WIN2], 1u); B.ovfWin2[k] = ir; }
                 else { u32 k = atomicAdd(&B.cursors[CUR_OVF_WIN], 1u); B.ovfWin[k] = ir; nOvf++; }
             }
             continue;
         }
-        if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir] = rd; continue; }   // nW=0 (:76-80)
+        if (s.tooMany) { rd.status |= STARAMD_ST_TOO_MANY_ANCHORS | STARAMD_ST_NO_GOOD_WINDOW; if (lane == 0) B.reads[ir].status = rd.status; continue; }   // nW=0 (:76-80)
         // ---- emit windows that hold seeds, in window order
         u32 nOut = 0, nWA = 0; u32 est = 0, nMax = 0;
         for (u32 j = lane; j < s.nW; j += 64) { u32 n = s.t.nwa[j]; if (n > 0) { nOut++; nWA += n; est += 1u << min(n, 20u); nMax = max(nMax, n); } }
         for (int o = 32; o > 0; o >>= 1) { nOut += (u32)__shfl_xor((int)nOut, o, 64); nWA += (u32)__shfl_xor((int)nWA, o, 64); est += (u32)__shfl_xor((int)est, o, 64); nMax = max(nMax, (u32)__shfl_xor((int)nMax, o, 64)); }
-        rd.wtOffset = nMax;
+        u32 rdWinOffset = 0, rdNWin = 0;           // (what k_seed_* left there: 0, 0 -- classifyRead)
         if (nOut > 0) {
             // stitch work items: a light read (its walks are bounded by est = sum over windows of 2^seeds) is ONE item -- its
             // windows are walked in order by one wavefront, so maxScoreMate is carried exactly and nothing has to be
@@ -495,7 +557,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
             if (lane == 0) { wo = atomicAdd(&B.cursors[CUR_WIN], nOut); ao = atomicAdd(&B.cursors[CUR_WA], nWA); io = atomicAdd(&B.cursors[CUR_ITEM], nIt); }
             wo = first32(wo); ao = first32(ao); io = first32(io);
             if (wo + nOut > B.winCap || ao + nWA > B.waCap || io + nIt > B.winCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_WINPOOL); continue; }
-            rd.winOffset = wo; rd.nWin = nOut;
+            rdWinOffset = wo; rdNWin = nOut;
             const u32 ioRead = io;
             if (light && lane == 0) B.items[io] = 0x80000000u | ir;
             for (u32 j = 0; j < s.nW; j++) {
@@ -519,7 +581,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
             }
             nWAtot += nWA;
         }
-        if (lane == 0) B.reads[ir] = rd;
+        if (lane == 0) { DRead *out = &B.reads[ir]; out->status = rd.status; out->winOffset = rdWinOffset; out->nWin = rdNWin; out->wtOffset = nMax; }
         WPROF_MARK(4);
     }
     if (lane == 0) {
