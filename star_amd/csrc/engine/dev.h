@@ -243,6 +243,16 @@ __device__ __forceinline__ u32 waveSumU32(u32 v) {
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);                      // row_bcast:31
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
+// inclusive prefix sum over the lanes (the same six DPP steps; lane i gets v[0] + ... + v[i])
+__device__ __forceinline__ u32 waveScanInclU32(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);                      // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);                      // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);                      // row_shr:4 (banks 1-3)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);                      // row_shr:8 (banks 2-3) -> a scan inside every row of 16
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);                      // row_bcast:15: rows 1 and 3 add the total of the row before
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);                      // row_bcast:31: rows 2 and 3 add the total of the first half
+    return v;
+}
 // value of lane srcLane, srcLane wave-uniform
 __device__ __forceinline__ u32 laneGet32(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)srcLane)); }
 __device__ __forceinline__ u64 laneGet64(u64 v, u32 l) { return ((u64)laneGet32((u32)(v >> 32), l) << 32) | laneGet32((u32)v, l); }

@@ -27,6 +27,9 @@
 #include "dev.h"
 
 #define NOWIN 0xFFFFFFFFu
+#ifndef WIN_EMIT_LANES
+#define WIN_EMIT_LANES 1            // emission: windows of one or two seeds copied by a lane each (windowsBody)
+#endif
 #ifndef WIN_UNIQ
 #define WIN_UNIQ 1                  // one-locus seeds converted and looked up together (windowsBody)
 #endif
@@ -560,6 +563,41 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
             rdWinOffset = wo; rdNWin = nOut;
             const u32 ioRead = io;
             if (light && lane == 0) B.items[io] = 0x80000000u | ir;
+#if WIN_EMIT_LANES
+            // Windows in index order get consecutive places in the pools.  One window per trip of a loop means one dependent round trip per window (its rows come from
+            // the seed-list arena in global memory) -- twenty per pair, most of them for a window of one or two seeds.  So: lane = window; places by a prefix sum over the
+            // lanes; a window of one or two rows is copied by its own lane (all of them in ONE round trip), the few longer lists by the whole wavefront as before.
+            for (u32 j0 = 0; j0 < s.nW; j0 += 64) {
+                const u32 j = j0 + lane;
+                const u32 n = j < s.nW ? s.t.nwa[j] : 0u;
+                const u32 inclW = waveScanInclU32(n ? 1u : 0u), inclA = waveScanInclU32(n);
+                const u32 myW = wo + inclW - (n ? 1u : 0u), myA = ao + inclA - n, myI = io + inclW - (n ? 1u : 0u);
+                u32 m = 0, blk = 0;
+                if (n) { m = s.t.meta[j]; blk = s.t.blk[j]; }
+                if (n == 1u || n == 2u) {
+                    const DWA *A = s.arena + (u64)blk * WA_MAX;
+                    const DWA r0 = A[0]; DWA r1 = r0; if (n == 2u) r1 = A[1];
+                    B.waPool[myA] = r0; if (n == 2u) B.waPool[myA + 1u] = r1;
+                    const u8 mates = (u8)(((r0.iFrag == 0 || r1.iFrag == 0) ? 1u : 0u) | ((r0.iFrag != 0 || r1.iFrag != 0) ? 2u : 0u));
+                    DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = myA; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.mates = mates; B.winPool[myW] = d;
+                    if (!light) { B.items[myI] = myW; B.itemClass[myI] = (u8)min(n + 1u, 31u); }
+                }
+                for (u64 lm = __ballot(n > 2u); lm; lm &= lm - 1) {                     // the longer lists: lane = row
+                    const u32 l = firstLane(lm);
+                    const u32 xn = laneGet32(n, l), xm = laneGet32(m, l), xW = laneGet32(myW, l), xA = laneGet32(myA, l), xI = laneGet32(myI, l);
+                    const DWA *A = s.arena + (u64)laneGet32(blk, l) * WA_MAX;
+                    u8 fr = 0;
+                    if (lane < xn) { const DWA row = A[lane]; fr = row.iFrag; B.waPool[xA + lane] = row; }
+                    const u8 mates = (u8)((__ballot(lane < xn && fr == 0) ? 1u : 0u) | (__ballot(lane < xn && fr != 0) ? 2u : 0u));
+                    if (lane == 0) {
+                        DWin d; d.read = ir; d.chr = xm >> 2; d.waOffset = xA; d.nWA = (u16)xn; d.str = (u8)((xm >> 1) & 1u); d.mates = mates; B.winPool[xW] = d;
+                        if (!light) { B.items[xI] = xW; B.itemClass[xI] = (u8)min(xn + 1u, 31u); }
+                    }
+                }
+                const u32 totW = laneGet32(inclW, 63u), totA = laneGet32(inclA, 63u);
+                wo += totW; ao += totA; io += light ? 0u : totW;
+            }
+#else
             for (u32 j = 0; j < s.nW; j++) {
                 u32 n = s.t.nwa[j];
                 if (n == 0) continue;
@@ -574,6 +612,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 }
                 wo++; ao += n;
             }
+#endif
             if (light && lane == 0) {
                 // cost class of a light read = bits of its walk-size estimate (k_order_* sorts by it, k_stitch_lane takes the classes up to its cap)
                 const u32 cls = 32u - (u32)__clz((int)est);

@@ -246,6 +246,7 @@ int staramd_cli_main(int argc, char **argv, const staramd_cli_hooks *hooks, star
     // idle for 25 - 30 ms every few batches (rocprofv3 timeline, profiles/r04_timeline_*.txt)
     int extraSlots = 3; if (const char *e = getenv("STARAMD_EXTRA_SLOTS")) extraSlots = std::max(0, atoi(e));
     const int nSlots = std::min(24, 2 * nDev + 3 + extraSlots);
+    ResBuf::seenTr().store(0); ResBuf::seenEx().store(0);          // (what an earlier run in this process learned -- another data set, other flags -- does not size this one's arrays)
     std::vector<ResBuf> rb(nSlots), rbMerged(nSlots), rbWasp(nSlots);
     std::vector<ResBuf> piecePart(nDev);
     for (auto &r : rb) r.size(batchReads);
