@@ -27,6 +27,8 @@
 #include "dev.h"
 
 #define NOWIN 0xFFFFFFFFu
+static_assert(sizeof(DWin) == 16, "a window record is four words (emission stores it as such)");
+static_assert(sizeof(DWA) == 24 && offsetof(DWA, iFrag) == 21, "a seed-list row is three 8-byte words, iFrag in byte 21 (emission)");
 #ifndef WIN_EMIT_LANES
 #define WIN_EMIT_LANES 1            // emission: windows of one or two seeds copied by a lane each (windowsBody)
 #endif
@@ -576,10 +578,14 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                 if (n) { m = s.t.meta[j]; blk = s.t.blk[j]; }
                 if (n == 1u || n == 2u) {
                     const DWA *A = s.arena + (u64)blk * WA_MAX;
-                    const DWA r0 = A[0]; DWA r1 = r0; if (n == 2u) r1 = A[1];
-                    B.waPool[myA] = r0; if (n == 2u) B.waPool[myA + 1u] = r1;
-                    const u8 mates = (u8)(((r0.iFrag == 0 || r1.iFrag == 0) ? 1u : 0u) | ((r0.iFrag != 0 || r1.iFrag != 0) ? 2u : 0u));
-                    DWin d; d.read = ir; d.chr = m >> 2; d.waOffset = myA; d.nWA = (u16)n; d.str = (u8)((m >> 1) & 1u); d.mates = mates; B.winPool[myW] = d;
+                    // (rows as three 8-byte words each: a struct copy of 24 bytes went through scratch memory)
+                    const u64 *src = (const u64 *)A; u64 *dst = (u64 *)&B.waPool[myA];
+                    const u64 a0 = src[0], a1 = src[1], a2 = src[2], b0 = src[3 * (n - 1u)], b1 = src[3 * (n - 1u) + 1u], b2 = src[3 * (n - 1u) + 2u];
+                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                    if (n == 2u) { dst[3] = b0; dst[4] = b1; dst[5] = b2; }
+                    const u32 f0 = (u32)(a2 >> 40) & 0xFFu, f1 = (u32)(b2 >> 40) & 0xFFu;          // DWA::iFrag (byte 21 of a row)
+                    const u8 mates = (u8)(((f0 == 0 || f1 == 0) ? 1u : 0u) | ((f0 != 0 || f1 != 0) ? 2u : 0u));
+                    { uint4 dw; dw.x = ir; dw.y = m >> 2; dw.z = myA; dw.w = n | (((m >> 1) & 1u) << 16) | ((u32)mates << 24); *(uint4 *)&B.winPool[myW] = dw; }      // = DWin {read, chr, waOffset, nWA, str, mates}
                     if (!light) { B.items[myI] = myW; B.itemClass[myI] = (u8)min(n + 1u, 31u); }
                 }
                 for (u64 lm = __ballot(n > 2u); lm; lm &= lm - 1) {                     // the longer lists: lane = row
