@@ -27,7 +27,7 @@
 #include "dev.h"
 
 #define NOWIN 0xFFFFFFFFu
-static_assert(sizeof(DWin) == 16, "a window record is four words (emission stores it as such)");
+static_assert(sizeof(DWin) == 16, "a window record is two 8-byte words (emission stores it as such)");
 static_assert(sizeof(DWA) == 24 && offsetof(DWA, iFrag) == 21, "a seed-list row is three 8-byte words, iFrag in byte 21 (emission)");
 #ifndef WIN_EMIT_LANES
 #define WIN_EMIT_LANES 1            // emission: windows of one or two seeds copied by a lane each (windowsBody)
@@ -585,7 +585,7 @@ template <bool BIG> __device__ __forceinline__ void windowsBody(const DevIndex *
                     if (n == 2u) { dst[3] = b0; dst[4] = b1; dst[5] = b2; }
                     const u32 f0 = (u32)(a2 >> 40) & 0xFFu, f1 = (u32)(b2 >> 40) & 0xFFu;          // DWA::iFrag (byte 21 of a row)
                     const u8 mates = (u8)(((f0 == 0 || f1 == 0) ? 1u : 0u) | ((f0 != 0 || f1 != 0) ? 2u : 0u));
-                    { uint4 dw; dw.x = ir; dw.y = m >> 2; dw.z = myA; dw.w = n | (((m >> 1) & 1u) << 16) | ((u32)mates << 24); *(uint4 *)&B.winPool[myW] = dw; }      // = DWin {read, chr, waOffset, nWA, str, mates}
+                    { u64 *dw = (u64 *)&B.winPool[myW]; dw[0] = (u64)ir | ((u64)(m >> 2) << 32); dw[1] = (u64)myA | ((u64)(n | (((m >> 1) & 1u) << 16) | ((u32)mates << 24)) << 32); }      // = DWin {read, chr, waOffset, nWA, str, mates}
                     if (!light) { B.items[myI] = myW; B.itemClass[myI] = (u8)min(n + 1u, 31u); }
                 }
                 for (u64 lm = __ballot(n > 2u); lm; lm &= lm - 1) {                     // the longer lists: lane = row
