@@ -78,6 +78,8 @@ struct staramd_ctx {
     // window kernel: one wave per read; fast pass (table in LDS) + big pass (reference limits, table in global memory)
     // the batch whose results did not fit the caller's arrays (STARAMD_ERR_RESULT_OVERFLOW): they stay resident; the same batch handed in again is copied out, not mapped again
     const void *ovfBases = nullptr, *ovfOffsets = nullptr; u32 ovfReads = 0; u64 ovfMark = 0; float ovfMs[4] = {0, 0, 0, 0};
+    bool residentInsertKeepsKeys = false;          // staramd_insert_junctions_fits said yes with the keys resident
+    u64 *sakBuf = nullptr; u64 sakCapBytes = 0;   // the allocation behind DevIndex::SAK (kept across a junction insertion: freeing and allocating 100 GB costs seconds)
     u64 nLaunches = 0;                    // times the kernels of a batch were enqueued (staramd_launch_count: tests)
     u32 winBlocks = 0, winBlocksBig = 0; u8 *scrWin = nullptr, *scrWinBig = nullptr; u32 capW = 0, capBlocks = 0, capWBig = 0, capBlocksBig = 0;
     // middle pass of k_windows: the few reads with more windows than the first pass has LDS rows for get a larger LDS table, one wavefront per block
@@ -235,25 +237,38 @@ static int buildSjdbHash(staramd_ctx *c, const staramd_genome *g) {
 // device from the resident genome and suffix array (~1 s at 6.3e9 suffixes); skipped (the seed stage then probes the packed array and the genome, as before) when
 // STARAMD_SA_KEYS=0, with a sparse suffix array, or when the array would not leave `reserve` bytes of HBM for the work space.
 extern "C" __global__ void k_sak_build(const DevIndex *Xp, u64 *out, u64 n0, u64 n1);
-static void dropSak(staramd_ctx *c) {
+// keepAllocation: the keys are void (the suffix array is about to change) but their memory stays for the ones that follow -- hipFree + hipMalloc of 100 GB between the
+// passes of a 2-pass run cost 6.4 s (profiles/r06_two_pass_leg_*), the rebuild itself 0.46 s
+static void dropSak(staramd_ctx *c, bool keepAllocation = false) {
     DevIndex &X = c->X;
-    if (X.SAK) for (size_t i = 0; i < c->indexAllocs.size(); i++) if (c->indexAllocs[i] == X.SAK) { (void)hipFree(c->indexAllocs[i]); c->indexAllocs.erase(c->indexAllocs.begin() + i); break; }
+    if (c->sakBuf && !keepAllocation) {
+        for (size_t i = 0; i < c->indexAllocs.size(); i++) if (c->indexAllocs[i] == (void *)c->sakBuf) { (void)hipFree(c->indexAllocs[i]); c->indexAllocs.erase(c->indexAllocs.begin() + i); break; }
+        c->sakBuf = nullptr; c->sakCapBytes = 0;
+    }
     X.SAK = nullptr; X.sakBases = 0;
 }
 static int buildSak(staramd_ctx *c) {
     DevIndex &X = c->X;
-    dropSak(c);
+    const u64 needNow = X.nSA * 16ull;
+    dropSak(c, c->sakBuf && needNow <= c->sakCapBytes);
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
-    if (!envU32("STARAMD_SA_KEYS", 1) || X.sparseD != 1 || X.saBits > 58 || X.saiNbases == 0 || X.nSA == 0) return 0;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 0;
-    const u64 need = X.nSA * 16ull, reserve = (u64)envU32("STARAMD_SA_KEYS_RESERVE_GB", 48) << 30;
-    if ((u64)freeB < need + std::min<u64>(reserve, (u64)totalB / 4)) {
-        if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: no keys beside the suffix array: %.1f GB needed, %.1f GB free\n", need / 1e9, freeB / 1e9);
-        return 0;
+    if (!envU32("STARAMD_SA_KEYS", 1) || X.sparseD != 1 || X.saBits > 58 || X.saiNbases == 0 || X.nSA == 0) { dropSak(c); return 0; }
+    const u64 need = X.nSA * 16ull;
+    u64 *out = c->sakBuf;
+    if (!out) {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 0;
+        const u64 reserve = (u64)envU32("STARAMD_SA_KEYS_RESERVE_GB", 48) << 30;
+        if ((u64)freeB < need + std::min<u64>(reserve, (u64)totalB / 4)) {
+            if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: no keys beside the suffix array: %.1f GB needed, %.1f GB free\n", need / 1e9, freeB / 1e9);
+            return 0;
+        }
+        // room for the suffixes a junction insertion adds (2 x junctions x sjdbLength: 0.4e9 for a million junctions of 2 x 100 bases), so that the rebuild behind it fits
+        u64 cap = need + std::min<u64>(std::max<u64>(need / 8, 64ull << 20), 8ull << 30);
+        if ((u64)freeB < cap + std::min<u64>(reserve, (u64)totalB / 4)) cap = need;
+        if (hipMalloc((void **)&out, cap) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        c->indexAllocs.push_back(out); c->sakBuf = out; c->sakCapBytes = cap;
     }
-    u64 *out = nullptr;
-    if (hipMalloc((void **)&out, need) != hipSuccess) { (void)hipGetLastError(); return 0; }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, 0);
     const u64 chunk = 1ull << 30;                      // (grids of at most 2^30 lanes)
     for (u64 n0 = 0; n0 < X.nSA; n0 += chunk) {
@@ -261,9 +276,8 @@ static int buildSak(staramd_ctx *c) {
         hipLaunchKernelGGL(k_sak_build, dim3((u32)((n1 - n0 + 255) / 256)), dim3(256), 0, 0, (const DevIndex *)c->dX, out, n0, n1);
     }
     (void)hipEventRecord(e1, 0);
-    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(out); g_err = "k_sak_build failed"; return STARAMD_ERR_DEVICE; }
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { dropSak(c); g_err = "k_sak_build failed"; return STARAMD_ERR_DEVICE; }
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    c->indexAllocs.push_back(out);
     X.SAK = out; X.sakBases = X.saiNbases;
     HIPCHK(hipMemcpy(c->dX, &X, sizeof(DevIndex), hipMemcpyHostToDevice));
     if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: keys beside the suffix array: %.1f GB, built in %.0f ms\n", need / 1e9, ms);
@@ -273,6 +287,7 @@ static int buildSak(staramd_ctx *c) {
 static int uploadIndex(staramd_ctx *c, const staramd_genome *g, const staramd_params *p) {
     DevIndex &X = c->X;
     memset(&X, 0, sizeof(X));
+    c->sakBuf = nullptr; c->sakCapBytes = 0; c->residentInsertKeepsKeys = false;          // (a new index: whatever held the keys of the old one was freed with it)
     if (g->gSAsparseD < 1 || g->gSAsparseD > 8) { g_err = "genomeSAsparseD must be in 1..8"; return STARAMD_ERR_ARG; }
     if (g->gSAindexNbases > 16 || g->GstrandBit + 3 > 63) { g_err = "unsupported index geometry"; return STARAMD_ERR_ARG; }
     if (p->seedPerWindowNmax > WA_MAX || p->seedPerWindowNmax < 1) { g_err = "seedPerWindowNmax must be in 1..64 on the device (one lane per window seed)"; return STARAMD_ERR_ARG; }
@@ -545,7 +560,7 @@ extern "C" int staramd_insert_junctions(staramd_ctx *c, const staramd_sjdb_args 
     HIPCHK(hipDeviceSynchronize());
     using namespace staridx;
     DevIndex &X = c->X;
-    dropSak(c);                                        // (the keys describe the old suffix array, and the insertion wants the memory: rebuilt below)
+    dropSak(c, c->residentInsertKeepsKeys);            // (the keys describe the old suffix array: rebuilt below -- in the same memory when staramd_insert_junctions_fits found room beside them)
     HipBackend be; be.s = c->stream;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, be.s);
     SjdbParams P; P.nGenomeOld = X.nGenome; P.nGenomeReal = a->nGenomeReal; P.nSAold = X.nSA; P.GstrandBit = X.strandBit;
@@ -597,6 +612,7 @@ extern "C" int staramd_insert_junctions_fits(staramd_ctx *c, uint64_t maxJunctio
              + (2ull << 30);                                                    // sort temporaries, slack
     if (const char *e = getenv("STARAMD_SJDB_FITS_FREE_GB")) freeB = (size_t)(strtod(e, nullptr) * 1e9);      // (tests: pretend this much is free)
     if (getenv("STARAMD_VERBOSE")) fprintf(stderr, "staramd: resident junction insertion needs up to %.1f GB, %.1f GB free\n", need / 1e9, freeB / 1e9);
+    c->residentInsertKeepsKeys = (u64)freeB >= need;            // (free memory was asked for with the keys in place)
     return (u64)freeB >= need ? 1 : 0;
 }
 
