@@ -631,7 +631,8 @@ int sah_chim_select_on_device(void *h) {
     Runner *r = (Runner *)h;
     staramd::RunParams &P = r->P;
     const bool mergedMates = P.peOverlapNbasesMin > 0 && P.dev.readNmates == 2;
-    if (!(P.chim.segmentMin > 0 && P.chim.multimapNmax == 0 && !mergedMates && P.dev.resultSelect == 0 && P.dev.chimSegmentMinPositive)) return 0;
+    // (chimSegmentMinPositive is 0 during the 1st pass of a 2-pass run -- twoPassRunPass1.cpp:24 -- and comes back with the 2nd: the choice is made once, for the run)
+    if (!(P.chim.segmentMin > 0 && P.chim.multimapNmax == 0 && !mergedMates && P.dev.resultSelect == 0)) return 0;
     P.dev.resultSelect = 2;
     return 1;
 }

@@ -158,7 +158,8 @@ def test_front_end_two_pass_without_any_junction(more, tmp_path, emul_cli):
 CHIM_FE = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15"], 30),
            ("pe150_chim", ["--chimSegmentMin", "20", "--chimOutJunctionFormat", "1", "--chimScoreDropMax", "30", "--chimScoreSeparation", "5", "--chimSegmentReadGapMax", "3"], 30),
            ("se50", ["--chimSegmentMin", "12", "--chimJunctionOverhangMin", "12", "--chimFilter", "None"], 120),
-           ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMainSegmentMultNmax", "1"], 40)]
+           ("pe76_overlap", ["--chimSegmentMin", "10", "--chimJunctionOverhangMin", "10", "--chimMainSegmentMultNmax", "1"], 40),
+           ("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin", "15", "--twopassMode", "Basic"], 30)]      # (the 1st pass runs without chimeric detection, twoPassRunPass1.cpp:24)
 
 
 @pytest.mark.parametrize("name,more,n", CHIM_FE)
