@@ -172,3 +172,23 @@ def test_chimeric_stress_engine(tmp_path, built):
     info, d = _stress("pe", tmp_path)
     _compare_buffers(info, [], os.path.join(d, "x_"))
     _compare(info, d, lambda g, p: capi.Engine(g, p, device=0, max_reads=4096), min_lines=400)
+
+
+@pytest.mark.parametrize("more,want", [(["--chimSegmentMin", "15"], 1), (["--chimSegmentMin", "15", "--twopassMode", "Basic"], 1),
+                                        (["--chimSegmentMin", "15", "--chimMultimapNmax", "10"], 0), ([], 0),
+                                        (["--chimSegmentMin", "15", "--peOverlapNbasesMin", "10", "--chimOutType", "WithinBAM", "--outSAMtype", "BAM", "Unsorted"], 0)])
+def test_which_runs_ask_the_engine_for_the_partner(more, want, tmp_path, built):
+    """sah_chim_select_on_device (include/star_amd_host.h): staramd_params::resultSelect 2 for --chimSegmentMin > 0 with the default algorithm and no mate merging --
+    also when a 1st pass comes first (it runs without chimeric detection, the 2nd pass needs the choice made) -- and for nothing else"""
+    import ctypes as C
+    info = prepare("pe150_chim", str(tmp_path), need_ref=False)
+    run = capi.HostRun(["--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", str(tmp_path / "sel_")] + list(info["extra"]) + more)
+    try:
+        L = run.L
+        L.sah_chim_select_on_device.restype = C.c_int; L.sah_chim_select_on_device.argtypes = [C.c_void_p]
+        before = run.params.contents.resultSelect
+        assert L.sah_chim_select_on_device(run.h) == want
+        assert run.params.contents.resultSelect == (2 if want else before)
+        assert run.params.contents.chimSegmentMin == (15 if "--chimSegmentMin" in more else 0)
+    finally:
+        run.close()
