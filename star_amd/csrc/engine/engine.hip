@@ -97,7 +97,8 @@ struct staramd_ctx {
     u32 mainDepth = 0, stBlocksMain = 0;
     // lane-per-read stitcher (k_stitch_lane.hip): takes the light reads whose windows hold few seeds; the cooperative kernel gets the rest
     u32 laneBlocks = 0, laneArenaBytes = 0, laneClass = 3; u8 *scrLane = nullptr;
-    u32 prune = 7;                        // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first, bit 2 = single-mate leaves of two-mate windows skipped (5.6)
+    u32 prune = 15;                       // STARAMD_PRUNE: bit 0 = window pruning, bit 1 = two-mate windows of a light read first, bit 2 = single-mate leaves of two-mate windows skipped (5.6),
+                                          // bit 3 = pruning under resultSelect 2 as well: reads whose best alignment cannot be the main segment of a chimera (5.8)
     u32 ldsLimit = 65536;                 // dynamic LDS a block may ask for
     u32 kernelTurns = 0;                  // STARAMD_KERNEL_TURNS=1: the kernel phase of a batch is serialised over the contexts of a device (runDevice); off: measured no gain
     u32 *dTrBase = nullptr, *dExBase = nullptr, *dTotals = nullptr, *dBlockTot = nullptr;
@@ -404,7 +405,7 @@ static int allocWork(staramd_ctx *c) {
     }
     // ---- window kernel
     c->lightEst = envU32("STARAMD_LIGHT_EST", 65536);
-    c->prune = envU32("STARAMD_PRUNE", 7); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 0); c->laneClass = envU32("STARAMD_LANE_CLASS", 0);          // (knobs are read here, once: not on the launch path)
+    c->prune = envU32("STARAMD_PRUNE", 15); c->kernelTurns = envU32("STARAMD_KERNEL_TURNS", 0); c->laneClass = envU32("STARAMD_LANE_CLASS", 0);          // (knobs are read here, once: not on the launch path)
     if (prop.sharedMemPerBlock >= 16384) c->ldsLimit = (u32)std::min<size_t>(prop.sharedMemPerBlock, 65536);
     // first launch: 128 table rows + 512 owner-map slots = 6 KB of LDS per wavefront, 6 blocks of 4 wavefronts per CU (k_windows is held to 6 waves per SIMD)
     c->capW = envU32("STARAMD_CAP_WINDOWS", 128); c->capBlocks = envU32("STARAMD_CAP_WA_BLOCKS", 128);

@@ -926,9 +926,12 @@ __device__ static bool stitchWindow(StitchCtx &c, u32 lane, const DWin &win, con
 }
 
 // copy the window's recorded transcripts (trAll[iW1][0..nWinTr-1]) into the result pools; false on pool overflow
-template <bool BIG> __device__ static bool flushWindowImpl(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o) {
+// headChim: could the window's head be the main segment of a chimeric alignment -- the test chimericDetectionOld makes of trBest before it looks at any other window
+// (ReadAlign_chimericDetectionOld.cpp:19-26): segment long enough, unmapped space of chimSegmentMin bases at one end of the read, no non-canonical junction, one strand
+template <bool BIG> __device__ static bool flushWindowImpl(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o, u32 chimSegmentMin, u32 Lread, bool &headChim) {
     u32 nTr = wr.nWinTr, nEx = 0;
     o.trOffset = 0; o.nTr = 0; o.exOffset = 0; o.nEx = 0; o.headScore = 0; o.headGlen = 0;
+    headChim = false;
     if (nTr == 0) return true;
     for (u32 k = 0; k < nTr; k++) nEx += recT<BIG>(wr, k)->nExons;
     u32 to = 0, eo = 0;
@@ -937,6 +940,11 @@ template <bool BIG> __device__ static bool flushWindowImpl(const DevBatch &B, u3
     if (to + nTr > B.trCap || eo + nEx > B.exCap) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_TRPOOL); return false; }
     typename AS<BIG>::trp hd = recT<BIG>(wr, 0);
     o.trOffset = to; o.nTr = nTr; o.exOffset = eo; o.nEx = nEx; o.headScore = hd->maxScore; o.headGlen = hd->gLength;
+    if (chimSegmentMin) {
+        typename AS<BIG>::exp hx = (typename AS<BIG>::exp)((typename AS<BIG>::u8p)hd + REC_HDR); const u32 hn = hd->nExons;
+        headChim = hd->rLength >= chimSegmentMin && ((u32)hx[hn - 1].R + hx[hn - 1].L + chimSegmentMin <= Lread || hx[0].R >= chimSegmentMin)
+                   && hd->intronMotifs[0] == 0 && (hd->intronMotifs[1] == 0 || hd->intronMotifs[2] == 0);
+    }
     u32 eoff = 0;
     for (u32 k = 0; k < nTr; k++) {
         typename AS<BIG>::u64p s = (typename AS<BIG>::u64p)recT<BIG>(wr, k);
@@ -954,8 +962,8 @@ template <bool BIG> __device__ static bool flushWindowImpl(const DevBatch &B, u3
     return true;
 }
 
-__device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o) {
-    return wr.big ? flushWindowImpl<true>(B, lane, wr, o) : flushWindowImpl<false>(B, lane, wr, o);
+__device__ static bool flushWindow(const DevBatch &B, u32 lane, const WinRec &wr, DWinOut &o, u32 chimSegmentMin, u32 Lread, bool &headChim) {
+    return wr.big ? flushWindowImpl<true>(B, lane, wr, o, chimSegmentMin, Lread, headChim) : flushWindowImpl<false>(B, lane, wr, o, chimSegmentMin, Lread, headChim);
 }
 
 __device__ __forceinline__ void laneSetup(LDS u8 *mine, u32 capDepth, u32 capRank, LaneMem &m) {
@@ -1035,7 +1043,14 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
     // transcript is wanted (resultSelect == 0: chimeric detection, merged mates), with a positive genomic-length term or positive indel scores, and for reads that
     // could reach alignTranscriptsPerReadNmax.
     const i32 perJ = max(0, P.sjdbScore) + max(0, max(max(P.scoreGap, P.scoreGapNoncan), max(P.scoreGapGCAG, P.scoreGapATAC)));
-    const bool pruneOn = pass0 && P.resultSelect == 1 && !P.chimSegmentMinPositive && X.glStep <= 0 && (pruneEnable & 3u) != 0
+    // Chimeric detection with the partner chosen on the device (resultSelect 2) wants every window of a read -- IF the read's best alignment can be the main
+    // segment of a chimera at all: chimericDetectionOld tests trBest alone before it looks at another window (flushWindowImpl headChim), and most reads fail that test (their
+    // best alignment covers them end to end).  So such a run prunes like any other at first -- with every transcript recorded (stitchWindowAligns.cpp:247) the windows of a
+    // read do not depend on each other at all, what is returned for multMapSelect is exact -- and a light read whose best head passes the test is walked again, every
+    // window, nothing pruned (chimFull below).  Reads whose windows are separate work items are not pruned in such a run; single-mate leaves are never skipped in it (5.6).
+    const bool chimMode = P.resultSelect == 2u && P.chimSegmentMinPositive && P.chimSegmentMin > 0;
+    const bool pruneOn = pass0 && ((P.resultSelect == 1 && !P.chimSegmentMinPositive) || (P.resultSelect == 2u && (chimMode || !P.chimSegmentMinPositive) && (pruneEnable & 8u) != 0))
+                         && X.glStep <= 0 && (pruneEnable & 3u) != 0
                          && P.scoreDelOpen <= 0 && P.scoreDelBase <= 0 && P.scoreInsOpen <= 0 && P.scoreInsBase <= 0;
 #ifdef STARAMD_PROFILE
     for (int k = 0; k < 16; k++) c.prof[k] = 0;
@@ -1066,6 +1081,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
         // those are all skipped unwalked (sweep 1) -- the reasoning of the pruning note above holds for any order of the walked windows, because
         // all that order changes are maxScoreMate-dependent decisions about single-mate transcripts, none of which can be selected then.  If it
         // does not, nothing is kept: the read is walked again from scratch, every window in the reference's order (sweep 2).
+        bool chimFull = false;                          // chimMode: the read is walked a second time, in full (its best head can be the main segment of a chimera)
         u32 sweep = 2;
         if (wholeRead && pruneOn && sweepEnable && nWin > 1 && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax) {
             bool anyPair = false, anySingle = false;
@@ -1076,8 +1092,10 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             }
             if (anyPair && anySingle) sweep = 0;
         }
+        i32 runScore = 0; u64 runGlen = 0; bool runChim = false; u32 itemPruned = 0;      // chimMode: the read's best head so far by k_stitch_finish's rule, its test, windows not walked
         for (;;) {
-        if (sweep == 2) { carry[0] = carry[1] = 0; bestSoFar = 0; }
+        const bool pruneItem = pruneOn && !chimFull && (!chimMode || wholeRead);
+        if (sweep == 2) { carry[0] = carry[1] = 0; bestSoFar = 0; runScore = 0; runGlen = 0; runChim = false; itemPruned = 0; }
         // The windows of the item 64 at a time, lane k = window chunk + k: one load brings the rows of all of them (a read has ~20 windows of which ~3 are
         // walked: going through them one dependent load at a time cost more round trips than the walks), the windows that are skipped unwalked get their
         // empty result from their own lane in one store, and only the windows a sweep has to look at are visited.
@@ -1093,9 +1111,9 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             DWin win; { u32 *d = (u32 *)&win; const u32 *sw = (const u32 *)&myWin; d[0] = laneGet32(sw[0], il); d[1] = laneGet32(sw[1], il); d[2] = laneGet32(sw[2], il); d[3] = laneGet32(sw[3], il); }
             if (win.read != lastRead) { ctxLoadRead(c, lane, B, P, win.read); lastRead = win.read; }
             if (win.nWA + 1u > capDepth || win.nWA > WA_MAX) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-            if (!wholeRead && pruneOn) { nWinRead = first32(B.reads[win.read].nWin); maxSeedsRead = first32(B.reads[win.read].wtOffset); }
+            if (!wholeRead && pruneItem) { nWinRead = first32(B.reads[win.read].nWin); maxSeedsRead = first32(B.reads[win.read].wtOffset); }
             const i32 singleBar = pruneSingleBar(P, perJ, c.readLength[0], c.readLength[1], maxSeedsRead);
-            if (pruneOn && win.mates != 0 && sweep == 2) {
+            if (pruneItem && win.mates != 0 && sweep == 2) {
                 if (!wholeRead) bestSoFar = firstI(__hip_atomic_load(&B.reads[win.read].pruneBest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if ((u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax
                     && pruneWindow(P, perJ, win.mates, win.nWA, c.readLength[0], c.readLength[1], singleBar, bestSoFar)) { emptyM |= 1ull << il; continue; }
@@ -1115,7 +1133,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             // act on containment), so the window's two-mate records and its best score H come out as in the full walk.  If every single-mate transcript
             // of the read is then below the selection bar (singleBar < H, stitch_common.h), none of them can be returned or change what
             // is, and the walk stands; else the window is walked again in full.  Same conditions as the window pruning (resultSelect == 1 ...).
-            bool skipSingle = pruneOn && skipEnable && win.mates == 3u && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax;
+            bool skipSingle = pruneItem && !chimMode && skipEnable && win.mates == 3u && (u64)(nWinRead + 1u) * P.alignTranscriptsPerWindowNmax < P.alignTranscriptsPerReadNmax;
             bool ok = false;
             for (;;) {
                 u32 nSkipped = 0;
@@ -1141,10 +1159,12 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
                 break;
             }
             if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-            if (!flushWindow(B, lane, wr, o)) continue;
+            bool headChim = false;
+            if (!flushWindow(B, lane, wr, o, chimMode ? P.chimSegmentMin : 0u, c.Lread, headChim)) continue;
+            if (o.nTr && (o.headScore > runScore || (o.headScore == runScore && o.headGlen < runGlen))) { runScore = o.headScore; runGlen = o.headGlen; runChim = headChim; }
             o.mm[0] = c.maxScoreMate[0]; o.mm[1] = c.maxScoreMate[1];
             carry[0] = c.maxScoreMate[0]; carry[1] = c.maxScoreMate[1];
-            if (pruneOn && o.headScore > 0) {              // the window recorded a transcript of this score: later windows are measured against it
+            if (pruneItem && o.headScore > 0) {              // the window recorded a transcript of this score: later windows are measured against it
                 if (wholeRead) bestSoFar = max(bestSoFar, o.headScore);
                 else if (lane == 0) atomicMax(&B.reads[win.read].pruneBest, o.headScore);
             }
@@ -1165,7 +1185,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
                 z.headScore = 0; z.candOff32 = 0; z.headGlen = 0; z.nCand = 0; z.pad = 0;
                 B.wout[w0 + chunk + lane] = z;
             }
-            nPruned += (u32)__popcll(emptyM);
+            nPruned += (u32)__popcll(emptyM); itemPruned += (u32)__popcll(emptyM);
         }
         }
         if (sweep == 0) {
@@ -1174,6 +1194,7 @@ extern "C" __global__ void __launch_bounds__(256, STITCH_WAVES) k_stitch_win(con
             sweep = 2; nRewalk++;
             continue;
         }
+        if (chimMode && wholeRead && !chimFull && itemPruned && runChim) { chimFull = true; sweep = 2; nRewalk++; continue; }      // (see pruneOn)
         break;
         }
     }
@@ -1258,7 +1279,8 @@ extern "C" __global__ void __launch_bounds__(256) k_stitch_replay(const DevIndex
             ok = replayWindow(P, lane, o, log, wr);
         }
         if (!ok) { if (lane == 0) atomicOr(&B.cursors[CUR_FLAGS], (u32)OVF_HARD); continue; }
-        if (!flushWindow(B, lane, wr, o)) continue;
+        bool headChimUnused = false;
+        if (!flushWindow(B, lane, wr, o, 0u, 0u, headChimUnused)) continue;
         // mm (max over the leaves of this window) and the other fields keep their pass-0 values
         if (lane == 0) B.wout[w] = o;
     }

@@ -89,12 +89,15 @@ def test_chimeric_partner_chosen_on_the_device(tag, tmp_path, built):
     ref = tcp.refstar.align(info["idx"], info["fastq"], os.path.join(d, "ref_"), threads=1, extra=info["extra"])
     lines = lambda p: [l for l in open(p + "Chimeric.out.junction") if not l.startswith("# 2.7.11b")]
     assert len(lines(ref)) >= 400
-    for on in ("1", "0"):
+    for on in ("1", "0", "noprune"):             # noprune: on the device with every window of every read stitched (STARAMD_PRUNE without bit 3)
         new = os.path.join(d, "cli%s_" % on)
+        env = dict(os.environ, STARAMD_CHIM_ON_DEVICE="1" if on == "noprune" else on, STARAMD_VERBOSE="1")
+        if on == "noprune":
+            env["STARAMD_PRUNE"] = "7"
         p = subprocess.run([GPU_CLI, "--runMode", "alignReads", "--genomeDir", info["idx"], "--readFilesIn"] + info["fastq"] + ["--outFileNamePrefix", new, "--runThreadN", "4", "--gpuBatchReads", "700"] + info["extra"],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, STARAMD_CHIM_ON_DEVICE=on, STARAMD_VERBOSE="1"), timeout=600)
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
         assert p.returncode == 0, p.stderr[-1500:]
-        assert ("partner of chimeric detection chosen on the device" in p.stderr) == (on == "1"), p.stderr[-800:]
+        assert ("partner of chimeric detection chosen on the device" in p.stderr) == (on != "0"), p.stderr[-800:]
         assert lines(ref) == lines(new)
         assert tcp.refstar.sam_body_sorted(ref + "Aligned.out.sam") == tcp.refstar.sam_body_sorted(new + "Aligned.out.sam")
         assert open(ref + "SJ.out.tab", "rb").read() == open(new + "SJ.out.tab", "rb").read()

@@ -163,13 +163,15 @@ CHIM_FE = [("pe150_chim", ["--chimSegmentMin", "15", "--chimJunctionOverhangMin"
 
 
 @pytest.mark.parametrize("name,more,n", CHIM_FE)
-@pytest.mark.parametrize("on_device", ["1", "0"])
+@pytest.mark.parametrize("on_device", ["1", "0", "noprune"])
 def test_front_end_chimeric_detection_partner_chosen_on_the_device(name, more, n, on_device, tmp_path, emul_cli):
     """--chimSegmentMin > 0 through the shipped front end on the emulated engine: the partner loop of chimericDetectionOld runs in k_stitch_finish
     (staramd_params::resultSelect 2; STARAMD_CHIM_ON_DEVICE=0: on the host over every transcript of every window, as before) -- Chimeric.out.junction, SAM,
     SJ.out.tab against one reference run"""
     from test_cli_pipeline import run_cli_case
-    run_cli_case(emul_cli, name, more + ["--readMapNumber", str(n)], 25, tmp_path, env=dict(SMALL, STARAMD_CHIM_ON_DEVICE=on_device))
+    # ("noprune": on the device, every window of every read stitched -- STARAMD_PRUNE without bit 3; default: only the reads whose best alignment can be the main segment of a chimera)
+    env = dict(SMALL, STARAMD_CHIM_ON_DEVICE="1", STARAMD_PRUNE="7") if on_device == "noprune" else dict(SMALL, STARAMD_CHIM_ON_DEVICE=on_device)
+    run_cli_case(emul_cli, name, more + ["--readMapNumber", str(n)], 25, tmp_path, env=env)
 
 
 def test_front_end_two_contexts_on_one_device(tmp_path, emul_cli):
