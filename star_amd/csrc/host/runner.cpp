@@ -257,7 +257,7 @@ struct Runner {
                 // write() / pwrite() into ONE file are serialised by the inode lock (tmpfs: 2.9 GB/s from two threads on a box whose tmpfs takes 5.8 / 11.7 / 18.5 GB/s from
                 // 1 / 2 / 4 streams into separate files: the SAM writer at 230 MB per batch was the slowest stage of the pipeline there, 80 ms against 52 ms of kernels).  So the
                 // file is grown to the batch's end and the new part mapped: the threads copy their ranges into the mapping and take their page faults side by side.
-                const uint32_t wantW = getenv("STARAMD_WRITER_THREADS") ? (uint32_t)std::max(1, atoi(getenv("STARAMD_WRITER_THREADS"))) : (uint32_t)std::max(1, std::min(4, P.runThreadN / 4));      // (follows --runThreadN like every helper count)
+                const uint32_t wantW = getenv("STARAMD_WRITER_THREADS") ? (uint32_t)std::max(1, atoi(getenv("STARAMD_WRITER_THREADS"))) : (uint32_t)std::max(1, std::min(8, P.runThreadN / 2));      // (follows --runThreadN like every helper count; 8 of 16: the writer is level with the kernels now, 4 copy threads lost 2 % to 8 on one box -- profiles/r06_e2e_session37_*)
                 const uint64_t total = at[o.used] - samPos;
                 char *map = nullptr; uint64_t mapOff = 0, mapLen = 0;
                 // the blocks are reserved before they are written to (posix_fallocate also sets the new size): a full file system is an error return here, not a SIGBUS in a copy
